@@ -1,0 +1,60 @@
+"""Deterministic tiny models + data used by the golden generator and the parity tests.
+
+TEST INFRASTRUCTURE.  Architectures follow the reference's own test fixtures
+(tests/test_curv_backends_curvlinops.py:23-65: ``Linear(3,20)-Tanh-Linear(20,2)`` on
+``X[10,3]`` and the conv "complex_model" on ``X[10,3,5,5]``, seed 711) plus one ResNet-shaped
+conv stack (3x3 / padding 1 / stride 2 / bias-free conv) that the reference's fixtures lack but
+config c4 needs.  Weights and data are stored inside the golden files, so RNG drift between
+torch versions cannot silently change the fixtures.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+FIXTURES = ("mlp", "conv", "resnetish")
+
+
+def build_model(name: str) -> nn.Module:
+    if name == "mlp":
+        return nn.Sequential(nn.Linear(3, 20), nn.Tanh(), nn.Linear(20, 2))
+    if name == "conv":
+        return nn.Sequential(
+            nn.Conv2d(3, 4, 2, 2), nn.Flatten(), nn.Tanh(), nn.Linear(16, 20), nn.Tanh(), nn.Linear(20, 2)
+        )
+    if name == "resnetish":
+        return nn.Sequential(
+            nn.Conv2d(2, 4, 3, padding=1),
+            nn.ReLU(),
+            nn.Conv2d(4, 4, 3, stride=2, padding=1, bias=False),
+            nn.ReLU(),
+            nn.Flatten(),
+            nn.Linear(36, 3),
+        )
+    raise KeyError(name)
+
+
+def input_shape(name: str):
+    return {"mlp": (3,), "conv": (3, 5, 5), "resnetish": (2, 5, 5)}[name]
+
+
+def n_outputs(name: str) -> int:
+    return 3 if name == "resnetish" else 2
+
+
+def make_fixture(name: str, dtype=torch.float64, batch: int = 10, seed: int = 711):
+    """Fresh model + (X, y_cls, y_reg) from the reference's seed convention."""
+    torch.manual_seed(seed)
+    model = build_model(name).to(dtype)
+    torch.manual_seed(seed)
+    X = torch.randn(batch, *input_shape(name), dtype=dtype)
+    C = n_outputs(name)
+    y_cls = torch.randint(C, (batch,))
+    y_reg = torch.randn(batch, C, dtype=dtype)
+    return model, X, y_cls, y_reg
+
+
+def load_state(model: nn.Module, arrays: dict, prefix: str = "w.") -> nn.Module:
+    sd = {k[len(prefix):]: torch.as_tensor(v) for k, v in arrays.items() if k.startswith(prefix)}
+    model.load_state_dict(sd)
+    return model

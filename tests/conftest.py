@@ -1,0 +1,46 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(autouse=True)
+def _default_dtype():
+    torch.set_default_dtype(torch.float32)
+    yield
+    torch.set_default_dtype(torch.float32)
+
+
+def load_golden(name: str, likelihood: str) -> dict:
+    path = os.path.join(GOLDEN_DIR, f"{name}_{likelihood}.npz")
+    with np.load(path) as z:
+        return {k: z[k] for k in z.files}
+
+
+def golden_kfacs(g: dict, prefix: str, dtype=torch.float64):
+    out = []
+    for i in range(int(g[f"{prefix}.n_blocks"])):
+        out.append([torch.as_tensor(g[f"{prefix}.{i}.{j}"], dtype=dtype) for j in range(int(g[f"{prefix}.{i}.len"]))])
+    return out
+
+
+def golden_model(name: str, g: dict, dtype=torch.float64, device="cpu"):
+    from oracle.fixtures import build_model, load_state
+
+    model = load_state(build_model(name).to(torch.float64), g).to(dtype).to(device)
+    X = torch.as_tensor(g["X"], dtype=dtype, device=device)
+    y = torch.as_tensor(g["y"])
+    y = y.to(device) if not y.is_floating_point() else y.to(dtype).to(device)
+    return model, X, y
