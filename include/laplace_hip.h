@@ -1,0 +1,187 @@
+/*
+ * laplace_hip.h — C ABI of the MI355X (gfx950) curvature kernels behind
+ * `laplace_amd.HipGGN`, the drop-in `laplace.curvature.CurvatureInterface` backend.
+ *
+ * Conventions (all entry points):
+ *   - every tensor is a raw DEVICE pointer to fp32 (labels: int64) + explicit sizes; the caller
+ *     (torch) owns every buffer; kernels never allocate.  Scratch comes from a caller-provided
+ *     workspace sized by the matching lk_*_workspace_bytes().
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued asynchronously on it.  No
+ *     entry point synchronises with the host.
+ *   - return 0 on success, negative LK_E* on error; lk_last_error() returns a thread-local
+ *     message for the last failure on the calling thread.
+ *   - matrices are row-major and dense (leading dimension = number of columns) unless stated.
+ *
+ * Each function cites the reference code (relative to aleximmer/Laplace @ 0.2.3) it replaces.
+ */
+#ifndef LAPLACE_HIP_H
+#define LAPLACE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LK_OK 0
+#define LK_EINVAL (-1)    /* bad argument */
+#define LK_EWORKSPACE (-2) /* workspace too small */
+#define LK_ELAUNCH (-3)    /* HIP launch/runtime failure */
+#define LK_ENOTCONV (-4)   /* eigensolver did not converge (reported through `info`) */
+
+/* flags for the Gram (factor accumulation) family */
+#define LK_GRAM_UPPER_ONLY 1u /* update only the upper block triangle; caller runs lk_symmetrize_f32 later */
+
+int lk_version(void);
+const char* lk_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Likelihood: square root of the softmax-CE Hessian + loss.
+ * Replaces GGNInterface._get_functional_hessian (laplace/curvature/curvature.py:366-373) and the
+ * `factor * lossfunc(f, y)` evaluations (curvature.py:408,417; curvlinops.py:106).
+ *   S[c][n][j] = delta_jc*sqrt(p_nc) - p_nj*sqrt(p_nc)   (column c of a root of diag(p)-pp^T)
+ *   loss_accum[0] += sum_n -log p_n[y_n]                  (skipped when y or loss_accum is NULL)
+ * f: [B][C] logits; S: [C][B][C] (one backward seed per class, `is_grads_batched` layout).
+ * ------------------------------------------------------------------------------------------- */
+int lk_softmax_hess_sqrt_f32(const float* f, const int64_t* y, int64_t B, int64_t C, float* S,
+                             float* loss_accum, void* stream);
+
+/* loss_accum[0] += scale * sum (f - y)^2 over `numel` elements (MSELoss(sum) * factor). */
+int lk_sq_err_sum_f32(const float* f, const float* y, int64_t numel, float scale, float* loss_accum,
+                      void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Gram / factor accumulation:  C += alpha * X^T X   (exact-fp32 MFMA, split-K, deterministic).
+ * Replaces the A^T A / G^T G accumulations inside curvlinops' KFACLinearOperator._compute_kfac
+ * as consumed by CurvlinopsInterface.kron (laplace/curvature/curvlinops.py:55-108), and the
+ * dense einsums of GGNInterface.full / EFInterface.full (curvature.py:406,409,491).
+ *
+ *  _tn  : X is [K][n] row-major with leading dimension ldx      (nn.Linear inputs / output grads)
+ *  _nt  : X is [nb][n][L] row-major; C += alpha * sum_b X_b X_b^T (NCHW conv output grads,
+ *         NCHW inputs of 1x1 stride-1 convs)
+ *  _conv: x is an NHWC activation [B][H][W][Cin]; the Gram matrix of the *unfolded* patch matrix
+ *         (rows = (b,oh,ow), columns = (kh,kw,ci)) is accumulated WITHOUT materialising it.
+ *         Column order of C is (kh,kw,ci) ("native"); lk_permute_sym_f32 converts to the
+ *         reference's F.unfold order (ci,kh,kw).
+ * C is [n][n] (ldc = n).  Workspace: lk_gram_workspace_bytes(n, K_total).
+ * ------------------------------------------------------------------------------------------- */
+size_t lk_gram_workspace_bytes(int64_t n, int64_t K);
+int lk_gram_tn_f32(const float* X, int64_t K, int64_t n, int64_t ldx, float alpha, float* C,
+                   unsigned flags, void* ws, size_t ws_bytes, void* stream);
+int lk_gram_nt_f32(const float* X, int64_t nb, int64_t n, int64_t L, float alpha, float* C,
+                   unsigned flags, void* ws, size_t ws_bytes, void* stream);
+int lk_gram_conv_nhwc_f32(const float* x, int64_t B, int64_t H, int64_t W, int64_t Cin, int kh, int kw,
+                          int sh, int sw, int ph, int pw, int dh, int dw, float alpha, float* C,
+                          unsigned flags, void* ws, size_t ws_bytes, void* stream);
+
+/* dst[b][h][w][c] = src[b][c][h][w]  (NCHW -> NHWC staging for lk_gram_conv_nhwc_f32). */
+int lk_nchw_to_nhwc_f32(const float* src, int64_t B, int64_t C, int64_t HW, float* dst, void* stream);
+
+/* Mirror the upper block triangle written under LK_GRAM_UPPER_ONLY into the lower one. */
+int lk_symmetrize_f32(float* C, int64_t n, void* stream);
+
+/* dst[(ci*KK+d), (cj*KK+e)] (+)= src[(d*Cin+ci), (e*Cin+cj)]  — native (kh,kw,ci) -> unfold (ci,kh,kw)
+ * order.  accumulate != 0 adds into dst. */
+int lk_permute_sym_f32(const float* src, int64_t Cin, int64_t KK, float* dst, int accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Diagonal GGN / EF.  Replaces GGNInterface.diag / EFInterface.diag (curvature.py:413-433,494-505)
+ * for nn.Linear layers:  h_w[o][i] += alpha * sum_n (sum_c g[c][n][o]^2) a[n][i]^2,
+ *                        h_b[o]    += alpha * sum_n  sum_c g[c][n][o]^2          (h_b may be NULL)
+ * a: [B][Di], g: [Cc][B][Do].
+ * ------------------------------------------------------------------------------------------- */
+int lk_diag_ggn_linear_f32(const float* a, const float* g, int64_t B, int64_t Cc, int64_t Di, int64_t Do,
+                           float alpha, float* h_w, float* h_b, void* stream);
+
+/* Per-sample weight Jacobians of one layer written into Js[B][C][P] at column `col0`
+ * (replaces the jacrev materialisation of CurvatureInterface.jacobians, curvature.py:88-129):
+ *   linear: Js[n][c][col0 + o*Di + i] = g[c][n][o] * a[n][i];  bias: Js[n][c][bcol0 + o] = g[c][n][o]
+ *   conv  : Js[n][c][col0 + o*Dk + k] = sum_l g[c][n][o][l] * patches[n][l][k]   (patches NHWC-native
+ *           order is converted to unfold order on the fly) */
+int lk_jac_linear_f32(const float* a, const float* g, int64_t B, int64_t Cc, int64_t Di, int64_t Do,
+                      float* Js, int64_t P, int64_t col0, int64_t bcol0, void* stream);
+int lk_jac_conv_f32(const float* x_nchw, const float* g, int64_t B, int64_t Cc, int64_t Cin, int64_t H, int64_t W,
+                    int64_t Do, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
+                    float* Js, int64_t P, int64_t col0, int64_t bcol0, void* stream);
+
+/* h[p] += alpha * sum_r Js[r][col0 + p]^2 for p < width (rows r = (sample, class)); the conv-layer
+ * diagonal GGN / EF is the squared per-sample weight Jacobian summed over samples. */
+int lk_sq_colsum_f32(const float* Js, int64_t rows, int64_t P, int64_t col0, int64_t width, float alpha,
+                     float* h, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense last-layer GGN.  Replaces last_layer_jacobians + GGNInterface.full for a Linear head
+ * (curvature.py:131-167,375-411) without materialising Js, using J_n = I_C (x) [phi_n, 1]:
+ *   H[(j,a),(k,b)] += alpha * sum_n (delta_jk p_nj - p_nj p_nk) pt_na pt_nb      pt = [phi, 1]
+ *                   = alpha * ( blockdiag_j Gram(sqrt(p_j).Pt) - Gram(Y) ),  Y[n][(j,a)] = p_nj pt_na
+ * phi: [B][D]; probs: [B][C] softmax probabilities (NULL = regression, Lambda = I);
+ * H: [P][P] in the reference's parameter order (weight [C][D] row-major, then bias [C]),
+ * P = C*D (+C if has_bias).
+ * ------------------------------------------------------------------------------------------- */
+size_t lk_ll_ggn_workspace_bytes(int64_t B, int64_t C, int64_t D);
+int lk_ll_ggn_full_f32(const float* phi, const float* probs, int64_t B, int64_t C, int64_t D, int has_bias,
+                       float alpha, float* H, void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Symmetric eigendecomposition (two-sided block-Jacobi, exact-fp32 MFMA tile updates).
+ * Replaces utils.symeig -> torch.linalg.eigh(M, UPLO="U") as used by Kron.decompose
+ * (laplace/utils/utils.py:193-228, laplace/utils/matrix.py:123-150):
+ *   reads the UPPER triangle of A[n][n]; writes ascending eigenvalues w[n] clamped at >= 0 (when
+ *   clamp != 0) and eigenvectors as the COLUMNS of Q[n][n] (row-major), NaNs zeroed.
+ *   info[0] (device int32): 0 = converged, >0 = sweeps ran out with that many unconverged pivots.
+ * A is not modified.  Fully asynchronous on `stream`.
+ * ------------------------------------------------------------------------------------------- */
+size_t lk_syevj_workspace_bytes(int64_t n);
+int lk_syevj_f32(const float* A, int64_t n, float* w, float* Q, int clamp, int max_sweeps, int32_t* info,
+                 void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * KronDecomposed.logdet (laplace/utils/matrix.py:381-404) for one two-factor block, with the
+ * derivatives autograd needs for the marginal-likelihood sweep (baselaplace.py:466-485):
+ *   out[0] += sum_ij log(l1_i l2_j + delta);  d_delta[0] += sum_ij 1/(l1_i l2_j + delta)
+ *   d_l1[i] += sum_j l2_j/(.) ;  d_l2[j] += sum_i l1_i/(.)      (d_* may be NULL)
+ * n2 == 0 means a single-factor block: sum_i log(l1_i + delta).
+ * damping != 0 uses (l1+sqrt(delta)) (x) (l2+sqrt(delta)) (matrix.py:397-399; no derivatives).
+ * delta is read from DEVICE memory (delta[0]).
+ * ------------------------------------------------------------------------------------------- */
+size_t lk_kron_logdet_workspace_bytes(int64_t n1);
+int lk_kron_logdet_f32(const float* l1, int64_t n1, const float* l2, int64_t n2, const float* delta,
+                       int damping, float* out, float* d_l1, float* d_l2, float* d_delta, void* ws,
+                       size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * GLM predictive variances  f_var[n] = J_n Sigma J_n^T  without materialising J (V1-V3).
+ * ------------------------------------------------------------------------------------------- */
+/* Kron posterior, one nn.Linear layer (KronDecomposed.inv_square_form, matrix.py:406-461, called from
+ * KronLaplace.functional_variance, baselaplace.py:1834-1835).  u = g Q1 [Cc][B][Do], v = a Q2 [B][Di]
+ * are the eigenbasis projections (plain GEMMs done by the caller);
+ *   fvar[n][c][k] += sum_o u[c][n][o] u[k][n][o] * ( sum_i v[n][i]^2 / (l1_o l2_i + delta) )
+ *                  + (bias block, if lb != NULL: ub = g Qb, sum_o ub[c][n][o] ub[k][n][o]/(lb_o + delta_b)) */
+int lk_kron_quadform_linear_f32(const float* u, const float* v, const float* l1, const float* l2,
+                                const float* delta, int64_t B, int64_t Cc, int64_t Do, int64_t Di,
+                                const float* ub, const float* lb, const float* delta_b,
+                                float* fvar, void* stream);
+
+/* Diagonal posterior, one nn.Linear layer (DiagLaplace.functional_variance, baselaplace.py:2113-2115):
+ *   fvar[n][c][k] += sum_{o,i} g[c][n][o] g[k][n][o] a[n][i]^2 var_w[o][i] + sum_o g[c][n][o] g[k][n][o] var_b[o] */
+int lk_diag_quadform_linear_f32(const float* a, const float* g, const float* var_w, const float* var_b,
+                                int64_t B, int64_t Cc, int64_t Do, int64_t Di, float* fvar, void* stream);
+
+/* Generic streaming form over a materialised Jacobian (any layer type):
+ *   fvar[n][c][k] = sum_p Js[n][c][p] var[p] Js[n][k][p] */
+int lk_diag_quadform_js_f32(const float* Js, const float* var, int64_t B, int64_t C, int64_t P, float* fvar,
+                            void* stream);
+
+/* Dense last-layer posterior (FullLaplace.functional_variance with J = I (x) [phi,1],
+ * baselaplace.py:1683-1684, lllaplace.py:212-237):
+ *   fvar[n][c][k] = phit_n^T Sigma[(c,:),(k,:)] phit_n,   Sigma: [P][P] in the reference's parameter
+ *   order (weight [C][D] row-major, then bias [C]). */
+size_t lk_dense_quadform_ll_workspace_bytes(int64_t B, int64_t C, int64_t D);
+int lk_dense_quadform_ll_f32(const float* phi, const float* Sigma, int64_t B, int64_t C, int64_t D, int has_bias,
+                             float* fvar, void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LAPLACE_HIP_H */

@@ -1,0 +1,414 @@
+"""ctypes binding of ``csrc/liblaplace_hip.so`` (the C ABI declared in include/laplace_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every hot operation is one of
+our HIP entry points.  There is NO fallback: if the shared library is missing, or a tensor is
+not an fp32 contiguous tensor on a ROCm device, the call raises.
+
+The tensor-level API lives on :class:`HipKernels`; ``get_kernels()`` returns the process-wide
+instance.  Tests that exercise *host logic* on a CPU-only box install a stand-in through
+``set_kernels_for_testing`` (see tests/emulated_kernels.py) — the product never does.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "liblaplace_hip.so")
+
+LK_GRAM_UPPER_ONLY = 1
+
+_c_f32p = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+_f32 = ctypes.c_float
+_sz = ctypes.c_size_t
+_vp = ctypes.c_void_p
+_u32 = ctypes.c_uint
+
+# name -> (restype, argtypes); the single source of truth shared with tests/test_capi_symbols.py
+SIGNATURES = {
+    "lk_version": (_int, []),
+    "lk_last_error": (ctypes.c_char_p, []),
+    "lk_softmax_hess_sqrt_f32": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "lk_sq_err_sum_f32": (_int, [_vp, _vp, _i64, _f32, _vp, _vp]),
+    "lk_gram_workspace_bytes": (_sz, [_i64, _i64]),
+    "lk_gram_tn_f32": (_int, [_vp, _i64, _i64, _i64, _f32, _vp, _u32, _vp, _sz, _vp]),
+    "lk_gram_nt_f32": (_int, [_vp, _i64, _i64, _i64, _f32, _vp, _u32, _vp, _sz, _vp]),
+    "lk_gram_conv_nhwc_f32": (
+        _int,
+        [_vp, _i64, _i64, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _int, _f32, _vp, _u32, _vp, _sz, _vp],
+    ),
+    "lk_nchw_to_nhwc_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
+    "lk_symmetrize_f32": (_int, [_vp, _i64, _vp]),
+    "lk_permute_sym_f32": (_int, [_vp, _i64, _i64, _vp, _int, _vp]),
+    "lk_diag_ggn_linear_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp, _vp, _vp]),
+    "lk_jac_linear_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp]),
+    "lk_jac_conv_f32": (
+        _int,
+        [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _int, _vp, _i64, _i64, _i64, _vp],
+    ),
+    "lk_sq_colsum_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _f32, _vp, _vp]),
+    "lk_ll_ggn_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "lk_ll_ggn_full_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _f32, _vp, _vp, _sz, _vp]),
+    "lk_syevj_workspace_bytes": (_sz, [_i64]),
+    "lk_syevj_f32": (_int, [_vp, _i64, _vp, _vp, _int, _int, _vp, _vp, _sz, _vp]),
+    "lk_kron_logdet_workspace_bytes": (_sz, [_i64]),
+    "lk_kron_logdet_f32": (_int, [_vp, _i64, _vp, _i64, _vp, _int, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "lk_kron_quadform_linear_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "lk_diag_quadform_linear_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "lk_diag_quadform_js_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
+    "lk_dense_quadform_ll_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "lk_dense_quadform_ll_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _vp, _vp, _sz, _vp]),
+}
+
+
+class LaplaceHipError(RuntimeError):
+    pass
+
+
+def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
+    if not os.path.exists(path):
+        raise LaplaceHipError(
+            f"HIP extension not built: {path} is missing. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C laplace_amd/csrc`). There is no CPU fallback."
+        )
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _check(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise LaplaceHipError(f"{name}: expected a tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise LaplaceHipError(f"{name}: tensor is on {t.device}; the HIP backend needs a ROCm device (no CPU path)")
+    if t.dtype != dtype:
+        raise LaplaceHipError(f"{name}: dtype {t.dtype} not supported (need {dtype})")
+    if not t.is_contiguous():
+        raise LaplaceHipError(f"{name}: tensor must be contiguous")
+    return t
+
+
+def _pair(v):
+    return (int(v), int(v)) if isinstance(v, int) else (int(v[0]), int(v[1]))
+
+
+class HipKernels:
+    """Tensor-level wrappers; every method enqueues on torch's current stream and returns at once."""
+
+    name = "hip"
+
+    def __init__(self, lib: Optional[ctypes.CDLL] = None):
+        self.lib = lib if lib is not None else load_library()
+        self._ws: dict = {}
+
+    # ---- plumbing -----------------------------------------------------------------------------
+    def _stream(self, dev) -> ctypes.c_void_p:
+        return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def _workspace(self, nbytes: int, dev) -> torch.Tensor:
+        key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+        buf = self._ws.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=dev)
+            self._ws[key] = buf
+        return buf
+
+    def _rc(self, rc: int, what: str):
+        if rc != 0:
+            msg = self.lib.lk_last_error()
+            raise LaplaceHipError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+    # ---- likelihood ---------------------------------------------------------------------------
+    def softmax_hess_sqrt(self, f, y=None, loss_accum=None):
+        _check(f, "f")
+        B, C = f.shape
+        S = torch.empty(C, B, C, dtype=torch.float32, device=f.device)
+        if y is not None:
+            _check(y, "y", torch.int64)
+        if loss_accum is not None:
+            _check(loss_accum, "loss_accum")
+        self._rc(
+            self.lib.lk_softmax_hess_sqrt_f32(_ptr(f), _ptr(y), B, C, _ptr(S), _ptr(loss_accum), self._stream(f.device)),
+            "lk_softmax_hess_sqrt_f32",
+        )
+        return S
+
+    def sq_err_sum(self, f, y, scale, loss_accum):
+        _check(f, "f"), _check(y, "y"), _check(loss_accum, "loss_accum")
+        if f.shape != y.shape:
+            raise LaplaceHipError(f"sq_err_sum: shape mismatch {tuple(f.shape)} vs {tuple(y.shape)}")
+        self._rc(
+            self.lib.lk_sq_err_sum_f32(_ptr(f), _ptr(y), f.numel(), float(scale), _ptr(loss_accum), self._stream(f.device)),
+            "lk_sq_err_sum_f32",
+        )
+
+    # ---- Gram family --------------------------------------------------------------------------
+    def gram_tn(self, X, alpha, out, upper_only=False):
+        _check(X, "X"), _check(out, "out")
+        K, n = X.shape
+        assert out.shape == (n, n)
+        nb = self.lib.lk_gram_workspace_bytes(n, max(K, 1))
+        ws = self._workspace(nb, X.device)
+        self._rc(
+            self.lib.lk_gram_tn_f32(_ptr(X), K, n, n, float(alpha), _ptr(out), LK_GRAM_UPPER_ONLY if upper_only else 0,
+                                    _ptr(ws), ws.numel(), self._stream(X.device)),
+            "lk_gram_tn_f32",
+        )
+        return out
+
+    def gram_nt(self, X, alpha, out, upper_only=False):
+        _check(X, "X"), _check(out, "out")
+        nbat, n, L = X.shape
+        assert out.shape == (n, n)
+        bk = 64 if n <= 64 else 16  # must mirror lk_gram.hip's chunk size for the virtual K
+        Lp = (L + bk - 1) // bk * bk
+        nb = self.lib.lk_gram_workspace_bytes(n, max(nbat * Lp, 1))
+        ws = self._workspace(nb, X.device)
+        self._rc(
+            self.lib.lk_gram_nt_f32(_ptr(X), nbat, n, L, float(alpha), _ptr(out), LK_GRAM_UPPER_ONLY if upper_only else 0,
+                                    _ptr(ws), ws.numel(), self._stream(X.device)),
+            "lk_gram_nt_f32",
+        )
+        return out
+
+    def nchw_to_nhwc(self, x):
+        _check(x, "x")
+        B, C, H, W = x.shape
+        out = torch.empty(B, H, W, C, dtype=torch.float32, device=x.device)
+        if B:
+            self._rc(self.lib.lk_nchw_to_nhwc_f32(_ptr(x), B, C, H * W, _ptr(out), self._stream(x.device)),
+                     "lk_nchw_to_nhwc_f32")
+        return out
+
+    def gram_conv(self, x, kernel_size, stride, padding, dilation, alpha, out, upper_only=False, native=False):
+        """``out += alpha * unfold(x)^T unfold(x)`` for an NCHW input ``x`` — without materialising unfold.
+
+        ``native=True`` leaves ``out`` in the kernel's (kh, kw, ci) column order (fused accumulation);
+        otherwise the result is delivered in F.unfold's (ci, kh, kw) order.
+        """
+        _check(x, "x"), _check(out, "out")
+        B, Cin, H, W = x.shape
+        kh, kw = _pair(kernel_size)
+        sh, sw = _pair(stride)
+        ph, pw = _pair(padding)
+        dh, dw = _pair(dilation)
+        n = Cin * kh * kw
+        assert out.shape == (n, n)
+        OH = (H + 2 * ph - dh * (kh - 1) - 1) // sh + 1
+        OW = (W + 2 * pw - dw * (kw - 1) - 1) // sw + 1
+        xh = self.nchw_to_nhwc(x)
+        direct = native or kh * kw == 1
+        tgt = out if direct else torch.zeros(n, n, dtype=torch.float32, device=x.device)
+        nb = self.lib.lk_gram_workspace_bytes(n, max(B * OH * OW, 1))
+        ws = self._workspace(nb, x.device)
+        self._rc(
+            self.lib.lk_gram_conv_nhwc_f32(_ptr(xh), B, H, W, Cin, kh, kw, sh, sw, ph, pw, dh, dw, float(alpha), _ptr(tgt),
+                                           LK_GRAM_UPPER_ONLY if upper_only else 0, _ptr(ws), ws.numel(),
+                                           self._stream(x.device)),
+            "lk_gram_conv_nhwc_f32",
+        )
+        if not direct:
+            self._rc(self.lib.lk_permute_sym_f32(_ptr(tgt), Cin, kh * kw, _ptr(out), 1, self._stream(x.device)),
+                     "lk_permute_sym_f32")
+        return out
+
+    def permute_native_to_unfold(self, src, Cin, KK, dst, accumulate=False):
+        _check(src, "src"), _check(dst, "dst")
+        self._rc(self.lib.lk_permute_sym_f32(_ptr(src), Cin, KK, _ptr(dst), 1 if accumulate else 0, self._stream(src.device)),
+                 "lk_permute_sym_f32")
+        return dst
+
+    def symmetrize(self, C):
+        _check(C, "C")
+        self._rc(self.lib.lk_symmetrize_f32(_ptr(C), C.shape[0], self._stream(C.device)), "lk_symmetrize_f32")
+        return C
+
+    # ---- diag / Jacobians ---------------------------------------------------------------------
+    def diag_ggn_linear(self, a, g, alpha, h_w, h_b=None):
+        _check(a, "a"), _check(g, "g"), _check(h_w, "h_w")
+        Cc, B, Do = g.shape
+        Di = a.shape[1]
+        assert a.shape[0] == B and h_w.numel() == Do * Di
+        if h_b is not None:
+            _check(h_b, "h_b")
+        self._rc(
+            self.lib.lk_diag_ggn_linear_f32(_ptr(a), _ptr(g), B, Cc, Di, Do, float(alpha), _ptr(h_w), _ptr(h_b),
+                                            self._stream(a.device)),
+            "lk_diag_ggn_linear_f32",
+        )
+
+    def jac_linear(self, a, g, Js, col0, bcol0=-1):
+        _check(a, "a"), _check(g, "g"), _check(Js, "Js")
+        Cc, B, Do = g.shape
+        Di = a.shape[1]
+        P = Js.shape[-1]
+        self._rc(
+            self.lib.lk_jac_linear_f32(_ptr(a), _ptr(g), B, Cc, Di, Do, _ptr(Js), P, int(col0), int(bcol0),
+                                       self._stream(a.device)),
+            "lk_jac_linear_f32",
+        )
+
+    def jac_conv(self, x, g, kernel_size, stride, padding, dilation, Js, col0, bcol0=-1):
+        _check(x, "x"), _check(g, "g"), _check(Js, "Js")
+        B, Cin, H, W = x.shape
+        Cc, _, Do = g.shape[:3]
+        kh, kw = _pair(kernel_size)
+        sh, sw = _pair(stride)
+        ph, pw = _pair(padding)
+        dh, dw = _pair(dilation)
+        P = Js.shape[-1]
+        self._rc(
+            self.lib.lk_jac_conv_f32(_ptr(x), _ptr(g), B, Cc, Cin, H, W, Do, kh, kw, sh, sw, ph, pw, dh, dw, _ptr(Js), P,
+                                     int(col0), int(bcol0), self._stream(x.device)),
+            "lk_jac_conv_f32",
+        )
+
+    def sq_colsum(self, Js, col0, width, alpha, h):
+        _check(Js, "Js"), _check(h, "h")
+        P = Js.shape[-1]
+        rows = Js.numel() // P
+        self._rc(self.lib.lk_sq_colsum_f32(_ptr(Js), rows, P, int(col0), int(width), float(alpha), _ptr(h),
+                                           self._stream(Js.device)), "lk_sq_colsum_f32")
+
+    # ---- dense last-layer GGN -----------------------------------------------------------------
+    def ll_ggn_full(self, phi, probs, has_bias, alpha, H):
+        _check(phi, "phi"), _check(H, "H")
+        B, D = phi.shape
+        if probs is not None:
+            _check(probs, "probs")
+            C = probs.shape[1]
+        else:
+            C = (H.shape[0]) // (D + (1 if has_bias else 0))
+        nb = self.lib.lk_ll_ggn_workspace_bytes(B, C, D)
+        ws = self._workspace(nb, phi.device)
+        self._rc(
+            self.lib.lk_ll_ggn_full_f32(_ptr(phi), _ptr(probs), B, C, D, 1 if has_bias else 0, float(alpha), _ptr(H),
+                                        _ptr(ws), ws.numel(), self._stream(phi.device)),
+            "lk_ll_ggn_full_f32",
+        )
+        return H
+
+    # ---- eigensolver --------------------------------------------------------------------------
+    def syevj(self, A, clamp=True, max_sweeps=0):
+        _check(A, "A")
+        n = A.shape[0]
+        assert A.shape == (n, n)
+        w = torch.empty(n, dtype=torch.float32, device=A.device)
+        Q = torch.empty(n, n, dtype=torch.float32, device=A.device)
+        info = torch.zeros(1, dtype=torch.int32, device=A.device)
+        nb = self.lib.lk_syevj_workspace_bytes(n)
+        # the solve is long-running and asynchronous: give it a private workspace
+        ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=A.device)
+        self._rc(
+            self.lib.lk_syevj_f32(_ptr(A), n, _ptr(w), _ptr(Q), 1 if clamp else 0, int(max_sweeps), _ptr(info), _ptr(ws),
+                                  ws.numel(), self._stream(A.device)),
+            "lk_syevj_f32",
+        )
+        ws.record_stream(torch.cuda.current_stream(A.device))
+        return w, Q, info
+
+    # ---- logdet -------------------------------------------------------------------------------
+    def kron_logdet(self, l1, l2, delta, damping=False, want_grads=False):
+        """Returns (value[1], d_l1, d_l2, d_delta[1]); derivative tensors are None unless requested."""
+        _check(l1, "l1"), _check(delta, "delta")
+        n1 = l1.numel()
+        n2 = 0 if l2 is None else l2.numel()
+        if l2 is not None:
+            _check(l2, "l2")
+        dev = l1.device
+        out = torch.zeros(1, dtype=torch.float32, device=dev)
+        d1 = d2 = dd = None
+        if want_grads:
+            d1 = torch.zeros(n1, dtype=torch.float32, device=dev)
+            d2 = torch.zeros(n2, dtype=torch.float32, device=dev) if n2 else None
+            dd = torch.zeros(1, dtype=torch.float32, device=dev)
+        nb = self.lib.lk_kron_logdet_workspace_bytes(n1)
+        ws = self._workspace(nb, dev)
+        self._rc(
+            self.lib.lk_kron_logdet_f32(_ptr(l1), n1, _ptr(l2), n2, _ptr(delta), 1 if damping else 0, _ptr(out), _ptr(d1),
+                                        _ptr(d2), _ptr(dd), _ptr(ws), ws.numel(), self._stream(dev)),
+            "lk_kron_logdet_f32",
+        )
+        return out, d1, d2, dd
+
+    # ---- predictive ---------------------------------------------------------------------------
+    def kron_quadform_linear(self, u, v, l1, l2, delta, fvar, ub=None, lb=None, delta_b=None):
+        for t, nm in ((u, "u"), (v, "v"), (l1, "l1"), (l2, "l2"), (delta, "delta"), (fvar, "fvar")):
+            _check(t, nm)
+        Cc, B, Do = u.shape
+        Di = v.shape[1]
+        if ub is not None:
+            _check(ub, "ub"), _check(lb, "lb"), _check(delta_b, "delta_b")
+        self._rc(
+            self.lib.lk_kron_quadform_linear_f32(_ptr(u), _ptr(v), _ptr(l1), _ptr(l2), _ptr(delta), B, Cc, Do, Di, _ptr(ub),
+                                                 _ptr(lb), _ptr(delta_b), _ptr(fvar), self._stream(u.device)),
+            "lk_kron_quadform_linear_f32",
+        )
+        return fvar
+
+    def diag_quadform_linear(self, a, g, var_w, var_b, fvar):
+        for t, nm in ((a, "a"), (g, "g"), (var_w, "var_w"), (fvar, "fvar")):
+            _check(t, nm)
+        Cc, B, Do = g.shape
+        Di = a.shape[1]
+        if var_b is not None:
+            _check(var_b, "var_b")
+        self._rc(
+            self.lib.lk_diag_quadform_linear_f32(_ptr(a), _ptr(g), _ptr(var_w), _ptr(var_b), B, Cc, Do, Di, _ptr(fvar),
+                                                 self._stream(a.device)),
+            "lk_diag_quadform_linear_f32",
+        )
+        return fvar
+
+    def diag_quadform_js(self, Js, var):
+        _check(Js, "Js"), _check(var, "var")
+        B, C, P = Js.shape
+        fvar = torch.empty(B, C, C, dtype=torch.float32, device=Js.device)
+        self._rc(self.lib.lk_diag_quadform_js_f32(_ptr(Js), _ptr(var), B, C, P, _ptr(fvar), self._stream(Js.device)),
+                 "lk_diag_quadform_js_f32")
+        return fvar
+
+    def dense_quadform_ll(self, phi, Sigma, C, has_bias):
+        _check(phi, "phi"), _check(Sigma, "Sigma")
+        B, D = phi.shape
+        fvar = torch.empty(B, C, C, dtype=torch.float32, device=phi.device)
+        nb = self.lib.lk_dense_quadform_ll_workspace_bytes(B, C, D)
+        ws = self._workspace(nb, phi.device)
+        self._rc(
+            self.lib.lk_dense_quadform_ll_f32(_ptr(phi), _ptr(Sigma), B, C, D, 1 if has_bias else 0, _ptr(fvar), _ptr(ws),
+                                              ws.numel(), self._stream(phi.device)),
+            "lk_dense_quadform_ll_f32",
+        )
+        return fvar
+
+
+_KERNELS = None
+
+
+def get_kernels():
+    """The process-wide kernel provider (loads the HIP library on first use; raises if absent)."""
+    global _KERNELS
+    if _KERNELS is None:
+        _KERNELS = HipKernels()
+    return _KERNELS
+
+
+def set_kernels_for_testing(impl):
+    """Install a stand-in provider (CPU emulation of the kernels, used only by the `not gpu` tests
+    of the host logic).  Returns the previous provider."""
+    global _KERNELS
+    prev = _KERNELS
+    _KERNELS = impl
+    return prev

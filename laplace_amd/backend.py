@@ -1,0 +1,359 @@
+"""``HipGGN`` / ``HipEF`` — the MI355X-native curvature backend (drop-in ``CurvatureInterface``).
+
+Usage with the unmodified reference::
+
+    from laplace import Laplace
+    from laplace_amd import HipGGN
+    la = Laplace(model, "classification", "all", "kron", backend=HipGGN)
+    la.fit(train_loader)
+
+Boundary (laplace/baselaplace.py:179-194): the class is instantiated lazily as
+``cls(model, likelihood, dict_key_x=..., dict_key_y=..., **backend_kwargs)``; Laplace then calls
+``kron(X, y, N=N, **kw)`` (:1770), ``diag`` (:2069), ``full`` (:1623), ``jacobians`` (:1327) and
+``last_layer_jacobians`` (laplace/lllaplace.py:219-231).  Class names deliberately avoid the
+substrings ``backpack`` / ``asdl`` / ``asdfghjkl`` that baselaplace.py:142-149,943-952,1313-1325
+sniff for.
+
+What runs where: model forward + ONE batched reverse pass = stock PyTorch-ROCm
+(:mod:`laplace_amd.capture`); everything named in BASELINE.json's north_star — likelihood
+Hessian root + loss, A/G factor accumulation, diagonal / dense GGN, per-sample Jacobian
+assembly — is a HIP entry point of ``include/laplace_hip.h`` (through :mod:`laplace_amd._lib`).
+Only fp32 models on a ROCm device are accepted; there is no CPU path.
+"""
+from __future__ import annotations
+
+import math
+from collections.abc import MutableMapping
+
+import torch
+from torch import nn
+
+from laplace_amd._lib import get_kernels
+from laplace_amd.capture import Tape
+from laplace_amd.kron import HipKron
+from laplace_amd.refapi import EFInterface, GGNInterface
+
+
+class _HipCurvatureMixin:
+    """Shared machinery of :class:`HipGGN` and :class:`HipEF`."""
+
+    # ---- forward / taps -------------------------------------------------------------------------
+    def _tape(self) -> Tape:
+        tape = getattr(self, "_tape_cache", None)
+        if tape is None or tape.model is not self._model or tape.n_params != sum(p.numel() for p in self.params):
+            tape = Tape(self._model, self.params)
+            self._tape_cache = tape
+        return tape
+
+    def _check_dtype(self, f: torch.Tensor):
+        if f.dtype != torch.float32:
+            raise TypeError(f"HIP curvature backend computes in float32; model output is {f.dtype}")
+
+    def _forward(self, x):
+        """Returns (f [B,C] detached, tape, grad_fn) where grad_fn(seeds[S,B,C]) -> per-tap [S,B,...]."""
+        tape = self._tape()
+        if self.last_layer:
+            # f = last_layer(phi): the gradient w.r.t. the head's output IS the seed -> no reverse pass
+            with torch.no_grad():
+                f, phi = self.model.forward_with_features(x)
+            if len(tape.taps) != 1 or tape.taps[0].kind != "linear":
+                raise NotImplementedError("last-layer mode needs an nn.Linear head")
+            tape.taps[0].a = phi.detach()
+            self._check_dtype(f)
+            B = phi.shape[0]
+            f = f.detach().reshape(B, -1).contiguous()
+            return f, tape, lambda seeds: [seeds.contiguous()]
+        f = tape.forward(x)
+        self._check_dtype(f)
+        if f.ndim == 1:
+            f = f.unsqueeze(-1)
+        if f.ndim != 2:
+            raise NotImplementedError(f"model output must be [batch, outputs]; got {tuple(f.shape)}")
+        return f.detach().contiguous(), tape, lambda seeds, f_graph=f: tape.output_grads(f_graph, seeds)
+
+    # ---- seeds ----------------------------------------------------------------------------------
+    def _ggn_seeds(self, f, y, loss):
+        """Columns of a root of the loss Hessian w.r.t. f, laid out ``[C, B, C]``; accumulates
+        ``factor * loss`` into ``loss``.  Returns (seeds, hessian_scale)."""
+        K = get_kernels()
+        B, C = f.shape
+        if self.likelihood == "regression":
+            if y is not None:
+                K.sq_err_sum(f, y.reshape(B, C).to(torch.float32).contiguous(), self.factor, loss)
+            eye = torch.eye(C, dtype=f.dtype, device=f.device)
+            return eye[:, None, :].expand(C, B, C).contiguous(), 2.0  # d2/df2 MSELoss(sum) = 2 I
+        yy = None if y is None else y.reshape(B).to(torch.int64).contiguous()
+        return K.softmax_hess_sqrt(f, yy, loss if y is not None else None), 1.0
+
+    def _ef_seed(self, f, y, loss):
+        """Gradient of the (unscaled, summed) torch loss w.r.t. f, ``[1, B, C]``; accumulates
+        ``factor * loss``."""
+        K = get_kernels()
+        B, C = f.shape
+        if self.likelihood == "regression":
+            yy = y.reshape(B, C).to(torch.float32).contiguous()
+            K.sq_err_sum(f, yy, self.factor, loss)
+            return (2.0 * (f - yy)).unsqueeze(0).contiguous()
+        yy = y.reshape(B).to(torch.int64).contiguous()
+        K.softmax_hess_sqrt(f, yy, loss)  # loss only; the root itself is not needed for the EF
+        p = torch.softmax(f, dim=-1)
+        p[torch.arange(B, device=f.device), yy] -= 1.0
+        return p.unsqueeze(0).contiguous()
+
+    # ---- per-layer building blocks ----------------------------------------------------------------
+    @staticmethod
+    def _positions(tap, a) -> int:
+        if tap.kind == "conv2d":
+            m = tap.module
+            H, W = a.shape[-2:]
+            oh = (H + 2 * m.padding[0] - m.dilation[0] * (m.kernel_size[0] - 1) - 1) // m.stride[0] + 1
+            ow = (W + 2 * m.padding[1] - m.dilation[1] * (m.kernel_size[1] - 1) - 1) // m.stride[1] + 1
+            return oh * ow
+        return int(a[0].numel() // a.shape[-1])
+
+    def _layer_factors(self, tap, g, N, alpha_g, alpha_a_scale, kfac_approx):
+        """(G, A) of one module; ``g`` is ``[S, B, ...]``."""
+        K = get_kernels()
+        a = tap.a.to(torch.float32)
+        m = tap.module
+        dev = a.device
+        L = self._positions(tap, a)
+        S, B = g.shape[0], g.shape[1]
+        if tap.kind == "linear":
+            Di, Do = m.in_features, m.out_features
+            A = torch.zeros(Di, Di, dtype=torch.float32, device=dev)
+            G = torch.zeros(Do, Do, dtype=torch.float32, device=dev)
+            if kfac_approx == "expand" or L == 1:
+                K.gram_tn(a.reshape(-1, Di).contiguous(), alpha_a_scale / (N * L), A)
+                K.gram_tn(g.reshape(-1, Do).contiguous(), alpha_g, G)
+            else:  # 'reduce': average inputs / sum gradients over the weight-sharing positions
+                K.gram_tn(a.reshape(B, L, Di).mean(1).contiguous(), alpha_a_scale / N, A)
+                K.gram_tn(g.reshape(S, B, L, Do).sum(2).reshape(S * B, Do).contiguous(), alpha_g, G)
+            return G, A
+        Do = m.out_channels
+        Dk = m.in_channels * m.kernel_size[0] * m.kernel_size[1]
+        A = torch.zeros(Dk, Dk, dtype=torch.float32, device=dev)
+        G = torch.zeros(Do, Do, dtype=torch.float32, device=dev)
+        if kfac_approx == "expand":
+            K.gram_conv(a.contiguous(), m.kernel_size, m.stride, m.padding, m.dilation, alpha_a_scale / (N * L), A)
+            K.gram_nt(g.reshape(S * B, Do, L).contiguous(), alpha_g, G)
+        else:
+            cols = torch.nn.functional.unfold(a, m.kernel_size, dilation=m.dilation, padding=m.padding, stride=m.stride)
+            K.gram_tn(cols.mean(2).contiguous(), alpha_a_scale / N, A)
+            K.gram_tn(g.reshape(S * B, Do, L).sum(2).contiguous(), alpha_g, G)
+        return G, A
+
+    def _layer_jacobian(self, tap, g, Js):
+        """Writes this module's columns of ``Js[B, S, P]``; ``g`` is ``[S, B, ...]``."""
+        K = get_kernels()
+        a = tap.a.to(torch.float32)
+        m = tap.module
+        if tap.kind == "linear":
+            if a.ndim != 2:
+                raise NotImplementedError(f"{tap.name}: per-sample Jacobians of a Linear with weight sharing")
+            K.jac_linear(a.contiguous(), g.contiguous(), Js, tap.w_off, tap.b_off)
+        else:
+            K.jac_conv(a.contiguous(), g.contiguous(), m.kernel_size, m.stride, m.padding, m.dilation, Js,
+                       tap.w_off, tap.b_off)
+
+    def _rows(self, x, seeds_fn):
+        """``Z[B, S, P]`` = seed-contracted per-sample Jacobians (all tracked params must be covered)."""
+        f, tape, grad_fn = self._forward(x)
+        if tape.uncovered:
+            raise NotImplementedError("parameters outside nn.Linear / nn.Conv2d are not covered by the HIP kernels")
+        seeds = seeds_fn(f)
+        grads = grad_fn(seeds)
+        B, S = f.shape[0], seeds.shape[0]
+        Z = torch.zeros(B, S, tape.n_params, dtype=torch.float32, device=f.device)
+        for tap, g in zip(tape.taps, grads):
+            self._layer_jacobian(tap, g, Z)
+        tape.release()
+        return Z, f
+
+    def _supported(self) -> bool:
+        return not self._tape().uncovered
+
+    # ---- shared implementations ------------------------------------------------------------------
+    def _kron_impl(self, x, y, N, seeds_fn, hess_scale_fn, kfac_approx):
+        if kfac_approx not in ("expand", "reduce"):
+            raise ValueError(f"kfac_approx must be 'expand' or 'reduce', got {kfac_approx!r}")
+        f, tape, grad_fn = self._forward(x)
+        if tape.uncovered:
+            raise NotImplementedError(
+                "KFAC supports nn.Linear / nn.Conv2d parameters only (as the reference, docs/index.md:364-366); "
+                "freeze the others (requires_grad=False)"
+            )
+        loss = torch.zeros(1, dtype=torch.float32, device=f.device)
+        seeds, hs = seeds_fn(f, y, loss)
+        grads = grad_fn(seeds)
+        fac = float(self.factor)
+        rt = math.sqrt(fac)
+        kfacs = []
+        for tap, g in zip(tape.taps, grads):
+            G, A = self._layer_factors(tap, g, N, rt * hs, rt, kfac_approx)
+            if G.numel() == 1 and A.numel() == 1 and not tap.has_bias:
+                kfacs.append([G * A])  # curvlinops.py:68-71 collapses 1x1 (x) 1x1
+            else:
+                kfacs.append([G, A])
+            if tap.has_bias:
+                kfacs.append([G * rt])  # block scaled by `factor`, i.e. sqrt(factor) more than G
+        tape.release()
+        return loss[0], HipKron(kfacs)
+
+    def _diag_impl(self, x, y, seeds_fn, alpha):
+        K = get_kernels()
+        f, tape, grad_fn = self._forward(x)
+        if tape.uncovered:
+            return None
+        loss = torch.zeros(1, dtype=torch.float32, device=f.device)
+        seeds, _ = seeds_fn(f, y, loss)
+        grads = grad_fn(seeds)
+        h = torch.zeros(tape.n_params, dtype=torch.float32, device=f.device)
+        B, S = f.shape[0], seeds.shape[0]
+        for tap, g in zip(tape.taps, grads):
+            a = tap.a.to(torch.float32)
+            m = tap.module
+            if tap.kind == "linear" and a.ndim == 2:
+                n_w = m.out_features * m.in_features
+                K.diag_ggn_linear(a.contiguous(), g.contiguous(), alpha, h[tap.w_off:tap.w_off + n_w],
+                                  h[tap.b_off:tap.b_off + m.out_features] if tap.has_bias else None)
+            elif tap.kind == "linear":
+                raise NotImplementedError(f"{tap.name}: diagonal GGN of a Linear with weight-sharing dims")
+            else:
+                # exact conv diagonal = squared per-sample weight Jacobian, summed over (sample, seed)
+                width = m.weight.numel()
+                Jl = torch.zeros(B, S, width + (m.out_channels if tap.has_bias else 0), dtype=torch.float32, device=f.device)
+                K.jac_conv(a.contiguous(), g.contiguous(), m.kernel_size, m.stride, m.padding, m.dilation, Jl, 0,
+                           width if tap.has_bias else -1)
+                K.sq_colsum(Jl, 0, width, alpha, h[tap.w_off:tap.w_off + width])
+                if tap.has_bias:
+                    K.sq_colsum(Jl, width, m.out_channels, alpha, h[tap.b_off:tap.b_off + m.out_channels])
+        tape.release()
+        if self.subnetwork_indices is not None:
+            h = h[self.subnetwork_indices]
+        return loss[0], h
+
+    def _full_from_rows(self, Z, alpha):
+        K = get_kernels()
+        Z2 = Z.reshape(-1, Z.shape[-1])
+        if self.subnetwork_indices is not None:
+            Z2 = Z2[:, self.subnetwork_indices]
+        Z2 = Z2.contiguous()
+        H = torch.zeros(Z2.shape[1], Z2.shape[1], dtype=torch.float32, device=Z.device)
+        return K.gram_tn(Z2, alpha, H)
+
+
+class HipGGN(_HipCurvatureMixin, GGNInterface):
+    """Generalised Gauss-Newton on HIP (exact GGN; ``stochastic=True`` is not implemented)."""
+
+    def __init__(self, model, likelihood, last_layer=False, subnetwork_indices=None,
+                 dict_key_x="input_ids", dict_key_y="labels", stochastic=False, num_samples=1):
+        if stochastic:
+            raise NotImplementedError("HipGGN implements the exact GGN; the MC Fisher is not available yet")
+        super().__init__(model, likelihood, last_layer, subnetwork_indices, dict_key_x, dict_key_y,
+                         stochastic=False, num_samples=num_samples)
+
+    # KFAC — replaces CurvlinopsInterface.kron (laplace/curvature/curvlinops.py:77-108)
+    def kron(self, x, y, N, **kwargs):
+        kfac_approx = kwargs.get("kfac_approx", "expand")
+        return self._kron_impl(x, y, N, self._ggn_seeds, None, kfac_approx)
+
+    # diag GGN — replaces GGNInterface.diag (laplace/curvature/curvature.py:413-433)
+    def diag(self, x, y, **kwargs):
+        out = self._diag_impl(x, y, self._ggn_seeds, 1.0)
+        if out is None:  # layers without a kernel: the reference's generic path on our Jacobians
+            return super().diag(x, y, **kwargs)
+        return out
+
+    # dense GGN — replaces GGNInterface.full (laplace/curvature/curvature.py:375-411)
+    def full(self, x, y, **kwargs):
+        K = get_kernels()
+        if self.last_layer and self.subnetwork_indices is None:
+            f, tape, _ = self._forward(x)
+            phi = tape.taps[0].a.to(torch.float32).contiguous()
+            B, C = f.shape
+            has_bias = tape.taps[0].has_bias
+            loss = torch.zeros(1, dtype=torch.float32, device=f.device)
+            if self.likelihood == "regression":
+                K.sq_err_sum(f, y.reshape(B, C).to(torch.float32).contiguous(), self.factor, loss)
+                probs = None
+            else:
+                K.softmax_hess_sqrt(f, y.reshape(B).to(torch.int64).contiguous(), loss)
+                probs = torch.softmax(f, dim=-1).contiguous()
+            P = tape.n_params
+            H = torch.zeros(P, P, dtype=torch.float32, device=f.device)
+            K.ll_ggn_full(phi, probs, has_bias, 1.0, H)
+            tape.release()
+            return loss[0], H
+        if not self._supported():
+            return super().full(x, y, **kwargs)
+        loss = None
+
+        def seeds_fn(f):
+            nonlocal loss
+            loss = torch.zeros(1, dtype=torch.float32, device=f.device)
+            return self._ggn_seeds(f, y, loss)[0]
+
+        Z, _ = self._rows(x, seeds_fn)
+        return loss[0], self._full_from_rows(Z, 1.0)
+
+    # per-sample output Jacobians — replaces CurvatureInterface.jacobians (curvature.py:88-129)
+    def jacobians(self, x, enable_backprop: bool = False):
+        if enable_backprop or self.last_layer or not self._supported():
+            return super().jacobians(x, enable_backprop)
+
+        def seeds_fn(f):
+            B, C = f.shape
+            eye = torch.eye(C, dtype=f.dtype, device=f.device)
+            return eye[:, None, :].expand(C, B, C).contiguous()
+
+        Js, f = self._rows(x, seeds_fn)
+        if self.subnetwork_indices is not None:
+            Js = Js[:, :, self.subnetwork_indices]
+        return Js, f
+
+
+class HipEF(_HipCurvatureMixin, EFInterface):
+    """Empirical Fisher on HIP — replaces EFInterface (laplace/curvature/curvature.py:436-505) and
+    CurvlinopsEF's KFAC (curvlinops.py:167-176, FisherType.EMPIRICAL)."""
+
+    def _ef_seeds(self, f, y, loss):
+        return self._ef_seed(f, y, loss), 1.0
+
+    def kron(self, x, y, N, **kwargs):
+        return self._kron_impl(x, y, N, self._ef_seeds, None, kwargs.get("kfac_approx", "expand"))
+
+    def diag(self, x, y, **kwargs):
+        out = self._diag_impl(x, y, self._ef_seeds, float(self.factor))
+        if out is None:
+            return super().diag(x, y, **kwargs)
+        return out
+
+    def full(self, x, y, **kwargs):
+        if not self._supported() or self.last_layer:
+            return super().full(x, y, **kwargs)
+        loss = None
+
+        def seeds_fn(f):
+            nonlocal loss
+            loss = torch.zeros(1, dtype=torch.float32, device=f.device)
+            return self._ef_seed(f, y, loss)
+
+        Z, _ = self._rows(x, seeds_fn)
+        return loss[0], self._full_from_rows(Z, float(self.factor))
+
+    def gradients(self, x, y):
+        if not self._supported() or self.last_layer or isinstance(x, MutableMapping):
+            return super().gradients(x, y)
+        loss = None
+
+        def seeds_fn(f):
+            nonlocal loss
+            loss = torch.zeros(1, dtype=torch.float32, device=f.device)
+            return self._ef_seed(f, y, loss)
+
+        Z, _ = self._rows(x, seeds_fn)
+        Gs = Z[:, 0, :]
+        if self.subnetwork_indices is not None:
+            Gs = Gs[:, self.subnetwork_indices]
+        return Gs, loss[0] / float(self.factor)

@@ -1,0 +1,112 @@
+"""Extraction of per-layer inputs ``a`` and output gradients ``g`` from stock autograd.
+
+Host-side plumbing around the model (the model forward/backward stays PyTorch-ROCm): one forward
+with hooks on the supported modules, then ONE batched reverse pass (``is_grads_batched``) that
+delivers, for every seed (a column of the likelihood-Hessian root), the gradient w.r.t. every
+tapped module's *output* — no weight gradients are ever formed.  This replaces the C separate
+backward passes + second loss forward the reference's default backend performs
+(laplace/curvature/curvlinops.py:87-106) and the ``jacrev`` materialisation of
+laplace/curvature/curvature.py:88-129.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Sequence
+
+import torch
+from torch import nn
+
+SUPPORTED = (nn.Linear, nn.Conv2d)
+
+
+@dataclass
+class Tap:
+    name: str
+    module: nn.Module
+    kind: str  # 'linear' | 'conv2d'
+    w_off: int  # column offset of the weight in the flattened parameter vector
+    b_off: int  # column offset of the bias, -1 if the module has no (tracked) bias
+    a: torch.Tensor | None = None  # module input (detached)
+    out: torch.Tensor | None = None  # module output (in the autograd graph)
+
+    @property
+    def has_bias(self) -> bool:
+        return self.b_off >= 0
+
+
+def _conv_checks(m: nn.Conv2d, name: str):
+    if m.groups != 1:
+        raise NotImplementedError(f"{name}: grouped convolutions are not supported by the KFAC path")
+    if isinstance(m.padding, str):
+        raise NotImplementedError(f"{name}: string padding ('{m.padding}') not supported")
+    if m.padding_mode != "zeros":
+        raise NotImplementedError(f"{name}: padding_mode={m.padding_mode!r} not supported")
+
+
+class Tape:
+    """Finds the supported modules whose weight is Laplace-tracked (``named_modules`` order, as
+    laplace/curvature/curvlinops.py:55-75) and records their inputs/outputs during a forward."""
+
+    def __init__(self, model: nn.Module, params: Sequence[nn.Parameter]):
+        self.model = model
+        offsets, off = {}, 0
+        for p in params:
+            offsets[id(p)] = off
+            off += p.numel()
+        self.n_params = off
+        self.taps: list[Tap] = []
+        covered = set()
+        for name, mod in model.named_modules():
+            if not isinstance(mod, SUPPORTED) or id(mod.weight) not in offsets:
+                continue
+            if isinstance(mod, nn.Conv2d):
+                _conv_checks(mod, name)
+            b_off = -1
+            if mod.bias is not None and id(mod.bias) in offsets:
+                b_off = offsets[id(mod.bias)]
+                covered.add(id(mod.bias))
+            covered.add(id(mod.weight))
+            self.taps.append(Tap(name, mod, "linear" if isinstance(mod, nn.Linear) else "conv2d",
+                                 offsets[id(mod.weight)], b_off))
+        # tracked parameters that no supported module owns (norm layers, embeddings, lone biases ...)
+        self.uncovered = [p for p in params if id(p) not in covered]
+
+    def forward(self, x):
+        """Run ``model(x)`` with hooks; returns ``f`` (attached to the graph)."""
+        handles, seen = [], set()
+        for tap in self.taps:
+            def hook(m, inp, out, tap=tap):
+                if id(m) in seen:
+                    raise NotImplementedError(f"{tap.name}: module is applied more than once per forward")
+                seen.add(id(m))
+                tap.a = inp[0].detach()
+                tap.out = out
+            handles.append(tap.module.register_forward_hook(hook))
+        try:
+            with torch.enable_grad():
+                f = self.model(x)
+        finally:
+            for h in handles:
+                h.remove()
+        for tap in self.taps:
+            if tap.out is None:
+                raise RuntimeError(f"{tap.name}: module did not run in the forward pass")
+        return f
+
+    def output_grads(self, f: torch.Tensor, seeds: torch.Tensor) -> list[torch.Tensor]:
+        """``seeds[s]`` is a cotangent of ``f``; returns per tap ``[S, *out.shape]`` gradients."""
+        outs = [t.out for t in self.taps]
+        if seeds.shape[0] == 1:
+            return [g.unsqueeze(0).contiguous() for g in torch.autograd.grad(f, outs, grad_outputs=seeds[0])]
+        try:
+            grads = torch.autograd.grad(f, outs, grad_outputs=seeds, is_grads_batched=True, retain_graph=True)
+            return [g.contiguous() for g in grads]
+        except RuntimeError:
+            # an op without a batching rule: fall back to one reverse pass per seed
+            per_seed = [torch.autograd.grad(f, outs, grad_outputs=s, retain_graph=True) for s in seeds]
+            return [torch.stack([ps[i] for ps in per_seed]).contiguous() for i in range(len(outs))]
+
+    def release(self):
+        for t in self.taps:
+            t.a = None
+            t.out = None

@@ -1,0 +1,427 @@
+// Symmetric eigendecomposition on gfx950: two-sided block-Jacobi.
+//
+// Replaces utils.symeig -> torch.linalg.eigh(M, UPLO="U") + clamp/nan_to_num
+// (laplace/utils/utils.py:193-228) as called per Kronecker factor by Kron.decompose
+// (laplace/utils/matrix.py:123-150).
+//
+// Algorithm (n padded to np = multiple of 64; 32-wide index blocks; nb = np/32 blocks):
+//   sweep = nb-1 round-robin steps; in step s the nb blocks are paired into nb/2 disjoint pivots (I,J)
+//     1. pivot kernel   : each pivot's 64x64 symmetric sub-matrix [A_II A_IJ; A_JI A_JJ] is diagonalised
+//                         completely by a cyclic Jacobi in LDS -> orthogonal R_P (64x64) and its diagonal
+//     2. update kernel  : every 64x64 tile pair (P<=Q):  A_PQ <- R_P^T A_PQ R_Q   (two exact-fp32 MFMA
+//                         products; the mirrored tile is written from the same result, keeping A symmetric)
+//     3. vupdate kernel : V[:, Q] <- V[:, Q] R_Q
+//   a sweep in which no pivot performed a rotation sets the device-side `converged` flag; later launches
+//   return immediately, so the whole solve is enqueued without a single host synchronisation.
+//   Finally eigenvalues (the diagonal) are rank-sorted ascending, clamped, and V's columns gathered.
+// Zero padding is exact: padded rows/columns never rotate (their off-diagonals are exactly 0).
+#include "lk_common.h"
+
+namespace lk {
+
+constexpr int EB = 32;       // index block
+constexpr int EP = 64;       // pivot size (two blocks)
+constexpr int ELD = 65;      // LDS pitch, conflict-free for column access
+
+struct EigCtrl {             // lives in the workspace
+  float scale;               // max |A_ii| at start (float)
+  int rotations;             // rotations performed in the current sweep
+  int converged;             // set when a sweep performed none
+  int sweeps;                // completed sweeps
+};
+
+// round-robin pairing of nb blocks (nb even): step s in [0, nb-1), pivot p in [0, nb/2)
+__device__ __forceinline__ void pivot_blocks(int s, int p, int nb, int& I, int& J) {
+  const int m = nb - 1;
+  int a, b;
+  if (p == 0) {
+    a = m;
+    b = s % m;
+  } else {
+    a = (s + p) % m;
+    b = (s - p + m) % m;
+  }
+  I = a < b ? a : b;
+  J = a < b ? b : a;
+}
+
+__device__ __forceinline__ int pivot_index(int local, int I, int J) {  // local 0..63 -> global row/col
+  return (local < EB ? I * EB : J * EB - EB) + local;
+}
+
+__global__ __launch_bounds__(256) void eig_init_kernel(const float* __restrict__ A, int n, int np,
+                                                       float* __restrict__ Aw, float* __restrict__ V,
+                                                       EigCtrl* ctrl) {
+  const int64_t total = (int64_t)np * np;
+  float mx = 0.f;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int r = (int)(idx / np), c = (int)(idx - (int64_t)r * np);
+    float v = 0.f;
+    if (r < n && c < n) v = (r <= c) ? A[(int64_t)r * n + c] : A[(int64_t)c * n + r];  // UPLO="U"
+    if (!(v == v) || fabsf(v) > 3.0e38f) v = 0.f;                                       // NaN / inf guard
+    Aw[idx] = v;
+    V[idx] = (r == c) ? 1.f : 0.f;
+    if (r == c) mx = fmaxf(mx, fabsf(v));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(reinterpret_cast<int*>(&ctrl->scale), __float_as_int(mx));
+}
+
+// ---- 1. pivot solve -------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void eig_pivot_kernel(float* __restrict__ Aw, int np, int nb, int step,
+                                                        float* __restrict__ Rws, float* __restrict__ Dws,
+                                                        EigCtrl* ctrl, float tol_rel, float tol_abs,
+                                                        int max_inner) {
+  if (ctrl->converged) return;
+  __shared__ float S[EP][ELD];
+  __shared__ float R[EP][ELD];
+  __shared__ float cs[32][2];
+  __shared__ int pq[32][2];
+  __shared__ int any_rot;
+  __shared__ int sweep_rot;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int I, J;
+  pivot_blocks(step, blockIdx.x, nb, I, J);
+  const float floor_abs = tol_abs * ctrl->scale;
+
+  // load the upper triangle of the pivot sub-matrix and mirror it
+  for (int idx = tid; idx < EP * EP; idx += 256) {
+    const int r = idx >> 6, c = idx & 63;
+    const int gr = pivot_index(r, I, J), gc = pivot_index(c, I, J);
+    const float v = (r <= c) ? Aw[(int64_t)gr * np + gc] : Aw[(int64_t)gc * np + gr];
+    S[r][c] = v;
+    R[r][c] = (r == c) ? 1.f : 0.f;
+  }
+  int total_rot = 0;
+  __syncthreads();
+
+  for (int sw = 0; sw < max_inner; ++sw) {
+    if (tid == 0) sweep_rot = 0;
+    for (int t = 0; t < EP - 1; ++t) {
+      // (a) rotation parameters of the 32 disjoint pairs of this step
+      if (tid == 0) any_rot = 0;
+      __syncthreads();
+      if (tid < 32) {
+        int a, b;
+        if (tid == 0) {
+          a = EP - 1;
+          b = t;
+        } else {
+          a = (t + tid) % (EP - 1);
+          b = (t - tid + (EP - 1)) % (EP - 1);
+        }
+        const int p = a < b ? a : b, q = a < b ? b : a;
+        const float app = S[p][p], aqq = S[q][q], apq = S[p][q];
+        float c = 1.f, s = 0.f;
+        const float mag = fabsf(apq);
+        if (mag > floor_abs && mag > tol_rel * sqrtf(fabsf(app * aqq))) {
+          const float tau = (aqq - app) / (2.f * apq);
+          const float tt = (tau >= 0.f ? 1.f : -1.f) / (fabsf(tau) + sqrtf(1.f + tau * tau));
+          c = rsqrtf(1.f + tt * tt);
+          s = tt * c;
+          any_rot = 1;  // benign race: every writer stores 1
+          atomicAdd(&sweep_rot, 1);
+        }
+        cs[tid][0] = c;
+        cs[tid][1] = s;
+        pq[tid][0] = p;
+        pq[tid][1] = q;
+      }
+      __syncthreads();
+      if (!any_rot) continue;  // block-uniform
+      // (b) column rotation of S and R:  X[:, p], X[:, q]  <-  X J
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int k = wave * 8 + i;
+        const float c = cs[k][0], s = cs[k][1];
+        if (s != 0.f) {  // wave-uniform
+          const int p = pq[k][0], q = pq[k][1];
+          const float sp = S[lane][p], sq = S[lane][q];
+          S[lane][p] = c * sp - s * sq;
+          S[lane][q] = s * sp + c * sq;
+          const float rp = R[lane][p], rq = R[lane][q];
+          R[lane][p] = c * rp - s * rq;
+          R[lane][q] = s * rp + c * rq;
+        }
+      }
+      __syncthreads();
+      // (c) row rotation of S:  X[p, :], X[q, :]  <-  J^T X ; the annihilated element is set to exact 0
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int k = wave * 8 + i;
+        const float c = cs[k][0], s = cs[k][1];
+        if (s != 0.f) {
+          const int p = pq[k][0], q = pq[k][1];
+          const float sp = S[p][lane], sq = S[q][lane];
+          float np_ = c * sp - s * sq;
+          float nq_ = s * sp + c * sq;
+          if (lane == q) np_ = 0.f;
+          if (lane == p) nq_ = 0.f;
+          S[p][lane] = np_;
+          S[q][lane] = nq_;
+        }
+      }
+      // the barrier at the top of the next step orders (c) against the next (a)
+    }
+    __syncthreads();
+    const int r = sweep_rot;
+    __syncthreads();
+    total_rot += r;
+    if (r == 0) break;
+  }
+
+  // outputs: R_P (row-major 64x64) and the pivot's diagonal
+  float* Rout = Rws + (int64_t)blockIdx.x * EP * EP;
+  for (int idx = tid; idx < EP * EP; idx += 256) Rout[idx] = R[idx >> 6][idx & 63];
+  if (tid < EP) Dws[(int64_t)blockIdx.x * EP + tid] = S[tid][tid];
+  if (tid == 0 && total_rot > 0) atomicAdd(&ctrl->rotations, total_rot);
+}
+
+// ---- 2. tile update  A_PQ <- R_P^T A_PQ R_Q ----------------------------------------------------------
+// out = X * Y (64x64x64) for this wave's 32x32 quadrant; X read by column-of-row (pitch ELD), Y by row
+__device__ __forceinline__ f32x16 quad_mm_AB(const float (*X)[ELD], const float (*Y)[ELD], int wm, int wn, int lo,
+                                             int hi) {
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 8
+  for (int kk = 0; kk < EP / 2; ++kk) {
+    const int k = 2 * kk + hi;
+    const float a = X[wm * 32 + lo][k];  // A[i][k]
+    const float b = Y[k][wn * 32 + lo];  // B[k][j]
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+  }
+  return acc;
+}
+// out = X^T * Y
+__device__ __forceinline__ f32x16 quad_mm_AtB(const float (*X)[ELD], const float (*Y)[ELD], int wm, int wn, int lo,
+                                              int hi) {
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 8
+  for (int kk = 0; kk < EP / 2; ++kk) {
+    const int k = 2 * kk + hi;
+    const float a = X[k][wm * 32 + lo];  // X^T[i][k] = X[k][i]
+    const float b = Y[k][wn * 32 + lo];
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+  }
+  return acc;
+}
+__device__ __forceinline__ void quad_store(float (*Z)[ELD], const f32x16& acc, int wm, int wn, int lo, int hi) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) Z[wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi][wn * 32 + lo] = acc[r];
+}
+
+__global__ __launch_bounds__(256) void eig_update_kernel(float* __restrict__ Aw, int np, int nb, int step,
+                                                         const float* __restrict__ Rws,
+                                                         const float* __restrict__ Dws, const EigCtrl* ctrl) {
+  if (ctrl->converged) return;
+  __shared__ float X[EP][ELD];
+  __shared__ float Y[EP][ELD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lo = lane & 31, hi = lane >> 5, wm = wave >> 1, wn = wave & 1;
+  // linear index over pivot pairs P <= Q
+  const int npv = nb / 2;
+  int P = 0, rem = blockIdx.x, rowlen = npv;
+  while (rem >= rowlen) {
+    rem -= rowlen;
+    ++P;
+    --rowlen;
+  }
+  const int Q = P + rem;
+  int IP, JP, IQ, JQ;
+  pivot_blocks(step, P, nb, IP, JP);
+  pivot_blocks(step, Q, nb, IQ, JQ);
+
+  if (P == Q) {  // the pivot itself becomes exactly diagonal
+    for (int idx = tid; idx < EP * EP; idx += 256) {
+      const int r = idx >> 6, c = idx & 63;
+      Aw[(int64_t)pivot_index(r, IP, JP) * np + pivot_index(c, IP, JP)] =
+          (r == c) ? Dws[(int64_t)P * EP + r] : 0.f;
+    }
+    return;
+  }
+  const float* RP = Rws + (int64_t)P * EP * EP;
+  const float* RQ = Rws + (int64_t)Q * EP * EP;
+  for (int idx = tid; idx < EP * EP; idx += 256) {
+    const int r = idx >> 6, c = idx & 63;
+    X[r][c] = Aw[(int64_t)pivot_index(r, IP, JP) * np + pivot_index(c, IQ, JQ)];
+    Y[r][c] = RQ[idx];
+  }
+  __syncthreads();
+  f32x16 t = quad_mm_AB(X, Y, wm, wn, lo, hi);  // T = A_PQ R_Q
+  __syncthreads();
+  quad_store(X, t, wm, wn, lo, hi);  // X <- T
+  for (int idx = tid; idx < EP * EP; idx += 256) Y[idx >> 6][idx & 63] = RP[idx];
+  __syncthreads();
+  f32x16 m = quad_mm_AtB(Y, X, wm, wn, lo, hi);  // M = R_P^T T
+  __syncthreads();
+  quad_store(X, m, wm, wn, lo, hi);  // X <- M
+  __syncthreads();
+  for (int idx = tid; idx < EP * EP; idx += 256) {
+    const int r = idx >> 6, c = idx & 63;
+    Aw[(int64_t)pivot_index(r, IP, JP) * np + pivot_index(c, IQ, JQ)] = X[r][c];
+    Aw[(int64_t)pivot_index(r, IQ, JQ) * np + pivot_index(c, IP, JP)] = X[c][r];  // mirrored tile
+  }
+}
+
+// ---- 3. eigenvector update  V[:, Q] <- V[:, Q] R_Q -----------------------------------------------------
+__global__ __launch_bounds__(256) void eig_vupdate_kernel(float* __restrict__ V, int np, int nb, int step,
+                                                          const float* __restrict__ Rws, const EigCtrl* ctrl) {
+  if (ctrl->converged) return;
+  __shared__ float X[EP][ELD];
+  __shared__ float Y[EP][ELD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lo = lane & 31, hi = lane >> 5, wm = wave >> 1, wn = wave & 1;
+  const int Q = blockIdx.x, rb = blockIdx.y;
+  int IQ, JQ;
+  pivot_blocks(step, Q, nb, IQ, JQ);
+  const float* RQ = Rws + (int64_t)Q * EP * EP;
+  for (int idx = tid; idx < EP * EP; idx += 256) {
+    const int r = idx >> 6, c = idx & 63;
+    X[r][c] = V[(int64_t)(rb * EP + r) * np + pivot_index(c, IQ, JQ)];
+    Y[r][c] = RQ[idx];
+  }
+  __syncthreads();
+  f32x16 t = quad_mm_AB(X, Y, wm, wn, lo, hi);
+  __syncthreads();
+  quad_store(X, t, wm, wn, lo, hi);
+  __syncthreads();
+  for (int idx = tid; idx < EP * EP; idx += 256) {
+    const int r = idx >> 6, c = idx & 63;
+    V[(int64_t)(rb * EP + r) * np + pivot_index(c, IQ, JQ)] = X[r][c];
+  }
+}
+
+__global__ void eig_sweep_end_kernel(EigCtrl* ctrl) {
+  if (ctrl->converged) return;
+  if (ctrl->rotations == 0) ctrl->converged = 1;
+  ctrl->rotations = 0;
+  ctrl->sweeps += 1;
+}
+
+// ---- finalize: rank-sort ascending, clamp, gather eigenvector columns ----------------------------------
+__global__ __launch_bounds__(256) void eig_diag_kernel(const float* __restrict__ Aw, int n, int np,
+                                                       float* __restrict__ d) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    float l = Aw[(int64_t)i * np + i];
+    d[i] = (l == l) ? l : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void eig_rank_kernel(const float* __restrict__ d, int n, int* __restrict__ perm) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float li = d[i];
+  int rank = 0;
+  for (int j = 0; j < n; ++j) {
+    const float lj = d[j];
+    rank += (lj < li) || (lj == li && j < i);
+  }
+  perm[rank] = i;
+}
+
+__global__ __launch_bounds__(256) void eig_gather_kernel(const float* __restrict__ d, const float* __restrict__ V,
+                                                         const int* __restrict__ perm, int n, int np, int clamp,
+                                                         float* __restrict__ w, float* __restrict__ Q,
+                                                         const EigCtrl* ctrl, int32_t* info) {
+  const int64_t total = (int64_t)n * n;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int r = (int)(idx / n), k = (int)(idx - (int64_t)r * n);
+    float v = V[(int64_t)r * np + perm[k]];
+    if (!(v == v)) v = 0.f;
+    Q[idx] = v;
+    if (r == 0) {
+      float l = d[perm[k]];
+      if (clamp && l < 0.f) l = 0.f;
+      w[k] = l;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && info != nullptr) info[0] = ctrl->converged ? 0 : 1;
+}
+
+struct EigPlan {
+  int np, nb, npv;
+  size_t off_A, off_V, off_R, off_D, off_perm, off_diag, off_ctrl, total;
+};
+
+static EigPlan eig_plan(int64_t n) {
+  EigPlan p;
+  p.np = (int)((n + EP - 1) / EP * EP);
+  if (p.np < EP) p.np = EP;
+  p.nb = p.np / EB;
+  p.npv = p.nb / 2;
+  size_t off = 0;
+  p.off_A = off; off += align_up((size_t)p.np * p.np * 4, 256);
+  p.off_V = off; off += align_up((size_t)p.np * p.np * 4, 256);
+  p.off_R = off; off += align_up((size_t)p.npv * EP * EP * 4, 256);
+  p.off_D = off; off += align_up((size_t)p.npv * EP * 4, 256);
+  p.off_perm = off; off += align_up((size_t)p.np * 4, 256);
+  p.off_diag = off; off += align_up((size_t)p.np * 4, 256);
+  p.off_ctrl = off; off += 256;
+  p.total = off;
+  return p;
+}
+
+}  // namespace lk
+
+using namespace lk;
+
+extern "C" size_t lk_syevj_workspace_bytes(int64_t n) {
+  if (n <= 0) return 0;
+  return eig_plan(n).total;
+}
+
+extern "C" int lk_syevj_f32(const float* A, int64_t n, float* w, float* Q, int clamp, int max_sweeps, int32_t* info,
+                            void* ws, size_t ws_bytes, void* stream_) {
+  LK_REQUIRE(A && w && Q && n >= 0 && n <= 32768, "lk_syevj_f32: bad arguments");
+  if (n == 0) return LK_OK;
+  hipStream_t stream = (hipStream_t)stream_;
+  const EigPlan p = eig_plan(n);
+  if (ws == nullptr || ws_bytes < p.total) {
+    set_error("lk_syevj_f32: workspace too small (%zu < %zu bytes)", ws_bytes, p.total);
+    return LK_EWORKSPACE;
+  }
+  char* base = static_cast<char*>(ws);
+  float* Aw = reinterpret_cast<float*>(base + p.off_A);
+  float* V = reinterpret_cast<float*>(base + p.off_V);
+  float* Rws = reinterpret_cast<float*>(base + p.off_R);
+  float* Dws = reinterpret_cast<float*>(base + p.off_D);
+  int* perm = reinterpret_cast<int*>(base + p.off_perm);
+  float* dvec = reinterpret_cast<float*>(base + p.off_diag);
+  EigCtrl* ctrl = reinterpret_cast<EigCtrl*>(base + p.off_ctrl);
+  if (max_sweeps <= 0) max_sweeps = 14;
+  const float tol_rel = 3.0e-7f;   // ~2.5 eps: |a_pq| <= tol_rel*sqrt(|a_pp a_qq|) counts as annihilated
+  const float tol_abs = 6.0e-8f;   // x max|a_ii|: absolute floor for (numerically) rank-deficient factors
+
+  if (hipMemsetAsync(ctrl, 0, sizeof(EigCtrl), stream) != hipSuccess) {
+    set_error("lk_syevj_f32: hipMemsetAsync failed");
+    return LK_ELAUNCH;
+  }
+  int64_t blocks = ((int64_t)p.np * p.np + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(eig_init_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, A, (int)n, p.np, Aw, V, ctrl);
+  const int steps = p.nb - 1;
+  const int ntiles = p.npv * (p.npv + 1) / 2;
+  for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+    for (int s = 0; s < steps; ++s) {
+      hipLaunchKernelGGL(eig_pivot_kernel, dim3(p.npv), dim3(256), 0, stream, Aw, p.np, p.nb, s, Rws, Dws, ctrl,
+                         tol_rel, tol_abs, 12);
+      hipLaunchKernelGGL(eig_update_kernel, dim3(ntiles), dim3(256), 0, stream, Aw, p.np, p.nb, s, Rws, Dws, ctrl);
+      hipLaunchKernelGGL(eig_vupdate_kernel, dim3(p.npv, p.np / EP), dim3(256), 0, stream, V, p.np, p.nb, s, Rws,
+                         ctrl);
+    }
+    hipLaunchKernelGGL(eig_sweep_end_kernel, dim3(1), dim3(1), 0, stream, ctrl);
+  }
+  hipLaunchKernelGGL(eig_diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, Aw, (int)n, p.np, dvec);
+  hipLaunchKernelGGL(eig_rank_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dvec, (int)n, perm);
+  int64_t gblocks = (n * n + 255) / 256;
+  if (gblocks > 4096) gblocks = 4096;
+  hipLaunchKernelGGL(eig_gather_kernel, dim3((unsigned)gblocks), dim3(256), 0, stream, dvec, V, perm, (int)n, p.np,
+                     clamp, w, Q, ctrl, info);
+  return check_launch("lk_syevj_f32");
+}

@@ -1,0 +1,475 @@
+// Gram / Kronecker-factor accumulation on gfx950:  C += alpha * X^T X  with exact-fp32 MFMA.
+//
+// One MFMA engine, three operand loaders (the virtual row matrix X[K][n] is never materialised for
+// the NT and CONV forms):
+//   MODE_TN   X[K][n] row-major (ldx)                           nn.Linear inputs / output grads
+//   MODE_NT   x[nb][n][L]; row k=(b,l) -> x[b][:,l]             NCHW conv output grads, 1x1 conv inputs
+//   MODE_CONV x[B][H][W][Cin] NHWC; row k=(b,oh,ow), col=(dy,dx,ci)  implicit im2col of conv inputs
+//
+// Work decomposition: grid.x = upper-triangular tile pairs (bi <= bj) of the n x n output, grid.y =
+// split-K slices.  Every workgroup writes its partial tile to a workspace slab (deterministic, no
+// atomics); gram_reduce_kernel sums the slabs, scales by alpha, accumulates into C and mirrors the
+// off-diagonal tiles.  Two tile configurations:
+//   BIG   128x128 tile, BK=16, 4 waves as 2x2, each wave 2x2 MFMA 32x32x2 tiles (64 acc VGPRs)
+//   SMALL  64x64  tile (n <= 64), BK=64, 4 waves as 2x2, each wave one 32x32 tile: tiny-n / huge-K
+//          factors (conv G with 64 channels) keep all four SIMDs busy through deep split-K.
+//
+// Reference being replaced: the A^T A / G^T G products inside curvlinops' KFAC as consumed by
+// laplace/curvature/curvlinops.py:55-108, and the einsums of laplace/curvature/curvature.py:406,409,491.
+#include "lk_common.h"
+
+namespace lk {
+
+enum { MODE_TN = 0, MODE_NT = 1, MODE_CONV = 2 };
+
+struct GramGeom {
+  const float* x;
+  int64_t K;    // virtual rows
+  int n;        // columns (= output dim)
+  int64_t ldx;  // TN
+  int L, Lp;    // NT: positions per image, padded to a multiple of BK
+  int H, W, Cin, OH, OW, kw, sh, sw, ph, pw, dh, dw;  // CONV
+};
+
+template <bool SMALL>
+struct Cfg {
+  static constexpr int T = SMALL ? 64 : 128;   // output tile edge
+  static constexpr int BK = SMALL ? 64 : 16;   // virtual rows per chunk
+  static constexpr int LDP = T + 4;            // LDS row pitch (floats), keeps 16-B alignment
+  static constexpr int EPT = T * BK / 256;     // staged elements per thread per panel
+  static constexpr int TW = SMALL ? 1 : 2;     // MFMA 32x32 tiles per wave along each output dim
+  static constexpr int WT = 32 * TW;           // wave tile edge
+};
+
+// element e of this thread's share of a [BK][T] panel -> (krow, col)
+template <int MODE, int VEC, bool SMALL>
+__device__ __forceinline__ void elem_coord(int tid, int e, int& krow, int& col) {
+  using C = Cfg<SMALL>;
+  if (MODE == MODE_NT) {
+    if (VEC == 4) {
+      constexpr int TPC = C::BK / 4;
+      const int it = e >> 2, j = e & 3;
+      col = tid / TPC + (256 / TPC) * it;
+      krow = (tid % TPC) * 4 + j;
+    } else {
+      col = tid / C::BK + (256 / C::BK) * e;
+      krow = tid % C::BK;
+    }
+  } else {
+    if (VEC == 4) {
+      constexpr int TPR = C::T / 4;
+      const int it = e >> 2, j = e & 3;
+      krow = tid / TPR + (256 / TPR) * it;
+      col = (tid % TPR) * 4 + j;
+    } else {
+      krow = tid / C::T + (256 / C::T) * e;
+      col = tid % C::T;
+    }
+  }
+}
+
+// address + validity of virtual element (k, c)
+template <int MODE>
+__device__ __forceinline__ const float* elem_ptr(const GramGeom& g, int64_t k, int c, bool& valid) {
+  if (MODE == MODE_TN) {
+    valid = (k < g.K) && (c < g.n);
+    return g.x + k * g.ldx + c;
+  } else if (MODE == MODE_NT) {
+    const int b = (int)(k / g.Lp);
+    const int l = (int)(k - (int64_t)b * g.Lp);
+    valid = (k < g.K) && (l < g.L) && (c < g.n);
+    return g.x + ((int64_t)b * g.n + c) * g.L + l;
+  } else {
+    const int ohw = g.OH * g.OW;
+    const int b = (int)(k / ohw);
+    const int r = (int)(k - (int64_t)b * ohw);
+    const int oh = r / g.OW, ow = r - oh * g.OW;
+    const int d = c / g.Cin, ci = c - d * g.Cin;
+    const int dy = d / g.kw, dx = d - dy * g.kw;
+    const int ih = oh * g.sh - g.ph + dy * g.dh;
+    const int iw = ow * g.sw - g.pw + dx * g.dw;
+    valid = (k < g.K) && (c < g.n) && (ih >= 0) && (ih < g.H) && (iw >= 0) && (iw < g.W);
+    return g.x + (((int64_t)b * g.H + ih) * g.W + iw) * g.Cin + ci;
+  }
+}
+
+template <int MODE, int VEC, bool SMALL>
+__device__ __forceinline__ void load_panel(const GramGeom& g, int64_t k0, int col0, int tid,
+                                           float (&st)[Cfg<SMALL>::EPT]) {
+  using C = Cfg<SMALL>;
+  if (VEC == 4) {
+#pragma unroll
+    for (int it = 0; it < C::EPT / 4; ++it) {
+      int krow, col;
+      elem_coord<MODE, VEC, SMALL>(tid, it * 4, krow, col);
+      bool valid;
+      const float* p = elem_ptr<MODE>(g, k0 + krow, col0 + col, valid);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (valid) v = *reinterpret_cast<const f32x4*>(p);
+      st[it * 4 + 0] = v.x;
+      st[it * 4 + 1] = v.y;
+      st[it * 4 + 2] = v.z;
+      st[it * 4 + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < C::EPT; ++e) {
+      int krow, col;
+      elem_coord<MODE, VEC, SMALL>(tid, e, krow, col);
+      bool valid;
+      const float* p = elem_ptr<MODE>(g, k0 + krow, col0 + col, valid);
+      st[e] = valid ? *p : 0.f;
+    }
+  }
+}
+
+template <int MODE, int VEC, bool SMALL>
+__device__ __forceinline__ void store_panel(float* panel, int tid, const float (&st)[Cfg<SMALL>::EPT]) {
+  using C = Cfg<SMALL>;
+  if (MODE != MODE_NT && VEC == 4) {
+#pragma unroll
+    for (int it = 0; it < C::EPT / 4; ++it) {
+      int krow, col;
+      elem_coord<MODE, VEC, SMALL>(tid, it * 4, krow, col);
+      f32x4 v = {st[it * 4], st[it * 4 + 1], st[it * 4 + 2], st[it * 4 + 3]};
+      *reinterpret_cast<f32x4*>(panel + krow * C::LDP + col) = v;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < C::EPT; ++e) {
+      int krow, col;
+      elem_coord<MODE, VEC, SMALL>(tid, e, krow, col);
+      panel[krow * C::LDP + col] = st[e];
+    }
+  }
+}
+
+__device__ __forceinline__ void pair_to_tiles(int p, int nbt, int& bi, int& bj) {
+  bi = 0;
+  int rowlen = nbt;
+  while (p >= rowlen) {
+    p -= rowlen;
+    ++bi;
+    --rowlen;
+  }
+  bj = bi + p;
+}
+
+template <int MODE, int VEC, bool SMALL>
+__global__ __launch_bounds__(256) void gram_kernel(GramGeom g, float* __restrict__ slabs, int nbt, int npairs,
+                                                   int chunks_per_split, int nchunks) {
+  using C = Cfg<SMALL>;
+  constexpr int PANEL = C::BK * C::LDP;
+  constexpr int TW = C::TW;
+  constexpr int NP = SMALL ? 1 : 2;  // SMALL has a single (diagonal) tile: the B panel aliases A
+  __shared__ __attribute__((aligned(16))) float smem[2 * NP * PANEL];  // [buf][panel A|B]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int lo = lane & 31, hi = lane >> 5;
+  int bi, bj;
+  pair_to_tiles(blockIdx.x, nbt, bi, bj);
+  const bool diag = SMALL || (bi == bj);
+  const int colA = bi * C::T, colB = bj * C::T;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // wave-uniform activity of the 32x32 sub-tiles (skip MFMA work that is entirely padding)
+  bool actm[TW], actn[TW];
+#pragma unroll
+  for (int t = 0; t < TW; ++t) {
+    actm[t] = (colA + wm * C::WT + t * 32) < g.n;
+    actn[t] = (colB + wn * C::WT + t * 32) < g.n;
+  }
+
+  f32x16 acc[TW][TW];
+#pragma unroll
+  for (int a = 0; a < TW; ++a)
+#pragma unroll
+    for (int b = 0; b < TW; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int c_begin = blockIdx.y * chunks_per_split;
+  const int c_end = min(nchunks, c_begin + chunks_per_split);
+
+  float stA[C::EPT], stB[C::EPT];
+  if (c_begin < c_end) {
+    load_panel<MODE, VEC, SMALL>(g, (int64_t)c_begin * C::BK, colA, tid, stA);
+    if (!diag) load_panel<MODE, VEC, SMALL>(g, (int64_t)c_begin * C::BK, colB, tid, stB);
+    store_panel<MODE, VEC, SMALL>(smem, tid, stA);
+    if (!diag) store_panel<MODE, VEC, SMALL>(smem + PANEL, tid, stB);
+  }
+  __syncthreads();
+
+  int cur = 0;
+  for (int c = c_begin; c < c_end; ++c) {
+    const bool more = (c + 1) < c_end;
+    if (more) {
+      load_panel<MODE, VEC, SMALL>(g, (int64_t)(c + 1) * C::BK, colA, tid, stA);
+      if (!diag) load_panel<MODE, VEC, SMALL>(g, (int64_t)(c + 1) * C::BK, colB, tid, stB);
+    }
+    const float* pA = smem + cur * NP * PANEL;
+    const float* pB = diag ? pA : pA + PANEL;
+#pragma unroll 8
+    for (int kk = 0; kk < C::BK / 2; ++kk) {
+      const int krow = 2 * kk + hi;
+      float a[TW], b[TW];
+#pragma unroll
+      for (int t = 0; t < TW; ++t) {
+        a[t] = pA[krow * C::LDP + wm * C::WT + t * 32 + lo];
+        b[t] = pB[krow * C::LDP + wn * C::WT + t * 32 + lo];
+      }
+#pragma unroll
+      for (int tm = 0; tm < TW; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TW; ++tn)
+          if (actm[tm] && actn[tn])
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+    }
+    if (more) {
+      float* nx = smem + (cur ^ 1) * NP * PANEL;
+      store_panel<MODE, VEC, SMALL>(nx, tid, stA);
+      if (!diag) store_panel<MODE, VEC, SMALL>(nx + PANEL, tid, stB);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // epilogue: partial tile -> slab
+  float* slab = slabs + ((int64_t)blockIdx.y * npairs + blockIdx.x) * (C::T * C::T);
+#pragma unroll
+  for (int tm = 0; tm < TW; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TW; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * C::WT + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const int col = wn * C::WT + tn * 32 + lo;
+        slab[row * C::T + col] = acc[tm][tn][r];
+      }
+}
+
+// Sum slabs, scale, accumulate into C, mirror off-diagonal tiles.
+// grid = (npairs, (T/64)^2 * (64/rpw)); each workgroup owns `rpw` rows x 64 cols of one tile.
+__global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restrict__ slabs, int nslabs, int npairs,
+                                                          int T, int nbt, float alpha, float* __restrict__ Cmat,
+                                                          int n, int mirror, int rpw) {
+  __shared__ float tile[64][65];
+  const int tid = threadIdx.x;
+  int bi, bj;
+  pair_to_tiles(blockIdx.x, nbt, bi, bj);
+  const int subs = T / 64;
+  const int slices = 64 / rpw;
+  const int sub = blockIdx.y / slices, slice = blockIdx.y % slices;
+  const int sr = sub / subs, sc = sub % subs;
+  const int cx = tid & 63, ry = tid >> 6;
+  const int64_t tile_elems = (int64_t)T * T;
+  const bool do_mirror = mirror && (bi != bj);
+  const int row0 = sr * 64 + slice * rpw;  // first tile row of this workgroup
+  for (int lr = ry; lr < rpw; lr += 4) {
+    const float* p = slabs + (int64_t)blockIdx.x * tile_elems + (int64_t)(row0 + lr) * T + sc * 64 + cx;
+    float s = 0.f;
+    for (int k = 0; k < nslabs; ++k) s += p[(int64_t)k * npairs * tile_elems];
+    s *= alpha;
+    const int r = bi * T + row0 + lr, c = bj * T + sc * 64 + cx;
+    if (r < n && c < n) Cmat[(int64_t)r * n + c] += s;
+    if (do_mirror) tile[lr][cx] = s;
+  }
+  if (do_mirror) {
+    __syncthreads();
+    for (int idx = tid; idx < rpw * 64; idx += 256) {
+      const int srow = idx % rpw, scol = idx / rpw;
+      const int r = bj * T + sc * 64 + scol, c = bi * T + row0 + srow;
+      if (r < n && c < n) Cmat[(int64_t)r * n + c] += tile[srow][scol];
+    }
+  }
+}
+
+struct GramPlan {
+  bool small;
+  int T, BK, nbt, npairs, nchunks, nsplit, chunks_per_split, nslabs, rpw;
+  size_t ws_bytes;
+};
+
+static GramPlan make_plan(int64_t n, int64_t K) {
+  GramPlan p;
+  p.small = n <= 64;
+  p.T = p.small ? 64 : 128;
+  p.BK = p.small ? 64 : 16;
+  p.nbt = (int)((n + p.T - 1) / p.T);
+  p.npairs = p.nbt * (p.nbt + 1) / 2;
+  p.nchunks = (int)((K + p.BK - 1) / p.BK);
+  if (p.nchunks < 1) p.nchunks = 1;
+  // fill the chip (256 CUs x 4 resident workgroups) but keep >= 8 chunks per slice
+  int want = (1024 + p.npairs - 1) / p.npairs;
+  int cap = p.nchunks / 8;
+  if (cap < 1) cap = 1;
+  p.nsplit = want < cap ? want : cap;
+  if (p.nsplit > 256) p.nsplit = 256;
+  p.chunks_per_split = (p.nchunks + p.nsplit - 1) / p.nsplit;
+  p.nsplit = (p.nchunks + p.chunks_per_split - 1) / p.chunks_per_split;
+  p.nslabs = p.nsplit;
+  // reduce kernel: whole 64x64 sub-tiles per workgroup when there are many tiles, 4-row slices otherwise
+  const int subs = p.T / 64;
+  p.rpw = (p.npairs * subs * subs >= 512) ? 64 : 4;
+  p.ws_bytes = (size_t)p.nslabs * p.npairs * p.T * p.T * sizeof(float);
+  return p;
+}
+
+template <int MODE>
+static int launch_gram(const GramGeom& g, bool vec4, float alpha, float* C, unsigned flags, void* ws,
+                       size_t ws_bytes, hipStream_t stream) {
+  if (g.n <= 0) return LK_OK;
+  const GramPlan p = make_plan(g.n, g.K);
+  if (ws == nullptr || ws_bytes < p.ws_bytes) {
+    set_error("gram: workspace too small (%zu < %zu bytes)", ws_bytes, p.ws_bytes);
+    return LK_EWORKSPACE;
+  }
+  float* slabs = static_cast<float*>(ws);
+  dim3 grid(p.npairs, p.nsplit), block(256);
+#define LK_LAUNCH(V, S)                                                                                     \
+  hipLaunchKernelGGL((gram_kernel<MODE, V, S>), grid, block, 0, stream, g, slabs, p.nbt, p.npairs, \
+                     p.chunks_per_split, p.nchunks)
+  if (p.small) {
+    if (vec4) LK_LAUNCH(4, true); else LK_LAUNCH(1, true);
+  } else {
+    if (vec4) LK_LAUNCH(4, false); else LK_LAUNCH(1, false);
+  }
+#undef LK_LAUNCH
+  int rc = check_launch("gram_kernel");
+  if (rc) return rc;
+  const int subs = p.T / 64;
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3(p.npairs, subs * subs * (64 / p.rpw)), dim3(256), 0, stream, slabs,
+                     p.nslabs, p.npairs, p.T, p.nbt, alpha, C, g.n, (flags & LK_GRAM_UPPER_ONLY) ? 0 : 1, p.rpw);
+  return check_launch("gram_reduce_kernel");
+}
+
+// ---- layout helpers ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, int C, int HW,
+                                                           float* __restrict__ dst) {
+  // one workgroup transposes a 64(c) x 64(hw) tile of image blockIdx.z through LDS
+  __shared__ float tile[64][65];
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.y * 64, p0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const float* s = src + (int64_t)b * C * HW;
+  float* d = dst + (int64_t)b * C * HW;
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, p = p0 + tx;
+    tile[i][tx] = (c < C && p < HW) ? s[(int64_t)c * HW + p] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int p = p0 + i, c = c0 + tx;
+    if (c < C && p < HW) d[(int64_t)p * C + c] = tile[tx][i];
+  }
+}
+
+__global__ __launch_bounds__(256) void symmetrize_kernel(float* __restrict__ Cm, int n) {
+  // copy upper triangle (r < c) to the lower one, 64x64 tiles through LDS; grid over tile pairs bi<=bj
+  __shared__ float tile[64][65];
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  if (bi > bj) return;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = bi * 64 + i, c = bj * 64 + tx;
+    tile[i][tx] = (r < n && c < n) ? Cm[(int64_t)r * n + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int r = bj * 64 + i, c = bi * 64 + tx;  // destination (lower) element, source = tile[tx][i]
+    if (r < n && c < n && r > c) Cm[(int64_t)r * n + c] = tile[tx][i];
+  }
+}
+
+__global__ __launch_bounds__(256) void permute_sym_kernel(const float* __restrict__ src, int Cin, int KK,
+                                                          float* __restrict__ dst, int accumulate) {
+  const int n = Cin * KK;
+  const int64_t total = (int64_t)n * n;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int r = (int)(idx / n), c = (int)(idx - (int64_t)r * n);
+    const int ci = r / KK, d = r - ci * KK;
+    const int cj = c / KK, e = c - cj * KK;
+    const float v = src[(int64_t)(d * Cin + ci) * n + (e * Cin + cj)];
+    dst[idx] = accumulate ? dst[idx] + v : v;
+  }
+}
+
+}  // namespace lk
+
+using namespace lk;
+
+extern "C" size_t lk_gram_workspace_bytes(int64_t n, int64_t K) {
+  if (n <= 0) return 0;
+  return make_plan(n, K < 1 ? 1 : K).ws_bytes;
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+extern "C" int lk_gram_tn_f32(const float* X, int64_t K, int64_t n, int64_t ldx, float alpha, float* C,
+                              unsigned flags, void* ws, size_t ws_bytes, void* stream) {
+  LK_REQUIRE(X && C && K >= 0 && n >= 0 && ldx >= n, "lk_gram_tn_f32: bad arguments");
+  LK_REQUIRE(n < (1 << 30), "lk_gram_tn_f32: n too large");
+  GramGeom g{};
+  g.x = X; g.K = K; g.n = (int)n; g.ldx = ldx;
+  const bool vec4 = (n % 4 == 0) && (ldx % 4 == 0) && aligned16(X);
+  return launch_gram<MODE_TN>(g, vec4, alpha, C, flags, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int lk_gram_nt_f32(const float* X, int64_t nb, int64_t n, int64_t L, float alpha, float* C,
+                              unsigned flags, void* ws, size_t ws_bytes, void* stream) {
+  LK_REQUIRE(X && C && nb >= 0 && n >= 0 && L >= 1, "lk_gram_nt_f32: bad arguments");
+  LK_REQUIRE(n < (1 << 30) && L < (1 << 30), "lk_gram_nt_f32: dims too large");
+  const int BK = n <= 64 ? 64 : 16;
+  GramGeom g{};
+  g.x = X; g.n = (int)n; g.L = (int)L;
+  g.Lp = (int)((L + BK - 1) / BK * BK);
+  g.K = nb * g.Lp;
+  const bool vec4 = (L % 4 == 0) && aligned16(X);
+  return launch_gram<MODE_NT>(g, vec4, alpha, C, flags, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int lk_gram_conv_nhwc_f32(const float* x, int64_t B, int64_t H, int64_t W, int64_t Cin, int kh, int kw,
+                                     int sh, int sw, int ph, int pw, int dh, int dw, float alpha, float* C,
+                                     unsigned flags, void* ws, size_t ws_bytes, void* stream) {
+  LK_REQUIRE(x && C && B >= 0 && H > 0 && W > 0 && Cin > 0 && kh > 0 && kw > 0 && sh > 0 && sw > 0 && dh > 0 && dw > 0,
+             "lk_gram_conv_nhwc_f32: bad arguments");
+  const int64_t OH = (H + 2 * ph - dh * (kh - 1) - 1) / sh + 1;
+  const int64_t OW = (W + 2 * pw - dw * (kw - 1) - 1) / sw + 1;
+  LK_REQUIRE(OH > 0 && OW > 0, "lk_gram_conv_nhwc_f32: empty output");
+  GramGeom g{};
+  g.x = x; g.n = (int)(Cin * kh * kw); g.K = B * OH * OW;
+  g.H = (int)H; g.W = (int)W; g.Cin = (int)Cin; g.OH = (int)OH; g.OW = (int)OW; g.kw = kw;
+  g.sh = sh; g.sw = sw; g.ph = ph; g.pw = pw; g.dh = dh; g.dw = dw;
+  const bool vec4 = (Cin % 4 == 0) && aligned16(x);
+  return launch_gram<MODE_CONV>(g, vec4, alpha, C, flags, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int lk_nchw_to_nhwc_f32(const float* src, int64_t B, int64_t C, int64_t HW, float* dst, void* stream) {
+  LK_REQUIRE(src && dst && B >= 0 && C > 0 && HW > 0, "lk_nchw_to_nhwc_f32: bad arguments");
+  if (B == 0) return LK_OK;
+  LK_REQUIRE(B < 65536, "lk_nchw_to_nhwc_f32: batch too large for grid.z");
+  dim3 grid((unsigned)((HW + 63) / 64), (unsigned)((C + 63) / 64), (unsigned)B);
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, (int)C, (int)HW, dst);
+  return check_launch("nchw_to_nhwc_kernel");
+}
+
+extern "C" int lk_symmetrize_f32(float* C, int64_t n, void* stream) {
+  LK_REQUIRE(C && n >= 0, "lk_symmetrize_f32: bad arguments");
+  if (n == 0) return LK_OK;
+  const unsigned nb = (unsigned)((n + 63) / 64);
+  hipLaunchKernelGGL(symmetrize_kernel, dim3(nb, nb), dim3(256), 0, (hipStream_t)stream, C, (int)n);
+  return check_launch("symmetrize_kernel");
+}
+
+extern "C" int lk_permute_sym_f32(const float* src, int64_t Cin, int64_t KK, float* dst, int accumulate,
+                                  void* stream) {
+  LK_REQUIRE(src && dst && Cin > 0 && KK > 0 && src != dst, "lk_permute_sym_f32: bad arguments");
+  const int64_t n = Cin * KK;
+  const int64_t total = n * n;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(permute_sym_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, (int)Cin,
+                     (int)KK, dst, accumulate);
+  return check_launch("permute_sym_kernel");
+}

@@ -1,0 +1,80 @@
+// Likelihood-side kernels: Hessian square root of softmax cross-entropy, loss sums.
+// Replaces GGNInterface._get_functional_hessian (laplace/curvature/curvature.py:366-373) and the
+// `factor * lossfunc(f, y)` evaluations (curvature.py:408,417; curvlinops.py:106).
+#include "lk_common.h"
+
+namespace lk {
+
+// One wave per sample (C <= 64 fast path keeps the row in registers; larger C loops).
+// S[c][n][j] = (j == c ? sqrt(p_c) : 0) - p_j * sqrt(p_c)
+__global__ __launch_bounds__(256) void softmax_hess_sqrt_kernel(const float* __restrict__ f,
+                                                                const int64_t* __restrict__ y, int B, int C,
+                                                                float* __restrict__ S,
+                                                                float* __restrict__ loss_accum) {
+  __shared__ float red[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.x * 4 + wave;
+  float nll = 0.f;
+  if (n < B) {
+    const float* fr = f + (int64_t)n * C;
+    float m = -INFINITY;
+    for (int j = lane; j < C; j += 64) m = fmaxf(m, fr[j]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    float z = 0.f;
+    for (int j = lane; j < C; j += 64) z += expf(fr[j] - m);
+    z = wave_sum(z);
+    const float logz = logf(z) + m;
+    if (y != nullptr && lane == 0) nll = logz - fr[y[n]];
+    for (int c = 0; c < C; ++c) {
+      const float pc = expf(fr[c] - logz);
+      const float spc = sqrtf(pc);
+      float* out = S + ((int64_t)c * B + n) * C;
+      for (int j = lane; j < C; j += 64) {
+        const float pj = expf(fr[j] - logz);
+        out[j] = (j == c ? spc : 0.f) - pj * spc;
+      }
+    }
+  }
+  if (loss_accum != nullptr && y != nullptr) {
+    const float tot = block_sum_256(nll, red);
+    if (threadIdx.x == 0) atomicAdd(loss_accum, tot);
+  }
+}
+
+__global__ __launch_bounds__(256) void sq_err_sum_kernel(const float* __restrict__ f, const float* __restrict__ y,
+                                                         int64_t numel, float scale,
+                                                         float* __restrict__ loss_accum) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256) {
+    const float d = f[i] - y[i];
+    s += d * d;
+  }
+  const float tot = block_sum_256(s, red);
+  if (threadIdx.x == 0) atomicAdd(loss_accum, scale * tot);
+}
+
+}  // namespace lk
+
+using namespace lk;
+
+extern "C" int lk_softmax_hess_sqrt_f32(const float* f, const int64_t* y, int64_t B, int64_t C, float* S,
+                                        float* loss_accum, void* stream) {
+  LK_REQUIRE(f && S && B >= 0 && C >= 1 && B < (1ll << 31) && C < (1 << 24), "lk_softmax_hess_sqrt_f32: bad arguments");
+  if (B == 0) return LK_OK;
+  hipLaunchKernelGGL(softmax_hess_sqrt_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, f, y,
+                     (int)B, (int)C, S, loss_accum);
+  return check_launch("softmax_hess_sqrt_kernel");
+}
+
+extern "C" int lk_sq_err_sum_f32(const float* f, const float* y, int64_t numel, float scale, float* loss_accum,
+                                 void* stream) {
+  LK_REQUIRE(f && y && loss_accum && numel >= 0, "lk_sq_err_sum_f32: bad arguments");
+  if (numel == 0) return LK_OK;
+  int64_t blocks = (numel + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(sq_err_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, f, y, numel, scale,
+                     loss_accum);
+  return check_launch("sq_err_sum_kernel");
+}

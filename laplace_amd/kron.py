@@ -1,0 +1,340 @@
+"""``Kron`` / ``KronDecomposed`` with the hot operations on the HIP kernels.
+
+``HipKron`` implements the full contract of ``laplace.utils.matrix.Kron``
+(laplace/utils/matrix.py:16-279) and ``HipKronDecomposed`` that of ``KronDecomposed``
+(:282-560).  Both subclass the reference's classes when laplace-torch is importable
+(:mod:`laplace_amd.refapi`), so they survive the reference's own
+``self.H += H_batch`` (laplace/baselaplace.py:985), ``H_facs.decompose()`` (:1809),
+``H * _H_factor + prior_precision`` (:1820) and ``state_dict`` (:1867-1879) unchanged:
+``kfacs`` stay plain, mutable torch tensors.
+
+Hot paths on HIP: ``decompose`` (batched symmetric eigensolver ``lk_syevj_f32``), ``logdet``
+(``lk_kron_logdet_f32`` with analytic derivatives wrapped in an autograd Function so the
+marginal-likelihood optimisation of baselaplace.py:466-485 keeps working).  The generic
+``_bmm`` on a materialised ``[B, K, P]`` operand is plain GEMM plumbing (torch.matmul →
+rocBLAS); the structure-exploiting predictive that avoids materialising the Jacobian lives in
+:mod:`laplace_amd.predictive`.
+"""
+from __future__ import annotations
+
+from math import pow
+from typing import Iterable
+
+import numpy as np
+import torch
+from torch import nn
+
+from laplace_amd._lib import get_kernels
+from laplace_amd.refapi import Kron as _KronBase
+from laplace_amd.refapi import KronDecomposed as _KronDecomposedBase
+
+
+def _is_valid_scalar(s) -> bool:
+    if np.isscalar(s) and np.isreal(s):
+        return True
+    if torch.is_tensor(s) and s.ndim <= 1:
+        return not (s.ndim == 1 and len(s) != 1)
+    return False
+
+
+def _kron2(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    return torch.einsum("ij,kl->ikjl", a, b).reshape(a.shape[0] * b.shape[0], a.shape[1] * b.shape[1])
+
+
+class HipKron(_KronBase):
+    """Kronecker-factored curvature: ``kfacs[i]`` is ``[G, A]`` (weight) or ``[B]`` (bias)."""
+
+    def __init__(self, kfacs):
+        self.kfacs = kfacs
+
+    @classmethod
+    def init_from_model(cls, model: nn.Module | Iterable[nn.Parameter], device, dtype) -> "HipKron":
+        """Zero factors shaped after the parameters (matrix.py:33-77)."""
+        params = model.parameters() if isinstance(model, nn.Module) else model
+        kfacs = []
+        for p in params:
+            if p.ndim == 1:
+                kfacs.append([torch.zeros(p.size(0), p.size(0), device=device, dtype=dtype)])
+            elif 2 <= p.ndim <= 4:
+                d_out, d_in = p.shape[0], int(np.prod(p.shape[1:]))
+                kfacs.append([torch.zeros(d_out, d_out, device=device, dtype=dtype),
+                              torch.zeros(d_in, d_in, device=device, dtype=dtype)])
+            else:
+                raise ValueError("Invalid parameter shape in network.")
+        return cls(kfacs)
+
+    # -- accumulation (matrix.py:79-118) ---------------------------------------------------------
+    def __add__(self, other):
+        if not isinstance(other, _KronBase) or not hasattr(other, "kfacs"):
+            raise ValueError("Can only add Kron to Kron.")
+        return HipKron([[Hi.add(Hj) for Hi, Hj in zip(Fi, Fj)] for Fi, Fj in zip(self.kfacs, other.kfacs)])
+
+    __radd__ = __add__
+
+    def __iadd__(self, other):
+        if not isinstance(other, _KronBase) or not hasattr(other, "kfacs"):
+            raise ValueError("Can only add Kron to Kron.")
+        for Fi, Fj in zip(self.kfacs, other.kfacs):
+            for Hi, Hj in zip(Fi, Fj):
+                Hi.add_(Hj)
+        return self
+
+    def __mul__(self, scalar):
+        if not _is_valid_scalar(scalar):
+            raise ValueError("Input not valid python or torch scalar.")
+        return HipKron([[pow(scalar, 1 / len(F)) * Hi for Hi in F] for F in self.kfacs])
+
+    __rmul__ = __mul__
+
+    def __len__(self) -> int:
+        return len(self.kfacs)
+
+    # -- eigendecomposition (matrix.py:123-150; utils/utils.py:193-228) -----------------------------
+    def decompose(self, damping: bool = False) -> "HipKronDecomposed":
+        K = get_kernels()
+        eigvecs, eigvals, infos = [], [], []
+        for F in self.kfacs:
+            Qs, ls = [], []
+            for Hi in F:
+                if Hi.ndim > 1:
+                    l, Q, info = K.syevj(Hi.contiguous(), clamp=True)
+                    infos.append(info)
+                else:  # diagonal factor
+                    l, Q = Hi, torch.eye(len(Hi), dtype=Hi.dtype, device=Hi.device)
+                Qs.append(Q)
+                ls.append(l)
+            eigvecs.append(Qs)
+            eigvals.append(ls)
+        out = HipKronDecomposed(eigvecs, eigvals, damping=damping)
+        out._eig_info = infos  # device flags; checked lazily by `check_converged`
+        return out
+
+    # -- generic algebra (plumbing; torch ops) ------------------------------------------------------
+    def _bmm(self, W: torch.Tensor) -> torch.Tensor:
+        assert W.ndim == 3
+        B, K_, P = W.shape
+        W = W.reshape(B * K_, P)
+        cur, SW = 0, []
+        for Fs in self.kfacs:
+            if len(Fs) == 1:
+                Q = Fs[0]
+                p = len(Q)
+                Wp = W[:, cur:cur + p]
+                SW.append(Wp @ Q.T if Q.ndim > 1 else Wp * Q.view(1, -1))
+                cur += p
+            else:
+                Q, H = Fs
+                p_in, p_out = len(Q), len(H)
+                Wp = W[:, cur:cur + p_in * p_out].reshape(B * K_, p_in, p_out)
+                QW = Q @ Wp if Q.ndim > 1 else Q.view(-1, 1) * Wp
+                QWH = QW @ H.T if H.ndim > 1 else QW * H.view(1, -1)
+                SW.append(QWH.reshape(B * K_, p_in * p_out))
+                cur += p_in * p_out
+        return torch.cat(SW, dim=1).reshape(B, K_, P)
+
+    def bmm(self, W: torch.Tensor, exponent: float = 1) -> torch.Tensor:
+        if exponent != 1:
+            raise ValueError("Only supported after decomposition.")
+        if W.ndim == 1:
+            return self._bmm(W.unsqueeze(0).unsqueeze(0)).squeeze()
+        if W.ndim == 2:
+            return self._bmm(W.unsqueeze(1)).squeeze()
+        if W.ndim == 3:
+            return self._bmm(W)
+        raise ValueError("Invalid shape for W")
+
+    def logdet(self) -> torch.Tensor:
+        total = 0
+        for F in self.kfacs:
+            if len(F) == 1:
+                total = total + (F[0].logdet() if F[0].ndim > 1 else F[0].log().sum())
+            else:
+                Hi, Hj = F
+                p_in, p_out = len(Hi), len(Hj)
+                total = total + p_out * (Hi.logdet() if Hi.ndim > 1 else Hi.log().sum())
+                total = total + p_in * (Hj.logdet() if Hj.ndim > 1 else Hj.log().sum())
+        return total
+
+    def diag(self) -> torch.Tensor:
+        out = []
+        for F in self.kfacs:
+            d0 = F[0].diagonal() if F[0].ndim > 1 else F[0]
+            if len(F) == 1:
+                out.append(d0)
+            else:
+                d1 = F[1].diagonal() if F[1].ndim > 1 else F[1]
+                out.append(torch.outer(d0, d1).flatten())
+        return torch.cat(out)
+
+    def to_matrix(self) -> torch.Tensor:
+        blocks = []
+        for F in self.kfacs:
+            F0 = F[0] if F[0].ndim > 1 else F[0].diag()
+            if len(F) == 1:
+                blocks.append(F0)
+            else:
+                F1 = F[1] if F[1].ndim > 1 else F[1].diag()
+                blocks.append(_kron2(F0, F1))
+        return torch.block_diag(*blocks)
+
+
+class _KronLogdet(torch.autograd.Function):
+    """sum_ij log(l1_i l2_j + delta) on HIP, differentiable in l1, l2, delta."""
+
+    @staticmethod
+    def forward(ctx, l1, l2, delta):
+        need = any(t is not None and t.requires_grad for t in (l1, l2, delta))
+        d = delta.detach().reshape(1).to(torch.float32).contiguous()
+        val, d1, d2, dd = get_kernels().kron_logdet(
+            l1.detach().contiguous(), None if l2 is None else l2.detach().contiguous(), d, False, want_grads=need
+        )
+        ctx.has_l2 = l2 is not None
+        ctx.delta_shape = delta.shape
+        ctx.save_for_backward(*(t for t in (d1, d2, dd) if t is not None))
+        ctx.need = need
+        return val.reshape(())
+
+    @staticmethod
+    def backward(ctx, grad):
+        if not ctx.need:
+            return None, None, None
+        saved = list(ctx.saved_tensors)
+        d1 = saved.pop(0)
+        d2 = saved.pop(0) if ctx.has_l2 else None
+        dd = saved.pop(0)
+        return grad * d1, (grad * d2 if d2 is not None else None), (grad * dd).reshape(ctx.delta_shape)
+
+
+class HipKronDecomposed(_KronDecomposedBase):
+    """Eigendecomposed Kronecker factors + per-block additive ``deltas`` (matrix.py:282-560)."""
+
+    def __init__(self, eigenvectors, eigenvalues, deltas: torch.Tensor | None = None, damping: bool = False):
+        self.eigenvectors = eigenvectors
+        self.eigenvalues = eigenvalues
+        device, dtype = eigenvectors[0][0].device, eigenvectors[0][0].dtype
+        if deltas is None:
+            self.deltas = torch.zeros(len(self), device=device, dtype=dtype)
+        else:
+            self._check_deltas(deltas)
+            self.deltas = deltas
+        self.damping = damping
+        self._eig_info = []
+
+    def check_converged(self) -> None:
+        """Raise (never ``exit()``, cf. utils/utils.py:208-222) if an eigensolve ran out of sweeps.
+        Synchronises with the device; call it once after ``fit`` if a hard guarantee is wanted."""
+        for info in self._eig_info:
+            if int(info.item()) != 0:
+                raise RuntimeError("lk_syevj_f32: eigendecomposition did not converge")
+
+    def detach(self):
+        self.deltas = self.deltas.detach()
+        return self
+
+    def _check_deltas(self, deltas) -> None:
+        if not isinstance(deltas, torch.Tensor):
+            raise ValueError("Can only add torch.Tensor to KronDecomposed.")
+        if deltas.ndim == 0 or (deltas.ndim == 1 and (len(deltas) == 1 or len(deltas) == len(self))):
+            return
+        raise ValueError("Invalid shape of delta added to KronDecomposed.")
+
+    def _like(self, eigenvalues, deltas):
+        out = HipKronDecomposed(self.eigenvectors, eigenvalues, deltas, self.damping)
+        out._eig_info = self._eig_info
+        return out
+
+    def __add__(self, deltas: torch.Tensor):
+        self._check_deltas(deltas)
+        return self._like(self.eigenvalues, self.deltas + deltas)
+
+    def __mul__(self, scalar):
+        if not _is_valid_scalar(scalar):
+            raise ValueError("Invalid argument, can only multiply Kron with scalar.")
+        return self._like([[pow(scalar, 1 / len(ls)) * l for l in ls] for ls in self.eigenvalues], self.deltas)
+
+    __radd__ = __add__
+    __rmul__ = __mul__
+
+    def __len__(self) -> int:
+        return len(self.eigenvalues)
+
+    # -- logdet (matrix.py:381-404) on HIP ----------------------------------------------------------
+    def logdet(self) -> torch.Tensor:
+        total = 0
+        for ls, delta in zip(self.eigenvalues, self.deltas):
+            if len(ls) == 1:
+                total = total + _KronLogdet.apply(ls[0], None, delta)
+            elif len(ls) == 2:
+                l1, l2 = ls
+                if self.damping:
+                    sd = torch.sqrt(delta)
+                    total = total + torch.log(torch.outer(l1 + sd, l2 + sd)).sum()
+                else:
+                    total = total + _KronLogdet.apply(l1, l2, delta)
+            else:
+                raise ValueError("Too many Kronecker factors. Something went wrong.")
+        return total
+
+    # -- generic (materialised-operand) algebra: GEMM plumbing ---------------------------------------
+    def _block_pow(self, ls, delta, exponent):
+        if len(ls) == 1:
+            return torch.pow(ls[0] + delta, exponent)
+        l1, l2 = ls
+        if self.damping:
+            sd = torch.sqrt(delta)
+            return torch.pow(torch.outer(l1 + sd, l2 + sd), exponent)
+        return torch.pow(torch.outer(l1, l2) + delta, exponent)
+
+    def _bmm(self, W: torch.Tensor, exponent: float = -1) -> torch.Tensor:
+        assert W.ndim == 3
+        B, K_, P = W.shape
+        W = W.reshape(B * K_, P)
+        cur, SW = 0, []
+        for ls, Qs, delta in zip(self.eigenvalues, self.eigenvectors, self.deltas):
+            lam = self._block_pow(ls, delta, exponent)
+            if len(ls) == 1:
+                Q, p = Qs[0], len(ls[0])
+                Wp = W[:, cur:cur + p]
+                SW.append(((Wp @ Q) * lam.reshape(1, -1)) @ Q.T)
+                cur += p
+            else:
+                Q1, Q2 = Qs
+                p_in, p_out = len(ls[0]), len(ls[1])
+                Wp = W[:, cur:cur + p_in * p_out].reshape(B * K_, p_in, p_out)
+                Wp = (Q1.T @ Wp @ Q2) * lam.unsqueeze(0)
+                Wp = Q1 @ Wp @ Q2.T
+                SW.append(Wp.reshape(B * K_, p_in * p_out))
+                cur += p_in * p_out
+        return torch.cat(SW, dim=1).reshape(B, K_, P)
+
+    def inv_square_form(self, W: torch.Tensor) -> torch.Tensor:
+        SW = self._bmm(W, exponent=-1)
+        return torch.bmm(W, SW.transpose(1, 2))
+
+    def bmm(self, W: torch.Tensor, exponent: float = -1) -> torch.Tensor:
+        if W.ndim == 1:
+            return self._bmm(W.unsqueeze(0).unsqueeze(0), exponent).squeeze()
+        if W.ndim == 2:
+            return self._bmm(W.unsqueeze(1), exponent).squeeze()
+        if W.ndim == 3:
+            return self._bmm(W, exponent)
+        raise ValueError("Invalid shape for W")
+
+    def diag(self, exponent: float = 1) -> torch.Tensor:
+        out = []
+        for Qs, ls, delta in zip(self.eigenvectors, self.eigenvalues, self.deltas):
+            lam = self._block_pow(ls, delta, exponent)
+            if len(ls) == 1:
+                out.append(((Qs[0] ** 2) * lam.reshape(1, -1)).sum(1))
+            else:
+                Q1, Q2 = Qs
+                out.append(((Q1**2) @ lam @ (Q2**2).T).flatten())
+        return torch.cat(out)
+
+    def to_matrix(self, exponent: float = 1) -> torch.Tensor:
+        blocks = []
+        for Qs, ls, delta in zip(self.eigenvectors, self.eigenvalues, self.deltas):
+            lam = self._block_pow(ls, delta, exponent)
+            Q = Qs[0] if len(ls) == 1 else _kron2(Qs[0], Qs[1])
+            blocks.append((Q * lam.reshape(1, -1)) @ Q.T)
+        return torch.block_diag(*blocks)

@@ -1,0 +1,159 @@
+"""CPU stand-in for ``laplace_amd._lib.HipKernels`` — TEST INFRASTRUCTURE ONLY.
+
+Each method restates, with plain torch CPU ops, what the C-ABI entry point of the same name is
+specified to compute (include/laplace_hip.h).  It lets the `not gpu` tests drive the *host logic*
+(hooks, factor ordering/scaling, Kron subclasses inside the reference's own fit loop, sharding)
+on a machine without a GPU.  The product never installs it (laplace_amd._lib.get_kernels loads
+the HIP library or raises).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+
+class EmulatedKernels:
+    name = "emulated-cpu"
+
+    # likelihood
+    def softmax_hess_sqrt(self, f, y=None, loss_accum=None):
+        p = torch.softmax(f, dim=-1)
+        sp = p.sqrt()
+        S = torch.diag_embed(sp) - p.unsqueeze(2) * sp.unsqueeze(1)  # [B, j, c]
+        if y is not None and loss_accum is not None:
+            loss_accum += -torch.log_softmax(f, -1).gather(1, y.view(-1, 1)).sum()
+        return S.permute(2, 0, 1).contiguous()  # [c, B, j]
+
+    def sq_err_sum(self, f, y, scale, loss_accum):
+        loss_accum += scale * ((f - y) ** 2).sum()
+
+    # Gram family
+    def gram_tn(self, X, alpha, out, upper_only=False):
+        out += alpha * (X.T @ X)
+        return out
+
+    def gram_nt(self, X, alpha, out, upper_only=False):
+        out += alpha * torch.einsum("bil,bjl->ij", X, X)
+        return out
+
+    def gram_conv(self, x, kernel_size, stride, padding, dilation, alpha, out, upper_only=False, native=False):
+        cols = F.unfold(x, kernel_size, dilation=dilation, padding=padding, stride=stride)  # [B, D, L]
+        G = alpha * torch.einsum("bil,bjl->ij", cols, cols)
+        if native:
+            Cin = x.shape[1]
+            KK = G.shape[0] // Cin
+            idx = torch.arange(Cin * KK).reshape(Cin, KK).T.reshape(-1)  # native (d, ci) -> unfold index
+            G = G[idx][:, idx]
+        out += G
+        return out
+
+    def permute_native_to_unfold(self, src, Cin, KK, dst, accumulate=False):
+        idx = torch.arange(Cin * KK).reshape(KK, Cin).T.reshape(-1)  # unfold (ci, d) -> native index
+        v = src[idx][:, idx]
+        if accumulate:
+            dst += v
+        else:
+            dst.copy_(v)
+        return dst
+
+    def symmetrize(self, C):
+        C.copy_(torch.triu(C) + torch.triu(C, 1).T)
+        return C
+
+    def nchw_to_nhwc(self, x):
+        return x.permute(0, 2, 3, 1).contiguous()
+
+    # diag / Jacobians
+    def diag_ggn_linear(self, a, g, alpha, h_w, h_b=None):
+        gsq = (g**2).sum(0)  # [B, Do]
+        h_w += alpha * (gsq.T @ (a**2)).reshape(-1)
+        if h_b is not None:
+            h_b += alpha * gsq.sum(0)
+
+    def jac_linear(self, a, g, Js, col0, bcol0=-1):
+        S, B, Do = g.shape
+        Di = a.shape[1]
+        Js[:, :, col0:col0 + Do * Di] = torch.einsum("sbo,bi->bsoi", g, a).reshape(B, S, Do * Di)
+        if bcol0 >= 0:
+            Js[:, :, bcol0:bcol0 + Do] = g.permute(1, 0, 2)
+
+    def jac_conv(self, x, g, kernel_size, stride, padding, dilation, Js, col0, bcol0=-1):
+        S, B, Do = g.shape[:3]
+        cols = F.unfold(x, kernel_size, dilation=dilation, padding=padding, stride=stride)  # [B, Dk, L]
+        gl = g.reshape(S, B, Do, -1)
+        J = torch.einsum("sbol,bkl->bsok", gl, cols)
+        Dk = cols.shape[1]
+        Js[:, :, col0:col0 + Do * Dk] = J.reshape(B, S, Do * Dk)
+        if bcol0 >= 0:
+            Js[:, :, bcol0:bcol0 + Do] = gl.sum(-1).permute(1, 0, 2)
+
+    def sq_colsum(self, Js, col0, width, alpha, h):
+        P = Js.shape[-1]
+        h += alpha * (Js.reshape(-1, P)[:, col0:col0 + width] ** 2).sum(0)
+
+    def ll_ggn_full(self, phi, probs, has_bias, alpha, H):
+        B, D = phi.shape
+        pt = torch.cat([phi, torch.ones(B, 1, dtype=phi.dtype)], 1) if has_bias else phi
+        Dt = pt.shape[1]
+        C = probs.shape[1] if probs is not None else H.shape[0] // Dt
+        if probs is None:
+            Lam = torch.eye(C, dtype=phi.dtype).expand(B, C, C)
+        else:
+            Lam = torch.diag_embed(probs) - probs.unsqueeze(2) * probs.unsqueeze(1)
+        Haug = alpha * torch.einsum("njk,na,nb->jakb", Lam, pt, pt).reshape(C * Dt, C * Dt)
+        ref = torch.tensor([(j * D + a) if a < D else (C * D + j) for j in range(C) for a in range(Dt)])
+        H[ref[:, None], ref[None, :]] += Haug
+        return H
+
+    # eigensolver
+    def syevj(self, A, clamp=True, max_sweeps=0):
+        Au = torch.triu(A) + torch.triu(A, 1).T
+        w, Q = torch.linalg.eigh(Au)
+        if clamp:
+            w = w.clamp(min=0.0)
+        return torch.nan_to_num(w), torch.nan_to_num(Q), torch.zeros(1, dtype=torch.int32)
+
+    # logdet
+    def kron_logdet(self, l1, l2, delta, damping=False, want_grads=False):
+        d = delta.reshape(())
+        if l2 is None:
+            M = l1 + d
+            out = torch.log(M).sum().reshape(1)
+            if not want_grads:
+                return out, None, None, None
+            return out, 1.0 / M, None, (1.0 / M).sum().reshape(1)
+        if damping:
+            sd = d.sqrt()
+            return torch.log(torch.outer(l1 + sd, l2 + sd)).sum().reshape(1), None, None, None
+        M = torch.outer(l1, l2) + d
+        out = torch.log(M).sum().reshape(1)
+        if not want_grads:
+            return out, None, None, None
+        inv = 1.0 / M
+        return out, (inv * l2.view(1, -1)).sum(1), (inv * l1.view(-1, 1)).sum(0), inv.sum().reshape(1)
+
+    # predictive
+    def kron_quadform_linear(self, u, v, l1, l2, delta, fvar, ub=None, lb=None, delta_b=None):
+        w = torch.einsum("ni,oi->no", v**2, 1.0 / (torch.outer(l1, l2) + delta.reshape(())))
+        fvar += torch.einsum("cno,kno,no->nck", u, u, w)
+        if ub is not None:
+            fvar += torch.einsum("cno,kno,o->nck", ub, ub, 1.0 / (lb + delta_b.reshape(())))
+        return fvar
+
+    def diag_quadform_linear(self, a, g, var_w, var_b, fvar):
+        w = torch.einsum("ni,oi->no", a**2, var_w.reshape(g.shape[2], a.shape[1]))
+        fvar += torch.einsum("cno,kno,no->nck", g, g, w)
+        if var_b is not None:
+            fvar += torch.einsum("cno,kno,o->nck", g, g, var_b)
+        return fvar
+
+    def diag_quadform_js(self, Js, var):
+        return torch.einsum("ncp,p,nkp->nck", Js, var, Js)
+
+    def dense_quadform_ll(self, phi, Sigma, C, has_bias):
+        B, D = phi.shape
+        eye = torch.eye(C, dtype=phi.dtype)
+        Js = (eye[None, :, :, None] * phi[:, None, None, :]).reshape(B, C, -1)
+        if has_bias:
+            Js = torch.cat([Js, eye.expand(B, C, C)], 2)
+        return torch.einsum("ncp,pq,nkq->nck", Js, Sigma, Js)
