@@ -13,7 +13,9 @@
 //     3. vupdate kernel : V[:, Q] <- V[:, Q] R_Q
 //   a sweep in which no pivot performed a rotation sets the device-side `converged` flag; later launches
 //   return immediately, so the whole solve is enqueued without a single host synchronisation.
-//   Finally eigenvalues (the diagonal) are rank-sorted ascending, clamped, and V's columns gathered.
+//   Refinement: one Newton-Schulz step re-orthonormalises V, the eigenvalues are recomputed as Rayleigh
+//   quotients v_i^T A v_i against the ORIGINAL matrix (three MFMA GEMMs), then rank-sorted ascending,
+//   clamped, and V's columns gathered.
 // Zero padding is exact: padded rows/columns never rotate (their off-diagonals are exactly 0).
 #include "lk_common.h"
 
@@ -50,8 +52,8 @@ __device__ __forceinline__ int pivot_index(int local, int I, int J) {  // local 
 }
 
 __global__ __launch_bounds__(256) void eig_init_kernel(const float* __restrict__ A, int n, int np,
-                                                       float* __restrict__ Aw, float* __restrict__ V,
-                                                       EigCtrl* ctrl) {
+                                                       float* __restrict__ Aw, float* __restrict__ A0,
+                                                       float* __restrict__ V, EigCtrl* ctrl) {
   const int64_t total = (int64_t)np * np;
   float mx = 0.f;
   for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
@@ -60,6 +62,7 @@ __global__ __launch_bounds__(256) void eig_init_kernel(const float* __restrict__
     if (r < n && c < n) v = (r <= c) ? A[(int64_t)r * n + c] : A[(int64_t)c * n + r];  // UPLO="U"
     if (!(v == v) || fabsf(v) > 3.0e38f) v = 0.f;                                       // NaN / inf guard
     Aw[idx] = v;
+    A0[idx] = v;
     V[idx] = (r == c) ? 1.f : 0.f;
     if (r == c) mx = fmaxf(mx, fabsf(v));
   }
@@ -69,6 +72,10 @@ __global__ __launch_bounds__(256) void eig_init_kernel(const float* __restrict__
 }
 
 // ---- 1. pivot solve -------------------------------------------------------------------------------
+// Cyclic Jacobi on the 64x64 pivot in LDS.  One step = 32 disjoint (p,q) pairs (round-robin over the 64
+// indices): (a) 32 lanes compute the rotations; (b) ONE fused phase applies J^T S J on disjoint 2x2
+// blocks (block (k1,k2) = rows of pair k1 x columns of pair k2 sees exactly the row rotation k1 and
+// the column rotation k2) and the column rotation on R.  Two barriers per step.
 __global__ __launch_bounds__(256) void eig_pivot_kernel(float* __restrict__ Aw, int np, int nb, int step,
                                                         float* __restrict__ Rws, float* __restrict__ Dws,
                                                         EigCtrl* ctrl, float tol_rel, float tol_abs,
@@ -94,80 +101,91 @@ __global__ __launch_bounds__(256) void eig_pivot_kernel(float* __restrict__ Aw, 
     S[r][c] = v;
     R[r][c] = (r == c) ? 1.f : 0.f;
   }
+  if (tid == 0) sweep_rot = 0;
   int total_rot = 0;
   __syncthreads();
 
   for (int sw = 0; sw < max_inner; ++sw) {
-    if (tid == 0) sweep_rot = 0;
     for (int t = 0; t < EP - 1; ++t) {
-      // (a) rotation parameters of the 32 disjoint pairs of this step
-      if (tid == 0) any_rot = 0;
-      __syncthreads();
-      if (tid < 32) {
-        int a, b;
+      // (a) rotation parameters of the 32 disjoint pairs of this step (first half of wave 0)
+      if (tid < 64) {
+        bool rot = false;
+        if (tid < 32) {
+          int a, b;
+          if (tid == 0) {
+            a = EP - 1;
+            b = t;
+          } else {
+            a = (t + tid) % (EP - 1);
+            b = (t - tid + (EP - 1)) % (EP - 1);
+          }
+          const int p = a < b ? a : b, q = a < b ? b : a;
+          const float app = S[p][p], aqq = S[q][q], apq = S[p][q];
+          float c = 1.f, s = 0.f;
+          const float mag = fabsf(apq);
+          if (mag > floor_abs && mag > tol_rel * sqrtf(fabsf(app * aqq))) {
+            const float tau = (aqq - app) / (2.f * apq);
+            const float tt = (tau >= 0.f ? 1.f : -1.f) / (fabsf(tau) + sqrtf(1.f + tau * tau));
+            c = 1.f / sqrtf(1.f + tt * tt);
+            s = tt * c;
+            rot = true;
+          }
+          cs[tid][0] = c;
+          cs[tid][1] = s;
+          pq[tid][0] = p;
+          pq[tid][1] = q;
+        }
+        const unsigned long long m = __ballot(rot);
         if (tid == 0) {
-          a = EP - 1;
-          b = t;
-        } else {
-          a = (t + tid) % (EP - 1);
-          b = (t - tid + (EP - 1)) % (EP - 1);
-        }
-        const int p = a < b ? a : b, q = a < b ? b : a;
-        const float app = S[p][p], aqq = S[q][q], apq = S[p][q];
-        float c = 1.f, s = 0.f;
-        const float mag = fabsf(apq);
-        if (mag > floor_abs && mag > tol_rel * sqrtf(fabsf(app * aqq))) {
-          const float tau = (aqq - app) / (2.f * apq);
-          const float tt = (tau >= 0.f ? 1.f : -1.f) / (fabsf(tau) + sqrtf(1.f + tau * tau));
-          c = rsqrtf(1.f + tt * tt);
-          s = tt * c;
-          any_rot = 1;  // benign race: every writer stores 1
-          atomicAdd(&sweep_rot, 1);
-        }
-        cs[tid][0] = c;
-        cs[tid][1] = s;
-        pq[tid][0] = p;
-        pq[tid][1] = q;
-      }
-      __syncthreads();
-      if (!any_rot) continue;  // block-uniform
-      // (b) column rotation of S and R:  X[:, p], X[:, q]  <-  X J
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int k = wave * 8 + i;
-        const float c = cs[k][0], s = cs[k][1];
-        if (s != 0.f) {  // wave-uniform
-          const int p = pq[k][0], q = pq[k][1];
-          const float sp = S[lane][p], sq = S[lane][q];
-          S[lane][p] = c * sp - s * sq;
-          S[lane][q] = s * sp + c * sq;
-          const float rp = R[lane][p], rq = R[lane][q];
-          R[lane][p] = c * rp - s * rq;
-          R[lane][q] = s * rp + c * rq;
+          any_rot = (m != 0ull);
+          sweep_rot += __popcll(m);
         }
       }
       __syncthreads();
-      // (c) row rotation of S:  X[p, :], X[q, :]  <-  J^T X ; the annihilated element is set to exact 0
+      if (any_rot) {  // block-uniform
+        // (b1) S <- J^T S J on 2x2 blocks: thread owns row-pair k1 = tid/8 and column-pairs tid%8 + 8j
+        const int k1 = tid >> 3;
+        const float c1 = cs[k1][0], s1 = cs[k1][1];
+        const int p1 = pq[k1][0], q1 = pq[k1][1];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int k = wave * 8 + i;
-        const float c = cs[k][0], s = cs[k][1];
-        if (s != 0.f) {
-          const int p = pq[k][0], q = pq[k][1];
-          const float sp = S[p][lane], sq = S[q][lane];
-          float np_ = c * sp - s * sq;
-          float nq_ = s * sp + c * sq;
-          if (lane == q) np_ = 0.f;
-          if (lane == p) nq_ = 0.f;
-          S[p][lane] = np_;
-          S[q][lane] = nq_;
+        for (int j = 0; j < 4; ++j) {
+          const int k2 = (tid & 7) + 8 * j;
+          const float c2 = cs[k2][0], s2 = cs[k2][1];
+          if (s1 != 0.f || s2 != 0.f) {
+            const int p2 = pq[k2][0], q2 = pq[k2][1];
+            const float b00 = S[p1][p2], b01 = S[p1][q2], b10 = S[q1][p2], b11 = S[q1][q2];
+            const float t00 = c1 * b00 - s1 * b10, t01 = c1 * b01 - s1 * b11;
+            const float t10 = s1 * b00 + c1 * b10, t11 = s1 * b01 + c1 * b11;
+            float n00 = c2 * t00 - s2 * t01, n01 = s2 * t00 + c2 * t01;
+            float n10 = c2 * t10 - s2 * t11, n11 = s2 * t10 + c2 * t11;
+            if (k1 == k2) {  // the annihilated element is exactly zero
+              n01 = 0.f;
+              n10 = 0.f;
+            }
+            S[p1][p2] = n00;
+            S[p1][q2] = n01;
+            S[q1][p2] = n10;
+            S[q1][q2] = n11;
+          }
+        }
+        // (b2) R <- R J (columns), lane = row
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int k = wave * 8 + i;
+          const float c = cs[k][0], s = cs[k][1];
+          if (s != 0.f) {  // wave-uniform
+            const int p = pq[k][0], q = pq[k][1];
+            const float rp = R[lane][p], rq = R[lane][q];
+            R[lane][p] = c * rp - s * rq;
+            R[lane][q] = s * rp + c * rq;
+          }
         }
       }
-      // the barrier at the top of the next step orders (c) against the next (a)
+      __syncthreads();
     }
+    const int r = sweep_rot;  // stable: written only in phase (a), last one is behind the barrier above
     __syncthreads();
-    const int r = sweep_rot;
-    __syncthreads();
+    if (tid == 0) sweep_rot = 0;
     total_rot += r;
     if (r == 0) break;
   }
@@ -175,7 +193,8 @@ __global__ __launch_bounds__(256) void eig_pivot_kernel(float* __restrict__ Aw, 
   // outputs: R_P (row-major 64x64) and the pivot's diagonal
   float* Rout = Rws + (int64_t)blockIdx.x * EP * EP;
   for (int idx = tid; idx < EP * EP; idx += 256) Rout[idx] = R[idx >> 6][idx & 63];
-  if (tid < EP) Dws[(int64_t)blockIdx.x * EP + tid] = S[tid][tid];
+  float* Sout = Dws + (int64_t)blockIdx.x * EP * EP;  // the (nearly) diagonalised pivot itself
+  for (int idx = tid; idx < EP * EP; idx += 256) Sout[idx] = S[idx >> 6][idx & 63];
   if (tid == 0 && total_rot > 0) atomicAdd(&ctrl->rotations, total_rot);
 }
 
@@ -236,11 +255,11 @@ __global__ __launch_bounds__(256) void eig_update_kernel(float* __restrict__ Aw,
   pivot_blocks(step, P, nb, IP, JP);
   pivot_blocks(step, Q, nb, IQ, JQ);
 
-  if (P == Q) {  // the pivot itself becomes exactly diagonal
+  if (P == Q) {  // the pivot itself: written back from the LDS solve (upper triangle mirrored)
+    const float* Sp = Dws + (int64_t)P * EP * EP;
     for (int idx = tid; idx < EP * EP; idx += 256) {
       const int r = idx >> 6, c = idx & 63;
-      Aw[(int64_t)pivot_index(r, IP, JP) * np + pivot_index(c, IP, JP)] =
-          (r == c) ? Dws[(int64_t)P * EP + r] : 0.f;
+      Aw[(int64_t)pivot_index(r, IP, JP) * np + pivot_index(c, IP, JP)] = (r <= c) ? Sp[r * EP + c] : Sp[c * EP + r];
     }
     return;
   }
@@ -304,15 +323,6 @@ __global__ void eig_sweep_end_kernel(EigCtrl* ctrl) {
 }
 
 // ---- finalize: rank-sort ascending, clamp, gather eigenvector columns ----------------------------------
-__global__ __launch_bounds__(256) void eig_diag_kernel(const float* __restrict__ Aw, int n, int np,
-                                                       float* __restrict__ d) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) {
-    float l = Aw[(int64_t)i * np + i];
-    d[i] = (l == l) ? l : 0.f;
-  }
-}
-
 __global__ __launch_bounds__(256) void eig_rank_kernel(const float* __restrict__ d, int n, int* __restrict__ perm) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
@@ -337,6 +347,7 @@ __global__ __launch_bounds__(256) void eig_gather_kernel(const float* __restrict
     Q[idx] = v;
     if (r == 0) {
       float l = d[perm[k]];
+      if (!(l == l)) l = 0.f;
       if (clamp && l < 0.f) l = 0.f;
       w[k] = l;
     }
@@ -344,9 +355,69 @@ __global__ __launch_bounds__(256) void eig_gather_kernel(const float* __restrict
   if (blockIdx.x == 0 && threadIdx.x == 0 && info != nullptr) info[0] = ctrl->converged ? 0 : 1;
 }
 
+// ---- refinement GEMMs:  C = alpha * op(A) * B + beta * D   (all np x np, np % 64 == 0) ----------------
+template <bool TA>
+__global__ __launch_bounds__(256) void eig_gemm_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                       const float* __restrict__ D, float* __restrict__ C, int np,
+                                                       float alpha, float beta) {
+  __shared__ float sA[TA ? 16 : 64][TA ? 65 : 17];
+  __shared__ float sB[16][65];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lo = lane & 31, hi = lane >> 5, wm = wave >> 1, wn = wave & 1;
+  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int k0 = 0; k0 < np; k0 += 16) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = tid + 256 * e;
+      if (TA) {
+        const int kk = idx >> 6, ii = idx & 63;
+        sA[kk][ii] = A[(int64_t)(k0 + kk) * np + i0 + ii];
+      } else {
+        const int ii = idx >> 4, kk = idx & 15;
+        sA[ii][kk] = A[(int64_t)(i0 + ii) * np + k0 + kk];
+      }
+      const int kb = idx >> 6, jj = idx & 63;
+      sB[kb][jj] = B[(int64_t)(k0 + kb) * np + j0 + jj];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const int k = 2 * kk + hi;
+      const float a = TA ? sA[k][wm * 32 + lo] : sA[wm * 32 + lo][k];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, sB[k][wn * 32 + lo], acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = i0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi, col = j0 + wn * 32 + lo;
+    float v = alpha * acc[r];
+    if (D != nullptr) v += beta * D[(int64_t)row * np + col];
+    C[(int64_t)row * np + col] = v;
+  }
+}
+
+// d[i] = sum_r V[r][i] * T[r][i]   (Rayleigh quotients v_i^T A v_i)
+__global__ __launch_bounds__(256) void eig_coldot_kernel(const float* __restrict__ V, const float* __restrict__ T,
+                                                         int np, float* __restrict__ d) {
+  __shared__ float red[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  float s = 0.f;
+  for (int r = part; r < np; r += 4) s += V[(int64_t)r * np + col] * T[(int64_t)r * np + col];
+  red[part][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (part == 0) {
+    const int c = threadIdx.x & 63;
+    d[col] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+  }
+}
+
 struct EigPlan {
   int np, nb, npv;
-  size_t off_A, off_V, off_R, off_D, off_perm, off_diag, off_ctrl, total;
+  size_t off_A, off_V, off_A0, off_T, off_R, off_D, off_perm, off_diag, off_ctrl, total;
 };
 
 static EigPlan eig_plan(int64_t n) {
@@ -358,8 +429,10 @@ static EigPlan eig_plan(int64_t n) {
   size_t off = 0;
   p.off_A = off; off += align_up((size_t)p.np * p.np * 4, 256);
   p.off_V = off; off += align_up((size_t)p.np * p.np * 4, 256);
+  p.off_A0 = off; off += align_up((size_t)p.np * p.np * 4, 256);
+  p.off_T = off; off += align_up((size_t)p.np * p.np * 4, 256);
   p.off_R = off; off += align_up((size_t)p.npv * EP * EP * 4, 256);
-  p.off_D = off; off += align_up((size_t)p.npv * EP * 4, 256);
+  p.off_D = off; off += align_up((size_t)p.npv * EP * EP * 4, 256);
   p.off_perm = off; off += align_up((size_t)p.np * 4, 256);
   p.off_diag = off; off += align_up((size_t)p.np * 4, 256);
   p.off_ctrl = off; off += 256;
@@ -389,12 +462,15 @@ extern "C" int lk_syevj_f32(const float* A, int64_t n, float* w, float* Q, int c
   char* base = static_cast<char*>(ws);
   float* Aw = reinterpret_cast<float*>(base + p.off_A);
   float* V = reinterpret_cast<float*>(base + p.off_V);
+  float* A0 = reinterpret_cast<float*>(base + p.off_A0);
+  float* T = reinterpret_cast<float*>(base + p.off_T);
   float* Rws = reinterpret_cast<float*>(base + p.off_R);
   float* Dws = reinterpret_cast<float*>(base + p.off_D);
   int* perm = reinterpret_cast<int*>(base + p.off_perm);
   float* dvec = reinterpret_cast<float*>(base + p.off_diag);
   EigCtrl* ctrl = reinterpret_cast<EigCtrl*>(base + p.off_ctrl);
   if (max_sweeps <= 0) max_sweeps = 14;
+  const int kMaxInner = 3;         // inner sweeps per pivot visit (the outer sweeps finish the job)
   const float tol_rel = 3.0e-7f;   // ~2.5 eps: |a_pq| <= tol_rel*sqrt(|a_pp a_qq|) counts as annihilated
   const float tol_abs = 6.0e-8f;   // x max|a_ii|: absolute floor for (numerically) rank-deficient factors
 
@@ -404,24 +480,33 @@ extern "C" int lk_syevj_f32(const float* A, int64_t n, float* w, float* Q, int c
   }
   int64_t blocks = ((int64_t)p.np * p.np + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(eig_init_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, A, (int)n, p.np, Aw, V, ctrl);
+  hipLaunchKernelGGL(eig_init_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, A, (int)n, p.np, Aw, A0, V, ctrl);
   const int steps = p.nb - 1;
   const int ntiles = p.npv * (p.npv + 1) / 2;
   for (int sweep = 0; sweep < max_sweeps; ++sweep) {
     for (int s = 0; s < steps; ++s) {
       hipLaunchKernelGGL(eig_pivot_kernel, dim3(p.npv), dim3(256), 0, stream, Aw, p.np, p.nb, s, Rws, Dws, ctrl,
-                         tol_rel, tol_abs, 12);
+                         tol_rel, tol_abs, kMaxInner);
       hipLaunchKernelGGL(eig_update_kernel, dim3(ntiles), dim3(256), 0, stream, Aw, p.np, p.nb, s, Rws, Dws, ctrl);
       hipLaunchKernelGGL(eig_vupdate_kernel, dim3(p.npv, p.np / EP), dim3(256), 0, stream, V, p.np, p.nb, s, Rws,
                          ctrl);
     }
     hipLaunchKernelGGL(eig_sweep_end_kernel, dim3(1), dim3(1), 0, stream, ctrl);
   }
-  hipLaunchKernelGGL(eig_diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, Aw, (int)n, p.np, dvec);
+  // refinement: one Newton-Schulz step re-orthonormalises V (thousands of fp32 rotations leave
+  // ||V^T V - I|| ~ 1e-5), then the eigenvalues are recomputed as Rayleigh quotients against the ORIGINAL
+  // matrix, which removes the accumulated transformation error from the spectrum.
+  {
+    dim3 gg(p.np / 64, p.np / 64);
+    hipLaunchKernelGGL((eig_gemm_kernel<true>), gg, dim3(256), 0, stream, V, V, (const float*)nullptr, T, p.np, 1.f, 0.f);
+    hipLaunchKernelGGL((eig_gemm_kernel<false>), gg, dim3(256), 0, stream, V, T, V, Aw, p.np, -0.5f, 1.5f);  // Aw <- V2
+    hipLaunchKernelGGL((eig_gemm_kernel<false>), gg, dim3(256), 0, stream, A0, Aw, (const float*)nullptr, T, p.np, 1.f, 0.f);
+    hipLaunchKernelGGL(eig_coldot_kernel, dim3(p.np / 64), dim3(256), 0, stream, Aw, T, p.np, dvec);
+  }
   hipLaunchKernelGGL(eig_rank_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dvec, (int)n, perm);
   int64_t gblocks = (n * n + 255) / 256;
   if (gblocks > 4096) gblocks = 4096;
-  hipLaunchKernelGGL(eig_gather_kernel, dim3((unsigned)gblocks), dim3(256), 0, stream, dvec, V, perm, (int)n, p.np,
+  hipLaunchKernelGGL(eig_gather_kernel, dim3((unsigned)gblocks), dim3(256), 0, stream, dvec, Aw, perm, (int)n, p.np,
                      clamp, w, Q, ctrl, info);
   return check_launch("lk_syevj_f32");
 }

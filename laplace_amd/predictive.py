@@ -1,0 +1,122 @@
+"""Structure-exploiting GLM predictive variance ``f_var[n] = J_n Sigma J_n^T``.
+
+The reference materialises ``Js[B, C, P]`` (laplace/baselaplace.py:1306-1342) and contracts it with
+the posterior (Kron: laplace/utils/matrix.py:406-461; diag: baselaplace.py:2113-2115; full:
+:1683-1684).  Here the per-layer factors of the Jacobian — layer inputs ``a`` and output gradients
+``g`` from one batched reverse pass — go straight into HIP kernels:
+
+* nn.Linear, Kron posterior:  ``J_nc (Q1 (x) Q2) = (Q1^T g_nc) (x) (Q2^T a_n)``, so
+  ``f_var[n,c,k] = sum_o u_nco u_nko * sum_i v_ni^2 / (l1_o l2_i + delta)`` — two small GEMMs
+  (plumbing) + ``lk_kron_quadform_linear_f32``.
+* nn.Linear, diagonal posterior: ``lk_diag_quadform_linear_f32``.
+* dense last-layer posterior: ``lk_dense_quadform_ll_f32`` (``J = I (x) [phi, 1]``).
+* nn.Conv2d: the layer's Jacobian block is assembled by ``lk_jac_conv_f32`` (only that block,
+  never the full ``[B, C, P]``) and contracted with the block's posterior.
+"""
+from __future__ import annotations
+
+import torch
+
+from laplace_amd._lib import get_kernels
+
+
+def _identity_seeds(f: torch.Tensor) -> torch.Tensor:
+    B, C = f.shape
+    eye = torch.eye(C, dtype=f.dtype, device=f.device)
+    return eye[:, None, :].expand(C, B, C).contiguous()
+
+
+def _conv_block_jacobian(tap, g, B, C):
+    K = get_kernels()
+    m = tap.module
+    width = m.weight.numel()
+    nb = m.out_channels if tap.has_bias else 0
+    Jl = torch.zeros(B, C, width + nb, dtype=torch.float32, device=g.device)
+    K.jac_conv(tap.a.to(torch.float32).contiguous(), g.contiguous(), m.kernel_size, m.stride, m.padding, m.dilation,
+               Jl, 0, width if tap.has_bias else -1)
+    return Jl, width
+
+
+def glm_variance_kron(backend, x, post):
+    """``(f_mu, f_var)`` under a :class:`HipKronDecomposed` posterior precision ``post``
+    (= ``H * H_factor + prior_precision``), i.e. KronLaplace.functional_variance."""
+    K = get_kernels()
+    f, tape, grad_fn = backend._forward(x)
+    if tape.uncovered or post.damping:
+        raise NotImplementedError("fused Kron predictive needs Linear/Conv2d-only models and damping=False")
+    B, C = f.shape
+    grads = grad_fn(_identity_seeds(f))
+    fvar = torch.zeros(B, C, C, dtype=torch.float32, device=f.device)
+    blk = 0
+    for tap, g in zip(tape.taps, grads):
+        (Q1, Q2), (l1, l2), delta = post.eigenvectors[blk], post.eigenvalues[blk], post.deltas[blk]
+        blk += 1
+        Qb = lb = delta_b = None
+        if tap.has_bias:
+            Qb, lb, delta_b = post.eigenvectors[blk][0], post.eigenvalues[blk][0], post.deltas[blk]
+            blk += 1
+        d1 = delta.detach().reshape(1).contiguous()
+        if tap.kind == "linear" and tap.a.ndim == 2:
+            a = tap.a.to(torch.float32)
+            Do = g.shape[-1]
+            g2 = g.reshape(C * B, Do)
+            u = (g2 @ Q1).reshape(C, B, Do).contiguous()
+            v = (a @ Q2).contiguous()
+            ub = (g2 @ Qb).reshape(C, B, Do).contiguous() if Qb is not None else None
+            K.kron_quadform_linear(u, v, l1.contiguous(), l2.contiguous(), d1, fvar, ub,
+                                   None if lb is None else lb.contiguous(),
+                                   None if delta_b is None else delta_b.detach().reshape(1).contiguous())
+        elif tap.kind == "conv2d":
+            Jl, width = _conv_block_jacobian(tap, g, B, C)
+            Do, Dk = len(l1), len(l2)
+            W = Jl[:, :, :width].reshape(B * C, Do, Dk)
+            M = Q1.T @ W @ Q2
+            fvar += torch.einsum("ncoi,nkoi,oi->nck", M.reshape(B, C, Do, Dk), M.reshape(B, C, Do, Dk),
+                                 1.0 / (torch.outer(l1, l2) + delta))
+            if Qb is not None:
+                ub = Jl[:, :, width:] @ Qb
+                fvar += torch.einsum("nco,nko,o->nck", ub, ub, 1.0 / (lb + delta_b))
+        else:
+            raise NotImplementedError(f"{tap.name}: Kron predictive for Linear layers with weight sharing")
+    tape.release()
+    return f, fvar
+
+
+def glm_variance_diag(backend, x, post_var: torch.Tensor):
+    """``(f_mu, f_var)`` under a diagonal posterior with variances ``post_var[P]``."""
+    K = get_kernels()
+    f, tape, grad_fn = backend._forward(x)
+    if tape.uncovered:
+        raise NotImplementedError("fused diagonal predictive needs Linear/Conv2d-only models")
+    B, C = f.shape
+    grads = grad_fn(_identity_seeds(f))
+    post_var = post_var.detach().to(torch.float32).contiguous()
+    fvar = torch.zeros(B, C, C, dtype=torch.float32, device=f.device)
+    for tap, g in zip(tape.taps, grads):
+        m = tap.module
+        n_w = m.weight.numel()
+        vw = post_var[tap.w_off:tap.w_off + n_w]
+        if tap.kind == "linear" and tap.a.ndim == 2:
+            vb = post_var[tap.b_off:tap.b_off + m.out_features] if tap.has_bias else None
+            K.diag_quadform_linear(tap.a.to(torch.float32).contiguous(), g.contiguous(), vw, vb, fvar)
+        elif tap.kind == "conv2d":
+            Jl, width = _conv_block_jacobian(tap, g, B, C)
+            var = torch.cat([vw, post_var[tap.b_off:tap.b_off + m.out_channels]]) if tap.has_bias else vw
+            fvar += K.diag_quadform_js(Jl, var.contiguous())
+        else:
+            raise NotImplementedError(f"{tap.name}: diagonal predictive for Linear layers with weight sharing")
+    tape.release()
+    return f, fvar
+
+
+def glm_variance_full_last_layer(backend, x, Sigma: torch.Tensor):
+    """``(f_mu, f_var)`` for a last-layer Laplace with dense posterior covariance ``Sigma[P, P]``."""
+    K = get_kernels()
+    if not backend.last_layer:
+        raise NotImplementedError("dense fused predictive is implemented for last-layer Laplace")
+    f, tape, _ = backend._forward(x)
+    tap = tape.taps[0]
+    phi = tap.a.to(torch.float32).contiguous()
+    fvar = K.dense_quadform_ll(phi, Sigma.detach().to(torch.float32).contiguous(), f.shape[1], tap.has_bias)
+    tape.release()
+    return f, fvar

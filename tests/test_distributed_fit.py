@@ -1,0 +1,77 @@
+"""Data-parallel fit (one process per GPU in production; here world_size-2 `gloo` on CPU with the
+kernel emulation): minibatches sharded by rank + one all-reduce == single-process fit."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from torch.utils.data import DataLoader, TensorDataset
+
+from tests.conftest import golden_model, load_golden
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, hs, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from laplace_amd import _lib
+        from laplace_amd.laplace import HipLaplace, ShardedLoader
+        from tests.emulated_kernels import EmulatedKernels
+
+        _lib.set_kernels_for_testing(EmulatedKernels())
+        g = load_golden("resnetish", "classification")
+        model, X, y = golden_model("resnetish", g, dtype=torch.float32)
+        loader = ShardedLoader(DataLoader(TensorDataset(X, y), batch_size=2), rank, world)
+        la = HipLaplace(model, "classification", "all", hs, prior_precision=0.7)
+        la.fit(loader)
+        if rank == 0:
+            payload = {"loss": la.loss, "n_data": la.n_data}
+            if hs == "kron":
+                payload["H"] = [[Hi.clone() for Hi in F] for F in la.H_facs.kfacs]
+                payload["marglik"] = la.log_marginal_likelihood()
+            else:
+                payload["H"] = la.H.clone()
+            torch.save(payload, out_path)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("hs", ["kron", "diag", "full"])
+def test_sharded_fit_equals_single_process(tmp_path, hs):
+    from laplace_amd import _lib
+    from laplace_amd.laplace import HipLaplace
+    from tests.emulated_kernels import EmulatedKernels
+
+    out = str(tmp_path / "rank0.pt")
+    mp.spawn(_worker, args=(2, _free_port(), hs, out), nprocs=2, join=True)
+    got = torch.load(out, weights_only=False)
+
+    prev = _lib.set_kernels_for_testing(EmulatedKernels())
+    try:
+        g = load_golden("resnetish", "classification")
+        model, X, y = golden_model("resnetish", g, dtype=torch.float32)
+        la = HipLaplace(model, "classification", "all", hs, prior_precision=0.7)
+        la.fit(DataLoader(TensorDataset(X, y), batch_size=2), distributed=False)
+        ref_marglik = la.log_marginal_likelihood() if hs == "kron" else None
+    finally:
+        _lib.set_kernels_for_testing(prev)
+    assert got["n_data"] == la.n_data == 10
+    torch.testing.assert_close(got["loss"], la.loss, rtol=1e-5, atol=1e-6)
+    if hs == "kron":
+        for F_, G_ in zip(got["H"], la.H_facs.kfacs):
+            for a, b in zip(F_, G_):
+                torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(got["marglik"], ref_marglik, rtol=1e-5, atol=1e-5)
+    else:
+        torch.testing.assert_close(got["H"], la.H, rtol=1e-5, atol=1e-6)

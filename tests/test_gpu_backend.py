@@ -1,0 +1,207 @@
+"""End-to-end parity of the HIP backend (through the C ABI) against the golden outputs of the
+unmodified reference (tests/golden/*.npz) and the KFAC relations R1-R10, on the MI355X (-m gpu).
+
+Tolerance 1e-4 relative (BASELINE.json north_star), asserted on the quantities the reference's own
+tests assert on: factors, ``G (x) A``-level products (diag, logdet, inv_square_form), variances.
+"""
+import copy
+import os
+
+import pytest
+import torch
+from torch.utils.data import DataLoader, TensorDataset
+
+from oracle.fixtures import FIXTURES
+from oracle.make_golden import DELTA, H_FACTOR
+from tests.conftest import golden_kfacs, golden_model, load_golden
+
+pytestmark = pytest.mark.gpu
+# LK_TEST_DEVICE=cpu: self-check of this file's host logic on the kernel emulation (GPU-less box)
+DEV = os.environ.get("LK_TEST_DEVICE", "cuda")
+
+
+@pytest.fixture(autouse=True, scope="module")
+def _kernels():
+    if DEV != "cpu":
+        yield
+        return
+    from laplace_amd import _lib
+    from tests.emulated_kernels import EmulatedKernels
+
+    prev = _lib.set_kernels_for_testing(EmulatedKernels())
+    yield
+    _lib.set_kernels_for_testing(prev)
+
+LIKS = ("classification", "regression")
+CASES = [(n, l) for n in FIXTURES for l in LIKS]
+
+
+def rel(got, want):
+    got = got.detach().double().cpu()
+    want = torch.as_tensor(want).detach().double().cpu()
+    return (got - want).abs().max().item() / (want.abs().max().item() + 1e-30)
+
+
+def check(got, want, tol=1e-4, what=""):
+    e = rel(got, want)
+    assert e < tol, f"{what}: rel err {e:.3e}"
+
+
+def setup(name, lik):
+    g = load_golden(name, lik)
+    model, X, y = golden_model(name, g, dtype=torch.float32, device=DEV)
+    return g, model, X, y
+
+
+@pytest.mark.parametrize("name,lik", CASES)
+def test_ggn_against_reference_golden(name, lik):
+    from laplace_amd import HipGGN
+
+    g, model, X, y = setup(name, lik)
+    b = HipGGN(model, lik)
+    Js, f = b.jacobians(X)
+    check(Js, g["Js"], what="jacobians")
+    check(f, g["f"], what="f")
+    loss, H = b.full(X, y)
+    check(H, g["H_ggn"], what="full GGN")
+    check(loss, g["loss"], what="loss")
+    loss, h = b.diag(X, y)
+    check(h, g["h_ggn"], what="diag GGN")
+    check(loss, g["loss"], what="loss")
+    # diag split over two half batches == diag of the full GGN (tests/test_curv_backends_interface.py:104-121)
+    h2 = b.diag(X[:5], y[:5])[1] + b.diag(X[5:], y[5:])[1]
+    check(h2, g["h_ggn"], what="diag additivity")
+
+
+@pytest.mark.parametrize("name,lik", CASES)
+def test_ef_against_reference_golden(name, lik):
+    from laplace_amd import HipEF
+
+    g, model, X, y = setup(name, lik)
+    b = HipEF(model, lik)
+    loss, H = b.full(X, y)
+    check(H, g["H_ef"], what="full EF")
+    check(loss, g["loss_ef"], what="EF loss")
+    check(b.diag(X, y)[1], g["h_ef"], what="diag EF")
+
+
+@pytest.mark.parametrize("name,lik", CASES)
+def test_kfac_factors_and_kron_algebra(name, lik):
+    from laplace_amd import HipGGN
+
+    g, model, X, y = setup(name, lik)
+    b = HipGGN(model, lik)
+    loss, kron = b.kron(X, y, N=X.shape[0])
+    check(loss, g["loss_kfac"], what="loss")
+    for i, (F_, G_) in enumerate(zip(kron.kfacs, golden_kfacs(g, "kfac"))):
+        assert len(F_) == len(G_)
+        for j, (a, w) in enumerate(zip(F_, G_)):
+            check(a, w, what=f"kfac[{i}][{j}]")
+    check(kron.diag(), g["kron_diag"], what="kron.diag")
+    dec = kron.decompose()
+    dec.check_converged()
+    for i, ls in enumerate(dec.eigenvalues):
+        for j, l in enumerate(ls):
+            check(l, g[f"eigvals.{i}.{j}"], tol=2e-5, what=f"eigvals[{i}][{j}]")
+    post = dec * H_FACTOR + torch.tensor(DELTA, device=DEV)
+    check(post.logdet(), g["kd_logdet"], what="logdet")
+    W = torch.as_tensor(g["W"], dtype=torch.float32, device=DEV)
+    for tag, e in (("p1", 1.0), ("m1", -1.0), ("mh", -0.5)):
+        check(post.bmm(W, exponent=e), g[f"kd_bmm_{tag}"], what=f"bmm {e}")
+        check(post.diag(exponent=e), g[f"kd_diag_{tag}"], what=f"diag {e}")
+    Js = torch.as_tensor(g["Js"], dtype=torch.float32, device=DEV)
+    check(post.inv_square_form(Js), g["kd_isf"], what="inv_square_form")
+    pl = torch.as_tensor(g["per_layer_delta"], dtype=torch.float32, device=DEV)
+    post_l = dec * H_FACTOR + pl
+    check(post_l.logdet(), g["kd_logdet_layer"], what="logdet per-layer delta")
+    check(post_l.inv_square_form(Js), g["kd_isf_layer"], what="isf per-layer delta")
+
+
+@pytest.mark.parametrize("lik", LIKS)
+def test_logdet_is_differentiable(lik):
+    """marglik optimisation needs d logdet / d prior precision (baselaplace.py:466-485)."""
+    from laplace_amd import HipGGN
+
+    g, model, X, y = setup("mlp", lik)
+    dec = HipGGN(model, lik).kron(X, y, N=10)[1].decompose()
+    log_prec = torch.zeros(1, device=DEV, requires_grad=True)
+    h = 1.3  # (the reference's KronDecomposed.__mul__ uses math.pow: H_factor is not differentiated)
+    val = (dec * h + log_prec.exp()).logdet()
+    val.backward()
+    # finite differences in float64 on the CPU from the same eigenvalues
+    ev = [[l.double().cpu() for l in ls] for ls in dec.eigenvalues]
+
+    def f64(lp, hh):
+        tot = 0.0
+        for ls in ev:
+            lam = ls[0] * hh + lp.exp() if len(ls) == 1 else torch.outer(ls[0], ls[1]) * hh + lp.exp()
+            tot = tot + torch.log(lam).sum()
+        return tot
+
+    lp64 = torch.zeros(1, dtype=torch.float64, requires_grad=True)
+    h64 = 1.3
+    f64(lp64, h64).backward()
+    check(val, f64(lp64, h64), what="logdet")
+    check(log_prec.grad, lp64.grad, what="d/d log prior")
+
+
+@pytest.mark.parametrize("name,lik", CASES)
+def test_last_layer_modes(name, lik):
+    """last_layer=True (laplace/lllaplace.py:159): dense GGN, diag and KFAC of the head, accumulated
+    over two minibatches like ParametricLaplace.fit (baselaplace.py:969-985)."""
+    from laplace_amd import HipGGN
+    from laplace_amd.mirror import FeatureExtractor
+
+    g, model, X, y = setup(name, lik)
+    fe = FeatureExtractor(copy.deepcopy(model)).to(DEV)
+    b = HipGGN(fe, lik, last_layer=True)
+    N = X.shape[0]
+    H = sum(b.full(X[s], y[s])[1] for s in (slice(0, 5), slice(5, 10)))
+    check(H, g["la.last_layer.full.H"], what="LL full")
+    h = sum(b.diag(X[s], y[s])[1] for s in (slice(0, 5), slice(5, 10)))
+    check(h, g["la.last_layer.diag.H"], what="LL diag")
+    k1 = b.kron(X[:5], y[:5], N=N)[1]
+    k2 = b.kron(X[5:], y[5:], N=N)[1]
+    k1 += k2
+    for F_, G_ in zip(k1.kfacs, golden_kfacs(g, "la.last_layer.kron.H")):
+        for a, w in zip(F_, G_):
+            check(a, w, what="LL kron factors")
+    loss = b.full(X, y)[0]
+    check(loss, g["la.last_layer.full.loss"], what="LL loss")
+
+
+# ---- KFAC relations on the HIP path -------------------------------------------------
+@pytest.mark.parametrize("lik", LIKS)
+def test_R1_R2_R3(lik):
+    from laplace_amd import HipGGN
+
+    g, model, X, y = setup("mlp", lik)
+    b = HipGGN(model, lik)
+    l1, k1 = b.kron(X[:1], y[:1], N=1)
+    check(k1.diag(), b.diag(X[:1], y[:1])[1], tol=1e-5, what="R1 single datum")
+    X7, y7 = X[:1].repeat(7, 1), y[:1].repeat(7, *([1] * (y.ndim - 1)))
+    l7, k7 = b.kron(X7, y7, N=7)
+    check(k7.diag(), b.diag(X7, y7)[1], tol=1e-5, what="R2")
+    check(7 * k1.diag(), k7.diag(), tol=1e-5, what="R3")
+    check(7 * l1, l7, tol=1e-5, what="R3 loss")
+
+
+@pytest.mark.parametrize("name", ["mlp", "conv", "resnetish"])
+def test_R4_additivity_and_R7(name):
+    from laplace_amd import HipGGN
+
+    g, model, X, y = setup(name, "classification")
+    b = HipGGN(model, "classification")
+    N = X.shape[0]
+    lf, kf = b.kron(X, y, N=N)
+    la, ka = b.kron(X[:3], y[:3], N=N)
+    lb, kb = b.kron(X[3:], y[3:], N=N)
+    ks = ka + kb
+    for F_, G_ in zip(ks.kfacs, kf.kfacs):
+        for a, w in zip(F_, G_):
+            check(a, w, tol=1e-5, what="R4")
+    check(la + lb, lf, tol=1e-5, what="R4 loss")
+    if name != "mlp":
+        lr, kr = b.kron(X, y, N=N, kfac_approx="reduce")
+        check(lr, lf, tol=1e-6, what="R7 loss")
+        assert not torch.allclose(kr.diag(), kf.diag())
