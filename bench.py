@@ -1,0 +1,243 @@
+"""bench.py — KFAC-GGN fit throughput of the MI355X-native curvature backend (BASELINE.json metric).
+
+Workload (config c4, per GPU): ResNet-18 (CIFAR stem, BN affine frozen, random init), full-network
+KFAC exact GGN, minibatch 128 of synthetic N(0,1) 3x32x32 images, 10 classes.  A "step" is one
+minibatch through the hot path: forward + ONE batched reverse pass (stock PyTorch-ROCm), then our
+HIP kernels for the likelihood root, every A/G factor (exact-fp32 MFMA Gram engine) and the
+accumulation.  N > 1: one process per GPU, each rank its own K minibatches (weak scaling), one RCCL
+all-reduce of the accumulated factors inside the timed region (the fit's epoch end).
+
+Usage:  python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run)
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+BATCH = 128
+CLASSES = 10
+N_DATASET = 50_000  # the global N every rank passes to kron() (A factors carry 1/N)
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-predictive", action="store_true")
+    ap.add_argument("--no-eigh", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bound of the CPU-baseline leg")
+    return ap.parse_args()
+
+
+def make_batches(steps, dev, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    X = torch.randn(BATCH, 3, 32, 32, generator=g)
+    y = torch.randint(CLASSES, (BATCH,), generator=g)
+    # inputs resident in HBM before the timed region; a couple of distinct batches are cycled
+    xs = [(X.roll(i, 0).to(dev), y.roll(i, 0).to(dev)) for i in range(min(steps, 4))]
+    return xs
+
+
+def fit_steps(backend, H, batches, n_steps):
+    loss = torch.zeros((), device=batches[0][0].device)
+    for i in range(n_steps):
+        X, y = batches[i % len(batches)]
+        lb, Hb = backend.kron(X, y, N=N_DATASET)
+        loss = loss + lb
+        H += Hb
+    return loss
+
+
+def cpu_baseline(seconds: float):
+    """The oracle's KFAC restatement (curvlinops 2.0.0 semantics through
+    laplace/curvature/curvlinops.py:77-108), fp32, on this host's cores — a reported baseline only."""
+    from laplace_amd.nets import ResNet18
+    from oracle import curvature_oracle as co
+
+    torch.manual_seed(711)
+    model = ResNet18(CLASSES).eval()
+    g = torch.Generator().manual_seed(1)
+    bs = 32
+    X = torch.randn(bs, 3, 32, 32, generator=g)
+    y = torch.randint(CLASSES, (bs,), generator=g)
+    co.kfac_ggn(model, X[:4], y[:4], N_DATASET, "classification")  # warm-up
+    done, t0 = 0, time.time()
+    while done < 2 * bs or time.time() - t0 < seconds:
+        co.kfac_ggn(model, X, y, N_DATASET, "classification")
+        done += bs
+    dt = time.time() - t0
+    return {"value": done / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{done} synthetic images (batch {bs}) through oracle.kfac_ggn, ResNet-18, fp32, {dt:.1f} s"}
+
+
+def predictive_leg(dev):
+    """Config c3: ResNet-18 last-layer dense GGN fit + GLM predictive variance (batch 512)."""
+    from laplace_amd.laplace import HipLaplace
+    from laplace_amd.nets import ResNet18
+
+    torch.manual_seed(711)
+    model = ResNet18(CLASSES).to(dev).eval()
+    la = HipLaplace(model, "classification", "last_layer", "full", last_layer_name="fc")
+    g = torch.Generator().manual_seed(3)
+    X = torch.randn(512, 3, 32, 32, generator=g).to(dev)
+    y = torch.randint(CLASSES, (512,), generator=g).to(dev)
+
+    class _DS:
+        def __len__(self):
+            return N_DATASET
+
+    class _Loader:
+        dataset = _DS()
+
+        def __init__(self, n):
+            self.n = n
+
+        def __iter__(self):
+            return iter([(X, y)] * self.n)
+
+    la.fit(_Loader(2), distributed=False)  # warm-up
+    torch.cuda.synchronize()
+    t0 = time.time()
+    la.fit(_Loader(8), distributed=False)
+    torch.cuda.synchronize()
+    fit_rate = 8 * 512 / (time.time() - t0)
+    la._glm_predictive_distribution(X)  # warm-up incl. the one-off P^3 factorisation
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(10):
+        f_mu, f_var = la._glm_predictive_distribution(X)
+    torch.cuda.synchronize()
+    return {"workload": "ResNet-18 last-layer (P=5130) dense GGN + GLM predictive, batch 512",
+            "fit_samples_per_s": fit_rate, "predictive_samples_per_s": 10 * 512 / (time.time() - t0)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a ROCm device"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from laplace_amd import HipGGN, HipKron
+    from laplace_amd._lib import get_kernels
+    from laplace_amd.laplace import allreduce_curvature
+    from laplace_amd.nets import ResNet18
+
+    torch.manual_seed(711)
+    model = ResNet18(CLASSES).to(dev).eval()
+    backend = HipGGN(model, "classification")
+    batches = make_batches(args.steps, dev, seed=100 + rank)
+    K = get_kernels()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warm-up ------------------------------------------------------------------------------------
+    H = HipKron.init_from_model(backend.params, dev, torch.float32)
+    fit_steps(backend, H, batches, args.warmup)
+    if world > 1:
+        allreduce_curvature([Hi for F in H.kfacs for Hi in F])
+    barrier()
+
+    # ---- timed region: exactly K steps (+ the fit's single all-reduce) ------------------------------------
+    H = HipKron.init_from_model(backend.params, dev, torch.float32)
+    K.profile = {} if rank == 0 else None
+    barrier()
+    t0 = time.perf_counter()
+    loss = fit_steps(backend, H, batches, args.steps)
+    if world > 1:
+        lt = loss.reshape(1).clone()
+        allreduce_curvature([Hi for F in H.kfacs for Hi in F] + [lt])
+    barrier()
+    dt = time.perf_counter() - t0
+    prof, K.profile = K.profile, None
+    if world > 1:
+        t = torch.tensor([dt], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    result = None
+    if rank == 0:
+        samples = world * BATCH * args.steps
+        # roofline of the dominant kernel family: the implicit-im2col MFMA Gram kernel (A factors)
+        def agg(name):
+            evs = prof.get(name, [])
+            ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs)
+            work = sum(w for _, _, w in evs)
+            return ms, work, len(evs)
+
+        ms_c, work_c, n_c = agg("gram_conv")
+        ms_n, work_n, n_n = agg("gram_nt")
+        ms_t, work_t, n_t = agg("gram_tn")
+        ach = work_c / (ms_c * 1e-3) / 1e12 if ms_c > 0 else 0.0
+        result = {
+            "metric": "KFAC-GGN fit samples/sec, ResNet-18",
+            "value": samples / dt,
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "c4: ResNet-18 (CIFAR stem, BN frozen) full-network KFAC exact GGN fit, "
+                                   "per-GPU minibatch 128, synthetic N(0,1) 3x32x32, 10 classes, N=50000",
+                       "per_gpu_batch": BATCH, "parallelism": f"dp{world}"},
+            "roofline": {
+                "kernel": "lk::gram_kernel<MODE_CONV> (+ slab reduce): A-factor accumulation, exact-fp32 MFMA",
+                "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                "flop_convention": "symmetric half: K*n*(n+1) per launch (full-GEMM 2*K*n^2 would double it)",
+                "launches": n_c, "avg_launch_ms": ms_c / max(n_c, 1),
+            },
+            "kernel_time_ms_per_step": {"gram_conv": ms_c / args.steps, "gram_nt": ms_n / args.steps,
+                                        "gram_tn": ms_t / args.steps,
+                                        "gram_nt_tflops_sym": work_n / (ms_n * 1e-3) / 1e12 if ms_n else None},
+        }
+    # ---- untimed extras on rank 0 (separate line items per BASELINE.md) --------------------------------------
+    if rank == 0 and world == 1:
+        if not args.no_eigh:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            dec = H.decompose()
+            torch.cuda.synchronize()
+            result["eigh_ms"] = (time.perf_counter() - t0) * 1e3
+            result["eigh_converged"] = all(int(i.item()) == 0 for i in dec._eig_info)
+            del dec
+        if not args.no_predictive:
+            result["predictive"] = predictive_leg(dev)
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

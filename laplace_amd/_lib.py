@@ -112,6 +112,20 @@ class HipKernels:
     def __init__(self, lib: Optional[ctypes.CDLL] = None):
         self.lib = lib if lib is not None else load_library()
         self._ws: dict = {}
+        # optional per-launch timing (bench.py's roofline leg): name -> list of (start_evt, end_evt, work)
+        self.profile: Optional[dict] = None
+
+    def _timed(self, name: str, work: float, dev, call):
+        """Run ``call()``; when profiling is on, bracket it with HIP events on the launch stream."""
+        if self.profile is None:
+            return call()
+        st = torch.cuda.current_stream(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        rc = call()
+        e1.record(st)
+        self.profile.setdefault(name, []).append((e0, e1, work))
+        return rc
 
     # ---- plumbing -----------------------------------------------------------------------------
     def _stream(self, dev) -> ctypes.c_void_p:
@@ -162,8 +176,9 @@ class HipKernels:
         nb = self.lib.lk_gram_workspace_bytes(n, max(K, 1))
         ws = self._workspace(nb, X.device)
         self._rc(
-            self.lib.lk_gram_tn_f32(_ptr(X), K, n, n, float(alpha), _ptr(out), LK_GRAM_UPPER_ONLY if upper_only else 0,
-                                    _ptr(ws), ws.numel(), self._stream(X.device)),
+            self._timed("gram_tn", float(K) * n * (n + 1), X.device, lambda: self.lib.lk_gram_tn_f32(
+                _ptr(X), K, n, n, float(alpha), _ptr(out), LK_GRAM_UPPER_ONLY if upper_only else 0, _ptr(ws), ws.numel(),
+                self._stream(X.device))),
             "lk_gram_tn_f32",
         )
         return out
@@ -177,8 +192,9 @@ class HipKernels:
         nb = self.lib.lk_gram_workspace_bytes(n, max(nbat * Lp, 1))
         ws = self._workspace(nb, X.device)
         self._rc(
-            self.lib.lk_gram_nt_f32(_ptr(X), nbat, n, L, float(alpha), _ptr(out), LK_GRAM_UPPER_ONLY if upper_only else 0,
-                                    _ptr(ws), ws.numel(), self._stream(X.device)),
+            self._timed("gram_nt", float(nbat * L) * n * (n + 1), X.device, lambda: self.lib.lk_gram_nt_f32(
+                _ptr(X), nbat, n, L, float(alpha), _ptr(out), LK_GRAM_UPPER_ONLY if upper_only else 0, _ptr(ws), ws.numel(),
+                self._stream(X.device))),
             "lk_gram_nt_f32",
         )
         return out
@@ -214,9 +230,9 @@ class HipKernels:
         nb = self.lib.lk_gram_workspace_bytes(n, max(B * OH * OW, 1))
         ws = self._workspace(nb, x.device)
         self._rc(
-            self.lib.lk_gram_conv_nhwc_f32(_ptr(xh), B, H, W, Cin, kh, kw, sh, sw, ph, pw, dh, dw, float(alpha), _ptr(tgt),
-                                           LK_GRAM_UPPER_ONLY if upper_only else 0, _ptr(ws), ws.numel(),
-                                           self._stream(x.device)),
+            self._timed("gram_conv", float(B * OH * OW) * n * (n + 1), x.device, lambda: self.lib.lk_gram_conv_nhwc_f32(
+                _ptr(xh), B, H, W, Cin, kh, kw, sh, sw, ph, pw, dh, dw, float(alpha), _ptr(tgt),
+                LK_GRAM_UPPER_ONLY if upper_only else 0, _ptr(ws), ws.numel(), self._stream(x.device))),
             "lk_gram_conv_nhwc_f32",
         )
         if not direct:

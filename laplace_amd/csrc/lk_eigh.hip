@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void eig_init_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void eig_pivot_kernel(float* __restrict__ Aw, int np, int nb, int step,
                                                         float* __restrict__ Rws, float* __restrict__ Dws,
                                                         EigCtrl* ctrl, float tol_rel, float tol_abs,
-                                                        int max_inner) {
+                                                        float tol_conv, int max_inner) {
   if (ctrl->converged) return;
   __shared__ float S[EP][ELD];
   __shared__ float R[EP][ELD];
@@ -87,11 +87,13 @@ __global__ __launch_bounds__(256) void eig_pivot_kernel(float* __restrict__ Aw, 
   __shared__ int pq[32][2];
   __shared__ int any_rot;
   __shared__ int sweep_rot;
+  __shared__ int sweep_big;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int I, J;
   pivot_blocks(step, blockIdx.x, nb, I, J);
-  const float floor_abs = tol_abs * ctrl->scale;
+  const float floor_abs = tol_abs * ctrl->scale;   // below this an off-diagonal is rounding noise: never rotate
+  const float floor_conv = tol_conv * ctrl->scale; // rotations of elements below this do not count as "unconverged"
 
   // load the upper triangle of the pivot sub-matrix and mirror it
   for (int idx = tid; idx < EP * EP; idx += 256) {
@@ -101,15 +103,17 @@ __global__ __launch_bounds__(256) void eig_pivot_kernel(float* __restrict__ Aw, 
     S[r][c] = v;
     R[r][c] = (r == c) ? 1.f : 0.f;
   }
-  if (tid == 0) sweep_rot = 0;
-  int total_rot = 0;
+  if (tid == 0) {
+    sweep_rot = 0;
+    sweep_big = 0;
+  }
   __syncthreads();
 
   for (int sw = 0; sw < max_inner; ++sw) {
     for (int t = 0; t < EP - 1; ++t) {
       // (a) rotation parameters of the 32 disjoint pairs of this step (first half of wave 0)
       if (tid < 64) {
-        bool rot = false;
+        bool rot = false, big = false;
         if (tid < 32) {
           int a, b;
           if (tid == 0) {
@@ -129,6 +133,7 @@ __global__ __launch_bounds__(256) void eig_pivot_kernel(float* __restrict__ Aw, 
             c = 1.f / sqrtf(1.f + tt * tt);
             s = tt * c;
             rot = true;
+            big = mag > floor_conv;
           }
           cs[tid][0] = c;
           cs[tid][1] = s;
@@ -136,9 +141,11 @@ __global__ __launch_bounds__(256) void eig_pivot_kernel(float* __restrict__ Aw, 
           pq[tid][1] = q;
         }
         const unsigned long long m = __ballot(rot);
+        const unsigned long long mb = __ballot(big);
         if (tid == 0) {
           any_rot = (m != 0ull);
           sweep_rot += __popcll(m);
+          sweep_big += __popcll(mb);
         }
       }
       __syncthreads();
@@ -186,7 +193,6 @@ __global__ __launch_bounds__(256) void eig_pivot_kernel(float* __restrict__ Aw, 
     const int r = sweep_rot;  // stable: written only in phase (a), last one is behind the barrier above
     __syncthreads();
     if (tid == 0) sweep_rot = 0;
-    total_rot += r;
     if (r == 0) break;
   }
 
@@ -195,7 +201,7 @@ __global__ __launch_bounds__(256) void eig_pivot_kernel(float* __restrict__ Aw, 
   for (int idx = tid; idx < EP * EP; idx += 256) Rout[idx] = R[idx >> 6][idx & 63];
   float* Sout = Dws + (int64_t)blockIdx.x * EP * EP;  // the (nearly) diagonalised pivot itself
   for (int idx = tid; idx < EP * EP; idx += 256) Sout[idx] = S[idx >> 6][idx & 63];
-  if (tid == 0 && total_rot > 0) atomicAdd(&ctrl->rotations, total_rot);
+  if (tid == 0 && sweep_big > 0) atomicAdd(&ctrl->rotations, sweep_big);
 }
 
 // ---- 2. tile update  A_PQ <- R_P^T A_PQ R_Q ----------------------------------------------------------
@@ -473,6 +479,8 @@ extern "C" int lk_syevj_f32(const float* A, int64_t n, float* w, float* Q, int c
   const int kMaxInner = 3;         // inner sweeps per pivot visit (the outer sweeps finish the job)
   const float tol_rel = 3.0e-7f;   // ~2.5 eps: |a_pq| <= tol_rel*sqrt(|a_pp a_qq|) counts as annihilated
   const float tol_abs = 6.0e-8f;   // x max|a_ii|: absolute floor for (numerically) rank-deficient factors
+  const float tol_conv = 2.0e-6f;  // x max|a_ii|: only rotations of larger elements keep the solve "unconverged";
+                                   // what is left below it is removed from the spectrum by the Rayleigh refinement
 
   if (hipMemsetAsync(ctrl, 0, sizeof(EigCtrl), stream) != hipSuccess) {
     set_error("lk_syevj_f32: hipMemsetAsync failed");
@@ -486,7 +494,7 @@ extern "C" int lk_syevj_f32(const float* A, int64_t n, float* w, float* Q, int c
   for (int sweep = 0; sweep < max_sweeps; ++sweep) {
     for (int s = 0; s < steps; ++s) {
       hipLaunchKernelGGL(eig_pivot_kernel, dim3(p.npv), dim3(256), 0, stream, Aw, p.np, p.nb, s, Rws, Dws, ctrl,
-                         tol_rel, tol_abs, kMaxInner);
+                         tol_rel, tol_abs, tol_conv, kMaxInner);
       hipLaunchKernelGGL(eig_update_kernel, dim3(ntiles), dim3(256), 0, stream, Aw, p.np, p.nb, s, Rws, Dws, ctrl);
       hipLaunchKernelGGL(eig_vupdate_kernel, dim3(p.npv, p.np / EP), dim3(256), 0, stream, V, p.np, p.nb, s, Rws,
                          ctrl);

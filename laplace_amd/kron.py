@@ -90,15 +90,47 @@ class HipKron(_KronBase):
         return len(self.kfacs)
 
     # -- eigendecomposition (matrix.py:123-150; utils/utils.py:193-228) -----------------------------
-    def decompose(self, damping: bool = False) -> "HipKronDecomposed":
+    def decompose(self, damping: bool = False, n_streams: int = 6) -> "HipKronDecomposed":
+        """Eigendecompose every dense factor with the HIP block-Jacobi solver.
+
+        The solver of one matrix is a long chain of small launches (latency-bound pivot solves), so the
+        factors are spread over ``n_streams`` HIP streams (largest first) and run concurrently; the
+        calling stream waits for all of them before returning.
+        """
         K = get_kernels()
-        eigvecs, eigvals, infos = [], [], []
-        for F in self.kfacs:
+        dense = [(Hi.shape[0], bi, fi) for bi, F in enumerate(self.kfacs) for fi, Hi in enumerate(F) if Hi.ndim > 1]
+        dense.sort(reverse=True)
+        results = {}
+        infos = []
+        use_streams = bool(dense) and self.kfacs[dense[0][1]][dense[0][2]].is_cuda and n_streams > 1 and len(dense) > 1
+        if use_streams:
+            dev = self.kfacs[dense[0][1]][dense[0][2]].device
+            main = torch.cuda.current_stream(dev)
+            streams = [torch.cuda.Stream(dev) for _ in range(min(n_streams, len(dense)))]
+            for st in streams:
+                st.wait_stream(main)
+            for i, (_, bi, fi) in enumerate(dense):
+                st = streams[i % len(streams)]
+                Hi = self.kfacs[bi][fi].contiguous()
+                with torch.cuda.stream(st):
+                    l, Q, info = K.syevj(Hi, clamp=True)
+                for t in (Hi, l, Q, info):
+                    t.record_stream(st)
+                results[(bi, fi)] = (l, Q)
+                infos.append(info)
+            for st in streams:
+                main.wait_stream(st)
+        else:
+            for _, bi, fi in dense:
+                l, Q, info = K.syevj(self.kfacs[bi][fi].contiguous(), clamp=True)
+                results[(bi, fi)] = (l, Q)
+                infos.append(info)
+        eigvecs, eigvals = [], []
+        for bi, F in enumerate(self.kfacs):
             Qs, ls = [], []
-            for Hi in F:
+            for fi, Hi in enumerate(F):
                 if Hi.ndim > 1:
-                    l, Q, info = K.syevj(Hi.contiguous(), clamp=True)
-                    infos.append(info)
+                    l, Q = results[(bi, fi)]
                 else:  # diagonal factor
                     l, Q = Hi, torch.eye(len(Hi), dtype=Hi.dtype, device=Hi.device)
                 Qs.append(Q)
