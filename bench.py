@@ -52,14 +52,19 @@ def make_batches(steps, dev, seed):
     return xs
 
 
-def fit_steps(backend, H, batches, n_steps):
-    loss = torch.zeros((), device=batches[0][0].device)
+def fit_steps(backend, batches, n_steps, world):
+    """K minibatches through the fused accumulator, the fit's single all-reduce, and the one-off
+    symmetrise/permute into the reference's Kron layout — i.e. everything `fit` does before decompose."""
+    from laplace_amd.laplace import allreduce_curvature
+
+    acc = backend.kron_accumulator(N_DATASET)
     for i in range(n_steps):
         X, y = batches[i % len(batches)]
-        lb, Hb = backend.kron(X, y, N=N_DATASET)
-        loss = loss + lb
-        H += Hb
-    return loss
+        acc.add_batch(X, y)
+    if world > 1:
+        allreduce_curvature(acc.tensors())
+    loss, H = acc.finalize()
+    return loss, H
 
 
 def cpu_baseline(seconds: float):
@@ -137,9 +142,8 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
-    from laplace_amd import HipGGN, HipKron
+    from laplace_amd import HipGGN
     from laplace_amd._lib import get_kernels
-    from laplace_amd.laplace import allreduce_curvature
     from laplace_amd.nets import ResNet18
 
     torch.manual_seed(711)
@@ -154,21 +158,14 @@ def main():
         torch.cuda.synchronize()
 
     # ---- warm-up ------------------------------------------------------------------------------------
-    H = HipKron.init_from_model(backend.params, dev, torch.float32)
-    fit_steps(backend, H, batches, args.warmup)
-    if world > 1:
-        allreduce_curvature([Hi for F in H.kfacs for Hi in F])
+    fit_steps(backend, batches, max(args.warmup, 1), world)
     barrier()
 
-    # ---- timed region: exactly K steps (+ the fit's single all-reduce) ------------------------------------
-    H = HipKron.init_from_model(backend.params, dev, torch.float32)
+    # ---- timed region: exactly K steps (+ the fit's single all-reduce and layout finalisation) --------------
     K.profile = {} if rank == 0 else None
     barrier()
     t0 = time.perf_counter()
-    loss = fit_steps(backend, H, batches, args.steps)
-    if world > 1:
-        lt = loss.reshape(1).clone()
-        allreduce_curvature([Hi for F in H.kfacs for Hi in F] + [lt])
+    loss, H = fit_steps(backend, batches, args.steps, world)
     barrier()
     dt = time.perf_counter() - t0
     prof, K.profile = K.profile, None

@@ -58,8 +58,7 @@ int lk_sq_err_sum_f32(const float* f, const float* y, int64_t numel, float scale
  * dense einsums of GGNInterface.full / EFInterface.full (curvature.py:406,409,491).
  *
  *  _tn  : X is [K][n] row-major with leading dimension ldx      (nn.Linear inputs / output grads)
- *  _nt  : X is [nb][n][L] row-major; C += alpha * sum_b X_b X_b^T (NCHW conv output grads,
- *         NCHW inputs of 1x1 stride-1 convs)
+ *  _nt  : X is [nb][n][L] row-major; C += alpha * sum_b X_b X_b^T (NCHW conv output grads)
  *  _conv: x is an NHWC activation [B][H][W][Cin]; the Gram matrix of the *unfolded* patch matrix
  *         (rows = (b,oh,ow), columns = (kh,kw,ci)) is accumulated WITHOUT materialising it.
  *         Column order of C is (kh,kw,ci) ("native"); lk_permute_sym_f32 converts to the
@@ -71,6 +70,11 @@ int lk_gram_tn_f32(const float* X, int64_t K, int64_t n, int64_t ldx, float alph
                    unsigned flags, void* ws, size_t ws_bytes, void* stream);
 int lk_gram_nt_f32(const float* X, int64_t nb, int64_t n, int64_t L, float alpha, float* C,
                    unsigned flags, void* ws, size_t ws_bytes, void* stream);
+/* Same, with X given as `nseg` (<= 16) separate [nb][n][L] tensors (HOST array of device pointers):
+ * the per-seed output gradients of the C backward passes are consumed where autograd left them,
+ * without stacking them into one buffer. */
+int lk_gram_nt_seg_f32(const float* const* segs, int64_t nseg, int64_t nb, int64_t n, int64_t L, float alpha,
+                       float* C, unsigned flags, void* ws, size_t ws_bytes, void* stream);
 int lk_gram_conv_nhwc_f32(const float* x, int64_t B, int64_t H, int64_t W, int64_t Cin, int kh, int kw,
                           int sh, int sw, int ph, int pw, int dh, int dw, float alpha, float* C,
                           unsigned flags, void* ws, size_t ws_bytes, void* stream);

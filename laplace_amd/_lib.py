@@ -38,6 +38,7 @@ SIGNATURES = {
     "lk_gram_workspace_bytes": (_sz, [_i64, _i64]),
     "lk_gram_tn_f32": (_int, [_vp, _i64, _i64, _i64, _f32, _vp, _u32, _vp, _sz, _vp]),
     "lk_gram_nt_f32": (_int, [_vp, _i64, _i64, _i64, _f32, _vp, _u32, _vp, _sz, _vp]),
+    "lk_gram_nt_seg_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _f32, _vp, _u32, _vp, _sz, _vp]),
     "lk_gram_conv_nhwc_f32": (
         _int,
         [_vp, _i64, _i64, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _int, _f32, _vp, _u32, _vp, _sz, _vp],
@@ -184,18 +185,28 @@ class HipKernels:
         return out
 
     def gram_nt(self, X, alpha, out, upper_only=False):
-        _check(X, "X"), _check(out, "out")
-        nbat, n, L = X.shape
-        assert out.shape == (n, n)
+        """``out += alpha * sum_b X_b X_b^T``; ``X`` is ``[nb, n, L]`` or a list of up to 16 such tensors
+        (per-seed gradients, consumed in place through a pointer table)."""
+        segs = list(X) if isinstance(X, (list, tuple)) else [X]
+        for t in segs:
+            _check(t, "X")
+        _check(out, "out")
+        nbat, n, L = segs[0].shape
+        assert all(t.shape == segs[0].shape for t in segs) and out.shape == (n, n)
+        if len(segs) > 16:
+            segs = [torch.cat(segs)]
+            nbat = segs[0].shape[0]
         bk = 64 if n <= 64 else 16  # must mirror lk_gram.hip's chunk size for the virtual K
         Lp = (L + bk - 1) // bk * bk
-        nb = self.lib.lk_gram_workspace_bytes(n, max(nbat * Lp, 1))
-        ws = self._workspace(nb, X.device)
+        nb = self.lib.lk_gram_workspace_bytes(n, max(len(segs) * nbat * Lp, 1))
+        dev = segs[0].device
+        ws = self._workspace(nb, dev)
+        ptrs = (ctypes.c_void_p * len(segs))(*[t.data_ptr() for t in segs])
         self._rc(
-            self._timed("gram_nt", float(nbat * L) * n * (n + 1), X.device, lambda: self.lib.lk_gram_nt_f32(
-                _ptr(X), nbat, n, L, float(alpha), _ptr(out), LK_GRAM_UPPER_ONLY if upper_only else 0, _ptr(ws), ws.numel(),
-                self._stream(X.device))),
-            "lk_gram_nt_f32",
+            self._timed("gram_nt", float(len(segs) * nbat * L) * n * (n + 1), dev, lambda: self.lib.lk_gram_nt_seg_f32(
+                ptrs, len(segs), nbat, n, L, float(alpha), _ptr(out), LK_GRAM_UPPER_ONLY if upper_only else 0, _ptr(ws),
+                ws.numel(), self._stream(dev))),
+            "lk_gram_nt_seg_f32",
         )
         return out
 

@@ -62,14 +62,15 @@ class _HipCurvatureMixin:
             self._check_dtype(f)
             B = phi.shape[0]
             f = f.detach().reshape(B, -1).contiguous()
-            return f, tape, lambda seeds: [seeds.contiguous()]
+            return f, tape, lambda seeds, stack=True: [seeds.contiguous()]
         f = tape.forward(x)
         self._check_dtype(f)
         if f.ndim == 1:
             f = f.unsqueeze(-1)
         if f.ndim != 2:
             raise NotImplementedError(f"model output must be [batch, outputs]; got {tuple(f.shape)}")
-        return f.detach().contiguous(), tape, lambda seeds, f_graph=f: tape.output_grads(f_graph, seeds)
+        return (f.detach().contiguous(), tape,
+                lambda seeds, stack=True, f_graph=f: tape.output_grads(f_graph, seeds, stack=stack))
 
     # ---- seeds ----------------------------------------------------------------------------------
     def _ggn_seeds(self, f, y, loss):
@@ -111,36 +112,52 @@ class _HipCurvatureMixin:
             return oh * ow
         return int(a[0].numel() // a.shape[-1])
 
-    def _layer_factors(self, tap, g, N, alpha_g, alpha_a_scale, kfac_approx):
-        """(G, A) of one module; ``g`` is ``[S, B, ...]``."""
+    def _layer_factors(self, tap, g, N, alpha_g, alpha_a_scale, kfac_approx, out=None, fused=False):
+        """(G, A) of one module; ``g`` is ``[S, B, ...]`` (or the unstacked per-seed list for conv taps).
+
+        ``out=(G, A)`` accumulates into existing buffers.  ``fused=True`` is the accumulator mode: only the
+        upper block triangle is updated and conv A factors stay in the kernel-native (kh, kw, ci) column
+        order — :class:`KronAccumulator` symmetrises / permutes once at the end of the fit."""
         K = get_kernels()
         a = tap.a.to(torch.float32)
         m = tap.module
         dev = a.device
         L = self._positions(tap, a)
-        S, B = g.shape[0], g.shape[1]
+        if isinstance(g, (list, tuple)):  # conv tap, per-seed gradients left unstacked
+            S, B = len(g), g[0].shape[0]
+        else:
+            S, B = g.shape[0], g.shape[1]
         if tap.kind == "linear":
             Di, Do = m.in_features, m.out_features
-            A = torch.zeros(Di, Di, dtype=torch.float32, device=dev)
-            G = torch.zeros(Do, Do, dtype=torch.float32, device=dev)
+            G, A = out if out is not None else (torch.zeros(Do, Do, dtype=torch.float32, device=dev),
+                                                torch.zeros(Di, Di, dtype=torch.float32, device=dev))
             if kfac_approx == "expand" or L == 1:
-                K.gram_tn(a.reshape(-1, Di).contiguous(), alpha_a_scale / (N * L), A)
-                K.gram_tn(g.reshape(-1, Do).contiguous(), alpha_g, G)
+                K.gram_tn(a.reshape(-1, Di).contiguous(), alpha_a_scale / (N * L), A, upper_only=fused)
+                K.gram_tn(g.reshape(-1, Do).contiguous(), alpha_g, G, upper_only=fused)
             else:  # 'reduce': average inputs / sum gradients over the weight-sharing positions
-                K.gram_tn(a.reshape(B, L, Di).mean(1).contiguous(), alpha_a_scale / N, A)
-                K.gram_tn(g.reshape(S, B, L, Do).sum(2).reshape(S * B, Do).contiguous(), alpha_g, G)
+                K.gram_tn(a.reshape(B, L, Di).mean(1).contiguous(), alpha_a_scale / N, A, upper_only=fused)
+                K.gram_tn(g.reshape(S, B, L, Do).sum(2).reshape(S * B, Do).contiguous(), alpha_g, G, upper_only=fused)
             return G, A
         Do = m.out_channels
         Dk = m.in_channels * m.kernel_size[0] * m.kernel_size[1]
-        A = torch.zeros(Dk, Dk, dtype=torch.float32, device=dev)
-        G = torch.zeros(Do, Do, dtype=torch.float32, device=dev)
+        G, A = out if out is not None else (torch.zeros(Do, Do, dtype=torch.float32, device=dev),
+                                            torch.zeros(Dk, Dk, dtype=torch.float32, device=dev))
         if kfac_approx == "expand":
-            K.gram_conv(a.contiguous(), m.kernel_size, m.stride, m.padding, m.dilation, alpha_a_scale / (N * L), A)
-            K.gram_nt(g.reshape(S * B, Do, L).contiguous(), alpha_g, G)
+            K.gram_conv(a.contiguous(), m.kernel_size, m.stride, m.padding, m.dilation, alpha_a_scale / (N * L), A,
+                        upper_only=fused, native=fused)
+            if isinstance(g, (list, tuple)):
+                K.gram_nt([gs.reshape(B, Do, L) for gs in g], alpha_g, G, upper_only=fused)
+            else:
+                K.gram_nt(g.reshape(S * B, Do, L).contiguous(), alpha_g, G, upper_only=fused)
         else:
+            if isinstance(g, (list, tuple)):
+                g = torch.stack(g)
             cols = torch.nn.functional.unfold(a, m.kernel_size, dilation=m.dilation, padding=m.padding, stride=m.stride)
-            K.gram_tn(cols.mean(2).contiguous(), alpha_a_scale / N, A)
-            K.gram_tn(g.reshape(S * B, Do, L).sum(2).contiguous(), alpha_g, G)
+            if fused:  # keep the accumulator's native column order: (kh, kw, ci)
+                KK = m.kernel_size[0] * m.kernel_size[1]
+                cols = cols.reshape(cols.shape[0], m.in_channels, KK, -1).transpose(1, 2).reshape(cols.shape)
+            K.gram_tn(cols.mean(2).contiguous(), alpha_a_scale / N, A, upper_only=fused)
+            K.gram_tn(g.reshape(S * B, Do, L).sum(2).contiguous(), alpha_g, G, upper_only=fused)
         return G, A
 
     def _layer_jacobian(self, tap, g, Js):
@@ -185,7 +202,7 @@ class _HipCurvatureMixin:
             )
         loss = torch.zeros(1, dtype=torch.float32, device=f.device)
         seeds, hs = seeds_fn(f, y, loss)
-        grads = grad_fn(seeds)
+        grads = grad_fn(seeds, stack=False)
         fac = float(self.factor)
         rt = math.sqrt(fac)
         kfacs = []
@@ -243,6 +260,77 @@ class _HipCurvatureMixin:
         return K.gram_tn(Z2, alpha, H)
 
 
+class KronAccumulator:
+    """Running KFAC factors of one ``fit`` kept in the kernels' own form.
+
+    The reference accumulates with ``self.H += H_batch`` (laplace/baselaplace.py:985): a fresh set of
+    factors per minibatch (376 MB for ResNet-18), mirrored and permuted to the public layout, then
+    added.  Here every minibatch accumulates *in place* (``C += alpha X^T X`` is what the Gram kernels
+    do anyway), touching only the upper block triangle and leaving conv A factors in the native
+    (kh, kw, ci) order; ``finalize`` mirrors / permutes ONCE and hands back an ordinary
+    :class:`HipKron` (same values as the sum of per-batch ``kron()`` results; covered by
+    tests/test_laplace_e2e.py and tests/test_gpu_backend.py).
+    """
+
+    def __init__(self, backend, N: int, kfac_approx: str = "expand"):
+        self.backend, self.N, self.kfac_approx = backend, N, kfac_approx
+        self.factors = None  # per tap: [G, A]
+        self.loss = None
+        self._taps_meta = None
+
+    def _alloc(self, tape, dev):
+        self.factors, self._taps_meta = [], []
+        for tap in tape.taps:
+            m = tap.module
+            if tap.kind == "linear":
+                do, di = m.out_features, m.in_features
+                native = None
+            else:
+                do, di = m.out_channels, m.in_channels * m.kernel_size[0] * m.kernel_size[1]
+                native = (m.in_channels, m.kernel_size[0] * m.kernel_size[1])
+            self.factors.append([torch.zeros(do, do, dtype=torch.float32, device=dev),
+                                 torch.zeros(di, di, dtype=torch.float32, device=dev)])
+            self._taps_meta.append((tap.has_bias, native))
+        self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+
+    def add_batch(self, x, y):
+        b = self.backend
+        f, tape, grad_fn = b._forward(x)
+        if tape.uncovered:
+            raise NotImplementedError("KFAC supports nn.Linear / nn.Conv2d parameters only")
+        if self.factors is None:
+            self._alloc(tape, f.device)
+        seeds, hs = b._kron_seeds(f, y, self.loss)
+        grads = grad_fn(seeds, stack=False)
+        rt = math.sqrt(float(b.factor))
+        for tap, g, F in zip(tape.taps, grads, self.factors):
+            b._layer_factors(tap, g, self.N, rt * hs, rt, self.kfac_approx, out=(F[0], F[1]), fused=True)
+        tape.release()
+
+    def tensors(self) -> list[torch.Tensor]:
+        """Everything a data-parallel fit has to all-reduce (upper triangles are what counts)."""
+        return [t for F in self.factors for t in F] + [self.loss]
+
+    def finalize(self):
+        """-> (loss, HipKron) in the reference's layout (laplace/curvature/curvlinops.py:55-75)."""
+        K = get_kernels()
+        rt = math.sqrt(float(self.backend.factor))
+        kfacs = []
+        for (G, A), (has_bias, native) in zip(self.factors, self._taps_meta):
+            K.symmetrize(G)
+            K.symmetrize(A)
+            if native is not None and native[1] > 1:
+                A = K.permute_native_to_unfold(A, native[0], native[1], torch.empty_like(A))
+            if G.numel() == 1 and A.numel() == 1 and not has_bias:
+                kfacs.append([G * A])
+            else:
+                kfacs.append([G, A])
+            if has_bias:
+                kfacs.append([G * rt])
+        self.factors = None
+        return self.loss[0], HipKron(kfacs)
+
+
 class HipGGN(_HipCurvatureMixin, GGNInterface):
     """Generalised Gauss-Newton on HIP (exact GGN; ``stochastic=True`` is not implemented)."""
 
@@ -252,6 +340,12 @@ class HipGGN(_HipCurvatureMixin, GGNInterface):
             raise NotImplementedError("HipGGN implements the exact GGN; the MC Fisher is not available yet")
         super().__init__(model, likelihood, last_layer, subnetwork_indices, dict_key_x, dict_key_y,
                          stochastic=False, num_samples=num_samples)
+
+    _kron_seeds = _HipCurvatureMixin._ggn_seeds
+
+    def kron_accumulator(self, N: int, **kwargs) -> KronAccumulator:
+        """Fused-accumulation form of :meth:`kron` for a whole fit (see :class:`KronAccumulator`)."""
+        return KronAccumulator(self, N, kwargs.get("kfac_approx", "expand"))
 
     # KFAC — replaces CurvlinopsInterface.kron (laplace/curvature/curvlinops.py:77-108)
     def kron(self, x, y, N, **kwargs):
@@ -319,6 +413,11 @@ class HipEF(_HipCurvatureMixin, EFInterface):
 
     def _ef_seeds(self, f, y, loss):
         return self._ef_seed(f, y, loss), 1.0
+
+    _kron_seeds = _ef_seeds
+
+    def kron_accumulator(self, N: int, **kwargs) -> KronAccumulator:
+        return KronAccumulator(self, N, kwargs.get("kfac_approx", "expand"))
 
     def kron(self, x, y, N, **kwargs):
         return self._kron_impl(x, y, N, self._ef_seeds, None, kwargs.get("kfac_approx", "expand"))

@@ -93,18 +93,36 @@ class Tape:
                 raise RuntimeError(f"{tap.name}: module did not run in the forward pass")
         return f
 
-    def output_grads(self, f: torch.Tensor, seeds: torch.Tensor) -> list[torch.Tensor]:
-        """``seeds[s]`` is a cotangent of ``f``; returns per tap ``[S, *out.shape]`` gradients."""
+    def output_grads(self, f: torch.Tensor, seeds: torch.Tensor, stack: bool = True):
+        """``seeds[s]`` is a cotangent of ``f``; returns, per tap, the gradients w.r.t. the module output
+        for every seed: a ``[S, *out.shape]`` tensor, or — for conv taps when ``stack=False`` — the
+        list of the ``S`` per-seed tensors exactly as autograd produced them (the Gram kernel reads
+        them through a pointer table, so the multi-GB ``[S, B, C, H, W]`` stack is never written).
+
+        Pure-Linear models use ONE vmapped reverse pass (``is_grads_batched``); conv models run one
+        reverse pass per seed because functorch has no fused batching rule for MIOpen's conv backward
+        (it loops internally and then pays an extra concatenation).
+        """
         outs = [t.out for t in self.taps]
-        if seeds.shape[0] == 1:
+        S = seeds.shape[0]
+        has_conv = any(t.kind == "conv2d" for t in self.taps)
+        if S == 1:
             return [g.unsqueeze(0).contiguous() for g in torch.autograd.grad(f, outs, grad_outputs=seeds[0])]
-        try:
-            grads = torch.autograd.grad(f, outs, grad_outputs=seeds, is_grads_batched=True, retain_graph=True)
-            return [g.contiguous() for g in grads]
-        except RuntimeError:
-            # an op without a batching rule: fall back to one reverse pass per seed
-            per_seed = [torch.autograd.grad(f, outs, grad_outputs=s, retain_graph=True) for s in seeds]
-            return [torch.stack([ps[i] for ps in per_seed]).contiguous() for i in range(len(outs))]
+        if not has_conv:
+            try:
+                grads = torch.autograd.grad(f, outs, grad_outputs=seeds, is_grads_batched=True, retain_graph=True)
+                return [g.contiguous() for g in grads]
+            except RuntimeError:
+                pass  # an op without a batching rule: fall through to one reverse pass per seed
+        per_seed = [torch.autograd.grad(f, outs, grad_outputs=seeds[s], retain_graph=(s + 1 < S)) for s in range(S)]
+        result = []
+        for i, tap in enumerate(self.taps):
+            gs = [ps[i].contiguous() for ps in per_seed]
+            if tap.kind == "conv2d" and not stack:
+                result.append(gs)
+            else:
+                result.append(torch.stack(gs))
+        return result
 
     def release(self):
         for t in self.taps:

@@ -3,16 +3,19 @@
 // One MFMA engine, three operand loaders (the virtual row matrix X[K][n] is never materialised for
 // the NT and CONV forms):
 //   MODE_TN   X[K][n] row-major (ldx)                           nn.Linear inputs / output grads
-//   MODE_NT   x[nb][n][L]; row k=(b,l) -> x[b][:,l]             NCHW conv output grads, 1x1 conv inputs
+//   MODE_NT   x[seg][nb][n][L]; row k=(b,l) -> x[b][:,l]        NCHW conv output grads (one segment per
+//             backward seed, passed as a pointer table so the per-seed gradients are never stacked)
 //   MODE_CONV x[B][H][W][Cin] NHWC; row k=(b,oh,ow), col=(dy,dx,ci)  implicit im2col of conv inputs
 //
 // Work decomposition: grid.x = upper-triangular tile pairs (bi <= bj) of the n x n output, grid.y =
 // split-K slices.  Every workgroup writes its partial tile to a workspace slab (deterministic, no
 // atomics); gram_reduce_kernel sums the slabs, scales by alpha, accumulates into C and mirrors the
-// off-diagonal tiles.  Two tile configurations:
+// off-diagonal tiles.  Tile configurations:
 //   BIG   128x128 tile, BK=16, 4 waves as 2x2, each wave 2x2 MFMA 32x32x2 tiles (64 acc VGPRs)
 //   SMALL  64x64  tile (n <= 64), BK=64, 4 waves as 2x2, each wave one 32x32 tile: tiny-n / huge-K
 //          factors (conv G with 64 channels) keep all four SIMDs busy through deep split-K.
+// Interior tiles run a branch-free inner loop (4 LDS reads : 4 MFMAs per k-pair); only edge tiles
+// take the predicated path (wave-uniform scalar predicates).
 //
 // Reference being replaced: the A^T A / G^T G products inside curvlinops' KFAC as consumed by
 // laplace/curvature/curvlinops.py:55-108, and the einsums of laplace/curvature/curvature.py:406,409,491.
@@ -21,6 +24,7 @@
 namespace lk {
 
 enum { MODE_TN = 0, MODE_NT = 1, MODE_CONV = 2 };
+constexpr int MAX_SEG = 16;
 
 struct GramGeom {
   const float* x;
@@ -28,6 +32,9 @@ struct GramGeom {
   int n;        // columns (= output dim)
   int64_t ldx;  // TN
   int L, Lp;    // NT: positions per image, padded to a multiple of BK
+  int seg_nb;   // NT: images per segment
+  int nseg;     // NT: number of segments (1 = plain tensor)
+  const float* seg[MAX_SEG];                          // NT: segment base pointers
   int H, W, Cin, OH, OW, kw, sh, sw, ph, pw, dh, dw;  // CONV
 };
 
@@ -41,84 +48,106 @@ struct Cfg {
   static constexpr int WT = 32 * TW;           // wave tile edge
 };
 
-// element e of this thread's share of a [BK][T] panel -> (krow, col)
+// Linear staging index idx in [0, T*BK/VEC) -> (krow, col) of the first element.
+//   TN / CONV: consecutive idx walk along a row (columns are contiguous in memory)
+//   NT       : consecutive idx walk along k (positions are contiguous in memory)
 template <int MODE, int VEC, bool SMALL>
-__device__ __forceinline__ void elem_coord(int tid, int e, int& krow, int& col) {
+__device__ __forceinline__ void stage_coord(int idx, int& krow, int& col) {
   using C = Cfg<SMALL>;
   if (MODE == MODE_NT) {
-    if (VEC == 4) {
-      constexpr int TPC = C::BK / 4;
-      const int it = e >> 2, j = e & 3;
-      col = tid / TPC + (256 / TPC) * it;
-      krow = (tid % TPC) * 4 + j;
-    } else {
-      col = tid / C::BK + (256 / C::BK) * e;
-      krow = tid % C::BK;
-    }
+    constexpr int PER_COL = C::BK / VEC;
+    col = idx / PER_COL;
+    krow = (idx % PER_COL) * VEC;
   } else {
-    if (VEC == 4) {
-      constexpr int TPR = C::T / 4;
-      const int it = e >> 2, j = e & 3;
-      krow = tid / TPR + (256 / TPR) * it;
-      col = (tid % TPR) * 4 + j;
-    } else {
-      krow = tid / C::T + (256 / C::T) * e;
-      col = tid % C::T;
-    }
+    constexpr int PER_ROW = C::T / VEC;
+    krow = idx / PER_ROW;
+    col = (idx % PER_ROW) * VEC;
   }
 }
 
-// address + validity of virtual element (k, c)
-template <int MODE>
-__device__ __forceinline__ const float* elem_ptr(const GramGeom& g, int64_t k, int c, bool& valid) {
-  if (MODE == MODE_TN) {
-    valid = (k < g.K) && (c < g.n);
-    return g.x + k * g.ldx + c;
-  } else if (MODE == MODE_NT) {
-    const int b = (int)(k / g.Lp);
-    const int l = (int)(k - (int64_t)b * g.Lp);
-    valid = (k < g.K) && (l < g.L) && (c < g.n);
-    return g.x + ((int64_t)b * g.n + c) * g.L + l;
-  } else {
-    const int ohw = g.OH * g.OW;
-    const int b = (int)(k / ohw);
-    const int r = (int)(k - (int64_t)b * ohw);
-    const int oh = r / g.OW, ow = r - oh * g.OW;
-    const int d = c / g.Cin, ci = c - d * g.Cin;
-    const int dy = d / g.kw, dx = d - dy * g.kw;
-    const int ih = oh * g.sh - g.ph + dy * g.dh;
-    const int iw = ow * g.sw - g.pw + dx * g.dw;
-    valid = (k < g.K) && (c < g.n) && (ih >= 0) && (ih < g.H) && (iw >= 0) && (iw < g.W);
-    return g.x + (((int64_t)b * g.H + ih) * g.W + iw) * g.Cin + ci;
+// Per-thread, per-panel column context, computed once before the K loop (no div/mod in the loop).
+template <int MODE, int VEC, bool SMALL>
+struct ColCtx {
+  static constexpr int NL = Cfg<SMALL>::EPT / VEC;
+  int64_t off[NL];     // TN: column; NT: column*L; CONV: ci
+  int dy[NL], dx[NL];  // CONV: input offset of the patch element, padding folded in
+  bool ok[NL];
+};
+
+template <int MODE, int VEC, bool SMALL>
+__device__ __forceinline__ void make_colctx(const GramGeom& g, int col0, int tid, ColCtx<MODE, VEC, SMALL>& cc) {
+  constexpr int NL = ColCtx<MODE, VEC, SMALL>::NL;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    int krow, col;
+    stage_coord<MODE, VEC, SMALL>(tid + 256 * i, krow, col);
+    const int c = col0 + col;
+    cc.ok[i] = c < g.n;
+    cc.dy[i] = 0;
+    cc.dx[i] = 0;
+    if (MODE == MODE_TN) {
+      cc.off[i] = c;
+    } else if (MODE == MODE_NT) {
+      cc.off[i] = (int64_t)c * g.L;
+    } else {
+      const int d = c / g.Cin, ci = c - d * g.Cin;
+      const int dyy = d / g.kw, dxx = d - dyy * g.kw;
+      cc.dy[i] = dyy * g.dh - g.ph;
+      cc.dx[i] = dxx * g.dw - g.pw;
+      cc.off[i] = ci;
+    }
   }
 }
 
 template <int MODE, int VEC, bool SMALL>
-__device__ __forceinline__ void load_panel(const GramGeom& g, int64_t k0, int col0, int tid,
-                                           float (&st)[Cfg<SMALL>::EPT]) {
-  using C = Cfg<SMALL>;
-  if (VEC == 4) {
+__device__ __forceinline__ void load_panel(const GramGeom& g, int64_t k0, int tid,
+                                           const ColCtx<MODE, VEC, SMALL>& cc, float (&st)[Cfg<SMALL>::EPT]) {
+  constexpr int NL = ColCtx<MODE, VEC, SMALL>::NL;
+  // chunk-uniform part (NT: a chunk never straddles images because Lp % BK == 0)
+  const float* nt_base = nullptr;
+  int nt_l0 = 0;
+  if (MODE == MODE_NT) {
+    if (k0 < g.K) {
+      const int64_t b = k0 / g.Lp;
+      nt_l0 = (int)(k0 - b * g.Lp);
+      const int sgi = (int)(b / g.seg_nb);
+      const int bb = (int)(b - (int64_t)sgi * g.seg_nb);
+      nt_base = g.seg[sgi] + (int64_t)bb * g.n * g.L + nt_l0;
+    }
+  }
 #pragma unroll
-    for (int it = 0; it < C::EPT / 4; ++it) {
-      int krow, col;
-      elem_coord<MODE, VEC, SMALL>(tid, it * 4, krow, col);
-      bool valid;
-      const float* p = elem_ptr<MODE>(g, k0 + krow, col0 + col, valid);
+  for (int i = 0; i < NL; ++i) {
+    int krow, col;
+    stage_coord<MODE, VEC, SMALL>(tid + 256 * i, krow, col);
+    bool valid = cc.ok[i];
+    const float* p = g.x;
+    if (MODE == MODE_TN) {
+      const int64_t k = k0 + krow;
+      valid = valid && (k < g.K);
+      p = g.x + k * g.ldx + cc.off[i];
+    } else if (MODE == MODE_NT) {
+      valid = valid && (nt_base != nullptr) && (nt_l0 + krow < g.L);
+      p = nt_base + cc.off[i] + krow;
+    } else {
+      const int64_t k = k0 + krow;
+      const int ohw = g.OH * g.OW;
+      const int b = (int)(k / ohw);
+      const int r = (int)(k - (int64_t)b * ohw);
+      const int oh = r / g.OW, ow = r - oh * g.OW;
+      const int ih = oh * g.sh + cc.dy[i];
+      const int iw = ow * g.sw + cc.dx[i];
+      valid = valid && (k < g.K) && (ih >= 0) && (ih < g.H) && (iw >= 0) && (iw < g.W);
+      p = g.x + (((int64_t)b * g.H + ih) * g.W + iw) * g.Cin + cc.off[i];
+    }
+    if (VEC == 4) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (valid) v = *reinterpret_cast<const f32x4*>(p);
-      st[it * 4 + 0] = v.x;
-      st[it * 4 + 1] = v.y;
-      st[it * 4 + 2] = v.z;
-      st[it * 4 + 3] = v.w;
-    }
-  } else {
-#pragma unroll
-    for (int e = 0; e < C::EPT; ++e) {
-      int krow, col;
-      elem_coord<MODE, VEC, SMALL>(tid, e, krow, col);
-      bool valid;
-      const float* p = elem_ptr<MODE>(g, k0 + krow, col0 + col, valid);
-      st[e] = valid ? *p : 0.f;
+      st[i * 4 + 0] = v.x;
+      st[i * 4 + 1] = v.y;
+      st[i * 4 + 2] = v.z;
+      st[i * 4 + 3] = v.w;
+    } else {
+      st[i] = valid ? *p : 0.f;
     }
   }
 }
@@ -126,20 +155,19 @@ __device__ __forceinline__ void load_panel(const GramGeom& g, int64_t k0, int co
 template <int MODE, int VEC, bool SMALL>
 __device__ __forceinline__ void store_panel(float* panel, int tid, const float (&st)[Cfg<SMALL>::EPT]) {
   using C = Cfg<SMALL>;
-  if (MODE != MODE_NT && VEC == 4) {
+  constexpr int NL = C::EPT / VEC;
 #pragma unroll
-    for (int it = 0; it < C::EPT / 4; ++it) {
-      int krow, col;
-      elem_coord<MODE, VEC, SMALL>(tid, it * 4, krow, col);
-      f32x4 v = {st[it * 4], st[it * 4 + 1], st[it * 4 + 2], st[it * 4 + 3]};
+  for (int i = 0; i < NL; ++i) {
+    int krow, col;
+    stage_coord<MODE, VEC, SMALL>(tid + 256 * i, krow, col);
+    if (VEC == 4 && MODE != MODE_NT) {
+      f32x4 v = {st[i * 4], st[i * 4 + 1], st[i * 4 + 2], st[i * 4 + 3]};
       *reinterpret_cast<f32x4*>(panel + krow * C::LDP + col) = v;
-    }
-  } else {
+    } else if (VEC == 4) {  // NT: the four values are consecutive k-rows of one column
 #pragma unroll
-    for (int e = 0; e < C::EPT; ++e) {
-      int krow, col;
-      elem_coord<MODE, VEC, SMALL>(tid, e, krow, col);
-      panel[krow * C::LDP + col] = st[e];
+      for (int j = 0; j < 4; ++j) panel[(krow + j) * C::LDP + col] = st[i * 4 + j];
+    } else {
+      panel[krow * C::LDP + col] = st[i];
     }
   }
 }
@@ -155,31 +183,40 @@ __device__ __forceinline__ void pair_to_tiles(int p, int nbt, int& bi, int& bj) 
   bj = bi + p;
 }
 
-template <int MODE, int VEC, bool SMALL>
-__global__ __launch_bounds__(256) void gram_kernel(GramGeom g, float* __restrict__ slabs, int nbt, int npairs,
-                                                   int chunks_per_split, int nchunks) {
+// One chunk of MFMA work for this wave.  FULL: every 32x32 sub-tile of the wave is inside the matrix
+// (branch-free); otherwise (am, an) = number of active sub-tiles per dim, wave-uniform scalars.
+template <bool SMALL, bool FULL>
+__device__ __forceinline__ void compute_chunk(const float* __restrict__ pA, const float* __restrict__ pB,
+                                              f32x16 (&acc)[Cfg<SMALL>::TW][Cfg<SMALL>::TW], int am, int an) {
+  using C = Cfg<SMALL>;
+  constexpr int TW = C::TW;
+#pragma unroll
+  for (int kk = 0; kk < C::BK / 2; ++kk) {
+    float a[TW], b[TW];
+#pragma unroll
+    for (int t = 0; t < TW; ++t) {
+      a[t] = pA[2 * kk * C::LDP + t * 32];
+      b[t] = pB[2 * kk * C::LDP + t * 32];
+    }
+#pragma unroll
+    for (int tm = 0; tm < TW; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TW; ++tn)
+        if (FULL || (tm < am && tn < an))
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+  }
+}
+
+// Whole main loop + epilogue of one wave, specialised on FULL so that interior tiles get a branch-free
+// MFMA loop (the dispatch on `full` happens ONCE per wave, outside the loop).
+template <int MODE, int VEC, bool SMALL, bool FULL>
+__device__ __forceinline__ void gram_body(const GramGeom& g, float* __restrict__ smem, float* __restrict__ slab,
+                                          int tid, int wm, int wn, int lo, int hi, bool diag, int colA, int colB,
+                                          int c_begin, int c_end, int am, int an) {
   using C = Cfg<SMALL>;
   constexpr int PANEL = C::BK * C::LDP;
   constexpr int TW = C::TW;
-  constexpr int NP = SMALL ? 1 : 2;  // SMALL has a single (diagonal) tile: the B panel aliases A
-  __shared__ __attribute__((aligned(16))) float smem[2 * NP * PANEL];  // [buf][panel A|B]
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int lo = lane & 31, hi = lane >> 5;
-  int bi, bj;
-  pair_to_tiles(blockIdx.x, nbt, bi, bj);
-  const bool diag = SMALL || (bi == bj);
-  const int colA = bi * C::T, colB = bj * C::T;
-  const int wm = wave >> 1, wn = wave & 1;
-
-  // wave-uniform activity of the 32x32 sub-tiles (skip MFMA work that is entirely padding)
-  bool actm[TW], actn[TW];
-#pragma unroll
-  for (int t = 0; t < TW; ++t) {
-    actm[t] = (colA + wm * C::WT + t * 32) < g.n;
-    actn[t] = (colB + wn * C::WT + t * 32) < g.n;
-  }
+  constexpr int NP = SMALL ? 1 : 2;
 
   f32x16 acc[TW][TW];
 #pragma unroll
@@ -189,43 +226,33 @@ __global__ __launch_bounds__(256) void gram_kernel(GramGeom g, float* __restrict
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  const int c_begin = blockIdx.y * chunks_per_split;
-  const int c_end = min(nchunks, c_begin + chunks_per_split);
+  ColCtx<MODE, VEC, SMALL> ccA, ccB;
+  make_colctx<MODE, VEC, SMALL>(g, colA, tid, ccA);
+  make_colctx<MODE, VEC, SMALL>(g, colB, tid, ccB);
 
   float stA[C::EPT], stB[C::EPT];
   if (c_begin < c_end) {
-    load_panel<MODE, VEC, SMALL>(g, (int64_t)c_begin * C::BK, colA, tid, stA);
-    if (!diag) load_panel<MODE, VEC, SMALL>(g, (int64_t)c_begin * C::BK, colB, tid, stB);
+    load_panel<MODE, VEC, SMALL>(g, (int64_t)c_begin * C::BK, tid, ccA, stA);
+    if (!diag) load_panel<MODE, VEC, SMALL>(g, (int64_t)c_begin * C::BK, tid, ccB, stB);
     store_panel<MODE, VEC, SMALL>(smem, tid, stA);
     if (!diag) store_panel<MODE, VEC, SMALL>(smem + PANEL, tid, stB);
   }
   __syncthreads();
 
+  // this lane's operand offsets inside a panel: row = hi (k parity), column = wave tile origin + lo
+  const int offA = hi * C::LDP + wm * C::WT + lo;
+  const int offB = hi * C::LDP + wn * C::WT + lo;
+
   int cur = 0;
   for (int c = c_begin; c < c_end; ++c) {
     const bool more = (c + 1) < c_end;
     if (more) {
-      load_panel<MODE, VEC, SMALL>(g, (int64_t)(c + 1) * C::BK, colA, tid, stA);
-      if (!diag) load_panel<MODE, VEC, SMALL>(g, (int64_t)(c + 1) * C::BK, colB, tid, stB);
+      load_panel<MODE, VEC, SMALL>(g, (int64_t)(c + 1) * C::BK, tid, ccA, stA);
+      if (!diag) load_panel<MODE, VEC, SMALL>(g, (int64_t)(c + 1) * C::BK, tid, ccB, stB);
     }
     const float* pA = smem + cur * NP * PANEL;
     const float* pB = diag ? pA : pA + PANEL;
-#pragma unroll 8
-    for (int kk = 0; kk < C::BK / 2; ++kk) {
-      const int krow = 2 * kk + hi;
-      float a[TW], b[TW];
-#pragma unroll
-      for (int t = 0; t < TW; ++t) {
-        a[t] = pA[krow * C::LDP + wm * C::WT + t * 32 + lo];
-        b[t] = pB[krow * C::LDP + wn * C::WT + t * 32 + lo];
-      }
-#pragma unroll
-      for (int tm = 0; tm < TW; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TW; ++tn)
-          if (actm[tm] && actn[tn])
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
-    }
+    compute_chunk<SMALL, FULL>(pA + offA, pB + offB, acc, am, an);
     if (more) {
       float* nx = smem + (cur ^ 1) * NP * PANEL;
       store_panel<MODE, VEC, SMALL>(nx, tid, stA);
@@ -236,7 +263,6 @@ __global__ __launch_bounds__(256) void gram_kernel(GramGeom g, float* __restrict
   }
 
   // epilogue: partial tile -> slab
-  float* slab = slabs + ((int64_t)blockIdx.y * npairs + blockIdx.x) * (C::T * C::T);
 #pragma unroll
   for (int tm = 0; tm < TW; ++tm)
 #pragma unroll
@@ -247,6 +273,43 @@ __global__ __launch_bounds__(256) void gram_kernel(GramGeom g, float* __restrict
         const int col = wn * C::WT + tn * 32 + lo;
         slab[row * C::T + col] = acc[tm][tn][r];
       }
+}
+
+template <int MODE, int VEC, bool SMALL>
+__global__ __launch_bounds__(256) void gram_kernel(GramGeom g, float* __restrict__ slabs, int nbt, int npairs,
+                                                   int chunks_per_split, int nchunks) {
+  using C = Cfg<SMALL>;
+  constexpr int PANEL = C::BK * C::LDP;
+  constexpr int TW = C::TW;
+  constexpr int NP = SMALL ? 1 : 2;  // SMALL has a single (diagonal) tile: the B panel aliases A
+  __shared__ __attribute__((aligned(16))) float smem[2 * NP * PANEL];  // [buf][panel A|B]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lo = lane & 31, hi = lane >> 5;
+  int bi, bj;
+  pair_to_tiles(blockIdx.x, nbt, bi, bj);
+  const bool diag = SMALL || (bi == bj);
+  const int colA = bi * C::T, colB = bj * C::T;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // number of active 32x32 sub-tiles of this wave along each dim (wave-uniform scalars)
+  int am = (g.n - (colA + wm * C::WT) + 31) / 32;
+  int an = (g.n - (colB + wn * C::WT) + 31) / 32;
+  am = am < 0 ? 0 : (am > TW ? TW : am);
+  an = an < 0 ? 0 : (an > TW ? TW : an);
+
+  const int c_begin = blockIdx.y * chunks_per_split;
+  const int c_end = min(nchunks, c_begin + chunks_per_split);
+  float* slab = slabs + ((int64_t)blockIdx.y * npairs + blockIdx.x) * (C::T * C::T);
+
+  // Every wave executes the same number of barriers on either path.
+  if (am == TW && an == TW) {
+    gram_body<MODE, VEC, SMALL, true>(g, smem, slab, tid, wm, wn, lo, hi, diag, colA, colB, c_begin, c_end, am, an);
+  } else {
+    gram_body<MODE, VEC, SMALL, false>(g, smem, slab, tid, wm, wn, lo, hi, diag, colA, colB, c_begin, c_end, am, an);
+  }
 }
 
 // Sum slabs, scale, accumulate into C, mirror off-diagonal tiles.
@@ -266,6 +329,7 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restric
   const int64_t tile_elems = (int64_t)T * T;
   const bool do_mirror = mirror && (bi != bj);
   const int row0 = sr * 64 + slice * rpw;  // first tile row of this workgroup
+  if (bi * T + row0 >= n || bj * T + sc * 64 >= n) return;  // entirely padding
   for (int lr = ry; lr < rpw; lr += 4) {
     const float* p = slabs + (int64_t)blockIdx.x * tile_elems + (int64_t)(row0 + lr) * T + sc * 64 + cx;
     float s = 0.f;
@@ -305,7 +369,7 @@ static GramPlan make_plan(int64_t n, int64_t K) {
   int cap = p.nchunks / 8;
   if (cap < 1) cap = 1;
   p.nsplit = want < cap ? want : cap;
-  if (p.nsplit > 256) p.nsplit = 256;
+  if (p.nsplit > 1024) p.nsplit = 1024;
   p.chunks_per_split = (p.nchunks + p.nsplit - 1) / p.nsplit;
   p.nsplit = (p.nchunks + p.chunks_per_split - 1) / p.chunks_per_split;
   p.nslabs = p.nsplit;
@@ -416,17 +480,33 @@ extern "C" int lk_gram_tn_f32(const float* X, int64_t K, int64_t n, int64_t ldx,
   return launch_gram<MODE_TN>(g, vec4, alpha, C, flags, ws, ws_bytes, (hipStream_t)stream);
 }
 
-extern "C" int lk_gram_nt_f32(const float* X, int64_t nb, int64_t n, int64_t L, float alpha, float* C,
-                              unsigned flags, void* ws, size_t ws_bytes, void* stream) {
-  LK_REQUIRE(X && C && nb >= 0 && n >= 0 && L >= 1, "lk_gram_nt_f32: bad arguments");
-  LK_REQUIRE(n < (1 << 30) && L < (1 << 30), "lk_gram_nt_f32: dims too large");
+extern "C" int lk_gram_nt_seg_f32(const float* const* segs, int64_t nseg, int64_t nb, int64_t n, int64_t L,
+                                  float alpha, float* C, unsigned flags, void* ws, size_t ws_bytes, void* stream) {
+  LK_REQUIRE(segs && C && nseg >= 1 && nseg <= MAX_SEG && nb >= 0 && n >= 0 && L >= 1,
+             "lk_gram_nt_seg_f32: bad arguments (at most 16 segments)");
+  LK_REQUIRE(n < (1 << 30) && L < (1 << 30), "lk_gram_nt_seg_f32: dims too large");
   const int BK = n <= 64 ? 64 : 16;
   GramGeom g{};
-  g.x = X; g.n = (int)n; g.L = (int)L;
+  g.n = (int)n; g.L = (int)L;
   g.Lp = (int)((L + BK - 1) / BK * BK);
-  g.K = nb * g.Lp;
-  const bool vec4 = (L % 4 == 0) && aligned16(X);
+  g.seg_nb = (int)(nb > 0 ? nb : 1);
+  g.nseg = (int)nseg;
+  g.K = nseg * nb * g.Lp;
+  bool vec4 = (L % 4 == 0);
+  for (int i = 0; i < nseg; ++i) {
+    LK_REQUIRE(segs[i] != nullptr, "lk_gram_nt_seg_f32: null segment");
+    g.seg[i] = segs[i];
+    vec4 = vec4 && aligned16(segs[i]);
+  }
+  g.x = segs[0];
   return launch_gram<MODE_NT>(g, vec4, alpha, C, flags, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int lk_gram_nt_f32(const float* X, int64_t nb, int64_t n, int64_t L, float alpha, float* C,
+                              unsigned flags, void* ws, size_t ws_bytes, void* stream) {
+  LK_REQUIRE(X != nullptr, "lk_gram_nt_f32: bad arguments");
+  const float* segs[1] = {X};
+  return lk_gram_nt_seg_f32(segs, 1, nb, n, L, alpha, C, flags, ws, ws_bytes, stream);
 }
 
 extern "C" int lk_gram_conv_nhwc_f32(const float* x, int64_t B, int64_t H, int64_t W, int64_t Cin, int kh, int kw,

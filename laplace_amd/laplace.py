@@ -77,10 +77,8 @@ class _HipLaplace:
         self._backend_kwargs = dict(backend_kwargs or {})
         self._backend = None
         if subset_of_weights == "last_layer":
-            try:
-                from laplace.utils.feature_extractor import FeatureExtractor  # the reference's, if present
-            except Exception:
-                from laplace_amd.mirror import FeatureExtractor
+            from laplace_amd.mirror import FeatureExtractor  # (an already wrapped model is used as is)
+
             self.model = model if hasattr(model, "forward_with_features") else FeatureExtractor(model, last_layer_name)
             if getattr(self.model, "last_layer", None) is None:
                 raise ValueError("give last_layer_name (lazy last-layer discovery is not supported here)")
@@ -278,10 +276,37 @@ class HipKronLaplace(_HipLaplace):
     def _curvature_tensors(self):
         return [Hi for F in self.H.kfacs for Hi in F]
 
-    def fit(self, train_loader, override: bool = True, process_group=None, distributed=None):
+    def fit(self, train_loader, override: bool = True, process_group=None, distributed=None, fused: bool = True):
+        """``fused=True`` (default) accumulates in place through :class:`KronAccumulator` (upper
+        triangles, native conv order; one symmetrise/permute per fit).  ``fused=False`` is the
+        reference's literal loop ``self.H += backend.kron(X, y, N)`` (baselaplace.py:969-985)."""
         if not override:
             raise NotImplementedError("online continuation (override=False) is left to the reference's KronLaplace")
-        super().fit(train_loader, override=True, process_group=process_group, distributed=distributed)
+        if not (fused and hasattr(self.backend, "kron_accumulator")):
+            super().fit(train_loader, override=True, process_group=process_group, distributed=distributed)
+        else:
+            self.model.eval()
+            self.mean = parameters_to_vector(self.params).detach()
+            N = len(train_loader.dataset)
+            acc = self.backend.kron_accumulator(N)
+            for data in train_loader:
+                if isinstance(data, dict) or hasattr(data, "keys"):
+                    X, y = data, data[self.backend.dict_key_y].to(self._device)
+                else:
+                    X, y = data
+                    X, y = X.to(self._device), y.to(self._device)
+                if self.n_outputs is None:
+                    with torch.no_grad():
+                        self.n_outputs = self.model(X[:1] if torch.is_tensor(X) else X).shape[-1]
+                    setattr(self.model, "output_size", self.n_outputs)
+                acc.add_batch(X, y)
+            if distributed is None:
+                distributed = dist.is_available() and dist.is_initialized()
+            if distributed:
+                allreduce_curvature(acc.tensors(), group=process_group)
+            self.loss, self.H = acc.finalize()
+            self.n_data = N
+            self._posterior_cache = None
         self.H_facs = self.H
         self.H = self.H_facs.decompose(damping=self.damping)  # HIP eigensolver per factor
 

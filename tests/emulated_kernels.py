@@ -33,6 +33,8 @@ class EmulatedKernels:
         return out
 
     def gram_nt(self, X, alpha, out, upper_only=False):
+        if isinstance(X, (list, tuple)):
+            X = torch.cat(list(X))
         out += alpha * torch.einsum("bil,bjl->ij", X, X)
         return out
 

@@ -82,6 +82,18 @@ def test_gram_nt(K, nb, n, L):
     assert_close(got, want, what=f"gram_nt nb={nb} n={n} L={L}")
 
 
+def test_gram_nt_segments(K):
+    """per-seed gradients passed as a pointer table == the stacked tensor"""
+    segs = [rnd(6, 128, 64, seed=s) for s in range(10)]
+    want = EMU.gram_nt(torch.cat(segs), 0.3, torch.zeros(128, 128, dtype=torch.float64))
+    got = K.gram_nt([s.float().to(DEV) for s in segs], 0.3, torch.zeros(128, 128, device=DEV))
+    assert_close(got, want, what="gram_nt segments")
+    segs = [rnd(3, 64, 100, seed=s) for s in range(5)]
+    want = EMU.gram_nt(torch.cat(segs), 1.0, torch.zeros(64, 64, dtype=torch.float64))
+    got = K.gram_nt([s.float().to(DEV) for s in segs], 1.0, torch.zeros(64, 64, device=DEV))
+    assert_close(got, want, what="gram_nt segments small/unaligned")
+
+
 CONV_CASES = [
     # B, Cin, H, W, k, stride, pad, dil
     (4, 3, 5, 5, 2, 2, 0, 1),      # reference "complex_model" conv

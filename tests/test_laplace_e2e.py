@@ -22,14 +22,17 @@ def rel(got, want):
     return (got - want).abs().max().item() / (want.abs().max().item() + 1e-30)
 
 
-def run_case(name, lik, sow, hs, dev, tol=1e-4):
+def run_case(name, lik, sow, hs, dev, tol=1e-4, fused=True):
     from laplace_amd.laplace import HipLaplace
 
     g = load_golden(name, lik)
     model, X, y = golden_model(name, g, dtype=torch.float32, device=dev)
     sig = SIGMA_NOISE if lik == "regression" else 1.0
     la = HipLaplace(model, lik, sow, hs, prior_precision=PRIOR_PREC, sigma_noise=sig)
-    la.fit(DataLoader(TensorDataset(X, y), batch_size=5))
+    if hs == "kron":
+        la.fit(DataLoader(TensorDataset(X, y), batch_size=5), fused=fused)
+    else:
+        la.fit(DataLoader(TensorDataset(X, y), batch_size=5))
     tag = f"la.{sow}.{hs}"
     assert rel(la.loss, g[f"{tag}.loss"]) < tol, "loss"
     if hs == "kron":
@@ -64,10 +67,22 @@ def test_e2e_host_logic_on_emulation(emulated, name, lik, sow, hs):
     run_case(name, lik, sow, hs, "cpu")
 
 
+@pytest.mark.parametrize("name", FIXTURES)
+def test_e2e_kron_unfused_loop_on_emulation(emulated, name):
+    """the reference's literal `self.H += backend.kron(...)` loop gives the same factors"""
+    run_case(name, "classification", "all", "kron", "cpu", fused=False)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,lik,sow,hs", CASES)
 def test_e2e_gpu(name, lik, sow, hs):
     run_case(name, lik, sow, hs, "cuda")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", FIXTURES)
+def test_e2e_kron_unfused_gpu(name):
+    run_case(name, "regression", "all", "kron", "cuda", fused=False)
 
 
 def test_marglik_prior_optimisation_moves_uphill(emulated):
