@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--no-predictive", action="store_true")
     ap.add_argument("--no-eigh", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bound of the CPU-baseline leg")
+    ap.add_argument("--no-overlap", action="store_true", help="A-factor kernels on the main stream (A/B switch)")
     return ap.parse_args()
 
 
@@ -52,12 +53,12 @@ def make_batches(steps, dev, seed):
     return xs
 
 
-def fit_steps(backend, batches, n_steps, world):
+def fit_steps(backend, batches, n_steps, world, overlap=True):
     """K minibatches through the fused accumulator, the fit's single all-reduce, and the one-off
     symmetrise/permute into the reference's Kron layout — i.e. everything `fit` does before decompose."""
     from laplace_amd.laplace import allreduce_curvature
 
-    acc = backend.kron_accumulator(N_DATASET)
+    acc = backend.kron_accumulator(N_DATASET, overlap=overlap)
     for i in range(n_steps):
         X, y = batches[i % len(batches)]
         acc.add_batch(X, y)
@@ -158,17 +159,27 @@ def main():
         torch.cuda.synchronize()
 
     # ---- warm-up ------------------------------------------------------------------------------------
-    fit_steps(backend, batches, max(args.warmup, 1), world)
+    overlap = not args.no_overlap
+    fit_steps(backend, batches, max(args.warmup, 1), world, overlap)
     barrier()
 
     # ---- timed region: exactly K steps (+ the fit's single all-reduce and layout finalisation) --------------
-    K.profile = {} if rank == 0 else None
     barrier()
     t0 = time.perf_counter()
-    loss, H = fit_steps(backend, batches, args.steps, world)
+    loss, H = fit_steps(backend, batches, args.steps, world, overlap)
     barrier()
     dt = time.perf_counter() - t0
-    prof, K.profile = K.profile, None
+
+    # ---- roofline leg (rank 0): the same steps once more with every Gram launch bracketed by HIP events on
+    # its launch stream, A-factor kernels NOT overlapped with the reverse passes so that the per-launch
+    # durations are the kernels' own (the throughput above is measured without this instrumentation)
+    prof = {}
+    if rank == 0:
+        K.profile = prof
+        fit_steps(backend, batches, min(args.steps, 5), 1, overlap=False)
+        torch.cuda.synchronize()
+        K.profile = None
+    prof_steps = min(args.steps, 5)
     if world > 1:
         t = torch.tensor([dt], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -211,8 +222,8 @@ def main():
                 "flop_convention": "symmetric half: K*n*(n+1) per launch (full-GEMM 2*K*n^2 would double it)",
                 "launches": n_c, "avg_launch_ms": ms_c / max(n_c, 1),
             },
-            "kernel_time_ms_per_step": {"gram_conv": ms_c / args.steps, "gram_nt": ms_n / args.steps,
-                                        "gram_tn": ms_t / args.steps,
+            "kernel_time_ms_per_step": {"gram_conv": ms_c / prof_steps, "gram_nt": ms_n / prof_steps,
+                                        "gram_tn": ms_t / prof_steps,
                                         "gram_nt_tflops_sym": work_n / (ms_n * 1e-3) / 1e12 if ms_n else None},
         }
     # ---- untimed extras on rank 0 (separate line items per BASELINE.md) --------------------------------------
@@ -223,7 +234,7 @@ def main():
             dec = H.decompose()
             torch.cuda.synchronize()
             result["eigh_ms"] = (time.perf_counter() - t0) * 1e3
-            result["eigh_converged"] = all(int(i.item()) == 0 for i in dec._eig_info)
+            result["eigh_converged"] = all(int(i[0].item()) == 0 for i in dec._eig_info)
             del dec
         if not args.no_predictive:
             result["predictive"] = predictive_leg(dev)

@@ -133,7 +133,7 @@ int lk_ll_ggn_full_f32(const float* phi, const float* probs, int64_t B, int64_t 
  * (laplace/utils/utils.py:193-228, laplace/utils/matrix.py:123-150):
  *   reads the UPPER triangle of A[n][n]; writes ascending eigenvalues w[n] clamped at >= 0 (when
  *   clamp != 0) and eigenvectors as the COLUMNS of Q[n][n] (row-major), NaNs zeroed.
- *   info[0] (device int32): 0 = converged, >0 = sweeps ran out with that many unconverged pivots.
+ *   info (device int32[2]): info[0] = 0 converged / 1 sweeps ran out; info[1] = sweeps executed.
  * A is not modified.  Fully asynchronous on `stream`.
  * ------------------------------------------------------------------------------------------- */
 size_t lk_syevj_workspace_bytes(int64_t n);

@@ -334,7 +334,7 @@ class HipKernels:
         assert A.shape == (n, n)
         w = torch.empty(n, dtype=torch.float32, device=A.device)
         Q = torch.empty(n, n, dtype=torch.float32, device=A.device)
-        info = torch.zeros(1, dtype=torch.int32, device=A.device)
+        info = torch.zeros(2, dtype=torch.int32, device=A.device)
         nb = self.lib.lk_syevj_workspace_bytes(n)
         # the solve is long-running and asynchronous: give it a private workspace
         ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=A.device)

@@ -112,39 +112,54 @@ class _HipCurvatureMixin:
             return oh * ow
         return int(a[0].numel() // a.shape[-1])
 
-    def _layer_factors(self, tap, g, N, alpha_g, alpha_a_scale, kfac_approx, out=None, fused=False):
-        """(G, A) of one module; ``g`` is ``[S, B, ...]`` (or the unstacked per-seed list for conv taps).
+    def _factor_shapes(self, tap):
+        m = tap.module
+        if tap.kind == "linear":
+            return m.out_features, m.in_features
+        return m.out_channels, m.in_channels * m.kernel_size[0] * m.kernel_size[1]
 
-        ``out=(G, A)`` accumulates into existing buffers.  ``fused=True`` is the accumulator mode: only the
-        upper block triangle is updated and conv A factors stay in the kernel-native (kh, kw, ci) column
-        order — :class:`KronAccumulator` symmetrises / permutes once at the end of the fit."""
+    def _factor_A(self, tap, N, alpha_a_scale, kfac_approx, A, fused=False):
+        """``A += alpha/(N L) * sum a a^T`` (input side; needs only the forward activations)."""
         K = get_kernels()
         a = tap.a.to(torch.float32)
         m = tap.module
-        dev = a.device
         L = self._positions(tap, a)
+        if tap.kind == "linear":
+            Di = m.in_features
+            if kfac_approx == "expand" or L == 1:
+                K.gram_tn(a.reshape(-1, Di).contiguous(), alpha_a_scale / (N * L), A, upper_only=fused)
+            else:  # 'reduce': average inputs over the weight-sharing positions
+                K.gram_tn(a.reshape(a.shape[0], L, Di).mean(1).contiguous(), alpha_a_scale / N, A, upper_only=fused)
+            return A
+        if kfac_approx == "expand":
+            K.gram_conv(a.contiguous(), m.kernel_size, m.stride, m.padding, m.dilation, alpha_a_scale / (N * L), A,
+                        upper_only=fused, native=fused)
+        else:
+            cols = torch.nn.functional.unfold(a, m.kernel_size, dilation=m.dilation, padding=m.padding, stride=m.stride)
+            if fused:  # keep the accumulator's native column order: (kh, kw, ci)
+                KK = m.kernel_size[0] * m.kernel_size[1]
+                cols = cols.reshape(cols.shape[0], m.in_channels, KK, -1).transpose(1, 2).reshape(cols.shape)
+            K.gram_tn(cols.mean(2).contiguous(), alpha_a_scale / N, A, upper_only=fused)
+        return A
+
+    def _factor_G(self, tap, g, alpha_g, kfac_approx, G, fused=False):
+        """``G += alpha * sum g g^T`` (output side; ``g`` is ``[S, B, ...]`` or the unstacked per-seed list)."""
+        K = get_kernels()
+        m = tap.module
+        L = self._positions(tap, tap.a)
         if isinstance(g, (list, tuple)):  # conv tap, per-seed gradients left unstacked
             S, B = len(g), g[0].shape[0]
         else:
             S, B = g.shape[0], g.shape[1]
         if tap.kind == "linear":
-            Di, Do = m.in_features, m.out_features
-            G, A = out if out is not None else (torch.zeros(Do, Do, dtype=torch.float32, device=dev),
-                                                torch.zeros(Di, Di, dtype=torch.float32, device=dev))
+            Do = m.out_features
             if kfac_approx == "expand" or L == 1:
-                K.gram_tn(a.reshape(-1, Di).contiguous(), alpha_a_scale / (N * L), A, upper_only=fused)
                 K.gram_tn(g.reshape(-1, Do).contiguous(), alpha_g, G, upper_only=fused)
-            else:  # 'reduce': average inputs / sum gradients over the weight-sharing positions
-                K.gram_tn(a.reshape(B, L, Di).mean(1).contiguous(), alpha_a_scale / N, A, upper_only=fused)
+            else:
                 K.gram_tn(g.reshape(S, B, L, Do).sum(2).reshape(S * B, Do).contiguous(), alpha_g, G, upper_only=fused)
-            return G, A
+            return G
         Do = m.out_channels
-        Dk = m.in_channels * m.kernel_size[0] * m.kernel_size[1]
-        G, A = out if out is not None else (torch.zeros(Do, Do, dtype=torch.float32, device=dev),
-                                            torch.zeros(Dk, Dk, dtype=torch.float32, device=dev))
         if kfac_approx == "expand":
-            K.gram_conv(a.contiguous(), m.kernel_size, m.stride, m.padding, m.dilation, alpha_a_scale / (N * L), A,
-                        upper_only=fused, native=fused)
             if isinstance(g, (list, tuple)):
                 K.gram_nt([gs.reshape(B, Do, L) for gs in g], alpha_g, G, upper_only=fused)
             else:
@@ -152,12 +167,20 @@ class _HipCurvatureMixin:
         else:
             if isinstance(g, (list, tuple)):
                 g = torch.stack(g)
-            cols = torch.nn.functional.unfold(a, m.kernel_size, dilation=m.dilation, padding=m.padding, stride=m.stride)
-            if fused:  # keep the accumulator's native column order: (kh, kw, ci)
-                KK = m.kernel_size[0] * m.kernel_size[1]
-                cols = cols.reshape(cols.shape[0], m.in_channels, KK, -1).transpose(1, 2).reshape(cols.shape)
-            K.gram_tn(cols.mean(2).contiguous(), alpha_a_scale / N, A, upper_only=fused)
             K.gram_tn(g.reshape(S * B, Do, L).sum(2).contiguous(), alpha_g, G, upper_only=fused)
+        return G
+
+    def _layer_factors(self, tap, g, N, alpha_g, alpha_a_scale, kfac_approx, out=None, fused=False):
+        """(G, A) of one module.  ``out=(G, A)`` accumulates into existing buffers.  ``fused=True`` is the
+        accumulator mode: only the upper block triangle is updated and conv A factors stay in the
+        kernel-native (kh, kw, ci) column order — :class:`KronAccumulator` symmetrises / permutes once
+        at the end of the fit."""
+        do, di = self._factor_shapes(tap)
+        dev = tap.a.device
+        G, A = out if out is not None else (torch.zeros(do, do, dtype=torch.float32, device=dev),
+                                            torch.zeros(di, di, dtype=torch.float32, device=dev))
+        self._factor_A(tap, N, alpha_a_scale, kfac_approx, A, fused)
+        self._factor_G(tap, g, alpha_g, kfac_approx, G, fused)
         return G, A
 
     def _layer_jacobian(self, tap, g, Js):
@@ -272,8 +295,10 @@ class KronAccumulator:
     tests/test_laplace_e2e.py and tests/test_gpu_backend.py).
     """
 
-    def __init__(self, backend, N: int, kfac_approx: str = "expand"):
+    def __init__(self, backend, N: int, kfac_approx: str = "expand", overlap: bool = True):
         self.backend, self.N, self.kfac_approx = backend, N, kfac_approx
+        self.overlap = overlap
+        self._side = None
         self.factors = None  # per tap: [G, A]
         self.loss = None
         self._taps_meta = None
@@ -300,11 +325,28 @@ class KronAccumulator:
             raise NotImplementedError("KFAC supports nn.Linear / nn.Conv2d parameters only")
         if self.factors is None:
             self._alloc(tape, f.device)
+        rt = math.sqrt(float(b.factor))
+        # The A factors need only the forward activations: enqueue them on a side stream so that they
+        # overlap the C reverse passes (whose late, small-spatial conv kernels do not fill the chip).
+        side = None
+        if self.overlap and f.is_cuda:
+            if self._side is None:
+                self._side = torch.cuda.Stream(f.device)
+            side = self._side
+            main = torch.cuda.current_stream(f.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                for tap, F in zip(tape.taps, self.factors):
+                    b._factor_A(tap, self.N, rt, self.kfac_approx, F[1], fused=True)
+        else:
+            for tap, F in zip(tape.taps, self.factors):
+                b._factor_A(tap, self.N, rt, self.kfac_approx, F[1], fused=True)
         seeds, hs = b._kron_seeds(f, y, self.loss)
         grads = grad_fn(seeds, stack=False)
-        rt = math.sqrt(float(b.factor))
         for tap, g, F in zip(tape.taps, grads, self.factors):
-            b._layer_factors(tap, g, self.N, rt * hs, rt, self.kfac_approx, out=(F[0], F[1]), fused=True)
+            b._factor_G(tap, g, rt * hs, self.kfac_approx, F[0], fused=True)
+        if side is not None:
+            torch.cuda.current_stream(f.device).wait_stream(side)
         tape.release()
 
     def tensors(self) -> list[torch.Tensor]:
@@ -345,7 +387,7 @@ class HipGGN(_HipCurvatureMixin, GGNInterface):
 
     def kron_accumulator(self, N: int, **kwargs) -> KronAccumulator:
         """Fused-accumulation form of :meth:`kron` for a whole fit (see :class:`KronAccumulator`)."""
-        return KronAccumulator(self, N, kwargs.get("kfac_approx", "expand"))
+        return KronAccumulator(self, N, kwargs.get("kfac_approx", "expand"), kwargs.get("overlap", True))
 
     # KFAC — replaces CurvlinopsInterface.kron (laplace/curvature/curvlinops.py:77-108)
     def kron(self, x, y, N, **kwargs):

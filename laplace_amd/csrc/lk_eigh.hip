@@ -78,8 +78,8 @@ __global__ __launch_bounds__(256) void eig_init_kernel(const float* __restrict__
 // the column rotation k2) and the column rotation on R.  Two barriers per step.
 __global__ __launch_bounds__(256) void eig_pivot_kernel(float* __restrict__ Aw, int np, int nb, int step,
                                                         float* __restrict__ Rws, float* __restrict__ Dws,
-                                                        EigCtrl* ctrl, float tol_rel, float tol_abs,
-                                                        float tol_conv, int max_inner) {
+                                                        int* __restrict__ rotated, EigCtrl* ctrl, float tol_rel,
+                                                        float tol_abs, float tol_conv, int max_inner) {
   if (ctrl->converged) return;
   __shared__ float S[EP][ELD];
   __shared__ float R[EP][ELD];
@@ -92,6 +92,7 @@ __global__ __launch_bounds__(256) void eig_pivot_kernel(float* __restrict__ Aw, 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int I, J;
   pivot_blocks(step, blockIdx.x, nb, I, J);
+  int total_rot = 0;
   const float floor_abs = tol_abs * ctrl->scale;   // below this an off-diagonal is rounding noise: never rotate
   const float floor_conv = tol_conv * ctrl->scale; // rotations of elements below this do not count as "unconverged"
 
@@ -193,10 +194,14 @@ __global__ __launch_bounds__(256) void eig_pivot_kernel(float* __restrict__ Aw, 
     const int r = sweep_rot;  // stable: written only in phase (a), last one is behind the barrier above
     __syncthreads();
     if (tid == 0) sweep_rot = 0;
+    total_rot += r;
     if (r == 0) break;
   }
 
-  // outputs: R_P (row-major 64x64) and the pivot's diagonal
+  // outputs: R_P (row-major 64x64), the solved pivot, and whether anything rotated at all (R_P == I otherwise,
+  // which lets the tile updates of untouched pivot pairs be skipped in the late, mostly-converged sweeps)
+  if (tid == 0) rotated[blockIdx.x] = total_rot > 0 ? 1 : 0;
+  if (total_rot == 0) return;
   float* Rout = Rws + (int64_t)blockIdx.x * EP * EP;
   for (int idx = tid; idx < EP * EP; idx += 256) Rout[idx] = R[idx >> 6][idx & 63];
   float* Sout = Dws + (int64_t)blockIdx.x * EP * EP;  // the (nearly) diagonalised pivot itself
@@ -242,7 +247,8 @@ __device__ __forceinline__ void quad_store(float (*Z)[ELD], const f32x16& acc, i
 
 __global__ __launch_bounds__(256) void eig_update_kernel(float* __restrict__ Aw, int np, int nb, int step,
                                                          const float* __restrict__ Rws,
-                                                         const float* __restrict__ Dws, const EigCtrl* ctrl) {
+                                                         const float* __restrict__ Dws,
+                                                         const int* __restrict__ rotated, const EigCtrl* ctrl) {
   if (ctrl->converged) return;
   __shared__ float X[EP][ELD];
   __shared__ float Y[EP][ELD];
@@ -257,6 +263,7 @@ __global__ __launch_bounds__(256) void eig_update_kernel(float* __restrict__ Aw,
     --rowlen;
   }
   const int Q = P + rem;
+  if (!rotated[P] && !rotated[Q]) return;  // R_P = R_Q = I: the tile is unchanged
   int IP, JP, IQ, JQ;
   pivot_blocks(step, P, nb, IP, JP);
   pivot_blocks(step, Q, nb, IQ, JQ);
@@ -271,16 +278,18 @@ __global__ __launch_bounds__(256) void eig_update_kernel(float* __restrict__ Aw,
   }
   const float* RP = Rws + (int64_t)P * EP * EP;
   const float* RQ = Rws + (int64_t)Q * EP * EP;
+  const bool rotP = rotated[P] != 0, rotQ = rotated[Q] != 0;
   for (int idx = tid; idx < EP * EP; idx += 256) {
     const int r = idx >> 6, c = idx & 63;
     X[r][c] = Aw[(int64_t)pivot_index(r, IP, JP) * np + pivot_index(c, IQ, JQ)];
-    Y[r][c] = RQ[idx];
+    Y[r][c] = rotQ ? RQ[idx] : (r == c ? 1.f : 0.f);
   }
   __syncthreads();
   f32x16 t = quad_mm_AB(X, Y, wm, wn, lo, hi);  // T = A_PQ R_Q
   __syncthreads();
   quad_store(X, t, wm, wn, lo, hi);  // X <- T
-  for (int idx = tid; idx < EP * EP; idx += 256) Y[idx >> 6][idx & 63] = RP[idx];
+  for (int idx = tid; idx < EP * EP; idx += 256)
+    Y[idx >> 6][idx & 63] = rotP ? RP[idx] : ((idx >> 6) == (idx & 63) ? 1.f : 0.f);
   __syncthreads();
   f32x16 m = quad_mm_AtB(Y, X, wm, wn, lo, hi);  // M = R_P^T T
   __syncthreads();
@@ -295,8 +304,9 @@ __global__ __launch_bounds__(256) void eig_update_kernel(float* __restrict__ Aw,
 
 // ---- 3. eigenvector update  V[:, Q] <- V[:, Q] R_Q -----------------------------------------------------
 __global__ __launch_bounds__(256) void eig_vupdate_kernel(float* __restrict__ V, int np, int nb, int step,
-                                                          const float* __restrict__ Rws, const EigCtrl* ctrl) {
-  if (ctrl->converged) return;
+                                                          const float* __restrict__ Rws,
+                                                          const int* __restrict__ rotated, const EigCtrl* ctrl) {
+  if (ctrl->converged || !rotated[blockIdx.x]) return;
   __shared__ float X[EP][ELD];
   __shared__ float Y[EP][ELD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -358,7 +368,10 @@ __global__ __launch_bounds__(256) void eig_gather_kernel(const float* __restrict
       w[k] = l;
     }
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0 && info != nullptr) info[0] = ctrl->converged ? 0 : 1;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && info != nullptr) {
+    info[0] = ctrl->converged ? 0 : 1;
+    info[1] = ctrl->sweeps;  // sweeps actually executed (diagnostic)
+  }
 }
 
 // ---- refinement GEMMs:  C = alpha * op(A) * B + beta * D   (all np x np, np % 64 == 0) ----------------
@@ -423,7 +436,7 @@ __global__ __launch_bounds__(256) void eig_coldot_kernel(const float* __restrict
 
 struct EigPlan {
   int np, nb, npv;
-  size_t off_A, off_V, off_A0, off_T, off_R, off_D, off_perm, off_diag, off_ctrl, total;
+  size_t off_A, off_V, off_A0, off_T, off_R, off_D, off_perm, off_diag, off_rot, off_ctrl, total;
 };
 
 static EigPlan eig_plan(int64_t n) {
@@ -441,6 +454,7 @@ static EigPlan eig_plan(int64_t n) {
   p.off_D = off; off += align_up((size_t)p.npv * EP * EP * 4, 256);
   p.off_perm = off; off += align_up((size_t)p.np * 4, 256);
   p.off_diag = off; off += align_up((size_t)p.np * 4, 256);
+  p.off_rot = off; off += align_up((size_t)p.npv * 4, 256);
   p.off_ctrl = off; off += 256;
   p.total = off;
   return p;
@@ -474,8 +488,9 @@ extern "C" int lk_syevj_f32(const float* A, int64_t n, float* w, float* Q, int c
   float* Dws = reinterpret_cast<float*>(base + p.off_D);
   int* perm = reinterpret_cast<int*>(base + p.off_perm);
   float* dvec = reinterpret_cast<float*>(base + p.off_diag);
+  int* rotated = reinterpret_cast<int*>(base + p.off_rot);
   EigCtrl* ctrl = reinterpret_cast<EigCtrl*>(base + p.off_ctrl);
-  if (max_sweeps <= 0) max_sweeps = 14;
+  if (max_sweeps <= 0) max_sweeps = 24;
   const int kMaxInner = 3;         // inner sweeps per pivot visit (the outer sweeps finish the job)
   const float tol_rel = 3.0e-7f;   // ~2.5 eps: |a_pq| <= tol_rel*sqrt(|a_pp a_qq|) counts as annihilated
   const float tol_abs = 6.0e-8f;   // x max|a_ii|: absolute floor for (numerically) rank-deficient factors
@@ -493,11 +508,12 @@ extern "C" int lk_syevj_f32(const float* A, int64_t n, float* w, float* Q, int c
   const int ntiles = p.npv * (p.npv + 1) / 2;
   for (int sweep = 0; sweep < max_sweeps; ++sweep) {
     for (int s = 0; s < steps; ++s) {
-      hipLaunchKernelGGL(eig_pivot_kernel, dim3(p.npv), dim3(256), 0, stream, Aw, p.np, p.nb, s, Rws, Dws, ctrl,
-                         tol_rel, tol_abs, tol_conv, kMaxInner);
-      hipLaunchKernelGGL(eig_update_kernel, dim3(ntiles), dim3(256), 0, stream, Aw, p.np, p.nb, s, Rws, Dws, ctrl);
-      hipLaunchKernelGGL(eig_vupdate_kernel, dim3(p.npv, p.np / EP), dim3(256), 0, stream, V, p.np, p.nb, s, Rws,
+      hipLaunchKernelGGL(eig_pivot_kernel, dim3(p.npv), dim3(256), 0, stream, Aw, p.np, p.nb, s, Rws, Dws, rotated,
+                         ctrl, tol_rel, tol_abs, tol_conv, kMaxInner);
+      hipLaunchKernelGGL(eig_update_kernel, dim3(ntiles), dim3(256), 0, stream, Aw, p.np, p.nb, s, Rws, Dws, rotated,
                          ctrl);
+      hipLaunchKernelGGL(eig_vupdate_kernel, dim3(p.npv, p.np / EP), dim3(256), 0, stream, V, p.np, p.nb, s, Rws,
+                         rotated, ctrl);
     }
     hipLaunchKernelGGL(eig_sweep_end_kernel, dim3(1), dim3(1), 0, stream, ctrl);
   }

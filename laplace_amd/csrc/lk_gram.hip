@@ -26,6 +26,26 @@ namespace lk {
 enum { MODE_TN = 0, MODE_NT = 1, MODE_CONV = 2 };
 constexpr int MAX_SEG = 16;
 
+// Exact unsigned division of n < 2^31 by a run-time constant d >= 1 without a divide:
+// q = (n * M) >> (32 + s),  s = ceil(log2 d),  M = ceil(2^(32+s) / d)  (fits 34 bits; product < 2^64).
+struct FastDiv {
+  uint64_t M;
+  int s;
+  int d;
+};
+static FastDiv make_fastdiv(int d) {
+  FastDiv f;
+  f.d = d;
+  f.s = 0;
+  while ((1ll << f.s) < d) ++f.s;
+  const unsigned __int128 one = 1;
+  f.M = (uint64_t)(((one << (32 + f.s)) + (unsigned)d - 1) / (unsigned)d);
+  return f;
+}
+__device__ __forceinline__ int fdiv(int n, const FastDiv& f) {
+  return (int)(((uint64_t)(uint32_t)n * f.M) >> (32 + f.s));
+}
+
 struct GramGeom {
   const float* x;
   int64_t K;    // virtual rows
@@ -36,6 +56,7 @@ struct GramGeom {
   int nseg;     // NT: number of segments (1 = plain tensor)
   const float* seg[MAX_SEG];                          // NT: segment base pointers
   int H, W, Cin, OH, OW, kw, sh, sw, ph, pw, dh, dw;  // CONV
+  FastDiv div_ohw, div_ow;                             // CONV: row index -> (b, oh, ow)
 };
 
 template <bool SMALL>
@@ -129,11 +150,10 @@ __device__ __forceinline__ void load_panel(const GramGeom& g, int64_t k0, int ti
       valid = valid && (nt_base != nullptr) && (nt_l0 + krow < g.L);
       p = nt_base + cc.off[i] + krow;
     } else {
-      const int64_t k = k0 + krow;
-      const int ohw = g.OH * g.OW;
-      const int b = (int)(k / ohw);
-      const int r = (int)(k - (int64_t)b * ohw);
-      const int oh = r / g.OW, ow = r - oh * g.OW;
+      const int k = (int)k0 + krow;  // conv: K < 2^31 (checked on the host)
+      const int b = fdiv(k, g.div_ohw);
+      const int r = k - b * g.div_ohw.d;
+      const int oh = fdiv(r, g.div_ow), ow = r - oh * g.div_ow.d;
       const int ih = oh * g.sh + cc.dy[i];
       const int iw = ow * g.sw + cc.dx[i];
       valid = valid && (k < g.K) && (ih >= 0) && (ih < g.H) && (iw >= 0) && (iw < g.W);
@@ -212,7 +232,8 @@ __device__ __forceinline__ void compute_chunk(const float* __restrict__ pA, cons
 template <int MODE, int VEC, bool SMALL, bool FULL>
 __device__ __forceinline__ void gram_body(const GramGeom& g, float* __restrict__ smem, float* __restrict__ slab,
                                           int tid, int wm, int wn, int lo, int hi, bool diag, int colA, int colB,
-                                          int c_begin, int c_end, int am, int an) {
+                                          int c_begin, int c_end, int am, int an, float* __restrict__ Cdirect,
+                                          float alpha) {
   using C = Cfg<SMALL>;
   constexpr int PANEL = C::BK * C::LDP;
   constexpr int TW = C::TW;
@@ -262,6 +283,21 @@ __device__ __forceinline__ void gram_body(const GramGeom& g, float* __restrict__
     cur ^= 1;
   }
 
+  if (Cdirect != nullptr) {
+    // single split, upper-only accumulation: C += alpha * tile straight from the accumulators
+    // (32 consecutive columns per lane group = 128-byte segments); no slab, no reduce launch
+#pragma unroll
+    for (int tm = 0; tm < TW; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TW; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = colA + wm * C::WT + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          const int col = colB + wn * C::WT + tn * 32 + lo;
+          if ((FULL || (row < g.n && col < g.n))) Cdirect[(int64_t)row * g.n + col] += alpha * acc[tm][tn][r];
+        }
+    return;
+  }
   // epilogue: partial tile -> slab
 #pragma unroll
   for (int tm = 0; tm < TW; ++tm)
@@ -277,7 +313,8 @@ __device__ __forceinline__ void gram_body(const GramGeom& g, float* __restrict__
 
 template <int MODE, int VEC, bool SMALL>
 __global__ __launch_bounds__(256) void gram_kernel(GramGeom g, float* __restrict__ slabs, int nbt, int npairs,
-                                                   int chunks_per_split, int nchunks) {
+                                                   int chunks_per_split, int nchunks, float* __restrict__ Cdirect,
+                                                   float alpha) {
   using C = Cfg<SMALL>;
   constexpr int PANEL = C::BK * C::LDP;
   constexpr int TW = C::TW;
@@ -306,17 +343,32 @@ __global__ __launch_bounds__(256) void gram_kernel(GramGeom g, float* __restrict
 
   // Every wave executes the same number of barriers on either path.
   if (am == TW && an == TW) {
-    gram_body<MODE, VEC, SMALL, true>(g, smem, slab, tid, wm, wn, lo, hi, diag, colA, colB, c_begin, c_end, am, an);
+    gram_body<MODE, VEC, SMALL, true>(g, smem, slab, tid, wm, wn, lo, hi, diag, colA, colB, c_begin, c_end, am, an,
+                                      Cdirect, alpha);
   } else {
-    gram_body<MODE, VEC, SMALL, false>(g, smem, slab, tid, wm, wn, lo, hi, diag, colA, colB, c_begin, c_end, am, an);
+    gram_body<MODE, VEC, SMALL, false>(g, smem, slab, tid, wm, wn, lo, hi, diag, colA, colB, c_begin, c_end, am, an,
+                                       Cdirect, alpha);
   }
 }
 
 // Sum slabs, scale, accumulate into C, mirror off-diagonal tiles.
 // grid = (npairs, (T/64)^2 * (64/rpw)); each workgroup owns `rpw` rows x 64 cols of one tile.
-__global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restrict__ slabs, int nslabs, int npairs,
-                                                          int T, int nbt, float alpha, float* __restrict__ Cmat,
-                                                          int n, int mirror, int rpw) {
+// First level of a two-level slab reduction: group g sums slabs [g*SG, (g+1)*SG) into slab g*SG (in place).
+__global__ __launch_bounds__(256) void gram_prereduce_kernel(float* __restrict__ slabs, int nslabs, int64_t slab_elems,
+                                                             int SG) {
+  const int first = blockIdx.y * SG;
+  const int last = min(nslabs, first + SG);
+  for (int64_t idx = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; idx < slab_elems;
+       idx += (int64_t)gridDim.x * 256 * 4) {
+    f32x4 s = *reinterpret_cast<const f32x4*>(slabs + (int64_t)first * slab_elems + idx);
+    for (int k = first + 1; k < last; ++k) s += *reinterpret_cast<const f32x4*>(slabs + (int64_t)k * slab_elems + idx);
+    *reinterpret_cast<f32x4*>(slabs + (int64_t)first * slab_elems + idx) = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restrict__ slabs, int nslabs, int slab_stride,
+                                                          int npairs, int T, int nbt, float alpha,
+                                                          float* __restrict__ Cmat, int n, int mirror, int rpw) {
   __shared__ float tile[64][65];
   const int tid = threadIdx.x;
   int bi, bj;
@@ -333,7 +385,7 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restric
   for (int lr = ry; lr < rpw; lr += 4) {
     const float* p = slabs + (int64_t)blockIdx.x * tile_elems + (int64_t)(row0 + lr) * T + sc * 64 + cx;
     float s = 0.f;
-    for (int k = 0; k < nslabs; ++k) s += p[(int64_t)k * npairs * tile_elems];
+    for (int k = 0; k < nslabs; ++k) s += p[(int64_t)k * slab_stride * npairs * tile_elems];
     s *= alpha;
     const int r = bi * T + row0 + lr, c = bj * T + sc * 64 + cx;
     if (r < n && c < n) Cmat[(int64_t)r * n + c] += s;
@@ -391,9 +443,11 @@ static int launch_gram(const GramGeom& g, bool vec4, float alpha, float* C, unsi
   }
   float* slabs = static_cast<float*>(ws);
   dim3 grid(p.npairs, p.nsplit), block(256);
+  // one split + upper-only accumulation: the kernel adds into C itself (no slab round trip)
+  float* Cdirect = (p.nsplit == 1 && (flags & LK_GRAM_UPPER_ONLY)) ? C : nullptr;
 #define LK_LAUNCH(V, S)                                                                                     \
   hipLaunchKernelGGL((gram_kernel<MODE, V, S>), grid, block, 0, stream, g, slabs, p.nbt, p.npairs, \
-                     p.chunks_per_split, p.nchunks)
+                     p.chunks_per_split, p.nchunks, Cdirect, alpha)
   if (p.small) {
     if (vec4) LK_LAUNCH(4, true); else LK_LAUNCH(1, true);
   } else {
@@ -401,10 +455,22 @@ static int launch_gram(const GramGeom& g, bool vec4, float alpha, float* C, unsi
   }
 #undef LK_LAUNCH
   int rc = check_launch("gram_kernel");
-  if (rc) return rc;
+  if (rc || Cdirect != nullptr) return rc;
+  int nslabs = p.nslabs, stride = 1;
+  const int64_t slab_elems = (int64_t)p.npairs * p.T * p.T;
+  if (nslabs > 32) {  // two-level reduction keeps every thread's serial chain short
+    const int SG = 32;
+    const int groups = (nslabs + SG - 1) / SG;
+    int64_t bx = (slab_elems / 4 + 255) / 256;
+    if (bx > 2048) bx = 2048;
+    hipLaunchKernelGGL(gram_prereduce_kernel, dim3((unsigned)bx, groups), dim3(256), 0, stream, slabs, nslabs, slab_elems,
+                       SG);
+    nslabs = groups;
+    stride = SG;
+  }
   const int subs = p.T / 64;
-  hipLaunchKernelGGL(gram_reduce_kernel, dim3(p.npairs, subs * subs * (64 / p.rpw)), dim3(256), 0, stream, slabs,
-                     p.nslabs, p.npairs, p.T, p.nbt, alpha, C, g.n, (flags & LK_GRAM_UPPER_ONLY) ? 0 : 1, p.rpw);
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3(p.npairs, subs * subs * (64 / p.rpw)), dim3(256), 0, stream, slabs, nslabs,
+                     stride, p.npairs, p.T, p.nbt, alpha, C, g.n, (flags & LK_GRAM_UPPER_ONLY) ? 0 : 1, p.rpw);
   return check_launch("gram_reduce_kernel");
 }
 
@@ -521,6 +587,9 @@ extern "C" int lk_gram_conv_nhwc_f32(const float* x, int64_t B, int64_t H, int64
   g.x = x; g.n = (int)(Cin * kh * kw); g.K = B * OH * OW;
   g.H = (int)H; g.W = (int)W; g.Cin = (int)Cin; g.OH = (int)OH; g.OW = (int)OW; g.kw = kw;
   g.sh = sh; g.sw = sw; g.ph = ph; g.pw = pw; g.dh = dh; g.dw = dw;
+  LK_REQUIRE(g.K < (1ll << 31) - 64, "lk_gram_conv_nhwc_f32: B*OH*OW must be < 2^31");
+  g.div_ohw = make_fastdiv((int)(OH * OW));
+  g.div_ow = make_fastdiv((int)OW);
   const bool vec4 = (Cin % 4 == 0) && aligned16(x);
   return launch_gram<MODE_CONV>(g, vec4, alpha, C, flags, ws, ws_bytes, (hipStream_t)stream);
 }

@@ -256,7 +256,7 @@ class HipKronDecomposed(_KronDecomposedBase):
         """Raise (never ``exit()``, cf. utils/utils.py:208-222) if an eigensolve ran out of sweeps.
         Synchronises with the device; call it once after ``fit`` if a hard guarantee is wanted."""
         for info in self._eig_info:
-            if int(info.item()) != 0:
+            if int(info[0].item()) != 0:
                 raise RuntimeError("lk_syevj_f32: eigendecomposition did not converge")
 
     def detach(self):

@@ -113,7 +113,7 @@ class EmulatedKernels:
         w, Q = torch.linalg.eigh(Au)
         if clamp:
             w = w.clamp(min=0.0)
-        return torch.nan_to_num(w), torch.nan_to_num(Q), torch.zeros(1, dtype=torch.int32)
+        return torch.nan_to_num(w), torch.nan_to_num(Q), torch.zeros(2, dtype=torch.int32)
 
     # logdet
     def kron_logdet(self, l1, l2, delta, damping=False, want_grads=False):

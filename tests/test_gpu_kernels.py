@@ -228,7 +228,7 @@ def _eig_checks(K, A64, tol_rec=2e-5, tol_orth=2e-5, tol_val=2e-5):
     n = A64.shape[0]
     w, Q, info = K.syevj(A64.float().to(DEV).contiguous())
     _sync()
-    assert int(info.item()) == 0, "eigensolver did not converge"
+    assert int(info[0].item()) == 0, "eigensolver did not converge"
     w64, Q64 = w.double().cpu(), Q.double().cpu()
     wref = torch.linalg.eigvalsh(A64).clamp(min=0)
     scale = wref.abs().max().item() + 1e-30

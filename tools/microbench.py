@@ -92,7 +92,7 @@ if which in ("all", "eig"):
         t0 = time.time()
         torch.linalg.eigh(Ac)
         t_cpu = (time.time() - t0) * 1e3
-        rec_ = {"n": n, "ms": ms, "first_ms": first, "info": int(info.item()), "rec_err": rec, "orth_err": orth, "val_err": val,
+        rec_ = {"n": n, "ms": ms, "first_ms": first, "info": int(info[0].item()), "rec_err": rec, "orth_err": orth, "val_err": val,
                 "torch_eigh_gpu_ms": t_ref, "torch_eigh_cpu_ms": t_cpu}
         out["eig"].append(rec_)
         print(rec_, flush=True)
