@@ -47,6 +47,12 @@ const char* lk_last_error(void);
 int lk_softmax_hess_sqrt_f32(const float* f, const int64_t* y, int64_t B, int64_t C, float* S,
                              float* loss_accum, void* stream);
 
+/* Same contract with the rank-revealing root: the softmax Hessian has rank C-1, and its closed-form Cholesky
+ * factor  L[j][j] = sqrt(p_j s_{j+1}/s_j),  L[i][j] = -p_i sqrt(p_j/(s_j s_{j+1})) (i > j),  s_j = sum_{k>=j} p_k
+ * has only C-1 non-zero columns: S is [C-1][B][C] and the fit needs one reverse pass fewer.  2 <= C <= 4096. */
+int lk_softmax_hess_chol_f32(const float* f, const int64_t* y, int64_t B, int64_t C, float* S,
+                             float* loss_accum, void* stream);
+
 /* loss_accum[0] += scale * sum (f - y)^2 over `numel` elements (MSELoss(sum) * factor). */
 int lk_sq_err_sum_f32(const float* f, const float* y, int64_t numel, float scale, float* loss_accum,
                       void* stream);

@@ -34,6 +34,7 @@ SIGNATURES = {
     "lk_version": (_int, []),
     "lk_last_error": (ctypes.c_char_p, []),
     "lk_softmax_hess_sqrt_f32": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "lk_softmax_hess_chol_f32": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "lk_sq_err_sum_f32": (_int, [_vp, _vp, _i64, _f32, _vp, _vp]),
     "lk_gram_workspace_bytes": (_sz, [_i64, _i64]),
     "lk_gram_tn_f32": (_int, [_vp, _i64, _i64, _i64, _f32, _vp, _u32, _vp, _sz, _vp]),
@@ -146,9 +147,22 @@ class HipKernels:
             raise LaplaceHipError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
 
     # ---- likelihood ---------------------------------------------------------------------------
-    def softmax_hess_sqrt(self, f, y=None, loss_accum=None):
+    def softmax_hess_sqrt(self, f, y=None, loss_accum=None, cholesky=False):
+        """Columns of a root of ``diag(p) - p p^T`` as backward seeds ``[S, B, C]``: the symmetric root
+        (``S = C``) or, with ``cholesky=True``, the rank-revealing Cholesky root (``S = C - 1``)."""
         _check(f, "f")
         B, C = f.shape
+        if cholesky and 2 <= C <= 4096:
+            S = torch.empty(C - 1, B, C, dtype=torch.float32, device=f.device)
+            if y is not None:
+                _check(y, "y", torch.int64)
+            if loss_accum is not None:
+                _check(loss_accum, "loss_accum")
+            self._rc(
+                self.lib.lk_softmax_hess_chol_f32(_ptr(f), _ptr(y), B, C, _ptr(S), _ptr(loss_accum), self._stream(f.device)),
+                "lk_softmax_hess_chol_f32",
+            )
+            return S
         S = torch.empty(C, B, C, dtype=torch.float32, device=f.device)
         if y is not None:
             _check(y, "y", torch.int64)

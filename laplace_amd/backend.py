@@ -84,7 +84,8 @@ class _HipCurvatureMixin:
             eye = torch.eye(C, dtype=f.dtype, device=f.device)
             return eye[:, None, :].expand(C, B, C).contiguous(), 2.0  # d2/df2 MSELoss(sum) = 2 I
         yy = None if y is None else y.reshape(B).to(torch.int64).contiguous()
-        return K.softmax_hess_sqrt(f, yy, loss if y is not None else None), 1.0
+        # rank-revealing root: C-1 seeds (one reverse pass fewer); G / diag / full are root-invariant
+        return K.softmax_hess_sqrt(f, yy, loss if y is not None else None, cholesky=True), 1.0
 
     def _ef_seed(self, f, y, loss):
         """Gradient of the (unscaled, summed) torch loss w.r.t. f, ``[1, B, C]``; accumulates

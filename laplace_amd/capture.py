@@ -1,12 +1,13 @@
 """Extraction of per-layer inputs ``a`` and output gradients ``g`` from stock autograd.
 
 Host-side plumbing around the model (the model forward/backward stays PyTorch-ROCm): one forward
-with hooks on the supported modules, then ONE batched reverse pass (``is_grads_batched``) that
-delivers, for every seed (a column of the likelihood-Hessian root), the gradient w.r.t. every
-tapped module's *output* — no weight gradients are ever formed.  This replaces the C separate
-backward passes + second loss forward the reference's default backend performs
-(laplace/curvature/curvlinops.py:87-106) and the ``jacrev`` materialisation of
-laplace/curvature/curvature.py:88-129.
+with hooks on the supported modules, then reverse passes that deliver, for every seed (a column of
+the likelihood-Hessian root), the gradient w.r.t. every tapped module's *output* — no weight
+gradients are ever formed and there is no second forward for the loss (cf. the reference's default
+backend, laplace/curvature/curvlinops.py:87-106, and the ``jacrev`` materialisation of
+laplace/curvature/curvature.py:88-129).  Pure-Linear models use one vmapped pass
+(``is_grads_batched``); conv models run one pass per seed and hand the per-seed gradients to the
+Gram kernel unstacked.
 """
 from __future__ import annotations
 

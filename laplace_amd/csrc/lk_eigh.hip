@@ -26,7 +26,7 @@ constexpr int EP = 64;       // pivot size (two blocks)
 constexpr int ELD = 65;      // LDS pitch, conflict-free for column access
 
 struct EigCtrl {             // lives in the workspace
-  float scale;               // max |A_ii| at start (float)
+  float scale;               // max(max |A_ii|, power-iteration estimate of lambda_max)
   int rotations;             // rotations performed in the current sweep
   int converged;             // set when a sweep performed none
   int sweeps;                // completed sweeps
@@ -69,6 +69,35 @@ __global__ __launch_bounds__(256) void eig_init_kernel(const float* __restrict__
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
   if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(reinterpret_cast<int*>(&ctrl->scale), __float_as_int(mx));
+}
+
+// ---- spectral scale: a few power iterations give lambda_max to within a few per cent -----------------
+// (KFAC factors often have one dominant eigenvalue ~ n x the largest diagonal entry, so thresholds relative
+// to max|a_ii| would sit far below fp32 noise and cost many useless sweeps)
+__global__ __launch_bounds__(256) void eig_matvec_kernel(const float* __restrict__ A, int np,
+                                                         const float* __restrict__ x, float* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= np) return;
+  float s = 0.f;
+  for (int c = lane; c < np; c += 64) s += A[(int64_t)row * np + c] * x[c];
+  s = wave_sum(s);
+  if (lane == 0) y[row] = s;
+}
+// x <- y / ||y||, ctrl->scale <- max(ctrl->scale, ||y||)   (one workgroup)
+__global__ __launch_bounds__(256) void eig_normalize_kernel(const float* __restrict__ y, int np, float* __restrict__ x,
+                                                            EigCtrl* ctrl, int init) {
+  __shared__ float red[4];
+  if (init) {  // deterministic pseudo-random start vector, never orthogonal to a non-negative dominant vector
+    for (int i = threadIdx.x; i < np; i += 256) x[i] = 1.f + 0.25f * __sinf(0.7f * (float)i);
+    return;
+  }
+  float s = 0.f;
+  for (int i = threadIdx.x; i < np; i += 256) s += y[i] * y[i];
+  const float nrm = sqrtf(block_sum_256(s, red));
+  const float inv = nrm > 0.f ? 1.f / nrm : 0.f;
+  for (int i = threadIdx.x; i < np; i += 256) x[i] = y[i] * inv;
+  if (threadIdx.x == 0 && nrm > ctrl->scale && nrm < 3.0e38f) ctrl->scale = nrm;
 }
 
 // ---- 1. pivot solve -------------------------------------------------------------------------------
@@ -384,10 +413,22 @@ __global__ __launch_bounds__(256) void eig_gemm_kernel(const float* __restrict__
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lo = lane & 31, hi = lane >> 5, wm = wave >> 1, wn = wave & 1;
   const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
-  f32x16 acc;
+  // two-level accumulation: `acc` sums 256 consecutive k, `tot` sums the blocks -- a plain fp32 chain over
+  // n = 4608 terms of one sign (dominant eigenvector) would cost ~1e-5 of relative accuracy in the refinement
+  f32x16 acc, tot;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int r = 0; r < 16; ++r) {
+    acc[r] = 0.f;
+    tot[r] = 0.f;
+  }
   for (int k0 = 0; k0 < np; k0 += 16) {
+    if ((k0 & 255) == 0 && k0 != 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        tot[r] += acc[r];
+        acc[r] = 0.f;
+      }
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int idx = tid + 256 * e;
@@ -413,7 +454,7 @@ __global__ __launch_bounds__(256) void eig_gemm_kernel(const float* __restrict__
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = i0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi, col = j0 + wn * 32 + lo;
-    float v = alpha * acc[r];
+    float v = alpha * (tot[r] + acc[r]);
     if (D != nullptr) v += beta * D[(int64_t)row * np + col];
     C[(int64_t)row * np + col] = v;
   }
@@ -422,15 +463,15 @@ __global__ __launch_bounds__(256) void eig_gemm_kernel(const float* __restrict__
 // d[i] = sum_r V[r][i] * T[r][i]   (Rayleigh quotients v_i^T A v_i)
 __global__ __launch_bounds__(256) void eig_coldot_kernel(const float* __restrict__ V, const float* __restrict__ T,
                                                          int np, float* __restrict__ d) {
-  __shared__ float red[4][64];
+  __shared__ double red[4][64];
   const int col = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
-  float s = 0.f;
-  for (int r = part; r < np; r += 4) s += V[(int64_t)r * np + col] * T[(int64_t)r * np + col];
+  double s = 0.0;  // HBM-bound reduction: fp64 accumulation is free and keeps the Rayleigh quotient exact
+  for (int r = part; r < np; r += 4) s += (double)V[(int64_t)r * np + col] * (double)T[(int64_t)r * np + col];
   red[part][threadIdx.x & 63] = s;
   __syncthreads();
   if (part == 0) {
     const int c = threadIdx.x & 63;
-    d[col] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    d[col] = (float)((red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
   }
 }
 
@@ -504,6 +545,15 @@ extern "C" int lk_syevj_f32(const float* A, int64_t n, float* w, float* Q, int c
   int64_t blocks = ((int64_t)p.np * p.np + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(eig_init_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, A, (int)n, p.np, Aw, A0, V, ctrl);
+  {  // lambda_max estimate -> ctrl->scale (x, y live in the not-yet-used T buffer)
+    float* xv = T;
+    float* yv = T + p.np;
+    hipLaunchKernelGGL(eig_normalize_kernel, dim3(1), dim3(256), 0, stream, yv, p.np, xv, ctrl, 1);
+    for (int it = 0; it < 8; ++it) {
+      hipLaunchKernelGGL(eig_matvec_kernel, dim3((p.np + 3) / 4), dim3(256), 0, stream, A0, p.np, xv, yv);
+      hipLaunchKernelGGL(eig_normalize_kernel, dim3(1), dim3(256), 0, stream, yv, p.np, xv, ctrl, 0);
+    }
+  }
   const int steps = p.nb - 1;
   const int ntiles = p.npv * (p.npv + 1) / 2;
   for (int sweep = 0; sweep < max_sweeps; ++sweep) {

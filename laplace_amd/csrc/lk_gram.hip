@@ -11,6 +11,9 @@
 // split-K slices.  Every workgroup writes its partial tile to a workspace slab (deterministic, no
 // atomics); gram_reduce_kernel sums the slabs, scales by alpha, accumulates into C and mirrors the
 // off-diagonal tiles.  Tile configurations:
+//   WIDE  192x192 tile, BK=16, 4 waves as 2x2, each wave 3x3 MFMA 32x32x2 tiles (144 acc VGPRs): 48 flop
+//          per staged byte instead of 32 -- the global->LDS path (~10 B/clk/CU), not the MFMA pipe, is what
+//          limits the 128-tile; used when 192 | n (every 3x3-conv A factor of a ResNet: 576 ... 4608)
 //   BIG   128x128 tile, BK=16, 4 waves as 2x2, each wave 2x2 MFMA 32x32x2 tiles (64 acc VGPRs)
 //   SMALL  64x64  tile (n <= 64), BK=64, 4 waves as 2x2, each wave one 32x32 tile: tiny-n / huge-K
 //          factors (conv G with 64 channels) keep all four SIMDs busy through deep split-K.
@@ -59,22 +62,24 @@ struct GramGeom {
   FastDiv div_ohw, div_ow;                             // CONV: row index -> (b, oh, ow)
 };
 
-template <bool SMALL>
+enum { CFG_SMALL = 0, CFG_BIG = 1, CFG_WIDE = 2 };
+template <int CFG>
 struct Cfg {
-  static constexpr int T = SMALL ? 64 : 128;   // output tile edge
+  static constexpr bool SMALL = (CFG == CFG_SMALL);
+  static constexpr int TW = CFG + 1;           // MFMA 32x32 tiles per wave along each output dim (1 / 2 / 3)
+  static constexpr int WT = 32 * TW;           // wave tile edge
+  static constexpr int T = 2 * WT;             // output tile edge (64 / 128 / 192), 4 waves as 2x2
   static constexpr int BK = SMALL ? 64 : 16;   // virtual rows per chunk
   static constexpr int LDP = T + 4;            // LDS row pitch (floats), keeps 16-B alignment
   static constexpr int EPT = T * BK / 256;     // staged elements per thread per panel
-  static constexpr int TW = SMALL ? 1 : 2;     // MFMA 32x32 tiles per wave along each output dim
-  static constexpr int WT = 32 * TW;           // wave tile edge
 };
 
 // Linear staging index idx in [0, T*BK/VEC) -> (krow, col) of the first element.
 //   TN / CONV: consecutive idx walk along a row (columns are contiguous in memory)
 //   NT       : consecutive idx walk along k (positions are contiguous in memory)
-template <int MODE, int VEC, bool SMALL>
+template <int MODE, int VEC, int CFG>
 __device__ __forceinline__ void stage_coord(int idx, int& krow, int& col) {
-  using C = Cfg<SMALL>;
+  using C = Cfg<CFG>;
   if (MODE == MODE_NT) {
     constexpr int PER_COL = C::BK / VEC;
     col = idx / PER_COL;
@@ -87,21 +92,21 @@ __device__ __forceinline__ void stage_coord(int idx, int& krow, int& col) {
 }
 
 // Per-thread, per-panel column context, computed once before the K loop (no div/mod in the loop).
-template <int MODE, int VEC, bool SMALL>
+template <int MODE, int VEC, int CFG>
 struct ColCtx {
-  static constexpr int NL = Cfg<SMALL>::EPT / VEC;
+  static constexpr int NL = Cfg<CFG>::EPT / VEC;
   int64_t off[NL];     // TN: column; NT: column*L; CONV: ci
   int dy[NL], dx[NL];  // CONV: input offset of the patch element, padding folded in
   bool ok[NL];
 };
 
-template <int MODE, int VEC, bool SMALL>
-__device__ __forceinline__ void make_colctx(const GramGeom& g, int col0, int tid, ColCtx<MODE, VEC, SMALL>& cc) {
-  constexpr int NL = ColCtx<MODE, VEC, SMALL>::NL;
+template <int MODE, int VEC, int CFG>
+__device__ __forceinline__ void make_colctx(const GramGeom& g, int col0, int tid, ColCtx<MODE, VEC, CFG>& cc) {
+  constexpr int NL = ColCtx<MODE, VEC, CFG>::NL;
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
     int krow, col;
-    stage_coord<MODE, VEC, SMALL>(tid + 256 * i, krow, col);
+    stage_coord<MODE, VEC, CFG>(tid + 256 * i, krow, col);
     const int c = col0 + col;
     cc.ok[i] = c < g.n;
     cc.dy[i] = 0;
@@ -120,10 +125,10 @@ __device__ __forceinline__ void make_colctx(const GramGeom& g, int col0, int tid
   }
 }
 
-template <int MODE, int VEC, bool SMALL>
+template <int MODE, int VEC, int CFG>
 __device__ __forceinline__ void load_panel(const GramGeom& g, int64_t k0, int tid,
-                                           const ColCtx<MODE, VEC, SMALL>& cc, float (&st)[Cfg<SMALL>::EPT]) {
-  constexpr int NL = ColCtx<MODE, VEC, SMALL>::NL;
+                                           const ColCtx<MODE, VEC, CFG>& cc, float (&st)[Cfg<CFG>::EPT]) {
+  constexpr int NL = ColCtx<MODE, VEC, CFG>::NL;
   // chunk-uniform part (NT: a chunk never straddles images because Lp % BK == 0)
   const float* nt_base = nullptr;
   int nt_l0 = 0;
@@ -139,7 +144,7 @@ __device__ __forceinline__ void load_panel(const GramGeom& g, int64_t k0, int ti
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
     int krow, col;
-    stage_coord<MODE, VEC, SMALL>(tid + 256 * i, krow, col);
+    stage_coord<MODE, VEC, CFG>(tid + 256 * i, krow, col);
     bool valid = cc.ok[i];
     const float* p = g.x;
     if (MODE == MODE_TN) {
@@ -172,14 +177,14 @@ __device__ __forceinline__ void load_panel(const GramGeom& g, int64_t k0, int ti
   }
 }
 
-template <int MODE, int VEC, bool SMALL>
-__device__ __forceinline__ void store_panel(float* panel, int tid, const float (&st)[Cfg<SMALL>::EPT]) {
-  using C = Cfg<SMALL>;
+template <int MODE, int VEC, int CFG>
+__device__ __forceinline__ void store_panel(float* panel, int tid, const float (&st)[Cfg<CFG>::EPT]) {
+  using C = Cfg<CFG>;
   constexpr int NL = C::EPT / VEC;
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
     int krow, col;
-    stage_coord<MODE, VEC, SMALL>(tid + 256 * i, krow, col);
+    stage_coord<MODE, VEC, CFG>(tid + 256 * i, krow, col);
     if (VEC == 4 && MODE != MODE_NT) {
       f32x4 v = {st[i * 4], st[i * 4 + 1], st[i * 4 + 2], st[i * 4 + 3]};
       *reinterpret_cast<f32x4*>(panel + krow * C::LDP + col) = v;
@@ -205,10 +210,10 @@ __device__ __forceinline__ void pair_to_tiles(int p, int nbt, int& bi, int& bj) 
 
 // One chunk of MFMA work for this wave.  FULL: every 32x32 sub-tile of the wave is inside the matrix
 // (branch-free); otherwise (am, an) = number of active sub-tiles per dim, wave-uniform scalars.
-template <bool SMALL, bool FULL>
+template <int CFG, bool FULL>
 __device__ __forceinline__ void compute_chunk(const float* __restrict__ pA, const float* __restrict__ pB,
-                                              f32x16 (&acc)[Cfg<SMALL>::TW][Cfg<SMALL>::TW], int am, int an) {
-  using C = Cfg<SMALL>;
+                                              f32x16 (&acc)[Cfg<CFG>::TW][Cfg<CFG>::TW], int am, int an) {
+  using C = Cfg<CFG>;
   constexpr int TW = C::TW;
 #pragma unroll
   for (int kk = 0; kk < C::BK / 2; ++kk) {
@@ -229,15 +234,15 @@ __device__ __forceinline__ void compute_chunk(const float* __restrict__ pA, cons
 
 // Whole main loop + epilogue of one wave, specialised on FULL so that interior tiles get a branch-free
 // MFMA loop (the dispatch on `full` happens ONCE per wave, outside the loop).
-template <int MODE, int VEC, bool SMALL, bool FULL>
+template <int MODE, int VEC, int CFG, bool FULL>
 __device__ __forceinline__ void gram_body(const GramGeom& g, float* __restrict__ smem, float* __restrict__ slab,
                                           int tid, int wm, int wn, int lo, int hi, bool diag, int colA, int colB,
                                           int c_begin, int c_end, int am, int an, float* __restrict__ Cdirect,
                                           float alpha) {
-  using C = Cfg<SMALL>;
+  using C = Cfg<CFG>;
   constexpr int PANEL = C::BK * C::LDP;
   constexpr int TW = C::TW;
-  constexpr int NP = SMALL ? 1 : 2;
+  constexpr int NP = C::SMALL ? 1 : 2;
 
   f32x16 acc[TW][TW];
 #pragma unroll
@@ -247,16 +252,16 @@ __device__ __forceinline__ void gram_body(const GramGeom& g, float* __restrict__
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  ColCtx<MODE, VEC, SMALL> ccA, ccB;
-  make_colctx<MODE, VEC, SMALL>(g, colA, tid, ccA);
-  make_colctx<MODE, VEC, SMALL>(g, colB, tid, ccB);
+  ColCtx<MODE, VEC, CFG> ccA, ccB;
+  make_colctx<MODE, VEC, CFG>(g, colA, tid, ccA);
+  make_colctx<MODE, VEC, CFG>(g, colB, tid, ccB);
 
   float stA[C::EPT], stB[C::EPT];
   if (c_begin < c_end) {
-    load_panel<MODE, VEC, SMALL>(g, (int64_t)c_begin * C::BK, tid, ccA, stA);
-    if (!diag) load_panel<MODE, VEC, SMALL>(g, (int64_t)c_begin * C::BK, tid, ccB, stB);
-    store_panel<MODE, VEC, SMALL>(smem, tid, stA);
-    if (!diag) store_panel<MODE, VEC, SMALL>(smem + PANEL, tid, stB);
+    load_panel<MODE, VEC, CFG>(g, (int64_t)c_begin * C::BK, tid, ccA, stA);
+    if (!diag) load_panel<MODE, VEC, CFG>(g, (int64_t)c_begin * C::BK, tid, ccB, stB);
+    store_panel<MODE, VEC, CFG>(smem, tid, stA);
+    if (!diag) store_panel<MODE, VEC, CFG>(smem + PANEL, tid, stB);
   }
   __syncthreads();
 
@@ -268,16 +273,16 @@ __device__ __forceinline__ void gram_body(const GramGeom& g, float* __restrict__
   for (int c = c_begin; c < c_end; ++c) {
     const bool more = (c + 1) < c_end;
     if (more) {
-      load_panel<MODE, VEC, SMALL>(g, (int64_t)(c + 1) * C::BK, tid, ccA, stA);
-      if (!diag) load_panel<MODE, VEC, SMALL>(g, (int64_t)(c + 1) * C::BK, tid, ccB, stB);
+      load_panel<MODE, VEC, CFG>(g, (int64_t)(c + 1) * C::BK, tid, ccA, stA);
+      if (!diag) load_panel<MODE, VEC, CFG>(g, (int64_t)(c + 1) * C::BK, tid, ccB, stB);
     }
     const float* pA = smem + cur * NP * PANEL;
     const float* pB = diag ? pA : pA + PANEL;
-    compute_chunk<SMALL, FULL>(pA + offA, pB + offB, acc, am, an);
+    compute_chunk<CFG, FULL>(pA + offA, pB + offB, acc, am, an);
     if (more) {
       float* nx = smem + (cur ^ 1) * NP * PANEL;
-      store_panel<MODE, VEC, SMALL>(nx, tid, stA);
-      if (!diag) store_panel<MODE, VEC, SMALL>(nx + PANEL, tid, stB);
+      store_panel<MODE, VEC, CFG>(nx, tid, stA);
+      if (!diag) store_panel<MODE, VEC, CFG>(nx + PANEL, tid, stB);
     }
     __syncthreads();
     cur ^= 1;
@@ -311,14 +316,14 @@ __device__ __forceinline__ void gram_body(const GramGeom& g, float* __restrict__
       }
 }
 
-template <int MODE, int VEC, bool SMALL>
+template <int MODE, int VEC, int CFG>
 __global__ __launch_bounds__(256) void gram_kernel(GramGeom g, float* __restrict__ slabs, int nbt, int npairs,
                                                    int chunks_per_split, int nchunks, float* __restrict__ Cdirect,
                                                    float alpha) {
-  using C = Cfg<SMALL>;
+  using C = Cfg<CFG>;
   constexpr int PANEL = C::BK * C::LDP;
   constexpr int TW = C::TW;
-  constexpr int NP = SMALL ? 1 : 2;  // SMALL has a single (diagonal) tile: the B panel aliases A
+  constexpr int NP = C::SMALL ? 1 : 2;  // SMALL has a single (diagonal) tile: the B panel aliases A
   __shared__ __attribute__((aligned(16))) float smem[2 * NP * PANEL];  // [buf][panel A|B]
 
   const int tid = threadIdx.x;
@@ -327,7 +332,7 @@ __global__ __launch_bounds__(256) void gram_kernel(GramGeom g, float* __restrict
   const int lo = lane & 31, hi = lane >> 5;
   int bi, bj;
   pair_to_tiles(blockIdx.x, nbt, bi, bj);
-  const bool diag = SMALL || (bi == bj);
+  const bool diag = C::SMALL || (bi == bj);
   const int colA = bi * C::T, colB = bj * C::T;
   const int wm = wave >> 1, wn = wave & 1;
 
@@ -343,10 +348,10 @@ __global__ __launch_bounds__(256) void gram_kernel(GramGeom g, float* __restrict
 
   // Every wave executes the same number of barriers on either path.
   if (am == TW && an == TW) {
-    gram_body<MODE, VEC, SMALL, true>(g, smem, slab, tid, wm, wn, lo, hi, diag, colA, colB, c_begin, c_end, am, an,
+    gram_body<MODE, VEC, CFG, true>(g, smem, slab, tid, wm, wn, lo, hi, diag, colA, colB, c_begin, c_end, am, an,
                                       Cdirect, alpha);
   } else {
-    gram_body<MODE, VEC, SMALL, false>(g, smem, slab, tid, wm, wn, lo, hi, diag, colA, colB, c_begin, c_end, am, an,
+    gram_body<MODE, VEC, CFG, false>(g, smem, slab, tid, wm, wn, lo, hi, diag, colA, colB, c_begin, c_end, am, an,
                                        Cdirect, alpha);
   }
 }
@@ -402,26 +407,44 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restric
 }
 
 struct GramPlan {
-  bool small;
+  int cfg;
   int T, BK, nbt, npairs, nchunks, nsplit, chunks_per_split, nslabs, rpw;
   size_t ws_bytes;
 };
 
 static GramPlan make_plan(int64_t n, int64_t K) {
   GramPlan p;
-  p.small = n <= 64;
-  p.T = p.small ? 64 : 128;
-  p.BK = p.small ? 64 : 16;
+  // WIDE pays where the 128-tile wastes an edge tile (n = 576 = 4.5 x 128 = 3 x 192); at n >= 1152 its single
+  // resident workgroup per CU (348 registers) loses to BIG's three (measured: profiles/r01_microbench_gram_*)
+  p.cfg = n <= 64 ? CFG_SMALL : ((n % 192 == 0 && n >= 576 && n <= 768) ? CFG_WIDE : CFG_BIG);
+  p.T = p.cfg == CFG_SMALL ? 64 : (p.cfg == CFG_BIG ? 128 : 192);
+  p.BK = p.cfg == CFG_SMALL ? 64 : 16;
   p.nbt = (int)((n + p.T - 1) / p.T);
   p.npairs = p.nbt * (p.nbt + 1) / 2;
   p.nchunks = (int)((K + p.BK - 1) / p.BK);
   if (p.nchunks < 1) p.nchunks = 1;
-  // fill the chip (256 CUs x 4 resident workgroups) but keep >= 8 chunks per slice
-  int want = (1024 + p.npairs - 1) / p.npairs;
-  int cap = p.nchunks / 8;
+  // Split-K selection: workgroups run in "rounds" of (256 CUs x resident workgroups per CU); choose the split
+  // count that minimises  rounds x (chunks per split + fixed per-workgroup overhead)  -- a launch of 1026
+  // workgroups on 768 slots costs two full rounds (PMC: 83 % CU residency before this rule).
+  const int occ = p.cfg == CFG_WIDE ? 1 : (p.cfg == CFG_BIG ? 3 : 4);
+  const int slots = 256 * occ;
+  int cap = p.nchunks / 4;
   if (cap < 1) cap = 1;
-  p.nsplit = want < cap ? want : cap;
-  if (p.nsplit > 1024) p.nsplit = 1024;
+  if (cap > 1024) cap = 1024;
+  const int overhead = p.cfg == CFG_SMALL ? 1 : 3;  // prologue + epilogue in units of one chunk
+  long best_cost = -1;
+  p.nsplit = 1;
+  for (int s = 1; s <= cap; ++s) {
+    const long wgs = (long)p.npairs * s;
+    const long rounds = (wgs + slots - 1) / slots;
+    const long cps = (p.nchunks + s - 1) / s;
+    const long cost = rounds * (cps + overhead);
+    if (best_cost < 0 || cost < best_cost) {
+      best_cost = cost;
+      p.nsplit = s;
+    }
+    if (wgs > 4L * slots) break;
+  }
   p.chunks_per_split = (p.nchunks + p.nsplit - 1) / p.nsplit;
   p.nsplit = (p.nchunks + p.chunks_per_split - 1) / p.chunks_per_split;
   p.nslabs = p.nsplit;
@@ -448,10 +471,12 @@ static int launch_gram(const GramGeom& g, bool vec4, float alpha, float* C, unsi
 #define LK_LAUNCH(V, S)                                                                                     \
   hipLaunchKernelGGL((gram_kernel<MODE, V, S>), grid, block, 0, stream, g, slabs, p.nbt, p.npairs, \
                      p.chunks_per_split, p.nchunks, Cdirect, alpha)
-  if (p.small) {
-    if (vec4) LK_LAUNCH(4, true); else LK_LAUNCH(1, true);
+  if (p.cfg == CFG_SMALL) {
+    if (vec4) LK_LAUNCH(4, CFG_SMALL); else LK_LAUNCH(1, CFG_SMALL);
+  } else if (p.cfg == CFG_BIG) {
+    if (vec4) LK_LAUNCH(4, CFG_BIG); else LK_LAUNCH(1, CFG_BIG);
   } else {
-    if (vec4) LK_LAUNCH(4, false); else LK_LAUNCH(1, false);
+    if (vec4) LK_LAUNCH(4, CFG_WIDE); else LK_LAUNCH(1, CFG_WIDE);
   }
 #undef LK_LAUNCH
   int rc = check_launch("gram_kernel");

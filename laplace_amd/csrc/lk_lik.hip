@@ -42,6 +42,59 @@ __global__ __launch_bounds__(256) void softmax_hess_sqrt_kernel(const float* __r
   }
 }
 
+// Rank-revealing root with C-1 columns (the softmax Hessian has rank C-1): the closed-form Cholesky factor
+//   L[j][j] = sqrt(p_j s_{j+1} / s_j),  L[i][j] = -p_i sqrt(p_j / (s_j s_{j+1}))  (i > j),  s_j = sum_{k>=j} p_k,
+// L L^T = diag(p) - p p^T exactly; one reverse pass fewer than the symmetric root.  S[c][n][i] = L_n[i][c].
+__global__ __launch_bounds__(256) void softmax_hess_chol_kernel(const float* __restrict__ f,
+                                                                const int64_t* __restrict__ y, int B, int C,
+                                                                float* __restrict__ S,
+                                                                float* __restrict__ loss_accum) {
+  extern __shared__ float dyn[];  // per wave: p[C], s[C+1]
+  __shared__ float red[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* p = dyn + wave * (2 * C + 1);
+  float* sfx = p + C;
+  const int n = blockIdx.x * 4 + wave;
+  float nll = 0.f;
+  if (n < B) {
+    const float* fr = f + (int64_t)n * C;
+    float m = -INFINITY;
+    for (int j = lane; j < C; j += 64) m = fmaxf(m, fr[j]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    float z = 0.f;
+    for (int j = lane; j < C; j += 64) z += expf(fr[j] - m);
+    z = wave_sum(z);
+    const float logz = logf(z) + m;
+    if (y != nullptr && lane == 0) nll = logz - fr[y[n]];
+    for (int j = lane; j < C; j += 64) p[j] = expf(fr[j] - logz);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {  // suffix sums of positive numbers (C is small)
+      float acc = 0.f;
+      sfx[C] = 0.f;
+      for (int j = C - 1; j >= 0; --j) {
+        acc += p[j];
+        sfx[j] = acc;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int c = 0; c < C - 1; ++c) {
+      const float pc = p[c], sc = sfx[c], sn = sfx[c + 1];
+      const bool ok = (sn > 0.f) && (sc > 0.f);
+      // factored so that nothing under/overflows for nearly one-hot rows: p_i <= s_{c+1} <= s_c <= 1
+      const float r0 = ok ? sqrtf(pc / sc) : 0.f;   // <= 1
+      const float dg = r0 * sqrtf(sn);
+      const float rs = ok ? rsqrtf(sn) : 0.f;
+      float* out = S + ((int64_t)c * B + n) * C;
+      for (int i = lane; i < C; i += 64) out[i] = (i < c) ? 0.f : (i == c ? dg : -(p[i] * rs) * r0);
+    }
+  }
+  if (loss_accum != nullptr && y != nullptr) {
+    const float tot = block_sum_256(nll, red);
+    if (threadIdx.x == 0) atomicAdd(loss_accum, tot);
+  }
+}
+
 __global__ __launch_bounds__(256) void sq_err_sum_kernel(const float* __restrict__ f, const float* __restrict__ y,
                                                          int64_t numel, float scale,
                                                          float* __restrict__ loss_accum) {
@@ -66,6 +119,16 @@ extern "C" int lk_softmax_hess_sqrt_f32(const float* f, const int64_t* y, int64_
   hipLaunchKernelGGL(softmax_hess_sqrt_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, f, y,
                      (int)B, (int)C, S, loss_accum);
   return check_launch("softmax_hess_sqrt_kernel");
+}
+
+extern "C" int lk_softmax_hess_chol_f32(const float* f, const int64_t* y, int64_t B, int64_t C, float* S,
+                                        float* loss_accum, void* stream) {
+  LK_REQUIRE(f && S && B >= 0 && C >= 2 && B < (1ll << 31) && C <= 4096, "lk_softmax_hess_chol_f32: bad arguments");
+  if (B == 0) return LK_OK;
+  const size_t lds = (size_t)4 * (2 * C + 1) * sizeof(float);
+  hipLaunchKernelGGL(softmax_hess_chol_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), lds, (hipStream_t)stream, f, y,
+                     (int)B, (int)C, S, loss_accum);
+  return check_launch("softmax_hess_chol_kernel");
 }
 
 extern "C" int lk_sq_err_sum_f32(const float* f, const float* y, int64_t numel, float scale, float* loss_accum,

@@ -12,8 +12,9 @@ from torch import nn
 
 
 class BasicBlock(nn.Module):
-    def __init__(self, cin: int, cout: int, stride: int):
+    def __init__(self, cin: int, cout: int, stride: int, act=torch.relu):
         super().__init__()
+        self.act = act
         self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
         self.bn1 = nn.BatchNorm2d(cout)
         self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
@@ -23,19 +24,25 @@ class BasicBlock(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
 
     def forward(self, x):
-        out = torch.relu(self.bn1(self.conv1(x)))
+        out = self.act(self.bn1(self.conv1(x)))
         out = self.bn2(self.conv2(out))
-        return torch.relu(out + (x if self.downsample is None else self.downsample(x)))
+        return self.act(out + (x if self.downsample is None else self.downsample(x)))
 
 
 class ResNet18(nn.Module):
-    def __init__(self, num_classes: int = 10, freeze_bn: bool = True):
+    """``act`` defaults to ReLU (the benchmark model).  Tests that compare two *separately executed*
+    forward/backward passes use a smooth activation: with ReLU, fp32 rounding differences between MIOpen
+    solvers flip a handful of pre-activations that sit within 1e-6 of zero, which changes individual
+    gradients by O(1) and is a property of the host framework, not of the curvature kernels."""
+
+    def __init__(self, num_classes: int = 10, freeze_bn: bool = True, act=torch.relu):
         super().__init__()
+        self.act = act
         self.conv1 = nn.Conv2d(3, 64, 3, 1, 1, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
         blocks, cin = [], 64
         for cout, stride in ((64, 1), (64, 1), (128, 2), (128, 1), (256, 2), (256, 1), (512, 2), (512, 1)):
-            blocks.append(BasicBlock(cin, cout, stride))
+            blocks.append(BasicBlock(cin, cout, stride, act))
             cin = cout
         self.layers = nn.Sequential(*blocks)
         self.pool = nn.AdaptiveAvgPool2d(1)
@@ -47,7 +54,7 @@ class ResNet18(nn.Module):
                     m.bias.requires_grad_(False)
 
     def forward(self, x):
-        x = torch.relu(self.bn1(self.conv1(x)))
+        x = self.act(self.bn1(self.conv1(x)))
         x = self.layers(x)
         return self.fc(torch.flatten(self.pool(x), 1))
 

@@ -16,8 +16,23 @@ class EmulatedKernels:
     name = "emulated-cpu"
 
     # likelihood
-    def softmax_hess_sqrt(self, f, y=None, loss_accum=None):
+    def softmax_hess_sqrt(self, f, y=None, loss_accum=None, cholesky=False):
         p = torch.softmax(f, dim=-1)
+        if cholesky and f.shape[1] >= 2:
+            B, C = p.shape
+            sfx = torch.flip(torch.cumsum(torch.flip(p, [1]), 1), [1])  # s_j = sum_{k>=j} p_k
+            sfx = torch.cat([sfx, torch.zeros(B, 1, dtype=p.dtype)], 1)
+            S = torch.zeros(C - 1, B, C, dtype=p.dtype)
+            for c in range(C - 1):
+                sc, sn = sfx[:, c], sfx[:, c + 1]
+                ok = (sn > 0) & (sc > 0)
+                r0 = torch.where(ok, torch.sqrt(p[:, c] / sc.clamp_min(1e-300)), torch.zeros_like(sc))
+                rs = torch.where(ok, 1.0 / torch.sqrt(sn.clamp_min(1e-300)), torch.zeros_like(sc))
+                S[c, :, c] = r0 * torch.sqrt(sn)
+                S[c, :, c + 1:] = -(p[:, c + 1:] * rs[:, None]) * r0[:, None]
+            if y is not None and loss_accum is not None:
+                loss_accum += -torch.log_softmax(f, -1).gather(1, y.view(-1, 1)).sum()
+            return S
         sp = p.sqrt()
         S = torch.diag_embed(sp) - p.unsqueeze(2) * sp.unsqueeze(1)  # [B, j, c]
         if y is not None and loss_accum is not None:

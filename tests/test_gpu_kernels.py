@@ -46,6 +46,13 @@ def assert_close(got, want, tol=1e-4, what=""):
     assert e < tol, f"{what}: rel err {e:.3e} >= {tol}"
 
 
+def _sum_others(p):
+    """sum_{k != i} p_k without forming 1 - p_i"""
+    C = p.shape[1]
+    mask = 1.0 - torch.eye(C, dtype=p.dtype)
+    return p @ mask
+
+
 def rnd(*shape, seed=0):
     g = torch.Generator().manual_seed(seed)
     return torch.randn(*shape, generator=g, dtype=torch.float64)
@@ -155,6 +162,27 @@ def test_softmax_hess_sqrt(K, B, C):
     S = got.permute(1, 2, 0).double().cpu()  # [B, j, c]
     p = torch.softmax(f, -1)
     assert_close(S @ S.transpose(1, 2), torch.diag_embed(p) - p.unsqueeze(2) * p.unsqueeze(1), tol=1e-5)
+
+
+@pytest.mark.parametrize("B,C", [(1, 2), (10, 2), (257, 10), (33, 100), (5, 3)])
+def test_softmax_hess_cholesky_root(K, B, C):
+    f = rnd(B, C, seed=B) * 4
+    f[0, 0] = 60.0  # one nearly one-hot row: vanishing tail sums
+    y = torch.randint(C, (B,), generator=torch.Generator().manual_seed(1))
+    la = torch.zeros(1, dtype=torch.float64)
+    want = EMU.softmax_hess_sqrt(f, y, la, cholesky=True)
+    lg = torch.zeros(1, device=DEV)
+    got = K.softmax_hess_sqrt(f.float().to(DEV), y.to(DEV), lg, cholesky=True)
+    assert got.shape == (C - 1, B, C)
+    assert_close(got, want, tol=1e-5, what="Cholesky root")
+    assert_close(lg, la, tol=1e-5, what="CE loss")
+    S = got.permute(1, 2, 0).double().cpu()
+    p = torch.softmax(f, -1)
+    # cancellation-free reference: Lambda_ii = p_i * sum_{k != i} p_k  (1 - p_i rounds to 0 for one-hot rows)
+    others = p.sum(1, keepdim=True) - p
+    Lam = -p.unsqueeze(2) * p.unsqueeze(1)
+    Lam[:, torch.arange(C), torch.arange(C)] = p * torch.where(others > 1e-3, others, _sum_others(p))
+    assert_close(S @ S.transpose(1, 2), Lam, tol=1e-5, what="L L^T")
 
 
 def test_sq_err_sum(K):
