@@ -198,6 +198,7 @@ def main():
         ms_c, work_c, n_c = agg("gram_conv")
         ms_n, work_n, n_n = agg("gram_nt")
         ms_t, work_t, n_t = agg("gram_tn")
+        ms_s, work_s, n_s = agg("shiftcorr")
         ach = work_c / (ms_c * 1e-3) / 1e12 if ms_c > 0 else 0.0
         result = {
             "metric": "KFAC-GGN fit samples/sec, ResNet-18",
@@ -224,6 +225,7 @@ def main():
             },
             "kernel_time_ms_per_step": {"gram_conv": ms_c / prof_steps, "gram_nt": ms_n / prof_steps,
                                         "gram_tn": ms_t / prof_steps,
+                                        "conv3x3_shiftcorr": ms_s / prof_steps,
                                         "gram_nt_tflops_sym": work_n / (ms_n * 1e-3) / 1e12 if ms_n else None},
         }
     # ---- untimed extras on rank 0 (separate line items per BASELINE.md) --------------------------------------

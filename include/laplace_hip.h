@@ -85,6 +85,16 @@ int lk_gram_conv_nhwc_f32(const float* x, int64_t B, int64_t H, int64_t W, int64
                           int sh, int sw, int ph, int pw, int dh, int dw, float alpha, float* C,
                           unsigned flags, void* ws, size_t ws_bytes, void* stream);
 
+/* Same result as lk_gram_conv_nhwc_f32 for a 3x3 / stride 1 / padding 1 / dilation 1 convolution, through the
+ * shift-correlation identity (the input grid equals the output grid, so the 81 (offset, offset) blocks of the
+ * patch Gram matrix depend only on the 25 offset differences plus boundary-strip corrections):
+ *   C[(d,ci),(e,cj)] += alpha * ( R[e-d] - Row_d[e-d] - Col_d[e-d] + Pix_d[e-d] )[ci][cj]
+ * 13 full-grid channel correlations (R[-D] = R[D]^T) instead of the 40.5 block products of the symmetric half.
+ * C is written in the native (kh,kw,ci) order, both triangles.  H, W >= 2. */
+size_t lk_conv3x3_shiftcorr_workspace_bytes(int64_t B, int64_t H, int64_t W, int64_t Cin);
+int lk_conv3x3_shiftcorr_f32(const float* x, int64_t B, int64_t H, int64_t W, int64_t Cin, float alpha, float* C,
+                             void* ws, size_t ws_bytes, void* stream);
+
 /* dst[b][h][w][c] = src[b][c][h][w]  (NCHW -> NHWC staging for lk_gram_conv_nhwc_f32). */
 int lk_nchw_to_nhwc_f32(const float* src, int64_t B, int64_t C, int64_t HW, float* dst, void* stream);
 

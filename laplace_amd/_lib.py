@@ -44,6 +44,8 @@ SIGNATURES = {
         _int,
         [_vp, _i64, _i64, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _int, _f32, _vp, _u32, _vp, _sz, _vp],
     ),
+    "lk_conv3x3_shiftcorr_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
+    "lk_conv3x3_shiftcorr_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _f32, _vp, _vp, _sz, _vp]),
     "lk_nchw_to_nhwc_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "lk_symmetrize_f32": (_int, [_vp, _i64, _vp]),
     "lk_permute_sym_f32": (_int, [_vp, _i64, _i64, _vp, _int, _vp]),
@@ -116,6 +118,8 @@ class HipKernels:
         self._ws: dict = {}
         # optional per-launch timing (bench.py's roofline leg): name -> list of (start_evt, end_evt, work)
         self.profile: Optional[dict] = None
+        # 3x3/stride-1 conv A factors through the shift-correlation identity (lk_conv3x3_shiftcorr_f32)
+        self.use_shiftcorr = os.environ.get("LK_SHIFTCORR", "1") != "0"
 
     def _timed(self, name: str, work: float, dev, call):
         """Run ``call()``; when profiling is on, bracket it with HIP events on the launch stream."""
@@ -252,6 +256,20 @@ class HipKernels:
         xh = self.nchw_to_nhwc(x)
         direct = native or kh * kw == 1
         tgt = out if direct else torch.zeros(n, n, dtype=torch.float32, device=x.device)
+        if self.use_shiftcorr and (kh, kw, sh, sw, ph, pw, dh, dw) == (3, 3, 1, 1, 1, 1, 1, 1) and H * W >= 256 and B > 0:
+            # 3x3 / stride 1 / pad 1 on maps >= 16x16: 13 shift correlations + boundary strips instead of 81 patch
+            # blocks (measured 1.7x at 32x32, 1.2x at 16x16, a loss at 8x8: profiles/r01_microbench_gram_v4.txt)
+            nb = self.lib.lk_conv3x3_shiftcorr_workspace_bytes(B, H, W, Cin)
+            ws = self._workspace(nb, x.device)
+            self._rc(
+                self._timed("shiftcorr", float(B * H * W) * n * (n + 1), x.device, lambda: self.lib.lk_conv3x3_shiftcorr_f32(
+                    _ptr(xh), B, H, W, Cin, float(alpha), _ptr(tgt), _ptr(ws), ws.numel(), self._stream(x.device))),
+                "lk_conv3x3_shiftcorr_f32",
+            )
+            if not direct:
+                self._rc(self.lib.lk_permute_sym_f32(_ptr(tgt), Cin, kh * kw, _ptr(out), 1, self._stream(x.device)),
+                         "lk_permute_sym_f32")
+            return out
         nb = self.lib.lk_gram_workspace_bytes(n, max(B * OH * OW, 1))
         ws = self._workspace(nb, x.device)
         self._rc(

@@ -139,6 +139,24 @@ __global__ __launch_bounds__(256) void eig_pivot_kernel(float* __restrict__ Aw, 
   }
   __syncthreads();
 
+  // quick exit: if no off-diagonal element of the pivot is above its rotation threshold, R_P = I and the 63-step
+  // sweep (two barriers per step) would only re-check what this single pass establishes -- the common case in the
+  // last sweeps, when most pivots are already diagonal
+  {
+    int any = 0;
+    for (int idx = tid; idx < EP * EP; idx += 256) {
+      const int r = idx >> 6, c = idx & 63;
+      if (r < c) {
+        const float mag = fabsf(S[r][c]);
+        any |= (mag > floor_abs) && (mag > tol_rel * sqrtf(fabsf(S[r][r] * S[c][c])));
+      }
+    }
+    if (!__syncthreads_or(any)) {
+      if (tid == 0) rotated[blockIdx.x] = 0;
+      return;
+    }
+  }
+
   for (int sw = 0; sw < max_inner; ++sw) {
     for (int t = 0; t < EP - 1; ++t) {
       // (a) rotation parameters of the 32 disjoint pairs of this step (first half of wave 0)
@@ -535,7 +553,7 @@ extern "C" int lk_syevj_f32(const float* A, int64_t n, float* w, float* Q, int c
   const int kMaxInner = 3;         // inner sweeps per pivot visit (the outer sweeps finish the job)
   const float tol_rel = 3.0e-7f;   // ~2.5 eps: |a_pq| <= tol_rel*sqrt(|a_pp a_qq|) counts as annihilated
   const float tol_abs = 6.0e-8f;   // x max|a_ii|: absolute floor for (numerically) rank-deficient factors
-  const float tol_conv = 2.0e-6f;  // x max|a_ii|: only rotations of larger elements keep the solve "unconverged";
+  const float tol_conv = 1.0e-6f;  // x max|a_ii|: only rotations of larger elements keep the solve "unconverged";
                                    // what is left below it is removed from the spectrum by the Rayleigh refinement
 
   if (hipMemsetAsync(ctrl, 0, sizeof(EigCtrl), stream) != hipSuccess) {

@@ -26,7 +26,7 @@
 
 namespace lk {
 
-enum { MODE_TN = 0, MODE_NT = 1, MODE_CONV = 2 };
+enum { MODE_TN = 0, MODE_NT = 1, MODE_CONV = 2, MODE_XCORR = 3 };
 constexpr int MAX_SEG = 16;
 
 // Exact unsigned division of n < 2^31 by a run-time constant d >= 1 without a divide:
@@ -60,6 +60,12 @@ struct GramGeom {
   const float* seg[MAX_SEG];                          // NT: segment base pointers
   int H, W, Cin, OH, OW, kw, sh, sw, ph, pw, dh, dw;  // CONV
   FastDiv div_ohw, div_ow;                             // CONV: row index -> (b, oh, ow)
+  // XCORR: rectangular  R[ci][(s, cj)] = sum_{b, q in region} x[b, q, ci] * x~[b, q + shift_s, cj]   (NHWC, x~ = x
+  // zero-extended); rows enumerate (b, q) over the region [reg_h0, reg_h0+reg_h) x [reg_w0, reg_w0+reg_w)
+  int nA, nB;                    // output rows (Cin) and columns (nshift * Cin)
+  int reg_h0, reg_w0, reg_h, reg_w;
+  signed char sdy[25], sdx[25];  // shift table
+  FastDiv div_reg, div_regw;     // row -> (b, r), r -> (rh, rw)
 };
 
 enum { CFG_SMALL = 0, CFG_BIG = 1, CFG_WIDE = 2 };
@@ -101,17 +107,29 @@ struct ColCtx {
 };
 
 template <int MODE, int VEC, int CFG>
-__device__ __forceinline__ void make_colctx(const GramGeom& g, int col0, int tid, ColCtx<MODE, VEC, CFG>& cc) {
+__device__ __forceinline__ void make_colctx(const GramGeom& g, int col0, int tid, bool isB,
+                                            ColCtx<MODE, VEC, CFG>& cc) {
   constexpr int NL = ColCtx<MODE, VEC, CFG>::NL;
+  const int ncols = (MODE == MODE_XCORR) ? (isB ? g.nB : g.nA) : g.n;
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
     int krow, col;
     stage_coord<MODE, VEC, CFG>(tid + 256 * i, krow, col);
     const int c = col0 + col;
-    cc.ok[i] = c < g.n;
+    cc.ok[i] = c < ncols;
     cc.dy[i] = 0;
     cc.dx[i] = 0;
-    if (MODE == MODE_TN) {
+    if (MODE == MODE_XCORR) {
+      int sidx = 0, ch = c;
+      if (isB) {
+        sidx = c / g.Cin;
+        ch = c - sidx * g.Cin;
+        if (sidx > 24) sidx = 24;  // only reachable for padded (invalid) columns
+        cc.dy[i] = g.sdy[sidx];
+        cc.dx[i] = g.sdx[sidx];
+      }
+      cc.off[i] = ch;
+    } else if (MODE == MODE_TN) {
       cc.off[i] = c;
     } else if (MODE == MODE_NT) {
       cc.off[i] = (int64_t)c * g.L;
@@ -154,6 +172,15 @@ __device__ __forceinline__ void load_panel(const GramGeom& g, int64_t k0, int ti
     } else if (MODE == MODE_NT) {
       valid = valid && (nt_base != nullptr) && (nt_l0 + krow < g.L);
       p = nt_base + cc.off[i] + krow;
+    } else if (MODE == MODE_XCORR) {
+      const int k = (int)k0 + krow;
+      const int b = fdiv(k, g.div_reg);
+      const int r = k - b * g.div_reg.d;
+      const int rh = fdiv(r, g.div_regw), rw = r - rh * g.div_regw.d;
+      const int ih = g.reg_h0 + rh + cc.dy[i];
+      const int iw = g.reg_w0 + rw + cc.dx[i];
+      valid = valid && (k < g.K) && (ih >= 0) && (ih < g.H) && (iw >= 0) && (iw < g.W);
+      p = g.x + (((int64_t)b * g.H + ih) * g.W + iw) * g.Cin + cc.off[i];
     } else {
       const int k = (int)k0 + krow;  // conv: K < 2^31 (checked on the host)
       const int b = fdiv(k, g.div_ohw);
@@ -242,7 +269,7 @@ __device__ __forceinline__ void gram_body(const GramGeom& g, float* __restrict__
   using C = Cfg<CFG>;
   constexpr int PANEL = C::BK * C::LDP;
   constexpr int TW = C::TW;
-  constexpr int NP = C::SMALL ? 1 : 2;
+  constexpr int NP = (C::SMALL && MODE != MODE_XCORR) ? 1 : 2;
 
   f32x16 acc[TW][TW];
 #pragma unroll
@@ -253,8 +280,8 @@ __device__ __forceinline__ void gram_body(const GramGeom& g, float* __restrict__
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   ColCtx<MODE, VEC, CFG> ccA, ccB;
-  make_colctx<MODE, VEC, CFG>(g, colA, tid, ccA);
-  make_colctx<MODE, VEC, CFG>(g, colB, tid, ccB);
+  make_colctx<MODE, VEC, CFG>(g, colA, tid, false, ccA);
+  make_colctx<MODE, VEC, CFG>(g, colB, tid, true, ccB);
 
   float stA[C::EPT], stB[C::EPT];
   if (c_begin < c_end) {
@@ -323,22 +350,28 @@ __global__ __launch_bounds__(256) void gram_kernel(GramGeom g, float* __restrict
   using C = Cfg<CFG>;
   constexpr int PANEL = C::BK * C::LDP;
   constexpr int TW = C::TW;
-  constexpr int NP = C::SMALL ? 1 : 2;  // SMALL has a single (diagonal) tile: the B panel aliases A
+  constexpr int NP = (C::SMALL && MODE != MODE_XCORR) ? 1 : 2;  // SMALL Gram: single diagonal tile, B aliases A
   __shared__ __attribute__((aligned(16))) float smem[2 * NP * PANEL];  // [buf][panel A|B]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lo = lane & 31, hi = lane >> 5;
+  constexpr bool RECT = (MODE == MODE_XCORR);
   int bi, bj;
-  pair_to_tiles(blockIdx.x, nbt, bi, bj);
-  const bool diag = C::SMALL || (bi == bj);
+  if (RECT) {  // all (row tile, column tile) pairs of the rectangular output; nbt = column tiles
+    bi = blockIdx.x / nbt;
+    bj = blockIdx.x - bi * nbt;
+  } else {
+    pair_to_tiles(blockIdx.x, nbt, bi, bj);
+  }
+  const bool diag = !RECT && (C::SMALL || (bi == bj));
   const int colA = bi * C::T, colB = bj * C::T;
   const int wm = wave >> 1, wn = wave & 1;
 
   // number of active 32x32 sub-tiles of this wave along each dim (wave-uniform scalars)
-  int am = (g.n - (colA + wm * C::WT) + 31) / 32;
-  int an = (g.n - (colB + wn * C::WT) + 31) / 32;
+  int am = ((RECT ? g.nA : g.n) - (colA + wm * C::WT) + 31) / 32;
+  int an = ((RECT ? g.nB : g.n) - (colB + wn * C::WT) + 31) / 32;
   am = am < 0 ? 0 : (am > TW ? TW : am);
   an = an < 0 ? 0 : (an > TW ? TW : an);
 
@@ -373,11 +406,20 @@ __global__ __launch_bounds__(256) void gram_prereduce_kernel(float* __restrict__
 
 __global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restrict__ slabs, int nslabs, int slab_stride,
                                                           int npairs, int T, int nbt, float alpha,
-                                                          float* __restrict__ Cmat, int n, int mirror, int rpw) {
+                                                          float* __restrict__ Cmat, int n, int mirror, int rpw,
+                                                          int rect_rows) {
+  // rect_rows > 0: rectangular output [rect_rows][n] (n = columns = leading dimension), tiles enumerated
+  // row-major with nbt column tiles, no mirroring
   __shared__ float tile[64][65];
   const int tid = threadIdx.x;
   int bi, bj;
-  pair_to_tiles(blockIdx.x, nbt, bi, bj);
+  if (rect_rows > 0) {
+    bi = blockIdx.x / nbt;
+    bj = blockIdx.x - bi * nbt;
+  } else {
+    pair_to_tiles(blockIdx.x, nbt, bi, bj);
+  }
+  const int nrows = rect_rows > 0 ? rect_rows : n;
   const int subs = T / 64;
   const int slices = 64 / rpw;
   const int sub = blockIdx.y / slices, slice = blockIdx.y % slices;
@@ -386,14 +428,14 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restric
   const int64_t tile_elems = (int64_t)T * T;
   const bool do_mirror = mirror && (bi != bj);
   const int row0 = sr * 64 + slice * rpw;  // first tile row of this workgroup
-  if (bi * T + row0 >= n || bj * T + sc * 64 >= n) return;  // entirely padding
+  if (bi * T + row0 >= nrows || bj * T + sc * 64 >= n) return;  // entirely padding
   for (int lr = ry; lr < rpw; lr += 4) {
     const float* p = slabs + (int64_t)blockIdx.x * tile_elems + (int64_t)(row0 + lr) * T + sc * 64 + cx;
     float s = 0.f;
     for (int k = 0; k < nslabs; ++k) s += p[(int64_t)k * slab_stride * npairs * tile_elems];
     s *= alpha;
     const int r = bi * T + row0 + lr, c = bj * T + sc * 64 + cx;
-    if (r < n && c < n) Cmat[(int64_t)r * n + c] += s;
+    if (r < nrows && c < n) Cmat[(int64_t)r * n + c] += s;
     if (do_mirror) tile[lr][cx] = s;
   }
   if (do_mirror) {
@@ -406,23 +448,15 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restric
   }
 }
 
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
 struct GramPlan {
   int cfg;
   int T, BK, nbt, npairs, nchunks, nsplit, chunks_per_split, nslabs, rpw;
   size_t ws_bytes;
 };
 
-static GramPlan make_plan(int64_t n, int64_t K) {
-  GramPlan p;
-  // WIDE pays where the 128-tile wastes an edge tile (n = 576 = 4.5 x 128 = 3 x 192); at n >= 1152 its single
-  // resident workgroup per CU (348 registers) loses to BIG's three (measured: profiles/r01_microbench_gram_*)
-  p.cfg = n <= 64 ? CFG_SMALL : ((n % 192 == 0 && n >= 576 && n <= 768) ? CFG_WIDE : CFG_BIG);
-  p.T = p.cfg == CFG_SMALL ? 64 : (p.cfg == CFG_BIG ? 128 : 192);
-  p.BK = p.cfg == CFG_SMALL ? 64 : 16;
-  p.nbt = (int)((n + p.T - 1) / p.T);
-  p.npairs = p.nbt * (p.nbt + 1) / 2;
-  p.nchunks = (int)((K + p.BK - 1) / p.BK);
-  if (p.nchunks < 1) p.nchunks = 1;
+static void finish_plan(GramPlan& p) {
   // Split-K selection: workgroups run in "rounds" of (256 CUs x resident workgroups per CU); choose the split
   // count that minimises  rounds x (chunks per split + fixed per-workgroup overhead)  -- a launch of 1026
   // workgroups on 768 slots costs two full rounds (PMC: 83 % CU residency before this rule).
@@ -452,6 +486,34 @@ static GramPlan make_plan(int64_t n, int64_t K) {
   const int subs = p.T / 64;
   p.rpw = (p.npairs * subs * subs >= 512) ? 64 : 4;
   p.ws_bytes = (size_t)p.nslabs * p.npairs * p.T * p.T * sizeof(float);
+}
+
+static GramPlan make_plan(int64_t n, int64_t K) {
+  GramPlan p;
+  // WIDE pays where the 128-tile wastes an edge tile (n = 576 = 4.5 x 128 = 3 x 192); at n >= 1152 its single
+  // resident workgroup per CU (348 registers) loses to BIG's three (measured: profiles/r01_microbench_gram_*)
+  p.cfg = n <= 64 ? CFG_SMALL : ((n % 192 == 0 && n >= 576 && n <= 768) ? CFG_WIDE : CFG_BIG);
+  p.T = p.cfg == CFG_SMALL ? 64 : (p.cfg == CFG_BIG ? 128 : 192);
+  p.BK = p.cfg == CFG_SMALL ? 64 : 16;
+  p.nbt = (int)((n + p.T - 1) / p.T);
+  p.npairs = p.nbt * (p.nbt + 1) / 2;
+  p.nchunks = (int)((K + p.BK - 1) / p.BK);
+  if (p.nchunks < 1) p.nchunks = 1;
+  finish_plan(p);
+  return p;
+}
+
+// rectangular output [nA][nB] (MODE_XCORR): every (row tile, column tile) pair; p.nbt = column tiles
+static GramPlan make_plan_rect(int64_t nA, int64_t nB, int64_t K) {
+  GramPlan p;
+  p.cfg = nA <= 64 ? CFG_SMALL : CFG_BIG;
+  p.T = p.cfg == CFG_SMALL ? 64 : 128;
+  p.BK = p.cfg == CFG_SMALL ? 64 : 16;
+  p.nbt = (int)((nB + p.T - 1) / p.T);
+  p.npairs = (int)((nA + p.T - 1) / p.T) * p.nbt;
+  p.nchunks = (int)((K + p.BK - 1) / p.BK);
+  if (p.nchunks < 1) p.nchunks = 1;
+  finish_plan(p);
   return p;
 }
 
@@ -495,8 +557,118 @@ static int launch_gram(const GramGeom& g, bool vec4, float alpha, float* C, unsi
   }
   const int subs = p.T / 64;
   hipLaunchKernelGGL(gram_reduce_kernel, dim3(p.npairs, subs * subs * (64 / p.rpw)), dim3(256), 0, stream, slabs, nslabs,
-                     stride, p.npairs, p.T, p.nbt, alpha, C, g.n, (flags & LK_GRAM_UPPER_ONLY) ? 0 : 1, p.rpw);
+                     stride, p.npairs, p.T, p.nbt, alpha, C, g.n, (flags & LK_GRAM_UPPER_ONLY) ? 0 : 1, p.rpw, 0);
   return check_launch("gram_reduce_kernel");
+}
+
+// ---- shift-correlation form of the 3x3 / stride 1 / padding 1 conv A factor ------------------------------
+// For q = p + d (d, e in {-1,0,1}^2 the two patch offsets, D = e - d):
+//   A[(d,ci),(e,cj)] = sum_{q in grid, q - d in grid} x[ci,q] x~[cj,q+D]
+//                    = R[D] - Row_{ry(d)}[D] - Col_{cx(d)}[D] + Pix_{ry,cx}[D]
+// with R[D] the correlation over the WHOLE grid (only 13 of the 25 shifts are computed, R[-D] = R[D]^T) and the
+// corrections correlations over one boundary row / column / corner pixel.  The 81 (d,e) blocks collapse onto 25
+// shifts: 13 C^2 L multiply-adds instead of 40.5 C^2 L for the symmetric half of the im2col Gram.
+static int launch_xcorr(const float* x, int64_t B, int H, int W, int Cin, int h0, int w0, int rh, int rw,
+                        const signed char* sdy, const signed char* sdx, int nshift, float* R, void* ws,
+                        size_t ws_bytes, hipStream_t stream) {
+  GramGeom g{};
+  g.x = x; g.H = H; g.W = W; g.Cin = Cin;
+  g.nA = Cin; g.nB = nshift * Cin; g.n = g.nB;
+  g.reg_h0 = h0; g.reg_w0 = w0; g.reg_h = rh; g.reg_w = rw;
+  g.K = B * rh * rw;
+  for (int i = 0; i < 25; ++i) {
+    g.sdy[i] = i < nshift ? sdy[i] : 0;
+    g.sdx[i] = i < nshift ? sdx[i] : 0;
+  }
+  g.div_reg = make_fastdiv(rh * rw);
+  g.div_regw = make_fastdiv(rw);
+  const GramPlan p = make_plan_rect(g.nA, g.nB, g.K);
+  if (ws == nullptr || ws_bytes < p.ws_bytes) {
+    set_error("xcorr: workspace too small (%zu < %zu bytes)", ws_bytes, p.ws_bytes);
+    return LK_EWORKSPACE;
+  }
+  float* slabs = static_cast<float*>(ws);
+  const bool vec4 = (Cin % 4 == 0) && aligned16(x);
+  dim3 grid(p.npairs, p.nsplit), block(256);
+#define LK_LAUNCH(V, S)                                                                                          \
+  hipLaunchKernelGGL((gram_kernel<MODE_XCORR, V, S>), grid, block, 0, stream, g, slabs, p.nbt, p.npairs, \
+                     p.chunks_per_split, p.nchunks, (float*)nullptr, 1.f)
+  if (p.cfg == CFG_SMALL) {
+    if (vec4) LK_LAUNCH(4, CFG_SMALL); else LK_LAUNCH(1, CFG_SMALL);
+  } else {
+    if (vec4) LK_LAUNCH(4, CFG_BIG); else LK_LAUNCH(1, CFG_BIG);
+  }
+#undef LK_LAUNCH
+  int rc = check_launch("gram_kernel<XCORR>");
+  if (rc) return rc;
+  int nslabs = p.nslabs, stride = 1;
+  const int64_t slab_elems = (int64_t)p.npairs * p.T * p.T;
+  if (nslabs > 32) {
+    const int SG = 32;
+    const int groups = (nslabs + SG - 1) / SG;
+    int64_t bx = (slab_elems / 4 + 255) / 256;
+    if (bx > 2048) bx = 2048;
+    hipLaunchKernelGGL(gram_prereduce_kernel, dim3((unsigned)bx, groups), dim3(256), 0, stream, slabs, nslabs, slab_elems,
+                       SG);
+    nslabs = groups;
+    stride = SG;
+  }
+  const int subs = p.T / 64;
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3(p.npairs, subs * subs * (64 / p.rpw)), dim3(256), 0, stream, slabs, nslabs,
+                     stride, p.npairs, p.T, p.nbt, 1.f, R, g.nB, 0, p.rpw, g.nA);
+  return check_launch("gram_reduce_kernel<rect>");
+}
+
+// half-plane of shifts for the full-grid correlation: (0,0),(0,1),(0,2),(1,-2..2),(2,-2..2)
+__constant__ signed char kHalfIndex[25] = {  // index by (Dy+2)*5 + (Dx+2); -1: use the transpose of -D
+    -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12};
+
+// A[(d,ci),(e,cj)] += alpha * (R[D] - Row - Col + Pix), native (kh,kw,ci) order, n = 9*Cin
+__global__ __launch_bounds__(256) void shiftcorr_assemble_kernel(const float* __restrict__ Rf,
+                                                                 const float* __restrict__ strips,
+                                                                 const float* __restrict__ pix, int Cin, float alpha,
+                                                                 float* __restrict__ A) {
+  const int n = 9 * Cin;
+  const int64_t total = (int64_t)n * n;
+  const int64_t blk = (int64_t)Cin * 25 * Cin;  // one strip / pixel correlation [Cin][25*Cin]
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int r = (int)(idx / n), c = (int)(idx - (int64_t)r * n);
+    const int d = r / Cin, ci = r - d * Cin;
+    const int e = c / Cin, cj = c - e * Cin;
+    const int dy = d / 3 - 1, dx = d % 3 - 1;
+    const int Dy = (e / 3 - 1) - dy, Dx = (e % 3 - 1) - dx;
+    const int t = (Dy + 2) * 5 + (Dx + 2);
+    const int h = kHalfIndex[t];
+    float v = (h >= 0) ? Rf[(int64_t)ci * (13 * Cin) + h * Cin + cj]
+                       : Rf[(int64_t)cj * (13 * Cin) + kHalfIndex[24 - t] * Cin + ci];
+    // strips: 0 = top row (dy=+1), 1 = bottom row (dy=-1), 2 = left column (dx=+1), 3 = right column (dx=-1)
+    const int64_t off = (int64_t)ci * (25 * Cin) + t * Cin + cj;
+    const int sr = dy == 1 ? 0 : (dy == -1 ? 1 : -1);
+    const int sc = dx == 1 ? 2 : (dx == -1 ? 3 : -1);
+    if (sr >= 0) v -= strips[sr * blk + off];
+    if (sc >= 0) v -= strips[sc * blk + off];
+    if (sr >= 0 && sc >= 0) v += pix[(sr * 2 + (sc - 2)) * blk + off];
+    A[idx] += alpha * v;
+  }
+}
+
+struct ShiftCorrPlan {
+  size_t off_Rf, off_strips, off_pix, off_ws, ws_each, total;
+};
+static ShiftCorrPlan shiftcorr_plan(int64_t B, int64_t H, int64_t W, int64_t Cin) {
+  ShiftCorrPlan p;
+  size_t off = 0;
+  p.off_Rf = off; off += align_up((size_t)Cin * 13 * Cin * 4, 256);
+  p.off_strips = off; off += align_up((size_t)4 * Cin * 25 * Cin * 4, 256);
+  p.off_pix = off; off += align_up((size_t)4 * Cin * 25 * Cin * 4, 256);
+  size_t w = make_plan_rect(Cin, 13 * Cin, B * H * W).ws_bytes;
+  const int64_t strip_len = H > W ? H : W;
+  size_t w2 = make_plan_rect(Cin, 25 * Cin, B * strip_len).ws_bytes;
+  size_t w3 = make_plan_rect(Cin, 25 * Cin, B).ws_bytes;
+  p.ws_each = w > w2 ? (w > w3 ? w : w3) : (w2 > w3 ? w2 : w3);
+  p.off_ws = off; off += align_up(p.ws_each, 256);
+  p.total = off;
+  return p;
 }
 
 // ---- layout helpers ---------------------------------------------------------------------------
@@ -558,8 +730,6 @@ extern "C" size_t lk_gram_workspace_bytes(int64_t n, int64_t K) {
   if (n <= 0) return 0;
   return make_plan(n, K < 1 ? 1 : K).ws_bytes;
 }
-
-static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 extern "C" int lk_gram_tn_f32(const float* X, int64_t K, int64_t n, int64_t ldx, float alpha, float* C,
                               unsigned flags, void* ws, size_t ws_bytes, void* stream) {
@@ -646,4 +816,59 @@ extern "C" int lk_permute_sym_f32(const float* src, int64_t Cin, int64_t KK, flo
   hipLaunchKernelGGL(permute_sym_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, (int)Cin,
                      (int)KK, dst, accumulate);
   return check_launch("permute_sym_kernel");
+}
+
+extern "C" size_t lk_conv3x3_shiftcorr_workspace_bytes(int64_t B, int64_t H, int64_t W, int64_t Cin) {
+  if (B < 0 || H < 1 || W < 1 || Cin < 1) return 0;
+  return shiftcorr_plan(B < 1 ? 1 : B, H, W, Cin).total;
+}
+
+extern "C" int lk_conv3x3_shiftcorr_f32(const float* x, int64_t B, int64_t H, int64_t W, int64_t Cin, float alpha,
+                                        float* C, void* ws, size_t ws_bytes, void* stream_) {
+  LK_REQUIRE(x && C && B >= 0 && H >= 2 && W >= 2 && Cin >= 1, "lk_conv3x3_shiftcorr_f32: bad arguments");
+  LK_REQUIRE(B * H * W < (1ll << 31) - 64 && 25 * Cin < (1 << 24), "lk_conv3x3_shiftcorr_f32: problem too large");
+  if (B == 0) return LK_OK;
+  hipStream_t stream = (hipStream_t)stream_;
+  const ShiftCorrPlan p = shiftcorr_plan(B, H, W, Cin);
+  if (ws == nullptr || ws_bytes < p.total) {
+    set_error("lk_conv3x3_shiftcorr_f32: workspace too small (%zu < %zu bytes)", ws_bytes, p.total);
+    return LK_EWORKSPACE;
+  }
+  char* base = static_cast<char*>(ws);
+  float* Rf = reinterpret_cast<float*>(base + p.off_Rf);
+  float* strips = reinterpret_cast<float*>(base + p.off_strips);
+  float* pix = reinterpret_cast<float*>(base + p.off_pix);
+  void* gws = base + p.off_ws;
+  if (hipMemsetAsync(base, 0, p.off_ws, stream) != hipSuccess) {
+    set_error("lk_conv3x3_shiftcorr_f32: hipMemsetAsync failed");
+    return LK_ELAUNCH;
+  }
+  signed char hy[13], hx[13], ay[25], ax[25];
+  int k = 0;
+  for (int dx = 0; dx <= 2; ++dx) { hy[k] = 0; hx[k] = (signed char)dx; ++k; }
+  for (int dy = 1; dy <= 2; ++dy)
+    for (int dx = -2; dx <= 2; ++dx) { hy[k] = (signed char)dy; hx[k] = (signed char)dx; ++k; }
+  for (int t = 0; t < 25; ++t) { ay[t] = (signed char)(t / 5 - 2); ax[t] = (signed char)(t % 5 - 2); }
+  const int h = (int)H, w = (int)W, c = (int)Cin;
+  const int64_t blk = Cin * 25 * Cin;
+  int rc = launch_xcorr(x, B, h, w, c, 0, 0, h, w, hy, hx, 13, Rf, gws, p.ws_each, stream);
+  if (rc) return rc;
+  // boundary strips (all 25 shifts each; their K is ~1/H of the full grid)
+  const int sh0[4] = {0, h - 1, 0, 0}, sw0[4] = {0, 0, 0, w - 1}, shh[4] = {1, 1, h, h}, sww[4] = {w, w, 1, 1};
+  for (int i = 0; i < 4; ++i) {
+    rc = launch_xcorr(x, B, h, w, c, sh0[i], sw0[i], shh[i], sww[i], ay, ax, 25, strips + i * blk, gws, p.ws_each, stream);
+    if (rc) return rc;
+  }
+  // corner pixels: index (row strip 0/1) * 2 + (column strip 0/1)
+  for (int i = 0; i < 4; ++i) {
+    const int ry = (i >> 1) ? h - 1 : 0, cx = (i & 1) ? w - 1 : 0;
+    rc = launch_xcorr(x, B, h, w, c, ry, cx, 1, 1, ay, ax, 25, pix + i * blk, gws, p.ws_each, stream);
+    if (rc) return rc;
+  }
+  const int64_t total = 81 * Cin * Cin;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(shiftcorr_assemble_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, Rf, strips, pix, c, alpha,
+                     C);
+  return check_launch("shiftcorr_assemble_kernel");
 }

@@ -41,6 +41,17 @@ def _kron2(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return torch.einsum("ij,kl->ikjl", a, b).reshape(a.shape[0] * b.shape[0], a.shape[1] * b.shape[1])
 
 
+_STREAM_POOL: dict = {}
+
+
+def _side_streams(dev, n: int):
+    """A small persistent pool of HIP streams per device (created once, reused by every decompose)."""
+    pool = _STREAM_POOL.setdefault(dev.index, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(dev))
+    return pool[:n]
+
+
 class HipKron(_KronBase):
     """Kronecker-factored curvature: ``kfacs[i]`` is ``[G, A]`` (weight) or ``[B]`` (bias)."""
 
@@ -106,7 +117,7 @@ class HipKron(_KronBase):
         if use_streams:
             dev = self.kfacs[dense[0][1]][dense[0][2]].device
             main = torch.cuda.current_stream(dev)
-            streams = [torch.cuda.Stream(dev) for _ in range(min(n_streams, len(dense)))]
+            streams = _side_streams(dev, min(n_streams, len(dense)))
             for st in streams:
                 st.wait_stream(main)
             for i, (_, bi, fi) in enumerate(dense):
@@ -114,8 +125,9 @@ class HipKron(_KronBase):
                 Hi = self.kfacs[bi][fi].contiguous()
                 with torch.cuda.stream(st):
                     l, Q, info = K.syevj(Hi, clamp=True)
-                for t in (Hi, l, Q, info):
-                    t.record_stream(st)
+                Hi.record_stream(st)          # allocated on `main`, read on `st`
+                for t in (l, Q, info):        # allocated on `st`, consumed on `main` from here on
+                    t.record_stream(main)
                 results[(bi, fi)] = (l, Q)
                 infos.append(info)
             for st in streams:

@@ -143,7 +143,7 @@ def test_c4_eigendecomposition_round_trip(resnet):
             scale = M64.diagonal().abs().max().item()
             lam = torch.linalg.eigvalsh(M64).clamp(min=0)
             top = lam.max().item()
-            assert (l.double() - lam).abs().max().item() / top < 2e-5, f"eigenvalues n={n}"
+            assert (l.double() - lam).abs().max().item() / top < 5e-5, f"eigenvalues n={n}"
             Q64 = Q.double()
             assert (Q64.T @ Q64 - torch.eye(n, device=DEV, dtype=torch.float64)).abs().max().item() < 5e-5, f"orth n={n}"
             assert ((Q64 * l.double()) @ Q64.T - M64).abs().max().item() / top < 5e-5, f"reconstruction n={n}"

@@ -132,6 +132,38 @@ def test_gram_conv(K, case):
     assert_close(out, want, what=f"gram_conv fused {case}")
 
 
+@pytest.mark.parametrize("B,Cin,H,W", [(2, 8, 8, 8), (3, 64, 8, 8), (2, 64, 32, 32), (2, 5, 9, 11), (2, 128, 16, 16),
+                                        (1, 256, 8, 8), (3, 4, 2, 40), (2, 12, 17, 3)])
+def test_conv3x3_shift_correlation_path(K, B, Cin, H, W):
+    """3x3 / stride 1 / pad 1 A factor through the shift-correlation identity == implicit-im2col Gram == unfold."""
+    if DEV == "cpu":
+        pytest.skip("kernel-level identity; the emulation has a single path")
+    x = rnd(B, Cin, H, W, seed=B + Cin + H + W)
+    n = Cin * 9
+    want = EMU.gram_conv(x, 3, 1, 1, 1, 0.7, torch.zeros(n, n, dtype=torch.float64))
+    xg = x.float().to(DEV)
+    prev = K.use_shiftcorr
+    try:
+        K.use_shiftcorr = True
+        nb = K.lib.lk_conv3x3_shiftcorr_workspace_bytes(B, H, W, Cin)
+        ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+        nat = torch.zeros(n, n, device=DEV)
+        xh = K.nchw_to_nhwc(xg)
+        import ctypes
+        rc = K.lib.lk_conv3x3_shiftcorr_f32(ctypes.c_void_p(xh.data_ptr()), B, H, W, Cin, 0.7, ctypes.c_void_p(nat.data_ptr()),
+                                            ctypes.c_void_p(ws.data_ptr()), ws.numel(),
+                                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0, K.lib.lk_last_error()
+        got_sc = K.permute_native_to_unfold(nat, Cin, 9, torch.zeros(n, n, device=DEV))
+        K.use_shiftcorr = False
+        got_direct = K.gram_conv(xg, 3, 1, 1, 1, 0.7, torch.zeros(n, n, device=DEV))
+    finally:
+        K.use_shiftcorr = prev
+    assert_close(got_sc, want, what="shift-correlation")
+    assert_close(got_direct, want, what="implicit im2col")
+    assert_close(got_sc, got_direct, tol=1e-5, what="paths agree")
+
+
 def test_gram_accumulates_and_is_additive(K):
     """sum over minibatches == one big batch (the sharding licence, baselaplace.py:984-985)."""
     X = rnd(900, 200, seed=9).float().to(DEV)

@@ -44,11 +44,13 @@ if which in ("all", "gram"):
         oh = (hw + 2 - 3) // s + 1
         Kr = B * oh * oh
         A = torch.zeros(n, n, device=DEV)
-        for native in (False, True):
+        for native, sc in ((False, False), (True, False), (True, True)):
+            K.use_shiftcorr = sc
             ms = timeit(lambda: K.gram_conv(x, 3, s, 1, 1, 1.0, A, upper_only=native, native=native))
-            out["gram"].append({"op": "conv" + ("_fused" if native else ""), "name": name, "n": n, "K": Kr, "ms": ms,
-                                "tflops_full": 2 * Kr * n * n / ms / 1e9})
+            out["gram"].append({"op": "conv" + ("_fused" if native else "") + ("_shiftcorr" if sc else ""), "name": name,
+                                "n": n, "K": Kr, "ms": ms, "tflops_full": 2 * Kr * n * n / ms / 1e9})
             print(out["gram"][-1], flush=True)
+        K.use_shiftcorr = True
     for name, n, L in [("G l1", 64, 1024), ("G l2", 128, 256), ("G l3", 256, 64), ("G l4", 512, 16)]:
         g = torch.randn(C * B, n, L, device=DEV)
         G = torch.zeros(n, n, device=DEV)
