@@ -62,11 +62,15 @@ struct GramGeom {
   FastDiv div_ohw, div_ow;                             // CONV: row index -> (b, oh, ow)
   // XCORR: rectangular  R[ci][(s, cj)] = sum_{b, q in region} x[b, q, ci] * x~[b, q + shift_s, cj]   (NHWC, x~ = x
   // zero-extended); rows enumerate (b, q) over the region [reg_h0, reg_h0+reg_h) x [reg_w0, reg_w0+reg_w)
+  // Up to MAX_REG regions are processed by one launch (blockIdx.z = region), each with its own output matrix.
   int nA, nB;                    // output rows (Cin) and columns (nshift * Cin)
-  int reg_h0, reg_w0, reg_h, reg_w;
+  int nreg;
+  int reg_h0[8], reg_w0[8];
+  int64_t reg_K[8];              // rows of region r = B * reg_h * reg_w
   signed char sdy[25], sdx[25];  // shift table
-  FastDiv div_reg, div_regw;     // row -> (b, r), r -> (rh, rw)
+  FastDiv div_reg[8], div_regw[8];  // row -> (b, r), r -> (rh, rw)
 };
+constexpr int MAX_REG = 8;
 
 enum { CFG_SMALL = 0, CFG_BIG = 1, CFG_WIDE = 2 };
 template <int CFG>
@@ -144,7 +148,7 @@ __device__ __forceinline__ void make_colctx(const GramGeom& g, int col0, int tid
 }
 
 template <int MODE, int VEC, int CFG>
-__device__ __forceinline__ void load_panel(const GramGeom& g, int64_t k0, int tid,
+__device__ __forceinline__ void load_panel(const GramGeom& g, int64_t k0, int tid, int reg,
                                            const ColCtx<MODE, VEC, CFG>& cc, float (&st)[Cfg<CFG>::EPT]) {
   constexpr int NL = ColCtx<MODE, VEC, CFG>::NL;
   // chunk-uniform part (NT: a chunk never straddles images because Lp % BK == 0)
@@ -174,12 +178,12 @@ __device__ __forceinline__ void load_panel(const GramGeom& g, int64_t k0, int ti
       p = nt_base + cc.off[i] + krow;
     } else if (MODE == MODE_XCORR) {
       const int k = (int)k0 + krow;
-      const int b = fdiv(k, g.div_reg);
-      const int r = k - b * g.div_reg.d;
-      const int rh = fdiv(r, g.div_regw), rw = r - rh * g.div_regw.d;
-      const int ih = g.reg_h0 + rh + cc.dy[i];
-      const int iw = g.reg_w0 + rw + cc.dx[i];
-      valid = valid && (k < g.K) && (ih >= 0) && (ih < g.H) && (iw >= 0) && (iw < g.W);
+      const int b = fdiv(k, g.div_reg[reg]);
+      const int r = k - b * g.div_reg[reg].d;
+      const int rh = fdiv(r, g.div_regw[reg]), rw = r - rh * g.div_regw[reg].d;
+      const int ih = g.reg_h0[reg] + rh + cc.dy[i];
+      const int iw = g.reg_w0[reg] + rw + cc.dx[i];
+      valid = valid && (k < g.reg_K[reg]) && (ih >= 0) && (ih < g.H) && (iw >= 0) && (iw < g.W);
       p = g.x + (((int64_t)b * g.H + ih) * g.W + iw) * g.Cin + cc.off[i];
     } else {
       const int k = (int)k0 + krow;  // conv: K < 2^31 (checked on the host)
@@ -265,7 +269,7 @@ template <int MODE, int VEC, int CFG, bool FULL>
 __device__ __forceinline__ void gram_body(const GramGeom& g, float* __restrict__ smem, float* __restrict__ slab,
                                           int tid, int wm, int wn, int lo, int hi, bool diag, int colA, int colB,
                                           int c_begin, int c_end, int am, int an, float* __restrict__ Cdirect,
-                                          float alpha) {
+                                          float alpha, int reg) {
   using C = Cfg<CFG>;
   constexpr int PANEL = C::BK * C::LDP;
   constexpr int TW = C::TW;
@@ -285,8 +289,8 @@ __device__ __forceinline__ void gram_body(const GramGeom& g, float* __restrict__
 
   float stA[C::EPT], stB[C::EPT];
   if (c_begin < c_end) {
-    load_panel<MODE, VEC, CFG>(g, (int64_t)c_begin * C::BK, tid, ccA, stA);
-    if (!diag) load_panel<MODE, VEC, CFG>(g, (int64_t)c_begin * C::BK, tid, ccB, stB);
+    load_panel<MODE, VEC, CFG>(g, (int64_t)c_begin * C::BK, tid, reg, ccA, stA);
+    if (!diag) load_panel<MODE, VEC, CFG>(g, (int64_t)c_begin * C::BK, tid, reg, ccB, stB);
     store_panel<MODE, VEC, CFG>(smem, tid, stA);
     if (!diag) store_panel<MODE, VEC, CFG>(smem + PANEL, tid, stB);
   }
@@ -300,8 +304,8 @@ __device__ __forceinline__ void gram_body(const GramGeom& g, float* __restrict__
   for (int c = c_begin; c < c_end; ++c) {
     const bool more = (c + 1) < c_end;
     if (more) {
-      load_panel<MODE, VEC, CFG>(g, (int64_t)(c + 1) * C::BK, tid, ccA, stA);
-      if (!diag) load_panel<MODE, VEC, CFG>(g, (int64_t)(c + 1) * C::BK, tid, ccB, stB);
+      load_panel<MODE, VEC, CFG>(g, (int64_t)(c + 1) * C::BK, tid, reg, ccA, stA);
+      if (!diag) load_panel<MODE, VEC, CFG>(g, (int64_t)(c + 1) * C::BK, tid, reg, ccB, stB);
     }
     const float* pA = smem + cur * NP * PANEL;
     const float* pB = diag ? pA : pA + PANEL;
@@ -375,17 +379,21 @@ __global__ __launch_bounds__(256) void gram_kernel(GramGeom g, float* __restrict
   am = am < 0 ? 0 : (am > TW ? TW : am);
   an = an < 0 ? 0 : (an > TW ? TW : an);
 
+  // MODE_XCORR: blockIdx.z = region; regions share the split geometry of the longest one and simply run out
+  // of chunks earlier (their remaining slabs stay zero)
+  const int reg = RECT ? (int)blockIdx.z : 0;
+  const int my_chunks = RECT ? (int)((g.reg_K[reg] + C::BK - 1) / C::BK) : nchunks;
   const int c_begin = blockIdx.y * chunks_per_split;
-  const int c_end = min(nchunks, c_begin + chunks_per_split);
-  float* slab = slabs + ((int64_t)blockIdx.y * npairs + blockIdx.x) * (C::T * C::T);
+  const int c_end = min(my_chunks, c_begin + chunks_per_split);
+  float* slab = slabs + (((int64_t)reg * gridDim.y + blockIdx.y) * npairs + blockIdx.x) * (C::T * C::T);
 
   // Every wave executes the same number of barriers on either path.
   if (am == TW && an == TW) {
     gram_body<MODE, VEC, CFG, true>(g, smem, slab, tid, wm, wn, lo, hi, diag, colA, colB, c_begin, c_end, am, an,
-                                      Cdirect, alpha);
+                                      Cdirect, alpha, reg);
   } else {
     gram_body<MODE, VEC, CFG, false>(g, smem, slab, tid, wm, wn, lo, hi, diag, colA, colB, c_begin, c_end, am, an,
-                                       Cdirect, alpha);
+                                       Cdirect, alpha, reg);
   }
 }
 
@@ -394,6 +402,7 @@ __global__ __launch_bounds__(256) void gram_kernel(GramGeom g, float* __restrict
 // First level of a two-level slab reduction: group g sums slabs [g*SG, (g+1)*SG) into slab g*SG (in place).
 __global__ __launch_bounds__(256) void gram_prereduce_kernel(float* __restrict__ slabs, int nslabs, int64_t slab_elems,
                                                              int SG) {
+  slabs += (int64_t)blockIdx.z * nslabs * slab_elems;  // region (MODE_XCORR), 0 otherwise
   const int first = blockIdx.y * SG;
   const int last = min(nslabs, first + SG);
   for (int64_t idx = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; idx < slab_elems;
@@ -407,7 +416,7 @@ __global__ __launch_bounds__(256) void gram_prereduce_kernel(float* __restrict__
 __global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restrict__ slabs, int nslabs, int slab_stride,
                                                           int npairs, int T, int nbt, float alpha,
                                                           float* __restrict__ Cmat, int n, int mirror, int rpw,
-                                                          int rect_rows) {
+                                                          int rect_rows, int nslabs_total) {
   // rect_rows > 0: rectangular output [rect_rows][n] (n = columns = leading dimension), tiles enumerated
   // row-major with nbt column tiles, no mirroring
   __shared__ float tile[64][65];
@@ -420,6 +429,10 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restric
     pair_to_tiles(blockIdx.x, nbt, bi, bj);
   }
   const int nrows = rect_rows > 0 ? rect_rows : n;
+  if (rect_rows > 0) {  // region (MODE_XCORR): its own slab range and its own output matrix
+    slabs += (int64_t)blockIdx.z * nslabs_total * npairs * (int64_t)T * T;
+    Cmat += (int64_t)blockIdx.z * rect_rows * n;
+  }
   const int subs = T / 64;
   const int slices = 64 / rpw;
   const int sub = blockIdx.y / slices, slice = blockIdx.y % slices;
@@ -557,7 +570,7 @@ static int launch_gram(const GramGeom& g, bool vec4, float alpha, float* C, unsi
   }
   const int subs = p.T / 64;
   hipLaunchKernelGGL(gram_reduce_kernel, dim3(p.npairs, subs * subs * (64 / p.rpw)), dim3(256), 0, stream, slabs, nslabs,
-                     stride, p.npairs, p.T, p.nbt, alpha, C, g.n, (flags & LK_GRAM_UPPER_ONLY) ? 0 : 1, p.rpw, 0);
+                     stride, p.npairs, p.T, p.nbt, alpha, C, g.n, (flags & LK_GRAM_UPPER_ONLY) ? 0 : 1, p.rpw, 0, 0);
   return check_launch("gram_reduce_kernel");
 }
 
@@ -568,28 +581,42 @@ static int launch_gram(const GramGeom& g, bool vec4, float alpha, float* C, unsi
 // with R[D] the correlation over the WHOLE grid (only 13 of the 25 shifts are computed, R[-D] = R[D]^T) and the
 // corrections correlations over one boundary row / column / corner pixel.  The 81 (d,e) blocks collapse onto 25
 // shifts: 13 C^2 L multiply-adds instead of 40.5 C^2 L for the symmetric half of the im2col Gram.
-static int launch_xcorr(const float* x, int64_t B, int H, int W, int Cin, int h0, int w0, int rh, int rw,
+struct Region {
+  int h0, w0, h, w;
+};
+// One launch for up to MAX_REG regions; outputs R[r] = [Cin][nshift*Cin], consecutive in memory.
+static int launch_xcorr(const float* x, int64_t B, int H, int W, int Cin, const Region* regs, int nreg,
                         const signed char* sdy, const signed char* sdx, int nshift, float* R, void* ws,
                         size_t ws_bytes, hipStream_t stream) {
+  if (nreg < 1 || nreg > MAX_REG) {
+    set_error("xcorr: bad region count %d", nreg);
+    return LK_EINVAL;
+  }
   GramGeom g{};
   g.x = x; g.H = H; g.W = W; g.Cin = Cin;
   g.nA = Cin; g.nB = nshift * Cin; g.n = g.nB;
-  g.reg_h0 = h0; g.reg_w0 = w0; g.reg_h = rh; g.reg_w = rw;
-  g.K = B * rh * rw;
+  g.nreg = nreg;
+  int64_t Kmax = 0;
+  for (int r = 0; r < nreg; ++r) {
+    g.reg_h0[r] = regs[r].h0; g.reg_w0[r] = regs[r].w0;
+    g.reg_K[r] = B * regs[r].h * regs[r].w;
+    g.div_reg[r] = make_fastdiv(regs[r].h * regs[r].w);
+    g.div_regw[r] = make_fastdiv(regs[r].w);
+    if (g.reg_K[r] > Kmax) Kmax = g.reg_K[r];
+  }
+  g.K = Kmax;
   for (int i = 0; i < 25; ++i) {
     g.sdy[i] = i < nshift ? sdy[i] : 0;
     g.sdx[i] = i < nshift ? sdx[i] : 0;
   }
-  g.div_reg = make_fastdiv(rh * rw);
-  g.div_regw = make_fastdiv(rw);
-  const GramPlan p = make_plan_rect(g.nA, g.nB, g.K);
-  if (ws == nullptr || ws_bytes < p.ws_bytes) {
-    set_error("xcorr: workspace too small (%zu < %zu bytes)", ws_bytes, p.ws_bytes);
+  GramPlan p = make_plan_rect(g.nA, g.nB, Kmax);
+  if (ws == nullptr || ws_bytes < p.ws_bytes * nreg) {
+    set_error("xcorr: workspace too small (%zu < %zu bytes)", ws_bytes, p.ws_bytes * nreg);
     return LK_EWORKSPACE;
   }
   float* slabs = static_cast<float*>(ws);
   const bool vec4 = (Cin % 4 == 0) && aligned16(x);
-  dim3 grid(p.npairs, p.nsplit), block(256);
+  dim3 grid(p.npairs, p.nsplit, nreg), block(256);
 #define LK_LAUNCH(V, S)                                                                                          \
   hipLaunchKernelGGL((gram_kernel<MODE_XCORR, V, S>), grid, block, 0, stream, g, slabs, p.nbt, p.npairs, \
                      p.chunks_per_split, p.nchunks, (float*)nullptr, 1.f)
@@ -608,14 +635,14 @@ static int launch_xcorr(const float* x, int64_t B, int H, int W, int Cin, int h0
     const int groups = (nslabs + SG - 1) / SG;
     int64_t bx = (slab_elems / 4 + 255) / 256;
     if (bx > 2048) bx = 2048;
-    hipLaunchKernelGGL(gram_prereduce_kernel, dim3((unsigned)bx, groups), dim3(256), 0, stream, slabs, nslabs, slab_elems,
-                       SG);
+    hipLaunchKernelGGL(gram_prereduce_kernel, dim3((unsigned)bx, groups, nreg), dim3(256), 0, stream, slabs, nslabs,
+                       slab_elems, SG);
     nslabs = groups;
     stride = SG;
   }
   const int subs = p.T / 64;
-  hipLaunchKernelGGL(gram_reduce_kernel, dim3(p.npairs, subs * subs * (64 / p.rpw)), dim3(256), 0, stream, slabs, nslabs,
-                     stride, p.npairs, p.T, p.nbt, 1.f, R, g.nB, 0, p.rpw, g.nA);
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3(p.npairs, subs * subs * (64 / p.rpw), nreg), dim3(256), 0, stream, slabs,
+                     nslabs, stride, p.npairs, p.T, p.nbt, 1.f, R, g.nB, 0, p.rpw, g.nA, p.nslabs);
   return check_launch("gram_reduce_kernel<rect>");
 }
 
@@ -659,13 +686,13 @@ static ShiftCorrPlan shiftcorr_plan(int64_t B, int64_t H, int64_t W, int64_t Cin
   ShiftCorrPlan p;
   size_t off = 0;
   p.off_Rf = off; off += align_up((size_t)Cin * 13 * Cin * 4, 256);
-  p.off_strips = off; off += align_up((size_t)4 * Cin * 25 * Cin * 4, 256);
-  p.off_pix = off; off += align_up((size_t)4 * Cin * 25 * Cin * 4, 256);
+  p.off_strips = off;                                  // 4 strips followed directly by the 4 corner pixels
+  p.off_pix = off + (size_t)4 * Cin * 25 * Cin * 4;
+  off += align_up((size_t)8 * Cin * 25 * Cin * 4, 256);
   size_t w = make_plan_rect(Cin, 13 * Cin, B * H * W).ws_bytes;
   const int64_t strip_len = H > W ? H : W;
-  size_t w2 = make_plan_rect(Cin, 25 * Cin, B * strip_len).ws_bytes;
-  size_t w3 = make_plan_rect(Cin, 25 * Cin, B).ws_bytes;
-  p.ws_each = w > w2 ? (w > w3 ? w : w3) : (w2 > w3 ? w2 : w3);
+  size_t w2 = make_plan_rect(Cin, 25 * Cin, B * strip_len).ws_bytes * 8;  // 4 strips + 4 pixels in one launch
+  p.ws_each = w > w2 ? w : w2;
   p.off_ws = off; off += align_up(p.ws_each, 256);
   p.total = off;
   return p;
@@ -851,20 +878,19 @@ extern "C" int lk_conv3x3_shiftcorr_f32(const float* x, int64_t B, int64_t H, in
   for (int t = 0; t < 25; ++t) { ay[t] = (signed char)(t / 5 - 2); ax[t] = (signed char)(t % 5 - 2); }
   const int h = (int)H, w = (int)W, c = (int)Cin;
   const int64_t blk = Cin * 25 * Cin;
-  int rc = launch_xcorr(x, B, h, w, c, 0, 0, h, w, hy, hx, 13, Rf, gws, p.ws_each, stream);
+  const Region full = {0, 0, h, w};
+  int rc = launch_xcorr(x, B, h, w, c, &full, 1, hy, hx, 13, Rf, gws, p.ws_each, stream);
   if (rc) return rc;
-  // boundary strips (all 25 shifts each; their K is ~1/H of the full grid)
-  const int sh0[4] = {0, h - 1, 0, 0}, sw0[4] = {0, 0, 0, w - 1}, shh[4] = {1, 1, h, h}, sww[4] = {w, w, 1, 1};
-  for (int i = 0; i < 4; ++i) {
-    rc = launch_xcorr(x, B, h, w, c, sh0[i], sw0[i], shh[i], sww[i], ay, ax, 25, strips + i * blk, gws, p.ws_each, stream);
-    if (rc) return rc;
+  // the four boundary strips (top row, bottom row, left column, right column) and the four corner pixels
+  // (index (row strip) * 2 + (column strip)) in ONE launch; `strips` and `pix` are adjacent in the workspace
+  const Region regs[8] = {{0, 0, 1, w},     {h - 1, 0, 1, w},     {0, 0, h, 1},     {0, w - 1, h, 1},
+                          {0, 0, 1, 1},     {0, w - 1, 1, 1},     {h - 1, 0, 1, 1}, {h - 1, w - 1, 1, 1}};
+  if (pix != strips + 4 * blk) {
+    set_error("lk_conv3x3_shiftcorr_f32: internal layout error");
+    return LK_EINVAL;
   }
-  // corner pixels: index (row strip 0/1) * 2 + (column strip 0/1)
-  for (int i = 0; i < 4; ++i) {
-    const int ry = (i >> 1) ? h - 1 : 0, cx = (i & 1) ? w - 1 : 0;
-    rc = launch_xcorr(x, B, h, w, c, ry, cx, 1, 1, ay, ax, 25, pix + i * blk, gws, p.ws_each, stream);
-    if (rc) return rc;
-  }
+  rc = launch_xcorr(x, B, h, w, c, regs, 8, ay, ax, 25, strips, gws, p.ws_each, stream);
+  if (rc) return rc;
   const int64_t total = 81 * Cin * Cin;
   int64_t blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
