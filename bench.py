@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-eigh", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bound of the CPU-baseline leg")
     ap.add_argument("--no-overlap", action="store_true", help="A-factor kernels on the main stream (A/B switch)")
+    ap.add_argument("--no-sweep", action="store_true", help="one autograd reverse pass per seed instead of the seed-batched sweep")
     return ap.parse_args()
 
 
@@ -150,6 +151,7 @@ def main():
     torch.manual_seed(711)
     model = ResNet18(CLASSES).to(dev).eval()
     backend = HipGGN(model, "classification")
+    backend.use_sweep = not args.no_sweep
     batches = make_batches(args.steps, dev, seed=100 + rank)
     K = get_kernels()
 

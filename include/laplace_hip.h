@@ -130,6 +130,16 @@ int lk_jac_conv_f32(const float* x_nchw, const float* g, int64_t B, int64_t Cc, 
 int lk_sq_colsum_f32(const float* Js, int64_t rows, int64_t P, int64_t col0, int64_t width, float alpha,
                      float* h, void* stream);
 
+/* Element-wise VJP of the seed-batched reverse sweep: all S seeds of an `activation(BatchNorm_eval(.))` backward
+ * in one pass (the reference gets these from stock autograd, one backward kernel per seed and layer —
+ * laplace/curvature/curvlinops.py:87-106 through curvlinops' hooks):
+ *   out[s][e] = (g[s][e] + g2[s][e]) * M[e] * scale[(e / HW) % C],   e < per_sample = B*C*HW
+ * g2: second branch of a residual connection, summed on the fly (NULL = none; may not alias out).
+ * M: per-sample multiplier (NULL = 1): bytes that are zero / non-zero (a ReLU mask, m_is_float = 0) or floats
+ * (f'(y), m_is_float = 1).  scale: per-channel factor gamma/sqrt(var+eps) (NULL = 1; then C, HW are ignored). */
+int lk_vjp_scale_mask_f32(const float* g, const float* g2, const void* m, int m_is_float, const float* scale, int64_t S,
+                          int64_t per_sample, int64_t C, int64_t HW, float* out, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Dense last-layer GGN.  Replaces last_layer_jacobians + GGNInterface.full for a Linear head
  * (curvature.py:131-167,375-411) without materialising Js, using J_n = I_C (x) [phi_n, 1]:

@@ -56,6 +56,7 @@ SIGNATURES = {
         [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _int, _vp, _i64, _i64, _i64, _vp],
     ),
     "lk_sq_colsum_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _f32, _vp, _vp]),
+    "lk_vjp_scale_mask_f32": (_int, [_vp, _vp, _vp, _int, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "lk_ll_ggn_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "lk_ll_ggn_full_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _f32, _vp, _vp, _sz, _vp]),
     "lk_syevj_workspace_bytes": (_sz, [_i64]),
@@ -340,6 +341,33 @@ class HipKernels:
         rows = Js.numel() // P
         self._rc(self.lib.lk_sq_colsum_f32(_ptr(Js), rows, P, int(col0), int(width), float(alpha), _ptr(h),
                                            self._stream(Js.device)), "lk_sq_colsum_f32")
+
+    def vjp_scale_mask(self, g, S, mult, scale, hw, g2=None):
+        """``out[s, e] = (g[s, e] + g2[s, e]) * mult[e] * scale[channel(e)]`` for the ``S`` seeds stacked in ``g``
+        ([S*B, ...]); ``g2``, ``mult`` ([B, ...], bool or float32) and ``scale`` ([C]) may be None."""
+        _check(g, "g")
+        if g2 is not None:
+            _check(g2, "g2")
+            if g2.shape != g.shape:
+                raise ValueError("vjp_scale_mask: g2 must have the shape of g")
+        per = g.numel() // S
+        out = torch.empty_like(g)
+        m_is_float = 0
+        if mult is not None:
+            if mult.dtype == torch.bool:
+                mult = mult.contiguous()
+            else:
+                mult, m_is_float = mult.to(torch.float32).contiguous(), 1
+            if mult.numel() != per:
+                raise ValueError("vjp_scale_mask: multiplier must have the per-seed shape")
+        C = 1
+        if scale is not None:
+            scale = scale.to(torch.float32).contiguous()
+            C = scale.numel()
+        self._rc(self.lib.lk_vjp_scale_mask_f32(_ptr(g), _ptr(g2), _ptr(mult), m_is_float,
+                                                _ptr(scale), int(S), per, C, int(hw),
+                                                _ptr(out), self._stream(g.device)), "lk_vjp_scale_mask_f32")
+        return out
 
     # ---- dense last-layer GGN -----------------------------------------------------------------
     def ll_ggn_full(self, phi, probs, has_bias, alpha, H):

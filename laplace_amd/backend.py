@@ -23,6 +23,7 @@ Only fp32 models on a ROCm device are accepted; there is no CPU path.
 from __future__ import annotations
 
 import math
+import os
 from collections.abc import MutableMapping
 
 import torch
@@ -30,6 +31,7 @@ from torch import nn
 
 from laplace_amd._lib import get_kernels
 from laplace_amd.capture import Tape
+from laplace_amd.sweep import SeedBatchedSweep, SweepUnsupported
 from laplace_amd.kron import HipKron
 from laplace_amd.refapi import EFInterface, GGNInterface
 
@@ -63,6 +65,9 @@ class _HipCurvatureMixin:
             B = phi.shape[0]
             f = f.detach().reshape(B, -1).contiguous()
             return f, tape, lambda seeds, stack=True: [seeds.contiguous()]
+        swept = self._forward_swept(x, tape)
+        if swept is not None:
+            return swept
         f = tape.forward(x)
         self._check_dtype(f)
         if f.ndim == 1:
@@ -71,6 +76,43 @@ class _HipCurvatureMixin:
             raise NotImplementedError(f"model output must be [batch, outputs]; got {tuple(f.shape)}")
         return (f.detach().contiguous(), tape,
                 lambda seeds, stack=True, f_graph=f: tape.output_grads(f_graph, seeds, stack=stack))
+
+    #: ``False`` forces the autograd tape (one reverse pass per seed); env LK_SWEEP=0 does the same.
+    use_sweep = os.environ.get("LK_SWEEP", "1") != "0"
+
+    def _forward_swept(self, x, tape):
+        """Seed-batched reverse sweep (laplace_amd/sweep.py) when the model is fx-traceable and built from
+        modules with a closed-form VJP; ``None`` -> caller uses the autograd tape."""
+        if not self.use_sweep or not torch.is_tensor(x) or not tape.taps:
+            return None
+        sweep = getattr(tape, "sweep", None)
+        if sweep is None:
+            try:
+                sweep = SeedBatchedSweep(self._model, {t.name: t.module for t in tape.taps}, kernels=get_kernels)
+            except SweepUnsupported as e:
+                sweep = False
+                tape.sweep_reason = str(e)
+            tape.sweep = sweep
+        if sweep is False:
+            return None
+        try:
+            f = sweep.forward(x)
+        except SweepUnsupported as e:  # e.g. the model is in training mode for this call
+            tape.sweep_reason = str(e)
+            return None
+        self._check_dtype(f)
+        if f.ndim == 1:
+            f = f.unsqueeze(-1)
+        if f.ndim != 2:
+            raise NotImplementedError(f"model output must be [batch, outputs]; got {tuple(f.shape)}")
+        for t in tape.taps:
+            t.a = sweep.taps[t.name]["a"]
+
+        def grad_fn(seeds, stack=True):
+            grads = sweep.backward(seeds.reshape(seeds.shape[0], seeds.shape[1], *sweep.out_shape))
+            return [grads[t.name] for t in tape.taps]
+
+        return f.detach().reshape(f.shape[0], -1).contiguous(), tape, grad_fn
 
     # ---- seeds ----------------------------------------------------------------------------------
     def _ggn_seeds(self, f, y, loss):

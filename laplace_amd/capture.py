@@ -129,3 +129,6 @@ class Tape:
         for t in self.taps:
             t.a = None
             t.out = None
+        sweep = getattr(self, "sweep", None)
+        if sweep:
+            sweep.release()

@@ -1,0 +1,299 @@
+"""Seed-batched reverse sweep: all C-1 likelihood-Hessian seeds in ONE pass with batch ``S*B``.
+
+Stock autograd gives the per-seed output gradients only one seed at a time on ROCm (functorch has
+no fused batching rule for MIOpen's convolution backward, so ``is_grads_batched`` loops and then
+concatenates).  For a ResNet-18 minibatch that is ~120 small conv launches and ~550 tiny
+element-wise kernels per step.  This module is the "fused host-side extraction" of SURVEY.md §8f:
+
+* ``torch.fx`` traces the model once into a graph of modules / functions;
+* the forward is executed node by node on the ``B`` samples, keeping only what a vector-Jacobian
+  product needs (ReLU masks, pooling indices, BatchNorm-eval scales, ...);
+* the reverse sweep pushes a cotangent of batch ``S*B`` (seed-major) through closed-form VJP rules:
+  one MIOpen backward-data call per conv for *all* seeds, one element-wise kernel per activation.
+
+It produces exactly what :class:`laplace_amd.capture.Tape` produces (layer inputs ``a`` and output
+gradients ``g`` per tapped module), so everything downstream is unchanged.  Unsupported graphs
+(untraceable control flow, modules in training mode, ops without a rule here) raise
+:class:`SweepUnsupported` and the caller falls back to the autograd tape.  The model still runs on
+stock PyTorch-ROCm kernels — this is host-side plumbing, not a replacement for them.
+"""
+from __future__ import annotations
+
+import operator
+from typing import Any
+
+import torch
+import torch.fx as fx
+import torch.nn.functional as F
+from torch import nn
+
+
+class SweepUnsupported(RuntimeError):
+    pass
+
+
+class SeedBatchedSweep:
+    """Forward + seed-batched reverse sweep over an fx-traced module."""
+
+    _ELEMENTWISE_FN = {torch.relu, F.relu, torch.tanh, F.tanh, torch.sigmoid, F.sigmoid}
+
+    def __init__(self, model: nn.Module, tap_modules: dict[str, nn.Module], kernels=None):
+        """``kernels``: callable returning the kernel object (``laplace_amd._lib.get_kernels``) whose
+        ``vjp_scale_mask`` applies the element-wise VJPs to all seeds in one launch (lk_vjp.hip); ``None``
+        = plain torch math (reference implementation of the same rule, used by the CPU tests)."""
+        self.kernels = kernels
+        self._bn_cache: dict[str, tuple] = {}
+        try:
+            self.gm = fx.symbolic_trace(model)
+        except Exception as e:  # data-dependent control flow, non-tensor inputs, ...
+            raise SweepUnsupported(f"torch.fx cannot trace the model: {e}") from e
+        self.modules = dict(self.gm.named_modules())
+        self.tap_names = set(tap_modules)
+        self._check_graph()
+
+    # ---- static checks -------------------------------------------------------------------------------
+    def _check_graph(self):
+        n_inputs = 0
+        for node in self.gm.graph.nodes:
+            if node.op == "placeholder":
+                n_inputs += 1
+            elif node.op == "call_module":
+                m = self.modules[node.target]
+                if not isinstance(m, (nn.Conv2d, nn.Linear, nn.BatchNorm2d, nn.BatchNorm1d, nn.ReLU, nn.Tanh,
+                                      nn.Sigmoid, nn.Identity, nn.Dropout, nn.Flatten, nn.AdaptiveAvgPool2d,
+                                      nn.MaxPool2d, nn.AvgPool2d, nn.Sequential)):
+                    raise SweepUnsupported(f"no VJP rule for module {type(m).__name__} ({node.target})")
+                if isinstance(m, nn.Conv2d) and (m.groups != 1 or isinstance(m.padding, str) or m.padding_mode != "zeros"):
+                    raise SweepUnsupported(f"{node.target}: unsupported convolution variant")
+            elif node.op == "call_function":
+                if node.target not in (self._ELEMENTWISE_FN | {operator.add, torch.add, torch.flatten, operator.iadd}):
+                    raise SweepUnsupported(f"no VJP rule for function {getattr(node.target, '__name__', node.target)}")
+            elif node.op == "call_method":
+                if node.target not in ("view", "reshape", "flatten", "relu", "tanh", "sigmoid", "contiguous"):
+                    raise SweepUnsupported(f"no VJP rule for method {node.target}")
+            elif node.op == "get_attr":
+                raise SweepUnsupported("graph reads attributes directly")
+        if n_inputs != 1:
+            raise SweepUnsupported("models with one tensor input only")
+
+    # ---- forward ---------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor):
+        """Returns ``f``; fills ``self.saved`` (per node: what the VJP needs) and ``self.taps[name]['a']``."""
+        if self.gm.training or any(m.training for m in self.gm.modules() if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d, nn.Dropout))):
+            raise SweepUnsupported("model must be in eval mode (BatchNorm / Dropout VJPs assume it)")
+        env: dict[fx.Node, Any] = {}
+        self.saved: dict[fx.Node, Any] = {}
+        self.taps: dict[str, dict] = {}
+        self.out_node = None
+        for node in self.gm.graph.nodes:
+            if node.op == "placeholder":
+                env[node] = x
+            elif node.op == "output":
+                self.out_node = node.args[0]
+                if not isinstance(self.out_node, fx.Node):
+                    raise SweepUnsupported("model must return a single tensor")
+            elif node.op == "call_module":
+                m = self.modules[node.target]
+                inp = env[node.args[0]]
+                if isinstance(m, nn.MaxPool2d):
+                    out, idx = F.max_pool2d(inp, m.kernel_size, m.stride, m.padding, m.dilation, m.ceil_mode, True)
+                    self.saved[node] = (idx, inp.shape)
+                else:
+                    out = m(inp)
+                    if isinstance(m, (nn.ReLU,)):
+                        self.saved[node] = out > 0
+                    elif isinstance(m, (nn.Tanh, nn.Sigmoid)):
+                        self.saved[node] = out
+                    elif isinstance(m, (nn.AdaptiveAvgPool2d, nn.AvgPool2d, nn.Flatten)):
+                        self.saved[node] = inp.shape
+                    elif isinstance(m, nn.Conv2d):
+                        self.saved[node] = inp.shape
+                if node.target in self.tap_names:
+                    if node.target in self.taps:
+                        raise SweepUnsupported(f"{node.target}: module is applied more than once per forward")
+                    self.taps[node.target] = {"a": inp, "node": node}
+                env[node] = out
+            elif node.op == "call_function":
+                args = [env[a] if isinstance(a, fx.Node) else a for a in node.args]
+                kwargs = {k: (env[v] if isinstance(v, fx.Node) else v) for k, v in node.kwargs.items()}
+                if node.target is operator.iadd:
+                    out = args[0] + args[1]
+                else:
+                    out = node.target(*args, **kwargs)
+                if node.target in (torch.relu, F.relu):
+                    self.saved[node] = out > 0
+                elif node.target in (torch.tanh, F.tanh, torch.sigmoid, F.sigmoid):
+                    self.saved[node] = out
+                elif node.target is torch.flatten:
+                    self.saved[node] = args[0].shape
+                env[node] = out
+            elif node.op == "call_method":
+                self_t = env[node.args[0]]
+                args = [env[a] if isinstance(a, fx.Node) else a for a in node.args[1:]]
+                out = getattr(self_t, node.target)(*args, **node.kwargs)
+                if node.target == "relu":
+                    self.saved[node] = out > 0
+                elif node.target in ("tanh", "sigmoid"):
+                    self.saved[node] = out
+                elif node.target in ("view", "reshape", "flatten"):
+                    self.saved[node] = self_t.shape
+                env[node] = out
+        missing = self.tap_names - set(self.taps)
+        if missing:
+            raise SweepUnsupported(f"tapped modules not reached by the traced forward: {sorted(missing)}")
+        out = env[self.out_node]
+        self.out_shape = tuple(out.shape[1:])
+        return out
+
+    # ---- element-wise VJPs ----------------------------------------------------------------------------------
+    def _bn_scale(self, name: str, m) -> torch.Tensor:
+        """gamma / sqrt(running_var + eps), cached until the module's buffers change."""
+        key = (m.running_var._version, None if m.weight is None else m.weight._version, m.running_var.data_ptr())
+        hit = self._bn_cache.get(name)
+        if hit is None or hit[0] != key:
+            scale = torch.rsqrt(m.running_var + m.eps)
+            if m.weight is not None:
+                scale = scale * m.weight.detach()
+            hit = (key, scale)
+            self._bn_cache[name] = hit
+        return hit[1]
+
+    def _is_activation(self, node) -> bool:
+        if node.op == "call_module":
+            return isinstance(self.modules[node.target], (nn.ReLU, nn.Tanh, nn.Sigmoid))
+        if node.op == "call_function":
+            return node.target in self._ELEMENTWISE_FN
+        return node.op == "call_method" and node.target in ("relu", "tanh", "sigmoid")
+
+    def _scale_mask(self, g, S, mult, scale, g2=None):
+        """``(g[s] + g2[s]) * mult * scale[channel]`` for all seeds (``g``: [S*B, C, ...], ``mult``: [B, C, ...])."""
+        if mult is None and scale is None:
+            return g if g2 is None else g + g2
+        hw = 1
+        for d in g.shape[2:]:
+            hw *= d
+        if self.kernels is not None:
+            return self.kernels().vjp_scale_mask(g.contiguous(), S, mult, scale, hw,
+                                                 None if g2 is None else g2.contiguous())
+        out = g if g2 is None else g + g2
+        if mult is not None:
+            out = (out.reshape(S, *mult.shape) * mult).reshape(g.shape)
+        if scale is not None:
+            out = out * scale.reshape((1, -1) + (1,) * (g.dim() - 2))
+        return out
+
+    @staticmethod
+    def _act_mult(kind, saved):
+        """per-sample derivative of the activation from what the forward kept (ReLU: the mask itself)"""
+        if kind in (torch.relu, F.relu, "relu") or isinstance(kind, nn.ReLU):
+            return saved
+        if kind in (torch.tanh, F.tanh, "tanh") or isinstance(kind, nn.Tanh):
+            return 1 - saved * saved
+        return saved * (1 - saved)  # sigmoid
+
+    def _fold_bn(self, src):
+        """If the activation's input is an eval-mode BatchNorm used only by it, its scale folds into the
+        activation's VJP: returns (scale, node to push the cotangent to)."""
+        if (isinstance(src, fx.Node) and src.op == "call_module" and len(src.users) == 1
+                and isinstance(self.modules[src.target], (nn.BatchNorm2d, nn.BatchNorm1d))):
+            return self._bn_scale(src.target, self.modules[src.target]), src.args[0]
+        return None, src
+
+    # ---- reverse sweep -----------------------------------------------------------------------------------
+    @torch.no_grad()
+    def backward(self, seeds: torch.Tensor) -> dict[str, torch.Tensor]:
+        """``seeds``: ``[S, B, C]`` cotangents of the output.  Returns per tapped module the gradient w.r.t.
+        its output, ``[S, B, ...]`` (a view of the ``S*B``-batched cotangent)."""
+        S, B = seeds.shape[0], seeds.shape[1]
+        # per node: the pending addends of its output cotangent (summed lazily, so that an activation can fold
+        # the residual-branch addition into its own kernel)
+        cot: dict[fx.Node, list] = {self.out_node: [seeds.reshape(S * B, *seeds.shape[2:])]}
+        grads: dict[str, torch.Tensor] = {}
+        remaining = set(self.tap_names)
+
+        def push(n, g):
+            if not isinstance(n, fx.Node) or n.op == "placeholder":
+                return
+            cot.setdefault(n, []).append(g)
+
+        for node in reversed(list(self.gm.graph.nodes)):
+            if node not in cot or node.op in ("placeholder", "output"):
+                continue
+            parts, g2 = cot.pop(node), None
+            g = parts[0]
+            if len(parts) > 1:
+                if self._is_activation(node):
+                    g2 = parts[1] if len(parts) == 2 else sum(parts[2:], parts[1])
+                else:
+                    g = sum(parts[1:], parts[0])
+            if node.op == "call_module":
+                m = self.modules[node.target]
+                if node.target in self.tap_names:
+                    grads[node.target] = g.reshape(S, B, *g.shape[1:])
+                    remaining.discard(node.target)
+                    if not remaining:
+                        break  # nothing upstream of the first tapped module is needed
+                src = node.args[0]
+                if isinstance(m, nn.Conv2d):
+                    in_shape = (S * B,) + tuple(self.saved[node][1:])
+                    push(src, torch.nn.grad.conv2d_input(in_shape, m.weight, g, m.stride, m.padding, m.dilation, m.groups))
+                elif isinstance(m, nn.Linear):
+                    push(src, g @ m.weight)
+                elif isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d)):
+                    push(src, self._scale_mask(g, S, None, self._bn_scale(node.target, m)))
+                elif isinstance(m, (nn.ReLU, nn.Tanh, nn.Sigmoid)):
+                    scale, dst = self._fold_bn(src)
+                    push(dst, self._scale_mask(g, S, self._act_mult(m, self.saved[node]), scale, g2))
+                elif isinstance(m, (nn.Identity, nn.Dropout)):
+                    push(src, g)
+                elif isinstance(m, nn.Flatten):
+                    push(src, g.reshape((S * B,) + tuple(self.saved[node][1:])))
+                elif isinstance(m, nn.AdaptiveAvgPool2d):
+                    shp = self.saved[node]
+                    if tuple(g.shape[-2:]) != (1, 1):
+                        raise SweepUnsupported("AdaptiveAvgPool2d VJP implemented for output size 1")
+                    push(src, (g / (shp[-1] * shp[-2])).expand(S * B, *shp[1:]))
+                elif isinstance(m, nn.AvgPool2d):
+                    shp = self.saved[node]
+                    k = m.kernel_size if isinstance(m.kernel_size, tuple) else (m.kernel_size, m.kernel_size)
+                    st = m.stride if isinstance(m.stride, tuple) else (m.stride, m.stride)
+                    if m.padding not in (0, (0, 0)) or k != st or shp[-2] % k[0] or shp[-1] % k[1]:
+                        raise SweepUnsupported("AvgPool2d VJP implemented for non-overlapping, unpadded windows")
+                    push(src, g.repeat_interleave(k[0], -2).repeat_interleave(k[1], -1) / (k[0] * k[1]))
+                elif isinstance(m, nn.MaxPool2d):
+                    idx, shp = self.saved[node]
+                    idx_s = idx.unsqueeze(0).expand(S, *idx.shape).reshape(S * B, *idx.shape[1:])
+                    out = torch.zeros(S * B, shp[1], shp[2] * shp[3], dtype=g.dtype, device=g.device)
+                    out.scatter_add_(2, idx_s.reshape(S * B, shp[1], -1), g.reshape(S * B, shp[1], -1))
+                    push(src, out.reshape(S * B, *shp[1:]))
+                elif isinstance(m, nn.Sequential):
+                    raise SweepUnsupported("nested Sequential was not inlined by the tracer")
+            elif node.op == "call_function":
+                t = node.target
+                if t in (operator.add, torch.add, operator.iadd):
+                    if node.kwargs.get("alpha", 1) != 1:
+                        raise SweepUnsupported("add with alpha")
+                    for a in node.args[:2]:
+                        push(a, g)
+                elif t in self._ELEMENTWISE_FN:
+                    scale, dst = self._fold_bn(node.args[0])
+                    push(dst, self._scale_mask(g, S, self._act_mult(t, self.saved[node]), scale, g2))
+                elif t is torch.flatten:
+                    push(node.args[0], g.reshape((S * B,) + tuple(self.saved[node][1:])))
+            elif node.op == "call_method":
+                t = node.target
+                if t in ("relu", "tanh", "sigmoid"):
+                    scale, dst = self._fold_bn(node.args[0])
+                    push(dst, self._scale_mask(g, S, self._act_mult(t, self.saved[node]), scale, g2))
+                elif t in ("view", "reshape", "flatten"):
+                    push(node.args[0], g.reshape((S * B,) + tuple(self.saved[node][1:])))
+                elif t == "contiguous":
+                    push(node.args[0], g)
+        if remaining:
+            raise SweepUnsupported(f"no cotangent reached {sorted(remaining)}")
+        return grads
+
+    def release(self):
+        self.saved = {}
+        self.taps = {}

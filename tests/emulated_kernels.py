@@ -108,6 +108,17 @@ class EmulatedKernels:
         P = Js.shape[-1]
         h += alpha * (Js.reshape(-1, P)[:, col0:col0 + width] ** 2).sum(0)
 
+    def vjp_scale_mask(self, g, S, mult, scale, hw, g2=None):
+        out = g.reshape(S, -1)
+        if g2 is not None:
+            out = out + g2.reshape(S, -1)
+        if mult is not None:
+            out = out * mult.reshape(1, -1).to(g.dtype)
+        if scale is not None:
+            C = scale.numel()
+            out = (out.reshape(S, -1, C, hw) * scale.reshape(1, 1, C, 1).to(g.dtype)).reshape(S, -1)
+        return (out + 0).reshape(g.shape)
+
     def ll_ggn_full(self, phi, probs, has_bias, alpha, H):
         B, D = phi.shape
         pt = torch.cat([phi, torch.ones(B, 1, dtype=phi.dtype)], 1) if has_bias else phi

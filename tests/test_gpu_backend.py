@@ -205,3 +205,26 @@ def test_R4_additivity_and_R7(name):
         lr, kr = b.kron(X, y, N=N, kfac_approx="reduce")
         check(lr, lf, tol=1e-6, what="R7 loss")
         assert not torch.allclose(kr.diag(), kf.diag())
+
+
+@pytest.mark.parametrize("act", ["relu", "tanh"])
+def test_seed_batched_sweep_matches_autograd_tape(act):
+    """laplace_amd/sweep.py: one reverse pass of batch (C-1)*B gives the factors of C-1 autograd passes.
+    (Same forward kernels on both sides, so the ReLU masks are identical.)"""
+    from laplace_amd.backend import HipGGN
+    from laplace_amd.nets import ResNet18
+
+    torch.manual_seed(5)
+    model = ResNet18(act=torch.relu if act == "relu" else torch.tanh).to(DEV).eval()
+    X = torch.randn(16, 3, 16, 16, device=DEV)
+    y = torch.randint(0, 10, (16,), device=DEV)
+    tape_b = HipGGN(model, "classification")
+    tape_b.use_sweep = False
+    loss0, H0 = tape_b.kron(X, y, N=64)
+    b = HipGGN(model, "classification")
+    loss1, H1 = b.kron(X, y, N=64)
+    assert b._tape().sweep not in (None, False), getattr(b._tape(), "sweep_reason", "")
+    check(loss1, loss0, what="loss")
+    for i, (F0, F1) in enumerate(zip(H0.kfacs, H1.kfacs)):
+        for a, c in zip(F0, F1):
+            check(c, a, what=f"factor of block {i}")

@@ -367,3 +367,32 @@ def test_quadforms(K, B, C, Do, Di):
     assert_close(got, want, what="diag_quadform_linear")
     Js, var = rnd(B, C, 301, seed=8), rnd(301, seed=9).abs()
     assert_close(K.diag_quadform_js(f32(Js), f32(var)), EMU.diag_quadform_js(Js, var), what="diag_quadform_js")
+
+
+# ---- element-wise VJP of the seed-batched sweep -------------------------------------------------------------
+@pytest.mark.parametrize("S,B,C,hw", [(9, 8, 16, 64), (3, 5, 7, 9), (1, 4, 6, 1), (4, 3, 5, 12), (9, 2, 3, 1024)])
+@pytest.mark.parametrize("mult", ["bool", "float", None])
+@pytest.mark.parametrize("scaled", [True, False])
+@pytest.mark.parametrize("two", [False, True])
+def test_vjp_scale_mask(K, S, B, C, hw, mult, scaled, two):
+    gen = torch.Generator().manual_seed(S * 1000 + B * 100 + C * 10 + hw)
+    g64 = torch.randn(S * B, C, hw, generator=gen, dtype=torch.float64)
+    m64 = None
+    if mult == "bool":
+        m64 = torch.rand(B, C, hw, generator=gen) > 0.4
+    elif mult == "float":
+        m64 = torch.randn(B, C, hw, generator=gen, dtype=torch.float64)
+    sc64 = torch.randn(C, generator=gen, dtype=torch.float64) if scaled else None
+    h64 = torch.randn(S * B, C, hw, generator=gen, dtype=torch.float64) if two else None
+    want = EMU.vjp_scale_mask(g64, S, m64, sc64, hw, h64)
+    g = g64.float().to(DEV)
+    h = None if h64 is None else h64.float().to(DEV)
+    m = None if m64 is None else (m64.to(DEV) if m64.dtype == torch.bool else m64.float().to(DEV))
+    sc = None if sc64 is None else sc64.float().to(DEV)
+    got = K.vjp_scale_mask(g, S, m, sc, hw, h)
+    _sync()
+    assert got.shape == g.shape
+    assert_close(got, want, 1e-6, "vjp_scale_mask")
+    if mult == "bool":  # masked entries are exact zeros
+        dead = (~m64).unsqueeze(0).expand(S, B, C, hw).reshape(S * B, C, hw)
+        assert (got.cpu()[dead] == 0).all()

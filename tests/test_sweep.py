@@ -1,0 +1,155 @@
+"""Seed-batched reverse sweep (laplace_amd/sweep.py) against stock autograd (laplace_amd/capture.py).
+
+The sweep replaces `C-1` reverse passes by one pass of batch `S*B`; what it hands the kernels must be
+what autograd hands them: same layer inputs, same output gradients (fp64 here, so the comparison is
+exact up to summation order).  Unsupported graphs must fall back to the tape, not fail.
+"""
+import pytest
+import torch
+from torch import nn
+
+from laplace_amd.capture import Tape
+from laplace_amd.nets import ResNet18, lenet5
+from laplace_amd.sweep import SeedBatchedSweep, SweepUnsupported
+from oracle.fixtures import FIXTURES, build_model, input_shape
+
+
+class Residual(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.c1 = nn.Conv2d(3, 6, 3, padding=1)
+        self.bn = nn.BatchNorm2d(6)
+        self.c2 = nn.Conv2d(6, 6, 3, padding=1, bias=False)
+        self.short = nn.Sequential(nn.Conv2d(3, 6, 1, bias=False), nn.BatchNorm2d(6))
+        self.pool = nn.AvgPool2d(2)
+        self.mp = nn.MaxPool2d(2)
+        self.fc = nn.Linear(6 * 2 * 2, 4)
+
+    def forward(self, x):
+        h = torch.relu(self.bn(self.c1(x)))
+        h = torch.sigmoid(self.c2(h))
+        h = h + self.short(x)
+        h = self.mp(self.pool(h.relu()))
+        return self.fc(h.flatten(1))
+
+
+def _models():
+    yield "resnet18", ResNet18(), (3, 16, 16), 10
+    yield "lenet5", lenet5(), (3, 32, 32), 10
+    yield "residual", Residual(), (3, 8, 8), 4
+    for n in FIXTURES:
+        m = build_model(n)
+        with torch.no_grad():
+            c = m(torch.zeros(1, *input_shape(n), dtype=next(m.parameters()).dtype)).shape[-1]
+        yield n, m, input_shape(n), c
+
+
+@pytest.mark.parametrize("name,model,shape,C", list(_models()), ids=lambda v: v if isinstance(v, str) else "")
+def test_sweep_matches_autograd(name, model, shape, C):
+    torch.manual_seed(3)
+    model = model.double().eval()
+    for m in model.modules():  # non-trivial BatchNorm statistics
+        if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d)):
+            m.running_mean.normal_()
+            m.running_var.uniform_(0.5, 2.0)
+            m.weight.data.normal_()
+    B, S = 5, 4
+    x = torch.randn(B, *shape, dtype=torch.float64)
+    params = [p for p in model.parameters() if p.requires_grad]
+    tape = Tape(model, params)
+    sweep = SeedBatchedSweep(model, {t.name: t.module for t in tape.taps})
+    f_ref = tape.forward(x)
+    f = sweep.forward(x)
+    assert torch.equal(f, f_ref.detach())
+    seeds = torch.randn(S, B, C, dtype=torch.float64)
+    want = tape.output_grads(f_ref, seeds)
+    got = sweep.backward(seeds)
+    for t, w in zip(tape.taps, want):
+        assert torch.equal(sweep.taps[t.name]["a"], t.a), t.name
+        g = got[t.name]
+        assert g.shape == w.shape, t.name
+        assert (g - w).abs().max() <= 1e-12 * (1 + w.abs().max()), t.name
+
+
+class Gated(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a, self.b = nn.Linear(3, 5), nn.Linear(5, 2)
+
+    def forward(self, x):
+        return self.b(self.a(x) * 2.0)  # operator.mul has no rule here
+
+
+def test_unsupported_graphs_are_refused():
+    m = Gated()
+    with pytest.raises(SweepUnsupported):
+        SeedBatchedSweep(m, {"a": m.a, "b": m.b})
+    sw = SeedBatchedSweep(ResNet18().train(), {})
+    with pytest.raises(SweepUnsupported):
+        sw.forward(torch.randn(2, 3, 8, 8))  # BatchNorm in training mode
+
+
+def test_backend_falls_back_to_the_tape():
+    """An untraceable / unsupported model still works (autograd tape) and gives the same factors."""
+    from laplace_amd import _lib
+    from laplace_amd.backend import HipGGN
+    from tests.emulated_kernels import EmulatedKernels
+
+    prev = _lib.set_kernels_for_testing(EmulatedKernels())
+    try:
+        torch.manual_seed(0)
+        m = Gated()
+        X, y = torch.randn(6, 3), torch.randint(0, 2, (6,))
+        b = HipGGN(m, "classification")
+        loss, H = b.kron(X, y, N=6)
+        assert b._tape().sweep is False and "mul" in b._tape().sweep_reason
+        # same model written with a supported graph: fold the factor 2 into the first layer
+        m2 = nn.Sequential(nn.Linear(3, 5), nn.Linear(5, 2))
+        m2[0].weight.data, m2[0].bias.data = 2 * m.a.weight.data, 2 * m.a.bias.data
+        m2[1].weight.data, m2[1].bias.data = m.b.weight.data, m.b.bias.data
+        b2 = HipGGN(m2, "classification")
+        loss2, H2 = b2.kron(X, y, N=6)
+        assert b2._tape().sweep not in (None, False)
+        assert torch.allclose(loss, loss2, rtol=1e-5)
+        # G factors coincide layer by layer scaled by 4 / 1 (first layer's output gradient is halved)
+        # kfacs = [[G_a, A_a], [G_a], [G_b, A_b], [G_b]]
+        assert torch.allclose(H.kfacs[2][0], H2.kfacs[2][0], rtol=1e-4, atol=1e-7)
+        assert torch.allclose(H.kfacs[2][1], H2.kfacs[2][1], rtol=1e-4, atol=1e-7)
+        assert torch.allclose(H.kfacs[0][0], 4 * H2.kfacs[0][0], rtol=1e-4, atol=1e-7)
+    finally:
+        _lib.set_kernels_for_testing(prev)
+
+
+@pytest.mark.parametrize("use_sweep", [True, False])
+def test_backend_sweep_and_tape_agree(use_sweep):
+    from laplace_amd import _lib
+    from laplace_amd.backend import HipGGN
+    from tests.emulated_kernels import EmulatedKernels
+
+    prev = _lib.set_kernels_for_testing(EmulatedKernels())
+    try:
+        torch.manual_seed(1)
+        model = Residual().eval()
+        for m in model.modules():  # the HIP Jacobian kernels cover nn.Linear / nn.Conv2d parameters
+            if isinstance(m, nn.BatchNorm2d):
+                m.weight.requires_grad_(False), m.bias.requires_grad_(False)
+        X, y = torch.randn(6, 3, 8, 8), torch.randint(0, 4, (6,))
+        ref = HipGGN(model, "classification")
+        ref.use_sweep = False
+        loss0, H0 = ref.kron(X, y, N=12)
+        b = HipGGN(model, "classification")
+        b.use_sweep = use_sweep
+        loss1, H1 = b.kron(X, y, N=12)
+        assert (b._tape().sweep not in (None, False)) == use_sweep if use_sweep else True
+        assert torch.allclose(loss0, loss1)
+        for F0, F1 in zip(H0.kfacs, H1.kfacs):
+            for a, c in zip(F0, F1):
+                assert torch.allclose(a, c, rtol=1e-4, atol=1e-7)
+        _, d0 = ref.diag(X, y, N=12)
+        _, d1 = b.diag(X, y, N=12)
+        assert torch.allclose(d0, d1, rtol=1e-4, atol=1e-7)
+        J0, f0 = ref.jacobians(X)
+        J1, f1 = b.jacobians(X)
+        assert torch.allclose(J0, J1, rtol=1e-4, atol=1e-6) and torch.allclose(f0, f1)
+    finally:
+        _lib.set_kernels_for_testing(prev)
