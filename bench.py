@@ -244,6 +244,21 @@ def main():
             result["predictive"] = predictive_leg(dev)
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+    if world > 1 and not args.no_eigh:
+        # the factors are identical on every rank after the all-reduce: shard the eigensolves over the GPUs
+        barrier()
+        t0 = time.perf_counter()
+        dec = H.decompose(distributed=True)
+        barrier()
+        t = torch.tensor([time.perf_counter() - t0], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ok = torch.tensor([float(all(int(i[0].item()) == 0 for i in dec._eig_info))], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if rank == 0:
+            result["eigh_ms"] = float(t.item()) * 1e3
+            result["eigh_sharded_over_gpus"] = world
+            result["eigh_converged"] = bool(ok.item())
+        del dec
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

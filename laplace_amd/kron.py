@@ -101,16 +101,43 @@ class HipKron(_KronBase):
         return len(self.kfacs)
 
     # -- eigendecomposition (matrix.py:123-150; utils/utils.py:193-228) -----------------------------
-    def decompose(self, damping: bool = False, n_streams: int = 6) -> "HipKronDecomposed":
+    @staticmethod
+    def shard_factors(sizes: list[int], world: int) -> list[int]:
+        """Owner rank of every dense factor: longest-processing-time-first on the eigensolver's ~n^3 cost.
+        Deterministic, so every rank computes the same assignment without communicating."""
+        load = [0.0] * world
+        owner = [0] * len(sizes)
+        for i in sorted(range(len(sizes)), key=lambda i: (-sizes[i], i)):
+            r = min(range(world), key=lambda r: (load[r], r))
+            owner[i] = r
+            load[r] += float(sizes[i]) ** 3
+        return owner
+
+    def decompose(self, damping: bool = False, n_streams: int = 6, process_group=None,
+                  distributed: bool = False) -> "HipKronDecomposed":
         """Eigendecompose every dense factor with the HIP block-Jacobi solver.
 
         The solver of one matrix is a long chain of small launches (latency-bound pivot solves), so the
         factors are spread over ``n_streams`` HIP streams (largest first) and run concurrently; the
         calling stream waits for all of them before returning.
+
+        ``distributed=True`` (every rank of ``process_group`` holds the SAME factors, i.e. after the fit's
+        all-reduce): the factors are sharded over the ranks (:meth:`shard_factors`), each rank solves its
+        share, and one all-reduce of a packed buffer — owners contribute their eigenpairs, everybody else
+        zeros — hands every rank the full decomposition.  The reference has no counterpart (single process).
         """
         K = get_kernels()
         dense = [(Hi.shape[0], bi, fi) for bi, F in enumerate(self.kfacs) for fi, Hi in enumerate(F) if Hi.ndim > 1]
         dense.sort(reverse=True)
+        import torch.distributed as dist
+
+        world = dist.get_world_size(process_group) if (distributed and dist.is_available() and dist.is_initialized()) else 1
+        mine = dense
+        if world > 1:
+            rank = dist.get_rank(process_group)
+            owner = self.shard_factors([n for n, _, _ in dense], world)
+            mine = [d for d, o in zip(dense, owner) if o == rank]
+        all_dense, dense = dense, mine
         results = {}
         infos = []
         use_streams = bool(dense) and self.kfacs[dense[0][1]][dense[0][2]].is_cuda and n_streams > 1 and len(dense) > 1
@@ -137,6 +164,27 @@ class HipKron(_KronBase):
                 l, Q, info = K.syevj(self.kfacs[bi][fi].contiguous(), clamp=True)
                 results[(bi, fi)] = (l, Q)
                 infos.append(info)
+        if world > 1 and all_dense:
+            # packed exchange: [eigenvalues | eigenvectors | not-converged flag] per factor, owners fill their slots
+            ref_t = self.kfacs[all_dense[0][1]][all_dense[0][2]]
+            total = sum(n + n * n + 1 for n, _, _ in all_dense)
+            flat = torch.zeros(total, dtype=ref_t.dtype, device=ref_t.device)
+            off, slots = 0, {}
+            for n, bi, fi in all_dense:
+                slots[(bi, fi)] = off
+                if (bi, fi) in results:
+                    l, Q = results[(bi, fi)]
+                    flat[off:off + n] = l
+                    flat[off + n:off + n + n * n] = Q.reshape(-1)
+                off += n + n * n + 1
+            for (n, bi, fi), info in zip(dense, infos):
+                flat[slots[(bi, fi)] + n + n * n] = info[0].to(flat.dtype)
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=process_group)
+            results, infos = {}, []
+            for n, bi, fi in all_dense:
+                off = slots[(bi, fi)]
+                results[(bi, fi)] = (flat[off:off + n], flat[off + n:off + n + n * n].view(n, n))
+                infos.append(flat[off + n + n * n:off + n + n * n + 1])
         eigvecs, eigvals = [], []
         for bi, F in enumerate(self.kfacs):
             Qs, ls = [], []

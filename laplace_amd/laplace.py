@@ -308,7 +308,10 @@ class HipKronLaplace(_HipLaplace):
             self.n_data = N
             self._posterior_cache = None
         self.H_facs = self.H
-        self.H = self.H_facs.decompose(damping=self.damping)  # HIP eigensolver per factor
+        if distributed is None:
+            distributed = dist.is_available() and dist.is_initialized()
+        # HIP eigensolver per factor; after a data-parallel fit the factors are sharded over the ranks
+        self.H = self.H_facs.decompose(damping=self.damping, distributed=bool(distributed), process_group=process_group)
 
     @property
     def posterior_precision(self):

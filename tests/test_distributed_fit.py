@@ -35,6 +35,8 @@ def _worker(rank, world, port, hs, out_path):
         loader = ShardedLoader(DataLoader(TensorDataset(X, y), batch_size=2), rank, world)
         la = HipLaplace(model, "classification", "all", hs, prior_precision=0.7)
         la.fit(loader)
+        if hs == "kron":  # every rank keeps the FULL decomposition although it solved only its share
+            torch.save({"l": la.H.eigenvalues, "Q": la.H.eigenvectors}, f"{out_path}.eig{rank}")
         if rank == 0:
             payload = {"loss": la.loss, "n_data": la.n_data}
             if hs == "kron":
@@ -73,5 +75,29 @@ def test_sharded_fit_equals_single_process(tmp_path, hs):
             for a, b in zip(F_, G_):
                 torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
         torch.testing.assert_close(got["marglik"], ref_marglik, rtol=1e-5, atol=1e-5)
+        # sharded eigendecomposition: identical on both ranks (it is exchanged, not recomputed), and a valid
+        # decomposition of every factor
+        e0 = torch.load(out + ".eig0", weights_only=False)
+        e1 = torch.load(out + ".eig1", weights_only=False)
+        for F_, ls0, ls1, Qs0, Qs1 in zip(la.H_facs.kfacs, e0["l"], e1["l"], e0["Q"], e1["Q"]):
+            for Hi, l0, l1, Q0, Q1 in zip(F_, ls0, ls1, Qs0, Qs1):
+                assert torch.equal(l0, l1) and torch.equal(Q0, Q1)
+                if Hi.ndim > 1:
+                    torch.testing.assert_close(Q0 @ torch.diag(l0) @ Q0.T, Hi, rtol=1e-4, atol=1e-5)
     else:
         torch.testing.assert_close(got["H"], la.H, rtol=1e-5, atol=1e-6)
+
+
+def test_factor_sharding_is_balanced_and_deterministic():
+    from laplace_amd.kron import HipKron
+
+    sizes = [4608, 4608, 4608, 2304, 2304, 2304, 2304, 1152, 1152, 1152, 1152, 576, 576, 576, 576, 576, 512, 512,
+             512, 512, 512, 256, 256, 256, 256, 256, 128, 128, 128, 128, 128, 64, 64, 64, 64, 64, 64, 27, 10]
+    for world in (1, 2, 4, 8):
+        owner = HipKron.shard_factors(sizes, world)
+        assert owner == HipKron.shard_factors(list(sizes), world) and set(owner) <= set(range(world))
+        load = [sum(float(n) ** 3 for n, o in zip(sizes, owner) if o == r) for r in range(world)]
+        # the critical path is at most one largest factor above the ideal split
+        assert max(load) <= sum(load) / world + float(max(sizes)) ** 3
+    owner = HipKron.shard_factors(sizes, 8)
+    assert len({owner[0], owner[1], owner[2]}) == 3  # the three 4608-factors land on different GPUs
