@@ -132,6 +132,24 @@ def predictive_leg(dev):
             "fit_samples_per_s": fit_rate, "predictive_samples_per_s": 10 * 512 / (time.time() - t0)}
 
 
+def pmc_traffic(kernel_prefix: str):
+    """HBM bytes per launch of the dominant kernel family from the committed rocprofv3 PMC passes over this very
+    command (FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied: tools/pmc_traffic.py).
+    Counters cannot be collected from inside the process, so the figure is read from profiles/; None if absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic_bench_c4.json")
+    try:
+        with open(path) as fh:
+            table = json.load(fh)
+    except (OSError, ValueError):
+        return None, None
+    rows = [v for k, v in table.items() if k.startswith(kernel_prefix)]
+    launches = sum(r["launches"] for r in rows)
+    if not launches:
+        return None, None
+    total = sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows)
+    return total / launches, "profiles/r01_pmc_traffic_bench_c4.{json,md} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2x read correction)"
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -202,6 +220,7 @@ def main():
         ms_t, work_t, n_t = agg("gram_tn")
         ms_s, work_s, n_s = agg("shiftcorr")
         ach = work_c / (ms_c * 1e-3) / 1e12 if ms_c > 0 else 0.0
+        traffic, traffic_src = pmc_traffic("void lk::gram_kernel<2,")
         result = {
             "metric": "KFAC-GGN fit samples/sec, ResNet-18",
             "value": samples / dt,
@@ -221,7 +240,8 @@ def main():
             "roofline": {
                 "kernel": "lk::gram_kernel<MODE_CONV> (+ slab reduce): A-factor accumulation, exact-fp32 MFMA",
                 "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch",
+                "traffic_source": traffic_src,
                 "flop_convention": "symmetric half: K*n*(n+1) per launch (full-GEMM 2*K*n^2 would double it)",
                 "launches": n_c, "avg_launch_ms": ms_c / max(n_c, 1),
             },

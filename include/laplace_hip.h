@@ -166,6 +166,18 @@ size_t lk_syevj_workspace_bytes(int64_t n);
 int lk_syevj_f32(const float* A, int64_t n, float* w, float* Q, int clamp, int max_sweeps, int32_t* info,
                  void* ws, size_t ws_bytes, void* stream);
 
+/* All factors of one Kron.decompose (laplace/utils/matrix.py:123-150 loops over them one by one) in one call.
+ * Matrix i (arguments as lk_syevj_f32, given as HOST arrays of `count` entries; ws[i] >=
+ * lk_syevj_workspace_bytes(n[i]), private to matrix i) runs on streams[i % nstreams], matrices sharing a stream in
+ * index order (pass the largest first).  A host-side scheduler keeps every stream two sweeps ahead of the device,
+ * reads each solve's `converged` flag back asynchronously and finalises a matrix as soon as it has converged, so
+ * no stream starves behind another one's launch queue and no empty sweeps are enqueued.
+ * EXCEPTION to the no-host-synchronisation rule: the call returns when the last sweep of every matrix has
+ * executed (the refinement / sort / gather of the last matrices may still be in flight on their streams). */
+int lk_syevj_batched_f32(int64_t count, const float* const* A, const int64_t* n, float* const* w, float* const* Q,
+                         int32_t* const* info, void* const* ws, const size_t* ws_bytes, int clamp, int max_sweeps,
+                         void* const* streams, int64_t nstreams);
+
 /* ---------------------------------------------------------------------------------------------
  * KronDecomposed.logdet (laplace/utils/matrix.py:381-404) for one two-factor block, with the
  * derivatives autograd needs for the marginal-likelihood sweep (baselaplace.py:466-485):

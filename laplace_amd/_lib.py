@@ -61,6 +61,7 @@ SIGNATURES = {
     "lk_ll_ggn_full_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _f32, _vp, _vp, _sz, _vp]),
     "lk_syevj_workspace_bytes": (_sz, [_i64]),
     "lk_syevj_f32": (_int, [_vp, _i64, _vp, _vp, _int, _int, _vp, _vp, _sz, _vp]),
+    "lk_syevj_batched_f32": (_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _vp, _i64]),
     "lk_kron_logdet_workspace_bytes": (_sz, [_i64]),
     "lk_kron_logdet_f32": (_int, [_vp, _i64, _vp, _i64, _vp, _int, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "lk_kron_quadform_linear_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
@@ -405,6 +406,51 @@ class HipKernels:
         )
         ws.record_stream(torch.cuda.current_stream(A.device))
         return w, Q, info
+
+    def syevj_batched(self, mats, clamp=True, max_sweeps=0, streams=None):
+        """Eigendecompose a list of symmetric matrices (largest first is best) -> list of (w, Q, info).
+
+        ``streams``: torch side streams the solves are spread over (matrix i on ``streams[i % len]``); the caller
+        orders them against its own stream (``wait_stream`` before / after).  ``None`` = the current stream."""
+        if not mats:
+            return []
+        dev = mats[0].device
+        cur = torch.cuda.current_stream(dev)
+        streams = list(streams) if streams else [cur]
+        count = len(mats)
+        outs, keep = [], []
+        arr = lambda ctype, vals: (ctype * count)(*vals)  # noqa: E731
+        ns = []
+        for i, A in enumerate(mats):
+            _check(A, "A")
+            n = A.shape[0]
+            assert A.shape == (n, n) and A.device == dev
+            w = torch.empty(n, dtype=torch.float32, device=dev)
+            Q = torch.empty(n, n, dtype=torch.float32, device=dev)
+            info = torch.zeros(2, dtype=torch.int32, device=dev)
+            ws = torch.empty(max(self.lib.lk_syevj_workspace_bytes(n), 1), dtype=torch.uint8, device=dev)
+            outs.append((w, Q, info))
+            keep.append(ws)
+            ns.append(n)
+        nstreams = min(len(streams), count)
+        used = streams[:nstreams]
+        # `info` was zero-filled on the current stream: the side streams must see that (and the inputs) first
+        for st in used:
+            if st != cur:
+                st.wait_stream(cur)
+        rc = self.lib.lk_syevj_batched_f32(
+            count, arr(ctypes.c_void_p, [A.data_ptr() for A in mats]), arr(ctypes.c_int64, ns),
+            arr(ctypes.c_void_p, [o[0].data_ptr() for o in outs]), arr(ctypes.c_void_p, [o[1].data_ptr() for o in outs]),
+            arr(ctypes.c_void_p, [o[2].data_ptr() for o in outs]), arr(ctypes.c_void_p, [w_.data_ptr() for w_ in keep]),
+            arr(ctypes.c_size_t, [w_.numel() for w_ in keep]), 1 if clamp else 0, int(max_sweeps),
+            arr(ctypes.c_void_p, [st.cuda_stream for st in used]), nstreams)
+        self._rc(rc, "lk_syevj_batched_f32")
+        for i, (A, o, ws) in enumerate(zip(mats, outs, keep)):
+            st = used[i % nstreams]
+            if st != cur:  # allocated on `cur`, used on `st`
+                for t in (A, ws) + o:
+                    t.record_stream(st)
+        return outs
 
     # ---- logdet -------------------------------------------------------------------------------
     def kron_logdet(self, l1, l2, delta, damping=False, want_grads=False):

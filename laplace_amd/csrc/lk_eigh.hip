@@ -17,6 +17,11 @@
 //   quotients v_i^T A v_i against the ORIGINAL matrix (three MFMA GEMMs), then rank-sorted ascending,
 //   clamped, and V's columns gathered.
 // Zero padding is exact: padded rows/columns never rotate (their off-diagonals are exactly 0).
+#include <chrono>
+#include <cstdlib>
+#include <thread>
+#include <vector>
+
 #include "lk_common.h"
 
 namespace lk {
@@ -292,10 +297,16 @@ __device__ __forceinline__ void quad_store(float (*Z)[ELD], const f32x16& acc, i
   for (int r = 0; r < 16; ++r) Z[wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi][wn * 32 + lo] = acc[r];
 }
 
-__global__ __launch_bounds__(256) void eig_update_kernel(float* __restrict__ Aw, int np, int nb, int step,
-                                                         const float* __restrict__ Rws,
+// One launch per round: workgroups [0, ntiles) rotate the tiles of A, the remaining npv * (np/64) rotate V
+// (section 3 below) -- the two updates are independent of each other, so they share the launch and the chip.
+__device__ void eig_vupdate_block(float (*X)[ELD], float (*Y)[ELD], float* __restrict__ V, int np, int nb, int step,
+                                  const float* __restrict__ Rws, const int* __restrict__ rotated, int Q, int rb);
+
+__global__ __launch_bounds__(256) void eig_update_kernel(float* __restrict__ Aw, float* __restrict__ V, int np, int nb,
+                                                         int step, const float* __restrict__ Rws,
                                                          const float* __restrict__ Dws,
-                                                         const int* __restrict__ rotated, const EigCtrl* ctrl) {
+                                                         const int* __restrict__ rotated, const EigCtrl* ctrl,
+                                                         int ntiles) {
   if (ctrl->converged) return;
   __shared__ float X[EP][ELD];
   __shared__ float Y[EP][ELD];
@@ -303,6 +314,11 @@ __global__ __launch_bounds__(256) void eig_update_kernel(float* __restrict__ Aw,
   const int lo = lane & 31, hi = lane >> 5, wm = wave >> 1, wn = wave & 1;
   // linear index over pivot pairs P <= Q
   const int npv = nb / 2;
+  if ((int)blockIdx.x >= ntiles) {
+    const int v = blockIdx.x - ntiles;
+    eig_vupdate_block(X, Y, V, np, nb, step, Rws, rotated, v % npv, v / npv);
+    return;
+  }
   int P = 0, rem = blockIdx.x, rowlen = npv;
   while (rem >= rowlen) {
     rem -= rowlen;
@@ -350,15 +366,11 @@ __global__ __launch_bounds__(256) void eig_update_kernel(float* __restrict__ Aw,
 }
 
 // ---- 3. eigenvector update  V[:, Q] <- V[:, Q] R_Q -----------------------------------------------------
-__global__ __launch_bounds__(256) void eig_vupdate_kernel(float* __restrict__ V, int np, int nb, int step,
-                                                          const float* __restrict__ Rws,
-                                                          const int* __restrict__ rotated, const EigCtrl* ctrl) {
-  if (ctrl->converged || !rotated[blockIdx.x]) return;
-  __shared__ float X[EP][ELD];
-  __shared__ float Y[EP][ELD];
+__device__ void eig_vupdate_block(float (*X)[ELD], float (*Y)[ELD], float* __restrict__ V, int np, int nb, int step,
+                                  const float* __restrict__ Rws, const int* __restrict__ rotated, int Q, int rb) {
+  if (!rotated[Q]) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lo = lane & 31, hi = lane >> 5, wm = wave >> 1, wn = wave & 1;
-  const int Q = blockIdx.x, rb = blockIdx.y;
   int IQ, JQ;
   pivot_blocks(step, Q, nb, IQ, JQ);
   const float* RQ = Rws + (int64_t)Q * EP * EP;
@@ -528,77 +540,242 @@ extern "C" size_t lk_syevj_workspace_bytes(int64_t n) {
   return eig_plan(n).total;
 }
 
-extern "C" int lk_syevj_f32(const float* A, int64_t n, float* w, float* Q, int clamp, int max_sweeps, int32_t* info,
-                            void* ws, size_t ws_bytes, void* stream_) {
-  LK_REQUIRE(A && w && Q && n >= 0 && n <= 32768, "lk_syevj_f32: bad arguments");
-  if (n == 0) return LK_OK;
-  hipStream_t stream = (hipStream_t)stream_;
-  const EigPlan p = eig_plan(n);
-  if (ws == nullptr || ws_bytes < p.total) {
-    set_error("lk_syevj_f32: workspace too small (%zu < %zu bytes)", ws_bytes, p.total);
+namespace lk {
+
+struct EigJob {  // one matrix in flight: buffers carved out of its workspace + the solver constants
+  EigPlan p;
+  const float* A;
+  int64_t n;
+  float *w, *Q;
+  int32_t* info;
+  float *Aw, *V, *A0, *T, *Rws, *Dws, *dvec;
+  int *perm, *rotated;
+  EigCtrl* ctrl;
+  int clamp;
+};
+
+static const float kTolRel = 3.0e-7f;   // ~2.5 eps: |a_pq| <= tol_rel*sqrt(|a_pp a_qq|) counts as annihilated
+static const float kTolAbs = 6.0e-8f;   // x lambda_max: absolute floor for (numerically) rank-deficient factors
+static const float kTolConv = 1.0e-6f;  // x lambda_max: only rotations of larger elements keep the solve "unconverged";
+                                        // what is left below it is removed from the spectrum by the Rayleigh refinement
+static int eig_max_inner() {
+  // inner sweeps per pivot visit.  One is best on the MI355X: the outer sweep count does not change (measured on the
+  // ResNet-18 KFAC factors, tools/eig_study.py: 1065 ms vs 1479 ms with three) and the pivot solve -- the latency
+  // chain of the whole solver -- is three times shorter.
+  static int v = [] {
+    int r = 1;
+    if (const char* e = getenv("LK_EIG_INNER")) {  // tuning knob (tools/eig_study.py)
+      const int t = atoi(e);
+      if (t >= 1 && t <= 8) r = t;
+    }
+    return r;
+  }();
+  return v;
+}
+
+static int eig_job_setup(EigJob& j, const float* A, int64_t n, float* w, float* Q, int clamp, int32_t* info, void* ws,
+                         size_t ws_bytes) {
+  j.p = eig_plan(n);
+  if (ws == nullptr || ws_bytes < j.p.total) {
+    set_error("lk_syevj_f32: workspace too small (%zu < %zu bytes)", ws_bytes, j.p.total);
     return LK_EWORKSPACE;
   }
   char* base = static_cast<char*>(ws);
-  float* Aw = reinterpret_cast<float*>(base + p.off_A);
-  float* V = reinterpret_cast<float*>(base + p.off_V);
-  float* A0 = reinterpret_cast<float*>(base + p.off_A0);
-  float* T = reinterpret_cast<float*>(base + p.off_T);
-  float* Rws = reinterpret_cast<float*>(base + p.off_R);
-  float* Dws = reinterpret_cast<float*>(base + p.off_D);
-  int* perm = reinterpret_cast<int*>(base + p.off_perm);
-  float* dvec = reinterpret_cast<float*>(base + p.off_diag);
-  int* rotated = reinterpret_cast<int*>(base + p.off_rot);
-  EigCtrl* ctrl = reinterpret_cast<EigCtrl*>(base + p.off_ctrl);
-  if (max_sweeps <= 0) max_sweeps = 24;
-  const int kMaxInner = 3;         // inner sweeps per pivot visit (the outer sweeps finish the job)
-  const float tol_rel = 3.0e-7f;   // ~2.5 eps: |a_pq| <= tol_rel*sqrt(|a_pp a_qq|) counts as annihilated
-  const float tol_abs = 6.0e-8f;   // x max|a_ii|: absolute floor for (numerically) rank-deficient factors
-  const float tol_conv = 1.0e-6f;  // x max|a_ii|: only rotations of larger elements keep the solve "unconverged";
-                                   // what is left below it is removed from the spectrum by the Rayleigh refinement
+  j.A = A, j.n = n, j.w = w, j.Q = Q, j.info = info, j.clamp = clamp;
+  j.Aw = reinterpret_cast<float*>(base + j.p.off_A);
+  j.V = reinterpret_cast<float*>(base + j.p.off_V);
+  j.A0 = reinterpret_cast<float*>(base + j.p.off_A0);
+  j.T = reinterpret_cast<float*>(base + j.p.off_T);
+  j.Rws = reinterpret_cast<float*>(base + j.p.off_R);
+  j.Dws = reinterpret_cast<float*>(base + j.p.off_D);
+  j.perm = reinterpret_cast<int*>(base + j.p.off_perm);
+  j.dvec = reinterpret_cast<float*>(base + j.p.off_diag);
+  j.rotated = reinterpret_cast<int*>(base + j.p.off_rot);
+  j.ctrl = reinterpret_cast<EigCtrl*>(base + j.p.off_ctrl);
+  return LK_OK;
+}
 
-  if (hipMemsetAsync(ctrl, 0, sizeof(EigCtrl), stream) != hipSuccess) {
+static int eig_enqueue_init(const EigJob& j, hipStream_t stream) {
+  const EigPlan& p = j.p;
+  if (hipMemsetAsync(j.ctrl, 0, sizeof(EigCtrl), stream) != hipSuccess) {
     set_error("lk_syevj_f32: hipMemsetAsync failed");
     return LK_ELAUNCH;
   }
   int64_t blocks = ((int64_t)p.np * p.np + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(eig_init_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, A, (int)n, p.np, Aw, A0, V, ctrl);
-  {  // lambda_max estimate -> ctrl->scale (x, y live in the not-yet-used T buffer)
-    float* xv = T;
-    float* yv = T + p.np;
-    hipLaunchKernelGGL(eig_normalize_kernel, dim3(1), dim3(256), 0, stream, yv, p.np, xv, ctrl, 1);
-    for (int it = 0; it < 8; ++it) {
-      hipLaunchKernelGGL(eig_matvec_kernel, dim3((p.np + 3) / 4), dim3(256), 0, stream, A0, p.np, xv, yv);
-      hipLaunchKernelGGL(eig_normalize_kernel, dim3(1), dim3(256), 0, stream, yv, p.np, xv, ctrl, 0);
-    }
+  hipLaunchKernelGGL(eig_init_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, j.A, (int)j.n, p.np, j.Aw, j.A0, j.V,
+                     j.ctrl);
+  // lambda_max estimate -> ctrl->scale (x, y live in the not-yet-used T buffer)
+  float* xv = j.T;
+  float* yv = j.T + p.np;
+  hipLaunchKernelGGL(eig_normalize_kernel, dim3(1), dim3(256), 0, stream, yv, p.np, xv, j.ctrl, 1);
+  for (int it = 0; it < 8; ++it) {
+    hipLaunchKernelGGL(eig_matvec_kernel, dim3((p.np + 3) / 4), dim3(256), 0, stream, j.A0, p.np, xv, yv);
+    hipLaunchKernelGGL(eig_normalize_kernel, dim3(1), dim3(256), 0, stream, yv, p.np, xv, j.ctrl, 0);
   }
+  return LK_OK;
+}
+
+static void eig_enqueue_sweep(const EigJob& j, hipStream_t stream) {
+  const EigPlan& p = j.p;
   const int steps = p.nb - 1;
   const int ntiles = p.npv * (p.npv + 1) / 2;
-  for (int sweep = 0; sweep < max_sweeps; ++sweep) {
-    for (int s = 0; s < steps; ++s) {
-      hipLaunchKernelGGL(eig_pivot_kernel, dim3(p.npv), dim3(256), 0, stream, Aw, p.np, p.nb, s, Rws, Dws, rotated,
-                         ctrl, tol_rel, tol_abs, tol_conv, kMaxInner);
-      hipLaunchKernelGGL(eig_update_kernel, dim3(ntiles), dim3(256), 0, stream, Aw, p.np, p.nb, s, Rws, Dws, rotated,
-                         ctrl);
-      hipLaunchKernelGGL(eig_vupdate_kernel, dim3(p.npv, p.np / EP), dim3(256), 0, stream, V, p.np, p.nb, s, Rws,
-                         rotated, ctrl);
-    }
-    hipLaunchKernelGGL(eig_sweep_end_kernel, dim3(1), dim3(1), 0, stream, ctrl);
+  const int nvblk = p.npv * (p.np / EP);
+  const int inner = eig_max_inner();
+  for (int s = 0; s < steps; ++s) {
+    hipLaunchKernelGGL(eig_pivot_kernel, dim3(p.npv), dim3(256), 0, stream, j.Aw, p.np, p.nb, s, j.Rws, j.Dws, j.rotated,
+                       j.ctrl, kTolRel, kTolAbs, kTolConv, inner);
+    hipLaunchKernelGGL(eig_update_kernel, dim3(ntiles + nvblk), dim3(256), 0, stream, j.Aw, j.V, p.np, p.nb, s, j.Rws,
+                       j.Dws, j.rotated, j.ctrl, ntiles);
   }
-  // refinement: one Newton-Schulz step re-orthonormalises V (thousands of fp32 rotations leave
-  // ||V^T V - I|| ~ 1e-5), then the eigenvalues are recomputed as Rayleigh quotients against the ORIGINAL
-  // matrix, which removes the accumulated transformation error from the spectrum.
-  {
-    dim3 gg(p.np / 64, p.np / 64);
-    hipLaunchKernelGGL((eig_gemm_kernel<true>), gg, dim3(256), 0, stream, V, V, (const float*)nullptr, T, p.np, 1.f, 0.f);
-    hipLaunchKernelGGL((eig_gemm_kernel<false>), gg, dim3(256), 0, stream, V, T, V, Aw, p.np, -0.5f, 1.5f);  // Aw <- V2
-    hipLaunchKernelGGL((eig_gemm_kernel<false>), gg, dim3(256), 0, stream, A0, Aw, (const float*)nullptr, T, p.np, 1.f, 0.f);
-    hipLaunchKernelGGL(eig_coldot_kernel, dim3(p.np / 64), dim3(256), 0, stream, Aw, T, p.np, dvec);
-  }
-  hipLaunchKernelGGL(eig_rank_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dvec, (int)n, perm);
-  int64_t gblocks = (n * n + 255) / 256;
+  hipLaunchKernelGGL(eig_sweep_end_kernel, dim3(1), dim3(1), 0, stream, j.ctrl);
+}
+
+// refinement: one Newton-Schulz step re-orthonormalises V (thousands of fp32 rotations leave
+// ||V^T V - I|| ~ 1e-5), then the eigenvalues are recomputed as Rayleigh quotients against the ORIGINAL
+// matrix, which removes the accumulated transformation error from the spectrum; then sort / clamp / gather.
+static void eig_enqueue_finalize(const EigJob& j, hipStream_t stream) {
+  const EigPlan& p = j.p;
+  dim3 gg(p.np / 64, p.np / 64);
+  hipLaunchKernelGGL((eig_gemm_kernel<true>), gg, dim3(256), 0, stream, j.V, j.V, (const float*)nullptr, j.T, p.np, 1.f, 0.f);
+  hipLaunchKernelGGL((eig_gemm_kernel<false>), gg, dim3(256), 0, stream, j.V, j.T, j.V, j.Aw, p.np, -0.5f, 1.5f);  // Aw <- V2
+  hipLaunchKernelGGL((eig_gemm_kernel<false>), gg, dim3(256), 0, stream, j.A0, j.Aw, (const float*)nullptr, j.T, p.np, 1.f, 0.f);
+  hipLaunchKernelGGL(eig_coldot_kernel, dim3(p.np / 64), dim3(256), 0, stream, j.Aw, j.T, p.np, j.dvec);
+  hipLaunchKernelGGL(eig_rank_kernel, dim3((unsigned)((j.n + 255) / 256)), dim3(256), 0, stream, j.dvec, (int)j.n, j.perm);
+  int64_t gblocks = (j.n * j.n + 255) / 256;
   if (gblocks > 4096) gblocks = 4096;
-  hipLaunchKernelGGL(eig_gather_kernel, dim3((unsigned)gblocks), dim3(256), 0, stream, dvec, Aw, perm, (int)n, p.np,
-                     clamp, w, Q, ctrl, info);
+  hipLaunchKernelGGL(eig_gather_kernel, dim3((unsigned)gblocks), dim3(256), 0, stream, j.dvec, j.Aw, j.perm, (int)j.n, p.np,
+                     j.clamp, j.w, j.Q, j.ctrl, j.info);
+}
+
+}  // namespace lk
+
+extern "C" int lk_syevj_f32(const float* A, int64_t n, float* w, float* Q, int clamp, int max_sweeps, int32_t* info,
+                            void* ws, size_t ws_bytes, void* stream_) {
+  LK_REQUIRE(A && w && Q && n >= 0 && n <= 32768, "lk_syevj_f32: bad arguments");
+  if (n == 0) return LK_OK;
+  hipStream_t stream = (hipStream_t)stream_;
+  EigJob j;
+  if (int rc = eig_job_setup(j, A, n, w, Q, clamp, info, ws, ws_bytes)) return rc;
+  if (max_sweeps <= 0) max_sweeps = 24;
+  if (int rc = eig_enqueue_init(j, stream)) return rc;
+  // fully asynchronous: every sweep is enqueued; once the device-side `converged` flag is up the rest return at once
+  for (int sweep = 0; sweep < max_sweeps; ++sweep) eig_enqueue_sweep(j, stream);
+  eig_enqueue_finalize(j, stream);
   return check_launch("lk_syevj_f32");
+}
+
+// ---- many matrices: host-side scheduler -------------------------------------------------------------------------
+// A KFAC posterior needs one decomposition per factor (42 for ResNet-18, n = 10 ... 4608).  Enqueuing them one after
+// the other serialises the whole job on the host: a single solve is ~10^4 dependent launches, the device queue
+// back-pressures the enqueuing thread, and the other streams starve.  The scheduler below keeps every stream
+// exactly `kLookahead` sweeps ahead of the device: per stream it enqueues one sweep of the current matrix, an
+// asynchronous read-back of its `converged` flag into pinned memory and an event, then moves on to the next
+// stream; flags are polled without blocking, a converged matrix is finalised immediately (no empty sweeps) and the
+// stream's next matrix starts.  The host only sleeps on an event when every stream is already `kLookahead` ahead.
+extern "C" int lk_syevj_batched_f32(int64_t count, const float* const* A, const int64_t* n, float* const* w,
+                                    float* const* Q, int32_t* const* info, void* const* ws, const size_t* ws_bytes,
+                                    int clamp, int max_sweeps, void* const* streams, int64_t nstreams) {
+  LK_REQUIRE(count >= 0 && nstreams >= 1 && streams && (count == 0 || (A && n && w && Q && info && ws && ws_bytes)),
+             "lk_syevj_batched_f32: bad arguments");
+  if (count == 0) return LK_OK;
+  if (max_sweeps <= 0) max_sweeps = 24;
+  constexpr int kLookahead = 2;
+  constexpr int kSlots = kLookahead + 1;
+  struct Lane {                 // one stream and the matrices queued on it (round-robin assignment, input order)
+    hipStream_t stream;
+    std::vector<int> jobs;
+    size_t cur = 0;             // index into jobs
+    bool started = false;
+    int enq = 0;                // sweeps enqueued for the current matrix
+    int pending_head = 0, pending = 0;  // ring of outstanding flag read-backs (<= kLookahead)
+    hipEvent_t ev[kSlots];
+  };
+  std::vector<EigJob> jobs((size_t)count);
+  for (int64_t i = 0; i < count; ++i) {
+    LK_REQUIRE(n[i] >= 0 && n[i] <= 32768 && (n[i] == 0 || (A[i] && w[i] && Q[i])), "lk_syevj_batched_f32: bad matrix");
+    if (n[i] == 0) continue;
+    if (int rc = eig_job_setup(jobs[(size_t)i], A[i], n[i], w[i], Q[i], clamp, info[i], ws[i], ws_bytes[i])) return rc;
+  }
+  const int64_t nl = nstreams < count ? nstreams : count;
+  std::vector<Lane> lanes((size_t)nl);
+  int* hflags = nullptr;
+  if (hipHostMalloc(reinterpret_cast<void**>(&hflags), sizeof(int) * kSlots * (size_t)nl, hipHostMallocDefault) != hipSuccess) {
+    set_error("lk_syevj_batched_f32: hipHostMalloc failed");
+    return LK_ELAUNCH;
+  }
+  int rc = LK_OK;
+  for (int64_t l = 0; l < nl; ++l) {
+    lanes[(size_t)l].stream = (hipStream_t)streams[l];
+    for (int k = 0; k < kSlots; ++k)
+      if (hipEventCreateWithFlags(&lanes[(size_t)l].ev[k], hipEventDisableTiming) != hipSuccess) rc = LK_ELAUNCH;
+  }
+  for (int64_t i = 0; i < count; ++i)
+    if (n[i] > 0) lanes[(size_t)(i % nl)].jobs.push_back((int)i);
+
+  size_t active = 0;
+  for (auto& L : lanes) active += L.cur < L.jobs.size();
+  while (active > 0 && rc == LK_OK) {
+    bool progressed = false;
+    for (size_t li = 0; li < lanes.size() && rc == LK_OK; ++li) {
+      Lane& L = lanes[li];
+      if (L.cur >= L.jobs.size()) continue;
+      const EigJob& j = jobs[(size_t)L.jobs[L.cur]];
+      if (!L.started) {
+        rc = eig_enqueue_init(j, L.stream);
+        L.started = true, L.enq = 0, L.pending = 0, L.pending_head = 0;
+        progressed = true;
+        if (rc != LK_OK) break;
+      }
+      // harvest finished read-backs (in order)
+      bool converged = false;
+      while (L.pending > 0) {
+        const int slot = L.pending_head % kSlots;
+        const hipError_t q = hipEventQuery(L.ev[slot]);
+        if (q == hipErrorNotReady) break;
+        if (q != hipSuccess) {
+          set_error("lk_syevj_batched_f32: %s", hipGetErrorString(q));
+          rc = LK_ELAUNCH;
+          break;
+        }
+        converged = converged || hflags[li * kSlots + slot] != 0;
+        ++L.pending_head, --L.pending;
+        progressed = true;
+      }
+      if (rc != LK_OK) break;
+      if (converged || L.enq >= max_sweeps) {
+        eig_enqueue_finalize(j, L.stream);
+        ++L.cur, L.started = false;
+        if (L.cur >= L.jobs.size()) --active;
+        progressed = true;
+        continue;
+      }
+      if (L.pending < kLookahead) {
+        eig_enqueue_sweep(j, L.stream);
+        const int slot = (L.pending_head + L.pending) % kSlots;
+        if (hipMemcpyAsync(&hflags[li * kSlots + slot], &j.ctrl->converged, sizeof(int), hipMemcpyDeviceToHost, L.stream) !=
+                hipSuccess ||
+            hipEventRecord(L.ev[slot], L.stream) != hipSuccess) {
+          set_error("lk_syevj_batched_f32: flag read-back failed");
+          rc = LK_ELAUNCH;
+          break;
+        }
+        ++L.enq, ++L.pending;
+        progressed = true;
+      }
+    }
+    // every lane is kLookahead sweeps ahead of the device: nap instead of spinning (a blocking wait on ONE lane's
+    // event would starve the lanes whose small matrices finish sooner)
+    if (!progressed && rc == LK_OK) std::this_thread::sleep_for(std::chrono::microseconds(20));
+  }
+  // speculative read-backs still in flight write into hflags: drain them before the pinned buffer goes away
+  for (auto& L : lanes) {
+    for (int k = 0; k < kSlots; ++k) {
+      (void)hipEventSynchronize(L.ev[k]);
+      (void)hipEventDestroy(L.ev[k]);
+    }
+  }
+  (void)hipHostFree(hflags);
+  if (rc != LK_OK) return rc;
+  return check_launch("lk_syevj_batched_f32");
 }

@@ -387,8 +387,12 @@ __global__ __launch_bounds__(256) void gram_kernel(GramGeom g, float* __restrict
   const int c_end = min(my_chunks, c_begin + chunks_per_split);
   float* slab = slabs + (((int64_t)reg * gridDim.y + blockIdx.y) * npairs + blockIdx.x) * (C::T * C::T);
 
+  // FULL = the wave's whole WT x WT patch lies inside the matrix: branch-free MFMA loop and unguarded direct
+  // epilogue.  (am == TW alone is NOT enough: am counts partially covered 32x32 sub-tiles too, and an unguarded
+  // `C[row][col] += 0` on the rows / columns beyond n is an out-of-bounds read-modify-write.)
+  const bool inside = (colA + (wm + 1) * C::WT <= (RECT ? g.nA : g.n)) && (colB + (wn + 1) * C::WT <= (RECT ? g.nB : g.n));
   // Every wave executes the same number of barriers on either path.
-  if (am == TW && an == TW) {
+  if (inside) {
     gram_body<MODE, VEC, CFG, true>(g, smem, slab, tid, wm, wn, lo, hi, diag, colA, colB, c_begin, c_end, am, an,
                                       Cdirect, alpha, reg);
   } else {

@@ -140,30 +140,21 @@ class HipKron(_KronBase):
         all_dense, dense = dense, mine
         results = {}
         infos = []
-        use_streams = bool(dense) and self.kfacs[dense[0][1]][dense[0][2]].is_cuda and n_streams > 1 and len(dense) > 1
-        if use_streams:
-            dev = self.kfacs[dense[0][1]][dense[0][2]].device
-            main = torch.cuda.current_stream(dev)
-            streams = _side_streams(dev, min(n_streams, len(dense)))
-            for st in streams:
-                st.wait_stream(main)
-            for i, (_, bi, fi) in enumerate(dense):
-                st = streams[i % len(streams)]
-                Hi = self.kfacs[bi][fi].contiguous()
-                with torch.cuda.stream(st):
-                    l, Q, info = K.syevj(Hi, clamp=True)
-                Hi.record_stream(st)          # allocated on `main`, read on `st`
-                for t in (l, Q, info):        # allocated on `st`, consumed on `main` from here on
-                    t.record_stream(main)
+        if dense:
+            mats = [self.kfacs[bi][fi].contiguous() for _, bi, fi in dense]
+            streams = None
+            if mats[0].is_cuda and n_streams > 1 and len(mats) > 1:
+                dev = mats[0].device
+                main = torch.cuda.current_stream(dev)
+                streams = _side_streams(dev, min(n_streams, len(mats)))
+            # one call for all factors: the native scheduler interleaves the solves over the streams
+            solved = K.syevj_batched(mats, clamp=True, streams=streams)
+            for (_, bi, fi), (l, Q, info) in zip(dense, solved):
                 results[(bi, fi)] = (l, Q)
                 infos.append(info)
-            for st in streams:
-                main.wait_stream(st)
-        else:
-            for _, bi, fi in dense:
-                l, Q, info = K.syevj(self.kfacs[bi][fi].contiguous(), clamp=True)
-                results[(bi, fi)] = (l, Q)
-                infos.append(info)
+            if streams is not None:
+                for st in streams:
+                    main.wait_stream(st)
         if world > 1 and all_dense:
             # packed exchange: [eigenvalues | eigenvectors | not-converged flag] per factor, owners fill their slots
             ref_t = self.kfacs[all_dense[0][1]][all_dense[0][2]]

@@ -141,6 +141,9 @@ class EmulatedKernels:
             w = w.clamp(min=0.0)
         return torch.nan_to_num(w), torch.nan_to_num(Q), torch.zeros(2, dtype=torch.int32)
 
+    def syevj_batched(self, mats, clamp=True, max_sweeps=0, streams=None):
+        return [self.syevj(A, clamp, max_sweeps) for A in mats]
+
     # logdet
     def kron_logdet(self, l1, l2, delta, damping=False, want_grads=False):
         d = delta.reshape(())
