@@ -115,9 +115,44 @@ class _HipCurvatureMixin:
         return f.detach().reshape(f.shape[0], -1).contiguous(), tape, grad_fn
 
     # ---- seeds ----------------------------------------------------------------------------------
+    def _mc_functional_grads(self, f):
+        """``num_samples`` draws of the functional gradient of the log-likelihood at the model's own predictive,
+        ``[S, B, C]`` (laplace/curvature/curvature.py:341-364): regression ``f - y~ = -eps``, ``y~ ~ N(f, 1)``;
+        classification ``softmax(f) - onehot(y~)``, ``y~ ~ Cat(softmax(f))``.  Device RNG = torch's Philox stream
+        (``self.generator`` if set)."""
+        S = int(self.num_samples)
+        gen = getattr(self, "generator", None)
+        B, C = f.shape
+        if self.likelihood == "regression":
+            return -torch.randn(S, B, C, generator=gen, device=f.device, dtype=f.dtype)
+        p = torch.softmax(f, dim=-1)
+        idx = torch.multinomial(p, S, replacement=True, generator=gen)  # [B, S]
+        g = p.unsqueeze(0).repeat(S, 1, 1)
+        g.scatter_add_(2, idx.t().unsqueeze(-1), torch.full((S, B, 1), -1.0, device=f.device, dtype=f.dtype))
+        return g
+
+    def _mc_seeds(self, f, y, loss):
+        """MC-Fisher seeds: ``sum_s seeds_s seeds_s^T = 1/S sum_s g_s g_s^T`` (the middle matrix of
+        ``_get_mc_functional_fisher``).  KFAC follows curvlinops' ``FisherType.MC`` for ``MSELoss``: the sampled
+        gradient of ``sum (f-y)^2`` has covariance ``2I``, hence the hessian_scale 2 as in the exact case."""
+        K = get_kernels()
+        B, C = f.shape
+        if self.likelihood == "regression":
+            if y is not None:
+                K.sq_err_sum(f, y.reshape(B, C).to(torch.float32).contiguous(), self.factor, loss)
+            hs = 2.0
+        else:
+            if y is not None:
+                K.softmax_hess_sqrt(f, y.reshape(B).to(torch.int64).contiguous(), loss)  # CE loss only
+            hs = 1.0
+        g = self._mc_functional_grads(f)
+        return (g / math.sqrt(g.shape[0])).contiguous(), hs
+
     def _ggn_seeds(self, f, y, loss):
         """Columns of a root of the loss Hessian w.r.t. f, laid out ``[C, B, C]``; accumulates
         ``factor * loss`` into ``loss``.  Returns (seeds, hessian_scale)."""
+        if getattr(self, "stochastic", False):
+            return self._mc_seeds(f, y, loss)
         K = get_kernels()
         B, C = f.shape
         if self.likelihood == "regression":
@@ -417,14 +452,19 @@ class KronAccumulator:
 
 
 class HipGGN(_HipCurvatureMixin, GGNInterface):
-    """Generalised Gauss-Newton on HIP (exact GGN; ``stochastic=True`` is not implemented)."""
+    """Generalised Gauss-Newton on HIP — replaces GGNInterface (laplace/curvature/curvature.py:293-433) and
+    CurvlinopsGGN's KFAC (curvlinops.py:150-164).  ``stochastic=True`` is the MC Fisher with ``num_samples`` draws
+    per data point (curvature.py:341-364; KFAC: ``FisherType.MC`` with ``mc_samples``): the same accumulation
+    kernels, ``num_samples`` seed columns instead of ``C - 1``.  ``self.generator`` (optional ``torch.Generator``
+    on the model's device) makes the draws reproducible."""
 
     def __init__(self, model, likelihood, last_layer=False, subnetwork_indices=None,
                  dict_key_x="input_ids", dict_key_y="labels", stochastic=False, num_samples=1):
-        if stochastic:
-            raise NotImplementedError("HipGGN implements the exact GGN; the MC Fisher is not available yet")
+        if stochastic and int(num_samples) < 1:
+            raise ValueError("num_samples must be >= 1")
         super().__init__(model, likelihood, last_layer, subnetwork_indices, dict_key_x, dict_key_y,
-                         stochastic=False, num_samples=num_samples)
+                         stochastic=stochastic, num_samples=num_samples)
+        self.generator = None
 
     _kron_seeds = _HipCurvatureMixin._ggn_seeds
 
@@ -447,7 +487,7 @@ class HipGGN(_HipCurvatureMixin, GGNInterface):
     # dense GGN — replaces GGNInterface.full (laplace/curvature/curvature.py:375-411)
     def full(self, x, y, **kwargs):
         K = get_kernels()
-        if self.last_layer and self.subnetwork_indices is None:
+        if self.last_layer and self.subnetwork_indices is None and not self.stochastic:
             f, tape, _ = self._forward(x)
             phi = tape.taps[0].a.to(torch.float32).contiguous()
             B, C = f.shape

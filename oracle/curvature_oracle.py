@@ -136,6 +136,19 @@ def functional_hessian_sqrt(f: torch.Tensor, likelihood: str):
 # --------------------------------------------------------------------------------------
 # dense / diagonal GGN and EF
 # --------------------------------------------------------------------------------------
+def mc_functional_fisher(grad_samples: torch.Tensor):
+    """Middle matrix of the MC Fisher GIVEN the sampled functional gradients ``[S, B, C]``
+    (curvature.py:341-364: ``F += 1/num_samples * einsum('bc,bk->bck', grad_sample, grad_sample)``; the sampling
+    itself — ``f - y~`` with ``y~ ~ N(f, 1)``, or ``softmax(f) - y~`` with ``y~ ~ Multinomial(logits=f)`` — is done
+    by the caller so that a test can hand the same draws to both sides)."""
+    S = grad_samples.shape[0]
+    F_ = torch.zeros(grad_samples.shape[1], grad_samples.shape[2], grad_samples.shape[2], dtype=grad_samples.dtype)
+    for s in range(S):
+        g = grad_samples[s]
+        F_ += g.unsqueeze(2) * g.unsqueeze(1) / S
+    return F_
+
+
 def ggn_full(Js: torch.Tensor, H_lik: torch.Tensor):
     """``H = sum_n J_n^T Lambda_n J_n`` (curvature.py:375-411, einsum ``bcp,bck,bkq->pq``)."""
     H = torch.zeros(Js.shape[-1], Js.shape[-1], dtype=Js.dtype)
@@ -221,6 +234,7 @@ def kfac_ggn(
     params: Sequence[nn.Parameter] | None = None,
     kfac_approx: str = "expand",
     empirical: bool = False,
+    mc_grads: torch.Tensor | None = None,
 ):
     """``(loss, kfacs)`` exactly as ``CurvlinopsInterface.kron`` returns them.
 
@@ -228,7 +242,11 @@ def kfac_ggn(
       1. forward with input hooks -> per-layer ``A = (1/(M L)) sum a a^T``            (K1)
       2. C backward passes seeded with the columns of the loss-Hessian square root
          (TYPE2/exact; MSE-sum Hessian is 2I, CE-sum Hessian is Lambda) -> ``G = sum g g^T``
-         (``empirical=True``: one pass seeded with the loss gradient, FisherType.EMPIRICAL)
+         (``empirical=True``: one pass seeded with the loss gradient, FisherType.EMPIRICAL;
+         ``mc_grads`` [S, B, C]: FisherType.MC with ``mc_samples = S`` (curvlinops.py:150-164 passes
+         ``fisher_type=MC if stochastic``) given the sampled functional gradients in the convention of
+         curvature.py:341-364 — curvlinops samples the *loss* gradient, which for ``MSELoss(sum)`` is the
+         functional gradient times sqrt(2) in distribution (covariance 2I), and averages over the draws)
       3. ordering ``[G, A]`` then ``[G]`` for the bias (curvlinops.py:55-75)             (K2)
       4. ``A *= M/N`` on two-factor blocks (curvlinops.py:46-53)                        (K3)
       5. ``kron *= factor`` = every factor of a 2-block times ``factor**0.5``, 1-blocks times
@@ -253,7 +271,10 @@ def kfac_ggn(
     M = B
     outs = [taps[name]["out"] for name, _ in mods]
 
-    if empirical:
+    if mc_grads is not None:
+        scale = (math.sqrt(2.0) if likelihood == "regression" else 1.0) / math.sqrt(mc_grads.shape[0])
+        seeds = [scale * mc_grads[s].to(f.dtype) for s in range(mc_grads.shape[0])]
+    elif empirical:
         if likelihood == "regression":
             seeds = [2.0 * (f.detach() - y)]
         else:
