@@ -69,9 +69,11 @@ int lk_sq_err_sum_f32(const float* f, const float* y, int64_t numel, float scale
  *         (rows = (b,oh,ow), columns = (kh,kw,ci)) is accumulated WITHOUT materialising it.
  *         Column order of C is (kh,kw,ci) ("native"); lk_permute_sym_f32 converts to the
  *         reference's F.unfold order (ci,kh,kw).
- * C is [n][n] (ldc = n).  Workspace: lk_gram_workspace_bytes(n, K_total).
+ * C is [n][n] (ldc = n).  Workspace: lk_gram_workspace_bytes(n, K) for _tn (K rows) and _conv (K = B*OH*OW);
+ * lk_gram_nt_workspace_bytes(nb_total, n, L) for _nt / _nt_seg (nb_total = nseg * nb images of L positions).
  * ------------------------------------------------------------------------------------------- */
 size_t lk_gram_workspace_bytes(int64_t n, int64_t K);
+size_t lk_gram_nt_workspace_bytes(int64_t nb_total, int64_t n, int64_t L);
 int lk_gram_tn_f32(const float* X, int64_t K, int64_t n, int64_t ldx, float alpha, float* C,
                    unsigned flags, void* ws, size_t ws_bytes, void* stream);
 int lk_gram_nt_f32(const float* X, int64_t nb, int64_t n, int64_t L, float alpha, float* C,

@@ -37,6 +37,7 @@ SIGNATURES = {
     "lk_softmax_hess_chol_f32": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "lk_sq_err_sum_f32": (_int, [_vp, _vp, _i64, _f32, _vp, _vp]),
     "lk_gram_workspace_bytes": (_sz, [_i64, _i64]),
+    "lk_gram_nt_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "lk_gram_tn_f32": (_int, [_vp, _i64, _i64, _i64, _f32, _vp, _u32, _vp, _sz, _vp]),
     "lk_gram_nt_f32": (_int, [_vp, _i64, _i64, _i64, _f32, _vp, _u32, _vp, _sz, _vp]),
     "lk_gram_nt_seg_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _f32, _vp, _u32, _vp, _sz, _vp]),
@@ -216,9 +217,7 @@ class HipKernels:
         if len(segs) > 16:
             segs = [torch.cat(segs)]
             nbat = segs[0].shape[0]
-        bk = 64 if n <= 64 else 16  # must mirror lk_gram.hip's chunk size for the virtual K
-        Lp = (L + bk - 1) // bk * bk
-        nb = self.lib.lk_gram_workspace_bytes(n, max(len(segs) * nbat * Lp, 1))
+        nb = self.lib.lk_gram_nt_workspace_bytes(len(segs) * nbat, n, L)
         dev = segs[0].device
         ws = self._workspace(nb, dev)
         ptrs = (ctypes.c_void_p * len(segs))(*[t.data_ptr() for t in segs])

@@ -22,6 +22,8 @@
 //
 // Reference being replaced: the A^T A / G^T G products inside curvlinops' KFAC as consumed by
 // laplace/curvature/curvlinops.py:55-108, and the einsums of laplace/curvature/curvature.py:406,409,491.
+#include <cstdlib>
+
 #include "lk_common.h"
 
 namespace lk {
@@ -72,14 +74,15 @@ struct GramGeom {
 };
 constexpr int MAX_REG = 8;
 
-enum { CFG_SMALL = 0, CFG_BIG = 1, CFG_WIDE = 2 };
+// CFG_BIG24 / CFG_BIG32: the 128x128 tile with deeper chunks (24 / 32 virtual rows per barrier instead of 16)
+enum { CFG_SMALL = 0, CFG_BIG = 1, CFG_WIDE = 2, CFG_BIG24 = 3, CFG_BIG32 = 4 };
 template <int CFG>
 struct Cfg {
   static constexpr bool SMALL = (CFG == CFG_SMALL);
-  static constexpr int TW = CFG + 1;           // MFMA 32x32 tiles per wave along each output dim (1 / 2 / 3)
+  static constexpr int TW = SMALL ? 1 : (CFG == CFG_WIDE ? 3 : 2);  // MFMA 32x32 tiles per wave along each output dim
   static constexpr int WT = 32 * TW;           // wave tile edge
   static constexpr int T = 2 * WT;             // output tile edge (64 / 128 / 192), 4 waves as 2x2
-  static constexpr int BK = SMALL ? 64 : 16;   // virtual rows per chunk
+  static constexpr int BK = SMALL ? 64 : (CFG == CFG_BIG24 ? 24 : (CFG == CFG_BIG32 ? 32 : 16));  // rows per chunk
   static constexpr int LDP = T + 4;            // LDS row pitch (floats), keeps 16-B alignment
   static constexpr int EPT = T * BK / 256;     // staged elements per thread per panel
 };
@@ -246,20 +249,34 @@ __device__ __forceinline__ void compute_chunk(const float* __restrict__ pA, cons
                                               f32x16 (&acc)[Cfg<CFG>::TW][Cfg<CFG>::TW], int am, int an) {
   using C = Cfg<CFG>;
   constexpr int TW = C::TW;
+  constexpr int KS = C::BK / 2;  // k-steps (two virtual rows each) per chunk
+  // Operands are software-pipelined through two register sets: the LDS reads of k-step kk+1 are issued BEFORE the
+  // MFMAs of k-step kk, so their latency hides behind TW*TW*64 cycles of matrix work instead of stalling the wave
+  // at every k-step (with a single operand set the compiler re-used the same registers and waited on lgkmcnt(0)
+  // right before each MFMA group).
+  float a[2][TW], b[2][TW];
 #pragma unroll
-  for (int kk = 0; kk < C::BK / 2; ++kk) {
-    float a[TW], b[TW];
+  for (int t = 0; t < TW; ++t) {
+    a[0][t] = pA[t * 32];
+    b[0][t] = pB[t * 32];
+  }
 #pragma unroll
-    for (int t = 0; t < TW; ++t) {
-      a[t] = pA[2 * kk * C::LDP + t * 32];
-      b[t] = pB[2 * kk * C::LDP + t * 32];
+  for (int kk = 0; kk < KS; ++kk) {
+    const int cur = kk & 1, nxt = cur ^ 1;
+    if (kk + 1 < KS) {
+#pragma unroll
+      for (int t = 0; t < TW; ++t) {
+        a[nxt][t] = pA[2 * (kk + 1) * C::LDP + t * 32];
+        b[nxt][t] = pB[2 * (kk + 1) * C::LDP + t * 32];
+      }
     }
+    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMA group (the scheduler sinks it otherwise)
 #pragma unroll
     for (int tm = 0; tm < TW; ++tm)
 #pragma unroll
       for (int tn = 0; tn < TW; ++tn)
         if (FULL || (tm < am && tn < an))
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][tm], b[cur][tn], acc[tm][tn], 0, 0, 0);
   }
 }
 
@@ -352,22 +369,30 @@ __global__ __launch_bounds__(256) void gram_kernel(GramGeom g, float* __restrict
                                                    int chunks_per_split, int nchunks, float* __restrict__ Cdirect,
                                                    float alpha) {
   using C = Cfg<CFG>;
-  constexpr int PANEL = C::BK * C::LDP;
   constexpr int TW = C::TW;
-  constexpr int NP = (C::SMALL && MODE != MODE_XCORR) ? 1 : 2;  // SMALL Gram: single diagonal tile, B aliases A
-  __shared__ __attribute__((aligned(16))) float smem[2 * NP * PANEL];  // [buf][panel A|B]
+  // dynamic LDS, 2 * NP * BK * LDP floats: [buf][panel A|B]; NP = 1 for the SMALL Gram (single diagonal tile, B
+  // aliases A), sized by cfg_lds_bytes() on the host
+  extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lo = lane & 31, hi = lane >> 5;
   constexpr bool RECT = (MODE == MODE_XCORR);
-  int bi, bj;
+  int bi, bj, split, pidx;
   if (RECT) {  // all (row tile, column tile) pairs of the rectangular output; nbt = column tiles
     bi = blockIdx.x / nbt;
     bj = blockIdx.x - bi * nbt;
+    split = blockIdx.y;
+    pidx = blockIdx.x;
   } else {
+    // Natural order: workgroup w runs on XCD w % 8, so every XCD sees every 8th tile pair -- all row panels and
+    // one residue class of column panels (~70 panels per chunk step, comfortably inside its 4 MB L2; PMC: ~0.2-0.4
+    // TB/s reach the fabric).  A contiguous-range-per-XCD remap with 8x8 super-tiles was measured 10-30 % SLOWER
+    // (96 workgroups hammering the same ~20 panels), so the simple mapping stays.
     pair_to_tiles(blockIdx.x, nbt, bi, bj);
+    split = blockIdx.y;
+    pidx = blockIdx.x;
   }
   const bool diag = !RECT && (C::SMALL || (bi == bj));
   const int colA = bi * C::T, colB = bj * C::T;
@@ -383,9 +408,9 @@ __global__ __launch_bounds__(256) void gram_kernel(GramGeom g, float* __restrict
   // of chunks earlier (their remaining slabs stay zero)
   const int reg = RECT ? (int)blockIdx.z : 0;
   const int my_chunks = RECT ? (int)((g.reg_K[reg] + C::BK - 1) / C::BK) : nchunks;
-  const int c_begin = blockIdx.y * chunks_per_split;
+  const int c_begin = split * chunks_per_split;
   const int c_end = min(my_chunks, c_begin + chunks_per_split);
-  float* slab = slabs + (((int64_t)reg * gridDim.y + blockIdx.y) * npairs + blockIdx.x) * (C::T * C::T);
+  float* slab = slabs + (((int64_t)reg * gridDim.y + split) * npairs + pidx) * (C::T * C::T);
 
   // FULL = the wave's whole WT x WT patch lies inside the matrix: branch-free MFMA loop and unguarded direct
   // epilogue.  (am == TW alone is NOT enough: am counts partially covered 32x32 sub-tiles too, and an unguarded
@@ -477,7 +502,7 @@ static void finish_plan(GramPlan& p) {
   // Split-K selection: workgroups run in "rounds" of (256 CUs x resident workgroups per CU); choose the split
   // count that minimises  rounds x (chunks per split + fixed per-workgroup overhead)  -- a launch of 1026
   // workgroups on 768 slots costs two full rounds (PMC: 83 % CU residency before this rule).
-  const int occ = p.cfg == CFG_WIDE ? 1 : (p.cfg == CFG_BIG ? 3 : 4);
+  const int occ = p.cfg == CFG_WIDE ? 1 : (p.cfg == CFG_BIG32 ? 2 : (p.cfg == CFG_SMALL ? 4 : 3));
   const int slots = 256 * occ;
   int cap = p.nchunks / 4;
   if (cap < 1) cap = 1;
@@ -505,13 +530,32 @@ static void finish_plan(GramPlan& p) {
   p.ws_bytes = (size_t)p.nslabs * p.npairs * p.T * p.T * sizeof(float);
 }
 
-static GramPlan make_plan(int64_t n, int64_t K) {
+static int cfg_tile(int cfg) { return cfg == CFG_SMALL ? 64 : (cfg == CFG_WIDE ? 192 : 128); }
+static int cfg_bk(int cfg) { return cfg == CFG_SMALL ? 64 : (cfg == CFG_BIG24 ? 24 : (cfg == CFG_BIG32 ? 32 : 16)); }
+// dynamic LDS of one workgroup: [2 buffers][panels][BK][T + 4] floats
+static size_t cfg_lds_bytes(int cfg, bool two_panels) {
+  return (size_t)2 * (two_panels ? 2 : 1) * cfg_bk(cfg) * (cfg_tile(cfg) + 4) * sizeof(float);
+}
+// The 128-tile's chunk depth.  16 rows per barrier (3 workgroups per CU) is the default; LK_GRAM_BK = 24 / 32 selects
+// the deeper variants (tuning knob, tools/microbench.py).  NT keeps 16 unless every image is a whole number of chunks.
+static int big_cfg(int64_t L_nt) {
+  static int pref = [] {
+    int v = 16;
+    if (const char* e = getenv("LK_GRAM_BK")) v = atoi(e);
+    return v;
+  }();
+  const int cfg = pref == 24 ? CFG_BIG24 : (pref == 32 ? CFG_BIG32 : CFG_BIG);
+  if (L_nt > 0 && L_nt % cfg_bk(cfg) != 0) return CFG_BIG;
+  return cfg;
+}
+
+static GramPlan make_plan(int64_t n, int64_t K, int64_t L_nt = 0) {
   GramPlan p;
   // WIDE pays where the 128-tile wastes an edge tile (n = 576 = 4.5 x 128 = 3 x 192); at n >= 1152 its single
   // resident workgroup per CU (348 registers) loses to BIG's three (measured: profiles/r01_microbench_gram_*)
-  p.cfg = n <= 64 ? CFG_SMALL : ((n % 192 == 0 && n >= 576 && n <= 768) ? CFG_WIDE : CFG_BIG);
-  p.T = p.cfg == CFG_SMALL ? 64 : (p.cfg == CFG_BIG ? 128 : 192);
-  p.BK = p.cfg == CFG_SMALL ? 64 : 16;
+  p.cfg = n <= 64 ? CFG_SMALL : ((n % 192 == 0 && n >= 576 && n <= 768) ? CFG_WIDE : big_cfg(L_nt));
+  p.T = cfg_tile(p.cfg);
+  p.BK = cfg_bk(p.cfg);
   p.nbt = (int)((n + p.T - 1) / p.T);
   p.npairs = p.nbt * (p.nbt + 1) / 2;
   p.nchunks = (int)((K + p.BK - 1) / p.BK);
@@ -523,9 +567,9 @@ static GramPlan make_plan(int64_t n, int64_t K) {
 // rectangular output [nA][nB] (MODE_XCORR): every (row tile, column tile) pair; p.nbt = column tiles
 static GramPlan make_plan_rect(int64_t nA, int64_t nB, int64_t K) {
   GramPlan p;
-  p.cfg = nA <= 64 ? CFG_SMALL : CFG_BIG;
-  p.T = p.cfg == CFG_SMALL ? 64 : 128;
-  p.BK = p.cfg == CFG_SMALL ? 64 : 16;
+  p.cfg = nA <= 64 ? CFG_SMALL : big_cfg(0);
+  p.T = cfg_tile(p.cfg);
+  p.BK = cfg_bk(p.cfg);
   p.nbt = (int)((nB + p.T - 1) / p.T);
   p.npairs = (int)((nA + p.T - 1) / p.T) * p.nbt;
   p.nchunks = (int)((K + p.BK - 1) / p.BK);
@@ -534,11 +578,22 @@ static GramPlan make_plan_rect(int64_t nA, int64_t nB, int64_t K) {
   return p;
 }
 
+// Kernels whose dynamic LDS exceeds the 64 KB default need the limit raised once per function.
+static bool allow_big_lds(const void* fn, size_t bytes) {
+  if (bytes <= 64 * 1024) return true;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+    set_error("gram: cannot raise the dynamic LDS limit to %zu bytes", bytes);
+    return false;
+  }
+  return true;
+}
+
 template <int MODE>
 static int launch_gram(const GramGeom& g, bool vec4, float alpha, float* C, unsigned flags, void* ws,
                        size_t ws_bytes, hipStream_t stream) {
   if (g.n <= 0) return LK_OK;
-  const GramPlan p = make_plan(g.n, g.K);
+  // NT: g.K counts padded positions (Lp per image); the plan wants the chunk count of exactly that
+  const GramPlan p = make_plan(g.n, g.K, MODE == MODE_NT ? g.L : 0);
   if (ws == nullptr || ws_bytes < p.ws_bytes) {
     set_error("gram: workspace too small (%zu < %zu bytes)", ws_bytes, p.ws_bytes);
     return LK_EWORKSPACE;
@@ -547,16 +602,26 @@ static int launch_gram(const GramGeom& g, bool vec4, float alpha, float* C, unsi
   dim3 grid(p.npairs, p.nsplit), block(256);
   // one split + upper-only accumulation: the kernel adds into C itself (no slab round trip)
   float* Cdirect = (p.nsplit == 1 && (flags & LK_GRAM_UPPER_ONLY)) ? C : nullptr;
-#define LK_LAUNCH(V, S)                                                                                     \
-  hipLaunchKernelGGL((gram_kernel<MODE, V, S>), grid, block, 0, stream, g, slabs, p.nbt, p.npairs, \
-                     p.chunks_per_split, p.nchunks, Cdirect, alpha)
-  if (p.cfg == CFG_SMALL) {
-    if (vec4) LK_LAUNCH(4, CFG_SMALL); else LK_LAUNCH(1, CFG_SMALL);
-  } else if (p.cfg == CFG_BIG) {
-    if (vec4) LK_LAUNCH(4, CFG_BIG); else LK_LAUNCH(1, CFG_BIG);
-  } else {
-    if (vec4) LK_LAUNCH(4, CFG_WIDE); else LK_LAUNCH(1, CFG_WIDE);
+  const size_t lds = cfg_lds_bytes(p.cfg, !(p.cfg == CFG_SMALL));
+#define LK_LAUNCH(V, S)                                                                                          \
+  do {                                                                                                           \
+    if (!allow_big_lds((const void*)gram_kernel<MODE, V, S>, lds)) return LK_ELAUNCH;                            \
+    hipLaunchKernelGGL((gram_kernel<MODE, V, S>), grid, block, lds, stream, g, slabs, p.nbt, p.npairs,           \
+                       p.chunks_per_split, p.nchunks, Cdirect, alpha);                                           \
+  } while (0)
+#define LK_LAUNCH_V(S)                    \
+  do {                                    \
+    if (vec4) LK_LAUNCH(4, S);            \
+    else LK_LAUNCH(1, S);                 \
+  } while (0)
+  switch (p.cfg) {
+    case CFG_SMALL: LK_LAUNCH_V(CFG_SMALL); break;
+    case CFG_BIG: LK_LAUNCH_V(CFG_BIG); break;
+    case CFG_BIG24: LK_LAUNCH_V(CFG_BIG24); break;
+    case CFG_BIG32: LK_LAUNCH_V(CFG_BIG32); break;
+    default: LK_LAUNCH_V(CFG_WIDE); break;
   }
+#undef LK_LAUNCH_V
 #undef LK_LAUNCH
   int rc = check_launch("gram_kernel");
   if (rc || Cdirect != nullptr) return rc;
@@ -621,14 +686,25 @@ static int launch_xcorr(const float* x, int64_t B, int H, int W, int Cin, const 
   float* slabs = static_cast<float*>(ws);
   const bool vec4 = (Cin % 4 == 0) && aligned16(x);
   dim3 grid(p.npairs, p.nsplit, nreg), block(256);
-#define LK_LAUNCH(V, S)                                                                                          \
-  hipLaunchKernelGGL((gram_kernel<MODE_XCORR, V, S>), grid, block, 0, stream, g, slabs, p.nbt, p.npairs, \
-                     p.chunks_per_split, p.nchunks, (float*)nullptr, 1.f)
-  if (p.cfg == CFG_SMALL) {
-    if (vec4) LK_LAUNCH(4, CFG_SMALL); else LK_LAUNCH(1, CFG_SMALL);
-  } else {
-    if (vec4) LK_LAUNCH(4, CFG_BIG); else LK_LAUNCH(1, CFG_BIG);
+  const size_t lds = cfg_lds_bytes(p.cfg, true);
+#define LK_LAUNCH(V, S)                                                                                            \
+  do {                                                                                                             \
+    if (!allow_big_lds((const void*)gram_kernel<MODE_XCORR, V, S>, lds)) return LK_ELAUNCH;                        \
+    hipLaunchKernelGGL((gram_kernel<MODE_XCORR, V, S>), grid, block, lds, stream, g, slabs, p.nbt, p.npairs,       \
+                       p.chunks_per_split, p.nchunks, (float*)nullptr, 1.f);                                       \
+  } while (0)
+#define LK_LAUNCH_V(S)                    \
+  do {                                    \
+    if (vec4) LK_LAUNCH(4, S);            \
+    else LK_LAUNCH(1, S);                 \
+  } while (0)
+  switch (p.cfg) {
+    case CFG_SMALL: LK_LAUNCH_V(CFG_SMALL); break;
+    case CFG_BIG24: LK_LAUNCH_V(CFG_BIG24); break;
+    case CFG_BIG32: LK_LAUNCH_V(CFG_BIG32); break;
+    default: LK_LAUNCH_V(CFG_BIG); break;
   }
+#undef LK_LAUNCH_V
 #undef LK_LAUNCH
   int rc = check_launch("gram_kernel<XCORR>");
   if (rc) return rc;
@@ -762,6 +838,13 @@ extern "C" size_t lk_gram_workspace_bytes(int64_t n, int64_t K) {
   return make_plan(n, K < 1 ? 1 : K).ws_bytes;
 }
 
+extern "C" size_t lk_gram_nt_workspace_bytes(int64_t nb_total, int64_t n, int64_t L) {
+  if (n <= 0 || L <= 0) return 0;
+  const int BK = cfg_bk(make_plan(n, 1, L).cfg);
+  const int64_t Lp = (L + BK - 1) / BK * BK;
+  return make_plan(n, nb_total < 1 ? Lp : nb_total * Lp, L).ws_bytes;
+}
+
 extern "C" int lk_gram_tn_f32(const float* X, int64_t K, int64_t n, int64_t ldx, float alpha, float* C,
                               unsigned flags, void* ws, size_t ws_bytes, void* stream) {
   LK_REQUIRE(X && C && K >= 0 && n >= 0 && ldx >= n, "lk_gram_tn_f32: bad arguments");
@@ -777,7 +860,7 @@ extern "C" int lk_gram_nt_seg_f32(const float* const* segs, int64_t nseg, int64_
   LK_REQUIRE(segs && C && nseg >= 1 && nseg <= MAX_SEG && nb >= 0 && n >= 0 && L >= 1,
              "lk_gram_nt_seg_f32: bad arguments (at most 16 segments)");
   LK_REQUIRE(n < (1 << 30) && L < (1 << 30), "lk_gram_nt_seg_f32: dims too large");
-  const int BK = n <= 64 ? 64 : 16;
+  const int BK = cfg_bk(make_plan(n, 1, L).cfg);
   GramGeom g{};
   g.n = (int)n; g.L = (int)L;
   g.Lp = (int)((L + BK - 1) / BK * BK);
