@@ -29,6 +29,9 @@
 namespace lk {
 
 enum { MODE_TN = 0, MODE_NT = 1, MODE_CONV = 2, MODE_XCORR = 3 };
+#ifdef LK_GRAM_TRACE  // development build (tools/gram_trace.py): per-phase cycle counts of one wave of the last launch
+__device__ long long g_gram_trace[5];
+#endif
 constexpr int MAX_SEG = 16;
 
 // Exact unsigned division of n < 2^31 by a run-time constant d >= 1 without a divide:
@@ -318,23 +321,47 @@ __device__ __forceinline__ void gram_body(const GramGeom& g, float* __restrict__
   const int offB = hi * C::LDP + wn * C::WT + lo;
 
   int cur = 0;
+#ifdef LK_GRAM_TRACE
+  const bool tracer = (blockIdx.x == 1 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0);
+  long long tr[5] = {0, 0, 0, 0, 0};
+#define LK_TSTAMP(v)                      \
+  __builtin_amdgcn_sched_barrier(0);      \
+  const long long v = __builtin_amdgcn_s_memtime(); \
+  __builtin_amdgcn_sched_barrier(0)
+#else
+#define LK_TSTAMP(v)
+#endif
   for (int c = c_begin; c < c_end; ++c) {
     const bool more = (c + 1) < c_end;
+    LK_TSTAMP(t0);
     if (more) {
       load_panel<MODE, VEC, CFG>(g, (int64_t)(c + 1) * C::BK, tid, reg, ccA, stA);
       if (!diag) load_panel<MODE, VEC, CFG>(g, (int64_t)(c + 1) * C::BK, tid, reg, ccB, stB);
     }
+    LK_TSTAMP(t1);
     const float* pA = smem + cur * NP * PANEL;
     const float* pB = diag ? pA : pA + PANEL;
     compute_chunk<CFG, FULL>(pA + offA, pB + offB, acc, am, an);
+    LK_TSTAMP(t2);
     if (more) {
       float* nx = smem + (cur ^ 1) * NP * PANEL;
       store_panel<MODE, VEC, CFG>(nx, tid, stA);
       if (!diag) store_panel<MODE, VEC, CFG>(nx + PANEL, tid, stB);
     }
+    LK_TSTAMP(t3);
     __syncthreads();
     cur ^= 1;
+#ifdef LK_GRAM_TRACE
+    __builtin_amdgcn_sched_barrier(0);
+    const long long t4 = __builtin_amdgcn_s_memtime();
+    tr[0] += t1 - t0, tr[1] += t2 - t1, tr[2] += t3 - t2, tr[3] += t4 - t3, tr[4] += 1;
+#endif
   }
+#ifdef LK_GRAM_TRACE
+  if (tracer)
+    for (int i = 0; i < 5; ++i) g_gram_trace[i] = tr[i];
+#endif
+#undef LK_TSTAMP
 
   if (Cdirect != nullptr) {
     // single split, upper-only accumulation: C += alpha * tile straight from the accumulators
@@ -832,6 +859,12 @@ __global__ __launch_bounds__(256) void permute_sym_kernel(const float* __restric
 }  // namespace lk
 
 using namespace lk;
+
+#ifdef LK_GRAM_TRACE
+extern "C" int lk_gram_trace_read(long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gram_trace), 5 * sizeof(long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" size_t lk_gram_workspace_bytes(int64_t n, int64_t K) {
   if (n <= 0) return 0;
