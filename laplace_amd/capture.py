@@ -28,7 +28,7 @@ class Tap:
     w_off: int  # column offset of the weight in the flattened parameter vector
     b_off: int  # column offset of the bias, -1 if the module has no (tracked) bias
     a: torch.Tensor | None = None  # module input (detached)
-    out: torch.Tensor | None = None  # module output (in the autograd graph)
+    out: object | None = None  # gradient edge of the module output in the autograd graph
 
     @property
     def has_bias(self) -> bool:
@@ -81,7 +81,10 @@ class Tape:
                     raise NotImplementedError(f"{tap.name}: module is applied more than once per forward")
                 seen.add(id(m))
                 tap.a = inp[0].detach()
-                tap.out = out
+                # the gradient EDGE of the output as it is now: models that go on to modify the tensor in place
+                # (torchvision's `out += identity; relu_(out)`) would otherwise hand back the gradient w.r.t. the
+                # mutated tensor — the reference's curvlinops hooks see the pre-mutation gradient as well
+                tap.out = torch.autograd.graph.get_gradient_edge(out) if out.requires_grad else out
             handles.append(tap.module.register_forward_hook(hook))
         try:
             with torch.enable_grad():
@@ -105,6 +108,9 @@ class Tape:
         (it loops internally and then pays an extra concatenation).
         """
         outs = [t.out for t in self.taps]
+        if any(torch.is_tensor(o) for o in outs):
+            raise RuntimeError("a tapped module's output does not require grad (frozen parameters upstream and "
+                               "downstream?)")
         S = seeds.shape[0]
         has_conv = any(t.kind == "conv2d" for t in self.taps)
         if S == 1:

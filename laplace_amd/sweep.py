@@ -36,6 +36,21 @@ class SeedBatchedSweep:
     """Forward + seed-batched reverse sweep over an fx-traced module."""
 
     _ELEMENTWISE_FN = {torch.relu, F.relu, torch.tanh, F.tanh, torch.sigmoid, F.sigmoid}
+    # any other element-wise activation: its per-sample derivative is taken ONCE from autograd on the [B, ...]
+    # forward value (1/S of the sweep's work) and then applied to all seeds by the same fused kernel
+    _GENERIC_ACT_MODULES = (nn.GELU, nn.SiLU, nn.LeakyReLU, nn.ELU, nn.Softplus, nn.Hardtanh, nn.ReLU6, nn.Mish,
+                            nn.Hardswish, nn.Hardsigmoid, nn.SELU, nn.CELU, nn.Softsign, nn.LogSigmoid)
+    _GENERIC_ACT_FN = {F.gelu, F.silu, F.leaky_relu, F.elu, F.softplus, F.hardtanh, F.relu6, F.mish, F.hardswish,
+                       F.hardsigmoid, F.selu, F.celu, F.softsign, F.logsigmoid}
+
+    @staticmethod
+    def _with_derivative(fn, inp):
+        """(fn(inp), d fn / d inp) for an element-wise ``fn``"""
+        with torch.enable_grad():
+            xin = inp.detach().requires_grad_(True)
+            out = fn(xin)
+            (d,) = torch.autograd.grad(out.sum(), xin)
+        return out.detach(), d
 
     def __init__(self, model: nn.Module, tap_modules: dict[str, nn.Module], kernels=None):
         """``kernels``: callable returning the kernel object (``laplace_amd._lib.get_kernels``) whose
@@ -59,6 +74,8 @@ class SeedBatchedSweep:
                 n_inputs += 1
             elif node.op == "call_module":
                 m = self.modules[node.target]
+                if isinstance(m, self._GENERIC_ACT_MODULES):
+                    continue
                 if not isinstance(m, (nn.Conv2d, nn.Linear, nn.BatchNorm2d, nn.BatchNorm1d, nn.ReLU, nn.Tanh,
                                       nn.Sigmoid, nn.Identity, nn.Dropout, nn.Flatten, nn.AdaptiveAvgPool2d,
                                       nn.MaxPool2d, nn.AvgPool2d, nn.Sequential)):
@@ -66,7 +83,8 @@ class SeedBatchedSweep:
                 if isinstance(m, nn.Conv2d) and (m.groups != 1 or isinstance(m.padding, str) or m.padding_mode != "zeros"):
                     raise SweepUnsupported(f"{node.target}: unsupported convolution variant")
             elif node.op == "call_function":
-                if node.target not in (self._ELEMENTWISE_FN | {operator.add, torch.add, torch.flatten, operator.iadd}):
+                if node.target not in (self._ELEMENTWISE_FN | self._GENERIC_ACT_FN
+                                       | {operator.add, torch.add, torch.flatten, operator.iadd}):
                     raise SweepUnsupported(f"no VJP rule for function {getattr(node.target, '__name__', node.target)}")
             elif node.op == "call_method":
                 if node.target not in ("view", "reshape", "flatten", "relu", "tanh", "sigmoid", "contiguous"):
@@ -99,6 +117,8 @@ class SeedBatchedSweep:
                 if isinstance(m, nn.MaxPool2d):
                     out, idx = F.max_pool2d(inp, m.kernel_size, m.stride, m.padding, m.dilation, m.ceil_mode, True)
                     self.saved[node] = (idx, inp.shape)
+                elif isinstance(m, self._GENERIC_ACT_MODULES):
+                    out, self.saved[node] = self._with_derivative(m, inp)
                 else:
                     out = m(inp)
                     if isinstance(m, (nn.ReLU,)):
@@ -119,6 +139,9 @@ class SeedBatchedSweep:
                 kwargs = {k: (env[v] if isinstance(v, fx.Node) else v) for k, v in node.kwargs.items()}
                 if node.target is operator.iadd:
                     out = args[0] + args[1]
+                elif node.target in self._GENERIC_ACT_FN:
+                    kwargs.pop("inplace", None)
+                    out, self.saved[node] = self._with_derivative(lambda t: node.target(t, *args[1:], **kwargs), args[0])
                 else:
                     out = node.target(*args, **kwargs)
                 if node.target in (torch.relu, F.relu):
@@ -161,9 +184,9 @@ class SeedBatchedSweep:
 
     def _is_activation(self, node) -> bool:
         if node.op == "call_module":
-            return isinstance(self.modules[node.target], (nn.ReLU, nn.Tanh, nn.Sigmoid))
+            return isinstance(self.modules[node.target], (nn.ReLU, nn.Tanh, nn.Sigmoid) + self._GENERIC_ACT_MODULES)
         if node.op == "call_function":
-            return node.target in self._ELEMENTWISE_FN
+            return node.target in self._ELEMENTWISE_FN or node.target in self._GENERIC_ACT_FN
         return node.op == "call_method" and node.target in ("relu", "tanh", "sigmoid")
 
     def _scale_mask(self, g, S, mult, scale, g2=None):
@@ -183,9 +206,11 @@ class SeedBatchedSweep:
             out = out * scale.reshape((1, -1) + (1,) * (g.dim() - 2))
         return out
 
-    @staticmethod
-    def _act_mult(kind, saved):
+    @classmethod
+    def _act_mult(cls, kind, saved):
         """per-sample derivative of the activation from what the forward kept (ReLU: the mask itself)"""
+        if isinstance(kind, cls._GENERIC_ACT_MODULES) or (callable(kind) and kind in cls._GENERIC_ACT_FN):
+            return saved  # the derivative itself
         if kind in (torch.relu, F.relu, "relu") or isinstance(kind, nn.ReLU):
             return saved
         if kind in (torch.tanh, F.tanh, "tanh") or isinstance(kind, nn.Tanh):
@@ -242,7 +267,7 @@ class SeedBatchedSweep:
                     push(src, g @ m.weight)
                 elif isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d)):
                     push(src, self._scale_mask(g, S, None, self._bn_scale(node.target, m)))
-                elif isinstance(m, (nn.ReLU, nn.Tanh, nn.Sigmoid)):
+                elif isinstance(m, (nn.ReLU, nn.Tanh, nn.Sigmoid) + self._GENERIC_ACT_MODULES):
                     scale, dst = self._fold_bn(src)
                     push(dst, self._scale_mask(g, S, self._act_mult(m, self.saved[node]), scale, g2))
                 elif isinstance(m, (nn.Identity, nn.Dropout)):
@@ -276,7 +301,7 @@ class SeedBatchedSweep:
                         raise SweepUnsupported("add with alpha")
                     for a in node.args[:2]:
                         push(a, g)
-                elif t in self._ELEMENTWISE_FN:
+                elif t in self._ELEMENTWISE_FN or t in self._GENERIC_ACT_FN:
                     scale, dst = self._fold_bn(node.args[0])
                     push(dst, self._scale_mask(g, S, self._act_mult(t, self.saved[node]), scale, g2))
                 elif t is torch.flatten:

@@ -33,8 +33,53 @@ class Residual(nn.Module):
         return self.fc(h.flatten(1))
 
 
+class TorchvisionStyleBlock(nn.Module):
+    """in-place ReLU module reused at two call sites + `out += identity`, as torchvision's BasicBlock"""
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 8, 3, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(8)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(8, 8, 3, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(8)
+        self.conv3 = nn.Conv2d(8, 8, 3, padding=1, bias=False)
+        self.pool = nn.AdaptiveAvgPool2d(1)
+        self.fc = nn.Linear(8, 5)
+
+    def forward(self, x):
+        x = self.relu(self.bn1(self.conv1(x)))
+        identity = x
+        out = self.relu(self.bn2(self.conv2(x)))
+        out = self.conv3(out)
+        out += identity
+        out = self.relu(out)
+        return self.fc(torch.flatten(self.pool(out), 1))
+
+
+class SmoothActs(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.c1 = nn.Conv2d(3, 6, 3, padding=1)
+        self.bn = nn.BatchNorm2d(6)
+        self.act1 = nn.GELU()
+        self.c2 = nn.Conv2d(6, 6, 3, stride=2, padding=1)
+        self.act2 = nn.LeakyReLU(0.1)
+        self.fc1 = nn.Linear(6 * 4 * 4, 12)
+        self.act3 = nn.SiLU()
+        self.fc2 = nn.Linear(12, 4)
+
+    def forward(self, x):
+        h = self.act1(self.bn(self.c1(x)))
+        h = self.act2(self.c2(h))
+        h = torch.nn.functional.elu(self.fc1(h.flatten(1)), alpha=0.7)
+        return self.fc2(torch.nn.functional.softplus(self.act3(h), beta=2.0))
+
+
 def _models():
     yield "resnet18", ResNet18(), (3, 16, 16), 10
+    yield "torchvision_block", TorchvisionStyleBlock(), (3, 8, 8), 5
+    yield "smooth_acts", SmoothActs(), (3, 8, 8), 4
     yield "lenet5", lenet5(), (3, 32, 32), 10
     yield "residual", Residual(), (3, 8, 8), 4
     for n in FIXTURES:
@@ -153,3 +198,35 @@ def test_backend_sweep_and_tape_agree(use_sweep):
         assert torch.allclose(J0, J1, rtol=1e-4, atol=1e-6) and torch.allclose(f0, f1)
     finally:
         _lib.set_kernels_for_testing(prev)
+
+
+def test_inplace_model_equals_its_out_of_place_twin():
+    """torchvision-style `out += identity; relu_(out)`: the gradient w.r.t. a tapped output must be the one of the
+    tensor as the module produced it, not of the tensor after the in-place updates (both extraction paths)."""
+    torch.manual_seed(4)
+    m_in = TorchvisionStyleBlock().double().eval()
+
+    class Twin(TorchvisionStyleBlock):
+        def forward(self, x):
+            x = torch.relu(self.bn1(self.conv1(x)))
+            out = torch.relu(self.bn2(self.conv2(x)))
+            out = self.conv3(out) + x
+            return self.fc(torch.flatten(self.pool(torch.relu(out)), 1))
+
+    m_out = Twin().double().eval()
+    m_out.load_state_dict(m_in.state_dict())
+    x = torch.randn(3, 3, 8, 8, dtype=torch.float64)
+    seeds = torch.randn(2, 3, 5, dtype=torch.float64)
+    results = []
+    for m in (m_in, m_out):
+        params = [p for p in m.parameters() if p.requires_grad]
+        tape = Tape(m, params)
+        f = tape.forward(x.clone())
+        results.append([g for g in tape.output_grads(f, seeds)])
+        sweep = SeedBatchedSweep(m, {t.name: t.module for t in tape.taps})
+        sweep.forward(x.clone())
+        got = sweep.backward(seeds)
+        results.append([got[t.name] for t in tape.taps])
+    for other in results[1:]:
+        for a, b in zip(results[0], other):
+            assert (a - b).abs().max() <= 1e-12 * (1 + a.abs().max())
