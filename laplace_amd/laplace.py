@@ -20,7 +20,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 from torch import nn
-from torch.nn.utils import parameters_to_vector
+from torch.nn.utils import parameters_to_vector, vector_to_parameters
 
 from laplace_amd import predictive as _pred
 from laplace_amd.backend import HipGGN
@@ -246,17 +246,124 @@ class _HipLaplace:
         raise NotImplementedError
 
     @torch.no_grad()
-    def __call__(self, x, pred_type: str = "glm", link_approx: str = "probit", diagonal_output: bool = False):
-        if pred_type != "glm":
-            raise NotImplementedError("only the GLM predictive is on the accelerated path")
+    def __call__(self, x, pred_type: str = "glm", link_approx: str = "probit", n_samples: int = 100,
+                 diagonal_output: bool = False, generator: torch.Generator | None = None):
+        """Posterior predictive (baselaplace.py:1112-1208): ``pred_type`` 'glm' with the 'probit' or 'mc' link
+        approximation, or 'nn' (weight-space sampling, 'mc' only)."""
+        if pred_type not in ("glm", "nn"):
+            raise ValueError("Only glm and nn supported as prediction types.")
+        if link_approx not in ("probit", "mc"):
+            raise NotImplementedError("link_approx: 'probit' and 'mc' are implemented here")
+        if pred_type == "nn":
+            if link_approx != "mc":
+                raise ValueError("Only mc link approximation is supported for nn prediction type.")
+            if self.likelihood == "regression":
+                samples = self._nn_predictive_samples(x, n_samples, generator)
+                return samples.mean(dim=0), samples.var(dim=0)
+            return self._nn_predictive_samples(x, n_samples, generator).mean(dim=0)
         f_mu, f_var = self._glm_predictive_distribution(x, diagonal_output=diagonal_output)
         if self.likelihood == "regression":
             return f_mu, f_var
-        if link_approx != "probit":
-            raise NotImplementedError("link_approx: only 'probit' is implemented here")
+        if link_approx == "mc":
+            fv = f_var if not diagonal_output else torch.diag_embed(f_var)
+            return self._glm_predictive_samples(f_mu, fv, n_samples, diagonal_output, generator).mean(dim=0)
         var_diag = f_var if diagonal_output else torch.diagonal(f_var, dim1=1, dim2=2)
         kappa = 1 / torch.sqrt(1.0 + pi / 8 * var_diag)
         return torch.softmax(kappa * f_mu, dim=-1)
+
+    # ---- sampling predictives (baselaplace.py:697-841,1210-1394) ------------------------------------------------
+    def sample(self, n_samples: int = 100, generator: torch.Generator | None = None) -> torch.Tensor:
+        """``[n_samples, P]`` draws from the Laplace posterior N(mean, posterior_precision^-1)."""
+        raise NotImplementedError
+
+    def _randn(self, *shape, generator=None):
+        return torch.randn(*shape, device=self._device, dtype=self._dtype, generator=generator)
+
+    @torch.no_grad()
+    def _nn_functional_samples(self, X, n_samples: int = 100, generator=None) -> torch.Tensor:
+        fs = []
+        try:
+            for sample in self.sample(n_samples, generator):
+                vector_to_parameters(sample, self.params)
+                fs.append(self.model(X.to(self._device) if torch.is_tensor(X) else X).detach())
+        finally:
+            vector_to_parameters(self.mean, self.params)
+        return torch.stack(fs)
+
+    def _nn_predictive_samples(self, X, n_samples: int = 100, generator=None) -> torch.Tensor:
+        fs = self._nn_functional_samples(X, n_samples, generator)
+        return torch.softmax(fs, dim=-1) if self.likelihood == "classification" else fs
+
+    def _glm_functional_samples(self, f_mu, f_var, n_samples, diagonal_output=False, generator=None):
+        """utils/utils.py:337-378 (normal_samples): the same ``[C, n_samples]`` standard-normal draw is shared by
+        all points of the batch, exactly as in the reference."""
+        if f_var.shape != (f_mu.shape[0], f_mu.shape[1], f_mu.shape[1]):
+            raise ValueError("f_var must be [batch, outputs, outputs]")
+        z = torch.randn(f_mu.shape[1], n_samples, device=f_mu.device, dtype=f_mu.dtype, generator=generator)
+        if diagonal_output:
+            scaled = torch.diagonal(f_var, dim1=1, dim2=2).sqrt().unsqueeze(-1) * z.unsqueeze(0)
+        else:
+            scaled = torch.matmul(torch.linalg.cholesky(f_var), z.unsqueeze(0))
+        return (f_mu.unsqueeze(-1) + scaled).permute(2, 0, 1)
+
+    def _glm_predictive_samples(self, f_mu, f_var, n_samples, diagonal_output=False, generator=None):
+        fs = self._glm_functional_samples(f_mu, f_var, n_samples, diagonal_output, generator)
+        return torch.softmax(fs, dim=-1) if self.likelihood == "classification" else fs
+
+    @torch.no_grad()
+    def functional_samples(self, x, pred_type: str = "glm", n_samples: int = 100, diagonal_output: bool = False,
+                           generator=None) -> torch.Tensor:
+        if pred_type == "glm":
+            f_mu, f_var = self._glm_predictive_distribution(x)
+            return self._glm_functional_samples(f_mu, f_var, n_samples, diagonal_output, generator)
+        if pred_type == "nn":
+            return self._nn_functional_samples(x, n_samples, generator)
+        raise ValueError("Only glm and nn supported as prediction types.")
+
+    @torch.no_grad()
+    def predictive_samples(self, x, pred_type: str = "glm", n_samples: int = 100, diagonal_output: bool = False,
+                           generator=None) -> torch.Tensor:
+        if pred_type == "glm":
+            f_mu, f_var = self._glm_predictive_distribution(x)
+            return self._glm_predictive_samples(f_mu, f_var, n_samples, diagonal_output, generator)
+        if pred_type == "nn":
+            return self._nn_predictive_samples(x, n_samples, generator)
+        raise ValueError("Only glm and nn supported as prediction types.")
+
+    # ---- prior-precision grid search on a validation set (baselaplace.py:487-561) --------------------------------
+    @torch.no_grad()
+    def gridsearch_prior_precision(self, val_loader, log_prior_prec_min: float = -4, log_prior_prec_max: float = 4,
+                                   grid_size: int = 100, pred_type: str = "glm", link_approx: str = "probit",
+                                   n_samples: int = 100, loss=None):
+        """Pick the scalar prior precision of ``logspace(min, max, grid_size)`` with the best validation loss
+        (default: NLL for classification, MSE for regression, as the reference's ``RunningNLLMetric`` /
+        ``MeanSquaredError``).  A grid point whose posterior is not positive definite scores ``inf``."""
+        interval = torch.logspace(log_prior_prec_min, log_prior_prec_max, grid_size)
+        results = []
+        for pp in interval:
+            self.prior_precision = pp
+            try:
+                tot, cnt = 0.0, 0
+                for X, y in val_loader:
+                    X, y = X.to(self._device), y.to(self._device)
+                    out = self(X, pred_type=pred_type, link_approx=link_approx, n_samples=n_samples)
+                    if loss is not None:
+                        tot += float(loss(out, y)) * len(y)
+                    elif self.likelihood == "regression":
+                        tot += float(((out[0] - y.reshape(out[0].shape)) ** 2).sum())
+                    else:
+                        tot += float(-torch.log(out[torch.arange(len(y)), y.long()].clamp_min(1e-30)).sum())
+                    cnt += len(y)
+                res = tot / max(cnt, 1)
+                results.append(res if res == res else float("inf"))
+            except RuntimeError as err:  # torch.linalg.LinAlgError is a RuntimeError
+                if "positive" in str(err) or "singular" in str(err) or isinstance(err, torch.linalg.LinAlgError):
+                    results.append(float("inf"))
+                else:
+                    raise
+        best = int(torch.tensor(results).argmin())
+        self.prior_precision = interval[best]
+        return self.prior_precision
 
 
 class HipKronLaplace(_HipLaplace):
@@ -327,6 +434,12 @@ class HipKronLaplace(_HipLaplace):
     def functional_variance(self, Js: torch.Tensor) -> torch.Tensor:
         return self.posterior_precision.inv_square_form(Js)
 
+    def sample(self, n_samples: int = 100, generator=None) -> torch.Tensor:
+        """baselaplace.py:1845-1858: ``mean + P^{-1/2} z`` block-wise through the eigendecomposition."""
+        z = self._randn(n_samples, self.n_params, generator=generator)
+        z = self.posterior_precision.bmm(z, exponent=-0.5)
+        return self.mean.reshape(1, self.n_params) + z.reshape(n_samples, self.n_params)
+
     def _glm_predictive_distribution(self, X, diagonal_output: bool = False):
         post = self.posterior_precision
         try:
@@ -363,6 +476,11 @@ class HipDiagLaplace(_HipLaplace):
     @property
     def log_det_posterior_precision(self):
         return self.posterior_precision.log().sum()
+
+    def sample(self, n_samples: int = 100, generator=None) -> torch.Tensor:
+        """baselaplace.py:2124-2131"""
+        z = self._randn(n_samples, self.n_params, generator=generator)
+        return self.mean.reshape(1, self.n_params) + z * self.posterior_variance.sqrt().reshape(1, self.n_params)
 
     def functional_variance(self, Js):
         return torch.einsum("ncp,p,nkp->nck", Js, self.posterior_variance, Js)
@@ -410,6 +528,13 @@ class HipFullLaplace(_HipLaplace):
 
     def functional_variance(self, Js):
         return torch.einsum("ncp,pq,nkq->nck", Js, self.posterior_covariance, Js)
+
+    def sample(self, n_samples: int = 100, generator=None) -> torch.Tensor:
+        """baselaplace.py:1691-1703: ``mean + z L^T``; ``L`` = lower Cholesky factor of the posterior covariance
+        (what ``invsqrt_precision`` / ``_precision_to_scale_tril`` return, utils/utils.py:118-129)."""
+        z = self._randn(n_samples, self.n_params, generator=generator)
+        scale = torch.linalg.cholesky(self.posterior_covariance)
+        return self.mean.reshape(1, self.n_params) + z @ scale.T
 
     def _glm_predictive_distribution(self, X, diagonal_output: bool = False):
         if self.subset_of_weights == "last_layer":

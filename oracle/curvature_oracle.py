@@ -260,7 +260,9 @@ def kfac_ggn(
     handles = []
     for name, mod in mods:
         def hook(m, inp, out, name=name):
-            taps[name] = {"a": inp[0].detach(), "out": out}
+            # gradient edge of the output AS PRODUCED (curvlinops registers its tensor hook at this point too; a
+            # model that later updates the tensor in place must not change which gradient is meant)
+            taps[name] = {"a": inp[0].detach(), "out": torch.autograd.graph.get_gradient_edge(out)}
         handles.append(mod.register_forward_hook(hook))
     try:
         f = model(X)

@@ -44,3 +44,33 @@ def golden_model(name: str, g: dict, dtype=torch.float64, device="cpu"):
     y = torch.as_tensor(g["y"])
     y = y.to(device) if not y.is_floating_point() else y.to(dtype).to(device)
     return model, X, y
+
+
+@pytest.fixture(scope="module")
+def reference_dropin():
+    """The unmodified reference imported (with the third-party shells of oracle/ref_import.py), our boundary classes
+    re-derived from ITS base classes if laplace_amd was imported first, and the CPU kernel emulation installed."""
+    from oracle.ref_import import import_reference, reference_available
+
+    if not reference_available():
+        pytest.skip("/root/reference not present")
+    import_reference()
+    import importlib
+
+    import laplace_amd.refapi as refapi
+
+    if not refapi.HAVE_REFERENCE:
+        import laplace_amd
+        import laplace_amd.backend
+        import laplace_amd.kron
+
+        importlib.reload(refapi)
+        importlib.reload(laplace_amd.kron)
+        importlib.reload(laplace_amd.backend)
+        importlib.reload(laplace_amd)
+    from laplace_amd import _lib
+    from tests.emulated_kernels import EmulatedKernels
+
+    prev = _lib.set_kernels_for_testing(EmulatedKernels())
+    yield
+    _lib.set_kernels_for_testing(prev)

@@ -13,30 +13,8 @@ pytestmark = pytest.mark.skipif(not reference_available(), reason="/root/referen
 
 
 @pytest.fixture(scope="module")
-def ref():
-    from oracle.ref_import import import_reference
-
-    import_reference()
-    import importlib
-
-    import laplace_amd.refapi as refapi
-
-    # make sure our classes were derived from the reference's (import order independent)
-    if not refapi.HAVE_REFERENCE:
-        import laplace_amd
-        import laplace_amd.backend
-        import laplace_amd.kron
-
-        importlib.reload(refapi)
-        importlib.reload(laplace_amd.kron)
-        importlib.reload(laplace_amd.backend)
-        importlib.reload(laplace_amd)
-    from laplace_amd import _lib
-    from tests.emulated_kernels import EmulatedKernels
-
-    prev = _lib.set_kernels_for_testing(EmulatedKernels())
+def ref(reference_dropin):
     yield
-    _lib.set_kernels_for_testing(prev)
 
 
 def rel(got, want):
