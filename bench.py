@@ -150,33 +150,61 @@ def pmc_traffic(kernel_prefix: str):
     return total / launches, "profiles/r01_pmc_traffic_bench_c4.{json,md} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2x read correction)"
 
 
+# LK_BENCH_SELFTEST=1: control-flow check of this script without a GPU (tests/test_bench_contract.py): CPU tensors,
+# gloo, the kernel emulation of the test-suite and a toy model.  Its numbers mean nothing; it exists so that the
+# multi-rank branches (all-reduce, sharded eigendecomposition, max-over-ranks timing) are exercised before the
+# driver runs them on 8 GPUs.
+SELFTEST = os.environ.get("LK_BENCH_SELFTEST") == "1"
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs a ROCm device"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+    if SELFTEST:
+        global BATCH
+        BATCH = 4
+        dev = torch.device("cpu")
+        if world > 1:
+            dist.init_process_group("gloo")
+        from laplace_amd import _lib
+        from tests.emulated_kernels import EmulatedKernels
+
+        _lib.set_kernels_for_testing(EmulatedKernels())
+    else:
+        assert torch.cuda.is_available(), "bench.py needs a ROCm device"
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        if world > 1:
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group("nccl", device_id=dev)
 
     from laplace_amd import HipGGN
     from laplace_amd._lib import get_kernels
     from laplace_amd.nets import ResNet18
 
     torch.manual_seed(711)
-    model = ResNet18(CLASSES).to(dev).eval()
+    if SELFTEST:
+        from torch import nn
+
+        model = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.ReLU(), nn.Conv2d(8, 8, 3, stride=2, padding=1), nn.ReLU(),
+                              nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(8, CLASSES)).eval()
+    else:
+        model = ResNet18(CLASSES).to(dev).eval()
     backend = HipGGN(model, "classification")
     backend.use_sweep = not args.no_sweep
     batches = make_batches(args.steps, dev, seed=100 + rank)
     K = get_kernels()
 
+    def sync():
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     # ---- warm-up ------------------------------------------------------------------------------------
     overlap = not args.no_overlap
@@ -194,7 +222,7 @@ def main():
     # its launch stream, A-factor kernels NOT overlapped with the reverse passes so that the per-launch
     # durations are the kernels' own (the throughput above is measured without this instrumentation)
     prof = {}
-    if rank == 0:
+    if rank == 0 and not SELFTEST:
         K.profile = prof
         fit_steps(backend, batches, min(args.steps, 5), 1, overlap=False)
         torch.cuda.synchronize()
@@ -253,17 +281,17 @@ def main():
     # ---- untimed extras on rank 0 (separate line items per BASELINE.md) --------------------------------------
     if rank == 0 and world == 1:
         if not args.no_eigh:
-            torch.cuda.synchronize()
+            sync()
             t0 = time.perf_counter()
             dec = H.decompose()
-            torch.cuda.synchronize()
+            sync()
             result["eigh_ms"] = (time.perf_counter() - t0) * 1e3
             result["eigh_converged"] = all(int(i[0].item()) == 0 for i in dec._eig_info)
             del dec
-        if not args.no_predictive:
+        if not args.no_predictive and not SELFTEST:
             result["predictive"] = predictive_leg(dev)
         if not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+            result["cpu_baseline"] = cpu_baseline(0.0 if SELFTEST else args.cpu_seconds)
     if world > 1 and not args.no_eigh:
         # the factors are identical on every rank after the all-reduce: shard the eigensolves over the GPUs
         barrier()
