@@ -169,6 +169,15 @@ class SeedBatchedSweep:
         self.out_shape = tuple(out.shape[1:])
         return out
 
+    @staticmethod
+    def _conv_input_grad(in_shape, m, g):
+        """Backward-data of a convolution for the whole seed batch.  ``torch.nn.grad.conv2d_input`` hands the op a
+        stride-0 dummy input, from which PyTorch infers a channels-last result that then has to be copied back to
+        NCHW (20 copies of [S*B, C, H, W] per ResNet-18 step); a contiguous, never-read dummy keeps it NCHW."""
+        dummy = g.new_empty(in_shape)
+        return torch.ops.aten.convolution_backward(g, dummy, m.weight, None, m.stride, m.padding, m.dilation, False,
+                                                   [0] * len(m.stride), m.groups, [True, False, False])[0]
+
     # ---- element-wise VJPs ----------------------------------------------------------------------------------
     def _bn_scale(self, name: str, m) -> torch.Tensor:
         """gamma / sqrt(running_var + eps), cached until the module's buffers change."""
@@ -262,7 +271,7 @@ class SeedBatchedSweep:
                 src = node.args[0]
                 if isinstance(m, nn.Conv2d):
                     in_shape = (S * B,) + tuple(self.saved[node][1:])
-                    push(src, torch.nn.grad.conv2d_input(in_shape, m.weight, g, m.stride, m.padding, m.dilation, m.groups))
+                    push(src, self._conv_input_grad(in_shape, m, g))
                 elif isinstance(m, nn.Linear):
                     push(src, g @ m.weight)
                 elif isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d)):
