@@ -1,4 +1,7 @@
 #!/bin/bash
+# Full GPU pass on the MI355X box (run through tools/gpurun_retry.sh): parity tests, default bench, rocprofv3 kernel
+# trace + the two PMC traffic passes over the bench command, smoke().  Writes under gpurun_out/; copy what should be
+# judged into profiles/.
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 rm -rf gpurun_out/summary.log gpurun_out/prof gpurun_out/pmc
