@@ -113,12 +113,12 @@ __global__ __launch_bounds__(256) void eig_normalize_kernel(const float* __restr
 __global__ __launch_bounds__(256) void eig_pivot_kernel(float* __restrict__ Aw, int np, int nb, int step,
                                                         float* __restrict__ Rws, float* __restrict__ Dws,
                                                         int* __restrict__ rotated, EigCtrl* ctrl, float tol_rel,
-                                                        float tol_abs, float tol_conv, int max_inner) {
+                                                        float tol_abs, float tol_conv, int max_inner, int cross_only) {
   if (ctrl->converged) return;
   __shared__ float S[EP][ELD];
   __shared__ float R[EP][ELD];
   __shared__ float cs[32][2];
-  __shared__ int pq[32][2];
+  __shared__ unsigned char sched[EP - 1][32][2];
   __shared__ int any_rot;
   __shared__ int sweep_rot;
   __shared__ int sweep_big;
@@ -162,36 +162,62 @@ __global__ __launch_bounds__(256) void eig_pivot_kernel(float* __restrict__ Aw, 
     }
   }
 
+  // Pair schedule, built once: sched[t][k] = (p, q), p < q, of pair k in step t.
+  //  * step 0 of an outer sweep (every index block sits in exactly one pivot): the full round-robin over the 64
+  //    indices, 63 steps -- this is where the diagonal blocks A_II get diagonalised, once per sweep;
+  //  * every other step: only the 32 x 32 CROSS pairs (i, 32 + (i + t) mod 32), 32 steps -- annihilating A_IJ is
+  //    what the block method needs from this visit, and it halves the latency chain of the solver.
+  const int nsteps = (step == 0 || !cross_only) ? EP - 1 : 32;
+  for (int e = tid; e < nsteps * 32; e += 256) {
+    const int t = e >> 5, k = e & 31;
+    int a, b;
+    if (nsteps == 32) {
+      a = k;
+      b = 32 + ((k + t) & 31);
+    } else if (k == 0) {
+      a = EP - 1;
+      b = t;
+    } else {
+      a = (t + k) % (EP - 1);
+      b = (t - k + (EP - 1)) % (EP - 1);
+    }
+    sched[t][k][0] = (unsigned char)(a < b ? a : b);
+    sched[t][k][1] = (unsigned char)(a < b ? b : a);
+  }
+  __syncthreads();
+
+  // thread -> block mapping of the fused update: the 32 lanes of a half-wave share ONE row pair k1 and take the 32
+  // column pairs k2 = lane.  With the LDS pitch of 65 the bank of S[p1][p2] is (p1 + p2) mod 32 and the p2 of
+  // consecutive k2 are consecutive indices, so every 32-lane access group is conflict-free (the former 8 x 8
+  // mapping mixed four row pairs per group: ~3-way conflicts on every access, and the LDS is what bounds this loop).
+  const int k2 = tid & 31, k1base = tid >> 5;
   for (int sw = 0; sw < max_inner; ++sw) {
-    for (int t = 0; t < EP - 1; ++t) {
+    for (int t = 0; t < nsteps; ++t) {
       // (a) rotation parameters of the 32 disjoint pairs of this step (first half of wave 0)
       if (tid < 64) {
         bool rot = false, big = false;
         if (tid < 32) {
-          int a, b;
-          if (tid == 0) {
-            a = EP - 1;
-            b = t;
-          } else {
-            a = (t + tid) % (EP - 1);
-            b = (t - tid + (EP - 1)) % (EP - 1);
-          }
-          const int p = a < b ? a : b, q = a < b ? b : a;
+          const int p = sched[t][tid][0], q = sched[t][tid][1];
           const float app = S[p][p], aqq = S[q][q], apq = S[p][q];
           float c = 1.f, s = 0.f;
           const float mag = fabsf(apq);
-          if (mag > floor_abs && mag > tol_rel * sqrtf(fabsf(app * aqq))) {
-            const float tau = (aqq - app) / (2.f * apq);
-            const float tt = (tau >= 0.f ? 1.f : -1.f) / (fabsf(tau) + sqrtf(1.f + tau * tau));
-            c = 1.f / sqrtf(1.f + tt * tt);
+          if (mag > floor_abs && mag > tol_rel * __builtin_amdgcn_sqrtf(fabsf(app * aqq))) {
+            // hardware reciprocal / rsqrt (1 ulp): the rotation only has to be orthogonal to ~1e-7, the eigenvalues
+            // are recomputed as Rayleigh quotients and V is re-orthonormalised at the end
+            const float tau = (aqq - app) * __builtin_amdgcn_rcpf(2.f * apq);
+            const float tt = (tau >= 0.f ? 1.f : -1.f) * __builtin_amdgcn_rcpf(fabsf(tau) + __builtin_amdgcn_sqrtf(1.f + tau * tau));
+            c = __builtin_amdgcn_rsqf(1.f + tt * tt);
             s = tt * c;
-            rot = true;
-            big = mag > floor_conv;
+            if (!(s == s) || !(c == c)) {  // tau overflowed: the pair is (numerically) already diagonal
+              c = 1.f;
+              s = 0.f;
+            } else {
+              rot = true;
+              big = mag > floor_conv;
+            }
           }
           cs[tid][0] = c;
           cs[tid][1] = s;
-          pq[tid][0] = p;
-          pq[tid][1] = q;
         }
         const unsigned long long m = __ballot(rot);
         const unsigned long long mb = __ballot(big);
@@ -203,16 +229,15 @@ __global__ __launch_bounds__(256) void eig_pivot_kernel(float* __restrict__ Aw, 
       }
       __syncthreads();
       if (any_rot) {  // block-uniform
-        // (b1) S <- J^T S J on 2x2 blocks: thread owns row-pair k1 = tid/8 and column-pairs tid%8 + 8j
-        const int k1 = tid >> 3;
-        const float c1 = cs[k1][0], s1 = cs[k1][1];
-        const int p1 = pq[k1][0], q1 = pq[k1][1];
+        // (b1) S <- J^T S J on 2x2 blocks: this thread's column pair k2 against four row pairs
+        const float c2 = cs[k2][0], s2 = cs[k2][1];
+        const int p2 = sched[t][k2][0], q2 = sched[t][k2][1];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int k2 = (tid & 7) + 8 * j;
-          const float c2 = cs[k2][0], s2 = cs[k2][1];
+          const int k1 = k1base + 8 * j;
+          const float c1 = cs[k1][0], s1 = cs[k1][1];  // broadcast within the half-wave
           if (s1 != 0.f || s2 != 0.f) {
-            const int p2 = pq[k2][0], q2 = pq[k2][1];
+            const int p1 = sched[t][k1][0], q1 = sched[t][k1][1];
             const float b00 = S[p1][p2], b01 = S[p1][q2], b10 = S[q1][p2], b11 = S[q1][q2];
             const float t00 = c1 * b00 - s1 * b10, t01 = c1 * b01 - s1 * b11;
             const float t10 = s1 * b00 + c1 * b10, t11 = s1 * b01 + c1 * b11;
@@ -234,7 +259,7 @@ __global__ __launch_bounds__(256) void eig_pivot_kernel(float* __restrict__ Aw, 
           const int k = wave * 8 + i;
           const float c = cs[k][0], s = cs[k][1];
           if (s != 0.f) {  // wave-uniform
-            const int p = pq[k][0], q = pq[k][1];
+            const int p = sched[t][k][0], q = sched[t][k][1];
             const float rp = R[lane][p], rq = R[lane][q];
             R[lane][p] = c * rp - s * rq;
             R[lane][q] = s * rp + c * rq;
@@ -573,6 +598,14 @@ static int eig_max_inner() {
   return v;
 }
 
+static int eig_cross_only() {
+  static int v = [] {
+    const char* e = getenv("LK_EIG_CROSS");  // tuning knob (tools/eig_study.py); default on
+    return (e && atoi(e) == 0) ? 0 : 1;
+  }();
+  return v;
+}
+
 static int eig_job_setup(EigJob& j, const float* A, int64_t n, float* w, float* Q, int clamp, int32_t* info, void* ws,
                          size_t ws_bytes) {
   j.p = eig_plan(n);
@@ -624,7 +657,7 @@ static void eig_enqueue_sweep(const EigJob& j, hipStream_t stream) {
   const int inner = eig_max_inner();
   for (int s = 0; s < steps; ++s) {
     hipLaunchKernelGGL(eig_pivot_kernel, dim3(p.npv), dim3(256), 0, stream, j.Aw, p.np, p.nb, s, j.Rws, j.Dws, j.rotated,
-                       j.ctrl, kTolRel, kTolAbs, kTolConv, inner);
+                       j.ctrl, kTolRel, kTolAbs, kTolConv, inner, eig_cross_only());
     hipLaunchKernelGGL(eig_update_kernel, dim3(ntiles + nvblk), dim3(256), 0, stream, j.Aw, j.V, p.np, p.nb, s, j.Rws,
                        j.Dws, j.rotated, j.ctrl, ntiles);
   }
