@@ -108,9 +108,11 @@ class _HipCurvatureMixin:
         for t in tape.taps:
             t.a = sweep.taps[t.name]["a"]
 
-        def grad_fn(seeds, stack=True):
-            grads = sweep.backward(seeds.reshape(seeds.shape[0], seeds.shape[1], *sweep.out_shape))
+        def grad_fn(seeds, stack=True, on_tap=None):
+            grads = sweep.backward(seeds.reshape(seeds.shape[0], seeds.shape[1], *sweep.out_shape), on_tap=on_tap)
             return [grads[t.name] for t in tape.taps]
+
+        grad_fn.streams_taps = True  # accepts on_tap: gradients are delivered layer by layer
 
         return f.detach().reshape(f.shape[0], -1).contiguous(), tape, grad_fn
 
@@ -420,9 +422,27 @@ class KronAccumulator:
             for tap, F in zip(tape.taps, self.factors):
                 b._factor_A(tap, self.N, rt, self.kfac_approx, F[1], fused=True)
         seeds, hs = b._kron_seeds(f, y, self.loss)
-        grads = grad_fn(seeds, stack=False)
-        for tap, g, F in zip(tape.taps, grads, self.factors):
-            b._factor_G(tap, g, rt * hs, self.kfac_approx, F[0], fused=True)
+        if side is not None and getattr(grad_fn, "streams_taps", False):
+            # G factors too go to the side stream, each as soon as the sweep has produced that layer's gradient: the
+            # MFMA-bound Gram kernels then overlap MIOpen's backward-data kernels of the earlier layers
+            by_name = {tap.name: (tap, F) for tap, F in zip(tape.taps, self.factors)}
+            keep = []
+
+            def on_tap(name, g):
+                tap, F = by_name[name]
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    b._factor_G(tap, g, rt * hs, self.kfac_approx, F[0], fused=True)
+                g.record_stream(side)  # allocated on the main stream, read on the side stream
+                keep.append(g)
+
+            grad_fn(seeds, stack=False, on_tap=on_tap)
+        else:
+            grads = grad_fn(seeds, stack=False)
+            for tap, g, F in zip(tape.taps, grads, self.factors):
+                b._factor_G(tap, g, rt * hs, self.kfac_approx, F[0], fused=True)
         if side is not None:
             torch.cuda.current_stream(f.device).wait_stream(side)
         tape.release()

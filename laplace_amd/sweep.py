@@ -236,9 +236,11 @@ class SeedBatchedSweep:
 
     # ---- reverse sweep -----------------------------------------------------------------------------------
     @torch.no_grad()
-    def backward(self, seeds: torch.Tensor) -> dict[str, torch.Tensor]:
+    def backward(self, seeds: torch.Tensor, on_tap=None) -> dict[str, torch.Tensor]:
         """``seeds``: ``[S, B, C]`` cotangents of the output.  Returns per tapped module the gradient w.r.t.
-        its output, ``[S, B, ...]`` (a view of the ``S*B``-batched cotangent)."""
+        its output, ``[S, B, ...]`` (a view of the ``S*B``-batched cotangent).  ``on_tap(name, g)`` is called the
+        moment a tapped module's gradient is complete — the accumulator uses it to start that layer's G-factor
+        kernel on a side stream while the sweep goes on through the earlier layers."""
         S, B = seeds.shape[0], seeds.shape[1]
         # per node: the pending addends of its output cotangent (summed lazily, so that an activation can fold
         # the residual-branch addition into its own kernel)
@@ -265,6 +267,8 @@ class SeedBatchedSweep:
                 m = self.modules[node.target]
                 if node.target in self.tap_names:
                     grads[node.target] = g.reshape(S, B, *g.shape[1:])
+                    if on_tap is not None:
+                        on_tap(node.target, grads[node.target])
                     remaining.discard(node.target)
                     if not remaining:
                         break  # nothing upstream of the first tapped module is needed
