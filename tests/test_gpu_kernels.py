@@ -465,3 +465,85 @@ def test_vjp_scale_mask(K, S, B, C, hw, mult, scaled, two):
     if mult == "bool":  # masked entries are exact zeros
         dead = (~m64).unsqueeze(0).expand(S, B, C, hw).reshape(S * B, C, hw)
         assert (got.cpu()[dead] == 0).all()
+
+
+# ---- guard bands: no kernel writes (or read-modify-writes) outside its output -----------------------------------
+def _banded(shape, fill=None):
+    """an output tensor carved out of a larger buffer whose margins are -0.0 (a `+= 0` flips the sign bit, a store of
+    anything else changes the value); returns (view, check)"""
+    numel = 1
+    for d in shape:
+        numel *= d
+    pad = 16 * 1024
+    buf = torch.full((2 * pad + numel,), -0.0, device=DEV)
+    view = buf[pad:pad + numel].view(*shape)
+    view.fill_(0.0 if fill is None else fill)
+
+    def check(what):
+        lo, hi = buf[:pad], buf[pad + numel:]
+        assert torch.signbit(lo).all() and (lo == 0).all(), f"{what}: wrote before the output"
+        assert torch.signbit(hi).all() and (hi == 0).all(), f"{what}: wrote past the output"
+
+    return view, check
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_outputs_stay_inside_their_buffers(K, seed):
+    """Ragged shapes through every entry point that writes into a caller-provided output (multi-split Gram paths
+    with slab reduction, Jacobian assembly, diagonal accumulation, predictive quadratic forms)."""
+    gen = torch.Generator().manual_seed(100 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=gen))  # noqa: E731
+    f32 = lambda t: t.float().to(DEV).contiguous()  # noqa: E731
+    # Gram family with K large enough for split-K + reduce, n ragged
+    n, Kr = ri(1, 300), ri(200, 5000)
+    out, chk = _banded((n, n))
+    K.gram_tn(f32(rnd(Kr, n, seed=seed)), 0.3, out)
+    _sync(); chk("gram_tn")
+    n, L, nb = ri(1, 200), ri(1, 70), ri(1, 40)
+    out, chk = _banded((n, n))
+    K.gram_nt(f32(rnd(nb, n, L, seed=seed)), 0.3, out)
+    _sync(); chk("gram_nt")
+    Cin, H, W, B = ri(1, 40), ri(2, 20), ri(2, 20), ri(1, 6)
+    out, chk = _banded((9 * Cin, 9 * Cin))
+    K.gram_conv(f32(rnd(B, Cin, H, W, seed=seed)), 3, 1, 1, 1, 0.3, out)
+    _sync(); chk("gram_conv 3x3")
+    k, s_, p_ = ri(1, 4), ri(1, 3), ri(0, 2)
+    if H + 2 * p_ >= k and W + 2 * p_ >= k:
+        out, chk = _banded((k * k * Cin, k * k * Cin))
+        K.gram_conv(f32(rnd(B, Cin, H, W, seed=seed + 1)), k, s_, p_, 1, 0.3, out, upper_only=True, native=True)
+        _sync(); chk("gram_conv general, fused")
+    # Jacobian assembly / diagonal
+    Bq, C, Di, Do = ri(1, 9), ri(1, 7), ri(1, 70), ri(1, 40)
+    P = Do * Di + Do + 5
+    Js, chk = _banded((Bq, C, P))
+    K.jac_linear(f32(rnd(Bq, Di, seed=seed)), f32(rnd(C, Bq, Do, seed=seed + 1)), Js, 3, 3 + Do * Di)
+    _sync(); chk("jac_linear")
+    hw, chk = _banded((Do * Di,))
+    hb, chk2 = _banded((Do,))
+    K.diag_ggn_linear(f32(rnd(Bq, Di, seed=seed)), f32(rnd(C, Bq, Do, seed=seed + 1)), 0.5, hw, hb)
+    _sync(); chk("diag_ggn_linear w"); chk2("diag_ggn_linear b")
+    Co, kk = ri(1, 9), ri(1, 3)
+    Hc, Wc = ri(kk, 9), ri(kk, 9)
+    oh, ow = Hc - kk + 1, Wc - kk + 1
+    width = Co * Cin * kk * kk
+    Jc, chk = _banded((Bq, C, width + Co))
+    K.jac_conv(f32(rnd(Bq, Cin, Hc, Wc, seed=seed)), f32(rnd(C, Bq, Co, oh, ow, seed=seed + 2)), kk, 1, 0, 1, Jc, 0, width)
+    _sync(); chk("jac_conv")
+    h, chk = _banded((width,))
+    K.sq_colsum(Jc, 0, width, 1.0, h)
+    _sync(); chk("sq_colsum")
+    # dense last-layer GGN and predictive quadratic forms
+    D = ri(1, 40)
+    Pll = C * D + C
+    Hm, chk = _banded((Pll, Pll))
+    probs = torch.softmax(rnd(Bq, C, seed=seed), -1) if C > 1 else None
+    K.ll_ggn_full(f32(rnd(Bq, D, seed=seed)), None if probs is None else f32(probs), True, 1.0, Hm)
+    _sync(); chk("ll_ggn_full")
+    fv, chk = _banded((Bq, C, C))
+    K.kron_quadform_linear(f32(rnd(C, Bq, Do, seed=seed)), f32(rnd(Bq, Di, seed=seed + 1)), f32(rnd(Do, seed=2).abs()),
+                           f32(rnd(Di, seed=3).abs()), f32(torch.tensor([0.5], dtype=torch.float64)), fv)
+    _sync(); chk("kron_quadform_linear")
+    fv, chk = _banded((Bq, C, C))
+    K.diag_quadform_linear(f32(rnd(Bq, Di, seed=seed)), f32(rnd(C, Bq, Do, seed=seed + 1)), f32(rnd(Do * Di, seed=4).abs()),
+                           f32(rnd(Do, seed=5).abs()), fv)
+    _sync(); chk("diag_quadform_linear")
