@@ -87,6 +87,14 @@ int lk_gram_conv_nhwc_f32(const float* x, int64_t B, int64_t H, int64_t W, int64
                           int sh, int sw, int ph, int pw, int dh, int dw, float alpha, float* C,
                           unsigned flags, void* ws, size_t ws_bytes, void* stream);
 
+/* Pixel-pair form of the same factor for SMALL maps (4x4 and below): the caller accumulates the pixel-pair Gram
+ *   Cp[(q,ci),(q',cj)] += sum_b x[b,q,ci] x[b,q',cj]     (lk_gram_tn_f32 on the NHWC images flattened to rows, then
+ * lk_symmetrize_f32) over ALL minibatches of a fit -- it is linear in the data -- and this call assembles the patch
+ * Gram from it once:  A[(d,ci),(e,cj)] += alpha * sum_{p: p+d, p+e in the grid} Cp[(p+d,ci),(p+e,cj)], native
+ * (kh,kw,ci) order.  Cp: [H*W*Cin][H*W*Cin], both triangles valid.  A: [9*Cin][9*Cin]. */
+int lk_conv3x3_pixgram_assemble_f32(const float* Cp, int64_t H, int64_t W, int64_t Cin, float alpha, float* A,
+                                    void* stream);
+
 /* Same result as lk_gram_conv_nhwc_f32 for a 3x3 / stride 1 / padding 1 / dilation 1 convolution, through the
  * shift-correlation identity (the input grid equals the output grid, so the 81 (offset, offset) blocks of the
  * patch Gram matrix depend only on the 25 offset differences plus boundary-strip corrections):

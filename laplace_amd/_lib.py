@@ -47,6 +47,7 @@ SIGNATURES = {
     ),
     "lk_conv3x3_shiftcorr_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "lk_conv3x3_shiftcorr_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _f32, _vp, _vp, _sz, _vp]),
+    "lk_conv3x3_pixgram_assemble_f32": (_int, [_vp, _i64, _i64, _i64, _f32, _vp, _vp]),
     "lk_nchw_to_nhwc_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "lk_symmetrize_f32": (_int, [_vp, _i64, _vp]),
     "lk_permute_sym_f32": (_int, [_vp, _i64, _i64, _vp, _int, _vp]),
@@ -283,6 +284,25 @@ class HipKernels:
             self._rc(self.lib.lk_permute_sym_f32(_ptr(tgt), Cin, kh * kw, _ptr(out), 1, self._stream(x.device)),
                      "lk_permute_sym_f32")
         return out
+
+    # ---- pixel-pair form of the 3x3/s1/p1 conv A factor on small maps (see lk_gram.hip) --------------------------
+    #: largest H*W for which KronAccumulator keeps a pixel-pair accumulator instead of calling gram_conv per step
+    pixgram_max_hw = 16
+
+    def pixgram_accumulate(self, x, alpha, Cp):
+        """``Cp += alpha * X^T X`` with ``X`` the NHWC images flattened to rows ``[B, H*W*Cin]`` (upper tiles only)."""
+        _check(x, "x"), _check(Cp, "Cp")
+        B = x.shape[0]
+        xh = self.nchw_to_nhwc(x)
+        return self.gram_tn(xh.reshape(B, -1), alpha, Cp, upper_only=True)
+
+    def pixgram_assemble(self, Cp, H, W, Cin, alpha, A_native):
+        """``A_native += alpha * assemble(Cp)`` (native (kh,kw,ci) order); symmetrises ``Cp`` in place first."""
+        _check(Cp, "Cp"), _check(A_native, "A")
+        self.symmetrize(Cp)
+        self._rc(self.lib.lk_conv3x3_pixgram_assemble_f32(_ptr(Cp), int(H), int(W), int(Cin), float(alpha), _ptr(A_native),
+                                                          self._stream(Cp.device)), "lk_conv3x3_pixgram_assemble_f32")
+        return A_native
 
     def permute_native_to_unfold(self, src, Cin, KK, dst, accumulate=False):
         _check(src, "src"), _check(dst, "dst")

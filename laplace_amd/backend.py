@@ -378,6 +378,7 @@ class KronAccumulator:
     def __init__(self, backend, N: int, kfac_approx: str = "expand", overlap: bool = True):
         self.backend, self.N, self.kfac_approx = backend, N, kfac_approx
         self.overlap = overlap
+        self.use_pixgram = os.environ.get("LK_PIXGRAM", "1") != "0"
         self._side = None
         self.factors = None  # per tap: [G, A]
         self.loss = None
@@ -397,6 +398,45 @@ class KronAccumulator:
                                  torch.zeros(di, di, dtype=torch.float32, device=dev)])
             self._taps_meta.append((tap.has_bias, native))
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._pix = {}  # tap index -> [Cp, H, W, Cin]: pixel-pair accumulators of small-map 3x3 convs
+
+    def _pixgram_geometry(self, tap):
+        """(H, W, Cin) if this tap's A factor is accumulated in pixel-pair form (3x3 / stride 1 / pad 1 conv on a map
+        of at most ``pixgram_max_hw`` pixels): one TN Gram with K = batch rows per minibatch, the 81-block patch
+        Gram assembled once per fit (lk_conv3x3_pixgram_assemble_f32)."""
+        m = tap.module
+        if tap.kind != "conv2d" or self.kfac_approx != "expand" or not self.use_pixgram:
+            return None
+        if (tuple(m.kernel_size), tuple(m.stride), tuple(m.padding), tuple(m.dilation)) != ((3, 3), (1, 1), (1, 1), (1, 1)):
+            return None
+        H, W = tap.a.shape[-2:]
+        if H * W > get_kernels().pixgram_max_hw or H * W * m.in_channels > 16384:
+            return None
+        return int(H), int(W), int(m.in_channels)
+
+    def _accumulate_A(self, idx, tap, F, rt):
+        K = get_kernels()
+        geo = self._pixgram_geometry(tap)
+        if geo is None:
+            self.backend._factor_A(tap, self.N, rt, self.kfac_approx, F[1], fused=True)
+            return
+        H, W, Cin = geo
+        K.pixgram_accumulate(tap.a.to(torch.float32).contiguous(), rt / (self.N * H * W), self._pix[idx][0])
+
+    def _ensure_pixgrams(self, tape):
+        """allocate the pixel-pair accumulators on the CALLING stream (they are consumed there at the end of the fit)"""
+        for idx, tap in enumerate(tape.taps):
+            geo = self._pixgram_geometry(tap)
+            if geo is not None and idx not in self._pix:
+                npix = geo[0] * geo[1] * geo[2]
+                self._pix[idx] = [torch.zeros(npix, npix, dtype=torch.float32, device=tap.a.device), *geo]
+
+    def _flush_pixgrams(self):
+        """fold the pixel-pair accumulators into the (native-order) A factors; idempotent"""
+        K = get_kernels()
+        for idx, (Cp, H, W, Cin) in self._pix.items():
+            K.pixgram_assemble(Cp, H, W, Cin, 1.0, self.factors[idx][1])
+        self._pix = {}
 
     def add_batch(self, x, y):
         b = self.backend
@@ -406,6 +446,7 @@ class KronAccumulator:
         if self.factors is None:
             self._alloc(tape, f.device)
         rt = math.sqrt(float(b.factor))
+        self._ensure_pixgrams(tape)
         # The A factors need only the forward activations: enqueue them on a side stream so that they
         # overlap the C reverse passes (whose late, small-spatial conv kernels do not fill the chip).
         side = None
@@ -416,11 +457,11 @@ class KronAccumulator:
             main = torch.cuda.current_stream(f.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                for tap, F in zip(tape.taps, self.factors):
-                    b._factor_A(tap, self.N, rt, self.kfac_approx, F[1], fused=True)
+                for i, (tap, F) in enumerate(zip(tape.taps, self.factors)):
+                    self._accumulate_A(i, tap, F, rt)
         else:
-            for tap, F in zip(tape.taps, self.factors):
-                b._factor_A(tap, self.N, rt, self.kfac_approx, F[1], fused=True)
+            for i, (tap, F) in enumerate(zip(tape.taps, self.factors)):
+                self._accumulate_A(i, tap, F, rt)
         seeds, hs = b._kron_seeds(f, y, self.loss)
         if side is not None and getattr(grad_fn, "streams_taps", False):
             # G factors too go to the side stream, each as soon as the sweep has produced that layer's gradient: the
@@ -449,12 +490,14 @@ class KronAccumulator:
 
     def tensors(self) -> list[torch.Tensor]:
         """Everything a data-parallel fit has to all-reduce (upper triangles are what counts)."""
+        self._flush_pixgrams()  # the assembled factors are what is exchanged, not the larger pixel-pair Grams
         return [t for F in self.factors for t in F] + [self.loss]
 
     def finalize(self):
         """-> (loss, HipKron) in the reference's layout (laplace/curvature/curvlinops.py:55-75)."""
         K = get_kernels()
         rt = math.sqrt(float(self.backend.factor))
+        self._flush_pixgrams()
         kfacs = []
         for (G, A), (has_bias, native) in zip(self.factors, self._taps_meta):
             K.symmetrize(G)

@@ -141,6 +141,30 @@ class EmulatedKernels:
             w = w.clamp(min=0.0)
         return torch.nan_to_num(w), torch.nan_to_num(Q), torch.zeros(2, dtype=torch.int32)
 
+    pixgram_max_hw = 25  # larger than the product's 16 so that the 5x5 test fixture exercises the pixel-pair path
+
+    def pixgram_accumulate(self, x, alpha, Cp):
+        X = x.permute(0, 2, 3, 1).reshape(x.shape[0], -1)
+        Cp += alpha * torch.triu(X.T @ X)  # upper only, like the fused accumulators
+        return Cp
+
+    def pixgram_assemble(self, Cp, H, W, Cin, alpha, A_native):
+        full = torch.triu(Cp) + torch.triu(Cp, 1).T
+        Cp.copy_(full)
+        C6 = full.reshape(H, W, Cin, H, W, Cin)
+        for d in range(9):
+            dy, dx = d // 3 - 1, d % 3 - 1
+            for e in range(9):
+                ey, ex = e // 3 - 1, e % 3 - 1
+                blk = torch.zeros(Cin, Cin, dtype=Cp.dtype)
+                for py in range(H):
+                    for px in range(W):
+                        ay, ax, by, bx = py + dy, px + dx, py + ey, px + ex
+                        if 0 <= ay < H and 0 <= ax < W and 0 <= by < H and 0 <= bx < W:
+                            blk += C6[ay, ax, :, by, bx, :]
+                A_native[d * Cin:(d + 1) * Cin, e * Cin:(e + 1) * Cin] += alpha * blk
+        return A_native
+
     def syevj_batched(self, mats, clamp=True, max_sweeps=0, streams=None):
         return [self.syevj(A, clamp, max_sweeps) for A in mats]
 

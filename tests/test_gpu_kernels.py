@@ -547,3 +547,20 @@ def test_outputs_stay_inside_their_buffers(K, seed):
     K.diag_quadform_linear(f32(rnd(Bq, Di, seed=seed)), f32(rnd(C, Bq, Do, seed=seed + 1)), f32(rnd(Do * Di, seed=4).abs()),
                            f32(rnd(Do, seed=5).abs()), fv)
     _sync(); chk("diag_quadform_linear")
+
+
+@pytest.mark.parametrize("B,Cin,H,W", [(3, 4, 4, 4), (5, 8, 2, 3), (2, 64, 4, 4), (4, 7, 1, 1), (3, 5, 3, 4), (2, 130, 4, 4)])
+def test_conv3x3_pixel_pair_form(K, B, Cin, H, W):
+    """Small-map 3x3/s1/p1 A factor: pixel-pair Gram accumulated over TWO minibatches, assembled once ==
+    the patch Gram of both minibatches (implicit im2col) == unfold."""
+    x1, x2 = rnd(B, Cin, H, W, seed=B + Cin), rnd(B, Cin, H, W, seed=B + Cin + 1)
+    n, npix = 9 * Cin, H * W * Cin
+    want = torch.zeros(n, n, dtype=torch.float64)
+    for x in (x1, x2):
+        EMU.gram_conv(x, 3, 1, 1, 1, 0.5, want)
+    Cp = torch.zeros(npix, npix, device=DEV)
+    for x in (x1, x2):
+        K.pixgram_accumulate(x.float().to(DEV), 0.5, Cp)
+    nat = K.pixgram_assemble(Cp, H, W, Cin, 1.0, torch.zeros(n, n, device=DEV))
+    got = K.permute_native_to_unfold(nat, Cin, 9, torch.zeros(n, n, device=DEV))
+    assert_close(got, want, what="pixel-pair form")
