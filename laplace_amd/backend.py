@@ -14,11 +14,12 @@ Boundary (laplace/baselaplace.py:179-194): the class is instantiated lazily as
 substrings ``backpack`` / ``asdl`` / ``asdfghjkl`` that baselaplace.py:142-149,943-952,1313-1325
 sniff for.
 
-What runs where: model forward + ONE batched reverse pass = stock PyTorch-ROCm
-(:mod:`laplace_amd.capture`); everything named in BASELINE.json's north_star — likelihood
-Hessian root + loss, A/G factor accumulation, diagonal / dense GGN, per-sample Jacobian
-assembly — is a HIP entry point of ``include/laplace_hip.h`` (through :mod:`laplace_amd._lib`).
-Only fp32 models on a ROCm device are accepted; there is no CPU path.
+What runs where: the model forward and the convolution backward-data kernels are stock PyTorch-ROCm / MIOpen,
+driven by the seed-batched reverse sweep of :mod:`laplace_amd.sweep` (all seeds in one pass; models it cannot
+trace fall back to the autograd tape of :mod:`laplace_amd.capture`); everything named in BASELINE.json's
+north_star — likelihood-Hessian root + loss, the element-wise VJPs of the sweep, A/G factor accumulation,
+diagonal / dense GGN, per-sample Jacobian assembly — is a HIP entry point of ``include/laplace_hip.h`` (through
+:mod:`laplace_amd._lib`).  Only fp32 models on a ROCm device are accepted; there is no CPU path.
 """
 from __future__ import annotations
 

@@ -95,3 +95,39 @@ def test_marglik_prior_optimisation_moves_uphill(emulated):
     before = la.log_marginal_likelihood().item()
     la.optimize_prior_precision(n_steps=30, lr=0.1)
     assert la.log_marginal_likelihood().item() > before
+
+
+def _sampling_smoke(dev):
+    """posterior samples have the posterior's moments; sampling predictives are valid and leave the model intact"""
+    from laplace_amd.laplace import HipLaplace
+
+    for hs in ("kron", "diag", "full"):
+        g = load_golden("mlp", "classification")
+        model, X, y = golden_model("mlp", g, dtype=torch.float32, device=dev)
+        la = HipLaplace(model, "classification", "all", hs, prior_precision=PRIOR_PREC)
+        la.fit(DataLoader(TensorDataset(X, y), batch_size=5))
+        gen = torch.Generator(device=dev).manual_seed(0)
+        s = la.sample(20000, generator=gen)
+        assert s.shape == (20000, la.n_params) and torch.isfinite(s).all()
+        assert (s.mean(0) - la.mean).abs().max() < 0.05 * (1 + la.mean.abs().max())
+        if hs == "diag":
+            assert rel(s.var(0), la.posterior_variance) < 0.1
+        elif hs == "full":
+            assert rel(torch.cov(s.T), la.posterior_covariance) < 0.1
+        else:
+            want = la.posterior_precision.to_matrix(exponent=-1)
+            assert rel(torch.cov(s.T), want) < 0.1
+        p = la.predictive_samples(X, pred_type="nn", n_samples=7, generator=gen)
+        assert p.shape == (7, len(X), 2) and torch.allclose(p.sum(-1), torch.ones(7, len(X), device=dev), atol=1e-5)
+        p = la(X, pred_type="glm", link_approx="mc", n_samples=50, generator=gen)
+        assert torch.allclose(p.sum(-1), torch.ones(len(X), device=dev), atol=1e-5)
+        assert torch.allclose(torch.nn.utils.parameters_to_vector(la.params), la.mean)
+
+
+def test_sampling_smoke_on_emulation(emulated):
+    _sampling_smoke("cpu")
+
+
+@pytest.mark.gpu
+def test_sampling_smoke_gpu():
+    _sampling_smoke("cuda")
