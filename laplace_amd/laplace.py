@@ -245,8 +245,23 @@ class _HipLaplace:
     def _glm_predictive_distribution(self, X, diagonal_output: bool = False):
         raise NotImplementedError
 
+    def functional_covariance(self, Js: torch.Tensor) -> torch.Tensor:
+        """``[B*C, B*C]`` joint GLM covariance ``Js P^-1 Js^T`` (baselaplace.py:1418-1437)."""
+        raise NotImplementedError
+
+    def _jacobians(self, X):
+        return (self.backend.last_layer_jacobians(X) if self.subset_of_weights == "last_layer"
+                else self.backend.jacobians(X))
+
     @torch.no_grad()
-    def __call__(self, x, pred_type: str = "glm", link_approx: str = "probit", n_samples: int = 100,
+    def _glm_joint_distribution(self, X):
+        """baselaplace.py:1329-1331: the joint predictive over a batch needs the materialised Jacobians (the
+        cross-sample blocks couple all rows), assembled by the HIP Jacobian kernels."""
+        Js, f_mu = self._jacobians(X)
+        return f_mu.flatten().detach(), self.functional_covariance(Js).detach()
+
+    @torch.no_grad()
+    def __call__(self, x, pred_type: str = "glm", joint: bool = False, link_approx: str = "probit", n_samples: int = 100,
                  diagonal_output: bool = False, generator: torch.Generator | None = None):
         """Posterior predictive (baselaplace.py:1112-1208): ``pred_type`` 'glm' with the 'probit' or 'mc' link
         approximation, or 'nn' (weight-space sampling, 'mc' only)."""
@@ -261,6 +276,8 @@ class _HipLaplace:
                 samples = self._nn_predictive_samples(x, n_samples, generator)
                 return samples.mean(dim=0), samples.var(dim=0)
             return self._nn_predictive_samples(x, n_samples, generator).mean(dim=0)
+        if joint and self.likelihood == "regression":  # joint=True only applies to regression (baselaplace.py:646-648)
+            return self._glm_joint_distribution(x)
         f_mu, f_var = self._glm_predictive_distribution(x, diagonal_output=diagonal_output)
         if self.likelihood == "regression":
             return f_mu, f_var
@@ -434,6 +451,11 @@ class HipKronLaplace(_HipLaplace):
     def functional_variance(self, Js: torch.Tensor) -> torch.Tensor:
         return self.posterior_precision.inv_square_form(Js)
 
+    def functional_covariance(self, Js: torch.Tensor) -> torch.Tensor:
+        """baselaplace.py:1837-1843"""
+        n_batch, n_outs, n_params = Js.shape
+        return self.posterior_precision.inv_square_form(Js.reshape(1, n_batch * n_outs, n_params)).squeeze(0)
+
     def sample(self, n_samples: int = 100, generator=None) -> torch.Tensor:
         """baselaplace.py:1845-1858: ``mean + P^{-1/2} z`` block-wise through the eigendecomposition."""
         z = self._randn(n_samples, self.n_params, generator=generator)
@@ -476,6 +498,12 @@ class HipDiagLaplace(_HipLaplace):
     @property
     def log_det_posterior_precision(self):
         return self.posterior_precision.log().sum()
+
+    def functional_covariance(self, Js: torch.Tensor) -> torch.Tensor:
+        """baselaplace.py:2117-2122"""
+        n_batch, n_outs, n_params = Js.shape
+        Js = Js.reshape(n_batch * n_outs, n_params)
+        return torch.einsum("np,p,mp->nm", Js, self.posterior_variance, Js)
 
     def sample(self, n_samples: int = 100, generator=None) -> torch.Tensor:
         """baselaplace.py:2124-2131"""
@@ -528,6 +556,12 @@ class HipFullLaplace(_HipLaplace):
 
     def functional_variance(self, Js):
         return torch.einsum("ncp,pq,nkq->nck", Js, self.posterior_covariance, Js)
+
+    def functional_covariance(self, Js: torch.Tensor) -> torch.Tensor:
+        """baselaplace.py:1686-1689"""
+        n_batch, n_outs, n_params = Js.shape
+        Js = Js.reshape(n_batch * n_outs, n_params)
+        return torch.einsum("np,pq,mq->nm", Js, self.posterior_covariance, Js)
 
     def sample(self, n_samples: int = 100, generator=None) -> torch.Tensor:
         """baselaplace.py:1691-1703: ``mean + z L^T``; ``L`` = lower Cholesky factor of the posterior covariance

@@ -79,3 +79,21 @@ def test_regression_nn_predictive_and_gridsearch(emulated):
         ours.prior_precision = pp
         losses.append(float(((ours(X)[0] - y) ** 2).mean()))
     assert abs(float(best) - float(torch.logspace(-2, 2, 9)[int(torch.tensor(losses).argmin())])) < 1e-6
+
+
+@pytest.mark.parametrize("hs", ["kron", "diag", "full"])
+@pytest.mark.parametrize("sow", ["all", "last_layer"])
+def test_joint_regression_predictive_matches_reference(emulated, hs, sow):
+    """`joint=True` (baselaplace.py:1329-1331): the [B*C, B*C] GLM covariance over a batch."""
+    ours, theirs, X, y = _pair("mlp", "regression", hs, sow)
+    mu1, cov1 = ours(X, joint=True)
+    mu2, cov2 = theirs(X, joint=True)
+    n = X.shape[0] * mu2.numel() // X.shape[0]
+    assert cov1.shape == cov2.shape == (n, n) and mu1.shape == mu2.shape
+    torch.testing.assert_close(mu1, mu2, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(cov1, cov2, rtol=5e-4, atol=1e-6)
+    # its diagonal blocks are the per-sample covariances of the ordinary call
+    f_mu, f_var = ours(X)
+    C = f_mu.shape[1]
+    for i in range(X.shape[0]):
+        torch.testing.assert_close(cov1[i * C:(i + 1) * C, i * C:(i + 1) * C], f_var[i], rtol=5e-4, atol=1e-6)
