@@ -72,6 +72,8 @@ class _HipLaplace:
             raise ValueError("subset_of_weights must be 'all' or 'last_layer'")
         self.likelihood = likelihood
         self.subset_of_weights = subset_of_weights
+        self._last_layer_name = last_layer_name  # as given (lllaplace.py:335-339 stores the constructor argument)
+        self.data = None  # first training datum of a last-layer fit (lllaplace.py: lazy head discovery on load)
         self.temperature = temperature
         self._backend_cls = backend
         self._backend_kwargs = dict(backend_kwargs or {})
@@ -184,6 +186,8 @@ class _HipLaplace:
                 with torch.no_grad():
                     self.n_outputs = self.model(X[:1] if torch.is_tensor(X) else X).shape[-1]
                 setattr(self.model, "output_size", self.n_outputs)
+                if self.subset_of_weights == "last_layer" and torch.is_tensor(X):
+                    self.data = (X[:1].detach().cpu(), y[:1].detach().cpu())
             loss_b, H_b = self._curv_closure(X, y, N)
             self.loss = self.loss + loss_b
             self.H += H_b
@@ -288,6 +292,57 @@ class _HipLaplace:
         kappa = 1 / torch.sqrt(1.0 + pi / 8 * var_diag)
         return torch.softmax(kappa * f_mu, dim=-1)
 
+    # ---- serialisation, interchangeable with the reference's classes (baselaplace.py:1509-1557,1867-1879) ----------
+    _REF_NAMES = {"kron": "Kron", "diag": "Diag", "full": "Full"}
+
+    @property
+    def _ref_cls_name(self) -> str:
+        """name of the reference class a checkpoint of this object loads into (and comes from)"""
+        return self._REF_NAMES[self._structure] + ("LLLaplace" if self.subset_of_weights == "last_layer" else "Laplace")
+
+    def _H_for_state(self):
+        return self.H
+
+    def state_dict(self) -> dict:
+        if self.H is None:
+            raise AttributeError("Laplace not fit. Run fit() first.")
+        sd = {"mean": self.mean, "H": self._H_for_state(), "loss": self.loss, "prior_mean": self.prior_mean,
+              "prior_precision": self.prior_precision, "sigma_noise": self.sigma_noise, "n_data": self.n_data,
+              "n_outputs": self.n_outputs, "likelihood": self.likelihood, "temperature": self.temperature,
+              "enable_backprop": False, "cls_name": self._ref_cls_name}
+        if self.subset_of_weights == "last_layer":  # lllaplace.py:335-339
+            sd["data"] = self.data
+            sd["_last_layer_name"] = self._last_layer_name
+        return sd
+
+    def _set_H_from_state(self, H):
+        self.H = H
+
+    def load_state_dict(self, state_dict: dict) -> None:
+        if state_dict["cls_name"] != self._ref_cls_name:
+            raise ValueError("Loading a wrong Laplace type. Make sure `subset_of_weights` and `hessian_structure` "
+                             "are correct!")
+        if self.subset_of_weights == "last_layer":
+            if state_dict.get("_last_layer_name", self._last_layer_name) != self._last_layer_name:
+                raise ValueError("Different `last_layer_name` detected!")
+            self.data = state_dict.get("data")
+        if len(state_dict["mean"]) != self.n_params:
+            raise ValueError("Attempting to load Laplace with different number of parameters than the model.")
+        if str(getattr(state_dict["likelihood"], "value", state_dict["likelihood"])) != self.likelihood:
+            raise ValueError("Different likelihoods detected!")
+        to = lambda t: t.to(self._device, self._dtype) if torch.is_tensor(t) else t  # noqa: E731
+        self.mean = to(state_dict["mean"])
+        self.loss = to(state_dict["loss"])
+        self.prior_mean = to(state_dict["prior_mean"])
+        self.prior_precision = to(state_dict["prior_precision"])
+        self.sigma_noise = to(state_dict["sigma_noise"])
+        self.n_data = state_dict["n_data"]
+        self.n_outputs = state_dict["n_outputs"]
+        setattr(self.model, "output_size", self.n_outputs)
+        self.temperature = state_dict["temperature"]
+        self._set_H_from_state(state_dict["H"])
+        self._posterior_cache = None
+
     # ---- sampling predictives (baselaplace.py:697-841,1210-1394) ------------------------------------------------
     def sample(self, n_samples: int = 100, generator: torch.Generator | None = None) -> torch.Tensor:
         """``[n_samples, P]`` draws from the Laplace posterior N(mean, posterior_precision^-1)."""
@@ -384,6 +439,8 @@ class _HipLaplace:
 
 
 class HipKronLaplace(_HipLaplace):
+    _structure = "kron"
+
     """KFAC Laplace (KronLaplace, baselaplace.py:1704-1879) on the HIP kernels."""
 
     def __init__(self, *args, damping: bool = False, **kwargs):
@@ -423,6 +480,8 @@ class HipKronLaplace(_HipLaplace):
                     with torch.no_grad():
                         self.n_outputs = self.model(X[:1] if torch.is_tensor(X) else X).shape[-1]
                     setattr(self.model, "output_size", self.n_outputs)
+                    if self.subset_of_weights == "last_layer" and torch.is_tensor(X):
+                        self.data = (X[:1].detach().cpu(), y[:1].detach().cpu())
                 acc.add_batch(X, y)
             if distributed is None:
                 distributed = dist.is_available() and dist.is_initialized()
@@ -451,6 +510,14 @@ class HipKronLaplace(_HipLaplace):
     def functional_variance(self, Js: torch.Tensor) -> torch.Tensor:
         return self.posterior_precision.inv_square_form(Js)
 
+    def _H_for_state(self):
+        return self.H_facs.kfacs  # the factors, not the eigendecomposition (baselaplace.py:1867-1871)
+
+    def _set_H_from_state(self, kfacs):
+        to = lambda t: t.to(self._device, self._dtype)  # noqa: E731
+        self.H_facs = HipKron([[to(Hi) for Hi in F] for F in kfacs])
+        self.H = self.H_facs.decompose(damping=self.damping)
+
     def functional_covariance(self, Js: torch.Tensor) -> torch.Tensor:
         """baselaplace.py:1837-1843"""
         n_batch, n_outs, n_params = Js.shape
@@ -476,6 +543,8 @@ class HipKronLaplace(_HipLaplace):
 
 
 class HipDiagLaplace(_HipLaplace):
+    _structure = "diag"
+
     """Diagonal Laplace (DiagLaplace, baselaplace.py:2048-2136)."""
 
     def _init_H(self):
@@ -526,6 +595,8 @@ class HipDiagLaplace(_HipLaplace):
 
 
 class HipFullLaplace(_HipLaplace):
+    _structure = "full"
+
     """Dense Laplace (FullLaplace, baselaplace.py:1572-1701).  The one-off ``P^3`` factorisation of
     the posterior precision stays a library call (torch.linalg.cholesky -> rocSOLVER), exactly where
     the reference calls it (utils/utils.py:118-129); accumulation and the predictive are HIP."""

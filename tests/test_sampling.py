@@ -97,3 +97,32 @@ def test_joint_regression_predictive_matches_reference(emulated, hs, sow):
     C = f_mu.shape[1]
     for i in range(X.shape[0]):
         torch.testing.assert_close(cov1[i * C:(i + 1) * C, i * C:(i + 1) * C], f_var[i], rtol=5e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("hs", ["kron", "diag", "full"])
+@pytest.mark.parametrize("sow", ["all", "last_layer"])
+def test_state_dict_interchange_with_reference(emulated, hs, sow, tmp_path):
+    """Checkpoints are interchangeable in both directions (baselaplace.py:1509-1557; Kron stores the factors,
+    :1867-1879) and survive torch.save / torch.load."""
+    import laplace as ref
+    from laplace_amd import HipGGN
+    from laplace_amd.laplace import HipLaplace
+
+    ours, theirs, X, y = _pair("mlp", "classification", hs, sow)
+    want = ours(X)
+    # ours -> file -> reference class
+    path = tmp_path / "la.pt"
+    torch.save(ours.state_dict(), path)
+    fresh_ref = ref.Laplace(theirs.model if sow == "all" else theirs.model.model, "classification", subset_of_weights=sow,
+                            hessian_structure=hs, backend=HipGGN)
+    fresh_ref.load_state_dict(torch.load(path, weights_only=False))
+    torch.testing.assert_close(fresh_ref(X), want, rtol=5e-4, atol=1e-5)
+    # reference -> ours
+    fresh = HipLaplace(ours.model if sow == "all" else ours.model.model, "classification", sow, hs)
+    fresh.load_state_dict(theirs.state_dict())
+    torch.testing.assert_close(fresh(X), want, rtol=5e-4, atol=1e-5)
+    torch.testing.assert_close(fresh.log_marginal_likelihood(), ours.log_marginal_likelihood(), rtol=1e-4, atol=1e-4)
+    with pytest.raises(ValueError):
+        other = HipLaplace(ours.model if sow == "all" else ours.model.model, "classification", sow,
+                           "diag" if hs != "diag" else "kron")
+        other.load_state_dict(ours.state_dict())
