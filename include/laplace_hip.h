@@ -95,6 +95,22 @@ int lk_gram_conv_nhwc_f32(const float* x, int64_t B, int64_t H, int64_t W, int64
 int lk_conv3x3_pixgram_assemble_f32(const float* Cp, int64_t H, int64_t W, int64_t Cin, float alpha, float* A,
                                     void* stream);
 
+/* Banded pixel-pair form for ANY map size (Cin % 64 == 0): only the pixel pairs (q, q + D) a 3x3 window can see are
+ * kept, D in the half plane {(0,0),(0,1),(0,2),(1,-2..2),(2,-2..2)}: `n_blocks` blocks Blk[q,D] = [Cin][Cin], stored
+ * back to back, accumulated over all minibatches of a fit and assembled once:
+ *   _plan      : tile edge (64 / 128), number of T x T launch tiles and of blocks for a geometry
+ *   _tables    : fills HOST tables  tiles[n_tiles][3] = (column of the A panel, column of the B panel, output offset)
+ *                and  slots[H*W][13] = block index of (q, D) or -1; the caller uploads them once per geometry
+ *   _accumulate: Blk[q,D] += alpha * sum_b x[b,q,:]^T x[b,q+D,:]   (x: NHWC [B][H][W][Cin]; tiles_dev on the device)
+ *   _assemble  : A[(d,ci),(e,cj)] += alpha * sum_{p: p+d, p+e in the map} Blk[p+d, e-d][ci][cj]  (native order)
+ * Replaces, like lk_conv3x3_shiftcorr_f32, the per-minibatch A^T A of curvlinops' KFAC for such layers. */
+int lk_conv3x3_pixpair_plan(int64_t H, int64_t W, int64_t Cin, int64_t* tile, int64_t* n_tiles, int64_t* n_blocks);
+int lk_conv3x3_pixpair_tables(int64_t H, int64_t W, int64_t Cin, int32_t* tiles, int32_t* slots);
+int lk_conv3x3_pixpair_accumulate_f32(const float* x, int64_t B, int64_t H, int64_t W, int64_t Cin, float alpha,
+                                      float* blocks, const int32_t* tiles_dev, int64_t n_tiles, void* stream);
+int lk_conv3x3_pixpair_assemble_f32(const float* blocks, const int32_t* slots_dev, int64_t H, int64_t W, int64_t Cin,
+                                    float alpha, float* A, void* stream);
+
 /* Same result as lk_gram_conv_nhwc_f32 for a 3x3 / stride 1 / padding 1 / dilation 1 convolution, through the
  * shift-correlation identity (the input grid equals the output grid, so the 81 (offset, offset) blocks of the
  * patch Gram matrix depend only on the 25 offset differences plus boundary-strip corrections):

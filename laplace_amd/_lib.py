@@ -48,6 +48,10 @@ SIGNATURES = {
     "lk_conv3x3_shiftcorr_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "lk_conv3x3_shiftcorr_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _f32, _vp, _vp, _sz, _vp]),
     "lk_conv3x3_pixgram_assemble_f32": (_int, [_vp, _i64, _i64, _i64, _f32, _vp, _vp]),
+    "lk_conv3x3_pixpair_plan": (_int, [_i64, _i64, _i64, _vp, _vp, _vp]),
+    "lk_conv3x3_pixpair_tables": (_int, [_i64, _i64, _i64, _vp, _vp]),
+    "lk_conv3x3_pixpair_accumulate_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _f32, _vp, _vp, _i64, _vp]),
+    "lk_conv3x3_pixpair_assemble_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _f32, _vp, _vp]),
     "lk_nchw_to_nhwc_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "lk_symmetrize_f32": (_int, [_vp, _i64, _vp]),
     "lk_permute_sym_f32": (_int, [_vp, _i64, _i64, _vp, _int, _vp]),
@@ -302,6 +306,46 @@ class HipKernels:
         self.symmetrize(Cp)
         self._rc(self.lib.lk_conv3x3_pixgram_assemble_f32(_ptr(Cp), int(H), int(W), int(Cin), float(alpha), _ptr(A_native),
                                                           self._stream(Cp.device)), "lk_conv3x3_pixgram_assemble_f32")
+        return A_native
+
+    # ---- banded pixel-pair form (any map size, Cin % 64 == 0) -------------------------------------------------------
+    def pixpair_plan(self, H, W, Cin, dev):
+        """(n_blocks, tiles_dev, slots_dev) for a geometry; tables are built by the library on the host and uploaded
+        once per (geometry, device).  None if the geometry is not eligible (Cin % 64 != 0 or too large)."""
+        key = (int(H), int(W), int(Cin), str(dev))
+        cache = self.__dict__.setdefault("_pixpair_cache", {})
+        if key not in cache:
+            T, nt, nb = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+            plan = None
+            if Cin >= 64 and Cin % 64 == 0 and self.lib.lk_conv3x3_pixpair_plan(
+                    int(H), int(W), int(Cin), ctypes.byref(T), ctypes.byref(nt), ctypes.byref(nb)) == 0:
+                tiles = torch.empty(nt.value, 3, dtype=torch.int32)
+                slots = torch.empty(int(H) * int(W), 13, dtype=torch.int32)
+                self._rc(self.lib.lk_conv3x3_pixpair_tables(int(H), int(W), int(Cin), ctypes.c_void_p(tiles.data_ptr()),
+                                                            ctypes.c_void_p(slots.data_ptr())), "lk_conv3x3_pixpair_tables")
+                plan = (nb.value, tiles.to(dev), slots.to(dev))
+            cache[key] = plan
+        return cache[key]
+
+    def pixpair_accumulate(self, x, alpha, blocks, plan):
+        """``Blk[q, D] += alpha * sum_b x[b,q,:]^T x[b,q+D,:]`` for an NCHW input ``x``."""
+        _check(x, "x"), _check(blocks, "blocks")
+        B, Cin, H, W = x.shape
+        nb, tiles, _ = plan
+        assert blocks.numel() == nb * Cin * Cin
+        xh = self.nchw_to_nhwc(x)
+        # HBM-bound (each block is read-modified-written once per minibatch): work = algorithmic BYTES
+        self._rc(self._timed("pixpair", 8.0 * blocks.numel() + 4.0 * x.numel(), x.device,
+                             lambda: self.lib.lk_conv3x3_pixpair_accumulate_f32(
+                                 _ptr(xh), B, H, W, Cin, float(alpha), _ptr(blocks), ctypes.c_void_p(tiles.data_ptr()),
+                                 tiles.shape[0], self._stream(x.device))), "lk_conv3x3_pixpair_accumulate_f32")
+        return blocks
+
+    def pixpair_assemble(self, blocks, plan, H, W, Cin, alpha, A_native):
+        _check(blocks, "blocks"), _check(A_native, "A")
+        self._rc(self.lib.lk_conv3x3_pixpair_assemble_f32(_ptr(blocks), ctypes.c_void_p(plan[2].data_ptr()), int(H), int(W),
+                                                          int(Cin), float(alpha), _ptr(A_native),
+                                                          self._stream(blocks.device)), "lk_conv3x3_pixpair_assemble_f32")
         return A_native
 
     def permute_native_to_unfold(self, src, Cin, KK, dst, accumulate=False):

@@ -399,44 +399,72 @@ class KronAccumulator:
                                  torch.zeros(di, di, dtype=torch.float32, device=dev)])
             self._taps_meta.append((tap.has_bias, native))
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
-        self._pix = {}  # tap index -> [Cp, H, W, Cin]: pixel-pair accumulators of small-map 3x3 convs
+        self._pix = {}  # tap index -> (geometry, buffer): pixel-pair accumulators of 3x3 convs
 
-    def _pixgram_geometry(self, tap):
-        """(H, W, Cin) if this tap's A factor is accumulated in pixel-pair form (3x3 / stride 1 / pad 1 conv on a map
-        of at most ``pixgram_max_hw`` pixels): one TN Gram with K = batch rows per minibatch, the 81-block patch
-        Gram assembled once per fit (lk_conv3x3_pixgram_assemble_f32)."""
+    def _pix_geometry(self, tap):
+        """How this tap's A factor is accumulated over the fit (3x3 / stride 1 / pad 1 convs, ``expand``):
+
+        * ``("pair", H, W, Cin, plan)``: banded pixel-pair blocks (any map size, ``Cin % 64 == 0``) —
+          ``lk_conv3x3_pixpair_*``;
+        * ``("dense", H, W, Cin)``: the full pixel-pair Gram of maps of at most ``pixgram_max_hw`` pixels —
+          ``lk_gram_tn_f32`` + ``lk_conv3x3_pixgram_assemble_f32``;
+        * ``None``: the per-minibatch kernels (shift correlation / implicit im2col).
+
+        Both pixel-pair forms are linear in the data: one small product per minibatch, the 81 patch blocks are
+        assembled once per fit."""
         m = tap.module
         if tap.kind != "conv2d" or self.kfac_approx != "expand" or not self.use_pixgram:
             return None
         if (tuple(m.kernel_size), tuple(m.stride), tuple(m.padding), tuple(m.dilation)) != ((3, 3), (1, 1), (1, 1), (1, 1)):
             return None
-        H, W = tap.a.shape[-2:]
-        if H * W > get_kernels().pixgram_max_hw or H * W * m.in_channels > 16384:
-            return None
-        return int(H), int(W), int(m.in_channels)
+        K = get_kernels()
+        H, W = (int(v) for v in tap.a.shape[-2:])
+        Cin = int(m.in_channels)
+        if H * W > K.pixgram_max_hw or Cin % 64 == 0:
+            plan = K.pixpair_plan(H, W, Cin, tap.a.device)
+            if plan is not None and plan[0] * Cin * Cin * 4 <= (1 << 30):
+                return ("pair", H, W, Cin, plan)
+        if H * W <= K.pixgram_max_hw and H * W * Cin <= 16384:
+            return ("dense", H, W, Cin)
+        return None
 
     def _accumulate_A(self, idx, tap, F, rt):
         K = get_kernels()
-        geo = self._pixgram_geometry(tap)
-        if geo is None:
+        acc = self._pix.get(idx)
+        if acc is None:
             self.backend._factor_A(tap, self.N, rt, self.kfac_approx, F[1], fused=True)
             return
-        H, W, Cin = geo
-        K.pixgram_accumulate(tap.a.to(torch.float32).contiguous(), rt / (self.N * H * W), self._pix[idx][0])
+        geo, buf = acc
+        alpha = rt / (self.N * geo[1] * geo[2])
+        a = tap.a.to(torch.float32).contiguous()
+        if geo[0] == "pair":
+            K.pixpair_accumulate(a, alpha, buf, geo[4])
+        else:
+            K.pixgram_accumulate(a, alpha, buf)
 
     def _ensure_pixgrams(self, tape):
         """allocate the pixel-pair accumulators on the CALLING stream (they are consumed there at the end of the fit)"""
         for idx, tap in enumerate(tape.taps):
-            geo = self._pixgram_geometry(tap)
-            if geo is not None and idx not in self._pix:
-                npix = geo[0] * geo[1] * geo[2]
-                self._pix[idx] = [torch.zeros(npix, npix, dtype=torch.float32, device=tap.a.device), *geo]
+            if idx in self._pix:
+                continue
+            geo = self._pix_geometry(tap)
+            if geo is None:
+                continue
+            if geo[0] == "pair":
+                buf = torch.zeros(geo[4][0] * geo[3] * geo[3], dtype=torch.float32, device=tap.a.device)
+            else:
+                npix = geo[1] * geo[2] * geo[3]
+                buf = torch.zeros(npix, npix, dtype=torch.float32, device=tap.a.device)
+            self._pix[idx] = (geo, buf)
 
     def _flush_pixgrams(self):
         """fold the pixel-pair accumulators into the (native-order) A factors; idempotent"""
         K = get_kernels()
-        for idx, (Cp, H, W, Cin) in self._pix.items():
-            K.pixgram_assemble(Cp, H, W, Cin, 1.0, self.factors[idx][1])
+        for idx, (geo, buf) in self._pix.items():
+            if geo[0] == "pair":
+                K.pixpair_assemble(buf, geo[4], geo[1], geo[2], geo[3], 1.0, self.factors[idx][1])
+            else:
+                K.pixgram_assemble(buf, geo[1], geo[2], geo[3], 1.0, self.factors[idx][1])
         self._pix = {}
 
     def add_batch(self, x, y):

@@ -28,7 +28,8 @@
 
 namespace lk {
 
-enum { MODE_TN = 0, MODE_NT = 1, MODE_CONV = 2, MODE_XCORR = 3 };
+// MODE_TNP: TN loader, tiles taken from a table (colA, colB, output offset): block-sparse products into compact blocks
+enum { MODE_TN = 0, MODE_NT = 1, MODE_CONV = 2, MODE_XCORR = 3, MODE_TNP = 4 };
 #ifdef LK_GRAM_TRACE  // development build (tools/gram_trace.py): per-phase cycle counts of one wave of the last launch
 __device__ long long g_gram_trace[5];
 #endif
@@ -59,6 +60,8 @@ struct GramGeom {
   int64_t K;    // virtual rows
   int n;        // columns (= output dim)
   int64_t ldx;  // TN
+  const int* tiles;  // TNP: [ntiles][3] = column offset of the A panel, of the B panel, output offset (floats)
+  int ldc;           // TNP: leading dimension of an output block
   int L, Lp;    // NT: positions per image, padded to a multiple of BK
   int seg_nb;   // NT: images per segment
   int nseg;     // NT: number of segments (1 = plain tensor)
@@ -139,7 +142,7 @@ __device__ __forceinline__ void make_colctx(const GramGeom& g, int col0, int tid
         cc.dx[i] = g.sdx[sidx];
       }
       cc.off[i] = ch;
-    } else if (MODE == MODE_TN) {
+    } else if (MODE == MODE_TN || MODE == MODE_TNP) {
       cc.off[i] = c;
     } else if (MODE == MODE_NT) {
       cc.off[i] = (int64_t)c * g.L;
@@ -175,7 +178,7 @@ __device__ __forceinline__ void load_panel(const GramGeom& g, int64_t k0, int ti
     stage_coord<MODE, VEC, CFG>(tid + 256 * i, krow, col);
     bool valid = cc.ok[i];
     const float* p = g.x;
-    if (MODE == MODE_TN) {
+    if (MODE == MODE_TN || MODE == MODE_TNP) {
       const int64_t k = k0 + krow;
       valid = valid && (k < g.K);
       p = g.x + k * g.ldx + cc.off[i];
@@ -293,7 +296,7 @@ __device__ __forceinline__ void gram_body(const GramGeom& g, float* __restrict__
   using C = Cfg<CFG>;
   constexpr int PANEL = C::BK * C::LDP;
   constexpr int TW = C::TW;
-  constexpr int NP = (C::SMALL && MODE != MODE_XCORR) ? 1 : 2;
+  constexpr int NP = (C::SMALL && MODE != MODE_XCORR && MODE != MODE_TNP) ? 1 : 2;
 
   f32x16 acc[TW][TW];
 #pragma unroll
@@ -365,17 +368,32 @@ __device__ __forceinline__ void gram_body(const GramGeom& g, float* __restrict__
 
   if (Cdirect != nullptr) {
     // single split, upper-only accumulation: C += alpha * tile straight from the accumulators
-    // (32 consecutive columns per lane group = 128-byte segments); no slab, no reduce launch
+    // (32 consecutive columns per lane group = 128-byte segments); no slab, no reduce launch.
+    // Two phases per 32x32 sub-tile -- 16 independent loads, then 16 stores: written as `C[i] += v` in one loop the
+    // compiler must assume the store aliases the next load and serialises 16 memory round trips.
+    const int ldc = MODE == MODE_TNP ? g.ldc : g.n;
+    const int row0 = (MODE == MODE_TNP ? 0 : colA) + wm * C::WT + 4 * hi;  // TNP: tile-local rows in a compact block
+    const int col0 = (MODE == MODE_TNP ? 0 : colB) + wn * C::WT + lo;
 #pragma unroll
     for (int tm = 0; tm < TW; ++tm)
 #pragma unroll
-      for (int tn = 0; tn < TW; ++tn)
+      for (int tn = 0; tn < TW; ++tn) {
+        float* base = Cdirect + (int64_t)(row0 + tm * 32) * ldc + col0 + tn * 32;
+        const int col = col0 + tn * 32;
+        float old[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = colA + wm * C::WT + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          const int col = colB + wn * C::WT + tn * 32 + lo;
-          if ((FULL || (row < g.n && col < g.n))) Cdirect[(int64_t)row * g.n + col] += alpha * acc[tm][tn][r];
+          const int dr = (r & 3) + 8 * (r >> 2);
+          const bool ok = FULL || MODE == MODE_TNP || (row0 + tm * 32 + dr < g.n && col < g.n);
+          old[r] = ok ? base[(int64_t)dr * ldc] : 0.f;
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dr = (r & 3) + 8 * (r >> 2);
+          const bool ok = FULL || MODE == MODE_TNP || (row0 + tm * 32 + dr < g.n && col < g.n);
+          if (ok) base[(int64_t)dr * ldc] = old[r] + alpha * acc[tm][tn][r];
+        }
+      }
     return;
   }
   // epilogue: partial tile -> slab
@@ -407,7 +425,15 @@ __global__ __launch_bounds__(256) void gram_kernel(GramGeom g, float* __restrict
   const int lo = lane & 31, hi = lane >> 5;
   constexpr bool RECT = (MODE == MODE_XCORR);
   int bi, bj, split, pidx;
-  if (RECT) {  // all (row tile, column tile) pairs of the rectangular output; nbt = column tiles
+  int tnp_colA = 0, tnp_colB = 0, tnp_out = 0;
+  if (MODE == MODE_TNP) {  // tile table: arbitrary column windows of X, output into a compact block
+    tnp_colA = g.tiles[3 * blockIdx.x];
+    tnp_colB = g.tiles[3 * blockIdx.x + 1];
+    tnp_out = g.tiles[3 * blockIdx.x + 2];
+    bi = 0, bj = 1;  // (never a diagonal tile: both panels are loaded)
+    split = blockIdx.y;
+    pidx = blockIdx.x;
+  } else if (RECT) {  // all (row tile, column tile) pairs of the rectangular output; nbt = column tiles
     bi = blockIdx.x / nbt;
     bj = blockIdx.x - bi * nbt;
     split = blockIdx.y;
@@ -421,8 +447,8 @@ __global__ __launch_bounds__(256) void gram_kernel(GramGeom g, float* __restrict
     split = blockIdx.y;
     pidx = blockIdx.x;
   }
-  const bool diag = !RECT && (C::SMALL || (bi == bj));
-  const int colA = bi * C::T, colB = bj * C::T;
+  const bool diag = !RECT && MODE != MODE_TNP && (C::SMALL || (bi == bj));
+  const int colA = MODE == MODE_TNP ? tnp_colA : bi * C::T, colB = MODE == MODE_TNP ? tnp_colB : bj * C::T;
   const int wm = wave >> 1, wn = wave & 1;
 
   // number of active 32x32 sub-tiles of this wave along each dim (wave-uniform scalars)
@@ -439,6 +465,7 @@ __global__ __launch_bounds__(256) void gram_kernel(GramGeom g, float* __restrict
   const int c_end = min(my_chunks, c_begin + chunks_per_split);
   float* slab = slabs + (((int64_t)reg * gridDim.y + split) * npairs + pidx) * (C::T * C::T);
 
+  if (MODE == MODE_TNP) Cdirect += tnp_out;
   // FULL = the wave's whole WT x WT patch lies inside the matrix: branch-free MFMA loop and unguarded direct
   // epilogue.  (am == TW alone is NOT enough: am counts partially covered 32x32 sub-tiles too, and an unguarded
   // `C[row][col] += 0` on the rows / columns beyond n is an out-of-bounds read-modify-write.)
@@ -818,6 +845,69 @@ __global__ __launch_bounds__(256) void pixgram_assemble_kernel(const float* __re
   }
 }
 
+// ---- banded pixel-pair form of the 3x3 / stride 1 / padding 1 conv A factor (any map size, Cin % 64 == 0) ----------
+// The same linearity as above, restricted to the pixel pairs the 3x3 window can see: for every pixel q and every
+// shift D of the half plane {(0,0),(0,1),(0,2),(1,-2..2),(2,-2..2)} with q+D inside the map, the Cin x Cin block
+//   Blk[q, D] += sum_b x[b, q, :]^T x[b, q+D, :]
+// is accumulated over the whole fit (MODE_TNP: the TN loader on the flattened NHWC images, one workgroup per
+// T x T tile of a block, K = batch rows, read-modify-write straight from the accumulators), and
+//   A[(d,ci),(e,cj)] = sum_{p : p+d, p+e in the map} Blk[p+d, e-d][ci, cj]      (transposed block for e-d outside
+// the half plane) is assembled once per fit.  13 C^2 L multiply-adds per sample like the shift-correlation form, but no
+// boundary strips, no split-K slabs and no per-minibatch assembly.
+static const signed char kHalfDy[13] = {0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2};
+static const signed char kHalfDx[13] = {0, 1, 2, -2, -1, 0, 1, 2, -2, -1, 0, 1, 2};
+
+// One thread per (shift h, ci, cj): every block element is read exactly once; up to nine (d, e) patch-offset pairs
+// share the shift D = e - d and differ only in which pixels q = p + d they may use (p itself must be in the map).
+__global__ __launch_bounds__(256) void pixpair_assemble_kernel(const float* __restrict__ blocks,
+                                                               const int* __restrict__ slots, int H, int W, int Cin,
+                                                               float alpha, float* __restrict__ A) {
+  const int n = 9 * Cin;
+  const int64_t bsz = (int64_t)Cin * Cin;
+  const int64_t total = 13 * bsz;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int h = (int)(idx / bsz);
+    const int64_t inner = idx - (int64_t)h * bsz;
+    const int ci = (int)(inner / Cin), cj = (int)(inner - (int64_t)ci * Cin);
+    const int Dy = h < 3 ? 0 : (h < 8 ? 1 : 2);
+    const int Dx = h < 3 ? h : (h < 8 ? h - 5 : h - 10);
+    // patch offsets d = (dy, dx) with e = d + D still inside {-1,0,1}^2
+    const int dy_lo = -1, dy_hi = 1 - Dy;
+    const int dx_lo = Dx < 0 ? -1 - Dx : -1, dx_hi = Dx > 0 ? 1 - Dx : 1;
+    float acc[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) acc[a][b] = 0.f;
+    for (int qy = 0; qy < H; ++qy)
+      for (int qx = 0; qx < W; ++qx) {
+        const int slot = slots[(qy * W + qx) * 13 + h];
+        if (slot < 0) continue;
+        const float v = blocks[(int64_t)slot * bsz + inner];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b = 0; b < 3; ++b) {
+            const int dy = a - 1, dx = b - 1;  // p = q - d has to be a pixel of the map
+            if (dy >= dy_lo && dy <= dy_hi && dx >= dx_lo && dx <= dx_hi && qy - dy >= 0 && qy - dy < H && qx - dx >= 0 &&
+                qx - dx < W)
+              acc[a][b] += v;
+          }
+      }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const int dy = a - 1, dx = b - 1;
+        if (!(dy >= dy_lo && dy <= dy_hi && dx >= dx_lo && dx <= dx_hi)) continue;
+        const int d = a * 3 + b, e = (dy + Dy + 1) * 3 + (dx + Dx + 1);
+        const float v = alpha * acc[a][b];
+        A[(int64_t)(d * Cin + ci) * n + e * Cin + cj] += v;
+        if (h != 0) A[(int64_t)(e * Cin + cj) * n + d * Cin + ci] += v;  // the mirrored block (shift -D)
+      }
+  }
+}
+
 struct ShiftCorrPlan {
   size_t off_Rf, off_strips, off_pix, off_ws, ws_each, total;
 };
@@ -995,6 +1085,93 @@ extern "C" int lk_permute_sym_f32(const float* src, int64_t Cin, int64_t KK, flo
   hipLaunchKernelGGL(permute_sym_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, (int)Cin,
                      (int)KK, dst, accumulate);
   return check_launch("permute_sym_kernel");
+}
+
+extern "C" int lk_conv3x3_pixpair_plan(int64_t H, int64_t W, int64_t Cin, int64_t* tile, int64_t* n_tiles,
+                                       int64_t* n_blocks) {
+  LK_REQUIRE(H >= 1 && W >= 1 && Cin >= 64 && Cin % 64 == 0 && tile && n_tiles && n_blocks,
+             "lk_conv3x3_pixpair_plan: needs Cin % 64 == 0");
+  int64_t nb = 0;
+  for (int64_t y = 0; y < H; ++y)
+    for (int64_t x = 0; x < W; ++x)
+      for (int h = 0; h < 13; ++h) {
+        const int64_t y2 = y + kHalfDy[h], x2 = x + kHalfDx[h];
+        nb += (y2 >= 0 && y2 < H && x2 >= 0 && x2 < W);
+      }
+  const int64_t T = Cin % 128 == 0 ? 128 : 64, tpp = Cin / T;
+  LK_REQUIRE(nb * Cin * Cin < (1ll << 31) && H * W * Cin < (1ll << 31), "lk_conv3x3_pixpair_plan: problem too large");
+  *tile = T;
+  *n_blocks = nb;
+  *n_tiles = nb * tpp * tpp;
+  return LK_OK;
+}
+
+extern "C" int lk_conv3x3_pixpair_tables(int64_t H, int64_t W, int64_t Cin, int32_t* tiles, int32_t* slots) {
+  int64_t T, nt, nb;
+  if (int rc = lk_conv3x3_pixpair_plan(H, W, Cin, &T, &nt, &nb)) return rc;
+  LK_REQUIRE(tiles && slots, "lk_conv3x3_pixpair_tables: null table");
+  const int64_t tpp = Cin / T;
+  int64_t slot = 0, k = 0;
+  for (int64_t y = 0; y < H; ++y)
+    for (int64_t x = 0; x < W; ++x)
+      for (int h = 0; h < 13; ++h) {
+        const int64_t q = y * W + x, y2 = y + kHalfDy[h], x2 = x + kHalfDx[h];
+        if (!(y2 >= 0 && y2 < H && x2 >= 0 && x2 < W)) {
+          slots[q * 13 + h] = -1;
+          continue;
+        }
+        const int64_t q2 = y2 * W + x2;
+        slots[q * 13 + h] = (int32_t)slot;
+        for (int64_t ta = 0; ta < tpp; ++ta)
+          for (int64_t tb = 0; tb < tpp; ++tb) {
+            tiles[3 * k] = (int32_t)(q * Cin + ta * T);
+            tiles[3 * k + 1] = (int32_t)(q2 * Cin + tb * T);
+            tiles[3 * k + 2] = (int32_t)(slot * Cin * Cin + ta * T * Cin + tb * T);
+            ++k;
+          }
+        ++slot;
+      }
+  return LK_OK;
+}
+
+extern "C" int lk_conv3x3_pixpair_accumulate_f32(const float* x, int64_t B, int64_t H, int64_t W, int64_t Cin, float alpha,
+                                                 float* blocks, const int32_t* tiles_dev, int64_t n_tiles, void* stream) {
+  LK_REQUIRE(x && blocks && tiles_dev && B >= 0 && n_tiles >= 0, "lk_conv3x3_pixpair_accumulate_f32: bad arguments");
+  int64_t T, nt, nb;
+  if (int rc = lk_conv3x3_pixpair_plan(H, W, Cin, &T, &nt, &nb)) return rc;
+  LK_REQUIRE(nt == n_tiles, "lk_conv3x3_pixpair_accumulate_f32: table does not match the geometry");
+  LK_REQUIRE(aligned16(x) && n_tiles < (1ll << 31), "lk_conv3x3_pixpair_accumulate_f32: unaligned input / too many tiles");
+  if (B == 0 || n_tiles == 0) return LK_OK;
+  GramGeom g{};
+  g.x = x; g.K = B; g.n = (int)(H * W * Cin); g.ldx = H * W * Cin;
+  g.tiles = tiles_dev; g.ldc = (int)Cin;
+  const int cfg = T == 64 ? CFG_SMALL : CFG_BIG;
+  const int nchunks = (int)((B + cfg_bk(cfg) - 1) / cfg_bk(cfg));
+  const size_t lds = cfg_lds_bytes(cfg, true);
+  dim3 grid((unsigned)n_tiles, 1), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (cfg == CFG_SMALL) {
+    if (!allow_big_lds((const void*)gram_kernel<MODE_TNP, 4, CFG_SMALL>, lds)) return LK_ELAUNCH;
+    hipLaunchKernelGGL((gram_kernel<MODE_TNP, 4, CFG_SMALL>), grid, block, lds, st, g, (float*)nullptr, 1, (int)n_tiles, nchunks,
+                       nchunks, blocks, alpha);
+  } else {
+    if (!allow_big_lds((const void*)gram_kernel<MODE_TNP, 4, CFG_BIG>, lds)) return LK_ELAUNCH;
+    hipLaunchKernelGGL((gram_kernel<MODE_TNP, 4, CFG_BIG>), grid, block, lds, st, g, (float*)nullptr, 1, (int)n_tiles, nchunks,
+                       nchunks, blocks, alpha);
+  }
+  return check_launch("gram_kernel<TNP>");
+}
+
+extern "C" int lk_conv3x3_pixpair_assemble_f32(const float* blocks, const int32_t* slots_dev, int64_t H, int64_t W,
+                                               int64_t Cin, float alpha, float* A, void* stream) {
+  LK_REQUIRE(blocks && slots_dev && A && H >= 1 && W >= 1 && Cin >= 1 && 9 * Cin < (1ll << 24),
+             "lk_conv3x3_pixpair_assemble_f32: bad arguments");
+  const int64_t total = 13 * Cin * Cin;
+  int64_t nblk = (total + 255) / 256;
+  if (nblk > 16384) nblk = 16384;
+  hipLaunchKernelGGL(pixpair_assemble_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, blocks, slots_dev,
+                     (int)H, (int)W, (int)Cin, alpha, A);
+  return check_launch("pixpair_assemble_kernel");
 }
 
 extern "C" int lk_conv3x3_pixgram_assemble_f32(const float* Cp, int64_t H, int64_t W, int64_t Cin, float alpha, float* A,

@@ -165,6 +165,50 @@ class EmulatedKernels:
                 A_native[d * Cin:(d + 1) * Cin, e * Cin:(e + 1) * Cin] += alpha * blk
         return A_native
 
+    _HALF = [(0, 0), (0, 1), (0, 2)] + [(1, dx) for dx in range(-2, 3)] + [(2, dx) for dx in range(-2, 3)]
+
+    def pixpair_plan(self, H, W, Cin, dev):
+        if Cin < 8 or Cin % 8:  # (the product needs Cin % 64 == 0; the emulation only mirrors the structure)
+            return None
+        slots, n = {}, 0
+        for y in range(H):
+            for x in range(W):
+                for h, (dy, dx) in enumerate(self._HALF):
+                    if 0 <= y + dy < H and 0 <= x + dx < W:
+                        slots[(y * W + x, h)] = n
+                        n += 1
+        return (n, None, slots)
+
+    def pixpair_accumulate(self, x, alpha, blocks, plan):
+        B, Cin, H, W = x.shape
+        xh = x.permute(0, 2, 3, 1).reshape(B, H * W, Cin)
+        blk = blocks.view(plan[0], Cin, Cin)
+        for (q, h), slot in plan[2].items():
+            dy, dx = self._HALF[h]
+            q2 = q + dy * W + dx
+            blk[slot] += alpha * xh[:, q, :].T @ xh[:, q2, :]
+        return blocks
+
+    def pixpair_assemble(self, blocks, plan, H, W, Cin, alpha, A_native):
+        blk = blocks.view(plan[0], Cin, Cin)
+        for d in range(9):
+            dy, dx = d // 3 - 1, d % 3 - 1
+            for e in range(9):
+                ey, ex = e // 3 - 1, e % 3 - 1
+                Dy, Dx = ey - dy, ex - dx
+                flip = Dy < 0 or (Dy == 0 and Dx < 0)
+                h = self._HALF.index((-Dy, -Dx) if flip else (Dy, Dx))
+                acc = torch.zeros(Cin, Cin, dtype=blocks.dtype)
+                for py in range(H):
+                    for px in range(W):
+                        ay, ax, by, bx = py + dy, px + dx, py + ey, px + ex
+                        if 0 <= ay < H and 0 <= ax < W and 0 <= by < H and 0 <= bx < W:
+                            q = (by * W + bx) if flip else (ay * W + ax)
+                            b_ = blk[plan[2][(q, h)]]
+                            acc += b_.T if flip else b_
+                A_native[d * Cin:(d + 1) * Cin, e * Cin:(e + 1) * Cin] += alpha * acc
+        return A_native
+
     def syevj_batched(self, mats, clamp=True, max_sweeps=0, streams=None):
         return [self.syevj(A, clamp, max_sweeps) for A in mats]
 

@@ -564,3 +564,24 @@ def test_conv3x3_pixel_pair_form(K, B, Cin, H, W):
     nat = K.pixgram_assemble(Cp, H, W, Cin, 1.0, torch.zeros(n, n, device=DEV))
     got = K.permute_native_to_unfold(nat, Cin, 9, torch.zeros(n, n, device=DEV))
     assert_close(got, want, what="pixel-pair form")
+
+
+@pytest.mark.parametrize("B,Cin,H,W", [(3, 64, 4, 4), (2, 64, 5, 7), (5, 128, 3, 3), (2, 256, 2, 5), (3, 64, 1, 1), (2, 128, 8, 8),
+                                        (130, 64, 3, 2)])
+def test_conv3x3_banded_pixel_pair_form(K, B, Cin, H, W):
+    """Banded pixel-pair blocks accumulated over TWO minibatches, assembled once == patch Gram of both."""
+    if DEV == "cpu":
+        Cin = 8  # the emulation mirrors the structure at a small width
+    x1, x2 = rnd(B, Cin, H, W, seed=B + Cin + H), rnd(B, Cin, H, W, seed=B + Cin + H + 1)
+    n = 9 * Cin
+    want = torch.zeros(n, n, dtype=torch.float64)
+    for x in (x1, x2):
+        EMU.gram_conv(x, 3, 1, 1, 1, 0.5, want)
+    plan = K.pixpair_plan(H, W, Cin, torch.device(DEV))
+    assert plan is not None
+    blocks = torch.zeros(plan[0] * Cin * Cin, device=DEV)
+    for x in (x1, x2):
+        K.pixpair_accumulate(x.float().to(DEV), 0.5, blocks, plan)
+    nat = K.pixpair_assemble(blocks, plan, H, W, Cin, 1.0, torch.zeros(n, n, device=DEV))
+    got = K.permute_native_to_unfold(nat, Cin, 9, torch.zeros(n, n, device=DEV))
+    assert_close(got, want, what="banded pixel-pair form")

@@ -230,3 +230,34 @@ def test_inplace_model_equals_its_out_of_place_twin():
     for other in results[1:]:
         for a, b in zip(results[0], other):
             assert (a - b).abs().max() <= 1e-12 * (1 + a.abs().max())
+
+
+def test_fused_accumulator_pixel_pair_paths_equal_literal_loop():
+    """KronAccumulator keeps 3x3/s1/p1 conv A factors in pixel-pair form over the fit (banded blocks / dense small
+    maps) and assembles once: same factors as summing per-minibatch kron() results."""
+    from laplace_amd import _lib
+    from laplace_amd.backend import HipGGN
+    from tests.emulated_kernels import EmulatedKernels
+
+    prev = _lib.set_kernels_for_testing(EmulatedKernels())
+    try:
+        torch.manual_seed(2)
+        model = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.ReLU(), nn.Conv2d(8, 8, 3, padding=1), nn.ReLU(),
+                              nn.Conv2d(8, 4, 3, padding=1), nn.Flatten(), nn.Linear(4 * 6 * 6, 3)).eval()
+        b = HipGGN(model, "classification")
+        acc = b.kron_accumulator(40)
+        H = None
+        for seed in (1, 2, 3):
+            g = torch.Generator().manual_seed(seed)
+            X, y = torch.randn(4, 3, 6, 6, generator=g), torch.randint(0, 3, (4,), generator=g)
+            acc.add_batch(X, y)
+            _, Hb = b.kron(X, y, N=40)
+            H = Hb if H is None else H + Hb
+        kinds = sorted(geo[0] for geo, _ in acc._pix.values())
+        assert kinds == ["pair", "pair"], kinds  # the two 8-channel convs; the 3-channel stem is not eligible
+        _, Hf = acc.finalize()
+        for F_, G_ in zip(Hf.kfacs, H.kfacs):
+            for a, c in zip(F_, G_):
+                assert torch.allclose(a, c, rtol=1e-4, atol=1e-7)
+    finally:
+        _lib.set_kernels_for_testing(prev)
