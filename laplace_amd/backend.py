@@ -446,7 +446,10 @@ class KronAccumulator:
         """allocate the pixel-pair accumulators on the CALLING stream (they are consumed there at the end of the fit)"""
         for idx, tap in enumerate(tape.taps):
             if idx in self._pix:
-                continue
+                old = self._pix[idx][0]
+                if (old[1], old[2]) == tuple(int(v) for v in tap.a.shape[-2:]):
+                    continue
+                self._flush_pixgrams(only=idx)  # the input size changed within the fit: fold what there is, start anew
             geo = self._pix_geometry(tap)
             if geo is None:
                 continue
@@ -457,15 +460,15 @@ class KronAccumulator:
                 buf = torch.zeros(npix, npix, dtype=torch.float32, device=tap.a.device)
             self._pix[idx] = (geo, buf)
 
-    def _flush_pixgrams(self):
+    def _flush_pixgrams(self, only=None):
         """fold the pixel-pair accumulators into the (native-order) A factors; idempotent"""
         K = get_kernels()
-        for idx, (geo, buf) in self._pix.items():
+        for idx in ([only] if only is not None else list(self._pix)):
+            geo, buf = self._pix.pop(idx)
             if geo[0] == "pair":
                 K.pixpair_assemble(buf, geo[4], geo[1], geo[2], geo[3], 1.0, self.factors[idx][1])
             else:
                 K.pixgram_assemble(buf, geo[1], geo[2], geo[3], 1.0, self.factors[idx][1])
-        self._pix = {}
 
     def add_batch(self, x, y):
         b = self.backend

@@ -255,6 +255,21 @@ def test_fused_accumulator_pixel_pair_paths_equal_literal_loop():
             H = Hb if H is None else H + Hb
         kinds = sorted(geo[0] for geo, _ in acc._pix.values())
         assert kinds == ["pair", "pair"], kinds  # the two 8-channel convs; the 3-channel stem is not eligible
+        # a minibatch of a different spatial size in the same fit (fully convolutional body): accumulators are
+        # folded and restarted for the new geometry
+        model2 = nn.Sequential(*list(model.children())[:5], nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(4, 3)).eval()
+        b2 = HipGGN(model2, "classification")
+        acc2, H2 = b2.kron_accumulator(40), None
+        for seed, hw in ((1, 6), (2, 5), (3, 6)):
+            g = torch.Generator().manual_seed(seed)
+            X, y = torch.randn(4, 3, hw, hw, generator=g), torch.randint(0, 3, (4,), generator=g)
+            acc2.add_batch(X, y)
+            _, Hb = b2.kron(X, y, N=40)
+            H2 = Hb if H2 is None else H2 + Hb
+        _, Hf2 = acc2.finalize()
+        for F_, G_ in zip(Hf2.kfacs, H2.kfacs):
+            for a, c in zip(F_, G_):
+                assert torch.allclose(a, c, rtol=1e-4, atol=1e-7)
         _, Hf = acc.finalize()
         for F_, G_ in zip(Hf.kfacs, H.kfacs):
             for a, c in zip(F_, G_):
