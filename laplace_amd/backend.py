@@ -296,30 +296,24 @@ class _HipCurvatureMixin:
 
     # ---- shared implementations ------------------------------------------------------------------
     def _kron_impl(self, x, y, N, seeds_fn, hess_scale_fn, kfac_approx):
+        """One minibatch's ``(loss, Kron)`` — what the reference's literal loop ``self.H += backend.kron(X, y, N)``
+        (laplace/baselaplace.py:969-985) consumes.  Same kernel schedule as a one-batch :class:`KronAccumulator`
+        (A factors on a side stream under the reverse sweep, G factors streamed layer by layer), followed by the
+        per-batch symmetrise / permute into the reference's layout; the pixel-pair forms, which pay off only when
+        their assembly is amortised over a whole fit, are left to :meth:`kron_accumulator`."""
         if kfac_approx not in ("expand", "reduce"):
             raise ValueError(f"kfac_approx must be 'expand' or 'reduce', got {kfac_approx!r}")
-        f, tape, grad_fn = self._forward(x)
-        if tape.uncovered:
-            raise NotImplementedError(
-                "KFAC supports nn.Linear / nn.Conv2d parameters only (as the reference, docs/index.md:364-366); "
-                "freeze the others (requires_grad=False)"
-            )
-        loss = torch.zeros(1, dtype=torch.float32, device=f.device)
-        seeds, hs = seeds_fn(f, y, loss)
-        grads = grad_fn(seeds, stack=False)
-        fac = float(self.factor)
-        rt = math.sqrt(fac)
-        kfacs = []
-        for tap, g in zip(tape.taps, grads):
-            G, A = self._layer_factors(tap, g, N, rt * hs, rt, kfac_approx)
-            if G.numel() == 1 and A.numel() == 1 and not tap.has_bias:
-                kfacs.append([G * A])  # curvlinops.py:68-71 collapses 1x1 (x) 1x1
-            else:
-                kfacs.append([G, A])
-            if tap.has_bias:
-                kfacs.append([G * rt])  # block scaled by `factor`, i.e. sqrt(factor) more than G
-        tape.release()
-        return loss[0], HipKron(kfacs)
+        acc = KronAccumulator(self, N, kfac_approx, overlap=True)
+        acc.use_pixgram = False
+        try:
+            acc.add_batch(x, y)
+        except NotImplementedError as e:
+            if "KFAC supports" in str(e):
+                raise NotImplementedError(
+                    "KFAC supports nn.Linear / nn.Conv2d parameters only (as the reference, docs/index.md:364-366); "
+                    "freeze the others (requires_grad=False)") from e
+            raise
+        return acc.finalize()
 
     def _diag_impl(self, x, y, seeds_fn, alpha):
         K = get_kernels()
@@ -483,8 +477,11 @@ class KronAccumulator:
         # overlap the C reverse passes (whose late, small-spatial conv kernels do not fill the chip).
         side = None
         if self.overlap and f.is_cuda:
-            if self._side is None:
-                self._side = torch.cuda.Stream(f.device)
+            if self._side is None:  # one side stream per backend object, shared by all its accumulators
+                cache = b.__dict__.setdefault("_side_streams", {})
+                if f.device not in cache:
+                    cache[f.device] = torch.cuda.Stream(f.device)
+                self._side = cache[f.device]
             side = self._side
             main = torch.cuda.current_stream(f.device)
             side.wait_stream(main)
