@@ -6,5 +6,13 @@ from laplace_amd.backend import HipEF, HipGGN
 from laplace_amd.kron import HipKron, HipKronDecomposed
 from laplace_amd.refapi import HAVE_REFERENCE
 
-__all__ = ["HipGGN", "HipEF", "HipKron", "HipKronDecomposed", "HAVE_REFERENCE"]
+
+def fit_kron(la, train_loader, process_group=None, distributed=None):
+    """Fused ``fit`` for the reference's ``KronLaplace`` objects — see :func:`laplace_amd.laplace.fit_kron`."""
+    from laplace_amd.laplace import fit_kron as _fit
+
+    return _fit(la, train_loader, process_group=process_group, distributed=distributed)
+
+
+__all__ = ["HipGGN", "HipEF", "HipKron", "HipKronDecomposed", "HAVE_REFERENCE", "fit_kron"]
 __version__ = "0.1.0"

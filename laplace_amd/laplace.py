@@ -652,6 +652,59 @@ class HipFullLaplace(_HipLaplace):
         return f_mu.detach(), f_var.detach()
 
 
+def fit_kron(la, train_loader, process_group=None, distributed: bool | None = None):
+    """Fused ``fit`` for the REFERENCE's own ``KronLaplace`` / ``KronLLLaplace`` objects built with
+    ``backend=HipGGN`` (or ``HipEF``)::
+
+        la = Laplace(model, "classification", "all", "kron", backend=HipGGN)
+        laplace_amd.fit_kron(la, train_loader)        # instead of la.fit(train_loader)
+
+    Same result as ``la.fit(train_loader)`` with ``override=True`` (laplace/baselaplace.py:904-987,1785-1809), but the
+    minibatches go through :class:`KronAccumulator` — in-place accumulation, pixel-pair A factors assembled once,
+    one symmetrise / permute per fit — instead of one ``Kron`` per minibatch, and on several ranks
+    (``torch.distributed`` initialised) the factors are summed with one all-reduce and decomposed sharded."""
+    from collections.abc import MutableMapping
+
+    la.model.eval()
+    if hasattr(la.model, "find_last_layer") and getattr(la.model, "last_layer", None) is None:
+        # last-layer flavours discover the head on the first batch (laplace/lllaplace.py:189-203)
+        la.data = next(iter(train_loader))
+        la._find_last_layer(la.data)
+        la.params = [p for p in la.model.last_layer.parameters() if p.requires_grad]
+        la.n_params = len(parameters_to_vector(la.model.last_layer.parameters()))
+        la.n_layers = len(list(la.model.last_layer.parameters()))
+        la.prior_precision = la._prior_precision
+        la.prior_mean = la._prior_mean
+    backend = la.backend  # (instantiated lazily by the reference; for last-layer flavours it needs the head)
+    if not hasattr(backend, "kron_accumulator"):
+        raise TypeError("fit_kron needs a laplace_amd backend (HipGGN / HipEF)")
+    la.mean = parameters_to_vector(la.params).detach()
+    N = len(train_loader.dataset)
+    acc = backend.kron_accumulator(N, **getattr(la, "_asdl_fisher_kwargs", {}))
+    first = True
+    for data in train_loader:
+        if isinstance(data, MutableMapping):
+            X, y = data, data[la.dict_key_y].to(la._device)
+        else:
+            X, y = data
+            X, y = X.to(la._device), y.to(la._device)
+        if first:
+            with torch.no_grad():
+                out = la.model(X if isinstance(X, MutableMapping) else X[:1])
+            la.n_outputs = out.shape[-1]
+            setattr(la.model, "output_size", la.n_outputs)
+            first = False
+        acc.add_batch(X, y)
+    if distributed is None:
+        distributed = dist.is_available() and dist.is_initialized()
+    if distributed:
+        allreduce_curvature(acc.tensors(), group=process_group)
+    la.loss, la.H_facs = acc.finalize()
+    la.n_data = N
+    la.H = la.H_facs.decompose(damping=la.damping, distributed=bool(distributed), process_group=process_group)
+    return la
+
+
 _FLAVOURS = {"kron": HipKronLaplace, "diag": HipDiagLaplace, "full": HipFullLaplace}
 
 

@@ -58,3 +58,31 @@ def test_reference_laplace_with_hip_backend(ref, name, lik, sow, hs):
     assert rel(f_mu, g[f"{tag}.f_mu"]) < 1e-4
     assert rel(f_var, g[f"{tag}.f_var"]) < 1e-4
     assert rel(la.log_marginal_likelihood(), g[f"{tag}.marglik"]) < 1e-4
+
+
+@pytest.mark.parametrize("name", ["mlp", "conv", "resnetish"])
+@pytest.mark.parametrize("lik", ["classification", "regression"])
+@pytest.mark.parametrize("sow", ["all", "last_layer"])
+def test_fit_kron_helper_equals_reference_fit(ref, name, lik, sow):
+    """`laplace_amd.fit_kron(la, loader)` on the reference's own KronLaplace object == `la.fit(loader)` (goldens)."""
+    from laplace import Laplace
+
+    import laplace_amd
+    from laplace_amd import HipGGN, HipKron, HipKronDecomposed
+    from oracle.make_golden import PRIOR_PREC, SIGMA_NOISE
+
+    g = load_golden(name, lik)
+    model, X, y = golden_model(name, g, dtype=torch.float32)
+    sig = SIGMA_NOISE if lik == "regression" else 1.0
+    la = Laplace(model, lik, subset_of_weights=sow, hessian_structure="kron", prior_precision=PRIOR_PREC,
+                 sigma_noise=sig, backend=HipGGN)
+    laplace_amd.fit_kron(la, DataLoader(TensorDataset(X, y), batch_size=5))
+    tag = f"la.{sow}.kron"
+    assert isinstance(la.H_facs, HipKron) and isinstance(la.H, HipKronDecomposed)
+    for F_, G_ in zip(la.H_facs.kfacs, golden_kfacs(g, f"{tag}.H")):
+        for a, w in zip(F_, G_):
+            assert rel(a, w) < 1e-4
+    assert rel(la.loss, g[f"{tag}.loss"]) < 1e-4
+    f_mu, f_var = la._glm_predictive_distribution(X)
+    assert rel(f_var, g[f"{tag}.f_var"]) < 1e-4
+    assert rel(la.log_marginal_likelihood(), g[f"{tag}.marglik"]) < 1e-4
