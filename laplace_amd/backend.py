@@ -251,19 +251,6 @@ class _HipCurvatureMixin:
             K.gram_tn(g.reshape(S * B, Do, L).sum(2).contiguous(), alpha_g, G, upper_only=fused)
         return G
 
-    def _layer_factors(self, tap, g, N, alpha_g, alpha_a_scale, kfac_approx, out=None, fused=False):
-        """(G, A) of one module.  ``out=(G, A)`` accumulates into existing buffers.  ``fused=True`` is the
-        accumulator mode: only the upper block triangle is updated and conv A factors stay in the
-        kernel-native (kh, kw, ci) column order — :class:`KronAccumulator` symmetrises / permutes once
-        at the end of the fit."""
-        do, di = self._factor_shapes(tap)
-        dev = tap.a.device
-        G, A = out if out is not None else (torch.zeros(do, do, dtype=torch.float32, device=dev),
-                                            torch.zeros(di, di, dtype=torch.float32, device=dev))
-        self._factor_A(tap, N, alpha_a_scale, kfac_approx, A, fused)
-        self._factor_G(tap, g, alpha_g, kfac_approx, G, fused)
-        return G, A
-
     def _layer_jacobian(self, tap, g, Js):
         """Writes this module's columns of ``Js[B, S, P]``; ``g`` is ``[S, B, ...]``."""
         K = get_kernels()
