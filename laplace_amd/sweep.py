@@ -43,6 +43,8 @@ class SeedBatchedSweep:
     _GENERIC_ACT_FN = {F.gelu, F.silu, F.leaky_relu, F.elu, F.softplus, F.hardtanh, F.relu6, F.mish, F.hardswish,
                        F.hardsigmoid, F.selu, F.celu, F.softsign, F.logsigmoid}
 
+    _POOL_FN = {F.max_pool2d, F.avg_pool2d, F.adaptive_avg_pool2d}
+
     @staticmethod
     def _with_derivative(fn, inp):
         """(fn(inp), d fn / d inp) for an element-wise ``fn``"""
@@ -83,11 +85,13 @@ class SeedBatchedSweep:
                 if isinstance(m, nn.Conv2d) and (m.groups != 1 or isinstance(m.padding, str) or m.padding_mode != "zeros"):
                     raise SweepUnsupported(f"{node.target}: unsupported convolution variant")
             elif node.op == "call_function":
-                if node.target not in (self._ELEMENTWISE_FN | self._GENERIC_ACT_FN
-                                       | {operator.add, torch.add, torch.flatten, operator.iadd}):
+                if node.target not in (self._ELEMENTWISE_FN | self._GENERIC_ACT_FN | self._POOL_FN
+                                       | {operator.add, torch.add, torch.flatten, operator.iadd, operator.getitem,
+                                          torch.mean}):
                     raise SweepUnsupported(f"no VJP rule for function {getattr(node.target, '__name__', node.target)}")
             elif node.op == "call_method":
-                if node.target not in ("view", "reshape", "flatten", "relu", "tanh", "sigmoid", "contiguous"):
+                if node.target not in ("view", "reshape", "flatten", "relu", "tanh", "sigmoid", "contiguous", "size",
+                                       "mean"):
                     raise SweepUnsupported(f"no VJP rule for method {node.target}")
             elif node.op == "get_attr":
                 raise SweepUnsupported("graph reads attributes directly")
@@ -135,8 +139,27 @@ class SeedBatchedSweep:
                     self.taps[node.target] = {"a": inp, "node": node}
                 env[node] = out
             elif node.op == "call_function":
-                args = [env[a] if isinstance(a, fx.Node) else a for a in node.args]
-                kwargs = {k: (env[v] if isinstance(v, fx.Node) else v) for k, v in node.kwargs.items()}
+                args = list(fx.node.map_arg(node.args, lambda n: env[n]))
+                kwargs = dict(fx.node.map_arg(node.kwargs, lambda n: env[n]))
+                if node.target is operator.getitem and torch.is_tensor(args[0]):
+                    raise SweepUnsupported("tensor indexing")
+                if node.target is F.max_pool2d:
+                    p = self._bind(node, ("kernel_size", "stride", "padding", "dilation", "ceil_mode", "return_indices"),
+                                   (None, None, 0, 1, False, False))
+                    if p["return_indices"]:
+                        raise SweepUnsupported("max_pool2d(return_indices=True)")
+                    out, idx = F.max_pool2d(args[0], p["kernel_size"], p["stride"], p["padding"], p["dilation"],
+                                            p["ceil_mode"], True)
+                    self.saved[node] = (idx, args[0].shape)
+                    env[node] = out
+                    continue
+                if node.target in (F.avg_pool2d, F.adaptive_avg_pool2d):
+                    self.saved[node] = args[0].shape
+                if node.target is torch.mean:
+                    dim = kwargs.get("dim", args[1] if len(args) > 1 else None)
+                    if not self._spatial_mean_dims(dim, args[0].dim()):
+                        raise SweepUnsupported("mean over dims other than the two spatial ones")
+                    self.saved[node] = (args[0].shape, bool(kwargs.get("keepdim", args[2] if len(args) > 2 else False)))
                 if node.target is operator.iadd:
                     out = args[0] + args[1]
                 elif node.target in self._GENERIC_ACT_FN:
@@ -153,8 +176,14 @@ class SeedBatchedSweep:
                 env[node] = out
             elif node.op == "call_method":
                 self_t = env[node.args[0]]
-                args = [env[a] if isinstance(a, fx.Node) else a for a in node.args[1:]]
-                out = getattr(self_t, node.target)(*args, **node.kwargs)
+                args = list(fx.node.map_arg(node.args[1:], lambda n: env[n]))
+                kwargs = dict(fx.node.map_arg(node.kwargs, lambda n: env[n]))
+                out = getattr(self_t, node.target)(*args, **kwargs)
+                if node.target == "mean":
+                    dim = kwargs.get("dim", args[0] if args else None)
+                    if not self._spatial_mean_dims(dim, self_t.dim()):
+                        raise SweepUnsupported("mean over dims other than the two spatial ones")
+                    self.saved[node] = (self_t.shape, bool(kwargs.get("keepdim", args[1] if len(args) > 1 else False)))
                 if node.target == "relu":
                     self.saved[node] = out > 0
                 elif node.target in ("tanh", "sigmoid"):
@@ -168,6 +197,45 @@ class SeedBatchedSweep:
         out = env[self.out_node]
         self.out_shape = tuple(out.shape[1:])
         return out
+
+    @staticmethod
+    def _bind(node, names, defaults):
+        """positional / keyword arguments of a functional call -> dict (input excluded)"""
+        vals = dict(zip(names, defaults))
+        for n, a in zip(names, node.args[1:]):
+            vals[n] = a
+        for k, v in node.kwargs.items():
+            if k in vals:
+                vals[k] = v
+        if any(isinstance(v, fx.Node) for v in vals.values()):
+            raise SweepUnsupported("data-dependent pooling arguments")
+        return vals
+
+    @staticmethod
+    def _pair2(v):
+        return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+
+    @staticmethod
+    def _avgpool_vjp(g, in_shape, kernel, stride, padding, SB):
+        k, st = SeedBatchedSweep._pair2(kernel), SeedBatchedSweep._pair2(kernel if stride in (None, []) else stride)
+        if SeedBatchedSweep._pair2(padding) != (0, 0) or k != st or in_shape[-2] % k[0] or in_shape[-1] % k[1]:
+            raise SweepUnsupported("AvgPool2d VJP implemented for non-overlapping, unpadded windows")
+        return g.repeat_interleave(k[0], -2).repeat_interleave(k[1], -1) / (k[0] * k[1])
+
+    @staticmethod
+    def _maxpool_vjp(g, idx, in_shape, S, B):
+        idx_s = idx.unsqueeze(0).expand(S, *idx.shape).reshape(S * B, *idx.shape[1:])
+        out = torch.zeros(S * B, in_shape[1], in_shape[2] * in_shape[3], dtype=g.dtype, device=g.device)
+        out.scatter_add_(2, idx_s.reshape(S * B, in_shape[1], -1), g.reshape(S * B, in_shape[1], -1))
+        return out.reshape(S * B, *in_shape[1:])
+
+    @staticmethod
+    def _spatial_mean_dims(dim, ndim):
+        """True if ``dim`` names exactly the two trailing (spatial) dims of an NCHW tensor"""
+        if dim is None or ndim != 4:
+            return False
+        dims = sorted(d % ndim for d in (dim if isinstance(dim, (tuple, list)) else (dim,)))
+        return dims == [2, 3]
 
     @staticmethod
     def _conv_input_grad(in_shape, m, g):
@@ -293,18 +361,10 @@ class SeedBatchedSweep:
                         raise SweepUnsupported("AdaptiveAvgPool2d VJP implemented for output size 1")
                     push(src, (g / (shp[-1] * shp[-2])).expand(S * B, *shp[1:]))
                 elif isinstance(m, nn.AvgPool2d):
-                    shp = self.saved[node]
-                    k = m.kernel_size if isinstance(m.kernel_size, tuple) else (m.kernel_size, m.kernel_size)
-                    st = m.stride if isinstance(m.stride, tuple) else (m.stride, m.stride)
-                    if m.padding not in (0, (0, 0)) or k != st or shp[-2] % k[0] or shp[-1] % k[1]:
-                        raise SweepUnsupported("AvgPool2d VJP implemented for non-overlapping, unpadded windows")
-                    push(src, g.repeat_interleave(k[0], -2).repeat_interleave(k[1], -1) / (k[0] * k[1]))
+                    push(src, self._avgpool_vjp(g, self.saved[node], m.kernel_size, m.stride, m.padding, S * B))
                 elif isinstance(m, nn.MaxPool2d):
                     idx, shp = self.saved[node]
-                    idx_s = idx.unsqueeze(0).expand(S, *idx.shape).reshape(S * B, *idx.shape[1:])
-                    out = torch.zeros(S * B, shp[1], shp[2] * shp[3], dtype=g.dtype, device=g.device)
-                    out.scatter_add_(2, idx_s.reshape(S * B, shp[1], -1), g.reshape(S * B, shp[1], -1))
-                    push(src, out.reshape(S * B, *shp[1:]))
+                    push(src, self._maxpool_vjp(g, idx, shp, S, B))
                 elif isinstance(m, nn.Sequential):
                     raise SweepUnsupported("nested Sequential was not inlined by the tracer")
             elif node.op == "call_function":
@@ -319,6 +379,21 @@ class SeedBatchedSweep:
                     push(dst, self._scale_mask(g, S, self._act_mult(t, self.saved[node]), scale, g2))
                 elif t is torch.flatten:
                     push(node.args[0], g.reshape((S * B,) + tuple(self.saved[node][1:])))
+                elif t is F.max_pool2d:
+                    idx, shp = self.saved[node]
+                    push(node.args[0], self._maxpool_vjp(g, idx, shp, S, B))
+                elif t is F.avg_pool2d:
+                    p = self._bind(node, ("kernel_size", "stride", "padding"), (None, None, 0))
+                    push(node.args[0], self._avgpool_vjp(g, self.saved[node], p["kernel_size"], p["stride"], p["padding"], S * B))
+                elif t is F.adaptive_avg_pool2d:
+                    shp = self.saved[node]
+                    if tuple(g.shape[-2:]) != (1, 1):
+                        raise SweepUnsupported("adaptive_avg_pool2d VJP implemented for output size 1")
+                    push(node.args[0], (g / (shp[-1] * shp[-2])).expand(S * B, *shp[1:]))
+                elif t is torch.mean:
+                    shp, keep = self.saved[node]
+                    gg = g if keep else g.reshape(S * B, shp[1], 1, 1)
+                    push(node.args[0], (gg / (shp[-1] * shp[-2])).expand(S * B, *shp[1:]))
             elif node.op == "call_method":
                 t = node.target
                 if t in ("relu", "tanh", "sigmoid"):
@@ -328,6 +403,10 @@ class SeedBatchedSweep:
                     push(node.args[0], g.reshape((S * B,) + tuple(self.saved[node][1:])))
                 elif t == "contiguous":
                     push(node.args[0], g)
+                elif t == "mean":
+                    shp, keep = self.saved[node]
+                    gg = g if keep else g.reshape(S * B, shp[1], 1, 1)
+                    push(node.args[0], (gg / (shp[-1] * shp[-2])).expand(S * B, *shp[1:]))
         if remaining:
             raise SweepUnsupported(f"no cotangent reached {sorted(remaining)}")
         return grads

@@ -76,10 +76,32 @@ class SmoothActs(nn.Module):
         return self.fc2(torch.nn.functional.softplus(self.act3(h), beta=2.0))
 
 
+class FunctionalStyle(nn.Module):
+    """the idioms of hand-written CNNs: functional pooling, `x.view(x.size(0), -1)`, spatial `mean`"""
+
+    def __init__(self):
+        super().__init__()
+        self.c1 = nn.Conv2d(3, 6, 3, padding=1)
+        self.c2 = nn.Conv2d(6, 8, 3, padding=1)
+        self.c3 = nn.Conv2d(8, 8, 3, padding=1)
+        self.fc1 = nn.Linear(8 * 2 * 2, 10)
+        self.fc2 = nn.Linear(10, 4)
+        self.fc3 = nn.Linear(8, 4)
+
+    def forward(self, x):
+        h = torch.nn.functional.max_pool2d(torch.relu(self.c1(x)), 2)
+        h = torch.nn.functional.avg_pool2d(torch.relu(self.c2(h)), kernel_size=2)
+        h = torch.tanh(self.c3(h))
+        a = torch.relu(self.fc1(h.view(h.size(0), -1)))
+        b = h.mean((2, 3)) + torch.mean(h, dim=[-1, -2]) + torch.nn.functional.adaptive_avg_pool2d(h, 1).flatten(1)
+        return self.fc2(a) + self.fc3(b)
+
+
 def _models():
     yield "resnet18", ResNet18(), (3, 16, 16), 10
     yield "torchvision_block", TorchvisionStyleBlock(), (3, 8, 8), 5
     yield "smooth_acts", SmoothActs(), (3, 8, 8), 4
+    yield "functional_style", FunctionalStyle(), (3, 8, 8), 4
     yield "lenet5", lenet5(), (3, 32, 32), 10
     yield "residual", Residual(), (3, 8, 8), 4
     for n in FIXTURES:
