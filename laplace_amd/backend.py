@@ -109,11 +109,13 @@ class _HipCurvatureMixin:
         for t in tape.taps:
             t.a = sweep.taps[t.name]["a"]
 
-        def grad_fn(seeds, stack=True, on_tap=None):
-            grads = sweep.backward(seeds.reshape(seeds.shape[0], seeds.shape[1], *sweep.out_shape), on_tap=on_tap)
+        def grad_fn(seeds, stack=True, on_tap=None, defer_bn_scale=False):
+            grads = sweep.backward(seeds.reshape(seeds.shape[0], seeds.shape[1], *sweep.out_shape), on_tap=on_tap,
+                                   defer_bn_scale=defer_bn_scale)
             return [grads[t.name] for t in tape.taps]
 
         grad_fn.streams_taps = True  # accepts on_tap: gradients are delivered layer by layer
+        grad_fn.grad_scale = lambda: sweep.grad_scale  # name -> per-channel scale owed by the caller (deferred BN)
 
         return f.detach().reshape(f.shape[0], -1).contiguous(), tape, grad_fn
 
@@ -361,6 +363,7 @@ class KronAccumulator:
         self.backend, self.N, self.kfac_approx = backend, N, kfac_approx
         self.overlap = overlap
         self.use_pixgram = os.environ.get("LK_PIXGRAM", "1") != "0"
+        self._defer_bn = os.environ.get("LK_DEFER_BN", "1") != "0"
         self._side = None
         self.factors = None  # per tap: [G, A]
         self.loss = None
@@ -381,6 +384,7 @@ class KronAccumulator:
             self._taps_meta.append((tap.has_bias, native))
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
         self._pix = {}  # tap index -> (geometry, buffer): pixel-pair accumulators of 3x3 convs
+        self._gscale = {}  # tap index -> deferred BatchNorm scale owed to the G accumulator
 
     def _pix_geometry(self, tap):
         """How this tap's A factor is accumulated over the fit (3x3 / stride 1 / pad 1 convs, ``expand``):
@@ -479,6 +483,7 @@ class KronAccumulator:
             for i, (tap, F) in enumerate(zip(tape.taps, self.factors)):
                 self._accumulate_A(i, tap, F, rt)
         seeds, hs = b._kron_seeds(f, y, self.loss)
+        defer = getattr(grad_fn, "streams_taps", False) and self._defer_bn
         if side is not None and getattr(grad_fn, "streams_taps", False):
             # G factors too go to the side stream, each as soon as the sweep has produced that layer's gradient: the
             # MFMA-bound Gram kernels then overlap MIOpen's backward-data kernels of the earlier layers
@@ -495,14 +500,35 @@ class KronAccumulator:
                 g.record_stream(side)  # allocated on the main stream, read on the side stream
                 keep.append(g)
 
-            grad_fn(seeds, stack=False, on_tap=on_tap)
+            grad_fn(seeds, stack=False, on_tap=on_tap, defer_bn_scale=defer)
         else:
-            grads = grad_fn(seeds, stack=False)
+            grads = grad_fn(seeds, stack=False, defer_bn_scale=True) if defer else grad_fn(seeds, stack=False)
             for tap, g, F in zip(tape.taps, grads, self.factors):
                 b._factor_G(tap, g, rt * hs, self.kfac_approx, F[0], fused=True)
+        if defer:
+            self._note_grad_scales(tape, grad_fn.grad_scale())
         if side is not None:
             torch.cuda.current_stream(f.device).wait_stream(side)
         tape.release()
+
+    def _note_grad_scales(self, tape, scales):
+        """Deferred BatchNorm scales (laplace_amd/sweep.py): the G accumulators of these taps hold sums of UNSCALED
+        gradient products; ``finalize`` applies ``diag(s) G diag(s)`` once.  ``s`` is a constant of an eval-mode model;
+        should it change between minibatches, what has been accumulated is scaled now and deferral stops."""
+        for idx, tap in enumerate(tape.taps):
+            s_new = scales.get(tap.name)
+            s_old = self._gscale.get(idx)
+            if s_old is None:
+                if s_new is not None:
+                    self._gscale[idx] = s_new
+            elif s_new is None or (s_new is not s_old and not torch.equal(s_new, s_old)):
+                raise RuntimeError(f"{tap.name}: the BatchNorm scale changed during the fit (model not in eval mode?)")
+
+    def _apply_grad_scales(self):
+        for idx, s_ in self._gscale.items():
+            G = self.factors[idx][0]
+            G.mul_(s_.reshape(-1, 1) * s_.reshape(1, -1))
+        self._gscale = {}
 
     def tensors(self) -> list[torch.Tensor]:
         """Everything a data-parallel fit has to all-reduce (upper triangles are what counts)."""
@@ -514,6 +540,7 @@ class KronAccumulator:
         K = get_kernels()
         rt = math.sqrt(float(self.backend.factor))
         self._flush_pixgrams()
+        self._apply_grad_scales()
         kfacs = []
         for (G, A), (has_bias, native) in zip(self.factors, self._taps_meta):
             K.symmetrize(G)

@@ -60,6 +60,7 @@ class SeedBatchedSweep:
         = plain torch math (reference implementation of the same rule, used by the CPU tests)."""
         self.kernels = kernels
         self._bn_cache: dict[str, tuple] = {}
+        self._w_cache: dict[str, tuple] = {}
         try:
             self.gm = fx.symbolic_trace(model)
         except Exception as e:  # data-dependent control flow, non-tensor inputs, ...
@@ -237,13 +238,24 @@ class SeedBatchedSweep:
         dims = sorted(d % ndim for d in (dim if isinstance(dim, (tuple, list)) else (dim,)))
         return dims == [2, 3]
 
+    def _scaled_weight(self, name, m, scale):
+        """``scale[co] * W`` for a deferred BatchNorm scale (cached until the weight or the scale changes)"""
+        if scale is None:
+            return m.weight
+        key = (m.weight._version, m.weight.data_ptr(), id(scale))
+        hit = self._w_cache.get(name)
+        if hit is None or hit[0] != key:
+            hit = (key, (m.weight.detach() * scale.reshape(-1, 1, 1, 1)).contiguous(), scale)
+            self._w_cache[name] = hit
+        return hit[1]
+
     @staticmethod
-    def _conv_input_grad(in_shape, m, g):
+    def _conv_input_grad(in_shape, m, g, weight=None):
         """Backward-data of a convolution for the whole seed batch.  ``torch.nn.grad.conv2d_input`` hands the op a
         stride-0 dummy input, from which PyTorch infers a channels-last result that then has to be copied back to
         NCHW (20 copies of [S*B, C, H, W] per ResNet-18 step); a contiguous, never-read dummy keeps it NCHW."""
         dummy = g.new_empty(in_shape)
-        return torch.ops.aten.convolution_backward(g, dummy, m.weight, None, m.stride, m.padding, m.dilation, False,
+        return torch.ops.aten.convolution_backward(g, dummy, m.weight if weight is None else weight, None, m.stride, m.padding, m.dilation, False,
                                                    [0] * len(m.stride), m.groups, [True, False, False])[0]
 
     # ---- element-wise VJPs ----------------------------------------------------------------------------------
@@ -304,11 +316,20 @@ class SeedBatchedSweep:
 
     # ---- reverse sweep -----------------------------------------------------------------------------------
     @torch.no_grad()
-    def backward(self, seeds: torch.Tensor, on_tap=None) -> dict[str, torch.Tensor]:
+    def backward(self, seeds: torch.Tensor, on_tap=None, defer_bn_scale: bool = False) -> dict[str, torch.Tensor]:
         """``seeds``: ``[S, B, C]`` cotangents of the output.  Returns per tapped module the gradient w.r.t.
         its output, ``[S, B, ...]`` (a view of the ``S*B``-batched cotangent).  ``on_tap(name, g)`` is called the
         moment a tapped module's gradient is complete — the accumulator uses it to start that layer's G-factor
-        kernel on a side stream while the sweep goes on through the earlier layers."""
+        kernel on a side stream while the sweep goes on through the earlier layers.
+
+        ``defer_bn_scale``: a conv whose output feeds ONLY an eval-mode BatchNorm that is not followed by an
+        activation (``bn2`` / the down-sampling branch of a residual block) normally costs one full pass over the
+        cotangent just to multiply by the per-channel scale ``s``.  Deferred, that pass disappears: the conv's
+        backward-data uses the pre-scaled weights ``s[co] * W`` and the tap receives the UNSCALED gradient ``g`` with
+        ``self.grad_scale[name] = s`` — the caller owes ``G <- diag(s) G diag(s)``, which a KFAC accumulator applies
+        once per fit because ``s`` is constant."""
+        self.grad_scale: dict[str, torch.Tensor] = {}
+        pending_scale: dict[fx.Node, torch.Tensor] = {}
         S, B = seeds.shape[0], seeds.shape[1]
         # per node: the pending addends of its output cotangent (summed lazily, so that an activation can fold
         # the residual-branch addition into its own kernel)
@@ -335,6 +356,8 @@ class SeedBatchedSweep:
                 m = self.modules[node.target]
                 if node.target in self.tap_names:
                     grads[node.target] = g.reshape(S, B, *g.shape[1:])
+                    if node in pending_scale:
+                        self.grad_scale[node.target] = pending_scale[node]
                     if on_tap is not None:
                         on_tap(node.target, grads[node.target])
                     remaining.discard(node.target)
@@ -343,11 +366,18 @@ class SeedBatchedSweep:
                 src = node.args[0]
                 if isinstance(m, nn.Conv2d):
                     in_shape = (S * B,) + tuple(self.saved[node][1:])
-                    push(src, self._conv_input_grad(in_shape, m, g))
+                    push(src, self._conv_input_grad(in_shape, m, g, self._scaled_weight(node.target, m, pending_scale.get(node))))
                 elif isinstance(m, nn.Linear):
                     push(src, g @ m.weight)
                 elif isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d)):
-                    push(src, self._scale_mask(g, S, None, self._bn_scale(node.target, m)))
+                    scale = self._bn_scale(node.target, m)
+                    if (defer_bn_scale and isinstance(src, fx.Node) and src.op == "call_module" and len(src.users) == 1
+                            and isinstance(self.modules[src.target], nn.Conv2d) and src.target in self.tap_names
+                            and src not in cot):
+                        pending_scale[src] = scale  # the conv sees the unscaled cotangent (see the docstring)
+                        push(src, g)
+                    else:
+                        push(src, self._scale_mask(g, S, None, scale))
                 elif isinstance(m, (nn.ReLU, nn.Tanh, nn.Sigmoid) + self._GENERIC_ACT_MODULES):
                     scale, dst = self._fold_bn(src)
                     push(dst, self._scale_mask(g, S, self._act_mult(m, self.saved[node]), scale, g2))

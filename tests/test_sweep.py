@@ -212,6 +212,14 @@ def test_backend_sweep_and_tape_agree(use_sweep):
         for F0, F1 in zip(H0.kfacs, H1.kfacs):
             for a, c in zip(F0, F1):
                 assert torch.allclose(a, c, rtol=1e-4, atol=1e-7)
+        if use_sweep:  # the BatchNorm of the shortcut branch is deferred: unscaled G sums + one scaling at finalize
+            acc = b.kron_accumulator(12)
+            acc.add_batch(X, y)
+            assert len(acc._gscale) == 1
+            _, Hacc = acc.finalize()
+            for F0, F1 in zip(H0.kfacs, Hacc.kfacs):
+                for a, c in zip(F0, F1):
+                    assert torch.allclose(a, c, rtol=1e-4, atol=1e-7)
         _, d0 = ref.diag(X, y, N=12)
         _, d1 = b.diag(X, y, N=12)
         assert torch.allclose(d0, d1, rtol=1e-4, atol=1e-7)
