@@ -109,7 +109,11 @@ class SeedBatchedSweep:
         self.saved: dict[fx.Node, Any] = {}
         self.taps: dict[str, dict] = {}
         self.out_node = None
+        fused_relu: dict[fx.Node, tuple] = {}  # ReLU node -> (output, mask) already produced by the BatchNorm kernel
         for node in self.gm.graph.nodes:
+            if node in fused_relu:
+                env[node], self.saved[node] = fused_relu.pop(node)
+                continue
             if node.op == "placeholder":
                 env[node] = x
             elif node.op == "output":
@@ -124,6 +128,16 @@ class SeedBatchedSweep:
                     self.saved[node] = (idx, inp.shape)
                 elif isinstance(m, self._GENERIC_ACT_MODULES):
                     out, self.saved[node] = self._with_derivative(m, inp)
+                elif (isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d)) and self.kernels is not None and inp.dim() >= 2
+                      and inp.dtype == torch.float32 and m.running_var is not None):
+                    # eval-mode BatchNorm = per-channel affine map: one fused launch, with the ReLU that follows it
+                    # (and the mask its VJP needs) when the BatchNorm output has no other consumer
+                    scale, shift = self._bn_scale(node.target, m), self._bn_shift(node.target, m)
+                    nxt = next(iter(node.users)) if len(node.users) == 1 else None
+                    relu = nxt is not None and self._is_plain_relu(nxt) and nxt.args[0] is node
+                    out, mask = self.kernels().bn_act_forward(inp.contiguous(), scale, shift, relu)
+                    if relu:
+                        fused_relu[nxt] = (out, mask)
                 else:
                     out = m(inp)
                     if isinstance(m, (nn.ReLU,)):
@@ -277,6 +291,26 @@ class SeedBatchedSweep:
         if node.op == "call_function":
             return node.target in self._ELEMENTWISE_FN or node.target in self._GENERIC_ACT_FN
         return node.op == "call_method" and node.target in ("relu", "tanh", "sigmoid")
+
+    def _bn_shift(self, name: str, m) -> torch.Tensor:
+        """beta - running_mean * scale (cached like the scale)"""
+        key = (m.running_mean._version, m.running_var._version, None if m.weight is None else m.weight._version,
+               None if m.bias is None else m.bias._version, m.running_mean.data_ptr())
+        hit = self._bn_cache.get(name + "/shift")
+        if hit is None or hit[0] != key:
+            shift = -m.running_mean * self._bn_scale(name, m)
+            if m.bias is not None:
+                shift = shift + m.bias.detach()
+            hit = (key, shift)
+            self._bn_cache[name + "/shift"] = hit
+        return hit[1]
+
+    def _is_plain_relu(self, node) -> bool:
+        if node.op == "call_module":
+            return isinstance(self.modules[node.target], nn.ReLU)
+        if node.op == "call_function":
+            return node.target in (torch.relu, F.relu)
+        return node.op == "call_method" and node.target == "relu"
 
     def _scale_mask(self, g, S, mult, scale, g2=None):
         """``(g[s] + g2[s]) * mult * scale[channel]`` for all seeds (``g``: [S*B, C, ...], ``mult``: [B, C, ...])."""

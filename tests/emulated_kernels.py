@@ -108,6 +108,14 @@ class EmulatedKernels:
         P = Js.shape[-1]
         h += alpha * (Js.reshape(-1, P)[:, col0:col0 + width] ** 2).sum(0)
 
+    def bn_act_forward(self, x, scale, shift, relu):
+        shape = (1, -1) + (1,) * (x.dim() - 2)
+        y = x * scale.reshape(shape).to(x.dtype) + shift.reshape(shape).to(x.dtype)
+        if relu:
+            y = y.clamp_min(0)
+            return y, y > 0
+        return y, None
+
     def vjp_scale_mask(self, g, S, mult, scale, hw, g2=None):
         out = g.reshape(S, -1)
         if g2 is not None:

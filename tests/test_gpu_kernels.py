@@ -585,3 +585,26 @@ def test_conv3x3_banded_pixel_pair_form(K, B, Cin, H, W):
     nat = K.pixpair_assemble(blocks, plan, H, W, Cin, 1.0, torch.zeros(n, n, device=DEV))
     got = K.permute_native_to_unfold(nat, Cin, 9, torch.zeros(n, n, device=DEV))
     assert_close(got, want, what="banded pixel-pair form")
+
+
+@pytest.mark.parametrize("shape", [(4, 16, 8, 8), (3, 7, 5, 3), (5, 6), (2, 64, 32, 32), (3, 5, 9)])
+@pytest.mark.parametrize("relu", [True, False])
+def test_bn_act_forward(K, shape, relu):
+    """eval-mode BatchNorm as an affine map (+ ReLU and its mask) == torch's batch_norm (+ relu) to fp32 rounding"""
+    gen = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=gen, dtype=torch.float64)
+    C = shape[1]
+    w, b = torch.randn(C, generator=gen, dtype=torch.float64), torch.randn(C, generator=gen, dtype=torch.float64)
+    rm, rv = torch.randn(C, generator=gen, dtype=torch.float64), torch.rand(C, generator=gen, dtype=torch.float64) + 0.5
+    want = torch.nn.functional.batch_norm(x, rm, rv, w, b, False, 0.1, 1e-5)
+    if relu:
+        want = want.clamp_min(0)
+    scale = w * torch.rsqrt(rv + 1e-5)
+    shift = b - rm * scale
+    y, mask = K.bn_act_forward(x.float().to(DEV).contiguous(), scale.float().to(DEV), shift.float().to(DEV), relu)
+    _sync()
+    assert_close(y, want, 2e-6, "bn_act_forward")
+    if relu:
+        assert mask.dtype == torch.bool and torch.equal(mask.cpu(), y.cpu() > 0)
+    else:
+        assert mask is None
