@@ -165,10 +165,11 @@ int lk_sq_colsum_f32(const float* Js, int64_t rows, int64_t P, int64_t col0, int
  * (f'(y), m_is_float = 1).  scale: per-channel factor gamma/sqrt(var+eps) (NULL = 1; then C, HW are ignored). */
 /* Forward counterpart in the sweep's own interpretation of the model: eval-mode BatchNorm (a per-channel affine map)
  * with an optional ReLU and the mask its VJP needs, in one pass:
- *   y[e] = act(x[e] * scale[c(e)] + shift[c(e)]),  mask[e] = y[e] > 0  (mask may be NULL; relu = 0: no activation),
+ *   y[e] = act(x[e] * scale[c(e)] + shift[c(e)] + addend[e]),  mask[e] = y[e] > 0
+ *   (addend: the other branch of a residual connection, NULL = none; mask may be NULL; relu = 0: no activation),
  *   scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale, e < total = B*C*HW. */
-int lk_bn_act_fwd_f32(const float* x, const float* scale, const float* shift, int64_t total, int64_t C, int64_t HW,
-                      int relu, float* y, unsigned char* mask, void* stream);
+int lk_bn_act_fwd_f32(const float* x, const float* scale, const float* shift, const float* addend, int64_t total,
+                      int64_t C, int64_t HW, int relu, float* y, unsigned char* mask, void* stream);
 int lk_vjp_scale_mask_f32(const float* g, const float* g2, const void* m, int m_is_float, const float* scale, int64_t S,
                           int64_t per_sample, int64_t C, int64_t HW, float* out, void* stream);
 

@@ -62,7 +62,7 @@ SIGNATURES = {
         [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _int, _vp, _i64, _i64, _i64, _vp],
     ),
     "lk_sq_colsum_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _f32, _vp, _vp]),
-    "lk_bn_act_fwd_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _int, _vp, _vp, _vp]),
+    "lk_bn_act_fwd_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _int, _vp, _vp, _vp]),
     "lk_vjp_scale_mask_f32": (_int, [_vp, _vp, _vp, _int, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "lk_ll_ggn_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "lk_ll_ggn_full_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _f32, _vp, _vp, _sz, _vp]),
@@ -407,15 +407,20 @@ class HipKernels:
         self._rc(self.lib.lk_sq_colsum_f32(_ptr(Js), rows, P, int(col0), int(width), float(alpha), _ptr(h),
                                            self._stream(Js.device)), "lk_sq_colsum_f32")
 
-    def bn_act_forward(self, x, scale, shift, relu):
-        """``(y, mask)``: ``y = act(x * scale[c] + shift[c])`` for ``x`` [B, C, ...]; ``mask = y > 0`` (bool) if ``relu``."""
+    def bn_act_forward(self, x, scale, shift, relu, addend=None):
+        """``(y, mask)``: ``y = act(x * scale[c] + shift[c] + addend)`` for ``x`` [B, C, ...]; ``mask = y > 0`` (bool) if
+        ``relu``."""
         _check(x, "x")
+        if addend is not None:
+            _check(addend, "addend")
+            if addend.shape != x.shape:
+                raise ValueError("bn_act_forward: addend must have the shape of x")
         C = x.shape[1]
         hw = x.numel() // (x.shape[0] * C) if x.numel() else 1
         y = torch.empty_like(x)
         mask = torch.empty(x.shape, dtype=torch.bool, device=x.device) if relu else None
         self._rc(self.lib.lk_bn_act_fwd_f32(_ptr(x), _ptr(scale.to(torch.float32).contiguous()),
-                                            _ptr(shift.to(torch.float32).contiguous()), x.numel(), C, max(hw, 1),
+                                            _ptr(shift.to(torch.float32).contiguous()), _ptr(addend), x.numel(), C, max(hw, 1),
                                             1 if relu else 0, _ptr(y), _ptr(mask), self._stream(x.device)),
                  "lk_bn_act_fwd_f32")
         return y, mask

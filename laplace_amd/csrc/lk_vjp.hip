@@ -76,7 +76,8 @@ __global__ __launch_bounds__(256) void vjp_scale_mask_kernel(const float* __rest
 //   a third of the HBM rate on these shapes, then clamp_min, then the compare that produces the mask).
 template <bool RELU>
 __global__ __launch_bounds__(256) void bn_act_fwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ scale,
-                                                             const float* __restrict__ shift, int64_t total, int C, int HW,
+                                                             const float* __restrict__ shift,
+                                                             const float* __restrict__ addend, int64_t total, int C, int HW,
                                                              float* __restrict__ y, unsigned char* __restrict__ mask) {
   const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (e >= total) return;
@@ -84,6 +85,10 @@ __global__ __launch_bounds__(256) void bn_act_fwd_vec_kernel(const float* __rest
   const float sc = scale[c], sh = shift[c];
   float4 v = *reinterpret_cast<const float4*>(x + e);
   v.x = v.x * sc + sh, v.y = v.y * sc + sh, v.z = v.z * sc + sh, v.w = v.w * sc + sh;
+  if (addend) {  // the other branch of a residual connection
+    const float4 a = *reinterpret_cast<const float4*>(addend + e);
+    v.x += a.x, v.y += a.y, v.z += a.z, v.w += a.w;
+  }
   if (RELU) {
     v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
     if (mask) *reinterpret_cast<uchar4*>(mask + e) = make_uchar4(v.x > 0.f, v.y > 0.f, v.z > 0.f, v.w > 0.f);
@@ -93,12 +98,14 @@ __global__ __launch_bounds__(256) void bn_act_fwd_vec_kernel(const float* __rest
 
 template <bool RELU>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale,
-                                                         const float* __restrict__ shift, int64_t total, int C, int HW,
-                                                         float* __restrict__ y, unsigned char* __restrict__ mask) {
+                                                         const float* __restrict__ shift, const float* __restrict__ addend,
+                                                         int64_t total, int C, int HW, float* __restrict__ y,
+                                                         unsigned char* __restrict__ mask) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= total) return;
   const int c = (int)((e / HW) % C);
   float v = x[e] * scale[c] + shift[c];
+  if (addend) v += addend[e];
   if (RELU) {
     v = fmaxf(v, 0.f);
     if (mask) mask[e] = v > 0.f;
@@ -110,30 +117,31 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
 
 using namespace lk;
 
-extern "C" int lk_bn_act_fwd_f32(const float* x, const float* scale, const float* shift, int64_t total, int64_t C, int64_t HW,
-                                 int relu, float* y, unsigned char* mask, void* stream) {
+extern "C" int lk_bn_act_fwd_f32(const float* x, const float* scale, const float* shift, const float* addend, int64_t total,
+                                 int64_t C, int64_t HW, int relu, float* y, unsigned char* mask, void* stream) {
   LK_REQUIRE(x && scale && shift && y && total >= 0 && C > 0 && HW > 0 && total % (C * HW) == 0 && C < (1ll << 31) &&
                  HW < (1ll << 31),
              "lk_bn_act_fwd_f32: bad arguments");
   if (total == 0) return LK_OK;
   hipStream_t st = (hipStream_t)stream;
-  const bool vec = HW % 4 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0 && (!mask || (uintptr_t)mask % 4 == 0);
+  const bool vec = HW % 4 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0 && (uintptr_t)addend % 16 == 0 &&
+                   (!mask || (uintptr_t)mask % 4 == 0);
   const int64_t nb = vec ? (total / 4 + 255) / 256 : (total + 255) / 256;
   LK_REQUIRE(nb < (1ll << 31), "lk_bn_act_fwd_f32: grid too large");
   if (vec) {
     if (relu)
-      hipLaunchKernelGGL(bn_act_fwd_vec_kernel<true>, dim3((unsigned)nb), dim3(256), 0, st, x, scale, shift, total, (int)C,
-                         (int)HW, y, mask);
+      hipLaunchKernelGGL(bn_act_fwd_vec_kernel<true>, dim3((unsigned)nb), dim3(256), 0, st, x, scale, shift, addend, total,
+                         (int)C, (int)HW, y, mask);
     else
-      hipLaunchKernelGGL(bn_act_fwd_vec_kernel<false>, dim3((unsigned)nb), dim3(256), 0, st, x, scale, shift, total, (int)C,
-                         (int)HW, y, mask);
+      hipLaunchKernelGGL(bn_act_fwd_vec_kernel<false>, dim3((unsigned)nb), dim3(256), 0, st, x, scale, shift, addend, total,
+                         (int)C, (int)HW, y, mask);
   } else {
     if (relu)
-      hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3((unsigned)nb), dim3(256), 0, st, x, scale, shift, total, (int)C, (int)HW,
-                         y, mask);
-    else
-      hipLaunchKernelGGL(bn_act_fwd_kernel<false>, dim3((unsigned)nb), dim3(256), 0, st, x, scale, shift, total, (int)C,
+      hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3((unsigned)nb), dim3(256), 0, st, x, scale, shift, addend, total, (int)C,
                          (int)HW, y, mask);
+    else
+      hipLaunchKernelGGL(bn_act_fwd_kernel<false>, dim3((unsigned)nb), dim3(256), 0, st, x, scale, shift, addend, total,
+                         (int)C, (int)HW, y, mask);
   }
   return check_launch("bn_act_fwd_kernel");
 }

@@ -112,7 +112,9 @@ class SeedBatchedSweep:
         fused_relu: dict[fx.Node, tuple] = {}  # ReLU node -> (output, mask) already produced by the BatchNorm kernel
         for node in self.gm.graph.nodes:
             if node in fused_relu:
-                env[node], self.saved[node] = fused_relu.pop(node)
+                env[node], keep = fused_relu.pop(node)
+                if keep is not None:
+                    self.saved[node] = keep
                 continue
             if node.op == "placeholder":
                 env[node] = x
@@ -134,8 +136,18 @@ class SeedBatchedSweep:
                     # (and the mask its VJP needs) when the BatchNorm output has no other consumer
                     scale, shift = self._bn_scale(node.target, m), self._bn_shift(node.target, m)
                     nxt = next(iter(node.users)) if len(node.users) == 1 else None
-                    relu = nxt is not None and self._is_plain_relu(nxt) and nxt.args[0] is node
-                    out, mask = self.kernels().bn_act_forward(inp.contiguous(), scale, shift, relu)
+                    addend, add_node = None, None
+                    if nxt is not None and self._is_plain_add(nxt):
+                        # residual join `bn(..) + other`: folded in when the other branch is already available
+                        other = nxt.args[1] if nxt.args[0] is node else nxt.args[0]
+                        if isinstance(other, fx.Node) and other in env and torch.is_tensor(env[other]) \
+                                and env[other].shape == inp.shape and env[other].dtype == inp.dtype:
+                            addend, add_node = env[other].contiguous(), nxt
+                            nxt = next(iter(add_node.users)) if len(add_node.users) == 1 else None
+                    relu = nxt is not None and self._is_plain_relu(nxt) and nxt.args[0] is (add_node or node)
+                    out, mask = self.kernels().bn_act_forward(inp.contiguous(), scale, shift, relu, addend)
+                    if add_node is not None:
+                        fused_relu[add_node] = (out, None)  # (the add node itself keeps nothing for its VJP)
                     if relu:
                         fused_relu[nxt] = (out, mask)
                 else:
@@ -304,6 +316,11 @@ class SeedBatchedSweep:
             hit = (key, shift)
             self._bn_cache[name + "/shift"] = hit
         return hit[1]
+
+    @staticmethod
+    def _is_plain_add(node) -> bool:
+        return (node.op == "call_function" and node.target in (operator.add, torch.add, operator.iadd) and len(node.args) == 2
+                and all(isinstance(a, fx.Node) for a in node.args) and node.kwargs.get("alpha", 1) == 1)
 
     def _is_plain_relu(self, node) -> bool:
         if node.op == "call_module":

@@ -589,7 +589,8 @@ def test_conv3x3_banded_pixel_pair_form(K, B, Cin, H, W):
 
 @pytest.mark.parametrize("shape", [(4, 16, 8, 8), (3, 7, 5, 3), (5, 6), (2, 64, 32, 32), (3, 5, 9)])
 @pytest.mark.parametrize("relu", [True, False])
-def test_bn_act_forward(K, shape, relu):
+@pytest.mark.parametrize("with_addend", [False, True])
+def test_bn_act_forward(K, shape, relu, with_addend):
     """eval-mode BatchNorm as an affine map (+ ReLU and its mask) == torch's batch_norm (+ relu) to fp32 rounding"""
     gen = torch.Generator().manual_seed(sum(shape))
     x = torch.randn(*shape, generator=gen, dtype=torch.float64)
@@ -597,11 +598,15 @@ def test_bn_act_forward(K, shape, relu):
     w, b = torch.randn(C, generator=gen, dtype=torch.float64), torch.randn(C, generator=gen, dtype=torch.float64)
     rm, rv = torch.randn(C, generator=gen, dtype=torch.float64), torch.rand(C, generator=gen, dtype=torch.float64) + 0.5
     want = torch.nn.functional.batch_norm(x, rm, rv, w, b, False, 0.1, 1e-5)
+    add = torch.randn(*shape, generator=gen, dtype=torch.float64) if with_addend else None
+    if add is not None:
+        want = want + add
     if relu:
         want = want.clamp_min(0)
     scale = w * torch.rsqrt(rv + 1e-5)
     shift = b - rm * scale
-    y, mask = K.bn_act_forward(x.float().to(DEV).contiguous(), scale.float().to(DEV), shift.float().to(DEV), relu)
+    y, mask = K.bn_act_forward(x.float().to(DEV).contiguous(), scale.float().to(DEV), shift.float().to(DEV), relu,
+                               None if add is None else add.float().to(DEV).contiguous())
     _sync()
     assert_close(y, want, 2e-6, "bn_act_forward")
     if relu:
