@@ -80,6 +80,8 @@ class _HipCurvatureMixin:
 
     #: ``False`` forces the autograd tape (one reverse pass per seed); env LK_SWEEP=0 does the same.
     use_sweep = os.environ.get("LK_SWEEP", "1") != "0"
+    #: largest batch (seeds x samples) of one reverse sweep; more seeds are processed in chunks
+    sweep_max_rows = 8192
 
     def _forward_swept(self, x, tape):
         """Seed-batched reverse sweep (laplace_amd/sweep.py) when the model is fx-traceable and built from
@@ -110,9 +112,23 @@ class _HipCurvatureMixin:
             t.a = sweep.taps[t.name]["a"]
 
         def grad_fn(seeds, stack=True, on_tap=None, defer_bn_scale=False):
-            grads = sweep.backward(seeds.reshape(seeds.shape[0], seeds.shape[1], *sweep.out_shape), on_tap=on_tap,
-                                   defer_bn_scale=defer_bn_scale)
-            return [grads[t.name] for t in tape.taps]
+            """All seeds in one sweep while ``S*B`` stays below ``sweep_max_rows`` images; many-output models
+            (C = 1000 -> 999 seeds) go through in seed chunks of that size.  With ``on_tap`` every chunk's gradients
+            are handed over layer by layer (additive consumers such as the KFAC accumulator) and nothing is returned."""
+            seeds = seeds.reshape(seeds.shape[0], seeds.shape[1], *sweep.out_shape)
+            S, B = seeds.shape[0], seeds.shape[1]
+            chunk = max(1, int(self.sweep_max_rows) // max(B, 1))
+            if S <= chunk:
+                grads = sweep.backward(seeds, on_tap=on_tap, defer_bn_scale=defer_bn_scale)
+                return [grads[t.name] for t in tape.taps]
+            parts = []
+            for s0 in range(0, S, chunk):
+                grads = sweep.backward(seeds[s0:s0 + chunk].contiguous(), on_tap=on_tap, defer_bn_scale=defer_bn_scale)
+                if on_tap is None:
+                    parts.append([grads[t.name] for t in tape.taps])
+            if on_tap is not None:
+                return None
+            return [torch.cat([p[i] for p in parts]) for i in range(len(tape.taps))]
 
         grad_fn.streams_taps = True  # accepts on_tap: gradients are delivered layer by layer
         grad_fn.grad_scale = lambda: sweep.grad_scale  # name -> per-channel scale owed by the caller (deferred BN)
@@ -484,25 +500,27 @@ class KronAccumulator:
                 self._accumulate_A(i, tap, F, rt)
         seeds, hs = b._kron_seeds(f, y, self.loss)
         defer = getattr(grad_fn, "streams_taps", False) and self._defer_bn
-        if side is not None and getattr(grad_fn, "streams_taps", False):
-            # G factors too go to the side stream, each as soon as the sweep has produced that layer's gradient: the
-            # MFMA-bound Gram kernels then overlap MIOpen's backward-data kernels of the earlier layers
+        if getattr(grad_fn, "streams_taps", False):
+            # The sweep hands over each layer's gradient the moment it is complete (and, for many-output models, seed
+            # chunk by seed chunk).  With a side stream the G-factor kernel goes there at once: the MFMA-bound Gram
+            # kernels then overlap MIOpen's backward-data kernels of the earlier layers.
             by_name = {tap.name: (tap, F) for tap, F in zip(tape.taps, self.factors)}
-            keep = []
 
             def on_tap(name, g):
                 tap, F = by_name[name]
+                if side is None:
+                    b._factor_G(tap, g, rt * hs, self.kfac_approx, F[0], fused=True)
+                    return
                 ev = torch.cuda.Event()
                 ev.record(main)
                 side.wait_event(ev)
                 with torch.cuda.stream(side):
                     b._factor_G(tap, g, rt * hs, self.kfac_approx, F[0], fused=True)
                 g.record_stream(side)  # allocated on the main stream, read on the side stream
-                keep.append(g)
 
             grad_fn(seeds, stack=False, on_tap=on_tap, defer_bn_scale=defer)
         else:
-            grads = grad_fn(seeds, stack=False, defer_bn_scale=True) if defer else grad_fn(seeds, stack=False)
+            grads = grad_fn(seeds, stack=False)
             for tap, g, F in zip(tape.taps, grads, self.factors):
                 b._factor_G(tap, g, rt * hs, self.kfac_approx, F[0], fused=True)
         if defer:

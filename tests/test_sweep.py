@@ -306,3 +306,35 @@ def test_fused_accumulator_pixel_pair_paths_equal_literal_loop():
                 assert torch.allclose(a, c, rtol=1e-4, atol=1e-7)
     finally:
         _lib.set_kernels_for_testing(prev)
+
+
+def test_seed_chunking_for_many_output_models():
+    """S*B above `sweep_max_rows`: the sweep runs in seed chunks; KFAC factors, diag and Jacobians are unchanged."""
+    from laplace_amd import _lib
+    from laplace_amd.backend import HipGGN
+    from tests.emulated_kernels import EmulatedKernels
+
+    prev = _lib.set_kernels_for_testing(EmulatedKernels())
+    try:
+        torch.manual_seed(6)
+        model = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.BatchNorm2d(8), nn.ReLU(), nn.Flatten(),
+                              nn.Linear(8 * 4 * 4, 12)).eval()
+        for m in model.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.weight.requires_grad_(False), m.bias.requires_grad_(False)
+        X, y = torch.randn(5, 3, 4, 4), torch.randint(0, 12, (5,))
+        ref = HipGGN(model, "classification")
+        loss0, H0 = ref.kron(X, y, N=20)
+        _, d0 = ref.diag(X, y)
+        J0, _ = ref.jacobians(X)
+        b = HipGGN(model, "classification")
+        b.sweep_max_rows = 15  # 11 seeds x 5 samples -> chunks of 3 seeds
+        loss1, H1 = b.kron(X, y, N=20)
+        assert torch.allclose(loss0, loss1)
+        for F0, F1 in zip(H0.kfacs, H1.kfacs):
+            for a, c in zip(F0, F1):
+                assert torch.allclose(a, c, rtol=1e-4, atol=1e-7)
+        assert torch.allclose(b.diag(X, y)[1], d0, rtol=1e-4, atol=1e-7)
+        assert torch.allclose(b.jacobians(X)[0], J0, rtol=1e-4, atol=1e-6)
+    finally:
+        _lib.set_kernels_for_testing(prev)
