@@ -80,8 +80,10 @@ class _HipCurvatureMixin:
 
     #: ``False`` forces the autograd tape (one reverse pass per seed); env LK_SWEEP=0 does the same.
     use_sweep = os.environ.get("LK_SWEEP", "1") != "0"
-    #: largest batch (seeds x samples) of one reverse sweep; more seeds are processed in chunks
+    #: largest batch (seeds x samples) of one reverse sweep and the memory its cotangents may take (4 live tensors of
+    #: the largest activation are assumed); more seeds are processed in chunks
     sweep_max_rows = 8192
+    sweep_mem_bytes = 16 << 30
 
     def _forward_swept(self, x, tape):
         """Seed-batched reverse sweep (laplace_amd/sweep.py) when the model is fx-traceable and built from
@@ -117,7 +119,9 @@ class _HipCurvatureMixin:
             are handed over layer by layer (additive consumers such as the KFAC accumulator) and nothing is returned."""
             seeds = seeds.reshape(seeds.shape[0], seeds.shape[1], *sweep.out_shape)
             S, B = seeds.shape[0], seeds.shape[1]
-            chunk = max(1, int(self.sweep_max_rows) // max(B, 1))
+            # a few cotangents of the largest activation are alive at once: keep them inside the memory budget
+            rows = min(int(self.sweep_max_rows), int(self.sweep_mem_bytes) // (16 * max(sweep.max_act_numel, 1)))
+            chunk = max(1, rows // max(B, 1))
             if S <= chunk:
                 grads = sweep.backward(seeds, on_tap=on_tap, defer_bn_scale=defer_bn_scale)
                 return [grads[t.name] for t in tape.taps]

@@ -110,6 +110,7 @@ class SeedBatchedSweep:
         self.taps: dict[str, dict] = {}
         self.out_node = None
         fused_relu: dict[fx.Node, tuple] = {}  # ReLU node -> (output, mask) already produced by the BatchNorm kernel
+        self.max_act_numel = 1  # largest per-sample activation: bounds the memory of a seed-batched cotangent
         for node in self.gm.graph.nodes:
             if node in fused_relu:
                 env[node], keep = fused_relu.pop(node)
@@ -218,6 +219,10 @@ class SeedBatchedSweep:
                 elif node.target in ("view", "reshape", "flatten"):
                     self.saved[node] = self_t.shape
                 env[node] = out
+        nb = max(int(x.shape[0]), 1)
+        for v in env.values():
+            if torch.is_tensor(v):
+                self.max_act_numel = max(self.max_act_numel, v.numel() // nb)
         missing = self.tap_names - set(self.taps)
         if missing:
             raise SweepUnsupported(f"tapped modules not reached by the traced forward: {sorted(missing)}")
