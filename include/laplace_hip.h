@@ -32,6 +32,9 @@ extern "C" {
 
 /* flags for the Gram (factor accumulation) family */
 #define LK_GRAM_UPPER_ONLY 1u /* update only the upper block triangle; caller runs lk_symmetrize_f32 later */
+#define LK_GRAM_SLABS_PERSIST 2u /* the workspace is a zero-initialised, caller-owned accumulator of split-K partial
+                                    tiles that persists across launches: `slab += partial`, C is not touched; reduce
+                                    once with lk_gram_slabs_reduce_f32 (a sum over minibatches is linear) */
 
 int lk_version(void);
 const char* lk_last_error(void);
@@ -74,6 +77,10 @@ int lk_sq_err_sum_f32(const float* f, const float* y, int64_t numel, float scale
  * ------------------------------------------------------------------------------------------- */
 size_t lk_gram_workspace_bytes(int64_t n, int64_t K);
 size_t lk_gram_nt_workspace_bytes(int64_t nb_total, int64_t n, int64_t L);
+/* C += alpha * sum of the persistent slabs (LK_GRAM_SLABS_PERSIST) of an n x n product; L_nt = L of the _nt launches
+ * that filled them (0 for _tn / _conv); `slabs` is modified.  flags: LK_GRAM_UPPER_ONLY as for the launches. */
+int lk_gram_slabs_reduce_f32(float* slabs, size_t slabs_bytes, int64_t n, int64_t L_nt, float alpha, float* C,
+                             unsigned flags, void* stream);
 int lk_gram_tn_f32(const float* X, int64_t K, int64_t n, int64_t ldx, float alpha, float* C,
                    unsigned flags, void* ws, size_t ws_bytes, void* stream);
 int lk_gram_nt_f32(const float* X, int64_t nb, int64_t n, int64_t L, float alpha, float* C,

@@ -20,6 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "liblaplace_hip.so")
 
 LK_GRAM_UPPER_ONLY = 1
+LK_GRAM_SLABS_PERSIST = 2
 
 _c_f32p = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -38,6 +39,7 @@ SIGNATURES = {
     "lk_sq_err_sum_f32": (_int, [_vp, _vp, _i64, _f32, _vp, _vp]),
     "lk_gram_workspace_bytes": (_sz, [_i64, _i64]),
     "lk_gram_nt_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "lk_gram_slabs_reduce_f32": (_int, [_vp, _sz, _i64, _i64, _f32, _vp, _u32, _vp]),
     "lk_gram_tn_f32": (_int, [_vp, _i64, _i64, _i64, _f32, _vp, _u32, _vp, _sz, _vp]),
     "lk_gram_nt_f32": (_int, [_vp, _i64, _i64, _i64, _f32, _vp, _u32, _vp, _sz, _vp]),
     "lk_gram_nt_seg_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _f32, _vp, _u32, _vp, _sz, _vp]),
@@ -211,9 +213,22 @@ class HipKernels:
         )
         return out
 
-    def gram_nt(self, X, alpha, out, upper_only=False):
+    def gram_nt_slab_bytes(self, nb_total, n, L) -> int:
+        return int(self.lib.lk_gram_nt_workspace_bytes(int(nb_total), int(n), int(L)))
+
+    def gram_slabs_reduce(self, slabs, n, L, alpha, out, upper_only=False):
+        """``out += alpha * sum(persistent slabs)`` — the one-off reduction of ``gram_nt(..., persist=slabs)``."""
+        _check(out, "out")
+        self._rc(self.lib.lk_gram_slabs_reduce_f32(_ptr(slabs), slabs.numel(), int(n), int(L), float(alpha), _ptr(out),
+                                                   LK_GRAM_UPPER_ONLY if upper_only else 0, self._stream(out.device)),
+                 "lk_gram_slabs_reduce_f32")
+        return out
+
+    def gram_nt(self, X, alpha, out, upper_only=False, persist=None):
         """``out += alpha * sum_b X_b X_b^T``; ``X`` is ``[nb, n, L]`` or a list of up to 16 such tensors
-        (per-seed gradients, consumed in place through a pointer table)."""
+        (per-seed gradients, consumed in place through a pointer table).  ``persist``: a zero-initialised uint8 buffer
+        of at least ``gram_nt_slab_bytes`` that accumulates the split-K partial tiles across calls instead of ``out``
+        (reduce once with :meth:`gram_slabs_reduce`; ``alpha`` is then applied there)."""
         segs = list(X) if isinstance(X, (list, tuple)) else [X]
         for t in segs:
             _check(t, "X")
@@ -225,11 +240,17 @@ class HipKernels:
             nbat = segs[0].shape[0]
         nb = self.lib.lk_gram_nt_workspace_bytes(len(segs) * nbat, n, L)
         dev = segs[0].device
-        ws = self._workspace(nb, dev)
+        flags = LK_GRAM_UPPER_ONLY if upper_only else 0
+        if persist is not None:
+            if persist.numel() < nb:
+                raise LaplaceHipError("gram_nt: persistent slab buffer too small")
+            ws, flags = persist, flags | LK_GRAM_SLABS_PERSIST
+        else:
+            ws = self._workspace(nb, dev)
         ptrs = (ctypes.c_void_p * len(segs))(*[t.data_ptr() for t in segs])
         self._rc(
             self._timed("gram_nt", float(len(segs) * nbat * L) * n * (n + 1), dev, lambda: self.lib.lk_gram_nt_seg_f32(
-                ptrs, len(segs), nbat, n, L, float(alpha), _ptr(out), LK_GRAM_UPPER_ONLY if upper_only else 0, _ptr(ws),
+                ptrs, len(segs), nbat, n, L, float(alpha), _ptr(out), flags, _ptr(ws),
                 ws.numel(), self._stream(dev))),
             "lk_gram_nt_seg_f32",
         )

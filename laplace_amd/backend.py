@@ -245,7 +245,7 @@ class _HipCurvatureMixin:
             K.gram_tn(cols.mean(2).contiguous(), alpha_a_scale / N, A, upper_only=fused)
         return A
 
-    def _factor_G(self, tap, g, alpha_g, kfac_approx, G, fused=False):
+    def _factor_G(self, tap, g, alpha_g, kfac_approx, G, fused=False, persist=None):
         """``G += alpha * sum g g^T`` (output side; ``g`` is ``[S, B, ...]`` or the unstacked per-seed list)."""
         K = get_kernels()
         m = tap.module
@@ -266,7 +266,7 @@ class _HipCurvatureMixin:
             if isinstance(g, (list, tuple)):
                 K.gram_nt([gs.reshape(B, Do, L) for gs in g], alpha_g, G, upper_only=fused)
             else:
-                K.gram_nt(g.reshape(S * B, Do, L).contiguous(), alpha_g, G, upper_only=fused)
+                K.gram_nt(g.reshape(S * B, Do, L).contiguous(), alpha_g, G, upper_only=fused, persist=persist)
         else:
             if isinstance(g, (list, tuple)):
                 g = torch.stack(g)
@@ -314,6 +314,7 @@ class _HipCurvatureMixin:
             raise ValueError(f"kfac_approx must be 'expand' or 'reduce', got {kfac_approx!r}")
         acc = KronAccumulator(self, N, kfac_approx, overlap=True)
         acc.use_pixgram = False
+        acc._persist_slabs = False
         try:
             acc.add_batch(x, y)
         except NotImplementedError as e:
@@ -384,6 +385,7 @@ class KronAccumulator:
         self.overlap = overlap
         self.use_pixgram = os.environ.get("LK_PIXGRAM", "1") != "0"
         self._defer_bn = os.environ.get("LK_DEFER_BN", "1") != "0"
+        self._persist_slabs = os.environ.get("LK_PERSIST_SLABS", "1") != "0"
         self._side = None
         self.factors = None  # per tap: [G, A]
         self.loss = None
@@ -405,6 +407,8 @@ class KronAccumulator:
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
         self._pix = {}  # tap index -> (geometry, buffer): pixel-pair accumulators of 3x3 convs
         self._gscale = {}  # tap index -> deferred BatchNorm scale owed to the G accumulator
+        self._gslabs = {}  # tap index -> (persistent split-K slabs, n, L, alpha) of a conv G factor
+        self._tap_index = {tap.name: i for i, tap in enumerate(tape.taps)}
 
     def _pix_geometry(self, tap):
         """How this tap's A factor is accumulated over the fit (3x3 / stride 1 / pad 1 convs, ``expand``):
@@ -512,14 +516,15 @@ class KronAccumulator:
 
             def on_tap(name, g):
                 tap, F = by_name[name]
+                persist = self._g_slabs(tap, g, rt * hs)
                 if side is None:
-                    b._factor_G(tap, g, rt * hs, self.kfac_approx, F[0], fused=True)
+                    b._factor_G(tap, g, rt * hs, self.kfac_approx, F[0], fused=True, persist=persist)
                     return
                 ev = torch.cuda.Event()
                 ev.record(main)
                 side.wait_event(ev)
                 with torch.cuda.stream(side):
-                    b._factor_G(tap, g, rt * hs, self.kfac_approx, F[0], fused=True)
+                    b._factor_G(tap, g, rt * hs, self.kfac_approx, F[0], fused=True, persist=persist)
                 g.record_stream(side)  # allocated on the main stream, read on the side stream
 
             grad_fn(seeds, stack=False, on_tap=on_tap, defer_bn_scale=defer)
@@ -532,6 +537,33 @@ class KronAccumulator:
         if side is not None:
             torch.cuda.current_stream(f.device).wait_stream(side)
         tape.release()
+
+    def _g_slabs(self, tap, g, alpha):
+        """Persistent split-K slabs of a conv tap's G factor (``expand``): the partial tiles of every minibatch are
+        accumulated in place (LK_GRAM_SLABS_PERSIST) and reduced ONCE per fit — the sum over minibatches is linear, so
+        the two reduce launches per tap and minibatch disappear.  Allocated on the calling stream; ``None`` = plain
+        per-launch reduction (Linear taps, `reduce`, the literal one-batch path)."""
+        if not self._persist_slabs or tap.kind != "conv2d" or self.kfac_approx != "expand" or g.dim() != 5:
+            return None
+        K = get_kernels()
+        S, B, Do = g.shape[0], g.shape[1], g.shape[2]
+        L = g.shape[3] * g.shape[4]
+        need = K.gram_nt_slab_bytes(S * B, Do, L)
+        idx = self._tap_index[tap.name]
+        cur = self._gslabs.get(idx)
+        if cur is not None and (cur[0].numel() < need or cur[2] != L or cur[3] != alpha):
+            self._flush_g_slabs(only=idx)  # geometry changed within the fit: fold what there is
+            cur = None
+        if cur is None:
+            cur = (torch.zeros(need, dtype=torch.uint8, device=g.device), Do, L, alpha)
+            self._gslabs[idx] = cur
+        return cur[0]
+
+    def _flush_g_slabs(self, only=None):
+        K = get_kernels()
+        for idx in ([only] if only is not None else list(self._gslabs)):
+            buf, n, L, alpha = self._gslabs.pop(idx)
+            K.gram_slabs_reduce(buf, n, L, alpha, self.factors[idx][0], upper_only=True)
 
     def _note_grad_scales(self, tape, scales):
         """Deferred BatchNorm scales (laplace_amd/sweep.py): the G accumulators of these taps hold sums of UNSCALED
@@ -555,6 +587,7 @@ class KronAccumulator:
     def tensors(self) -> list[torch.Tensor]:
         """Everything a data-parallel fit has to all-reduce (upper triangles are what counts)."""
         self._flush_pixgrams()  # the assembled factors are what is exchanged, not the larger pixel-pair Grams
+        self._flush_g_slabs()
         return [t for F in self.factors for t in F] + [self.loss]
 
     def finalize(self):
@@ -562,6 +595,7 @@ class KronAccumulator:
         K = get_kernels()
         rt = math.sqrt(float(self.backend.factor))
         self._flush_pixgrams()
+        self._flush_g_slabs()
         self._apply_grad_scales()
         kfacs = []
         for (G, A), (has_bias, native) in zip(self.factors, self._taps_meta):

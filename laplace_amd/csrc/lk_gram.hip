@@ -62,6 +62,7 @@ struct GramGeom {
   int64_t ldx;  // TN
   const int* tiles;  // TNP: [ntiles][3] = column offset of the A panel, of the B panel, output offset (floats)
   int ldc;           // TNP: leading dimension of an output block
+  int slab_accumulate;  // split-K slabs are persistent accumulators: `slab += partial tile` (LK_GRAM_SLABS_PERSIST)
   int L, Lp;    // NT: positions per image, padded to a multiple of BK
   int seg_nb;   // NT: images per segment
   int nseg;     // NT: number of segments (1 = plain tensor)
@@ -396,17 +397,21 @@ __device__ __forceinline__ void gram_body(const GramGeom& g, float* __restrict__
       }
     return;
   }
-  // epilogue: partial tile -> slab
+  // epilogue: partial tile -> slab (overwritten, or accumulated when the slabs persist across launches)
 #pragma unroll
   for (int tm = 0; tm < TW; ++tm)
 #pragma unroll
-    for (int tn = 0; tn < TW; ++tn)
+    for (int tn = 0; tn < TW; ++tn) {
+      float* base = slab + (wm * C::WT + tm * 32 + 4 * hi) * C::T + wn * C::WT + tn * 32 + lo;
+      float old[16];
+      if (g.slab_accumulate) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * C::WT + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        const int col = wn * C::WT + tn * 32 + lo;
-        slab[row * C::T + col] = acc[tm][tn][r];
+        for (int r = 0; r < 16; ++r) old[r] = base[((r & 3) + 8 * (r >> 2)) * C::T];
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        base[((r & 3) + 8 * (r >> 2)) * C::T] = g.slab_accumulate ? old[r] + acc[tm][tn][r] : acc[tm][tn][r];
+    }
 }
 
 template <int MODE, int VEC, int CFG>
@@ -632,6 +637,9 @@ static GramPlan make_plan_rect(int64_t nA, int64_t nB, int64_t K) {
   return p;
 }
 
+static int reduce_slabs(const GramPlan& p, float* slabs, int nslabs, float alpha, float* C, int n, unsigned flags,
+                        hipStream_t stream);
+
 // Kernels whose dynamic LDS exceeds the 64 KB default need the limit raised once per function.
 static bool allow_big_lds(const void* fn, size_t bytes) {
   if (bytes <= 64 * 1024) return true;
@@ -655,12 +663,15 @@ static int launch_gram(const GramGeom& g, bool vec4, float alpha, float* C, unsi
   float* slabs = static_cast<float*>(ws);
   dim3 grid(p.npairs, p.nsplit), block(256);
   // one split + upper-only accumulation: the kernel adds into C itself (no slab round trip)
-  float* Cdirect = (p.nsplit == 1 && (flags & LK_GRAM_UPPER_ONLY)) ? C : nullptr;
+  const bool persist = (flags & LK_GRAM_SLABS_PERSIST) != 0;
+  float* Cdirect = (!persist && p.nsplit == 1 && (flags & LK_GRAM_UPPER_ONLY)) ? C : nullptr;
+  GramGeom gp = g;
+  gp.slab_accumulate = persist ? 1 : 0;
   const size_t lds = cfg_lds_bytes(p.cfg, !(p.cfg == CFG_SMALL));
 #define LK_LAUNCH(V, S)                                                                                          \
   do {                                                                                                           \
     if (!allow_big_lds((const void*)gram_kernel<MODE, V, S>, lds)) return LK_ELAUNCH;                            \
-    hipLaunchKernelGGL((gram_kernel<MODE, V, S>), grid, block, lds, stream, g, slabs, p.nbt, p.npairs,           \
+    hipLaunchKernelGGL((gram_kernel<MODE, V, S>), grid, block, lds, stream, gp, slabs, p.nbt, p.npairs,          \
                        p.chunks_per_split, p.nchunks, Cdirect, alpha);                                           \
   } while (0)
 #define LK_LAUNCH_V(S)                    \
@@ -678,8 +689,14 @@ static int launch_gram(const GramGeom& g, bool vec4, float alpha, float* C, unsi
 #undef LK_LAUNCH_V
 #undef LK_LAUNCH
   int rc = check_launch("gram_kernel");
-  if (rc || Cdirect != nullptr) return rc;
-  int nslabs = p.nslabs, stride = 1;
+  if (rc || Cdirect != nullptr || persist) return rc;  // persistent slabs are reduced once: lk_gram_slabs_reduce_f32
+  return reduce_slabs(p, slabs, p.nslabs, alpha, C, g.n, flags, stream);
+}
+
+// sum `nslabs` slabs (two-level beyond 32), scale, accumulate into C, mirror off-diagonal tiles
+static int reduce_slabs(const GramPlan& p, float* slabs, int nslabs, float alpha, float* C, int n, unsigned flags,
+                        hipStream_t stream) {
+  int stride = 1;
   const int64_t slab_elems = (int64_t)p.npairs * p.T * p.T;
   if (nslabs > 32) {  // two-level reduction keeps every thread's serial chain short
     const int SG = 32;
@@ -693,7 +710,7 @@ static int launch_gram(const GramGeom& g, bool vec4, float alpha, float* C, unsi
   }
   const int subs = p.T / 64;
   hipLaunchKernelGGL(gram_reduce_kernel, dim3(p.npairs, subs * subs * (64 / p.rpw)), dim3(256), 0, stream, slabs, nslabs,
-                     stride, p.npairs, p.T, p.nbt, alpha, C, g.n, (flags & LK_GRAM_UPPER_ONLY) ? 0 : 1, p.rpw, 0, 0);
+                     stride, p.npairs, p.T, p.nbt, alpha, C, n, (flags & LK_GRAM_UPPER_ONLY) ? 0 : 1, p.rpw, 0, 0);
   return check_launch("gram_reduce_kernel");
 }
 
@@ -998,6 +1015,16 @@ extern "C" size_t lk_gram_nt_workspace_bytes(int64_t nb_total, int64_t n, int64_
   const int BK = cfg_bk(make_plan(n, 1, L).cfg);
   const int64_t Lp = (L + BK - 1) / BK * BK;
   return make_plan(n, nb_total < 1 ? Lp : nb_total * Lp, L).ws_bytes;
+}
+
+extern "C" int lk_gram_slabs_reduce_f32(float* slabs, size_t slabs_bytes, int64_t n, int64_t L_nt, float alpha, float* C,
+                                        unsigned flags, void* stream) {
+  LK_REQUIRE(slabs && C && n > 0 && n < (1 << 30), "lk_gram_slabs_reduce_f32: bad arguments");
+  const GramPlan p = make_plan(n, 1, L_nt);  // tile geometry depends on n (and the NT chunk depth) only
+  const size_t slab_bytes = (size_t)p.npairs * p.T * p.T * sizeof(float);
+  const int nslabs = (int)(slabs_bytes / slab_bytes);
+  LK_REQUIRE(nslabs >= 1, "lk_gram_slabs_reduce_f32: buffer smaller than one slab");
+  return reduce_slabs(p, slabs, nslabs, alpha, C, (int)n, flags, (hipStream_t)stream);
 }
 
 extern "C" int lk_gram_tn_f32(const float* X, int64_t K, int64_t n, int64_t ldx, float alpha, float* C,

@@ -47,10 +47,22 @@ class EmulatedKernels:
         out += alpha * (X.T @ X)
         return out
 
-    def gram_nt(self, X, alpha, out, upper_only=False):
+    def gram_nt_slab_bytes(self, nb_total, n, L) -> int:
+        return n * n * 8  # one "slab" holding the running sum (a float64 view of the uint8 buffer)
+
+    def gram_nt(self, X, alpha, out, upper_only=False, persist=None):
         if isinstance(X, (list, tuple)):
             X = torch.cat(list(X))
-        out += alpha * torch.einsum("bil,bjl->ij", X, X)
+        G = torch.einsum("bil,bjl->ij", X, X)
+        if persist is not None:  # accumulate unscaled partial sums; alpha is applied by gram_slabs_reduce
+            n = G.shape[0]
+            persist[: n * n * 8].view(torch.float64).view(n, n).add_(G.double())
+            return out
+        out += alpha * G
+        return out
+
+    def gram_slabs_reduce(self, slabs, n, L, alpha, out, upper_only=False):
+        out += alpha * slabs[: n * n * 8].view(torch.float64).view(n, n).to(out.dtype)
         return out
 
     def gram_conv(self, x, kernel_size, stride, padding, dilation, alpha, out, upper_only=False, native=False):

@@ -613,3 +613,25 @@ def test_bn_act_forward(K, shape, relu, with_addend):
         assert mask.dtype == torch.bool and torch.equal(mask.cpu(), y.cpu() > 0)
     else:
         assert mask is None
+
+
+@pytest.mark.parametrize("nb,n,L", [(40, 64, 256), (30, 128, 64), (24, 200, 16), (9, 512, 16), (6, 16, 100)])
+def test_gram_nt_persistent_slabs(K, nb, n, L):
+    """Split-K partial tiles accumulated across launches (LK_GRAM_SLABS_PERSIST) and reduced once == the same launches
+    with their own reductions (the sum over minibatches is linear)."""
+    xs = [rnd(nb, n, L, seed=nb + n + L + i) for i in range(3)]
+    want = torch.zeros(n, n, dtype=torch.float64)
+    for x in xs:
+        EMU.gram_nt(x, 0.7, want)
+    slabs = torch.zeros(max(K.gram_nt_slab_bytes(nb, n, L), 1), dtype=torch.uint8, device=DEV)
+    out = torch.zeros(n, n, device=DEV)
+    for x in xs:
+        K.gram_nt(x.float().to(DEV), 0.7, out, upper_only=True, persist=slabs)
+    _sync()
+    assert (out == 0).all(), "persistent mode must not touch C"
+    K.gram_slabs_reduce(slabs, n, L, 0.7, out, upper_only=True)
+    if DEV != "cpu":
+        K.symmetrize(out)
+    _sync()
+    got = out.double().cpu()
+    assert_close(torch.triu(got), torch.triu(want), what="persistent slabs")
