@@ -82,11 +82,12 @@ struct GramGeom {
 constexpr int MAX_REG = 8;
 
 // CFG_BIG24 / CFG_BIG32: the 128x128 tile with deeper chunks (24 / 32 virtual rows per barrier instead of 16)
-enum { CFG_SMALL = 0, CFG_BIG = 1, CFG_WIDE = 2, CFG_BIG24 = 3, CFG_BIG32 = 4 };
+// CFG_SMALL16: the 64x64 tile with 16-row chunks (17 KB of LDS: many resident workgroups for the short MODE_TNP launches)
+enum { CFG_SMALL = 0, CFG_BIG = 1, CFG_WIDE = 2, CFG_BIG24 = 3, CFG_BIG32 = 4, CFG_SMALL16 = 5 };
 template <int CFG>
 struct Cfg {
   static constexpr bool SMALL = (CFG == CFG_SMALL);
-  static constexpr int TW = SMALL ? 1 : (CFG == CFG_WIDE ? 3 : 2);  // MFMA 32x32 tiles per wave along each output dim
+  static constexpr int TW = (SMALL || CFG == CFG_SMALL16) ? 1 : (CFG == CFG_WIDE ? 3 : 2);  // MFMA 32x32 tiles per wave
   static constexpr int WT = 32 * TW;           // wave tile edge
   static constexpr int T = 2 * WT;             // output tile edge (64 / 128 / 192), 4 waves as 2x2
   static constexpr int BK = SMALL ? 64 : (CFG == CFG_BIG24 ? 24 : (CFG == CFG_BIG32 ? 32 : 16));  // rows per chunk
@@ -589,7 +590,7 @@ static void finish_plan(GramPlan& p) {
   p.ws_bytes = (size_t)p.nslabs * p.npairs * p.T * p.T * sizeof(float);
 }
 
-static int cfg_tile(int cfg) { return cfg == CFG_SMALL ? 64 : (cfg == CFG_WIDE ? 192 : 128); }
+static int cfg_tile(int cfg) { return (cfg == CFG_SMALL || cfg == CFG_SMALL16) ? 64 : (cfg == CFG_WIDE ? 192 : 128); }
 static int cfg_bk(int cfg) { return cfg == CFG_SMALL ? 64 : (cfg == CFG_BIG24 ? 24 : (cfg == CFG_BIG32 ? 32 : 16)); }
 // dynamic LDS of one workgroup: [2 buffers][panels][BK][T + 4] floats
 static size_t cfg_lds_bytes(int cfg, bool two_panels) {
@@ -1172,12 +1173,19 @@ extern "C" int lk_conv3x3_pixpair_accumulate_f32(const float* x, int64_t B, int6
   GramGeom g{};
   g.x = x; g.K = B; g.n = (int)(H * W * Cin); g.ldx = H * W * Cin;
   g.tiles = tiles_dev; g.ldc = (int)Cin;
-  const int cfg = T == 64 ? CFG_SMALL : CFG_BIG;
+  static const bool small16 = [] {
+    const char* e = getenv("LK_TNP_SMALL16");  // tuning knob
+    return !(e && atoi(e) == 0);
+  }();
+  const int cfg = T == 64 ? (small16 ? CFG_SMALL16 : CFG_SMALL) : CFG_BIG;
   const int nchunks = (int)((B + cfg_bk(cfg) - 1) / cfg_bk(cfg));
   const size_t lds = cfg_lds_bytes(cfg, true);
   dim3 grid((unsigned)n_tiles, 1), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (cfg == CFG_SMALL) {
+  if (cfg == CFG_SMALL16) {
+    hipLaunchKernelGGL((gram_kernel<MODE_TNP, 4, CFG_SMALL16>), grid, block, lds, st, g, (float*)nullptr, 1, (int)n_tiles,
+                       nchunks, nchunks, blocks, alpha);
+  } else if (cfg == CFG_SMALL) {
     if (!allow_big_lds((const void*)gram_kernel<MODE_TNP, 4, CFG_SMALL>, lds)) return LK_ELAUNCH;
     hipLaunchKernelGGL((gram_kernel<MODE_TNP, 4, CFG_SMALL>), grid, block, lds, st, g, (float*)nullptr, 1, (int)n_tiles, nchunks,
                        nchunks, blocks, alpha);
