@@ -12,7 +12,27 @@ from __future__ import annotations
 import torch
 from torch import nn
 
-FIXTURES = ("mlp", "conv", "resnetish")
+FIXTURES = ("mlp", "conv", "resnetish", "bnres")
+
+
+class _BNResBlock(nn.Module):
+    """torchvision-style BasicBlock: conv-BN-ReLU(in place)-conv-BN, `out += identity`, ReLU; BatchNorm in eval mode with
+    non-trivial running statistics and frozen affine parameters (the reference's KFAC covers Linear / Conv2d only)."""
+
+    def __init__(self, c: int):
+        super().__init__()
+        self.conv1 = nn.Conv2d(c, c, 3, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(c)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(c, c, 3, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(c)
+
+    def forward(self, x):
+        identity = x
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        out += identity
+        return self.relu(out)
 
 
 def build_model(name: str) -> nn.Module:
@@ -31,15 +51,27 @@ def build_model(name: str) -> nn.Module:
             nn.Flatten(),
             nn.Linear(36, 3),
         )
+    if name == "bnres":
+        model = nn.Sequential(nn.Conv2d(2, 4, 3, padding=1), _BNResBlock(4), nn.AdaptiveAvgPool2d(1), nn.Flatten(),
+                              nn.Linear(4, 3))
+        for m in model.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.running_mean.normal_(0.0, 0.5)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.data.uniform_(0.5, 1.5)
+                m.bias.data.normal_(0.0, 0.3)
+                m.weight.requires_grad_(False)
+                m.bias.requires_grad_(False)
+        return model.eval()
     raise KeyError(name)
 
 
 def input_shape(name: str):
-    return {"mlp": (3,), "conv": (3, 5, 5), "resnetish": (2, 5, 5)}[name]
+    return {"mlp": (3,), "conv": (3, 5, 5), "resnetish": (2, 5, 5), "bnres": (2, 4, 4)}[name]
 
 
 def n_outputs(name: str) -> int:
-    return 3 if name == "resnetish" else 2
+    return 3 if name in ("resnetish", "bnres") else 2
 
 
 def make_fixture(name: str, dtype=torch.float64, batch: int = 10, seed: int = 711):
