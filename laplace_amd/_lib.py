@@ -428,7 +428,7 @@ class HipKernels:
         self._rc(self.lib.lk_sq_colsum_f32(_ptr(Js), rows, P, int(col0), int(width), float(alpha), _ptr(h),
                                            self._stream(Js.device)), "lk_sq_colsum_f32")
 
-    def bn_act_forward(self, x, scale, shift, relu, addend=None):
+    def bn_act_forward(self, x, scale, shift, relu, addend=None, want_mask=True):
         """``(y, mask)``: ``y = act(x * scale[c] + shift[c] + addend)`` for ``x`` [B, C, ...]; ``mask = y > 0`` (bool) if
         ``relu``."""
         _check(x, "x")
@@ -439,7 +439,7 @@ class HipKernels:
         C = x.shape[1]
         hw = x.numel() // (x.shape[0] * C) if x.numel() else 1
         y = torch.empty_like(x)
-        mask = torch.empty(x.shape, dtype=torch.bool, device=x.device) if relu else None
+        mask = torch.empty(x.shape, dtype=torch.bool, device=x.device) if (relu and want_mask) else None
         self._rc(self.lib.lk_bn_act_fwd_f32(_ptr(x), _ptr(scale.to(torch.float32).contiguous()),
                                             _ptr(shift.to(torch.float32).contiguous()), _ptr(addend), x.numel(), C, max(hw, 1),
                                             1 if relu else 0, _ptr(y), _ptr(mask), self._stream(x.device)),

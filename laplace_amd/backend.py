@@ -57,8 +57,12 @@ class _HipCurvatureMixin:
         tape = self._tape()
         if self.last_layer:
             # f = last_layer(phi): the gradient w.r.t. the head's output IS the seed -> no reverse pass
-            with torch.no_grad():
-                f, phi = self.model.forward_with_features(x)
+            swept = self._features_swept(x, tape)
+            if swept is not None:
+                f, phi = swept
+            else:
+                with torch.no_grad():
+                    f, phi = self.model.forward_with_features(x)
             if len(tape.taps) != 1 or tape.taps[0].kind != "linear":
                 raise NotImplementedError("last-layer mode needs an nn.Linear head")
             tape.taps[0].a = phi.detach()
@@ -84,6 +88,31 @@ class _HipCurvatureMixin:
     #: the largest activation are assumed); more seeds are processed in chunks
     sweep_max_rows = 8192
     sweep_mem_bytes = 16 << 30
+
+    def _features_swept(self, x, tape):
+        """Feature pass of the last-layer flavours through the sweep's own forward (fused eval-BatchNorm / residual /
+        ReLU kernels) when the wrapped model is fx-traceable; ``None`` -> ``forward_with_features`` of the extractor."""
+        inner = getattr(self.model, "model", None)
+        name = getattr(self.model, "_last_layer_name", None)
+        if (not self.use_sweep or not torch.is_tensor(x) or not isinstance(inner, nn.Module) or name is None
+                or not x.is_floating_point()):
+            return None
+        fs = getattr(tape, "feature_sweep", None)
+        if fs is None:
+            try:
+                fs = SeedBatchedSweep(inner, {name: dict(inner.named_modules())[name]}, kernels=get_kernels)
+            except (SweepUnsupported, KeyError):
+                fs = False
+            tape.feature_sweep = fs
+        if fs is False:
+            return None
+        try:
+            f = fs.forward(x, need_vjp=False)
+        except SweepUnsupported:
+            return None
+        phi = fs.taps[name]["a"]
+        fs.release()
+        return f, phi
 
     def _forward_swept(self, x, tape):
         """Seed-batched reverse sweep (laplace_amd/sweep.py) when the model is fx-traceable and built from

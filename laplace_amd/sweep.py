@@ -101,8 +101,10 @@ class SeedBatchedSweep:
 
     # ---- forward ---------------------------------------------------------------------------------------
     @torch.no_grad()
-    def forward(self, x: torch.Tensor):
-        """Returns ``f``; fills ``self.saved`` (per node: what the VJP needs) and ``self.taps[name]['a']``."""
+    def forward(self, x: torch.Tensor, need_vjp: bool = True):
+        """Returns ``f``; fills ``self.saved`` (per node: what the VJP needs) and ``self.taps[name]['a']``.
+        ``need_vjp=False``: inference only (the feature pass of the last-layer flavours) — nothing is kept for a
+        reverse sweep, only the tapped inputs."""
         if self.gm.training or any(m.training for m in self.gm.modules() if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d, nn.Dropout))):
             raise SweepUnsupported("model must be in eval mode (BatchNorm / Dropout VJPs assume it)")
         env: dict[fx.Node, Any] = {}
@@ -130,7 +132,7 @@ class SeedBatchedSweep:
                     out, idx = F.max_pool2d(inp, m.kernel_size, m.stride, m.padding, m.dilation, m.ceil_mode, True)
                     self.saved[node] = (idx, inp.shape)
                 elif isinstance(m, self._GENERIC_ACT_MODULES):
-                    out, self.saved[node] = self._with_derivative(m, inp)
+                    out, self.saved[node] = self._with_derivative(m, inp) if need_vjp else (m(inp), None)
                 elif (isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d)) and self.kernels is not None and inp.dim() >= 2
                       and inp.dtype == torch.float32 and m.running_var is not None):
                     # eval-mode BatchNorm = per-channel affine map: one fused launch, with the ReLU that follows it
@@ -146,7 +148,8 @@ class SeedBatchedSweep:
                             addend, add_node = env[other].contiguous(), nxt
                             nxt = next(iter(add_node.users)) if len(add_node.users) == 1 else None
                     relu = nxt is not None and self._is_plain_relu(nxt) and nxt.args[0] is (add_node or node)
-                    out, mask = self.kernels().bn_act_forward(inp.contiguous(), scale, shift, relu, addend)
+                    out, mask = self.kernels().bn_act_forward(inp.contiguous(), scale, shift, relu, addend,
+                                                              want_mask=need_vjp)
                     if add_node is not None:
                         fused_relu[add_node] = (out, None)  # (the add node itself keeps nothing for its VJP)
                     if relu:
@@ -154,7 +157,7 @@ class SeedBatchedSweep:
                 else:
                     out = m(inp)
                     if isinstance(m, (nn.ReLU,)):
-                        self.saved[node] = out > 0
+                        self.saved[node] = (out > 0) if need_vjp else None
                     elif isinstance(m, (nn.Tanh, nn.Sigmoid)):
                         self.saved[node] = out
                     elif isinstance(m, (nn.AdaptiveAvgPool2d, nn.AvgPool2d, nn.Flatten)):
@@ -192,11 +195,14 @@ class SeedBatchedSweep:
                     out = args[0] + args[1]
                 elif node.target in self._GENERIC_ACT_FN:
                     kwargs.pop("inplace", None)
-                    out, self.saved[node] = self._with_derivative(lambda t: node.target(t, *args[1:], **kwargs), args[0])
+                    if need_vjp:
+                        out, self.saved[node] = self._with_derivative(lambda t: node.target(t, *args[1:], **kwargs), args[0])
+                    else:
+                        out = node.target(*args, **kwargs)
                 else:
                     out = node.target(*args, **kwargs)
                 if node.target in (torch.relu, F.relu):
-                    self.saved[node] = out > 0
+                    self.saved[node] = (out > 0) if need_vjp else None
                 elif node.target in (torch.tanh, F.tanh, torch.sigmoid, F.sigmoid):
                     self.saved[node] = out
                 elif node.target is torch.flatten:
@@ -213,12 +219,14 @@ class SeedBatchedSweep:
                         raise SweepUnsupported("mean over dims other than the two spatial ones")
                     self.saved[node] = (self_t.shape, bool(kwargs.get("keepdim", args[1] if len(args) > 1 else False)))
                 if node.target == "relu":
-                    self.saved[node] = out > 0
+                    self.saved[node] = (out > 0) if need_vjp else None
                 elif node.target in ("tanh", "sigmoid"):
                     self.saved[node] = out
                 elif node.target in ("view", "reshape", "flatten"):
                     self.saved[node] = self_t.shape
                 env[node] = out
+        if not need_vjp:
+            self.saved = {}
         nb = max(int(x.shape[0]), 1)
         for v in env.values():
             if torch.is_tensor(v):

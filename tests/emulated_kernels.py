@@ -120,14 +120,14 @@ class EmulatedKernels:
         P = Js.shape[-1]
         h += alpha * (Js.reshape(-1, P)[:, col0:col0 + width] ** 2).sum(0)
 
-    def bn_act_forward(self, x, scale, shift, relu, addend=None):
+    def bn_act_forward(self, x, scale, shift, relu, addend=None, want_mask=True):
         shape = (1, -1) + (1,) * (x.dim() - 2)
         y = x * scale.reshape(shape).to(x.dtype) + shift.reshape(shape).to(x.dtype)
         if addend is not None:
             y = y + addend
         if relu:
             y = y.clamp_min(0)
-            return y, y > 0
+            return y, (y > 0 if want_mask else None)
         return y, None
 
     def vjp_scale_mask(self, g, S, mult, scale, hw, g2=None):
