@@ -232,6 +232,20 @@ int lk_kron_logdet_f32(const float* l1, int64_t n1, const float* l2, int64_t n2,
                        int damping, float* out, float* d_l1, float* d_l2, float* d_delta, void* ws,
                        size_t ws_bytes, void* stream);
 
+/* The whole posterior precision in one pass: every block of a KronDecomposed (matrix.py:381-404 loops over the blocks;
+ * the marginal-likelihood sweep, baselaplace.py:466-485 and marglik_training.py:303-314, calls it once per step):
+ *   out[0]      += sum_b sum_ij log(s * l1[b]_i l2[b]_j + delta[b])      (n2[b] == 0: sum_i log(s * l1[b]_i + delta[b]))
+ *   d_delta[b]  += sum_ij 1 / (.)                                         (may be NULL)
+ *   d_scale[0]  += sum_b sum_ij l1[b]_i l2[b]_j / (.)                     (may be NULL)
+ * s = scale[0] is the scalar H_factor = 1/(sigma^2 T) of `H * H_factor + delta` (baselaplace.py:1820), applied to the
+ * eigenvalue PRODUCT (matrix.py:366-376 splits it as s^(1/2) per factor); scale == NULL means 1.
+ * l1, n1, l2, n2 are HOST arrays of nblocks entries (device pointers / lengths); delta, scale, out, d_* are DEVICE
+ * memory (delta has nblocks entries).  Three launches per 32 blocks, fixed-order fp64 reduction: deterministic. */
+size_t lk_kron_logdet_blocks_workspace_bytes(int64_t total_rows /* sum_b n1[b] */, int64_t nblocks);
+int lk_kron_logdet_blocks_f32(int64_t nblocks, const float* const* l1, const int64_t* n1, const float* const* l2,
+                              const int64_t* n2, const float* delta, const float* scale, float* out, float* d_delta,
+                              float* d_scale, void* ws, size_t ws_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * GLM predictive variances  f_var[n] = J_n Sigma J_n^T  without materialising J (V1-V3).
  * ------------------------------------------------------------------------------------------- */

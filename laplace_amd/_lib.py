@@ -73,6 +73,8 @@ SIGNATURES = {
     "lk_syevj_batched_f32": (_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _vp, _i64]),
     "lk_kron_logdet_workspace_bytes": (_sz, [_i64]),
     "lk_kron_logdet_f32": (_int, [_vp, _i64, _vp, _i64, _vp, _int, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "lk_kron_logdet_blocks_workspace_bytes": (_sz, [_i64, _i64]),
+    "lk_kron_logdet_blocks_f32": (_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "lk_kron_quadform_linear_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "lk_diag_quadform_linear_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "lk_diag_quadform_js_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
@@ -578,6 +580,36 @@ class HipKernels:
             "lk_kron_logdet_f32",
         )
         return out, d1, d2, dd
+
+    def kron_logdet_blocks(self, blocks, deltas, scale=None, want_grads=False):
+        """``blocks``: list of ``(l1,)`` / ``(l1, l2)`` eigenvalue vectors; ``deltas [len(blocks)]``; ``scale [1]`` or
+        None.  Returns ``(value[1], d_deltas or None, d_scale or None)`` -- the whole posterior in three launches."""
+        nb = len(blocks)
+        _check(deltas, "deltas")
+        if deltas.numel() != nb:
+            raise ValueError("kron_logdet_blocks: one delta per block")
+        dev = deltas.device
+        for ls in blocks:
+            for l in ls:
+                _check(l, "eigenvalues")
+        if scale is not None:
+            _check(scale, "scale")
+        PA, LA = ctypes.c_void_p * nb, ctypes.c_int64 * nb
+        l1 = PA(*[ls[0].data_ptr() for ls in blocks])
+        l2 = PA(*[(ls[1].data_ptr() if len(ls) == 2 else None) for ls in blocks])
+        n1 = LA(*[ls[0].numel() for ls in blocks])
+        n2 = LA(*[(ls[1].numel() if len(ls) == 2 else 0) for ls in blocks])
+        out = torch.zeros(1, dtype=torch.float32, device=dev)
+        dd = torch.zeros(nb, dtype=torch.float32, device=dev) if want_grads else None
+        ds = torch.zeros(1, dtype=torch.float32, device=dev) if want_grads and scale is not None else None
+        nbytes = self.lib.lk_kron_logdet_blocks_workspace_bytes(sum(n1), nb)
+        ws = self._workspace(nbytes, dev)
+        self._rc(
+            self.lib.lk_kron_logdet_blocks_f32(nb, l1, n1, l2, n2, _ptr(deltas), _ptr(scale), _ptr(out), _ptr(dd), _ptr(ds),
+                                               _ptr(ws), ws.numel(), self._stream(dev)),
+            "lk_kron_logdet_blocks_f32",
+        )
+        return out, dd, ds
 
     # ---- predictive ---------------------------------------------------------------------------
     def kron_quadform_linear(self, u, v, l1, l2, delta, fvar, ub=None, lb=None, delta_b=None):

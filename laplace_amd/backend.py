@@ -37,6 +37,18 @@ from laplace_amd.kron import HipKron
 from laplace_amd.refapi import EFInterface, GGNInterface
 
 
+class CachedFeatures:
+    """Head input ``phi [B, D]`` and output ``f [B, C]`` of one batch; accepted wherever a last-layer backend takes ``x``."""
+
+    __slots__ = ("f", "phi")
+
+    def __init__(self, f: torch.Tensor, phi: torch.Tensor):
+        self.f, self.phi = f, phi
+
+    def __len__(self):
+        return self.f.shape[0]
+
+
 class _HipCurvatureMixin:
     """Shared machinery of :class:`HipGGN` and :class:`HipEF`."""
 
@@ -57,7 +69,7 @@ class _HipCurvatureMixin:
         tape = self._tape()
         if self.last_layer:
             # f = last_layer(phi): the gradient w.r.t. the head's output IS the seed -> no reverse pass
-            swept = self._features_swept(x, tape)
+            swept = (x.f, x.phi) if isinstance(x, CachedFeatures) else self._features_swept(x, tape)
             if swept is not None:
                 f, phi = swept
             else:
@@ -88,6 +100,16 @@ class _HipCurvatureMixin:
     #: the largest activation are assumed); more seeds are processed in chunks
     sweep_max_rows = 8192
     sweep_mem_bytes = 16 << 30
+
+    def cache_features(self, x) -> "CachedFeatures":
+        """One feature pass of a last-layer flavour, kept for repeated predictives on the same batch (the prior
+        gridsearch evaluates 100 posteriors on every validation batch; the backbone output does not depend on them)."""
+        if not self.last_layer:
+            raise NotImplementedError("feature caching is for the last-layer flavours")
+        f, tape, _ = self._forward(x)
+        phi = tape.taps[0].a
+        tape.taps[0].a = None
+        return CachedFeatures(f, phi)
 
     def _features_swept(self, x, tape):
         """Feature pass of the last-layer flavours through the sweep's own forward (fused eval-BatchNorm / residual /

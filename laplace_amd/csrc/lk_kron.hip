@@ -86,6 +86,115 @@ __global__ __launch_bounds__(256) void logdet_final_kernel(const float* __restri
   }
 }
 
+// ---- whole-posterior logdet: every block of a KronDecomposed in one pass -------------------------------------------
+// sum_b sum_ij log(s * l1_i l2_j + delta_b), with d/d delta_b and d/d s, s = the scalar the posterior precision carries
+// (H * H_factor, baselaplace.py:1820).  Up to LOGDET_BLOCKS blocks travel in the kernel arguments per launch.
+constexpr int LOGDET_BLOCKS = 32;
+struct LogdetBlocks {
+  const float* l1[LOGDET_BLOCKS];
+  const float* l2[LOGDET_BLOCKS];
+  int n1[LOGDET_BLOCKS];
+  int n2[LOGDET_BLOCKS];
+  int row0[LOGDET_BLOCKS + 1];  // first row of block b in the workspace (rows of all launches are concatenated)
+  int wg0[LOGDET_BLOCKS + 1];   // first workgroup of block b within this launch
+  int count;
+  int block0;                   // index of this launch's first block in delta / d_delta
+};
+
+// one wave per eigenvalue l1_i of its block: partial sums over j of log, 1/(.), l1 l2/(.)
+__global__ __launch_bounds__(256) void logdet_blocks_rows_kernel(LogdetBlocks tb, const float* __restrict__ delta,
+                                                                 const float* __restrict__ scale,
+                                                                 float* __restrict__ rows) {
+  int b = 0;
+  while (b + 1 < tb.count && (int)blockIdx.x >= tb.wg0[b + 1]) ++b;
+  const int lane = threadIdx.x & 63;
+  const int i = ((int)blockIdx.x - tb.wg0[b]) * 4 + (threadIdx.x >> 6);
+  const int n1 = tb.n1[b], n2 = tb.n2[b];
+  if (i >= n1) return;
+  const float d = delta[tb.block0 + b];
+  const float s = scale != nullptr ? scale[0] : 1.f;
+  const float a = tb.l1[b][i];
+  float slog = 0.f, sdd = 0.f, sds = 0.f;
+  if (n2 == 0) {
+    if (lane == 0) {
+      const float inv = 1.f / (s * a + d);
+      slog = logf(s * a + d);
+      sdd = inv;
+      sds = a * inv;
+    }
+  } else {
+    const float* __restrict__ l2 = tb.l2[b];
+    for (int j = lane; j < n2; j += 64) {
+      const float lam = a * l2[j];
+      const float v = s * lam + d;
+      const float inv = 1.f / v;
+      slog += logf(v);
+      sdd += inv;
+      sds += lam * inv;
+    }
+  }
+  slog = wave_sum(slog);
+  sdd = wave_sum(sdd);
+  sds = wave_sum(sds);
+  if (lane == 0) {
+    float* r = rows + 3 * (size_t)(tb.row0[b] + i);
+    r[0] = slog;
+    r[1] = sdd;
+    r[2] = sds;
+  }
+}
+
+// one workgroup per block: fixed-order fp64 reduction of its rows -> per-block (log, d_delta, d_scale)
+__global__ __launch_bounds__(256) void logdet_blocks_reduce_kernel(LogdetBlocks tb, const float* __restrict__ rows,
+                                                                   double* __restrict__ per_block,
+                                                                   float* __restrict__ d_delta) {
+  __shared__ double red[3][256];
+  const int b = blockIdx.x;
+  double acc[3] = {0.0, 0.0, 0.0};
+  for (int i = threadIdx.x; i < tb.n1[b]; i += 256) {
+    const float* r = rows + 3 * (size_t)(tb.row0[b] + i);
+    acc[0] += (double)r[0];
+    acc[1] += (double)r[1];
+    acc[2] += (double)r[2];
+  }
+  for (int q = 0; q < 3; ++q) red[q][threadIdx.x] = acc[q];
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s)
+      for (int q = 0; q < 3; ++q) red[q][threadIdx.x] += red[q][threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    per_block[2 * (tb.block0 + b)] = red[0][0];
+    per_block[2 * (tb.block0 + b) + 1] = red[2][0];
+    if (d_delta != nullptr) d_delta[tb.block0 + b] += (float)red[1][0];
+  }
+}
+
+__global__ __launch_bounds__(256) void logdet_blocks_total_kernel(const double* __restrict__ per_block, int nblocks,
+                                                                  float* __restrict__ out, float* __restrict__ d_scale) {
+  __shared__ double red[2][256];
+  double a = 0.0, c = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += 256) {
+    a += per_block[2 * b];
+    c += per_block[2 * b + 1];
+  }
+  red[0][threadIdx.x] = a;
+  red[1][threadIdx.x] = c;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + s];
+      red[1][threadIdx.x] += red[1][threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] += (float)red[0][0];
+    if (d_scale != nullptr) d_scale[0] += (float)red[1][0];
+  }
+}
+
 // ---- predictive variance of one nn.Linear layer ------------------------------------------------------
 // fvar[n][c][k] += sum_o u[c][n][o] u[k][n][o] * wgt[n][o],  wgt[n][o] = sum_i v[n][i]^2 * W(o,i)
 //   MODE 0 (Kron):  W(o,i) = 1 / (l1[o]*l2[i] + delta)         u,v = eigenbasis projections
@@ -185,6 +294,59 @@ extern "C" int lk_kron_logdet_f32(const float* l1, int64_t n1, const float* l2, 
                        (int)n2, delta, d_l2);
   hipLaunchKernelGGL(logdet_final_kernel, dim3(1), dim3(256), 0, stream, row_log, row_dd, (int)n1, out, d_delta);
   return check_launch("lk_kron_logdet_f32");
+}
+
+extern "C" size_t lk_kron_logdet_blocks_workspace_bytes(int64_t total_rows, int64_t nblocks) {
+  if (total_rows < 0 || nblocks < 0) return 0;
+  return align_up((size_t)total_rows * 3 * sizeof(float), 256) + (size_t)nblocks * 2 * sizeof(double);
+}
+
+extern "C" int lk_kron_logdet_blocks_f32(int64_t nblocks, const float* const* l1, const int64_t* n1,
+                                         const float* const* l2, const int64_t* n2, const float* delta,
+                                         const float* scale, float* out, float* d_delta, float* d_scale, void* ws,
+                                         size_t ws_bytes, void* stream_) {
+  LK_REQUIRE(nblocks >= 0 && out && (nblocks == 0 || (l1 && n1 && l2 && n2 && delta)),
+             "lk_kron_logdet_blocks_f32: bad arguments");
+  if (nblocks == 0) return LK_OK;
+  int64_t total_rows = 0;
+  for (int64_t b = 0; b < nblocks; ++b) {
+    LK_REQUIRE(l1[b] && n1[b] >= 1 && n2[b] >= 0 && (n2[b] == 0 || l2[b]) && n1[b] < (1ll << 30) && n2[b] < (1ll << 30),
+               "lk_kron_logdet_blocks_f32: bad block");
+    total_rows += n1[b];
+  }
+  LK_REQUIRE(total_rows < (1ll << 30), "lk_kron_logdet_blocks_f32: too many eigenvalues");
+  if (ws == nullptr || ws_bytes < lk_kron_logdet_blocks_workspace_bytes(total_rows, nblocks)) {
+    set_error("lk_kron_logdet_blocks_f32: workspace too small");
+    return LK_EWORKSPACE;
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  float* rows = static_cast<float*>(ws);
+  double* per_block =
+      reinterpret_cast<double*>(static_cast<char*>(ws) + align_up((size_t)total_rows * 3 * sizeof(float), 256));
+  int row = 0;
+  for (int64_t b0 = 0; b0 < nblocks; b0 += LOGDET_BLOCKS) {
+    LogdetBlocks tb;
+    tb.count = (int)(nblocks - b0 < LOGDET_BLOCKS ? nblocks - b0 : LOGDET_BLOCKS);
+    tb.block0 = (int)b0;
+    int wg = 0;
+    for (int b = 0; b < tb.count; ++b) {
+      tb.l1[b] = l1[b0 + b];
+      tb.l2[b] = l2[b0 + b];
+      tb.n1[b] = (int)n1[b0 + b];
+      tb.n2[b] = (int)n2[b0 + b];
+      tb.row0[b] = row;
+      tb.wg0[b] = wg;
+      row += tb.n1[b];
+      wg += (tb.n1[b] + 3) / 4;
+    }
+    tb.row0[tb.count] = row;
+    tb.wg0[tb.count] = wg;
+    hipLaunchKernelGGL(logdet_blocks_rows_kernel, dim3((unsigned)wg), dim3(256), 0, stream, tb, delta, scale, rows);
+    hipLaunchKernelGGL(logdet_blocks_reduce_kernel, dim3((unsigned)tb.count), dim3(256), 0, stream, tb, rows, per_block,
+                       d_delta);
+  }
+  hipLaunchKernelGGL(logdet_blocks_total_kernel, dim3(1), dim3(256), 0, stream, per_block, (int)nblocks, out, d_scale);
+  return check_launch("lk_kron_logdet_blocks_f32");
 }
 
 template <int MODE>

@@ -288,8 +288,38 @@ class _KronLogdet(torch.autograd.Function):
         return grad * d1, (grad * d2 if d2 is not None else None), (grad * dd).reshape(ctx.delta_shape)
 
 
+class _KronLogdetBlocks(torch.autograd.Function):
+    """``sum_b sum_ij log(s * l1_i l2_j + delta_b)`` over all blocks of a :class:`HipKronDecomposed` in one
+    ``lk_kron_logdet_blocks_f32`` call; differentiable in the per-block deltas (the prior precision)."""
+
+    @staticmethod
+    def forward(ctx, deltas, post):
+        need = deltas.requires_grad
+        d = deltas.detach().to(torch.float32).contiguous()
+        s = post._scale
+        if s is not None:
+            s = (s if torch.is_tensor(s) else torch.tensor(s)).to(device=d.device, dtype=torch.float32).reshape(1)
+        blocks = [tuple(l.contiguous() for l in ls) for ls in post._base_eigenvalues]
+        val, dd, _ = get_kernels().kron_logdet_blocks(blocks, d, s, want_grads=need)
+        ctx.need = need
+        ctx.dtype = deltas.dtype
+        if need:
+            ctx.save_for_backward(dd)
+        return val.reshape(()).to(deltas.dtype)
+
+    @staticmethod
+    def backward(ctx, grad):
+        if not ctx.need:
+            return None, None
+        (dd,) = ctx.saved_tensors
+        return (grad * dd).to(ctx.dtype), None
+
+
 class HipKronDecomposed(_KronDecomposedBase):
     """Eigendecomposed Kronecker factors + per-block additive ``deltas`` (matrix.py:282-560)."""
+
+    #: ``False`` evaluates ``logdet`` block by block (``lk_kron_logdet_f32``; A/B switch for tools/marglik_bench.py)
+    fused_logdet = True
 
     def __init__(self, eigenvectors, eigenvalues, deltas: torch.Tensor | None = None, damping: bool = False):
         self.eigenvectors = eigenvectors
@@ -302,6 +332,24 @@ class HipKronDecomposed(_KronDecomposedBase):
             self.deltas = deltas
         self.damping = damping
         self._eig_info = []
+
+    # ``H * scalar`` (matrix.py:366-376) is kept as a pending scalar on the eigenvalue PRODUCT of every block: the
+    # fused logdet takes it as a kernel argument, everything else sees the materialised ``scalar^(1/len) * l``.
+    @property
+    def eigenvalues(self):
+        if self._scale is None:
+            return self._base_eigenvalues
+        if self._scaled is None:
+            s = self._scale
+            self._scaled = [[(s ** (1 / len(ls)) if torch.is_tensor(s) else pow(s, 1 / len(ls))) * l for l in ls]
+                            for ls in self._base_eigenvalues]
+        return self._scaled
+
+    @eigenvalues.setter
+    def eigenvalues(self, value):
+        self._base_eigenvalues = value
+        self._scale = None
+        self._scaled = None
 
     def check_converged(self) -> None:
         """Raise (never ``exit()``, cf. utils/utils.py:208-222) if an eigensolve ran out of sweeps.
@@ -321,19 +369,22 @@ class HipKronDecomposed(_KronDecomposedBase):
             return
         raise ValueError("Invalid shape of delta added to KronDecomposed.")
 
-    def _like(self, eigenvalues, deltas):
-        out = HipKronDecomposed(self.eigenvectors, eigenvalues, deltas, self.damping)
+    def _like(self, deltas, scale=None):
+        out = HipKronDecomposed(self.eigenvectors, self._base_eigenvalues, deltas, self.damping)
+        out._scale = scale
         out._eig_info = self._eig_info
         return out
 
     def __add__(self, deltas: torch.Tensor):
         self._check_deltas(deltas)
-        return self._like(self.eigenvalues, self.deltas + deltas)
+        return self._like(self.deltas + deltas, self._scale)
 
     def __mul__(self, scalar):
         if not _is_valid_scalar(scalar):
             raise ValueError("Invalid argument, can only multiply Kron with scalar.")
-        return self._like([[pow(scalar, 1 / len(ls)) * l for l in ls] for ls in self.eigenvalues], self.deltas)
+        # the reference's math.pow (matrix.py:373) takes the VALUE of a tensor scalar: no gradient flows through it
+        s = scalar.detach().reshape(()) if torch.is_tensor(scalar) else float(scalar)
+        return self._like(self.deltas, s if self._scale is None else self._scale * s)
 
     __radd__ = __add__
     __rmul__ = __mul__
@@ -343,6 +394,12 @@ class HipKronDecomposed(_KronDecomposedBase):
 
     # -- logdet (matrix.py:381-404) on HIP ----------------------------------------------------------
     def logdet(self) -> torch.Tensor:
+        base = self._base_eigenvalues
+        fused = (self.fused_logdet and not self.damping and self.deltas.ndim == 1 and len(self.deltas) == len(base)
+                 and all(len(ls) in (1, 2) for ls in base)
+                 and all(l.dtype == torch.float32 and l.ndim == 1 and not l.requires_grad for ls in base for l in ls))
+        if fused:  # every block in one pass (three launches), differentiable in the deltas
+            return _KronLogdetBlocks.apply(self.deltas, self)
         total = 0
         for ls, delta in zip(self.eigenvalues, self.deltas):
             if len(ls) == 1:

@@ -233,7 +233,8 @@ class _HipLaplace:
 
     def optimize_prior_precision(self, n_steps: int = 100, lr: float = 1e-1, init_prior_prec=1.0):
         """Marginal-likelihood optimisation of a scalar / layer-wise prior precision with Adam
-        (the 'marglik' branch of baselaplace.py:466-485); every step is one HIP ``logdet`` per block."""
+        (the 'marglik' branch of baselaplace.py:466-485); every step is one ``lk_kron_logdet_blocks_f32`` call over
+        all blocks of the posterior (Kron flavours), with the analytic derivative in the prior precision."""
         init = torch.as_tensor(init_prior_prec, device=self._device, dtype=self._dtype).reshape(-1)
         log_pp = init.log().clone().requires_grad_(True)
         opt = torch.optim.Adam([log_pp], lr=lr)
@@ -410,23 +411,38 @@ class _HipLaplace:
         """Pick the scalar prior precision of ``logspace(min, max, grid_size)`` with the best validation loss
         (default: NLL for classification, MSE for regression, as the reference's ``RunningNLLMetric`` /
         ``MeanSquaredError``).  A grid point whose posterior is not positive definite scores ``inf``."""
+        from collections.abc import MutableMapping
+
+        from .backend import CachedFeatures
+
+        def batches():
+            for data in val_loader:
+                if isinstance(data, MutableMapping):  # HuggingFace-style batch: labels under dict_key_y
+                    yield data, data[self.backend.dict_key_y].to(self._device)
+                else:
+                    yield data[0].to(self._device), data[1].to(self._device)
+
+        cached = None
+        if self.subset_of_weights == "last_layer" and pred_type == "glm" and self.backend.last_layer:
+            # the backbone does not depend on the prior: one feature pass per validation batch for the whole grid
+            cached = [(self.backend.cache_features(X), y) for X, y in batches()]
         interval = torch.logspace(log_prior_prec_min, log_prior_prec_max, grid_size)
         results = []
         for pp in interval:
             self.prior_precision = pp
             try:
-                tot, cnt = 0.0, 0
-                for X, y in val_loader:
-                    X, y = X.to(self._device), y.to(self._device)
+                tot = torch.zeros((), dtype=torch.float64, device=self._device)
+                cnt = 0
+                for X, y in (cached if cached is not None else batches()):
                     out = self(X, pred_type=pred_type, link_approx=link_approx, n_samples=n_samples)
                     if loss is not None:
-                        tot += float(loss(out, y)) * len(y)
+                        tot += loss(out, y) * len(y)
                     elif self.likelihood == "regression":
-                        tot += float(((out[0] - y.reshape(out[0].shape)) ** 2).sum())
+                        tot += ((out[0] - y.reshape(out[0].shape)) ** 2).sum()
                     else:
-                        tot += float(-torch.log(out[torch.arange(len(y)), y.long()].clamp_min(1e-30)).sum())
+                        tot += -torch.log(out[torch.arange(len(y), device=y.device), y.long()].clamp_min(1e-30)).sum()
                     cnt += len(y)
-                res = tot / max(cnt, 1)
+                res = float(tot) / max(cnt, 1)  # the one host read-back of this grid point
                 results.append(res if res == res else float("inf"))
             except RuntimeError as err:  # torch.linalg.LinAlgError is a RuntimeError
                 if "positive" in str(err) or "singular" in str(err) or isinstance(err, torch.linalg.LinAlgError):

@@ -253,6 +253,20 @@ class EmulatedKernels:
         inv = 1.0 / M
         return out, (inv * l2.view(1, -1)).sum(1), (inv * l1.view(-1, 1)).sum(0), inv.sum().reshape(1)
 
+    def kron_logdet_blocks(self, blocks, deltas, scale=None, want_grads=False):
+        s = 1.0 if scale is None else scale.reshape(()).double()
+        out = torch.zeros((), dtype=torch.float64)
+        dd, ds = [], torch.zeros((), dtype=torch.float64)
+        for ls, d in zip(blocks, deltas.double()):
+            lam = ls[0].double() if len(ls) == 1 else torch.outer(ls[0].double(), ls[1].double())
+            M = s * lam + d
+            out = out + torch.log(M).sum()
+            dd.append((1.0 / M).sum())
+            ds = ds + (lam / M).sum()
+        f32 = lambda t: t.to(torch.float32).reshape(-1)
+        return (f32(out), f32(torch.stack(dd)) if want_grads else None,
+                f32(ds) if want_grads and scale is not None else None)
+
     # predictive
     def kron_quadform_linear(self, u, v, l1, l2, delta, fvar, ub=None, lb=None, delta_b=None):
         w = torch.einsum("ni,oi->no", v**2, 1.0 / (torch.outer(l1, l2) + delta.reshape(())))

@@ -75,6 +75,18 @@ def _run(dev):
     assert err < 1e-4, err
     probs = la(batch)
     assert probs.shape == (8, 2)
+    # validation gridsearch on dict batches: one cached feature pass per batch, same choice as the literal loop
+    interval = torch.logspace(-2, 2, 7)
+    nll = []
+    for pp in interval:
+        la.prior_precision = pp
+        tot = 0.0
+        for b in loader:
+            p = la(b)
+            tot += float(-torch.log(p[torch.arange(len(p)), b["labels"]]).sum())
+        nll.append(tot)
+    chosen = la.gridsearch_prior_precision(loader, log_prior_prec_min=-2, log_prior_prec_max=2, grid_size=7)
+    assert float(chosen) == pytest.approx(float(interval[int(torch.tensor(nll).argmin())]))
 
 
 def _pooled(m, data):

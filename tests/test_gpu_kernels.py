@@ -420,6 +420,33 @@ def test_kron_logdet(K, n1, n2):
         assert_close(gd, wd, tol=1e-5, what="damped")
 
 
+@pytest.mark.parametrize("nblocks,with_scale", [(1, False), (5, True), (45, True), (70, False)])
+def test_kron_logdet_blocks(K, nblocks, with_scale):
+    """whole-posterior logdet: mixed one-/two-factor blocks, more blocks than one launch carries (32), per-block
+    deltas, the pending `H * scalar`; value and both derivatives against fp64"""
+    g = torch.Generator().manual_seed(nblocks)
+    blocks = []
+    for b in range(nblocks):
+        n1 = int(torch.randint(1, 300, (1,), generator=g))
+        n2 = 0 if b % 3 == 2 else int(torch.randint(1, 700, (1,), generator=g))
+        l1 = torch.rand(n1, generator=g, dtype=torch.float64) + 1e-3
+        blocks.append((l1,) if n2 == 0 else (l1, torch.rand(n2, generator=g, dtype=torch.float64) * 3))
+    deltas = torch.rand(nblocks, generator=g, dtype=torch.float64) + 0.05
+    scale = torch.tensor([0.37], dtype=torch.float64) if with_scale else None
+    want = EMU.kron_logdet_blocks(blocks, deltas, scale, True)
+    f32 = lambda t: t.float().to(DEV).contiguous()
+    got = K.kron_logdet_blocks([tuple(f32(l) for l in ls) for ls in blocks], f32(deltas),
+                               None if scale is None else f32(scale), True)
+    for g_, w_, nm in zip(got, want, ("val", "d_delta", "d_scale")):
+        assert (g_ is None) == (w_ is None), nm
+        if w_ is not None:
+            assert_close(g_, w_, tol=1e-5, what=nm)
+    # bitwise reproducible (fixed-order reduction)
+    again = K.kron_logdet_blocks([tuple(f32(l) for l in ls) for ls in blocks], f32(deltas),
+                                 None if scale is None else f32(scale), True)
+    assert torch.equal(again[0], got[0]) and torch.equal(again[1], got[1])
+
+
 @pytest.mark.parametrize("B,C,Do,Di", [(10, 2, 2, 20), (33, 10, 10, 512), (7, 3, 120, 400), (5, 1, 1, 50)])
 def test_quadforms(K, B, C, Do, Di):
     u, v = rnd(C, B, Do, seed=1), rnd(B, Di, seed=2)
