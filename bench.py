@@ -306,6 +306,22 @@ def main():
             sync()
             result["eigh_ms"] = (time.perf_counter() - t0) * 1e3
             result["eigh_converged"] = all(int(i[0].item()) == 0 for i in dec._eig_info)
+            if not args.no_predictive and not SELFTEST:
+                # GLM predictive variance under the full-network KFAC posterior just fitted (V1 of SURVEY.md 8a):
+                # one seed-batched reverse sweep + the weight-sharing quadratic-form kernel per layer
+                from laplace_amd import predictive as _pred
+
+                post = dec + torch.ones(1, device=dev)
+                Xp = batches[0][0]
+                _pred.glm_variance_kron(backend, Xp, post)
+                sync()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    f_mu, f_var = _pred.glm_variance_kron(backend, Xp, post)
+                sync()
+                result["predictive_kron_c4"] = {
+                    "workload": "c4 posterior: ResNet-18 full-network KFAC, GLM predictive variance [B,10,10], batch 128",
+                    "samples_per_s": 3 * len(Xp) / (time.perf_counter() - t0), "finite": bool(torch.isfinite(f_var).all())}
             del dec
         if not args.no_predictive and not SELFTEST:
             result["predictive"] = predictive_leg(dev)

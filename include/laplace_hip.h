@@ -264,6 +264,24 @@ int lk_kron_quadform_linear_f32(const float* u, const float* v, const float* l1,
 int lk_diag_quadform_linear_f32(const float* a, const float* g, const float* var_w, const float* var_b,
                                 int64_t B, int64_t Cc, int64_t Do, int64_t Di, float* fvar, void* stream);
 
+/* Weight-sharing layers (nn.Conv2d; nn.Linear applied along a sequence): the per-sample Jacobian of output c is
+ * J_c = sum_l u[n][c][l][:] v[n][l][:]^T  (Do x Dk, L shared positions), and KronLaplace / DiagLaplace
+ * .functional_variance (baselaplace.py:1834-1835 via matrix.py:406-461; baselaplace.py:2113-2115) contract the
+ * materialised [B, C, Do*Dk] block.  These two never form it:
+ *   fvar[n][c][k] += sum_{o,i} J_c[o,i] J_k[o,i] w[o,i]
+ *   Kronecker posterior: u = (grad w.r.t. the layer output) Q1, v = (unfolded input) Q2, w = 1/(l1[o] l2[i] + delta[0])
+ *   diagonal posterior:  u, v raw,                                                   w = var_w[o][i]
+ * u [B][C][L][Do], v [B][L][Dk] (both position-major, i.e. channels-last), C <= 10 (LK_EINVAL beyond: use the generic
+ * Jacobian form).  Per sample one MFMA GEMM [(C*Do) x L].[L x Dk] whose 32x32 tiles stay in accumulators for all C
+ * outputs and are folded into the C(C+1)/2 pair sums in registers; workgroup partials are reduced in fixed order.
+ * Requires C*L*Do < 2^29 and L*Dk < 2^29. */
+size_t lk_quadform_shared_workspace_bytes(int64_t B, int64_t C, int64_t Do, int64_t Dk);
+int lk_kron_quadform_shared_f32(const float* u, const float* v, const float* l1, const float* l2, const float* delta,
+                                int64_t B, int64_t C, int64_t Do, int64_t Dk, int64_t L, float* fvar, void* ws,
+                                size_t ws_bytes, void* stream);
+int lk_diag_quadform_shared_f32(const float* u, const float* v, const float* var_w, int64_t B, int64_t C, int64_t Do,
+                                int64_t Dk, int64_t L, float* fvar, void* ws, size_t ws_bytes, void* stream);
+
 /* Generic streaming form over a materialised Jacobian (any layer type):
  *   fvar[n][c][k] = sum_p Js[n][c][p] var[p] Js[n][k][p] */
 int lk_diag_quadform_js_f32(const float* Js, const float* var, int64_t B, int64_t C, int64_t P, float* fvar,

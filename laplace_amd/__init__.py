@@ -14,5 +14,12 @@ def fit_kron(la, train_loader, process_group=None, distributed=None):
     return _fit(la, train_loader, process_group=process_group, distributed=distributed)
 
 
-__all__ = ["HipGGN", "HipEF", "HipKron", "HipKronDecomposed", "HAVE_REFERENCE", "fit_kron"]
+def glm_predictive(la, X, diagonal_output=False):
+    """Fused GLM predictive for the reference's Laplace objects — see :func:`laplace_amd.laplace.glm_predictive`."""
+    from laplace_amd.laplace import glm_predictive as _glm
+
+    return _glm(la, X, diagonal_output=diagonal_output)
+
+
+__all__ = ["HipGGN", "HipEF", "HipKron", "HipKronDecomposed", "HAVE_REFERENCE", "fit_kron", "glm_predictive"]
 __version__ = "0.1.0"

@@ -77,6 +77,9 @@ SIGNATURES = {
     "lk_kron_logdet_blocks_f32": (_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "lk_kron_quadform_linear_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "lk_diag_quadform_linear_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "lk_quadform_shared_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
+    "lk_kron_quadform_shared_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
+    "lk_diag_quadform_shared_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "lk_diag_quadform_js_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "lk_dense_quadform_ll_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "lk_dense_quadform_ll_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _vp, _vp, _sz, _vp]),
@@ -623,6 +626,37 @@ class HipKernels:
             self.lib.lk_kron_quadform_linear_f32(_ptr(u), _ptr(v), _ptr(l1), _ptr(l2), _ptr(delta), B, Cc, Do, Di, _ptr(ub),
                                                  _ptr(lb), _ptr(delta_b), _ptr(fvar), self._stream(u.device)),
             "lk_kron_quadform_linear_f32",
+        )
+        return fvar
+
+    #: most outputs the fused weight-sharing predictive holds in accumulators at once
+    quadform_shared_max_outputs = 10
+
+    def kron_quadform_shared(self, u, v, l1, l2, delta, fvar):
+        """``u [B, C, L, Do]``, ``v [B, L, Dk]`` (eigenbasis projections); ``fvar [B, C, C] +=``."""
+        for t, nm in ((u, "u"), (v, "v"), (l1, "l1"), (l2, "l2"), (delta, "delta"), (fvar, "fvar")):
+            _check(t, nm)
+        B, C, L, Do = u.shape
+        Dk = v.shape[2]
+        ws = self._workspace(self.lib.lk_quadform_shared_workspace_bytes(B, C, Do, Dk), u.device)
+        self._rc(
+            self.lib.lk_kron_quadform_shared_f32(_ptr(u), _ptr(v), _ptr(l1), _ptr(l2), _ptr(delta), B, C, Do, Dk, L,
+                                                 _ptr(fvar), _ptr(ws), ws.numel(), self._stream(u.device)),
+            "lk_kron_quadform_shared_f32",
+        )
+        return fvar
+
+    def diag_quadform_shared(self, u, v, var_w, fvar):
+        """``u [B, C, L, Do]`` output gradients, ``v [B, L, Dk]`` unfolded inputs, ``var_w [Do, Dk]``."""
+        for t, nm in ((u, "u"), (v, "v"), (var_w, "var_w"), (fvar, "fvar")):
+            _check(t, nm)
+        B, C, L, Do = u.shape
+        Dk = v.shape[2]
+        ws = self._workspace(self.lib.lk_quadform_shared_workspace_bytes(B, C, Do, Dk), u.device)
+        self._rc(
+            self.lib.lk_diag_quadform_shared_f32(_ptr(u), _ptr(v), _ptr(var_w), B, C, Do, Dk, L, _ptr(fvar), _ptr(ws),
+                                                 ws.numel(), self._stream(u.device)),
+            "lk_diag_quadform_shared_f32",
         )
         return fvar
 

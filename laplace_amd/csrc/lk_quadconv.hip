@@ -1,0 +1,246 @@
+// GLM predictive variance of a weight-sharing layer (Conv2d, Linear over a sequence) without its Jacobian.
+// Replaces, for such layers, KronDecomposed._bmm / inv_square_form as used by KronLaplace.functional_variance
+// (laplace/utils/matrix.py:406-461, laplace/baselaplace.py:1834-1835) and DiagLaplace.functional_variance
+// (baselaplace.py:2113-2115), both of which contract a materialised [B, C, Do*Dk] Jacobian block.
+//
+// The per-sample Jacobian of such a layer is a sum over the L shared positions, J_c = sum_l u_c[l] v[l]^T (Do x Dk),
+// so  f_var[c][k] = sum_{o,i} J_c[o,i] J_k[o,i] w[o,i]  needs, per sample, one GEMM [(C*Do) x L] . [L x Dk] whose
+// (o,i) tile is held for all C outputs at once in MFMA accumulators, weighted, and folded into the C(C+1)/2 pair sums
+// in registers: nothing of size Do*Dk is ever written.  u, v are the output gradients / unfolded inputs, already
+// rotated into the factors' eigenbases by the caller for the Kronecker posterior (w = 1/(l1_o l2_i + delta)), raw for
+// the diagonal one (w = posterior variance of weight (o,i)).
+#include "lk_common.h"
+
+namespace lk {
+
+constexpr int QC_KC = 16;  // positions per LDS chunk (8 MFMA k-steps)
+
+// grid = B * split workgroups of 4 waves; workgroup (n, sp) walks the super-tiles (32 rows o) x (128 columns i)
+// t = sp, sp + split, ...; wave w owns columns [32 w, 32 w + 32) of the super-tile for all CT outputs.
+template <int CT, int MODE>
+__global__ __launch_bounds__(256) void quadform_conv_kernel(const float* __restrict__ u, const float* __restrict__ v,
+                                                            const float* __restrict__ w0, const float* __restrict__ w1,
+                                                            const float* __restrict__ delta, int C, int Do, int Dk, int L,
+                                                            int split, float* __restrict__ partial) {
+  constexpr int NP = CT * (CT + 1) / 2;
+  constexpr int NA = 2 * CT;  // staged dwords per thread per chunk: CT * QC_KC * 32 / 256
+  __shared__ float sA[2][CT][QC_KC][32];
+  __shared__ float sR[4][NP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
+  const int n = blockIdx.x / split, sp = blockIdx.x % split;
+  const int nOt = (Do + 31) / 32, nIg = (Dk + 127) / 128, ntiles = nOt * nIg;
+  const float* __restrict__ un = u + (size_t)n * C * L * Do;
+  const float* __restrict__ vn = v + (size_t)n * L * Dk;
+  const float dlt = MODE == 0 ? delta[0] : 0.f;
+
+  float pair[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) pair[p] = 0.f;
+
+  for (int t = sp; t < ntiles; t += split) {
+    const int o0 = (t % nOt) * 32, i0 = (t / nOt) * 128 + wave * 32;
+    const int icol = i0 + lo;
+    f32x16 acc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+    float ra[NA], rb[QC_KC / 2];
+    auto fetch = [&](int l0) {
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        const int e = tid + 256 * j, o = e & 31, ll = (e >> 5) & (QC_KC - 1), c = e >> 9;
+        const bool ok = c < C && l0 + ll < L && o0 + o < Do;
+        // 32-bit offsets from the sample's (uniform) base pointer: the host checks C*L*Do and L*Dk < 2^29
+        ra[j] = ok ? un[(unsigned)((c * L + l0 + ll) * Do + o0 + o)] : 0.f;
+      }
+#pragma unroll
+      for (int kk = 0; kk < QC_KC / 2; ++kk) {
+        const int l = l0 + 2 * kk + hi;
+        rb[kk] = (l < L && icol < Dk) ? vn[(unsigned)(l * Dk + icol)] : 0.f;
+      }
+    };
+    fetch(0);
+    int buf = 0;
+    for (int l0 = 0; l0 < L; l0 += QC_KC) {
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        const int e = tid + 256 * j;
+        sA[buf][e >> 9][(e >> 5) & (QC_KC - 1)][e & 31] = ra[j];
+      }
+      float b[QC_KC / 2];
+#pragma unroll
+      for (int kk = 0; kk < QC_KC / 2; ++kk) b[kk] = rb[kk];
+      __syncthreads();
+      if (l0 + QC_KC < L) fetch(l0 + QC_KC);  // next chunk's operands travel while this one is multiplied
+      // LDS operand reads run exactly one k-step ahead of the MFMAs (the scheduler would otherwise hoist all
+      // 8 * CT of them and spill)
+      float a_cur[CT], a_nxt[CT];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) a_cur[c] = sA[buf][c][hi][lo];
+#pragma unroll
+      for (int kk = 0; kk < QC_KC / 2; ++kk) {
+        if (kk + 1 < QC_KC / 2) {
+#pragma unroll
+          for (int c = 0; c < CT; ++c) a_nxt[c] = sA[buf][c][2 * kk + 2 + hi][lo];
+        }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[c], b[kk], acc[c], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) a_cur[c] = a_nxt[c];
+      }
+      buf ^= 1;  // the other buffer was last read two chunks ago: one barrier per chunk suffices
+    }
+
+    // weights of this lane's 16 (o, i) positions and the pair sums, four accumulator rows at a time (the
+    // accumulators live in AGPRs; only 4 * CT of them are copied out at once)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      float wgt[4], a[CT][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int o = o0 + j + 8 * rg + 4 * hi;
+        const bool ok = o < Do && icol < Dk;
+        if (MODE == 0) {
+          const float d = w0[ok ? o : 0] * w1[ok ? icol : 0] + dlt;
+          wgt[j] = ok ? __builtin_amdgcn_rcpf(d) : 0.f;
+        } else {
+          wgt[j] = ok ? w0[(unsigned)(o * Dk + icol)] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[c][j] = acc[c][4 * rg + j];
+      int p = 0;
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        float sc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sc[j] = a[c][j] * wgt[j];
+#pragma unroll
+        for (int k = c; k < CT; ++k) {
+          pair[p] += (sc[0] * a[k][0] + sc[1] * a[k][1]) + (sc[2] * a[k][2] + sc[3] * a[k][3]);
+          ++p;
+        }
+      }
+    }
+    __syncthreads();  // all waves are done with both LDS buffers before the next tile refills them
+  }
+
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const float s = wave_sum(pair[p]);
+    if (lane == 0) sR[wave][p] = s;
+  }
+  __syncthreads();
+  if (tid < NP) partial[(size_t)blockIdx.x * NP + tid] = (sR[0][tid] + sR[1][tid]) + (sR[2][tid] + sR[3][tid]);
+}
+
+// fvar[n][c][k] (and [k][c]) += sum over the workgroups of sample n, in fixed order
+__global__ __launch_bounds__(256) void quadform_conv_reduce_kernel(const float* __restrict__ partial, int64_t B, int C,
+                                                                   int CT, int split, float* __restrict__ fvar) {
+  const int NP = CT * (CT + 1) / 2;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= B * NP) return;
+  const int64_t n = e / NP;
+  int p = (int)(e % NP), c = 0, rowlen = CT;
+  while (p >= rowlen) {
+    p -= rowlen;
+    ++c;
+    --rowlen;
+  }
+  const int k = c + p;
+  if (k >= C) return;  // padded outputs
+  float s = 0.f;
+  for (int sp = 0; sp < split; ++sp) s += partial[((size_t)n * split + sp) * NP + (e % NP)];
+  fvar[(n * C + c) * C + k] += s;
+  if (k != c) fvar[(n * C + k) * C + c] += s;
+}
+
+}  // namespace lk
+
+using namespace lk;
+
+static int qc_class_tile(int64_t C) {
+  static const int tiles[] = {1, 2, 3, 4, 5, 6, 8, 10};  // 12 outputs would spill accumulators
+  for (int t : tiles)
+    if (C <= t) return t;
+  return 0;
+}
+
+static int qc_split(int64_t B, int64_t Do, int64_t Dk) {
+  const int64_t ntiles = ((Do + 31) / 32) * ((Dk + 127) / 128);
+  int64_t want = (2048 + B - 1) / B;
+  if (want < 1) want = 1;
+  return (int)(want < ntiles ? want : ntiles);
+}
+
+extern "C" size_t lk_quadform_shared_workspace_bytes(int64_t B, int64_t C, int64_t Do, int64_t Dk) {
+  const int ct = qc_class_tile(C);
+  if (B < 0 || ct == 0 || Do < 1 || Dk < 1) return 0;
+  return (size_t)B * qc_split(B, Do, Dk) * (ct * (ct + 1) / 2) * sizeof(float);
+}
+
+template <int MODE>
+static int launch_quadform_conv(const float* u, const float* v, const float* w0, const float* w1, const float* delta,
+                                int64_t B, int64_t C, int64_t Do, int64_t Dk, int64_t L, float* fvar, void* ws,
+                                size_t ws_bytes, hipStream_t stream, const char* what) {
+  const int ct = qc_class_tile(C);
+  if (ct == 0) {
+    set_error("%s: more than 10 outputs are not supported by the fused kernel", what);
+    return LK_EINVAL;
+  }
+  if (B == 0) return LK_OK;
+  if (ws == nullptr || ws_bytes < lk_quadform_shared_workspace_bytes(B, C, Do, Dk)) {
+    set_error("%s: workspace too small", what);
+    return LK_EWORKSPACE;
+  }
+  const int split = qc_split(B, Do, Dk);
+  float* partial = static_cast<float*>(ws);
+  const dim3 grid((unsigned)(B * split));
+#define LK_QC_CASE(CT)                                                                                              \
+  case CT:                                                                                                          \
+    hipLaunchKernelGGL((quadform_conv_kernel<CT, MODE>), grid, dim3(256), 0, stream, u, v, w0, w1, delta, (int)C,   \
+                       (int)Do, (int)Dk, (int)L, split, partial);                                                   \
+    break;
+  switch (ct) {
+    LK_QC_CASE(1)
+    LK_QC_CASE(2)
+    LK_QC_CASE(3)
+    LK_QC_CASE(4)
+    LK_QC_CASE(5)
+    LK_QC_CASE(6)
+    LK_QC_CASE(8)
+    LK_QC_CASE(10)
+  }
+#undef LK_QC_CASE
+  const int64_t total = B * (ct * (ct + 1) / 2);
+  hipLaunchKernelGGL(quadform_conv_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, partial, B,
+                     (int)C, ct, split, fvar);
+  return check_launch(what);
+}
+
+extern "C" int lk_kron_quadform_shared_f32(const float* u, const float* v, const float* l1, const float* l2,
+                                           const float* delta, int64_t B, int64_t C, int64_t Do, int64_t Dk, int64_t L,
+                                           float* fvar, void* ws, size_t ws_bytes, void* stream) {
+  LK_REQUIRE(u && v && l1 && l2 && delta && fvar && B >= 0 && C >= 1 && Do >= 1 && Dk >= 1 && L >= 1,
+             "lk_kron_quadform_shared_f32: bad arguments");
+  LK_REQUIRE(B * 64 < (1ll << 31) && C * L * Do < (1ll << 29) && L * Dk < (1ll << 29),
+             "lk_kron_quadform_shared_f32: sizes out of range");
+  return launch_quadform_conv<0>(u, v, l1, l2, delta, B, C, Do, Dk, L, fvar, ws, ws_bytes, (hipStream_t)stream,
+                                 "lk_kron_quadform_shared_f32");
+}
+
+extern "C" int lk_diag_quadform_shared_f32(const float* u, const float* v, const float* var_w, int64_t B, int64_t C,
+                                           int64_t Do, int64_t Dk, int64_t L, float* fvar, void* ws, size_t ws_bytes,
+                                           void* stream) {
+  LK_REQUIRE(u && v && var_w && fvar && B >= 0 && C >= 1 && Do >= 1 && Dk >= 1 && L >= 1,
+             "lk_diag_quadform_shared_f32: bad arguments");
+  LK_REQUIRE(B * 64 < (1ll << 31) && C * L * Do < (1ll << 29) && L * Dk < (1ll << 29) && Do * Dk < (1ll << 31),
+             "lk_diag_quadform_shared_f32: sizes out of range");
+  return launch_quadform_conv<1>(u, v, var_w, nullptr, nullptr, B, C, Do, Dk, L, fvar, ws, ws_bytes, (hipStream_t)stream,
+                                 "lk_diag_quadform_shared_f32");
+}

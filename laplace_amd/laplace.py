@@ -721,6 +721,34 @@ def fit_kron(la, train_loader, process_group=None, distributed: bool | None = No
     return la
 
 
+def glm_predictive(la, X, diagonal_output: bool = False):
+    """Fused GLM predictive ``(f_mu, f_var)`` for the REFERENCE's own Laplace objects built with ``backend=HipGGN``::
+
+        f_mu, f_var = laplace_amd.glm_predictive(la, x_test)     # instead of la._glm_predictive_distribution(x_test)
+
+    Same result as ``_glm_predictive_distribution`` (laplace/baselaplace.py:1306-1342, lllaplace.py:212-237), which
+    materialises ``Js [B, C, P]`` (447 MB per sample for ResNet-18) before ``functional_variance``; here the layer
+    factors of the Jacobian go straight into the quadratic-form kernels (:mod:`laplace_amd.predictive`).  Posteriors
+    the fused kernels do not cover (dense full-network, damping, models with parameters outside Linear/Conv2d) fall
+    through to the reference's own method."""
+    backend = la.backend
+    if not hasattr(backend, "_forward"):
+        raise TypeError("glm_predictive needs a laplace_amd backend (HipGGN / HipEF)")
+    la.model.eval()
+    try:
+        if hasattr(la, "H_facs"):
+            f_mu, f_var = _pred.glm_variance_kron(backend, X, la.posterior_precision)
+        elif torch.is_tensor(la.H) and la.H.ndim == 1:
+            f_mu, f_var = _pred.glm_variance_diag(backend, X, la.posterior_variance)
+        else:
+            f_mu, f_var = _pred.glm_variance_full_last_layer(backend, X, la.posterior_covariance)
+    except NotImplementedError:
+        return la._glm_predictive_distribution(X, diagonal_output=diagonal_output)
+    if diagonal_output:
+        f_var = torch.diagonal(f_var, dim1=-2, dim2=-1)
+    return f_mu.detach(), f_var.detach()
+
+
 _FLAVOURS = {"kron": HipKronLaplace, "diag": HipDiagLaplace, "full": HipFullLaplace}
 
 

@@ -10,12 +10,20 @@ the posterior (Kron: laplace/utils/matrix.py:406-461; diag: baselaplace.py:2113-
   (plumbing) + ``lk_kron_quadform_linear_f32``.
 * nn.Linear, diagonal posterior: ``lk_diag_quadform_linear_f32``.
 * dense last-layer posterior: ``lk_dense_quadform_ll_f32`` (``J = I (x) [phi, 1]``).
-* nn.Conv2d: the layer's Jacobian block is assembled by ``lk_jac_conv_f32`` (only that block,
-  never the full ``[B, C, P]``) and contracted with the block's posterior.
+* nn.Conv2d and nn.Linear along a sequence (weight sharing over ``L`` positions): ``J_nc = sum_l g_ncl a_nl^T``,
+  so ``Q1^T J_nc Q2 = (g Q1)^T (a Q2)`` — the input rotation is ONE convolution with the eigenvectors as filters
+  (library conv), the output rotation a small GEMM, and ``lk_kron_quadform_shared_f32`` /
+  ``lk_diag_quadform_shared_f32`` contract the per-sample ``[(C Do) x L] . [L x Dk]`` product with the posterior
+  inside MFMA accumulators: no ``Do x Dk`` block per (sample, output) is ever written.  As written
+  (matrix.py:406-461) the Kronecker form costs ``4 C (Do^2 Dk + Do Dk^2)`` flop per sample and layer — 484 GFLOP
+  for one 512x4608 ResNet-18 layer; here ``2 L (Dk^2 + C Do^2 + C Do Dk)`` = 1.5 GFLOP.
+* more than 10 outputs, or other layer types: the layer's Jacobian block is assembled by ``lk_jac_conv_f32``
+  (only that block, never the full ``[B, C, P]``) and contracted with the block's posterior.
 """
 from __future__ import annotations
 
 import torch
+import torch.nn.functional as F
 
 from laplace_amd._lib import get_kernels
 
@@ -35,6 +43,39 @@ def _conv_block_jacobian(tap, g, B, C):
     K.jac_conv(tap.a.to(torch.float32).contiguous(), g.contiguous(), m.kernel_size, m.stride, m.padding, m.dilation,
                Jl, 0, width if tap.has_bias else -1)
     return Jl, width
+
+
+def _shared_operands(tap, g, B, C, Q1=None, Q2=None):
+    """``u [B, C, L, Do]`` and ``v [B, L, Dk]`` of a weight-sharing layer (module docstring), rotated into the
+    eigenbases ``Q1`` / ``Q2`` if given; plus the position-summed output gradient ``[C, B, Do]`` for the bias."""
+    m = tap.module
+    a = tap.a.to(torch.float32)
+    if tap.kind == "conv2d":
+        Do = m.out_channels
+        g4 = g.reshape(C, B, Do, -1)                                  # [C, B, Do, L]
+        L = g4.shape[-1]
+        Dk = m.weight[0].numel()
+        if Q2 is None:
+            v = F.unfold(a, m.kernel_size, m.dilation, m.padding, m.stride).transpose(1, 2).contiguous()
+        else:
+            # unfolded patches (x) Q2 = one convolution whose filters are the eigenvectors (rows of the A factor
+            # follow F.unfold's (c_in, kh, kw) order = the weight layout); channels-last output IS [B, L, Dk]
+            filt = Q2.T.reshape(Dk, *m.weight.shape[1:])
+            v = F.conv2d(a.contiguous(memory_format=torch.channels_last),
+                         filt.contiguous(memory_format=torch.channels_last), None, m.stride, m.padding, m.dilation)
+            v = v.permute(0, 2, 3, 1).contiguous().reshape(B, L, Dk)
+        gsum = g4.sum(-1)
+        u = g4.permute(1, 0, 3, 2)                                     # [B, C, L, Do]
+    else:                                                              # Linear over [B, ..., Di]
+        Do = m.out_features
+        v = a.reshape(B, -1, a.shape[-1])
+        L = v.shape[1]
+        u = g.reshape(C, B, L, Do).permute(1, 0, 2, 3)
+        gsum = g.reshape(C, B, L, Do).sum(2)
+        if Q2 is not None:
+            v = v @ Q2
+    u = (u @ Q1) if Q1 is not None else u
+    return u.contiguous(), v.contiguous(), gsum
 
 
 def glm_variance_kron(backend, x, post):
@@ -66,6 +107,12 @@ def glm_variance_kron(backend, x, post):
             K.kron_quadform_linear(u, v, l1.contiguous(), l2.contiguous(), d1, fvar, ub,
                                    None if lb is None else lb.contiguous(),
                                    None if delta_b is None else delta_b.detach().reshape(1).contiguous())
+        elif C <= K.quadform_shared_max_outputs:
+            u, v, gsum = _shared_operands(tap, g, B, C, Q1, Q2)
+            K.kron_quadform_shared(u, v, l1.contiguous(), l2.contiguous(), d1, fvar)
+            if Qb is not None:
+                ub = gsum @ Qb
+                fvar += torch.einsum("cno,kno,o->nck", ub, ub, 1.0 / (lb + delta_b))
         elif tap.kind == "conv2d":
             Jl, width = _conv_block_jacobian(tap, g, B, C)
             Do, Dk = len(l1), len(l2)
@@ -77,7 +124,7 @@ def glm_variance_kron(backend, x, post):
                 ub = Jl[:, :, width:] @ Qb
                 fvar += torch.einsum("nco,nko,o->nck", ub, ub, 1.0 / (lb + delta_b))
         else:
-            raise NotImplementedError(f"{tap.name}: Kron predictive for Linear layers with weight sharing")
+            raise NotImplementedError(f"{tap.name}: Kron predictive for weight-shared Linear layers with > 10 outputs")
     tape.release()
     return f, fvar
 
@@ -99,12 +146,18 @@ def glm_variance_diag(backend, x, post_var: torch.Tensor):
         if tap.kind == "linear" and tap.a.ndim == 2:
             vb = post_var[tap.b_off:tap.b_off + m.out_features] if tap.has_bias else None
             K.diag_quadform_linear(tap.a.to(torch.float32).contiguous(), g.contiguous(), vw, vb, fvar)
+        elif C <= K.quadform_shared_max_outputs:
+            u, v, gsum = _shared_operands(tap, g, B, C)
+            K.diag_quadform_shared(u, v, vw.reshape(u.shape[-1], v.shape[-1]).contiguous(), fvar)
+            if tap.has_bias:
+                vb = post_var[tap.b_off:tap.b_off + u.shape[-1]]
+                fvar += torch.einsum("cno,kno,o->nck", gsum, gsum, vb)
         elif tap.kind == "conv2d":
             Jl, width = _conv_block_jacobian(tap, g, B, C)
             var = torch.cat([vw, post_var[tap.b_off:tap.b_off + m.out_channels]]) if tap.has_bias else vw
             fvar += K.diag_quadform_js(Jl, var.contiguous())
         else:
-            raise NotImplementedError(f"{tap.name}: diagonal predictive for Linear layers with weight sharing")
+            raise NotImplementedError(f"{tap.name}: diagonal predictive for weight-shared Linear layers with > 10 outputs")
     tape.release()
     return f, fvar
 

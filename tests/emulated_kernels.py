@@ -253,6 +253,18 @@ class EmulatedKernels:
         inv = 1.0 / M
         return out, (inv * l2.view(1, -1)).sum(1), (inv * l1.view(-1, 1)).sum(0), inv.sum().reshape(1)
 
+    quadform_shared_max_outputs = 10
+
+    def kron_quadform_shared(self, u, v, l1, l2, delta, fvar):
+        M = torch.einsum("nclo,nli->ncoi", u, v)
+        fvar += torch.einsum("ncoi,nkoi,oi->nck", M, M, 1.0 / (torch.outer(l1, l2) + delta.reshape(())))
+        return fvar
+
+    def diag_quadform_shared(self, u, v, var_w, fvar):
+        M = torch.einsum("nclo,nli->ncoi", u, v)
+        fvar += torch.einsum("ncoi,nkoi,oi->nck", M, M, var_w)
+        return fvar
+
     def kron_logdet_blocks(self, blocks, deltas, scale=None, want_grads=False):
         s = 1.0 if scale is None else scale.reshape(()).double()
         out = torch.zeros((), dtype=torch.float64)

@@ -58,6 +58,19 @@ def test_reference_laplace_with_hip_backend(ref, name, lik, sow, hs):
     assert rel(f_mu, g[f"{tag}.f_mu"]) < 1e-4
     assert rel(f_var, g[f"{tag}.f_var"]) < 1e-4
     assert rel(la.log_marginal_likelihood(), g[f"{tag}.marglik"]) < 1e-4
+    # the Jacobian-free predictive helper on the reference's object: same numbers
+    import laplace_amd
+
+    if hs != "full" or sow == "last_layer":  # these must take the fused kernels, not fall through
+        def boom(*a, **k):
+            raise AssertionError("glm_predictive fell through to the reference's materialised-Jacobian method")
+
+        la._glm_predictive_distribution = boom
+    f_mu2, f_var2 = laplace_amd.glm_predictive(la, X)
+    assert rel(f_mu2, g[f"{tag}.f_mu"]) < 1e-4
+    assert rel(f_var2, g[f"{tag}.f_var"]) < 1e-4
+    d_mu, d_var = laplace_amd.glm_predictive(la, X, diagonal_output=True)
+    assert rel(d_var, torch.diagonal(torch.as_tensor(g[f"{tag}.f_var"]), dim1=-2, dim2=-1)) < 1e-4
 
 
 @pytest.mark.parametrize("name", ["mlp", "conv", "resnetish"])

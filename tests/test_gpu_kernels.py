@@ -420,6 +420,40 @@ def test_kron_logdet(K, n1, n2):
         assert_close(gd, wd, tol=1e-5, what="damped")
 
 
+@pytest.mark.parametrize("B,C,Do,Dk,L", [(3, 2, 5, 27, 9), (4, 10, 64, 576, 64), (2, 10, 512, 4608, 16),
+                                        (5, 3, 40, 150, 100), (2, 1, 7, 9, 1), (130, 4, 33, 129, 17), (3, 7, 96, 200, 33),
+                                        (2, 9, 64, 64, 256), (600, 5, 16, 16, 4)])
+def test_quadform_shared(K, B, C, Do, Dk, L):
+    """weight-sharing predictive (conv / sequence Linear): ragged tiles, padded output counts (7 -> 8, 9 -> 10),
+    one and many workgroups per sample, Kronecker and diagonal weights; against the fp64 einsum"""
+    u, v = rnd(B, C, L, Do, seed=1), rnd(B, L, Dk, seed=2)
+    l1, l2 = rnd(Do, seed=3).abs(), rnd(Dk, seed=4).abs()
+    d = torch.tensor([0.3], dtype=torch.float64)
+    f32 = lambda t: t.float().to(DEV).contiguous()
+    base = rnd(B, C, C, seed=5)
+    base = base + base.transpose(1, 2)
+    want = EMU.kron_quadform_shared(u, v, l1, l2, d, base.clone())
+    got = K.kron_quadform_shared(f32(u), f32(v), f32(l1), f32(l2), f32(d), f32(base))
+    assert_close(got, want, what="kron_quadform_shared")
+    assert_close(got, got.transpose(1, 2), tol=1e-6, what="symmetry")
+    var = rnd(Do, Dk, seed=6).abs()
+    want = EMU.diag_quadform_shared(u, v, var, torch.zeros(B, C, C, dtype=torch.float64))
+    got = K.diag_quadform_shared(f32(u), f32(v), f32(var), torch.zeros(B, C, C, device=DEV))
+    assert_close(got, want, what="diag_quadform_shared")
+    again = K.diag_quadform_shared(f32(u), f32(v), f32(var), torch.zeros(B, C, C, device=DEV))
+    assert torch.equal(again, got)  # fixed-order reduction
+
+
+def test_quadform_shared_rejects_more_outputs_than_accumulators(K):
+    if DEV == "cpu":
+        pytest.skip("limit of the HIP kernel")
+    from laplace_amd._lib import LaplaceHipError
+
+    z = lambda *s: torch.zeros(*s, device=DEV)
+    with pytest.raises(LaplaceHipError, match="more than 10 outputs"):
+        K.kron_quadform_shared(z(1, 11, 2, 4), z(1, 2, 4), z(4) + 1, z(4) + 1, z(1) + 1, z(1, 11, 11))
+
+
 @pytest.mark.parametrize("nblocks,with_scale", [(1, False), (5, True), (45, True), (70, False)])
 def test_kron_logdet_blocks(K, nblocks, with_scale):
     """whole-posterior logdet: mixed one-/two-factor blocks, more blocks than one launch carries (32), per-block
