@@ -324,18 +324,28 @@ class _HipCurvatureMixin:
             K.gram_tn(g.reshape(S * B, Do, L).sum(2).contiguous(), alpha_g, G, upper_only=fused)
         return G
 
+    @staticmethod
+    def _conv_view(tap, a, g):
+        """``(a, g, kernel_size, stride, padding, dilation)`` of a weight-sharing tap as a convolution: a Conv2d as it
+        is; an ``nn.Linear`` applied along extra dims (``a [B, ..., Di]``, ``g [S, B, ..., Do]``) is the 1x1
+        convolution over its ``T`` shared positions, whose ``[Do, Di, 1, 1]`` weight flattens like the Linear's."""
+        m = tap.module
+        if tap.kind == "conv2d":
+            return a.contiguous(), g.contiguous(), m.kernel_size, m.stride, m.padding, m.dilation
+        B, S = a.shape[0], g.shape[0]
+        a4 = a.reshape(B, -1, a.shape[-1]).transpose(1, 2).unsqueeze(-1).contiguous()          # [B, Di, T, 1]
+        g5 = g.reshape(S, B, -1, g.shape[-1]).transpose(2, 3).unsqueeze(-1).contiguous()       # [S, B, Do, T, 1]
+        return a4, g5, (1, 1), (1, 1), (0, 0), (1, 1)
+
     def _layer_jacobian(self, tap, g, Js):
         """Writes this module's columns of ``Js[B, S, P]``; ``g`` is ``[S, B, ...]``."""
         K = get_kernels()
         a = tap.a.to(torch.float32)
-        m = tap.module
-        if tap.kind == "linear":
-            if a.ndim != 2:
-                raise NotImplementedError(f"{tap.name}: per-sample Jacobians of a Linear with weight sharing")
+        if tap.kind == "linear" and a.ndim == 2:
             K.jac_linear(a.contiguous(), g.contiguous(), Js, tap.w_off, tap.b_off)
         else:
-            K.jac_conv(a.contiguous(), g.contiguous(), m.kernel_size, m.stride, m.padding, m.dilation, Js,
-                       tap.w_off, tap.b_off)
+            a4, g5, ks, st, pd, dl = self._conv_view(tap, a, g)
+            K.jac_conv(a4, g5, ks, st, pd, dl, Js, tap.w_off, tap.b_off)
 
     def _rows(self, x, seeds_fn):
         """``Z[B, S, P]`` = seed-contracted per-sample Jacobians (all tracked params must be covered)."""
@@ -393,17 +403,17 @@ class _HipCurvatureMixin:
                 n_w = m.out_features * m.in_features
                 K.diag_ggn_linear(a.contiguous(), g.contiguous(), alpha, h[tap.w_off:tap.w_off + n_w],
                                   h[tap.b_off:tap.b_off + m.out_features] if tap.has_bias else None)
-            elif tap.kind == "linear":
-                raise NotImplementedError(f"{tap.name}: diagonal GGN of a Linear with weight-sharing dims")
             else:
-                # exact conv diagonal = squared per-sample weight Jacobian, summed over (sample, seed)
+                # exact diagonal of a weight-sharing layer = squared per-sample weight Jacobian, summed over
+                # (sample, seed)
                 width = m.weight.numel()
-                Jl = torch.zeros(B, S, width + (m.out_channels if tap.has_bias else 0), dtype=torch.float32, device=f.device)
-                K.jac_conv(a.contiguous(), g.contiguous(), m.kernel_size, m.stride, m.padding, m.dilation, Jl, 0,
-                           width if tap.has_bias else -1)
+                n_out = m.weight.shape[0]
+                Jl = torch.zeros(B, S, width + (n_out if tap.has_bias else 0), dtype=torch.float32, device=f.device)
+                a4, g5, ks, st, pd, dl = self._conv_view(tap, a, g)
+                K.jac_conv(a4, g5, ks, st, pd, dl, Jl, 0, width if tap.has_bias else -1)
                 K.sq_colsum(Jl, 0, width, alpha, h[tap.w_off:tap.w_off + width])
                 if tap.has_bias:
-                    K.sq_colsum(Jl, width, m.out_channels, alpha, h[tap.b_off:tap.b_off + m.out_channels])
+                    K.sq_colsum(Jl, width, n_out, alpha, h[tap.b_off:tap.b_off + n_out])
         tape.release()
         if self.subnetwork_indices is not None:
             h = h[self.subnetwork_indices]
