@@ -282,6 +282,15 @@ int lk_kron_quadform_shared_f32(const float* u, const float* v, const float* l1,
 int lk_diag_quadform_shared_f32(const float* u, const float* v, const float* var_w, int64_t B, int64_t C, int64_t Do,
                                 int64_t Dk, int64_t L, float* fvar, void* ws, size_t ws_bytes, void* stream);
 
+/* Exact GGN / Fisher diagonal of a weight-sharing layer (GGNInterface.diag, laplace/curvature/curvature.py:413-433,
+ * restricted to the layer's weight): h[o][i] += alpha * sum_{n,s} (sum_l u[n][s][l][o] v[n][l][i])^2 with
+ * u [B][S][L][Do] the seed cotangents at the layer output and v [B][L][Dk] the unfolded input, S <= 10 seeds per call.
+ * Same tile GEMM as lk_*_quadform_shared_f32; the squares are summed over (sample, seed) in registers, so the
+ * [B, S, Do*Dk] per-sample Jacobian the as-written einsum contracts is never formed. */
+size_t lk_diag_ggn_shared_workspace_bytes(int64_t B, int64_t Do, int64_t Dk);
+int lk_diag_ggn_shared_f32(const float* u, const float* v, int64_t B, int64_t S, int64_t Do, int64_t Dk, int64_t L,
+                           float alpha, float* h, void* ws, size_t ws_bytes, void* stream);
+
 /* Generic streaming form over a materialised Jacobian (any layer type):
  *   fvar[n][c][k] = sum_p Js[n][c][p] var[p] Js[n][k][p] */
 int lk_diag_quadform_js_f32(const float* Js, const float* var, int64_t B, int64_t C, int64_t P, float* fvar,

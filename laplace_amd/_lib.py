@@ -80,6 +80,8 @@ SIGNATURES = {
     "lk_quadform_shared_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "lk_kron_quadform_shared_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "lk_diag_quadform_shared_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
+    "lk_diag_ggn_shared_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "lk_diag_ggn_shared_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_float, _vp, _vp, _sz, _vp]),
     "lk_diag_quadform_js_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "lk_dense_quadform_ll_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "lk_dense_quadform_ll_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _vp, _vp, _sz, _vp]),
@@ -659,6 +661,20 @@ class HipKernels:
             "lk_diag_quadform_shared_f32",
         )
         return fvar
+
+    def diag_ggn_shared(self, u, v, alpha, h):
+        """``h[Do*Dk] += alpha * sum_{n,s} (u[n,s]^T v[n])^2``; ``u [B, S, L, Do]``, ``v [B, L, Dk]``, ``S <= 10``."""
+        for t, nm in ((u, "u"), (v, "v"), (h, "h")):
+            _check(t, nm)
+        B, S, L, Do = u.shape
+        Dk = v.shape[2]
+        ws = self._workspace(self.lib.lk_diag_ggn_shared_workspace_bytes(B, Do, Dk), u.device)
+        self._rc(
+            self.lib.lk_diag_ggn_shared_f32(_ptr(u), _ptr(v), B, S, Do, Dk, L, float(alpha), _ptr(h), _ptr(ws), ws.numel(),
+                                            self._stream(u.device)),
+            "lk_diag_ggn_shared_f32",
+        )
+        return h
 
     def diag_quadform_linear(self, a, g, var_w, var_b, fvar):
         for t, nm in ((a, "a"), (g, "g"), (var_w, "var_w"), (fvar, "fvar")):

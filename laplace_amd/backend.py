@@ -28,6 +28,7 @@ import os
 from collections.abc import MutableMapping
 
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from laplace_amd._lib import get_kernels
@@ -35,6 +36,40 @@ from laplace_amd.capture import Tape
 from laplace_amd.sweep import SeedBatchedSweep, SweepUnsupported
 from laplace_amd.kron import HipKron
 from laplace_amd.refapi import EFInterface, GGNInterface
+
+
+def shared_operands(tap, g, B, C, Q1=None, Q2=None):
+    """``u [B, C, L, Do]`` and ``v [B, L, Dk]`` of a weight-sharing layer (Conv2d, or Linear along a sequence), whose
+    per-sample Jacobian of output / seed ``c`` is ``sum_l u[n, c, l, :] v[n, l, :]^T`` (:mod:`laplace_amd.predictive`), rotated into the
+    eigenbases ``Q1`` / ``Q2`` if given; plus the position-summed output gradient ``[C, B, Do]`` for the bias."""
+    m = tap.module
+    a = tap.a.to(torch.float32)
+    if tap.kind == "conv2d":
+        Do = m.out_channels
+        g4 = g.reshape(C, B, Do, -1)                                  # [C, B, Do, L]
+        L = g4.shape[-1]
+        Dk = m.weight[0].numel()
+        if Q2 is None:
+            v = F.unfold(a, m.kernel_size, m.dilation, m.padding, m.stride).transpose(1, 2).contiguous()
+        else:
+            # unfolded patches (x) Q2 = one convolution whose filters are the eigenvectors (rows of the A factor
+            # follow F.unfold's (c_in, kh, kw) order = the weight layout); channels-last output IS [B, L, Dk]
+            filt = Q2.T.reshape(Dk, *m.weight.shape[1:])
+            v = F.conv2d(a.contiguous(memory_format=torch.channels_last),
+                         filt.contiguous(memory_format=torch.channels_last), None, m.stride, m.padding, m.dilation)
+            v = v.permute(0, 2, 3, 1).contiguous().reshape(B, L, Dk)
+        gsum = g4.sum(-1)
+        u = g4.permute(1, 0, 3, 2)                                     # [B, C, L, Do]
+    else:                                                              # Linear over [B, ..., Di]
+        Do = m.out_features
+        v = a.reshape(B, -1, a.shape[-1])
+        L = v.shape[1]
+        u = g.reshape(C, B, L, Do).permute(1, 0, 2, 3)
+        gsum = g.reshape(C, B, L, Do).sum(2)
+        if Q2 is not None:
+            v = v @ Q2
+    u = (u @ Q1) if Q1 is not None else u
+    return u.contiguous(), v.contiguous(), gsum
 
 
 class CachedFeatures:
@@ -408,12 +443,13 @@ class _HipCurvatureMixin:
                 # (sample, seed)
                 width = m.weight.numel()
                 n_out = m.weight.shape[0]
-                Jl = torch.zeros(B, S, width + (n_out if tap.has_bias else 0), dtype=torch.float32, device=f.device)
-                a4, g5, ks, st, pd, dl = self._conv_view(tap, a, g)
-                K.jac_conv(a4, g5, ks, st, pd, dl, Jl, 0, width if tap.has_bias else -1)
-                K.sq_colsum(Jl, 0, width, alpha, h[tap.w_off:tap.w_off + width])
+                smax = K.quadform_shared_max_outputs
+                u, v, gsum = shared_operands(tap, g, B, S)
+                for s0 in range(0, S, smax):  # the sum over seeds is additive: any S goes through in chunks
+                    us = u if S <= smax else u[:, s0:s0 + smax].contiguous()
+                    K.diag_ggn_shared(us, v, alpha, h[tap.w_off:tap.w_off + width])
                 if tap.has_bias:
-                    K.sq_colsum(Jl, width, n_out, alpha, h[tap.b_off:tap.b_off + n_out])
+                    h[tap.b_off:tap.b_off + n_out] += alpha * (gsum * gsum).sum((0, 1))
         tape.release()
         if self.subnetwork_indices is not None:
             h = h[self.subnetwork_indices]

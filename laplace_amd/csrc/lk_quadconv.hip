@@ -15,6 +15,70 @@ namespace lk {
 
 constexpr int QC_KC = 16;  // positions per LDS chunk (8 MFMA k-steps)
 
+// acc[c] = the 32x32 tile (rows o0.., this wave's columns icol) of  u_c^T v = sum_l u[c][l][:]^T v[l][:]  for all CT
+// outputs of one sample.  A operand (u, all outputs) through double-buffered LDS shared by the 4 waves, B operand (v)
+// straight from memory; the next chunk's operands travel while the current one is multiplied.
+template <int CT>
+__device__ __forceinline__ void qc_tile_gemm(const float* __restrict__ un, const float* __restrict__ vn, int o0,
+                                             int icol, int C, int Do, int Dk, int L, float (*sA)[CT][QC_KC][32],
+                                             f32x16 (&acc)[CT]) {
+  constexpr int NA = 2 * CT;  // staged dwords per thread per chunk: CT * QC_KC * 32 / 256
+  const int tid = threadIdx.x, lane = tid & 63, lo = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+  float ra[NA], rb[QC_KC / 2];
+  auto fetch = [&](int l0) {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int e = tid + 256 * j, o = e & 31, ll = (e >> 5) & (QC_KC - 1), c = e >> 9;
+      const bool ok = c < C && l0 + ll < L && o0 + o < Do;
+      // 32-bit offsets from the sample's (uniform) base pointer: the host checks C*L*Do and L*Dk < 2^29
+      ra[j] = ok ? un[(unsigned)((c * L + l0 + ll) * Do + o0 + o)] : 0.f;
+    }
+#pragma unroll
+    for (int kk = 0; kk < QC_KC / 2; ++kk) {
+      const int l = l0 + 2 * kk + hi;
+      rb[kk] = (l < L && icol < Dk) ? vn[(unsigned)(l * Dk + icol)] : 0.f;
+    }
+  };
+  fetch(0);
+  int buf = 0;
+  for (int l0 = 0; l0 < L; l0 += QC_KC) {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int e = tid + 256 * j;
+      sA[buf][e >> 9][(e >> 5) & (QC_KC - 1)][e & 31] = ra[j];
+    }
+    float b[QC_KC / 2];
+#pragma unroll
+    for (int kk = 0; kk < QC_KC / 2; ++kk) b[kk] = rb[kk];
+    __syncthreads();
+    if (l0 + QC_KC < L) fetch(l0 + QC_KC);
+    // LDS operand reads run exactly one k-step ahead of the MFMAs (the scheduler would otherwise hoist all
+    // 8 * CT of them and spill)
+    float a_cur[CT], a_nxt[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) a_cur[c] = sA[buf][c][hi][lo];
+#pragma unroll
+    for (int kk = 0; kk < QC_KC / 2; ++kk) {
+      if (kk + 1 < QC_KC / 2) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) a_nxt[c] = sA[buf][c][2 * kk + 2 + hi][lo];
+      }
+#pragma unroll
+      for (int c = 0; c < CT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[c], b[kk], acc[c], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < CT; ++c) a_cur[c] = a_nxt[c];
+    }
+    buf ^= 1;  // the other buffer was last read two chunks ago: one barrier per chunk suffices
+  }
+  __syncthreads();  // every wave is done with both LDS buffers before the caller's next tile refills them
+}
+
 // grid = B * split workgroups of 4 waves; workgroup (n, sp) walks the super-tiles (32 rows o) x (128 columns i)
 // t = sp, sp + split, ...; wave w owns columns [32 w, 32 w + 32) of the super-tile for all CT outputs.
 template <int CT, int MODE>
@@ -23,7 +87,6 @@ __global__ __launch_bounds__(256) void quadform_conv_kernel(const float* __restr
                                                             const float* __restrict__ delta, int C, int Do, int Dk, int L,
                                                             int split, float* __restrict__ partial) {
   constexpr int NP = CT * (CT + 1) / 2;
-  constexpr int NA = 2 * CT;  // staged dwords per thread per chunk: CT * QC_KC * 32 / 256
   __shared__ float sA[2][CT][QC_KC][32];
   __shared__ float sR[4][NP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
@@ -41,58 +104,7 @@ __global__ __launch_bounds__(256) void quadform_conv_kernel(const float* __restr
     const int o0 = (t % nOt) * 32, i0 = (t / nOt) * 128 + wave * 32;
     const int icol = i0 + lo;
     f32x16 acc[CT];
-#pragma unroll
-    for (int c = 0; c < CT; ++c)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
-
-    float ra[NA], rb[QC_KC / 2];
-    auto fetch = [&](int l0) {
-#pragma unroll
-      for (int j = 0; j < NA; ++j) {
-        const int e = tid + 256 * j, o = e & 31, ll = (e >> 5) & (QC_KC - 1), c = e >> 9;
-        const bool ok = c < C && l0 + ll < L && o0 + o < Do;
-        // 32-bit offsets from the sample's (uniform) base pointer: the host checks C*L*Do and L*Dk < 2^29
-        ra[j] = ok ? un[(unsigned)((c * L + l0 + ll) * Do + o0 + o)] : 0.f;
-      }
-#pragma unroll
-      for (int kk = 0; kk < QC_KC / 2; ++kk) {
-        const int l = l0 + 2 * kk + hi;
-        rb[kk] = (l < L && icol < Dk) ? vn[(unsigned)(l * Dk + icol)] : 0.f;
-      }
-    };
-    fetch(0);
-    int buf = 0;
-    for (int l0 = 0; l0 < L; l0 += QC_KC) {
-#pragma unroll
-      for (int j = 0; j < NA; ++j) {
-        const int e = tid + 256 * j;
-        sA[buf][e >> 9][(e >> 5) & (QC_KC - 1)][e & 31] = ra[j];
-      }
-      float b[QC_KC / 2];
-#pragma unroll
-      for (int kk = 0; kk < QC_KC / 2; ++kk) b[kk] = rb[kk];
-      __syncthreads();
-      if (l0 + QC_KC < L) fetch(l0 + QC_KC);  // next chunk's operands travel while this one is multiplied
-      // LDS operand reads run exactly one k-step ahead of the MFMAs (the scheduler would otherwise hoist all
-      // 8 * CT of them and spill)
-      float a_cur[CT], a_nxt[CT];
-#pragma unroll
-      for (int c = 0; c < CT; ++c) a_cur[c] = sA[buf][c][hi][lo];
-#pragma unroll
-      for (int kk = 0; kk < QC_KC / 2; ++kk) {
-        if (kk + 1 < QC_KC / 2) {
-#pragma unroll
-          for (int c = 0; c < CT; ++c) a_nxt[c] = sA[buf][c][2 * kk + 2 + hi][lo];
-        }
-#pragma unroll
-        for (int c = 0; c < CT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[c], b[kk], acc[c], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int c = 0; c < CT; ++c) a_cur[c] = a_nxt[c];
-      }
-      buf ^= 1;  // the other buffer was last read two chunks ago: one barrier per chunk suffices
-    }
+    qc_tile_gemm<CT>(un, vn, o0, icol, C, Do, Dk, L, sA, acc);
 
     // weights of this lane's 16 (o, i) positions and the pair sums, four accumulator rows at a time (the
     // accumulators live in AGPRs; only 4 * CT of them are copied out at once)
@@ -127,7 +139,6 @@ __global__ __launch_bounds__(256) void quadform_conv_kernel(const float* __restr
         }
       }
     }
-    __syncthreads();  // all waves are done with both LDS buffers before the next tile refills them
   }
 
 #pragma unroll
@@ -158,6 +169,47 @@ __global__ __launch_bounds__(256) void quadform_conv_reduce_kernel(const float* 
   for (int sp = 0; sp < split; ++sp) s += partial[((size_t)n * split + sp) * NP + (e % NP)];
   fvar[(n * C + c) * C + k] += s;
   if (k != c) fvar[(n * C + k) * C + c] += s;
+}
+
+// Exact GGN diagonal of a weight-sharing layer: h[o][i] = sum_{n, s} (sum_l u[n][s][l][o] v[n][l][i])^2 -- the squared
+// per-sample, per-seed weight Jacobian summed over the minibatch, without the [B, S, Do*Dk] Jacobian.
+// grid = ntiles * nsplit workgroups; workgroup (t, sp) owns the super-tile t for the samples sp, sp + nsplit, ... and
+// keeps the running sum of squares of its 32x32 wave tiles in registers.
+template <int CT>
+__global__ __launch_bounds__(256) void diag_ggn_shared_kernel(const float* __restrict__ u, const float* __restrict__ v,
+                                                              int B, int C, int Do, int Dk, int L, int nsplit,
+                                                              float* __restrict__ partial) {
+  __shared__ float sA[2][CT][QC_KC][32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lo = lane & 31, hi = lane >> 5;
+  const int t = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
+  const int nOt = (Do + 31) / 32;
+  const int o0 = (t % nOt) * 32, icol = (t / nOt) * 128 + wave * 32 + lo;
+  float hacc[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) hacc[r] = 0.f;
+  for (int n = sp; n < B; n += nsplit) {
+    f32x16 acc[CT];
+    qc_tile_gemm<CT>(u + (size_t)n * C * L * Do, v + (size_t)n * L * Dk, o0, icol, C, Do, Dk, L, sA, acc);
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hacc[r] += acc[c][r] * acc[c][r];
+  }
+  float* __restrict__ out = partial + (size_t)sp * Do * Dk;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+    if (o < Do && icol < Dk) out[(size_t)o * Dk + icol] = hacc[r];
+  }
+}
+
+__global__ __launch_bounds__(256) void diag_ggn_shared_reduce_kernel(const float* __restrict__ partial, int64_t width,
+                                                                     int nsplit, float alpha, float* __restrict__ h) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= width) return;
+  float s = 0.f;
+  for (int sp = 0; sp < nsplit; ++sp) s += partial[(size_t)sp * width + e];
+  h[e] += alpha * s;
 }
 
 }  // namespace lk
@@ -243,4 +295,59 @@ extern "C" int lk_diag_quadform_shared_f32(const float* u, const float* v, const
              "lk_diag_quadform_shared_f32: sizes out of range");
   return launch_quadform_conv<1>(u, v, var_w, nullptr, nullptr, B, C, Do, Dk, L, fvar, ws, ws_bytes, (hipStream_t)stream,
                                  "lk_diag_quadform_shared_f32");
+}
+
+static int dg_split(int64_t B, int64_t Do, int64_t Dk) {
+  const int64_t ntiles = ((Do + 31) / 32) * ((Dk + 127) / 128);
+  int64_t want = (1024 + ntiles - 1) / ntiles;
+  if (want < 1) want = 1;
+  return (int)(want < B ? want : (B < 1 ? 1 : B));
+}
+
+extern "C" size_t lk_diag_ggn_shared_workspace_bytes(int64_t B, int64_t Do, int64_t Dk) {
+  if (B < 0 || Do < 1 || Dk < 1) return 0;
+  return (size_t)dg_split(B, Do, Dk) * Do * Dk * sizeof(float);
+}
+
+extern "C" int lk_diag_ggn_shared_f32(const float* u, const float* v, int64_t B, int64_t S, int64_t Do, int64_t Dk,
+                                      int64_t L, float alpha, float* h, void* ws, size_t ws_bytes, void* stream_) {
+  LK_REQUIRE(u && v && h && B >= 0 && S >= 1 && Do >= 1 && Dk >= 1 && L >= 1, "lk_diag_ggn_shared_f32: bad arguments");
+  LK_REQUIRE(S * L * Do < (1ll << 29) && L * Dk < (1ll << 29) && Do * Dk < (1ll << 31),
+             "lk_diag_ggn_shared_f32: sizes out of range");
+  const int ct = qc_class_tile(S);
+  if (ct == 0) {
+    set_error("lk_diag_ggn_shared_f32: more than 10 seeds per call are not supported (chunk them)");
+    return LK_EINVAL;
+  }
+  if (B == 0) return LK_OK;
+  if (ws == nullptr || ws_bytes < lk_diag_ggn_shared_workspace_bytes(B, Do, Dk)) {
+    set_error("lk_diag_ggn_shared_f32: workspace too small");
+    return LK_EWORKSPACE;
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  const int nsplit = dg_split(B, Do, Dk);
+  const int64_t ntiles = ((Do + 31) / 32) * ((Dk + 127) / 128);
+  LK_REQUIRE(ntiles * nsplit < (1ll << 31), "lk_diag_ggn_shared_f32: grid too large");
+  float* partial = static_cast<float*>(ws);
+  const dim3 grid((unsigned)(ntiles * nsplit));
+#define LK_DG_CASE(CT)                                                                                                 \
+  case CT:                                                                                                             \
+    hipLaunchKernelGGL((diag_ggn_shared_kernel<CT>), grid, dim3(256), 0, stream, u, v, (int)B, (int)S, (int)Do, (int)Dk, \
+                       (int)L, nsplit, partial);                                                                       \
+    break;
+  switch (ct) {
+    LK_DG_CASE(1)
+    LK_DG_CASE(2)
+    LK_DG_CASE(3)
+    LK_DG_CASE(4)
+    LK_DG_CASE(5)
+    LK_DG_CASE(6)
+    LK_DG_CASE(8)
+    LK_DG_CASE(10)
+  }
+#undef LK_DG_CASE
+  const int64_t width = Do * Dk;
+  hipLaunchKernelGGL(diag_ggn_shared_reduce_kernel, dim3((unsigned)((width + 255) / 256)), dim3(256), 0, stream, partial,
+                     width, nsplit, alpha, h);
+  return check_launch("lk_diag_ggn_shared_f32");
 }

@@ -23,9 +23,9 @@ the posterior (Kron: laplace/utils/matrix.py:406-461; diag: baselaplace.py:2113-
 from __future__ import annotations
 
 import torch
-import torch.nn.functional as F
 
 from laplace_amd._lib import get_kernels
+from laplace_amd.backend import shared_operands as _shared_operands
 
 
 def _identity_seeds(f: torch.Tensor) -> torch.Tensor:
@@ -43,39 +43,6 @@ def _conv_block_jacobian(tap, g, B, C):
     K.jac_conv(tap.a.to(torch.float32).contiguous(), g.contiguous(), m.kernel_size, m.stride, m.padding, m.dilation,
                Jl, 0, width if tap.has_bias else -1)
     return Jl, width
-
-
-def _shared_operands(tap, g, B, C, Q1=None, Q2=None):
-    """``u [B, C, L, Do]`` and ``v [B, L, Dk]`` of a weight-sharing layer (module docstring), rotated into the
-    eigenbases ``Q1`` / ``Q2`` if given; plus the position-summed output gradient ``[C, B, Do]`` for the bias."""
-    m = tap.module
-    a = tap.a.to(torch.float32)
-    if tap.kind == "conv2d":
-        Do = m.out_channels
-        g4 = g.reshape(C, B, Do, -1)                                  # [C, B, Do, L]
-        L = g4.shape[-1]
-        Dk = m.weight[0].numel()
-        if Q2 is None:
-            v = F.unfold(a, m.kernel_size, m.dilation, m.padding, m.stride).transpose(1, 2).contiguous()
-        else:
-            # unfolded patches (x) Q2 = one convolution whose filters are the eigenvectors (rows of the A factor
-            # follow F.unfold's (c_in, kh, kw) order = the weight layout); channels-last output IS [B, L, Dk]
-            filt = Q2.T.reshape(Dk, *m.weight.shape[1:])
-            v = F.conv2d(a.contiguous(memory_format=torch.channels_last),
-                         filt.contiguous(memory_format=torch.channels_last), None, m.stride, m.padding, m.dilation)
-            v = v.permute(0, 2, 3, 1).contiguous().reshape(B, L, Dk)
-        gsum = g4.sum(-1)
-        u = g4.permute(1, 0, 3, 2)                                     # [B, C, L, Do]
-    else:                                                              # Linear over [B, ..., Di]
-        Do = m.out_features
-        v = a.reshape(B, -1, a.shape[-1])
-        L = v.shape[1]
-        u = g.reshape(C, B, L, Do).permute(1, 0, 2, 3)
-        gsum = g.reshape(C, B, L, Do).sum(2)
-        if Q2 is not None:
-            v = v @ Q2
-    u = (u @ Q1) if Q1 is not None else u
-    return u.contiguous(), v.contiguous(), gsum
 
 
 def glm_variance_kron(backend, x, post):

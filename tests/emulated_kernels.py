@@ -265,6 +265,11 @@ class EmulatedKernels:
         fvar += torch.einsum("ncoi,nkoi,oi->nck", M, M, var_w)
         return fvar
 
+    def diag_ggn_shared(self, u, v, alpha, h):
+        M = torch.einsum("nslo,nli->nsoi", u, v)
+        h += alpha * (M * M).sum((0, 1)).reshape(-1)
+        return h
+
     def kron_logdet_blocks(self, blocks, deltas, scale=None, want_grads=False):
         s = 1.0 if scale is None else scale.reshape(()).double()
         out = torch.zeros((), dtype=torch.float64)

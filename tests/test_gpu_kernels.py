@@ -444,6 +444,21 @@ def test_quadform_shared(K, B, C, Do, Dk, L):
     assert torch.equal(again, got)  # fixed-order reduction
 
 
+@pytest.mark.parametrize("B,S,Do,Dk,L", [(3, 2, 5, 27, 9), (4, 9, 64, 576, 64), (2, 10, 512, 1152, 16), (130, 4, 33, 129, 17),
+                                        (7, 1, 96, 200, 33), (1, 3, 16, 16, 4)])
+def test_diag_ggn_shared(K, B, S, Do, Dk, L):
+    """exact GGN diagonal of a weight-sharing layer: sum over (sample, seed) of the squared per-sample Jacobian,
+    accumulated on top of what h already holds; ragged tiles, one and many samples per workgroup"""
+    u, v = rnd(B, S, L, Do, seed=1), rnd(B, L, Dk, seed=2)
+    base = rnd(Do * Dk, seed=3)
+    f32 = lambda t: t.float().to(DEV).contiguous()
+    want = EMU.diag_ggn_shared(u, v, 0.7, base.clone())
+    got = K.diag_ggn_shared(f32(u), f32(v), 0.7, f32(base))
+    assert_close(got, want, what="diag_ggn_shared")
+    again = K.diag_ggn_shared(f32(u), f32(v), 0.7, f32(base))
+    assert torch.equal(again, got)
+
+
 def test_quadform_shared_rejects_more_outputs_than_accumulators(K):
     if DEV == "cpu":
         pytest.skip("limit of the HIP kernel")
