@@ -14,7 +14,7 @@
 //   parameter order (weight [C][D] row-major, then bias [C]).
 //
 // Predictive.  fvar[n][c][k] = pt_n^T Sigma[(c,:),(k,:)] pt_n : for every class pair (c <= k) one
-//   [64 x D~] x [D~ x D~] MFMA product per 64-sample tile with the row-dot against pt fused into the
+//   [128 x D~] x [D~ x D~] MFMA product per 128-sample tile with the row-dot against pt fused into the
 //   epilogue; 2 C(C+1)/2 D~^2 flop per sample instead of 2 C P^2.
 #include "lk_common.h"
 
@@ -76,14 +76,19 @@ __global__ __launch_bounds__(256) void ll_scatter_kernel(const float* __restrict
 }
 
 // ---- dense last-layer predictive -----------------------------------------------------------------
-// grid = (ceil(B/64), C(C+1)/2); 4 waves as 2x2 over a 64(n) x 64(q) tile.
+// grid = (ceil(B/128), C(C+1)/2); workgroup = 128 samples x one class pair (c <= k); 4 waves as 2x2, each owning a
+// 64(n) x 64(q) block = 2x2 MFMA tiles of T = Pt Sigma_ck; q walks D~ in steps of 128 and the row-dot with Pt[n][q]
+// is folded in after every q-step, so T is never written.  Operands through double-buffered LDS (p-major), the next
+// chunk's global loads in flight during the MFMAs, LDS reads one k-step ahead.
+constexpr int LLQ_BK = 16;
+constexpr int LLQ_LD = 132;  // 128 + 4: the two half-waves of an operand read land on disjoint banks
+
 __global__ __launch_bounds__(256) void dense_quadform_ll_kernel(const float* __restrict__ phi,
                                                                 const float* __restrict__ Sigma, int64_t B, int C,
                                                                 int D, int Dt, int64_t P, float* __restrict__ fvar) {
-  __shared__ float sA[64][17];   // pt[n][p-chunk]
-  __shared__ float sB[16][65];   // Sigma[(c,p)][(k,q)] chunk
-  __shared__ float sE[64][65];   // pt[n][q-chunk] for the fused row-dot
-  __shared__ float sR[2][64];    // cross-wave (wn) reduction
+  __shared__ float sA[2][LLQ_BK][LLQ_LD];  // Pt[n][p] as [p][n]
+  __shared__ float sB[2][LLQ_BK][LLQ_LD];  // Sigma[(c,p)][(k,q)] as [p][q]
+  __shared__ float sR[2][128];             // cross-wave (wn) reduction
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lo = lane & 31, hi = lane >> 5, wm = wave >> 1, wn = wave & 1;
   int c = 0, rem = blockIdx.y, rowlen = C;
@@ -93,65 +98,108 @@ __global__ __launch_bounds__(256) void dense_quadform_ll_kernel(const float* __r
     --rowlen;
   }
   const int k = c + rem;
-  const int64_t n0 = (int64_t)blockIdx.x * 64;
+  const int64_t n0 = (int64_t)blockIdx.x * 128;
 
-  float psum[16];
+  float psum[2][16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) psum[r] = 0.f;
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) psum[tm][r] = 0.f;
 
-  for (int q0 = 0; q0 < Dt; q0 += 64) {
-    f32x16 acc;
+  // staging coordinates of this thread: A element (n = e >> 4, p = e & 15), B element (p = e >> 7, q = e & 127)
+  const int a_p = tid & 15, a_n = tid >> 4;  // + 16 rows of n per j
+  const int b_q = tid & 127, b_p = tid >> 7;  // + 2 rows of p per j
+
+  for (int q0 = 0; q0 < Dt; q0 += 128) {
+    f32x16 acc[2][2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    // epilogue operand tile
-    for (int e = tid; e < 64 * 64; e += 256) {
-      const int nn = e >> 6, qq = e & 63;
-      const int64_t n = n0 + nn;
-      sE[nn][qq] = (n < B && q0 + qq < Dt) ? phi_aug(phi, n, q0 + qq, D) : 0.f;
-    }
-    for (int p0 = 0; p0 < Dt; p0 += 16) {
-      for (int e = tid; e < 64 * 16; e += 256) {
-        const int nn = e >> 4, pp = e & 15;
-        const int64_t n = n0 + nn;
-        sA[nn][pp] = (n < B && p0 + pp < Dt) ? phi_aug(phi, n, p0 + pp, D) : 0.f;
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+    const int qg = q0 + b_q;
+    const int64_t colB = qg < Dt ? ref_index(k, qg, C, D) : -1;
+
+    float ra[8], rb[8];
+    auto fetch = [&](int p0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int64_t n = n0 + a_n + 16 * j;
+        const int p = p0 + a_p;
+        ra[j] = (n < B && p < Dt) ? phi_aug(phi, n, p, D) : 0.f;
       }
-      for (int e = tid; e < 16 * 64; e += 256) {
-        const int pp = e >> 6, qq = e & 63;
-        float v = 0.f;
-        if (p0 + pp < Dt && q0 + qq < Dt)
-          v = Sigma[(int64_t)ref_index(c, p0 + pp, C, D) * P + ref_index(k, q0 + qq, C, D)];
-        sB[pp][qq] = v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int p = p0 + b_p + 2 * j;
+        rb[j] = (p < Dt && colB >= 0) ? Sigma[(int64_t)ref_index(c, p, C, D) * P + colB] : 0.f;
       }
+    };
+    fetch(0);
+    int buf = 0;
+    for (int p0 = 0; p0 < Dt; p0 += LLQ_BK) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sA[buf][a_p][a_n + 16 * j] = ra[j];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sB[buf][b_p + 2 * j][b_q] = rb[j];
       __syncthreads();
+      if (p0 + LLQ_BK < Dt) fetch(p0 + LLQ_BK);
+      float a_cur[2], b_cur[2], a_nxt[2], b_nxt[2];
 #pragma unroll
-      for (int kk = 0; kk < 8; ++kk) {
-        const int pp = 2 * kk + hi;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[wm * 32 + lo][pp], sB[pp][wn * 32 + lo], acc, 0, 0, 0);
+      for (int t = 0; t < 2; ++t) {
+        a_cur[t] = sA[buf][hi][wm * 64 + t * 32 + lo];
+        b_cur[t] = sB[buf][hi][wn * 64 + t * 32 + lo];
       }
-      __syncthreads();
-    }
-    // fused row-dot with pt[n][q]
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      psum[r] += acc[r] * sE[row][wn * 32 + lo];
+      for (int kk = 0; kk < LLQ_BK / 2; ++kk) {
+        if (kk + 1 < LLQ_BK / 2) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            a_nxt[t] = sA[buf][2 * kk + 2 + hi][wm * 64 + t * 32 + lo];
+            b_nxt[t] = sB[buf][2 * kk + 2 + hi][wn * 64 + t * 32 + lo];
+          }
+        }
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[tm], b_cur[tn], acc[tm][tn], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          a_cur[t] = a_nxt[t];
+          b_cur[t] = b_nxt[t];
+        }
+      }
+      buf ^= 1;  // the other buffer was last read two chunks ago: one barrier per chunk
     }
-    __syncthreads();  // sE is rewritten by the next q-chunk
+    __syncthreads();
+    // fused row-dot with Pt[n][q]
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      const int q = q0 + wn * 64 + tn * 32 + lo;
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t n = n0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          const float e = (n < B && q < Dt) ? phi_aug(phi, n, q, D) : 0.f;
+          psum[tm][r] += acc[tm][tn][r] * e;
+        }
+    }
   }
   // reduce over the 32 lanes sharing `hi`, then over the two column-waves
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    float v = psum[r];
+  for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    psum[r] = v;
-  }
-  if (lo == 0) {
+    for (int r = 0; r < 16; ++r) {
+      float v = psum[tm][r];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sR[wn][wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi] = psum[r];
-  }
+      for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lo == 0) sR[wn][wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi] = v;
+    }
   __syncthreads();
-  if (tid < 64) {
+  if (tid < 128) {
     const int64_t n = n0 + tid;
     if (n < B) {
       const float v = sR[0][tid] + sR[1][tid];
@@ -259,7 +307,7 @@ extern "C" int lk_dense_quadform_ll_f32(const float* phi, const float* Sigma, in
   LK_REQUIRE(C * (C + 1) / 2 <= 65535, "lk_dense_quadform_ll_f32: too many class pairs");
   if (B == 0) return LK_OK;
   const int Dt = (int)(D + (has_bias ? 1 : 0));
-  dim3 grid((unsigned)((B + 63) / 64), (unsigned)(C * (C + 1) / 2));
+  dim3 grid((unsigned)((B + 127) / 128), (unsigned)(C * (C + 1) / 2));
   hipLaunchKernelGGL(dense_quadform_ll_kernel, grid, dim3(256), 0, (hipStream_t)stream, phi, Sigma, B, (int)C, (int)D, Dt,
                      (int64_t)C * Dt, fvar);
   return check_launch("dense_quadform_ll_kernel");

@@ -300,7 +300,8 @@ def test_jac_conv_and_sq_colsum(K, case):
 
 # ---- dense last layer --------------------------------------------------------------------------------
 @pytest.mark.parametrize("B,C,D,bias,cls", [(10, 2, 20, True, True), (64, 10, 33, True, True), (50, 3, 16, False, True),
-                                            (40, 2, 20, True, False), (33, 1, 50, True, False), (200, 10, 130, True, True)])
+                                            (40, 2, 20, True, False), (33, 1, 50, True, False), (200, 10, 130, True, True),
+                                            (300, 3, 512, True, True), (129, 2, 257, False, False)])
 def test_ll_ggn_full_and_quadform(K, B, C, D, bias, cls):
     phi = rnd(B, D, seed=B)
     probs = torch.softmax(rnd(B, C, seed=3), -1) if cls else None
