@@ -443,13 +443,24 @@ class _HipCurvatureMixin:
                 # (sample, seed)
                 width = m.weight.numel()
                 n_out = m.weight.shape[0]
-                smax = K.quadform_shared_max_outputs
-                u, v, gsum = shared_operands(tap, g, B, S)
-                for s0 in range(0, S, smax):  # the sum over seeds is additive: any S goes through in chunks
-                    us = u if S <= smax else u[:, s0:s0 + smax].contiguous()
-                    K.diag_ggn_shared(us, v, alpha, h[tap.w_off:tap.w_off + width])
-                if tap.has_bias:
-                    h[tap.b_off:tap.b_off + n_out] += alpha * (gsum * gsum).sum((0, 1))
+                if n_out >= 32 and width // n_out >= 64:
+                    # MFMA tile GEMM of the per-sample Jacobian, squares summed in registers
+                    smax = K.quadform_shared_max_outputs
+                    u, v, gsum = shared_operands(tap, g, B, S)
+                    for s0 in range(0, S, smax):  # the sum over seeds is additive: any S goes through in chunks
+                        us = u if S <= smax else u[:, s0:s0 + smax].contiguous()
+                        K.diag_ggn_shared(us, v, alpha, h[tap.w_off:tap.w_off + width])
+                    if tap.has_bias:
+                        h[tap.b_off:tap.b_off + n_out] += alpha * (gsum * gsum).sum((0, 1))
+                else:
+                    # narrow layers (LeNet's 6- and 16-channel convs) would leave the 32-row MFMA tiles mostly empty:
+                    # their per-sample Jacobian block is small, write it and square-sum its columns
+                    Jl = torch.zeros(B, S, width + (n_out if tap.has_bias else 0), dtype=torch.float32, device=f.device)
+                    a4, g5, ks, st, pd, dl = self._conv_view(tap, a, g)
+                    K.jac_conv(a4, g5, ks, st, pd, dl, Jl, 0, width if tap.has_bias else -1)
+                    K.sq_colsum(Jl, 0, width, alpha, h[tap.w_off:tap.w_off + width])
+                    if tap.has_bias:
+                        K.sq_colsum(Jl, width, n_out, alpha, h[tap.b_off:tap.b_off + n_out])
         tape.release()
         if self.subnetwork_indices is not None:
             h = h[self.subnetwork_indices]

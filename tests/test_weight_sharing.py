@@ -96,3 +96,51 @@ def test_sequence_linear_on_emulation(lik, bias):
 @pytest.mark.parametrize("lik", ["classification", "regression"])
 def test_sequence_linear_gpu(lik):
     _run("cuda", lik, True)
+
+
+class WideConvNet(nn.Module):
+    """a conv wide enough (32 x 72) for the MFMA-tile route of the exact diagonal"""
+
+    def __init__(self):
+        super().__init__()
+        self.c1 = nn.Conv2d(8, 32, 3, padding=1)
+        self.act = nn.Tanh()
+        self.pool = nn.AdaptiveAvgPool2d(1)
+        self.flat = nn.Flatten()
+        self.fc = nn.Linear(32, 3)
+
+    def forward(self, x):
+        return self.fc(self.flat(self.pool(self.act(self.c1(x)))))
+
+
+def _run_wide_conv(dev):
+    from laplace_amd import HipEF, HipGGN
+
+    torch.manual_seed(5)
+    model = WideConvNet().to(dev)
+    X = torch.randn(6, 8, 5, 5, device=dev)
+    y = torch.randint(3, (6,), device=dev)
+    m64 = WideConvNet().double()
+    m64.load_state_dict({k: v.double().cpu() for k, v in model.state_dict().items()})
+    Js64, f64 = co.jacobians(m64, X.double().cpu())
+    _, h = HipGGN(model, "classification").diag(X, y)
+    assert rel(h, co.ggn_diag(Js64, co.functional_hessian(f64, "classification"))) < 1e-4
+    Gs, _ = co.per_sample_gradients(m64, X.double().cpu(), y.cpu(), "classification")
+    _, h_ef = HipEF(model, "classification").diag(X, y)
+    assert rel(h_ef, co.ef_diag(Gs, "classification")) < 1e-4
+
+
+def test_wide_conv_exact_diagonal_on_emulation():
+    from laplace_amd import _lib
+    from tests.emulated_kernels import EmulatedKernels
+
+    prev = _lib.set_kernels_for_testing(EmulatedKernels())
+    try:
+        _run_wide_conv("cpu")
+    finally:
+        _lib.set_kernels_for_testing(prev)
+
+
+@pytest.mark.gpu
+def test_wide_conv_exact_diagonal_gpu():
+    _run_wide_conv("cuda")
