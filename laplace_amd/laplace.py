@@ -14,9 +14,8 @@ KronLaplace :1704-1879, DiagLaplace :2048-2136, FullLaplace :1572-1701, log marg
 """
 from __future__ import annotations
 
-from math import log, pi, sqrt
+from math import pi, sqrt
 
-import numpy as np
 import torch
 import torch.distributed as dist
 from torch import nn
@@ -412,8 +411,6 @@ class _HipLaplace:
         (default: NLL for classification, MSE for regression, as the reference's ``RunningNLLMetric`` /
         ``MeanSquaredError``).  A grid point whose posterior is not positive definite scores ``inf``."""
         from collections.abc import MutableMapping
-
-        from .backend import CachedFeatures
 
         def batches():
             for data in val_loader:

@@ -1,7 +1,6 @@
 """Backward-data of the ResNet-18 3x3 convs at the sweep's batch (S*B = 1152): MIOpen solver choices (dev tool).
 usage: conv_bwd_bench.py [channels_last]"""
 import sys
-import time
 
 import torch
 

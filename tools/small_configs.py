@@ -6,7 +6,6 @@ import sys
 import time
 
 import torch
-from torch.utils.data import DataLoader, TensorDataset
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from laplace_amd.laplace import HipLaplace  # noqa: E402
