@@ -9,6 +9,8 @@
 // in registers: nothing of size Do*Dk is ever written.  u, v are the output gradients / unfolded inputs, already
 // rotated into the factors' eigenbases by the caller for the Kronecker posterior (w = 1/(l1_o l2_i + delta)), raw for
 // the diagonal one (w = posterior variance of weight (o,i)).
+#include <stdlib.h>
+
 #include "lk_common.h"
 
 namespace lk {
@@ -79,9 +81,100 @@ __device__ __forceinline__ void qc_tile_gemm(const float* __restrict__ un, const
   __syncthreads();  // every wave is done with both LDS buffers before the caller's next tile refills them
 }
 
+// Same tile product for Do % 4 == 0 (every layer of a ResNet): the A chunk travels as CT/2 float4 loads and
+// ds_write_b128 per thread instead of 2 CT dwords, addresses are one per-thread offset plus uniform strides, and the
+// next chunk's loads are issued one per k-step between the MFMAs instead of in a burst before them (with one wave per
+// SIMD nothing else hides that burst).  The pipeline runs across tiles: during the last chunk of a tile the first
+// chunk of the NEXT tile (other rows / columns, or the next sample) is fetched, so short K loops (L = 16) do not pay
+// a cold start per tile.  Loads are issued raw from a clamped (always valid) address and zeroed where the value is
+// consumed a chunk later -- a select right behind the load would make the wave wait out the memory latency.
+struct QcOperands {  // one tile's operands: sample base pointers, first row, this lane's column
+  const float* un;
+  const float* vn;
+  int o0, icol;
+};
+
+template <int CT>
+struct QcStage {  // operands in flight: a thread's float4 slots of the A chunk and its lane's B column
+  f32x4 ra[(CT + 1) / 2];
+  float rb[QC_KC / 2];
+};
+
+template <int CT>
+__device__ __forceinline__ void qc_fetch_v4(QcStage<CT>& st, int j_lo, int j_hi, int kk_lo, int kk_hi, const QcOperands& t,
+                                            int l0, int C, int Do, int Dk, int L) {
+  const int tid = threadIdx.x, hi = (tid & 63) >> 5;
+  const int o4 = 4 * (tid & 7), ll = (tid >> 3) & (QC_KC - 1), c0 = tid >> 7;
+#pragma unroll
+  for (int j = j_lo; j < j_hi; ++j) {
+    const bool ok = t.o0 + o4 < Do && c0 + 2 * j < C && l0 + ll < L;
+    const unsigned off = ok ? ((unsigned)((c0 + 2 * j) * L + l0 + ll) * (unsigned)Do + (unsigned)(t.o0 + o4)) : 0u;
+    st.ra[j] = *reinterpret_cast<const f32x4*>(t.un + off);
+  }
+#pragma unroll
+  for (int kk = kk_lo; kk < kk_hi; ++kk) {
+    const bool ok = t.icol < Dk && l0 + 2 * kk + hi < L;
+    st.rb[kk] = t.vn[ok ? (unsigned)((l0 + 2 * kk + hi) * Dk + t.icol) : 0u];
+  }
+}
+
+// On entry `st` holds chunk 0 of `cur`; on exit chunk 0 of `nxt` (if has_next).
+template <int CT>
+__device__ __forceinline__ void qc_tile_gemm_v4(const QcOperands& cur, const QcOperands& nxt, bool has_next, int C,
+                                                int Do, int Dk, int L, float (*sA)[CT][QC_KC][32], f32x16 (&acc)[CT],
+                                                QcStage<CT>& st) {
+  constexpr int NA4 = (CT + 1) / 2;  // float4 slots per thread per chunk: CT * QC_KC * 8 / 256
+  constexpr int KS = QC_KC / 2;
+  static_assert(NA4 <= KS, "one A load per k-step");
+  const int tid = threadIdx.x, lane = tid & 63, lo = lane & 31, hi = lane >> 5;
+  const int o4 = 4 * (tid & 7), ll = (tid >> 3) & (QC_KC - 1), c0 = tid >> 7;
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+  const bool okO = cur.o0 + o4 < Do, okI = cur.icol < Dk;
+  int buf = 0;
+  for (int l0 = 0; l0 < L; l0 += QC_KC) {
+#pragma unroll
+    for (int j = 0; j < NA4; ++j)
+      if (c0 + 2 * j < CT) {
+        const bool ok = okO && c0 + 2 * j < C && l0 + ll < L;
+        *reinterpret_cast<f32x4*>(&sA[buf][c0 + 2 * j][ll][o4]) = ok ? st.ra[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    float b[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) b[kk] = (okI && l0 + 2 * kk + hi < L) ? st.rb[kk] : 0.f;
+    __syncthreads();
+    // what travels during this chunk: the tile's next chunk, or chunk 0 of the next tile -- chosen with uniform
+    // selects, not branches (a branch per k-step splits the MFMA stream into basic blocks and costs 15 % at large L);
+    // the very last chunk of a workgroup re-reads its own chunk 0 for nothing
+    const bool more = l0 + QC_KC < L;
+    const QcOperands src = more ? cur : (has_next ? nxt : cur);
+    const int lsrc = more ? l0 + QC_KC : 0;
+    float a_cur[CT], a_nxt[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) a_cur[c] = sA[buf][c][hi][lo];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      if (kk + 1 < KS) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) a_nxt[c] = sA[buf][c][2 * kk + 2 + hi][lo];
+      }
+      qc_fetch_v4<CT>(st, kk, kk < NA4 ? kk + 1 : kk, kk, kk + 1, src, lsrc, C, Do, Dk, L);
+#pragma unroll
+      for (int c = 0; c < CT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[c], b[kk], acc[c], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < CT; ++c) a_cur[c] = a_nxt[c];
+    }
+    buf ^= 1;
+  }
+  __syncthreads();
+}
+
 // grid = B * split workgroups of 4 waves; workgroup (n, sp) walks the super-tiles (32 rows o) x (128 columns i)
 // t = sp, sp + split, ...; wave w owns columns [32 w, 32 w + 32) of the super-tile for all CT outputs.
-template <int CT, int MODE>
+template <int CT, int MODE, bool V4>
 __global__ __launch_bounds__(256) void quadform_conv_kernel(const float* __restrict__ u, const float* __restrict__ v,
                                                             const float* __restrict__ w0, const float* __restrict__ w1,
                                                             const float* __restrict__ delta, int C, int Do, int Dk, int L,
@@ -100,11 +193,17 @@ __global__ __launch_bounds__(256) void quadform_conv_kernel(const float* __restr
 #pragma unroll
   for (int p = 0; p < NP; ++p) pair[p] = 0.f;
 
+  auto operands = [&](int t) { return QcOperands{un, vn, (t % nOt) * 32, (t / nOt) * 128 + wave * 32 + lo}; };
+  QcStage<CT> st;
+  if (V4 && sp < ntiles) qc_fetch_v4<CT>(st, 0, (CT + 1) / 2, 0, QC_KC / 2, operands(sp), 0, C, Do, Dk, L);
   for (int t = sp; t < ntiles; t += split) {
-    const int o0 = (t % nOt) * 32, i0 = (t / nOt) * 128 + wave * 32;
-    const int icol = i0 + lo;
+    const QcOperands cur = operands(t);
+    const int o0 = cur.o0, icol = cur.icol;
     f32x16 acc[CT];
-    qc_tile_gemm<CT>(un, vn, o0, icol, C, Do, Dk, L, sA, acc);
+    if (V4)
+      qc_tile_gemm_v4<CT>(cur, operands(t + split), t + split < ntiles, C, Do, Dk, L, sA, acc, st);
+    else
+      qc_tile_gemm<CT>(un, vn, o0, icol, C, Do, Dk, L, sA, acc);
 
     // weights of this lane's 16 (o, i) positions and the pair sums, four accumulator rows at a time (the
     // accumulators live in AGPRs; only 4 * CT of them are copied out at once)
@@ -175,7 +274,7 @@ __global__ __launch_bounds__(256) void quadform_conv_reduce_kernel(const float* 
 // per-sample, per-seed weight Jacobian summed over the minibatch, without the [B, S, Do*Dk] Jacobian.
 // grid = ntiles * nsplit workgroups; workgroup (t, sp) owns the super-tile t for the samples sp, sp + nsplit, ... and
 // keeps the running sum of squares of its 32x32 wave tiles in registers.
-template <int CT>
+template <int CT, bool V4>
 __global__ __launch_bounds__(256) void diag_ggn_shared_kernel(const float* __restrict__ u, const float* __restrict__ v,
                                                               int B, int C, int Do, int Dk, int L, int nsplit,
                                                               float* __restrict__ partial) {
@@ -187,9 +286,15 @@ __global__ __launch_bounds__(256) void diag_ggn_shared_kernel(const float* __res
   float hacc[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) hacc[r] = 0.f;
+  auto operands = [&](int n) { return QcOperands{u + (size_t)n * C * L * Do, v + (size_t)n * L * Dk, o0, icol}; };
+  QcStage<CT> st;
+  if (V4 && sp < B) qc_fetch_v4<CT>(st, 0, (CT + 1) / 2, 0, QC_KC / 2, operands(sp), 0, C, Do, Dk, L);
   for (int n = sp; n < B; n += nsplit) {
     f32x16 acc[CT];
-    qc_tile_gemm<CT>(u + (size_t)n * C * L * Do, v + (size_t)n * L * Dk, o0, icol, C, Do, Dk, L, sA, acc);
+    if (V4)
+      qc_tile_gemm_v4<CT>(operands(n), operands(n + nsplit < B ? n + nsplit : n), n + nsplit < B, C, Do, Dk, L, sA, acc, st);
+    else
+      qc_tile_gemm<CT>(u + (size_t)n * C * L * Do, v + (size_t)n * L * Dk, o0, icol, C, Do, Dk, L, sA, acc);
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
@@ -215,6 +320,14 @@ __global__ __launch_bounds__(256) void diag_ggn_shared_reduce_kernel(const float
 }  // namespace lk
 
 using namespace lk;
+
+static int qc_v4_enabled() {
+  static const int on = [] {
+    const char* e = getenv("LK_QC_V4");  // development switch: 0 = scalar staging everywhere
+    return (e == nullptr || atoi(e) != 0) ? 1 : 0;
+  }();
+  return on;
+}
 
 static int qc_class_tile(int64_t C) {
   static const int tiles[] = {1, 2, 3, 4, 5, 6, 8, 10};  // 12 outputs would spill accumulators
@@ -253,10 +366,15 @@ static int launch_quadform_conv(const float* u, const float* v, const float* w0,
   const int split = qc_split(B, Do, Dk);
   float* partial = static_cast<float*>(ws);
   const dim3 grid((unsigned)(B * split));
+  const bool v4 = (Do % 4 == 0) && qc_v4_enabled();
 #define LK_QC_CASE(CT)                                                                                              \
   case CT:                                                                                                          \
-    hipLaunchKernelGGL((quadform_conv_kernel<CT, MODE>), grid, dim3(256), 0, stream, u, v, w0, w1, delta, (int)C,   \
-                       (int)Do, (int)Dk, (int)L, split, partial);                                                   \
+    if (v4)                                                                                                         \
+      hipLaunchKernelGGL((quadform_conv_kernel<CT, MODE, true>), grid, dim3(256), 0, stream, u, v, w0, w1, delta,   \
+                         (int)C, (int)Do, (int)Dk, (int)L, split, partial);                                         \
+    else                                                                                                            \
+      hipLaunchKernelGGL((quadform_conv_kernel<CT, MODE, false>), grid, dim3(256), 0, stream, u, v, w0, w1, delta,  \
+                         (int)C, (int)Do, (int)Dk, (int)L, split, partial);                                         \
     break;
   switch (ct) {
     LK_QC_CASE(1)
@@ -330,10 +448,15 @@ extern "C" int lk_diag_ggn_shared_f32(const float* u, const float* v, int64_t B,
   LK_REQUIRE(ntiles * nsplit < (1ll << 31), "lk_diag_ggn_shared_f32: grid too large");
   float* partial = static_cast<float*>(ws);
   const dim3 grid((unsigned)(ntiles * nsplit));
-#define LK_DG_CASE(CT)                                                                                                 \
-  case CT:                                                                                                             \
-    hipLaunchKernelGGL((diag_ggn_shared_kernel<CT>), grid, dim3(256), 0, stream, u, v, (int)B, (int)S, (int)Do, (int)Dk, \
-                       (int)L, nsplit, partial);                                                                       \
+  const bool v4 = (Do % 4 == 0) && qc_v4_enabled();
+#define LK_DG_CASE(CT)                                                                                               \
+  case CT:                                                                                                           \
+    if (v4)                                                                                                          \
+      hipLaunchKernelGGL((diag_ggn_shared_kernel<CT, true>), grid, dim3(256), 0, stream, u, v, (int)B, (int)S,       \
+                         (int)Do, (int)Dk, (int)L, nsplit, partial);                                                 \
+    else                                                                                                             \
+      hipLaunchKernelGGL((diag_ggn_shared_kernel<CT, false>), grid, dim3(256), 0, stream, u, v, (int)B, (int)S,      \
+                         (int)Do, (int)Dk, (int)L, nsplit, partial);                                                 \
     break;
   switch (ct) {
     LK_DG_CASE(1)
