@@ -188,9 +188,8 @@ class SeedBatchedSweep:
                     self.saved[node] = args[0].shape
                 if node.target is torch.mean:
                     dim = kwargs.get("dim", args[1] if len(args) > 1 else None)
-                    if not self._spatial_mean_dims(dim, args[0].dim()):
-                        raise SweepUnsupported("mean over dims other than the two spatial ones")
-                    self.saved[node] = (args[0].shape, bool(kwargs.get("keepdim", args[2] if len(args) > 2 else False)))
+                    self.saved[node] = (args[0].shape, bool(kwargs.get("keepdim", args[2] if len(args) > 2 else False)),
+                                        self._mean_dims(dim, args[0].dim()))
                 if node.target is operator.iadd:
                     out = args[0] + args[1]
                 elif node.target in self._GENERIC_ACT_FN:
@@ -215,9 +214,8 @@ class SeedBatchedSweep:
                 out = getattr(self_t, node.target)(*args, **kwargs)
                 if node.target == "mean":
                     dim = kwargs.get("dim", args[0] if args else None)
-                    if not self._spatial_mean_dims(dim, self_t.dim()):
-                        raise SweepUnsupported("mean over dims other than the two spatial ones")
-                    self.saved[node] = (self_t.shape, bool(kwargs.get("keepdim", args[1] if len(args) > 1 else False)))
+                    self.saved[node] = (self_t.shape, bool(kwargs.get("keepdim", args[1] if len(args) > 1 else False)),
+                                        self._mean_dims(dim, self_t.dim()))
                 if node.target == "relu":
                     self.saved[node] = (out > 0) if need_vjp else None
                 elif node.target in ("tanh", "sigmoid"):
@@ -270,12 +268,26 @@ class SeedBatchedSweep:
         return out.reshape(S * B, *in_shape[1:])
 
     @staticmethod
-    def _spatial_mean_dims(dim, ndim):
-        """True if ``dim`` names exactly the two trailing (spatial) dims of an NCHW tensor"""
-        if dim is None or ndim != 4:
-            return False
-        dims = sorted(d % ndim for d in (dim if isinstance(dim, (tuple, list)) else (dim,)))
-        return dims == [2, 3]
+    def _mean_dims(dim, ndim):
+        """sorted non-batch dims a ``mean`` reduces (spatial pooling of a conv map, pooling over the positions of a
+        sequence, ...); the batch dim must survive"""
+        if dim is None:
+            raise SweepUnsupported("mean over all dims (the batch dim included)")
+        dims = sorted({d % ndim for d in (dim if isinstance(dim, (tuple, list)) else (dim,))})
+        if 0 in dims:
+            raise SweepUnsupported("mean over the batch dim")
+        return dims
+
+    @staticmethod
+    def _mean_vjp(g, saved, SB):
+        shp, keep, dims = saved
+        if not keep:
+            for d in dims:
+                g = g.unsqueeze(d)
+        count = 1
+        for d in dims:
+            count *= shp[d]
+        return (g / count).expand(SB, *shp[1:])
 
     def _scaled_weight(self, name, m, scale):
         """``scale[co] * W`` for a deferred BatchNorm scale (cached until the weight or the scale changes)"""
@@ -485,9 +497,7 @@ class SeedBatchedSweep:
                         raise SweepUnsupported("adaptive_avg_pool2d VJP implemented for output size 1")
                     push(node.args[0], (g / (shp[-1] * shp[-2])).expand(S * B, *shp[1:]))
                 elif t is torch.mean:
-                    shp, keep = self.saved[node]
-                    gg = g if keep else g.reshape(S * B, shp[1], 1, 1)
-                    push(node.args[0], (gg / (shp[-1] * shp[-2])).expand(S * B, *shp[1:]))
+                    push(node.args[0], self._mean_vjp(g, self.saved[node], S * B))
             elif node.op == "call_method":
                 t = node.target
                 if t in ("relu", "tanh", "sigmoid"):
@@ -498,9 +508,7 @@ class SeedBatchedSweep:
                 elif t == "contiguous":
                     push(node.args[0], g)
                 elif t == "mean":
-                    shp, keep = self.saved[node]
-                    gg = g if keep else g.reshape(S * B, shp[1], 1, 1)
-                    push(node.args[0], (gg / (shp[-1] * shp[-2])).expand(S * B, *shp[1:]))
+                    push(node.args[0], self._mean_vjp(g, self.saved[node], S * B))
         if remaining:
             raise SweepUnsupported(f"no cotangent reached {sorted(remaining)}")
         return grads

@@ -4,7 +4,7 @@ TEST INFRASTRUCTURE.  Architectures follow the reference's own test fixtures
 (tests/test_curv_backends_curvlinops.py:23-65: ``Linear(3,20)-Tanh-Linear(20,2)`` on
 ``X[10,3]`` and the conv "complex_model" on ``X[10,3,5,5]``, seed 711) plus one ResNet-shaped
 conv stack (3x3 / padding 1 / stride 2 / bias-free conv) that the reference's fixtures lack but
-config c4 needs.  Weights and data are stored inside the golden files, so RNG drift between
+config c4 needs, a torchvision-style BatchNorm residual block, and a Linear applied along a sequence.  Weights and data are stored inside the golden files, so RNG drift between
 torch versions cannot silently change the fixtures.
 """
 from __future__ import annotations
@@ -12,7 +12,7 @@ from __future__ import annotations
 import torch
 from torch import nn
 
-FIXTURES = ("mlp", "conv", "resnetish", "bnres")
+FIXTURES = ("mlp", "conv", "resnetish", "bnres", "seqlin")
 
 
 class _BNResBlock(nn.Module):
@@ -35,6 +35,13 @@ class _BNResBlock(nn.Module):
         return self.relu(out)
 
 
+class _MeanOverPositions(nn.Module):
+    """[B, T, D] -> [B, D]"""
+
+    def forward(self, x):
+        return x.mean(1)
+
+
 def build_model(name: str) -> nn.Module:
     if name == "mlp":
         return nn.Sequential(nn.Linear(3, 20), nn.Tanh(), nn.Linear(20, 2))
@@ -51,6 +58,10 @@ def build_model(name: str) -> nn.Module:
             nn.Flatten(),
             nn.Linear(36, 3),
         )
+    if name == "seqlin":
+        # an nn.Linear applied along a sequence (weight sharing over T positions, as in a transformer block), pooled,
+        # then an ordinary head
+        return nn.Sequential(nn.Linear(5, 6), nn.Tanh(), _MeanOverPositions(), nn.Linear(6, 2))
     if name == "bnres":
         model = nn.Sequential(nn.Conv2d(2, 4, 3, padding=1), _BNResBlock(4), nn.AdaptiveAvgPool2d(1), nn.Flatten(),
                               nn.Linear(4, 3))
@@ -67,7 +78,7 @@ def build_model(name: str) -> nn.Module:
 
 
 def input_shape(name: str):
-    return {"mlp": (3,), "conv": (3, 5, 5), "resnetish": (2, 5, 5), "bnres": (2, 4, 4)}[name]
+    return {"mlp": (3,), "conv": (3, 5, 5), "resnetish": (2, 5, 5), "bnres": (2, 4, 4), "seqlin": (4, 5)}[name]
 
 
 def n_outputs(name: str) -> int:

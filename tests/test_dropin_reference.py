@@ -23,7 +23,7 @@ def rel(got, want):
     return (got - want).abs().max().item() / (want.abs().max().item() + 1e-30)
 
 
-@pytest.mark.parametrize("name", ["mlp", "conv", "resnetish"])
+@pytest.mark.parametrize("name", ["mlp", "conv", "resnetish", "bnres", "seqlin"])
 @pytest.mark.parametrize("lik", ["classification", "regression"])
 @pytest.mark.parametrize("sow,hs", [("all", "kron"), ("all", "diag"), ("all", "full"), ("last_layer", "kron"),
                                     ("last_layer", "full"), ("last_layer", "diag")])
@@ -73,7 +73,7 @@ def test_reference_laplace_with_hip_backend(ref, name, lik, sow, hs):
     assert rel(d_var, torch.diagonal(torch.as_tensor(g[f"{tag}.f_var"]), dim1=-2, dim2=-1)) < 1e-4
 
 
-@pytest.mark.parametrize("name", ["mlp", "conv", "resnetish"])
+@pytest.mark.parametrize("name", ["mlp", "conv", "resnetish", "bnres", "seqlin"])
 @pytest.mark.parametrize("lik", ["classification", "regression"])
 @pytest.mark.parametrize("sow", ["all", "last_layer"])
 def test_fit_kron_helper_equals_reference_fit(ref, name, lik, sow):

@@ -186,7 +186,7 @@ def test_R1_R2_R3(lik):
     check(7 * l1, l7, tol=1e-5, what="R3 loss")
 
 
-@pytest.mark.parametrize("name", ["mlp", "conv", "resnetish"])
+@pytest.mark.parametrize("name", ["mlp", "conv", "resnetish", "seqlin"])
 def test_R4_additivity_and_R7(name):
     from laplace_amd import HipGGN
 

@@ -40,7 +40,7 @@ def test_R2_R3_repeated_datum(lik):
     torch.testing.assert_close(7 * l1, l7)
 
 
-@pytest.mark.parametrize("name", ["mlp", "conv", "resnetish"])
+@pytest.mark.parametrize("name", ["mlp", "conv", "resnetish", "seqlin"])
 @pytest.mark.parametrize("lik", LIKS)
 def test_R4_minibatch_additivity(name, lik):
     """tests/test_curv_backends_curvlinops.py:207-238,277-293 (factors add with a fixed N)."""
@@ -74,7 +74,7 @@ def test_R5_norm_ratio(lik):
     assert abs(r - 1) < 0.011
 
 
-@pytest.mark.parametrize("name", ["mlp", "conv", "resnetish"])
+@pytest.mark.parametrize("name", ["mlp", "conv", "resnetish", "seqlin"])
 def test_R6_block_shapes(name):
     """tests/test_matrix.py:32-48 / utils/matrix.py:33-77."""
     model, X, y = _setup(name, "classification")
@@ -99,18 +99,21 @@ def test_R7_expand_vs_reduce():
     assert not torch.allclose(co.kron_diag(ke), co.kron_diag(kr))
 
 
-@pytest.mark.parametrize("name", ["mlp", "conv", "resnetish"])
+@pytest.mark.parametrize("name", ["mlp", "conv", "resnetish", "seqlin"])
 @pytest.mark.parametrize("lik", LIKS)
 def test_R9_bias_block_is_exact(name, lik):
     """Linear bias block [G] == bias-bias block of the dense GGN (curvature.py:375-411).
     (A conv bias under 'expand' carries sum_{n,l} g g^T, which is NOT the exact block - the
-    exact one sums over positions first - so conv biases are excluded.)"""
+    exact one sums over positions first - so conv biases are excluded; likewise the bias of a
+    Linear applied along a sequence, the `seqlin` fixture's first layer.)"""
     model, X, y = _setup(name, lik)
     _, kf = co.kfac_ggn(model, X, y, X.shape[0], lik)
     Js, f = co.jacobians(model, X)
     H = co.ggn_full(Js, co.functional_hessian(f, lik))
     off = 0
     conv_biases = {id(m.bias) for m in model.modules() if isinstance(m, torch.nn.Conv2d) and m.bias is not None}
+    if name == "seqlin":
+        conv_biases.add(id(model[0].bias))
     for F_, p in zip(kf, co.trainable_params(model)):
         n = p.numel()
         if p.ndim == 1 and id(p) not in conv_biases:
