@@ -206,3 +206,43 @@ def test_c3_last_layer_dense_predictive(resnet):
     Sigma = torch.linalg.inv(la.posterior_precision.double().cpu()).to(DEV)  # fp64 inverse on the host
     want_var = torch.einsum("ncp,pq,nkq->nck", Js[:64].double(), Sigma, Js[:64].double())
     assert rel(f_var, want_var) < 1e-4
+
+
+def test_c4_kron_and_diag_predictive_equal_the_block_jacobian_route(resnet_smooth):
+    """ResNet-18 full-network posterior (config c4): the Jacobian-free predictive kernels (lk_kron_quadform_shared_f32,
+    lk_diag_quadform_shared_f32) against the route they replaced on the same cotangents — every layer's Jacobian block
+    assembled and contracted as written (matrix.py:406-461, baselaplace.py:2113-2115) — plus symmetry / PSD of the
+    variances.  Smooth activation: the two routes run separate reverse passes."""
+    from laplace_amd import HipGGN
+    from laplace_amd import predictive as P
+    from laplace_amd._lib import get_kernels
+
+    for p_ in resnet_smooth.parameters():
+        p_.requires_grad_(True)
+    for m in resnet_smooth.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            for p_ in m.parameters():
+                p_.requires_grad_(False)
+    backend = HipGGN(resnet_smooth, "classification")
+    X, y = _resnet_batch(64, 21)
+    acc = backend.kron_accumulator(50_000)
+    acc.add_batch(X, y)
+    _, H = acc.finalize()
+    post = H.decompose() + torch.ones(1, device=DEV)
+    Xs = X[:4]
+    K = get_kernels()
+    f1, v1 = P.glm_variance_kron(backend, Xs, post)
+    post_var = 1.0 / (H.diag() + 1.0)
+    _, d1 = P.glm_variance_diag(backend, Xs, post_var)
+    prev = K.quadform_shared_max_outputs
+    K.quadform_shared_max_outputs = 0
+    try:
+        f2, v2 = P.glm_variance_kron(backend, Xs, post)
+        _, d2 = P.glm_variance_diag(backend, Xs, post_var)
+    finally:
+        K.quadform_shared_max_outputs = prev
+    assert rel(f1, f2) < 1e-5
+    assert rel(v1, v2) < 1e-4 and rel(d1, d2) < 1e-4
+    for v in (v1, d1):
+        assert rel(v, v.transpose(1, 2)) < 1e-6
+        assert torch.linalg.eigvalsh(v.double()).min().item() > -1e-6 * v.abs().max().item()
