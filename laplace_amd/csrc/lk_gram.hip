@@ -29,7 +29,10 @@
 namespace lk {
 
 // MODE_TNP: TN loader, tiles taken from a table (colA, colB, output offset): block-sparse products into compact blocks
-enum { MODE_TN = 0, MODE_NT = 1, MODE_CONV = 2, MODE_XCORR = 3, MODE_TNP = 4 };
+enum { MODE_TN = 0, MODE_NT = 1, MODE_CONV = 2, MODE_XCORR = 3, MODE_TNP = 4, MODE_NTB = 5 };
+// MODE_NTB: the NT product with the operands split into three bf16 pieces in LDS and six bf16 MFMAs per fp32 product
+// (see `split3` below): same loader, same accumulators, same epilogue as MODE_NT.
+__host__ __device__ constexpr bool is_nt(int mode) { return mode == MODE_NT || mode == MODE_NTB; }
 #ifdef LK_GRAM_TRACE  // development build (tools/gram_trace.py): per-phase cycle counts of one wave of the last launch
 __device__ long long g_gram_trace[5];
 #endif
@@ -101,7 +104,7 @@ struct Cfg {
 template <int MODE, int VEC, int CFG>
 __device__ __forceinline__ void stage_coord(int idx, int& krow, int& col) {
   using C = Cfg<CFG>;
-  if (MODE == MODE_NT) {
+  if (is_nt(MODE)) {
     constexpr int PER_COL = C::BK / VEC;
     col = idx / PER_COL;
     krow = (idx % PER_COL) * VEC;
@@ -146,7 +149,7 @@ __device__ __forceinline__ void make_colctx(const GramGeom& g, int col0, int tid
       cc.off[i] = ch;
     } else if (MODE == MODE_TN || MODE == MODE_TNP) {
       cc.off[i] = c;
-    } else if (MODE == MODE_NT) {
+    } else if (is_nt(MODE)) {
       cc.off[i] = (int64_t)c * g.L;
     } else {
       const int d = c / g.Cin, ci = c - d * g.Cin;
@@ -165,7 +168,7 @@ __device__ __forceinline__ void load_panel(const GramGeom& g, int64_t k0, int ti
   // chunk-uniform part (NT: a chunk never straddles images because Lp % BK == 0)
   const float* nt_base = nullptr;
   int nt_l0 = 0;
-  if (MODE == MODE_NT) {
+  if (is_nt(MODE)) {
     if (k0 < g.K) {
       const int64_t b = k0 / g.Lp;
       nt_l0 = (int)(k0 - b * g.Lp);
@@ -184,7 +187,7 @@ __device__ __forceinline__ void load_panel(const GramGeom& g, int64_t k0, int ti
       const int64_t k = k0 + krow;
       valid = valid && (k < g.K);
       p = g.x + k * g.ldx + cc.off[i];
-    } else if (MODE == MODE_NT) {
+    } else if (is_nt(MODE)) {
       valid = valid && (nt_base != nullptr) && (nt_l0 + krow < g.L);
       p = nt_base + cc.off[i] + krow;
     } else if (MODE == MODE_XCORR) {
@@ -219,10 +222,105 @@ __device__ __forceinline__ void load_panel(const GramGeom& g, int64_t k0, int ti
   }
 }
 
+// ---- fp32 products on the bf16 matrix cores (MODE_NTB) ------------------------------------------------------
+// x = h + m + l exactly, each piece a bf16 (8 significant bits; truncation makes every subtraction exact), and
+//   x y ~= h h' + h m' + m h' + m m' + h l' + l h'      (dropped: m l', l m', l l' <= 3 * 2^-24 |x y|)
+// i.e. six v_mfma_f32_32x32x16_bf16 (32 cycles, K = 16) replace eight v_mfma_f32_32x32x2_f32 (64 cycles, K = 2) per
+// 16 rows of a 32x32 tile at fp32-level accuracy: 192 instead of 512 matrix-pipe cycles.  The operand is split ONCE,
+// by the thread that stages it; a panel holds [piece][column][k] bf16 with k contiguous, which is how the NT loader
+// reads memory anyway (positions of one channel) and what a lane of the bf16 MFMA wants (8 consecutive k).
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+template <int CFG>
+struct NtbCfg {
+  using C = Cfg<CFG>;
+  static constexpr int BKP = C::BK == 16 ? 16 : C::BK + 8;  // k pitch (bf16): 144-B rows keep ds_read_b128 conflict-free
+  static constexpr int PIECE = C::T * BKP * 2;             // bytes of one piece of a panel
+  static constexpr int PANEL_F = 3 * PIECE / 4;            // panel size in floats (the LDS arena is float-typed)
+};
+
+__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
+  h = __float_as_uint(x) & 0xffff0000u;
+  const float r1 = x - __uint_as_float(h);
+  m = __float_as_uint(r1) & 0xffff0000u;
+  l = __float_as_uint(r1 - __uint_as_float(m));  // at most 8 significant bits are left: exact in bf16
+}
+__device__ __forceinline__ unsigned pack_hi16(unsigned lo_elem, unsigned hi_elem) {
+  return (lo_elem >> 16) | (hi_elem & 0xffff0000u);
+}
+
+template <int VEC, int CFG>
+__device__ __forceinline__ void store_panel_ntb(float* panel, int tid, const float (&st)[Cfg<CFG>::EPT]) {
+  using C = Cfg<CFG>;
+  using N = NtbCfg<CFG>;
+  constexpr int NL = C::EPT / VEC;
+  char* base = reinterpret_cast<char*>(panel);
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    int krow, col;
+    stage_coord<MODE_NTB, VEC, CFG>(tid + 256 * i, krow, col);
+    char* dst = base + (col * N::BKP + krow) * 2;
+    if (VEC == 4) {
+      unsigned h[4], m[4], l[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) split3(st[i * 4 + j], h[j], m[j], l[j]);
+      *reinterpret_cast<u32x2*>(dst) = u32x2{pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3])};
+      *reinterpret_cast<u32x2*>(dst + N::PIECE) = u32x2{pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3])};
+      *reinterpret_cast<u32x2*>(dst + 2 * N::PIECE) = u32x2{pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3])};
+    } else {
+      unsigned h, m, l;
+      split3(st[i], h, m, l);
+      *reinterpret_cast<unsigned short*>(dst) = (unsigned short)(h >> 16);
+      *reinterpret_cast<unsigned short*>(dst + N::PIECE) = (unsigned short)(m >> 16);
+      *reinterpret_cast<unsigned short*>(dst + 2 * N::PIECE) = (unsigned short)(l >> 16);
+    }
+  }
+}
+
+// One chunk of the split product for this wave: per 16 rows, 3 ds_read_b128 per 32-column operand tile and 6 MFMAs
+// per 32x32 output tile.  pA / pB point at this lane's (column, k-half) inside piece 0 of the panels.
+template <int CFG, bool FULL>
+__device__ __forceinline__ void compute_chunk_ntb(const char* __restrict__ pA, const char* __restrict__ pB,
+                                                  f32x16 (&acc)[Cfg<CFG>::TW][Cfg<CFG>::TW], int am, int an) {
+  using C = Cfg<CFG>;
+  using N = NtbCfg<CFG>;
+  constexpr int TW = C::TW;
+#pragma unroll
+  for (int k16 = 0; k16 < C::BK / 16; ++k16) {
+    bf16x8 a[3][TW], b[3][TW];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int t = 0; t < TW; ++t) {
+        a[p][t] = *reinterpret_cast<const bf16x8*>(pA + p * N::PIECE + (t * 32 * N::BKP + k16 * 16) * 2);
+        b[p][t] = *reinterpret_cast<const bf16x8*>(pB + p * N::PIECE + (t * 32 * N::BKP + k16 * 16) * 2);
+      }
+#pragma unroll
+    for (int tm = 0; tm < TW; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TW; ++tn)
+        if (FULL || (tm < am && tn < an)) {
+          f32x16 c = acc[tm][tn];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][tm], b[0][tn], c, 0, 0, 0);  // small terms first
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][tm], b[2][tn], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][tm], b[1][tn], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][tm], b[0][tn], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][tm], b[1][tn], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][tm], b[0][tn], c, 0, 0, 0);
+          acc[tm][tn] = c;
+        }
+  }
+}
+
 template <int MODE, int VEC, int CFG>
 __device__ __forceinline__ void store_panel(float* panel, int tid, const float (&st)[Cfg<CFG>::EPT]) {
   using C = Cfg<CFG>;
   constexpr int NL = C::EPT / VEC;
+  if (MODE == MODE_NTB) {
+    store_panel_ntb<VEC, CFG>(panel, tid, st);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
     int krow, col;
@@ -296,7 +394,7 @@ __device__ __forceinline__ void gram_body(const GramGeom& g, float* __restrict__
                                           int c_begin, int c_end, int am, int an, float* __restrict__ Cdirect,
                                           float alpha, int reg) {
   using C = Cfg<CFG>;
-  constexpr int PANEL = C::BK * C::LDP;
+  constexpr int PANEL = MODE == MODE_NTB ? NtbCfg<CFG>::PANEL_F : C::BK * C::LDP;
   constexpr int TW = C::TW;
   constexpr int NP = (C::SMALL && MODE != MODE_XCORR && MODE != MODE_TNP) ? 1 : 2;
 
@@ -346,7 +444,13 @@ __device__ __forceinline__ void gram_body(const GramGeom& g, float* __restrict__
     LK_TSTAMP(t1);
     const float* pA = smem + cur * NP * PANEL;
     const float* pB = diag ? pA : pA + PANEL;
-    compute_chunk<CFG, FULL>(pA + offA, pB + offB, acc, am, an);
+    if (MODE == MODE_NTB) {
+      constexpr int BKP = NtbCfg<CFG>::BKP;
+      compute_chunk_ntb<CFG, FULL>(reinterpret_cast<const char*>(pA) + ((wm * C::WT + lo) * BKP + 8 * hi) * 2,
+                                   reinterpret_cast<const char*>(pB) + ((wn * C::WT + lo) * BKP + 8 * hi) * 2, acc, am, an);
+    } else {
+      compute_chunk<CFG, FULL>(pA + offA, pB + offB, acc, am, an);
+    }
     LK_TSTAMP(t2);
     if (more) {
       float* nx = smem + (cur ^ 1) * NP * PANEL;
@@ -593,7 +697,11 @@ static void finish_plan(GramPlan& p) {
 static int cfg_tile(int cfg) { return (cfg == CFG_SMALL || cfg == CFG_SMALL16) ? 64 : (cfg == CFG_WIDE ? 192 : 128); }
 static int cfg_bk(int cfg) { return cfg == CFG_SMALL ? 64 : (cfg == CFG_BIG24 ? 24 : (cfg == CFG_BIG32 ? 32 : 16)); }
 // dynamic LDS of one workgroup: [2 buffers][panels][BK][T + 4] floats
-static size_t cfg_lds_bytes(int cfg, bool two_panels) {
+static size_t cfg_lds_bytes(int cfg, bool two_panels, bool ntb = false) {
+  if (ntb) {  // [2 buffers][panels][3 pieces][T][BKP] bf16 (NtbCfg)
+    const int bk = cfg_bk(cfg), bkp = bk == 16 ? 16 : bk + 8;
+    return (size_t)2 * (two_panels ? 2 : 1) * 3 * cfg_tile(cfg) * bkp * 2;
+  }
   return (size_t)2 * (two_panels ? 2 : 1) * cfg_bk(cfg) * (cfg_tile(cfg) + 4) * sizeof(float);
 }
 // The 128-tile's chunk depth.  16 rows per barrier (3 workgroups per CU) is the default; LK_GRAM_BK = 24 / 32 selects
@@ -656,7 +764,7 @@ static int launch_gram(const GramGeom& g, bool vec4, float alpha, float* C, unsi
                        size_t ws_bytes, hipStream_t stream) {
   if (g.n <= 0) return LK_OK;
   // NT: g.K counts padded positions (Lp per image); the plan wants the chunk count of exactly that
-  const GramPlan p = make_plan(g.n, g.K, MODE == MODE_NT ? g.L : 0);
+  const GramPlan p = make_plan(g.n, g.K, is_nt(MODE) ? g.L : 0);
   if (ws == nullptr || ws_bytes < p.ws_bytes) {
     set_error("gram: workspace too small (%zu < %zu bytes)", ws_bytes, p.ws_bytes);
     return LK_EWORKSPACE;
@@ -668,7 +776,7 @@ static int launch_gram(const GramGeom& g, bool vec4, float alpha, float* C, unsi
   float* Cdirect = (!persist && p.nsplit == 1 && (flags & LK_GRAM_UPPER_ONLY)) ? C : nullptr;
   GramGeom gp = g;
   gp.slab_accumulate = persist ? 1 : 0;
-  const size_t lds = cfg_lds_bytes(p.cfg, !(p.cfg == CFG_SMALL));
+  const size_t lds = cfg_lds_bytes(p.cfg, !(p.cfg == CFG_SMALL), MODE == MODE_NTB);
 #define LK_LAUNCH(V, S)                                                                                          \
   do {                                                                                                           \
     if (!allow_big_lds((const void*)gram_kernel<MODE, V, S>, lds)) return LK_ELAUNCH;                            \
@@ -1057,6 +1165,12 @@ extern "C" int lk_gram_nt_seg_f32(const float* const* segs, int64_t nseg, int64_
     vec4 = vec4 && aligned16(segs[i]);
   }
   g.x = segs[0];
+  // fp32 products from split-bf16 MFMAs (MODE_NTB) whenever the positions can be read four at a time
+  static const bool ntb = [] {
+    const char* e = getenv("LK_GRAM_NTB");  // development switch: 0 = the fp32-MFMA NT kernel
+    return e == nullptr || atoi(e) != 0;
+  }();
+  if (ntb && vec4 && BK % 16 == 0) return launch_gram<MODE_NTB>(g, vec4, alpha, C, flags, ws, ws_bytes, (hipStream_t)stream);
   return launch_gram<MODE_NT>(g, vec4, alpha, C, flags, ws, ws_bytes, (hipStream_t)stream);
 }
 
