@@ -265,15 +265,18 @@ int lk_diag_quadform_linear_f32(const float* a, const float* g, const float* var
                                 int64_t B, int64_t Cc, int64_t Do, int64_t Di, float* fvar, void* stream);
 
 /* Weight-sharing layers (nn.Conv2d; nn.Linear applied along a sequence): the per-sample Jacobian of output c is
- * J_c = sum_l u[n][c][l][:] v[n][l][:]^T  (Do x Dk, L shared positions), and KronLaplace / DiagLaplace
+ * J_c = sum_l u[n][c][:][l] v[n][:][l]^T  (Do x Dk, L shared positions), and KronLaplace / DiagLaplace
  * .functional_variance (baselaplace.py:1834-1835 via matrix.py:406-461; baselaplace.py:2113-2115) contract the
  * materialised [B, C, Do*Dk] block.  These two never form it:
  *   fvar[n][c][k] += sum_{o,i} J_c[o,i] J_k[o,i] w[o,i]
- *   Kronecker posterior: u = (grad w.r.t. the layer output) Q1, v = (unfolded input) Q2, w = 1/(l1[o] l2[i] + delta[0])
- *   diagonal posterior:  u, v raw,                                                   w = var_w[o][i]
- * u [B][C][L][Do], v [B][L][Dk] (both position-major, i.e. channels-last), C <= 10 (LK_EINVAL beyond: use the generic
- * Jacobian form).  Per sample one MFMA GEMM [(C*Do) x L].[L x Dk] whose 32x32 tiles stay in accumulators for all C
- * outputs and are folded into the C(C+1)/2 pair sums in registers; workgroup partials are reduced in fixed order.
+ *   Kronecker posterior: u = Q1^T (grad w.r.t. the layer output), v = Q2^T (unfolded input), w = 1/(l1[o] l2[i] + delta[0])
+ *   diagonal posterior:  u, v raw,                                                          w = var_w[o][i]
+ * u [B][C][Do][L], v [B][Dk][L] (both position-contiguous: the NCHW layout of a convolution's output gradient and of
+ * F.unfold), C <= 10 (LK_EINVAL beyond: use the generic Jacobian form).  Per sample one MFMA GEMM
+ * [(C*Do) x L].[L x Dk] whose 32x32 tiles stay in accumulators for all C outputs and are folded into the C(C+1)/2 pair
+ * sums in registers; workgroup partials are reduced in fixed order.  With L % 4 == 0 and 16-byte aligned u, v the
+ * product runs on the bf16 matrix cores at fp32 accuracy (operands split into three bf16 pieces, six
+ * v_mfma_f32_32x32x16_bf16 per fp32 product; dropped terms <= 3 * 2^-24), otherwise on v_mfma_f32_32x32x2_f32.
  * Requires C*L*Do < 2^29 and L*Dk < 2^29. */
 size_t lk_quadform_shared_workspace_bytes(int64_t B, int64_t C, int64_t Do, int64_t Dk);
 int lk_kron_quadform_shared_f32(const float* u, const float* v, const float* l1, const float* l2, const float* delta,
@@ -283,8 +286,8 @@ int lk_diag_quadform_shared_f32(const float* u, const float* v, const float* var
                                 int64_t Dk, int64_t L, float* fvar, void* ws, size_t ws_bytes, void* stream);
 
 /* Exact GGN / Fisher diagonal of a weight-sharing layer (GGNInterface.diag, laplace/curvature/curvature.py:413-433,
- * restricted to the layer's weight): h[o][i] += alpha * sum_{n,s} (sum_l u[n][s][l][o] v[n][l][i])^2 with
- * u [B][S][L][Do] the seed cotangents at the layer output and v [B][L][Dk] the unfolded input, S <= 10 seeds per call.
+ * restricted to the layer's weight): h[o][i] += alpha * sum_{n,s} (sum_l u[n][s][o][l] v[n][i][l])^2 with
+ * u [B][S][Do][L] the seed cotangents at the layer output and v [B][Dk][L] the unfolded input, S <= 10 seeds per call.
  * Same tile GEMM as lk_*_quadform_shared_f32; the squares are summed over (sample, seed) in registers, so the
  * [B, S, Do*Dk] per-sample Jacobian the as-written einsum contracts is never formed. */
 size_t lk_diag_ggn_shared_workspace_bytes(int64_t B, int64_t Do, int64_t Dk);

@@ -635,11 +635,11 @@ class HipKernels:
     quadform_shared_max_outputs = 10
 
     def kron_quadform_shared(self, u, v, l1, l2, delta, fvar):
-        """``u [B, C, L, Do]``, ``v [B, L, Dk]`` (eigenbasis projections); ``fvar [B, C, C] +=``."""
+        """``u [B, C, Do, L]``, ``v [B, Dk, L]`` (eigenbasis projections); ``fvar [B, C, C] +=``."""
         for t, nm in ((u, "u"), (v, "v"), (l1, "l1"), (l2, "l2"), (delta, "delta"), (fvar, "fvar")):
             _check(t, nm)
-        B, C, L, Do = u.shape
-        Dk = v.shape[2]
+        B, C, Do, L = u.shape
+        Dk = v.shape[1]
         ws = self._workspace(self.lib.lk_quadform_shared_workspace_bytes(B, C, Do, Dk), u.device)
         self._rc(
             self.lib.lk_kron_quadform_shared_f32(_ptr(u), _ptr(v), _ptr(l1), _ptr(l2), _ptr(delta), B, C, Do, Dk, L,
@@ -649,11 +649,11 @@ class HipKernels:
         return fvar
 
     def diag_quadform_shared(self, u, v, var_w, fvar):
-        """``u [B, C, L, Do]`` output gradients, ``v [B, L, Dk]`` unfolded inputs, ``var_w [Do, Dk]``."""
+        """``u [B, C, Do, L]`` output gradients, ``v [B, Dk, L]`` unfolded inputs, ``var_w [Do, Dk]``."""
         for t, nm in ((u, "u"), (v, "v"), (var_w, "var_w"), (fvar, "fvar")):
             _check(t, nm)
-        B, C, L, Do = u.shape
-        Dk = v.shape[2]
+        B, C, Do, L = u.shape
+        Dk = v.shape[1]
         ws = self._workspace(self.lib.lk_quadform_shared_workspace_bytes(B, C, Do, Dk), u.device)
         self._rc(
             self.lib.lk_diag_quadform_shared_f32(_ptr(u), _ptr(v), _ptr(var_w), B, C, Do, Dk, L, _ptr(fvar), _ptr(ws),
@@ -663,11 +663,11 @@ class HipKernels:
         return fvar
 
     def diag_ggn_shared(self, u, v, alpha, h):
-        """``h[Do*Dk] += alpha * sum_{n,s} (u[n,s]^T v[n])^2``; ``u [B, S, L, Do]``, ``v [B, L, Dk]``, ``S <= 10``."""
+        """``h[Do*Dk] += alpha * sum_{n,s} (u[n,s] v[n]^T)^2``; ``u [B, S, Do, L]``, ``v [B, Dk, L]``, ``S <= 10``."""
         for t, nm in ((u, "u"), (v, "v"), (h, "h")):
             _check(t, nm)
-        B, S, L, Do = u.shape
-        Dk = v.shape[2]
+        B, S, Do, L = u.shape
+        Dk = v.shape[1]
         ws = self._workspace(self.lib.lk_diag_ggn_shared_workspace_bytes(B, Do, Dk), u.device)
         self._rc(
             self.lib.lk_diag_ggn_shared_f32(_ptr(u), _ptr(v), B, S, Do, Dk, L, float(alpha), _ptr(h), _ptr(ws), ws.numel(),

@@ -39,9 +39,10 @@ from laplace_amd.refapi import EFInterface, GGNInterface
 
 
 def shared_operands(tap, g, B, C, Q1=None, Q2=None):
-    """``u [B, C, L, Do]`` and ``v [B, L, Dk]`` of a weight-sharing layer (Conv2d, or Linear along a sequence), whose
-    per-sample Jacobian of output / seed ``c`` is ``sum_l u[n, c, l, :] v[n, l, :]^T`` (:mod:`laplace_amd.predictive`), rotated into the
-    eigenbases ``Q1`` / ``Q2`` if given; plus the position-summed output gradient ``[C, B, Do]`` for the bias."""
+    """``u [B, C, Do, L]`` and ``v [B, Dk, L]`` (both position-contiguous) of a weight-sharing layer (Conv2d, or Linear
+    along a sequence), whose per-sample Jacobian of output / seed ``c`` is ``sum_l u[n, c, :, l] v[n, :, l]^T``
+    (:mod:`laplace_amd.predictive`), rotated into the eigenbases ``Q1`` / ``Q2`` if given; plus the position-summed
+    output gradient ``[C, B, Do]`` for the bias."""
     m = tap.module
     a = tap.a.to(torch.float32)
     if tap.kind == "conv2d":
@@ -50,25 +51,29 @@ def shared_operands(tap, g, B, C, Q1=None, Q2=None):
         L = g4.shape[-1]
         Dk = m.weight[0].numel()
         if Q2 is None:
-            v = F.unfold(a, m.kernel_size, m.dilation, m.padding, m.stride).transpose(1, 2).contiguous()
+            v = F.unfold(a, m.kernel_size, m.dilation, m.padding, m.stride)          # [B, Dk, L]
         else:
             # unfolded patches (x) Q2 = one convolution whose filters are the eigenvectors (rows of the A factor
-            # follow F.unfold's (c_in, kh, kw) order = the weight layout); channels-last output IS [B, L, Dk]
+            # follow F.unfold's (c_in, kh, kw) order = the weight layout); its NCHW output IS [B, Dk, L]
             filt = Q2.T.reshape(Dk, *m.weight.shape[1:])
-            v = F.conv2d(a.contiguous(memory_format=torch.channels_last),
-                         filt.contiguous(memory_format=torch.channels_last), None, m.stride, m.padding, m.dilation)
-            v = v.permute(0, 2, 3, 1).contiguous().reshape(B, L, Dk)
+            v = F.conv2d(a, filt, None, m.stride, m.padding, m.dilation).reshape(B, Dk, L)
         gsum = g4.sum(-1)
-        u = g4.permute(1, 0, 3, 2)                                     # [B, C, L, Do]
+        u = g4.permute(1, 0, 2, 3)                                     # [B, C, Do, L]
+        if Q1 is not None:
+            u = torch.matmul(Q1.T, u)
     else:                                                              # Linear over [B, ..., Di]
         Do = m.out_features
         v = a.reshape(B, -1, a.shape[-1])
         L = v.shape[1]
-        u = g.reshape(C, B, L, Do).permute(1, 0, 2, 3)
-        gsum = g.reshape(C, B, L, Do).sum(2)
+        gt = g.reshape(C, B, L, Do)
+        gsum = gt.sum(2)
+        u = gt.permute(1, 0, 2, 3)                                     # [B, C, L, Do]
         if Q2 is not None:
             v = v @ Q2
-    u = (u @ Q1) if Q1 is not None else u
+        if Q1 is not None:
+            u = u @ Q1
+        v = v.transpose(1, 2)
+        u = u.transpose(2, 3)
     return u.contiguous(), v.contiguous(), gsum
 
 

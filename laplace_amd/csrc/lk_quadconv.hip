@@ -9,22 +9,40 @@
 // in registers: nothing of size Do*Dk is ever written.  u, v are the output gradients / unfolded inputs, already
 // rotated into the factors' eigenbases by the caller for the Kronecker posterior (w = 1/(l1_o l2_i + delta)), raw for
 // the diagonal one (w = posterior variance of weight (o,i)).
+#include <stdint.h>
 #include <stdlib.h>
 
 #include "lk_common.h"
 
 namespace lk {
 
-constexpr int QC_KC = 16;  // positions per LDS chunk (8 MFMA k-steps)
+constexpr int QC_KC = 16;  // positions per chunk
 
-// acc[c] = the 32x32 tile (rows o0.., this wave's columns icol) of  u_c^T v = sum_l u[c][l][:]^T v[l][:]  for all CT
-// outputs of one sample.  A operand (u, all outputs) through double-buffered LDS shared by the 4 waves, B operand (v)
-// straight from memory; the next chunk's operands travel while the current one is multiplied.
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct QcOperands {  // one tile's operands: sample base pointers, first row, this lane's column
+  const float* un;   // u[n]: [C][Do][L]
+  const float* vn;   // v[n]: [Dk][L]
+  int o0, icol;
+};
+
+// LDS arena of one workgroup, reinterpreted by the two tile products below
 template <int CT>
-__device__ __forceinline__ void qc_tile_gemm(const float* __restrict__ un, const float* __restrict__ vn, int o0,
-                                             int icol, int C, int Do, int Dk, int L, float (*sA)[CT][QC_KC][32],
+struct QcLds {
+  static constexpr int BYTES = CT * 6144;  // split-bf16: [2][3 pieces][CT][32 o][16 k] bf16; fp32: [2][CT][16 k][32 o] (4096 CT)
+};
+
+// ---- generic tile product (any L, any alignment): fp32 operands, v_mfma_f32_32x32x2_f32 --------------------------
+// acc[c] = the 32x32 tile (rows o0.., this wave's columns icol) of  sum_l u[c][:, l] v[:, l]^T  for all CT outputs of
+// one sample.  A operand (u, all outputs) through double-buffered LDS shared by the 4 waves, B operand straight from
+// memory.  Used when the positions cannot be read four at a time.
+template <int CT>
+__device__ __forceinline__ void qc_tile_gemm(const QcOperands& t, int C, int Do, int Dk, int L, char* lds,
                                              f32x16 (&acc)[CT]) {
   constexpr int NA = 2 * CT;  // staged dwords per thread per chunk: CT * QC_KC * 32 / 256
+  float(*sA)[CT][QC_KC][32] = reinterpret_cast<float(*)[CT][QC_KC][32]>(lds);
   const int tid = threadIdx.x, lane = tid & 63, lo = lane & 31, hi = lane >> 5;
 #pragma unroll
   for (int c = 0; c < CT; ++c)
@@ -36,14 +54,14 @@ __device__ __forceinline__ void qc_tile_gemm(const float* __restrict__ un, const
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
       const int e = tid + 256 * j, o = e & 31, ll = (e >> 5) & (QC_KC - 1), c = e >> 9;
-      const bool ok = c < C && l0 + ll < L && o0 + o < Do;
+      const bool ok = c < C && l0 + ll < L && t.o0 + o < Do;
       // 32-bit offsets from the sample's (uniform) base pointer: the host checks C*L*Do and L*Dk < 2^29
-      ra[j] = ok ? un[(unsigned)((c * L + l0 + ll) * Do + o0 + o)] : 0.f;
+      ra[j] = ok ? t.un[(unsigned)((c * Do + t.o0 + o) * L + l0 + ll)] : 0.f;
     }
 #pragma unroll
     for (int kk = 0; kk < QC_KC / 2; ++kk) {
       const int l = l0 + 2 * kk + hi;
-      rb[kk] = (l < L && icol < Dk) ? vn[(unsigned)(l * Dk + icol)] : 0.f;
+      rb[kk] = (l < L && t.icol < Dk) ? t.vn[(unsigned)(t.icol * L + l)] : 0.f;
     }
   };
   fetch(0);
@@ -59,8 +77,6 @@ __device__ __forceinline__ void qc_tile_gemm(const float* __restrict__ un, const
     for (int kk = 0; kk < QC_KC / 2; ++kk) b[kk] = rb[kk];
     __syncthreads();
     if (l0 + QC_KC < L) fetch(l0 + QC_KC);
-    // LDS operand reads run exactly one k-step ahead of the MFMAs (the scheduler would otherwise hoist all
-    // 8 * CT of them and spill)
     float a_cur[CT], a_nxt[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c) a_cur[c] = sA[buf][c][hi][lo];
@@ -81,112 +97,150 @@ __device__ __forceinline__ void qc_tile_gemm(const float* __restrict__ un, const
   __syncthreads();  // every wave is done with both LDS buffers before the caller's next tile refills them
 }
 
-// Same tile product for Do % 4 == 0 (every layer of a ResNet): the A chunk travels as CT/2 float4 loads and
-// ds_write_b128 per thread instead of 2 CT dwords, addresses are one per-thread offset plus uniform strides, and the
-// next chunk's loads are issued one per k-step between the MFMAs instead of in a burst before them (with one wave per
-// SIMD nothing else hides that burst).  The pipeline runs across tiles: during the last chunk of a tile the first
-// chunk of the NEXT tile (other rows / columns, or the next sample) is fetched, so short K loops (L = 16) do not pay
-// a cold start per tile.  Loads are issued raw from a clamped (always valid) address and zeroed where the value is
-// consumed a chunk later -- a select right behind the load would make the wave wait out the memory latency.
-struct QcOperands {  // one tile's operands: sample base pointers, first row, this lane's column
-  const float* un;
-  const float* vn;
-  int o0, icol;
-};
+// ---- the tile product on the bf16 matrix cores at fp32 accuracy (L % 4 == 0) --------------------------------------
+// Every operand is split ONCE into three bf16 pieces, x = h + m + l exactly (truncation keeps the subtractions exact),
+// and  x y ~= h h' + h m' + m h' + m m' + h l' + l h'  (dropped terms <= 3 * 2^-24 |x y|): six
+// v_mfma_f32_32x32x16_bf16 (32 cycles, 16 positions) instead of eight v_mfma_f32_32x32x2_f32 (64 cycles, 2 positions)
+// per chunk and output -- 192 matrix-pipe cycles where the fp32 form needs 512.  Both operands are position-contiguous
+// in memory, which is what a lane of the bf16 MFMA wants (8 consecutive k): the A chunk is staged as float4s along
+// the positions, split by the staging thread and kept in LDS as [piece][output][row o][16 k]; the B operand is this
+// lane's own 8 positions of column icol, split in registers.  The pipeline runs across tiles: during a tile's last
+// chunk the first chunk of the NEXT tile (other rows / columns, or the next sample) is fetched; loads are issued raw
+// from a clamped address and zeroed where they are consumed.
+__device__ __forceinline__ void qc_split3(float x, unsigned& h, unsigned& m, unsigned& l) {
+  h = __float_as_uint(x) & 0xffff0000u;
+  const float r1 = x - __uint_as_float(h);
+  m = __float_as_uint(r1) & 0xffff0000u;
+  l = __float_as_uint(r1 - __uint_as_float(m));  // at most 8 significant bits are left: exact in bf16
+}
+__device__ __forceinline__ unsigned qc_pack(unsigned even, unsigned odd) { return (even >> 16) | (odd & 0xffff0000u); }
 
 template <int CT>
-struct QcStage {  // operands in flight: a thread's float4 slots of the A chunk and its lane's B column
+struct QcStage {  // raw operands in flight: this thread's float4 slots of the A chunk, this lane's 8 positions of B
   f32x4 ra[(CT + 1) / 2];
-  float rb[QC_KC / 2];
+  f32x4 rb[2];
 };
 
+// staging coordinates of thread tid: float4 slot e4 = tid + 256 j  ->  k4 = 4 (tid & 3), row o = (tid >> 2) & 31,
+// output c = (tid >> 7) + 2 j
 template <int CT>
-__device__ __forceinline__ void qc_fetch_v4(QcStage<CT>& st, int j_lo, int j_hi, int kk_lo, int kk_hi, const QcOperands& t,
+__device__ __forceinline__ void qc_fetch_b6(QcStage<CT>& st, int j_lo, int j_hi, int h_lo, int h_hi, const QcOperands& t,
                                             int l0, int C, int Do, int Dk, int L) {
   const int tid = threadIdx.x, hi = (tid & 63) >> 5;
-  const int o4 = 4 * (tid & 7), ll = (tid >> 3) & (QC_KC - 1), c0 = tid >> 7;
+  const int k4 = 4 * (tid & 3), o = (tid >> 2) & 31, c0 = tid >> 7;
 #pragma unroll
   for (int j = j_lo; j < j_hi; ++j) {
-    const bool ok = t.o0 + o4 < Do && c0 + 2 * j < C && l0 + ll < L;
-    const unsigned off = ok ? ((unsigned)((c0 + 2 * j) * L + l0 + ll) * (unsigned)Do + (unsigned)(t.o0 + o4)) : 0u;
+    const bool ok = t.o0 + o < Do && c0 + 2 * j < C && l0 + k4 < L;
+    const unsigned off = ok ? (unsigned)(((c0 + 2 * j) * Do + t.o0 + o) * L + l0 + k4) : 0u;
     st.ra[j] = *reinterpret_cast<const f32x4*>(t.un + off);
   }
 #pragma unroll
-  for (int kk = kk_lo; kk < kk_hi; ++kk) {
-    const bool ok = t.icol < Dk && l0 + 2 * kk + hi < L;
-    st.rb[kk] = t.vn[ok ? (unsigned)((l0 + 2 * kk + hi) * Dk + t.icol) : 0u];
+  for (int h = h_lo; h < h_hi; ++h) {
+    const int l = l0 + 8 * hi + 4 * h;
+    const bool ok = t.icol < Dk && l < L;
+    st.rb[h] = *reinterpret_cast<const f32x4*>(t.vn + (ok ? (unsigned)(t.icol * L + l) : 0u));
   }
 }
 
 // On entry `st` holds chunk 0 of `cur`; on exit chunk 0 of `nxt` (if has_next).
 template <int CT>
-__device__ __forceinline__ void qc_tile_gemm_v4(const QcOperands& cur, const QcOperands& nxt, bool has_next, int C,
-                                                int Do, int Dk, int L, float (*sA)[CT][QC_KC][32], f32x16 (&acc)[CT],
-                                                QcStage<CT>& st) {
-  constexpr int NA4 = (CT + 1) / 2;  // float4 slots per thread per chunk: CT * QC_KC * 8 / 256
-  constexpr int KS = QC_KC / 2;
-  static_assert(NA4 <= KS, "one A load per k-step");
+__device__ __forceinline__ void qc_tile_gemm_b6(const QcOperands& cur, const QcOperands& nxt, bool has_next, int C,
+                                                int Do, int Dk, int L, char* lds, f32x16 (&acc)[CT], QcStage<CT>& st) {
+  constexpr int NA4 = (CT + 1) / 2;        // float4 slots per thread per chunk: CT * 32 * 4 / 256
+  constexpr int PIECE = CT * 32 * 16 * 2;  // bytes of one piece of one buffer
   const int tid = threadIdx.x, lane = tid & 63, lo = lane & 31, hi = lane >> 5;
-  const int o4 = 4 * (tid & 7), ll = (tid >> 3) & (QC_KC - 1), c0 = tid >> 7;
+  const int k4 = 4 * (tid & 3), o = (tid >> 2) & 31, c0 = tid >> 7;
 #pragma unroll
   for (int c = 0; c < CT; ++c)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
-  const bool okO = cur.o0 + o4 < Do, okI = cur.icol < Dk;
+  const bool okO = cur.o0 + o < Do, okI = cur.icol < Dk;
   int buf = 0;
   for (int l0 = 0; l0 < L; l0 += QC_KC) {
+    char* wr = lds + buf * 3 * PIECE;
 #pragma unroll
     for (int j = 0; j < NA4; ++j)
       if (c0 + 2 * j < CT) {
-        const bool ok = okO && c0 + 2 * j < C && l0 + ll < L;
-        *reinterpret_cast<f32x4*>(&sA[buf][c0 + 2 * j][ll][o4]) = ok ? st.ra[j] : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-    float b[KS];
+        const bool ok = okO && c0 + 2 * j < C && l0 + k4 < L;
+        const f32x4 x = ok ? st.ra[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+        unsigned h[4], m[4], l[4];
 #pragma unroll
-    for (int kk = 0; kk < KS; ++kk) b[kk] = (okI && l0 + 2 * kk + hi < L) ? st.rb[kk] : 0.f;
+        for (int q = 0; q < 4; ++q) qc_split3(x[q], h[q], m[q], l[q]);
+        char* dst = wr + (((c0 + 2 * j) * 32 + o) * 16 + k4) * 2;
+        *reinterpret_cast<u32x2*>(dst) = u32x2{qc_pack(h[0], h[1]), qc_pack(h[2], h[3])};
+        *reinterpret_cast<u32x2*>(dst + PIECE) = u32x2{qc_pack(m[0], m[1]), qc_pack(m[2], m[3])};
+        *reinterpret_cast<u32x2*>(dst + 2 * PIECE) = u32x2{qc_pack(l[0], l[1]), qc_pack(l[2], l[3])};
+      }
+    // this lane's B operand: positions l0 + 8 hi .. + 7 of column icol, as three bf16x8
+    u32x4 bp[3];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const bool ok = okI && l0 + 8 * hi + 4 * hh < L;
+      const f32x4 x = ok ? st.rb[hh] : f32x4{0.f, 0.f, 0.f, 0.f};
+      unsigned h[4], m[4], l[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) qc_split3(x[q], h[q], m[q], l[q]);
+      bp[0][2 * hh] = qc_pack(h[0], h[1]);
+      bp[0][2 * hh + 1] = qc_pack(h[2], h[3]);
+      bp[1][2 * hh] = qc_pack(m[0], m[1]);
+      bp[1][2 * hh + 1] = qc_pack(m[2], m[3]);
+      bp[2][2 * hh] = qc_pack(l[0], l[1]);
+      bp[2][2 * hh + 1] = qc_pack(l[2], l[3]);
+    }
+    bf16x8 b[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(bf16x8, bp[p]);
     __syncthreads();
     // what travels during this chunk: the tile's next chunk, or chunk 0 of the next tile -- chosen with uniform
-    // selects, not branches (a branch per k-step splits the MFMA stream into basic blocks and costs 15 % at large L);
-    // the very last chunk of a workgroup re-reads its own chunk 0 for nothing
+    // selects, not branches; the very last chunk of a workgroup re-reads its own chunk 0 for nothing
     const bool more = l0 + QC_KC < L;
     const QcOperands src = more ? cur : (has_next ? nxt : cur);
     const int lsrc = more ? l0 + QC_KC : 0;
-    float a_cur[CT], a_nxt[CT];
+    const char* rd = lds + buf * 3 * PIECE + (lo * 16 + 8 * hi) * 2;  // this lane's (row, k half) in output 0, piece 0
+    bf16x8 a_cur[3], a_nxt[3];
 #pragma unroll
-    for (int c = 0; c < CT; ++c) a_cur[c] = sA[buf][c][hi][lo];
+    for (int p = 0; p < 3; ++p) a_cur[p] = *reinterpret_cast<const bf16x8*>(rd + p * PIECE);
 #pragma unroll
-    for (int kk = 0; kk < KS; ++kk) {
-      if (kk + 1 < KS) {
+    for (int c = 0; c < CT; ++c) {
+      if (c + 1 < CT) {
 #pragma unroll
-        for (int c = 0; c < CT; ++c) a_nxt[c] = sA[buf][c][2 * kk + 2 + hi][lo];
+        for (int p = 0; p < 3; ++p) a_nxt[p] = *reinterpret_cast<const bf16x8*>(rd + p * PIECE + (c + 1) * 32 * 16 * 2);
       }
-      qc_fetch_v4<CT>(st, kk, kk < NA4 ? kk + 1 : kk, kk, kk + 1, src, lsrc, C, Do, Dk, L);
-#pragma unroll
-      for (int c = 0; c < CT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[c], b[kk], acc[c], 0, 0, 0);
+      // the next chunk's loads go out one per output between the MFMA groups
+      qc_fetch_b6<CT>(st, c, c < NA4 ? c + 1 : c, c < 2 ? c : 2, (c < 2 ? c + 1 : 2) + (CT == 1 ? 1 : 0), src, lsrc, C, Do,
+                      Dk, L);
+      f32x16 d = acc[c];
+      d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[2], b[0], d, 0, 0, 0);  // small terms first
+      d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[0], b[2], d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[1], b[1], d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[1], b[0], d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[0], b[1], d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[0], b[0], d, 0, 0, 0);
+      acc[c] = d;
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int c = 0; c < CT; ++c) a_cur[c] = a_nxt[c];
+      for (int p = 0; p < 3; ++p) a_cur[p] = a_nxt[p];
     }
-    buf ^= 1;
+    buf ^= 1;  // the other buffer was last read two chunks ago: one barrier per chunk suffices
   }
   __syncthreads();
 }
 
 // grid = B * split workgroups of 4 waves; workgroup (n, sp) walks the super-tiles (32 rows o) x (128 columns i)
 // t = sp, sp + split, ...; wave w owns columns [32 w, 32 w + 32) of the super-tile for all CT outputs.
-template <int CT, int MODE, bool V4>
+template <int CT, int MODE, bool B6>
 __global__ __launch_bounds__(256) void quadform_conv_kernel(const float* __restrict__ u, const float* __restrict__ v,
                                                             const float* __restrict__ w0, const float* __restrict__ w1,
                                                             const float* __restrict__ delta, int C, int Do, int Dk, int L,
                                                             int split, float* __restrict__ partial) {
   constexpr int NP = CT * (CT + 1) / 2;
-  __shared__ float sA[2][CT][QC_KC][32];
+  __shared__ __attribute__((aligned(16))) char lds[QcLds<CT>::BYTES];
   __shared__ float sR[4][NP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
   const int n = blockIdx.x / split, sp = blockIdx.x % split;
   const int nOt = (Do + 31) / 32, nIg = (Dk + 127) / 128, ntiles = nOt * nIg;
-  const float* __restrict__ un = u + (size_t)n * C * L * Do;
-  const float* __restrict__ vn = v + (size_t)n * L * Dk;
+  const float* __restrict__ un = u + (size_t)n * C * Do * L;
+  const float* __restrict__ vn = v + (size_t)n * Dk * L;
   const float dlt = MODE == 0 ? delta[0] : 0.f;
 
   float pair[NP];
@@ -195,15 +249,15 @@ __global__ __launch_bounds__(256) void quadform_conv_kernel(const float* __restr
 
   auto operands = [&](int t) { return QcOperands{un, vn, (t % nOt) * 32, (t / nOt) * 128 + wave * 32 + lo}; };
   QcStage<CT> st;
-  if (V4 && sp < ntiles) qc_fetch_v4<CT>(st, 0, (CT + 1) / 2, 0, QC_KC / 2, operands(sp), 0, C, Do, Dk, L);
+  if (B6 && sp < ntiles) qc_fetch_b6<CT>(st, 0, (CT + 1) / 2, 0, 2, operands(sp), 0, C, Do, Dk, L);
   for (int t = sp; t < ntiles; t += split) {
     const QcOperands cur = operands(t);
     const int o0 = cur.o0, icol = cur.icol;
     f32x16 acc[CT];
-    if (V4)
-      qc_tile_gemm_v4<CT>(cur, operands(t + split), t + split < ntiles, C, Do, Dk, L, sA, acc, st);
+    if (B6)
+      qc_tile_gemm_b6<CT>(cur, operands(t + split), t + split < ntiles, C, Do, Dk, L, lds, acc, st);
     else
-      qc_tile_gemm<CT>(un, vn, o0, icol, C, Do, Dk, L, sA, acc);
+      qc_tile_gemm<CT>(cur, C, Do, Dk, L, lds, acc);
 
     // weights of this lane's 16 (o, i) positions and the pair sums, four accumulator rows at a time (the
     // accumulators live in AGPRs; only 4 * CT of them are copied out at once)
@@ -274,11 +328,11 @@ __global__ __launch_bounds__(256) void quadform_conv_reduce_kernel(const float* 
 // per-sample, per-seed weight Jacobian summed over the minibatch, without the [B, S, Do*Dk] Jacobian.
 // grid = ntiles * nsplit workgroups; workgroup (t, sp) owns the super-tile t for the samples sp, sp + nsplit, ... and
 // keeps the running sum of squares of its 32x32 wave tiles in registers.
-template <int CT, bool V4>
+template <int CT, bool B6>
 __global__ __launch_bounds__(256) void diag_ggn_shared_kernel(const float* __restrict__ u, const float* __restrict__ v,
                                                               int B, int C, int Do, int Dk, int L, int nsplit,
                                                               float* __restrict__ partial) {
-  __shared__ float sA[2][CT][QC_KC][32];
+  __shared__ __attribute__((aligned(16))) char lds[QcLds<CT>::BYTES];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lo = lane & 31, hi = lane >> 5;
   const int t = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
   const int nOt = (Do + 31) / 32;
@@ -286,15 +340,15 @@ __global__ __launch_bounds__(256) void diag_ggn_shared_kernel(const float* __res
   float hacc[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) hacc[r] = 0.f;
-  auto operands = [&](int n) { return QcOperands{u + (size_t)n * C * L * Do, v + (size_t)n * L * Dk, o0, icol}; };
+  auto operands = [&](int n) { return QcOperands{u + (size_t)n * C * Do * L, v + (size_t)n * Dk * L, o0, icol}; };
   QcStage<CT> st;
-  if (V4 && sp < B) qc_fetch_v4<CT>(st, 0, (CT + 1) / 2, 0, QC_KC / 2, operands(sp), 0, C, Do, Dk, L);
+  if (B6 && sp < B) qc_fetch_b6<CT>(st, 0, (CT + 1) / 2, 0, 2, operands(sp), 0, C, Do, Dk, L);
   for (int n = sp; n < B; n += nsplit) {
     f32x16 acc[CT];
-    if (V4)
-      qc_tile_gemm_v4<CT>(operands(n), operands(n + nsplit < B ? n + nsplit : n), n + nsplit < B, C, Do, Dk, L, sA, acc, st);
+    if (B6)
+      qc_tile_gemm_b6<CT>(operands(n), operands(n + nsplit < B ? n + nsplit : n), n + nsplit < B, C, Do, Dk, L, lds, acc, st);
     else
-      qc_tile_gemm<CT>(u + (size_t)n * C * L * Do, v + (size_t)n * L * Dk, o0, icol, C, Do, Dk, L, sA, acc);
+      qc_tile_gemm<CT>(operands(n), C, Do, Dk, L, lds, acc);
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
@@ -321,13 +375,14 @@ __global__ __launch_bounds__(256) void diag_ggn_shared_reduce_kernel(const float
 
 using namespace lk;
 
-static int qc_v4_enabled() {
+static int qc_b6_enabled() {
   static const int on = [] {
-    const char* e = getenv("LK_QC_V4");  // development switch: 0 = scalar staging everywhere
+    const char* e = getenv("LK_QC_B6");  // development switch: 0 = the fp32-MFMA tile product everywhere
     return (e == nullptr || atoi(e) != 0) ? 1 : 0;
   }();
   return on;
 }
+static bool qc_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 static int qc_class_tile(int64_t C) {
   static const int tiles[] = {1, 2, 3, 4, 5, 6, 8, 10};  // 12 outputs would spill accumulators
@@ -366,7 +421,7 @@ static int launch_quadform_conv(const float* u, const float* v, const float* w0,
   const int split = qc_split(B, Do, Dk);
   float* partial = static_cast<float*>(ws);
   const dim3 grid((unsigned)(B * split));
-  const bool v4 = (Do % 4 == 0) && qc_v4_enabled();
+  const bool v4 = (L % 4 == 0) && qc_aligned16(u) && qc_aligned16(v) && qc_b6_enabled();
 #define LK_QC_CASE(CT)                                                                                              \
   case CT:                                                                                                          \
     if (v4)                                                                                                         \
@@ -448,7 +503,7 @@ extern "C" int lk_diag_ggn_shared_f32(const float* u, const float* v, int64_t B,
   LK_REQUIRE(ntiles * nsplit < (1ll << 31), "lk_diag_ggn_shared_f32: grid too large");
   float* partial = static_cast<float*>(ws);
   const dim3 grid((unsigned)(ntiles * nsplit));
-  const bool v4 = (Do % 4 == 0) && qc_v4_enabled();
+  const bool v4 = (L % 4 == 0) && qc_aligned16(u) && qc_aligned16(v) && qc_b6_enabled();
 #define LK_DG_CASE(CT)                                                                                               \
   case CT:                                                                                                           \
     if (v4)                                                                                                          \

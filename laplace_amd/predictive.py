@@ -115,9 +115,9 @@ def glm_variance_diag(backend, x, post_var: torch.Tensor):
             K.diag_quadform_linear(tap.a.to(torch.float32).contiguous(), g.contiguous(), vw, vb, fvar)
         elif C <= K.quadform_shared_max_outputs:
             u, v, gsum = _shared_operands(tap, g, B, C)
-            K.diag_quadform_shared(u, v, vw.reshape(u.shape[-1], v.shape[-1]).contiguous(), fvar)
+            K.diag_quadform_shared(u, v, vw.reshape(u.shape[2], v.shape[1]).contiguous(), fvar)
             if tap.has_bias:
-                vb = post_var[tap.b_off:tap.b_off + u.shape[-1]]
+                vb = post_var[tap.b_off:tap.b_off + u.shape[2]]
                 fvar += torch.einsum("cno,kno,o->nck", gsum, gsum, vb)
         elif tap.kind == "conv2d":
             Jl, width = _conv_block_jacobian(tap, g, B, C)

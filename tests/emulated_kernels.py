@@ -256,17 +256,17 @@ class EmulatedKernels:
     quadform_shared_max_outputs = 10
 
     def kron_quadform_shared(self, u, v, l1, l2, delta, fvar):
-        M = torch.einsum("nclo,nli->ncoi", u, v)
+        M = torch.einsum("ncol,nil->ncoi", u, v)
         fvar += torch.einsum("ncoi,nkoi,oi->nck", M, M, 1.0 / (torch.outer(l1, l2) + delta.reshape(())))
         return fvar
 
     def diag_quadform_shared(self, u, v, var_w, fvar):
-        M = torch.einsum("nclo,nli->ncoi", u, v)
+        M = torch.einsum("ncol,nil->ncoi", u, v)
         fvar += torch.einsum("ncoi,nkoi,oi->nck", M, M, var_w)
         return fvar
 
     def diag_ggn_shared(self, u, v, alpha, h):
-        M = torch.einsum("nslo,nli->nsoi", u, v)
+        M = torch.einsum("nsol,nil->nsoi", u, v)
         h += alpha * (M * M).sum((0, 1)).reshape(-1)
         return h
 

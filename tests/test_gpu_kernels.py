@@ -427,7 +427,7 @@ def test_kron_logdet(K, n1, n2):
 def test_quadform_shared(K, B, C, Do, Dk, L):
     """weight-sharing predictive (conv / sequence Linear): ragged tiles, padded output counts (7 -> 8, 9 -> 10),
     one and many workgroups per sample, Kronecker and diagonal weights; against the fp64 einsum"""
-    u, v = rnd(B, C, L, Do, seed=1), rnd(B, L, Dk, seed=2)
+    u, v = rnd(B, C, Do, L, seed=1), rnd(B, Dk, L, seed=2)
     l1, l2 = rnd(Do, seed=3).abs(), rnd(Dk, seed=4).abs()
     d = torch.tensor([0.3], dtype=torch.float64)
     f32 = lambda t: t.float().to(DEV).contiguous()
@@ -450,7 +450,7 @@ def test_quadform_shared(K, B, C, Do, Dk, L):
 def test_diag_ggn_shared(K, B, S, Do, Dk, L):
     """exact GGN diagonal of a weight-sharing layer: sum over (sample, seed) of the squared per-sample Jacobian,
     accumulated on top of what h already holds; ragged tiles, one and many samples per workgroup"""
-    u, v = rnd(B, S, L, Do, seed=1), rnd(B, L, Dk, seed=2)
+    u, v = rnd(B, S, Do, L, seed=1), rnd(B, Dk, L, seed=2)
     base = rnd(Do * Dk, seed=3)
     f32 = lambda t: t.float().to(DEV).contiguous()
     want = EMU.diag_ggn_shared(u, v, 0.7, base.clone())
@@ -467,7 +467,7 @@ def test_quadform_shared_rejects_more_outputs_than_accumulators(K):
 
     z = lambda *s: torch.zeros(*s, device=DEV)
     with pytest.raises(LaplaceHipError, match="more than 10 outputs"):
-        K.kron_quadform_shared(z(1, 11, 2, 4), z(1, 2, 4), z(4) + 1, z(4) + 1, z(1) + 1, z(1, 11, 11))
+        K.kron_quadform_shared(z(1, 11, 4, 2), z(1, 4, 2), z(4) + 1, z(4) + 1, z(1) + 1, z(1, 11, 11))
 
 
 @pytest.mark.parametrize("nblocks,with_scale", [(1, False), (5, True), (45, True), (70, False)])

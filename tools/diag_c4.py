@@ -41,8 +41,8 @@ for name, Cin, Do, HW in (("layer1 3x3 64->64 @32x32", 64, 64, 32), ("layer4 3x3
     a = torch.randn(B, Cin, HW, HW, device=dev)
     gg = torch.randn(S, B, Do, HW, HW, device=dev)
     Dk, L = Cin * 9, HW * HW
-    u = gg.reshape(S, B, Do, L).permute(1, 0, 3, 2).contiguous()
-    v = torch.nn.functional.unfold(a, 3, 1, 1, 1).transpose(1, 2).contiguous()
+    u = gg.reshape(S, B, Do, L).permute(1, 0, 2, 3).contiguous()
+    v = torch.nn.functional.unfold(a, 3, 1, 1, 1).contiguous()
     h1 = torch.zeros(Do * Dk, device=dev)
     h0 = torch.zeros(Do * Dk, device=dev)
 

@@ -17,8 +17,8 @@ shapes = [("conv1", 64, 27, 1024), ("layer1", 64, 576, 1024), ("layer2.0", 128, 
           ("layer4", 512, 4608, 16), ("layer4.sc", 512, 256, 16)]
 out = {}
 for name, Do, Dk, L in shapes:
-    u = torch.randn(B, C, L, Do, device=dev)
-    v = torch.randn(B, L, Dk, device=dev)
+    u = torch.randn(B, C, Do, L, device=dev)
+    v = torch.randn(B, Dk, L, device=dev)
     l1, l2 = torch.rand(Do, device=dev), torch.rand(Dk, device=dev)
     d = torch.ones(1, device=dev)
     fv = torch.zeros(B, C, C, device=dev)
