@@ -249,8 +249,10 @@ def main():
         # priced on its algorithmic bytes (2 x blocks + input) against HBM.
         PEAK_HBM_GBS = 8000.0
         fams = {
-            "gram_nt": ("lk::gram_kernel<MODE_NT> (+ slab reduce): G-factor accumulation from the seed-batched "
-                        "cotangents, exact-fp32 MFMA", "mfma", "void lk::gram_kernel<1,"),
+            "gram_nt": ("lk::gram_kernel<MODE_NTB> (+ slab reduce): G-factor accumulation from the seed-batched "
+                        "cotangents; fp32-accurate products from three-piece split-bf16 operands, 6 bf16 MFMA flops per "
+                        "algorithmic fp32 flop (priced against the fp32-MFMA peak; the emulation's own ceiling is "
+                        "2500/6 = 417 TFLOP/s)", "mfma", "void lk::gram_kernel<5,"),
             "pixpair": ("lk::gram_kernel<MODE_TNP>: banded pixel-pair accumulation of the 3x3-conv A factors "
                         "(block read-modify-write)", "hbm", "void lk::gram_kernel<4,"),
             "gram_conv": ("lk::gram_kernel<MODE_CONV> (+ slab reduce): implicit-im2col A-factor accumulation, "
