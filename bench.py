@@ -3,7 +3,7 @@
 Workload (config c4, per GPU): ResNet-18 (CIFAR stem, BN affine frozen, random init), full-network
 KFAC exact GGN, minibatch 128 of synthetic N(0,1) 3x32x32 images, 10 classes.  A "step" is one
 minibatch through the hot path: forward + ONE batched reverse pass (stock PyTorch-ROCm), then our
-HIP kernels for the likelihood root, every A/G factor (exact-fp32 MFMA Gram engine) and the
+HIP kernels for the likelihood root, every A/G factor (fp32 MFMA Gram engine; G factors as split-bf16 products) and the
 accumulation.  N > 1: one process per GPU, each rank its own K minibatches (weak scaling), one RCCL
 all-reduce of the accumulated factors inside the timed region (the fit's epoch end).
 

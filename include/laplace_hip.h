@@ -61,13 +61,16 @@ int lk_sq_err_sum_f32(const float* f, const float* y, int64_t numel, float scale
                       void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Gram / factor accumulation:  C += alpha * X^T X   (exact-fp32 MFMA, split-K, deterministic).
+ * Gram / factor accumulation:  C += alpha * X^T X   (fp32 MFMA, split-K, deterministic).
  * Replaces the A^T A / G^T G accumulations inside curvlinops' KFACLinearOperator._compute_kfac
  * as consumed by CurvlinopsInterface.kron (laplace/curvature/curvlinops.py:55-108), and the
  * dense einsums of GGNInterface.full / EFInterface.full (curvature.py:406,409,491).
  *
  *  _tn  : X is [K][n] row-major with leading dimension ldx      (nn.Linear inputs / output grads)
- *  _nt  : X is [nb][n][L] row-major; C += alpha * sum_b X_b X_b^T (NCHW conv output grads)
+ *  _nt  : X is [nb][n][L] row-major; C += alpha * sum_b X_b X_b^T (NCHW conv output grads).  With L % 4 == 0 and
+ *         16-byte aligned X the products run on the bf16 matrix cores at fp32 accuracy: every operand is split once
+ *         into three bf16 pieces (x = h + m + l exactly) and six v_mfma_f32_32x32x16_bf16 form hh' + hm' + mh' + mm' +
+ *         hl' + lh' (dropped terms <= 3 * 2^-24 |x y|, accumulation in fp32); otherwise v_mfma_f32_32x32x2_f32.
  *  _conv: x is an NHWC activation [B][H][W][Cin]; the Gram matrix of the *unfolded* patch matrix
  *         (rows = (b,oh,ow), columns = (kh,kw,ci)) is accumulated WITHOUT materialising it.
  *         Column order of C is (kh,kw,ci) ("native"); lk_permute_sym_f32 converts to the
