@@ -263,10 +263,14 @@ class HipKernels:
         )
         return out
 
-    def nchw_to_nhwc(self, x):
+    def nchw_to_nhwc(self, x, out=None):
         _check(x, "x")
         B, C, H, W = x.shape
-        out = torch.empty(B, H, W, C, dtype=torch.float32, device=x.device)
+        if out is None:
+            out = torch.empty(B, H, W, C, dtype=torch.float32, device=x.device)
+        else:
+            _check(out, "out")
+            assert tuple(out.shape) == (B, H, W, C)
         if B:
             self._rc(self.lib.lk_nchw_to_nhwc_f32(_ptr(x), B, C, H * W, _ptr(out), self._stream(x.device)),
                      "lk_nchw_to_nhwc_f32")
@@ -358,12 +362,18 @@ class HipKernels:
 
     def pixpair_accumulate(self, x, alpha, blocks, plan):
         """``Blk[q, D] += alpha * sum_b x[b,q,:]^T x[b,q+D,:]`` for an NCHW input ``x``."""
-        _check(x, "x"), _check(blocks, "blocks")
-        B, Cin, H, W = x.shape
+        _check(x, "x")
+        return self.pixpair_accumulate_nhwc(self.nchw_to_nhwc(x), alpha, blocks, plan)
+
+    def pixpair_accumulate_nhwc(self, xh, alpha, blocks, plan):
+        """Same for an NHWC input ``xh [B, H, W, Cin]`` (several minibatches may be stacked along ``B``: the blocks
+        are read-modified-written once per launch, whatever the number of rows)."""
+        _check(xh, "xh"), _check(blocks, "blocks")
+        B, H, W, Cin = xh.shape
         nb, tiles, _ = plan
         assert blocks.numel() == nb * Cin * Cin
-        xh = self.nchw_to_nhwc(x)
-        # HBM-bound (each block is read-modified-written once per minibatch): work = algorithmic BYTES
+        x = xh
+        # HBM-bound (each block is read-modified-written once per launch): work = algorithmic BYTES
         self._rc(self._timed("pixpair", 8.0 * blocks.numel() + 4.0 * x.numel(), x.device,
                              lambda: self.lib.lk_conv3x3_pixpair_accumulate_f32(
                                  _ptr(xh), B, H, W, Cin, float(alpha), _ptr(blocks), ctypes.c_void_p(tiles.data_ptr()),

@@ -499,6 +499,9 @@ class KronAccumulator:
         self.use_pixgram = os.environ.get("LK_PIXGRAM", "1") != "0"
         self._defer_bn = os.environ.get("LK_DEFER_BN", "1") != "0"
         self._persist_slabs = os.environ.get("LK_PERSIST_SLABS", "1") != "0"
+        #: minibatches stacked per pixel-pair launch: the kernel is bound by the read-modify-write of its blocks, which
+        #: happens once per LAUNCH, so stacking the NHWC inputs of consecutive minibatches divides that traffic
+        self.pix_group = max(1, int(os.environ.get("LK_PIX_GROUP", "2")))
         self._side = None
         self.factors = None  # per tap: [G, A]
         self.loss = None
@@ -519,6 +522,7 @@ class KronAccumulator:
             self._taps_meta.append((tap.has_bias, native))
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
         self._pix = {}  # tap index -> (geometry, buffer): pixel-pair accumulators of 3x3 convs
+        self._pix_pending = {}  # tap index -> minibatches stacked for the next pixel-pair launch
         self._gscale = {}  # tap index -> deferred BatchNorm scale owed to the G accumulator
         self._gslabs = {}  # tap index -> (persistent split-K slabs, n, L, alpha) of a conv G factor
         self._tap_index = {tap.name: i for i, tap in enumerate(tape.taps)}
@@ -559,10 +563,41 @@ class KronAccumulator:
         geo, buf = acc
         alpha = rt / (self.N * geo[1] * geo[2])
         a = tap.a.to(torch.float32).contiguous()
-        if geo[0] == "pair":
+        if geo[0] != "pair":
+            K.pixgram_accumulate(a, alpha, buf)
+        elif self.pix_group <= 1:
             K.pixpair_accumulate(a, alpha, buf, geo[4])
         else:
-            K.pixgram_accumulate(a, alpha, buf)
+            # NHWC copy of this minibatch into its slot of the group buffer; launch when the group is full
+            B = a.shape[0]
+            pend = self._pix_pending.get(idx)
+            if pend is not None and (pend["B"] != B or pend["alpha"] != alpha):
+                self._drain_pixpair(idx)  # ragged last batch / changed scale: flush what is stacked
+                pend = None
+            if pend is None:
+                stack = torch.empty(self.pix_group * B, geo[1], geo[2], geo[3], dtype=torch.float32, device=a.device)
+                pend = self._pix_pending[idx] = {"B": B, "alpha": alpha, "stack": stack, "n": 0}
+            K.nchw_to_nhwc(a, out=pend["stack"][pend["n"] * B:(pend["n"] + 1) * B])
+            pend["n"] += 1
+            if pend["n"] == self.pix_group:
+                self._drain_pixpair(idx, keep=True)
+
+    def _drain_pixpair(self, idx, keep=False):
+        """launch the pixel-pair product over the minibatches stacked so far"""
+        pend = self._pix_pending.get(idx)
+        if pend is None:
+            return
+        if pend["n"]:
+            geo, buf = self._pix[idx]
+            xh = pend["stack"][:pend["n"] * pend["B"]]
+            cur = torch.cuda.current_stream(xh.device) if xh.is_cuda else None
+            get_kernels().pixpair_accumulate_nhwc(xh, pend["alpha"], buf, geo[4])
+            if cur is not None:
+                pend["stack"].record_stream(cur)  # filled on the side stream, possibly consumed on another one
+        if keep:
+            pend["n"] = 0
+        else:
+            del self._pix_pending[idx]
 
     def _ensure_pixgrams(self, tape):
         """allocate the pixel-pair accumulators on the CALLING stream (they are consumed there at the end of the fit)"""
@@ -586,6 +621,7 @@ class KronAccumulator:
         """fold the pixel-pair accumulators into the (native-order) A factors; idempotent"""
         K = get_kernels()
         for idx in ([only] if only is not None else list(self._pix)):
+            self._drain_pixpair(idx)
             geo, buf = self._pix.pop(idx)
             if geo[0] == "pair":
                 K.pixpair_assemble(buf, geo[4], geo[1], geo[2], geo[3], 1.0, self.factors[idx][1])

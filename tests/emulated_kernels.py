@@ -89,8 +89,11 @@ class EmulatedKernels:
         C.copy_(torch.triu(C) + torch.triu(C, 1).T)
         return C
 
-    def nchw_to_nhwc(self, x):
-        return x.permute(0, 2, 3, 1).contiguous()
+    def nchw_to_nhwc(self, x, out=None):
+        if out is None:
+            return x.permute(0, 2, 3, 1).contiguous()
+        out.copy_(x.permute(0, 2, 3, 1))
+        return out
 
     # diag / Jacobians
     def diag_ggn_linear(self, a, g, alpha, h_w, h_b=None):
@@ -202,8 +205,11 @@ class EmulatedKernels:
         return (n, None, slots)
 
     def pixpair_accumulate(self, x, alpha, blocks, plan):
-        B, Cin, H, W = x.shape
-        xh = x.permute(0, 2, 3, 1).reshape(B, H * W, Cin)
+        return self.pixpair_accumulate_nhwc(x.permute(0, 2, 3, 1), alpha, blocks, plan)
+
+    def pixpair_accumulate_nhwc(self, xh, alpha, blocks, plan):
+        B, H, W, Cin = xh.shape
+        xh = xh.reshape(B, H * W, Cin)
         blk = blocks.view(plan[0], Cin, Cin)
         for (q, h), slot in plan[2].items():
             dy, dx = self._HALF[h]

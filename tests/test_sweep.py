@@ -262,9 +262,11 @@ def test_inplace_model_equals_its_out_of_place_twin():
             assert (a - b).abs().max() <= 1e-12 * (1 + a.abs().max())
 
 
-def test_fused_accumulator_pixel_pair_paths_equal_literal_loop():
+@pytest.mark.parametrize("pix_group", [1, 2, 3])
+def test_fused_accumulator_pixel_pair_paths_equal_literal_loop(pix_group):
     """KronAccumulator keeps 3x3/s1/p1 conv A factors in pixel-pair form over the fit (banded blocks / dense small
-    maps) and assembles once: same factors as summing per-minibatch kron() results."""
+    maps) and assembles once: same factors as summing per-minibatch kron() results -- whatever the number of
+    minibatches stacked per pixel-pair launch, including a ragged batch in the middle of a group."""
     from laplace_amd import _lib
     from laplace_amd.backend import HipGGN
     from tests.emulated_kernels import EmulatedKernels
@@ -276,10 +278,11 @@ def test_fused_accumulator_pixel_pair_paths_equal_literal_loop():
                               nn.Conv2d(8, 4, 3, padding=1), nn.Flatten(), nn.Linear(4 * 6 * 6, 3)).eval()
         b = HipGGN(model, "classification")
         acc = b.kron_accumulator(40)
+        acc.pix_group = pix_group
         H = None
-        for seed in (1, 2, 3):
+        for seed, bs in ((1, 4), (2, 4), (3, 3), (4, 4), (5, 4)):
             g = torch.Generator().manual_seed(seed)
-            X, y = torch.randn(4, 3, 6, 6, generator=g), torch.randint(0, 3, (4,), generator=g)
+            X, y = torch.randn(bs, 3, 6, 6, generator=g), torch.randint(0, 3, (bs,), generator=g)
             acc.add_batch(X, y)
             _, Hb = b.kron(X, y, N=40)
             H = Hb if H is None else H + Hb
@@ -290,6 +293,7 @@ def test_fused_accumulator_pixel_pair_paths_equal_literal_loop():
         model2 = nn.Sequential(*list(model.children())[:5], nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(4, 3)).eval()
         b2 = HipGGN(model2, "classification")
         acc2, H2 = b2.kron_accumulator(40), None
+        acc2.pix_group = pix_group
         for seed, hw in ((1, 6), (2, 5), (3, 6)):
             g = torch.Generator().manual_seed(seed)
             X, y = torch.randn(4, 3, hw, hw, generator=g), torch.randint(0, 3, (4,), generator=g)
