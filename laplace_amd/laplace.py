@@ -168,10 +168,14 @@ class _HipLaplace:
         consumes its shard of minibatches (wrap the loader in :class:`ShardedLoader`; ``N`` stays the
         global dataset size) and the packed curvature + loss are summed with one all-reduce.
         """
-        if override:
-            self._init_H()
-            self.loss = torch.zeros((), device=self._device, dtype=self._dtype)
-            self.n_data = 0
+        # override=False (baselaplace.py:904-987): online continuation, the new curvature is ADDED to what is there.
+        # It is accumulated separately first, so that a data-parallel continuation all-reduces the new part only.
+        old = None
+        if not override and getattr(self, "n_data", 0) and getattr(self, "H", None) is not None:
+            old = (self.H, self.loss, self.n_data)
+        self._init_H()
+        self.loss = torch.zeros((), device=self._device, dtype=self._dtype)
+        self.n_data = 0
         self.model.eval()
         self.mean = parameters_to_vector(self.params).detach()
         N = len(train_loader.dataset)
@@ -197,6 +201,10 @@ class _HipLaplace:
             allreduce_curvature(self._curvature_tensors() + [loss_t], group=process_group)
             self.loss = loss_t[0]
         self.n_data += N
+        if old is not None:
+            self.H += old[0]
+            self.loss = self.loss + old[1]
+            self.n_data += old[2]
         self._posterior_cache = None
 
     # ---- marginal likelihood (baselaplace.py:214-241,1003-1037,1074-1109) ------------------------------------
@@ -470,12 +478,24 @@ class HipKronLaplace(_HipLaplace):
     def _curvature_tensors(self):
         return [Hi for F in self.H.kfacs for Hi in F]
 
+    @staticmethod
+    def _rescale_factors(kron, factor: float):
+        """``A *= factor`` on the two-factor blocks (baselaplace.py:1773-1777)"""
+        for F in kron.kfacs:
+            if len(F) == 2:
+                F[1] *= factor
+        return kron
+
     def fit(self, train_loader, override: bool = True, process_group=None, distributed=None, fused: bool = True):
         """``fused=True`` (default) accumulates in place through :class:`KronAccumulator` (upper
         triangles, native conv order; one symmetrise/permute per fit).  ``fused=False`` is the
         reference's literal loop ``self.H += backend.kron(X, y, N)`` (baselaplace.py:969-985)."""
-        if not override:
-            raise NotImplementedError("online continuation (override=False) is left to the reference's KronLaplace")
+        # online continuation (baselaplace.py:1785-1806): the A factors carry 1/N, so the old ones are discounted by
+        # n_old / (n_old + n_new) and the new ones (computed with N = n_new) by n_new / (n_old + n_new)
+        old = None
+        if not override and self.H_facs is not None:
+            n_old, n_new = self.n_data, len(train_loader.dataset)
+            old = (self._rescale_factors(self.H_facs, n_old / (n_old + n_new)), self.loss, n_old, n_new)
         if not (fused and hasattr(self.backend, "kron_accumulator")):
             super().fit(train_loader, override=True, process_group=process_group, distributed=distributed)
         else:
@@ -503,7 +523,14 @@ class HipKronLaplace(_HipLaplace):
             self.loss, self.H = acc.finalize()
             self.n_data = N
             self._posterior_cache = None
-        self.H_facs = self.H
+        if old is None:
+            self.H_facs = self.H
+        else:
+            facs, loss_old, n_old, n_new = old
+            facs += self._rescale_factors(self.H, n_new / (n_new + n_old))
+            self.H_facs = facs
+            self.loss = self.loss + loss_old
+            self.n_data = n_old + n_new
         if distributed is None:
             distributed = dist.is_available() and dist.is_initialized()
         # HIP eigensolver per factor; after a data-parallel fit the factors are sharded over the ranks

@@ -99,3 +99,41 @@ def test_fit_kron_helper_equals_reference_fit(ref, name, lik, sow):
     f_mu, f_var = la._glm_predictive_distribution(X)
     assert rel(f_var, g[f"{tag}.f_var"]) < 1e-4
     assert rel(la.log_marginal_likelihood(), g[f"{tag}.marglik"]) < 1e-4
+
+
+@pytest.mark.parametrize("name", ["mlp", "conv"])
+@pytest.mark.parametrize("lik", ["classification", "regression"])
+@pytest.mark.parametrize("hs", ["kron", "diag", "full"])
+def test_online_continuation_matches_the_reference_classes(ref, name, lik, hs):
+    """`fit(loader2, override=False)` after `fit(loader1)` (baselaplace.py:904-987,1785-1806): the lean drivers follow
+    the reference's bookkeeping — the unmodified reference classes driven by the same backend are the yardstick."""
+    from laplace import Laplace
+
+    from laplace_amd import HipGGN
+    from laplace_amd.laplace import HipLaplace
+    from oracle.make_golden import PRIOR_PREC, SIGMA_NOISE
+
+    g = load_golden(name, lik)
+    model, X, y = golden_model(name, g, dtype=torch.float32)
+    sig = SIGMA_NOISE if lik == "regression" else 1.0
+    l1 = DataLoader(TensorDataset(X[:6], y[:6]), batch_size=3)
+    l2 = DataLoader(TensorDataset(X[6:], y[6:]), batch_size=2)
+    la_ref = Laplace(model, lik, subset_of_weights="all", hessian_structure=hs, prior_precision=PRIOR_PREC,
+                     sigma_noise=sig, backend=HipGGN)
+    la_ref.fit(l1)
+    la_ref.fit(l2, override=False)
+    lean = HipLaplace(model, lik, "all", hs, prior_precision=PRIOR_PREC, sigma_noise=sig)
+    lean.fit(l1)
+    lean.fit(l2, override=False)
+    assert lean.n_data == la_ref.n_data == 10
+    assert rel(lean.loss, la_ref.loss) < 1e-5
+    if hs == "kron":
+        for F_, G_ in zip(lean.H_facs.kfacs, la_ref.H_facs.kfacs):
+            for a, w in zip(F_, G_):
+                assert rel(a, w) < 1e-5
+    else:
+        assert rel(lean.H, la_ref.H) < 1e-5
+    assert rel(lean.log_marginal_likelihood(), la_ref.log_marginal_likelihood()) < 1e-4
+    f_mu, f_var = lean._glm_predictive_distribution(X)
+    r_mu, r_var = la_ref._glm_predictive_distribution(X)
+    assert rel(f_var, r_var) < 1e-4
