@@ -238,19 +238,40 @@ class _HipLaplace:
             self.sigma_noise = sigma_noise
         return self.log_likelihood - 0.5 * (self.log_det_ratio + self.scatter)
 
-    def optimize_prior_precision(self, n_steps: int = 100, lr: float = 1e-1, init_prior_prec=1.0):
-        """Marginal-likelihood optimisation of a scalar / layer-wise prior precision with Adam
-        (the 'marglik' branch of baselaplace.py:466-485); every step is one ``lk_kron_logdet_blocks_f32`` call over
-        all blocks of the posterior (Kron flavours), with the analytic derivative in the prior precision."""
-        init = torch.as_tensor(init_prior_prec, device=self._device, dtype=self._dtype).reshape(-1)
-        log_pp = init.log().clone().requires_grad_(True)
-        opt = torch.optim.Adam([log_pp], lr=lr)
-        for _ in range(n_steps):
-            opt.zero_grad()
-            neg = -self.log_marginal_likelihood(prior_precision=log_pp.exp())
-            neg.backward()
-            opt.step()
-        self.prior_precision = log_pp.detach().exp()
+    def optimize_prior_precision(self, pred_type: str = "glm", method: str = "marglik", n_steps: int = 100,
+                                 lr: float = 1e-1, init_prior_prec=1.0, prior_structure: str = "diag", val_loader=None,
+                                 loss=None, log_prior_prec_min: float = -4, log_prior_prec_max: float = 4,
+                                 grid_size: int = 100, link_approx: str = "probit", n_samples: int = 100,
+                                 verbose: bool = False, progress_bar: bool = False):
+        """Same call as the reference's (baselaplace.py:363-509).  ``method='marglik'``: Adam on the log prior
+        precision (scalar / layer-wise / per-parameter: a scalar ``init_prior_prec`` is expanded to
+        ``prior_structure``, a tensor keeps its own structure); every step is one ``lk_kron_logdet_blocks_f32`` call
+        over all blocks of the posterior for the Kron flavours, with the analytic derivative in the prior precision.
+        ``method='gridsearch'``: :meth:`gridsearch_prior_precision` on ``val_loader``."""
+        if method == "marglik":
+            pp = torch.as_tensor(init_prior_prec, device=self._device, dtype=self._dtype).reshape(-1)
+            if len(pp) == 1 and prior_structure != "scalar":
+                if prior_structure not in ("layerwise", "diag"):
+                    raise ValueError(f"Invalid prior structure {prior_structure}.")
+                pp = pp.repeat(self.n_layers if prior_structure == "layerwise" else self.n_params)
+            self.prior_precision = pp
+            log_pp = self.prior_precision.log().clone().requires_grad_(True)
+            opt = torch.optim.Adam([log_pp], lr=lr)
+            for _ in range(n_steps):
+                opt.zero_grad()
+                neg = -self.log_marginal_likelihood(prior_precision=log_pp.exp())
+                neg.backward()
+                opt.step()
+            self.prior_precision = log_pp.detach().exp()
+        elif method == "gridsearch":
+            if val_loader is None:
+                raise ValueError("gridsearch requires a validation set DataLoader")
+            self.gridsearch_prior_precision(val_loader, log_prior_prec_min, log_prior_prec_max, grid_size, pred_type,
+                                            link_approx, n_samples, loss)
+        else:
+            raise ValueError("For now only marglik and gridsearch is implemented.")
+        if verbose:
+            print(f"Optimized prior precision is {self.prior_precision}.")
         return self.prior_precision
 
     # ---- GLM predictive (baselaplace.py:598-695,1306-1342) ------------------------------------------------------

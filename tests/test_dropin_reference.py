@@ -137,3 +137,38 @@ def test_online_continuation_matches_the_reference_classes(ref, name, lik, hs):
     f_mu, f_var = lean._glm_predictive_distribution(X)
     r_mu, r_var = la_ref._glm_predictive_distribution(X)
     assert rel(f_var, r_var) < 1e-4
+
+
+@pytest.mark.parametrize("hs,structure", [("kron", "scalar"), ("kron", "layerwise"), ("diag", "diag"), ("full", "layerwise")])
+def test_prior_optimisation_call_matches_the_reference(ref, hs, structure):
+    """`optimize_prior_precision(pred_type, method, ..., prior_structure)` (baselaplace.py:363-509): same call, same
+    Adam trajectory (marglik) and same grid choice (gridsearch) as the reference classes on the same backend."""
+    import warnings
+
+    from laplace import Laplace
+
+    from laplace_amd import HipGGN
+    from laplace_amd.laplace import HipLaplace
+
+    g = load_golden("mlp", "classification")
+    model, X, y = golden_model("mlp", g, dtype=torch.float32)
+    loader = DataLoader(TensorDataset(X, y), batch_size=5)
+    la_ref = Laplace(model, "classification", subset_of_weights="all", hessian_structure=hs, backend=HipGGN)
+    la_ref.fit(loader)
+    lean = HipLaplace(model, "classification", "all", hs)
+    lean.fit(loader)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        la_ref.optimize_prior_precision(pred_type="glm", method="marglik", n_steps=15, lr=0.1, prior_structure=structure)
+    lean.optimize_prior_precision(pred_type="glm", method="marglik", n_steps=15, lr=0.1, prior_structure=structure)
+    assert lean.prior_precision.shape == la_ref.prior_precision.shape
+    assert rel(lean.prior_precision, la_ref.prior_precision) < 1e-4
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        la_ref.optimize_prior_precision(pred_type="glm", method="gridsearch", val_loader=loader, log_prior_prec_min=-2,
+                                        log_prior_prec_max=2, grid_size=9)
+    lean.optimize_prior_precision(pred_type="glm", method="gridsearch", val_loader=loader, log_prior_prec_min=-2,
+                                  log_prior_prec_max=2, grid_size=9)
+    assert float(lean.prior_precision.reshape(-1)[0]) == pytest.approx(float(la_ref.prior_precision.reshape(-1)[0]))
+    with pytest.raises(ValueError, match="validation set"):
+        lean.optimize_prior_precision(pred_type="glm", method="gridsearch")

@@ -93,7 +93,7 @@ def test_marglik_prior_optimisation_moves_uphill(emulated):
     la = HipLaplace(model, "regression", "all", "kron", prior_precision=1.0, sigma_noise=0.8)
     la.fit(DataLoader(TensorDataset(X, y), batch_size=5))
     before = la.log_marginal_likelihood().item()
-    la.optimize_prior_precision(n_steps=30, lr=0.1)
+    la.optimize_prior_precision(method="marglik", n_steps=30, lr=0.1, prior_structure="scalar")
     assert la.log_marginal_likelihood().item() > before
 
 

@@ -99,7 +99,7 @@ out["factor_shapes"] = [[list(f.shape) for f in blk] for blk in la.H_facs.kfacs]
 
 sync()
 t0 = time.perf_counter()
-la.optimize_prior_precision(n_steps=100, lr=0.1)
+la.optimize_prior_precision(pred_type="glm", method="marglik", n_steps=100, lr=0.1, prior_structure="layerwise")
 sync()
 out["marglik_100_steps_ms"] = (time.perf_counter() - t0) * 1e3
 out["marglik_prior_precision"] = float(la.prior_precision.reshape(-1)[0])
