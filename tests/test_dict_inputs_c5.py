@@ -64,7 +64,7 @@ def _run(dev):
             err = (a.double().cpu() - w).abs().max().item() / (w.abs().max().item() + 1e-30)
             assert err < 1e-4, err
     before = la.log_marginal_likelihood().item()
-    la.optimize_prior_precision(method="marglik", n_steps=40, lr=0.1, prior_structure="layerwise")
+    la.optimize_prior_precision(method="marglik", n_steps=40, lr=0.1, prior_structure="scalar")
     assert la.log_marginal_likelihood().item() >= before - 1e-3
     batch = next(iter(loader))
     f_mu, f_var = la._glm_predictive_distribution(batch)
