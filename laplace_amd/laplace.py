@@ -296,12 +296,12 @@ class _HipLaplace:
     @torch.no_grad()
     def __call__(self, x, pred_type: str = "glm", joint: bool = False, link_approx: str = "probit", n_samples: int = 100,
                  diagonal_output: bool = False, generator: torch.Generator | None = None):
-        """Posterior predictive (baselaplace.py:1112-1208): ``pred_type`` 'glm' with the 'probit' or 'mc' link
-        approximation, or 'nn' (weight-space sampling, 'mc' only)."""
+        """Posterior predictive (baselaplace.py:598-695,1112-1208): ``pred_type`` 'glm' with the 'probit', 'mc', 'bridge'
+        or 'bridge_norm' link approximation, or 'nn' (weight-space sampling, 'mc' only)."""
         if pred_type not in ("glm", "nn"):
             raise ValueError("Only glm and nn supported as prediction types.")
-        if link_approx not in ("probit", "mc"):
-            raise NotImplementedError("link_approx: 'probit' and 'mc' are implemented here")
+        if link_approx not in ("probit", "mc", "bridge", "bridge_norm"):
+            raise ValueError(f"Unsupported link approximation {link_approx}.")
         if pred_type == "nn":
             if link_approx != "mc":
                 raise ValueError("Only mc link approximation is supported for nn prediction type.")
@@ -317,9 +317,28 @@ class _HipLaplace:
         if link_approx == "mc":
             fv = f_var if not diagonal_output else torch.diag_embed(f_var)
             return self._glm_predictive_samples(f_mu, fv, n_samples, diagonal_output, generator).mean(dim=0)
+        if link_approx in ("bridge", "bridge_norm"):
+            if diagonal_output:
+                f_mu, f_var = self._glm_predictive_distribution(x)  # the bridge needs the full output covariance
+            return self._laplace_bridge(f_mu, f_var, normalise=link_approx == "bridge_norm")
         var_diag = f_var if diagonal_output else torch.diagonal(f_var, dim1=1, dim2=2)
         kappa = 1 / torch.sqrt(1.0 + pi / 8 * var_diag)
         return torch.softmax(kappa * f_mu, dim=-1)
+
+    def _laplace_bridge(self, f_mu, f_var, normalise: bool):
+        """Dirichlet mean of the Laplace bridge (baselaplace.py:665-692): project the logit Gaussian onto the
+        zero-sum subspace, optionally rescale it to a mean output variance of sqrt(K/2), map it to Dirichlet
+        concentrations and normalise."""
+        K_out = f_mu.shape[-1]
+        row, col, tot = f_var.sum(-1), f_var.sum(-2), f_var.sum((1, 2))
+        mu = f_mu - row * (f_mu.sum(-1) / tot).unsqueeze(-1)
+        var = torch.diagonal(f_var, dim1=1, dim2=2) - row * col / tot.unsqueeze(-1)
+        if normalise:
+            scale = var.mean(dim=1, keepdim=True) / (K_out / 2) ** 0.5
+            mu = mu / scale.sqrt()
+            var = var / scale
+        alpha = (1 - 2 / K_out + mu.exp() / K_out**2 * torch.exp(-mu).sum(dim=1, keepdim=True)) / var
+        return torch.nan_to_num(alpha / alpha.sum(dim=1, keepdim=True), nan=1.0)
 
     # ---- serialisation, interchangeable with the reference's classes (baselaplace.py:1509-1557,1867-1879) ----------
     _REF_NAMES = {"kron": "Kron", "diag": "Diag", "full": "Full"}

@@ -172,3 +172,25 @@ def test_prior_optimisation_call_matches_the_reference(ref, hs, structure):
     assert float(lean.prior_precision.reshape(-1)[0]) == pytest.approx(float(la_ref.prior_precision.reshape(-1)[0]))
     with pytest.raises(ValueError, match="validation set"):
         lean.optimize_prior_precision(pred_type="glm", method="gridsearch")
+
+
+@pytest.mark.parametrize("hs", ["kron", "diag", "full"])
+@pytest.mark.parametrize("link", ["probit", "bridge", "bridge_norm"])
+def test_link_approximations_match_the_reference(ref, hs, link):
+    """classification predictive `la(x, link_approx=...)` (baselaplace.py:598-695): lean drivers == reference classes"""
+    from laplace import Laplace
+
+    from laplace_amd import HipGGN
+    from laplace_amd.laplace import HipLaplace
+
+    g = load_golden("resnetish", "classification")
+    model, X, y = golden_model("resnetish", g, dtype=torch.float32)
+    loader = DataLoader(TensorDataset(X, y), batch_size=5)
+    la_ref = Laplace(model, "classification", subset_of_weights="all", hessian_structure=hs, backend=HipGGN)
+    la_ref.fit(loader)
+    lean = HipLaplace(model, "classification", "all", hs)
+    lean.fit(loader)
+    want = la_ref(X, pred_type="glm", link_approx=link)
+    got = lean(X, pred_type="glm", link_approx=link)
+    assert rel(got, want) < 1e-4
+    assert torch.allclose(got.sum(-1), torch.ones(len(X)), atol=1e-5)
