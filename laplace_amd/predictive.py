@@ -45,6 +45,42 @@ def _conv_block_jacobian(tap, g, B, C):
     return Jl, width
 
 
+def _shared_quadform(K, call, u, v, fvar, weight_sharing_only: bool):
+    """``fvar += `` the weight-sharing quadratic form for ANY number of outputs C.  The kernel holds at most
+    ``K.quadform_shared_max_outputs`` (10) outputs in accumulators, so more of them are covered by pairs of 5-output
+    blocks: the launch on blocks (I, J) yields the I x I, J x J and I x J parts of ``f_var`` (the diagonal parts are
+    taken from the first launch that produces them).  That recomputes each output's tile product ``ceil(C/5) - 1``
+    times -- against the as-written block route's ``4 C (Do^2 Dk + Do Dk^2)`` flop still the cheaper way for layers
+    with few positions; returns False (nothing done) where it is not, unless the layer has no other route."""
+    B, C, Do, L = u.shape
+    Dk = v.shape[1]
+    cap = K.quadform_shared_max_outputs
+    if C <= cap:
+        call(u, v, fvar)
+        return True
+    h = max(cap // 2, 1)
+    blocks = [list(range(i, min(i + h, C))) for i in range(0, C, h)]
+    n_launch = len(blocks) * (len(blocks) - 1) // 2
+    if not weight_sharing_only and n_launch * 2.0 * cap * Do * L * Dk > 4.0 * C * (Do * Do * Dk + Do * Dk * Dk):
+        return False
+    seen = set()
+    for ia in range(len(blocks)):
+        for ib in range(ia + 1, len(blocks)):
+            A_, B_ = blocks[ia], blocks[ib]
+            tmp = torch.zeros(B, len(A_) + len(B_), len(A_) + len(B_), dtype=torch.float32, device=u.device)
+            call(u[:, A_ + B_].contiguous(), v, tmp)
+            na = len(A_)
+            fvar[:, A_[0]:A_[-1] + 1, B_[0]:B_[-1] + 1] += tmp[:, :na, na:]
+            fvar[:, B_[0]:B_[-1] + 1, A_[0]:A_[-1] + 1] += tmp[:, na:, :na]
+            if ia not in seen:
+                fvar[:, A_[0]:A_[-1] + 1, A_[0]:A_[-1] + 1] += tmp[:, :na, :na]
+                seen.add(ia)
+            if ib not in seen:
+                fvar[:, B_[0]:B_[-1] + 1, B_[0]:B_[-1] + 1] += tmp[:, na:, na:]
+                seen.add(ib)
+    return True
+
+
 def glm_variance_kron(backend, x, post):
     """``(f_mu, f_var)`` under a :class:`HipKronDecomposed` posterior precision ``post``
     (= ``H * H_factor + prior_precision``), i.e. KronLaplace.functional_variance."""
@@ -74,24 +110,26 @@ def glm_variance_kron(backend, x, post):
             K.kron_quadform_linear(u, v, l1.contiguous(), l2.contiguous(), d1, fvar, ub,
                                    None if lb is None else lb.contiguous(),
                                    None if delta_b is None else delta_b.detach().reshape(1).contiguous())
-        elif C <= K.quadform_shared_max_outputs:
-            u, v, gsum = _shared_operands(tap, g, B, C, Q1, Q2)
-            K.kron_quadform_shared(u, v, l1.contiguous(), l2.contiguous(), d1, fvar)
-            if Qb is not None:
-                ub = gsum @ Qb
-                fvar += torch.einsum("cno,kno,o->nck", ub, ub, 1.0 / (lb + delta_b))
-        elif tap.kind == "conv2d":
-            Jl, width = _conv_block_jacobian(tap, g, B, C)
-            Do, Dk = len(l1), len(l2)
-            W = Jl[:, :, :width].reshape(B * C, Do, Dk)
-            M = Q1.T @ W @ Q2
-            fvar += torch.einsum("ncoi,nkoi,oi->nck", M.reshape(B, C, Do, Dk), M.reshape(B, C, Do, Dk),
-                                 1.0 / (torch.outer(l1, l2) + delta))
-            if Qb is not None:
-                ub = Jl[:, :, width:] @ Qb
-                fvar += torch.einsum("nco,nko,o->nck", ub, ub, 1.0 / (lb + delta_b))
         else:
-            raise NotImplementedError(f"{tap.name}: Kron predictive for weight-shared Linear layers with > 10 outputs")
+            u, v, gsum = _shared_operands(tap, g, B, C, Q1, Q2)
+            l1c, l2c = l1.contiguous(), l2.contiguous()
+            done = _shared_quadform(K, lambda uu, vv, out: K.kron_quadform_shared(uu, vv, l1c, l2c, d1, out), u, v, fvar,
+                                    weight_sharing_only=tap.kind != "conv2d")
+            if done:
+                if Qb is not None:
+                    ub = gsum @ Qb
+                    fvar += torch.einsum("cno,kno,o->nck", ub, ub, 1.0 / (lb + delta_b))
+            else:  # many outputs and many positions: the layer's Jacobian block, rotated as written
+                del u, v
+                Jl, width = _conv_block_jacobian(tap, g, B, C)
+                Do, Dk = len(l1), len(l2)
+                W = Jl[:, :, :width].reshape(B * C, Do, Dk)
+                M = Q1.T @ W @ Q2
+                fvar += torch.einsum("ncoi,nkoi,oi->nck", M.reshape(B, C, Do, Dk), M.reshape(B, C, Do, Dk),
+                                     1.0 / (torch.outer(l1, l2) + delta))
+                if Qb is not None:
+                    ub = Jl[:, :, width:] @ Qb
+                    fvar += torch.einsum("nco,nko,o->nck", ub, ub, 1.0 / (lb + delta_b))
     tape.release()
     return f, fvar
 
@@ -113,18 +151,18 @@ def glm_variance_diag(backend, x, post_var: torch.Tensor):
         if tap.kind == "linear" and tap.a.ndim == 2:
             vb = post_var[tap.b_off:tap.b_off + m.out_features] if tap.has_bias else None
             K.diag_quadform_linear(tap.a.to(torch.float32).contiguous(), g.contiguous(), vw, vb, fvar)
-        elif C <= K.quadform_shared_max_outputs:
+        elif C <= K.quadform_shared_max_outputs or tap.kind != "conv2d":
             u, v, gsum = _shared_operands(tap, g, B, C)
-            K.diag_quadform_shared(u, v, vw.reshape(u.shape[2], v.shape[1]).contiguous(), fvar)
+            vw2 = vw.reshape(u.shape[2], v.shape[1]).contiguous()
+            _shared_quadform(K, lambda uu, vv, out: K.diag_quadform_shared(uu, vv, vw2, out), u, v, fvar,
+                             weight_sharing_only=True)
             if tap.has_bias:
                 vb = post_var[tap.b_off:tap.b_off + u.shape[2]]
                 fvar += torch.einsum("cno,kno,o->nck", gsum, gsum, vb)
-        elif tap.kind == "conv2d":
+        else:  # many outputs: assembling the block Jacobian once is cheaper than re-forming tile products per pair
             Jl, width = _conv_block_jacobian(tap, g, B, C)
             var = torch.cat([vw, post_var[tap.b_off:tap.b_off + m.out_channels]]) if tap.has_bias else vw
             fvar += K.diag_quadform_js(Jl, var.contiguous())
-        else:
-            raise NotImplementedError(f"{tap.name}: diagonal predictive for weight-shared Linear layers with > 10 outputs")
     tape.release()
     return f, fvar
 

@@ -262,11 +262,13 @@ class EmulatedKernels:
     quadform_shared_max_outputs = 10
 
     def kron_quadform_shared(self, u, v, l1, l2, delta, fvar):
+        assert u.shape[1] <= self.quadform_shared_max_outputs, "the HIP kernel holds at most 10 outputs"
         M = torch.einsum("ncol,nil->ncoi", u, v)
         fvar += torch.einsum("ncoi,nkoi,oi->nck", M, M, 1.0 / (torch.outer(l1, l2) + delta.reshape(())))
         return fvar
 
     def diag_quadform_shared(self, u, v, var_w, fvar):
+        assert u.shape[1] <= self.quadform_shared_max_outputs, "the HIP kernel holds at most 10 outputs"
         M = torch.einsum("ncol,nil->ncoi", u, v)
         fvar += torch.einsum("ncoi,nkoi,oi->nck", M, M, var_w)
         return fvar

@@ -144,3 +144,51 @@ def test_wide_conv_exact_diagonal_on_emulation():
 @pytest.mark.gpu
 def test_wide_conv_exact_diagonal_gpu():
     _run_wide_conv("cuda")
+
+
+class ManyOutputsNet(nn.Module):
+    """13 outputs: more than the predictive kernel holds in accumulators at once (10) -> 5-output block pairs"""
+
+    def __init__(self, seq: bool):
+        super().__init__()
+        self.seq = seq
+        self.body = nn.Linear(5, 7) if seq else nn.Conv2d(2, 6, 3, padding=1)
+        self.act = nn.Tanh()
+        self.head = nn.Linear(7 if seq else 6, 13)
+
+    def forward(self, x):
+        h = self.act(self.body(x))
+        return self.head(h.mean(1) if self.seq else h.mean((2, 3)))
+
+
+@pytest.mark.parametrize("seq", [True, False])
+def test_more_outputs_than_accumulators_on_emulation(seq):
+    """Kron and diagonal GLM predictive with 13 outputs == J P^-1 J^T on the autograd Jacobian (fp64)"""
+    from laplace_amd import _lib
+    from laplace_amd.laplace import HipLaplace
+    from tests.emulated_kernels import EmulatedKernels
+
+    prev = _lib.set_kernels_for_testing(EmulatedKernels())
+    try:
+        torch.manual_seed(9)
+        model = ManyOutputsNet(seq)
+        X = torch.randn(6, 4, 5) if seq else torch.randn(6, 2, 4, 4)
+        y = torch.randint(13, (6,))
+        m64 = ManyOutputsNet(seq).double()
+        m64.load_state_dict({k: v.double() for k, v in model.state_dict().items()})
+        Js64, f64 = co.jacobians(m64, X.double())
+        loader = _Loader([(X, y)])
+        loader.dataset = range(6)
+        la = HipLaplace(model, "classification", "all", "kron", prior_precision=0.5)
+        la.fit(loader)
+        _, f_var = la._glm_predictive_distribution(X)
+        _, kf = co.kfac_ggn(m64, X.double(), y, 6, "classification")
+        Qs, ls = co.kron_decompose(kf)
+        assert rel(f_var, co.functional_variance_kron(Js64, Qs, ls, 0.5)) < 1e-4
+        ld = HipLaplace(model, "classification", "all", "diag", prior_precision=0.5)
+        ld.fit(loader)
+        _, f_var_d = ld._glm_predictive_distribution(X)
+        post_var = 1.0 / (co.ggn_diag(Js64, co.functional_hessian(f64, "classification")) + 0.5)
+        assert rel(f_var_d, co.functional_variance_diag(Js64, post_var)) < 1e-4
+    finally:
+        _lib.set_kernels_for_testing(prev)
