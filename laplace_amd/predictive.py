@@ -17,8 +17,9 @@ the posterior (Kron: laplace/utils/matrix.py:406-461; diag: baselaplace.py:2113-
   inside MFMA accumulators: no ``Do x Dk`` block per (sample, output) is ever written.  As written
   (matrix.py:406-461) the Kronecker form costs ``4 C (Do^2 Dk + Do Dk^2)`` flop per sample and layer — 484 GFLOP
   for one 512x4608 ResNet-18 layer; here ``2 L (Dk^2 + C Do^2 + C Do Dk)`` = 1.5 GFLOP.
-* more than 10 outputs, or other layer types: the layer's Jacobian block is assembled by ``lk_jac_conv_f32``
-  (only that block, never the full ``[B, C, P]``) and contracted with the block's posterior.
+* more than 10 outputs (the kernel's accumulator budget): pairs of 5-output blocks of the same kernel where that is
+  cheaper than the as-written route — the layer's Jacobian block assembled by ``lk_jac_conv_f32`` (only that block,
+  never the full ``[B, C, P]``) and contracted with the block's posterior — which serves the rest.
 """
 from __future__ import annotations
 
