@@ -161,34 +161,45 @@ class ManyOutputsNet(nn.Module):
         return self.head(h.mean(1) if self.seq else h.mean((2, 3)))
 
 
+def _run_many_outputs(dev, seq):
+    from laplace_amd.laplace import HipLaplace
+
+    torch.manual_seed(9)
+    model = ManyOutputsNet(seq).to(dev)
+    X = (torch.randn(6, 4, 5) if seq else torch.randn(6, 2, 4, 4)).to(dev)
+    y = torch.randint(13, (6,)).to(dev)
+    m64 = ManyOutputsNet(seq).double()
+    m64.load_state_dict({k: v.double().cpu() for k, v in model.state_dict().items()})
+    Js64, f64 = co.jacobians(m64, X.double().cpu())
+    loader = _Loader([(X, y)])
+    loader.dataset = range(6)
+    la = HipLaplace(model, "classification", "all", "kron", prior_precision=0.5)
+    la.fit(loader)
+    _, f_var = la._glm_predictive_distribution(X)
+    _, kf = co.kfac_ggn(m64, X.double().cpu(), y.cpu(), 6, "classification")
+    Qs, ls = co.kron_decompose(kf)
+    assert rel(f_var, co.functional_variance_kron(Js64, Qs, ls, 0.5)) < 1e-4
+    ld = HipLaplace(model, "classification", "all", "diag", prior_precision=0.5)
+    ld.fit(loader)
+    _, f_var_d = ld._glm_predictive_distribution(X)
+    post_var = 1.0 / (co.ggn_diag(Js64, co.functional_hessian(f64, "classification")) + 0.5)
+    assert rel(f_var_d, co.functional_variance_diag(Js64, post_var)) < 1e-4
+
+
 @pytest.mark.parametrize("seq", [True, False])
 def test_more_outputs_than_accumulators_on_emulation(seq):
     """Kron and diagonal GLM predictive with 13 outputs == J P^-1 J^T on the autograd Jacobian (fp64)"""
     from laplace_amd import _lib
-    from laplace_amd.laplace import HipLaplace
     from tests.emulated_kernels import EmulatedKernels
 
     prev = _lib.set_kernels_for_testing(EmulatedKernels())
     try:
-        torch.manual_seed(9)
-        model = ManyOutputsNet(seq)
-        X = torch.randn(6, 4, 5) if seq else torch.randn(6, 2, 4, 4)
-        y = torch.randint(13, (6,))
-        m64 = ManyOutputsNet(seq).double()
-        m64.load_state_dict({k: v.double() for k, v in model.state_dict().items()})
-        Js64, f64 = co.jacobians(m64, X.double())
-        loader = _Loader([(X, y)])
-        loader.dataset = range(6)
-        la = HipLaplace(model, "classification", "all", "kron", prior_precision=0.5)
-        la.fit(loader)
-        _, f_var = la._glm_predictive_distribution(X)
-        _, kf = co.kfac_ggn(m64, X.double(), y, 6, "classification")
-        Qs, ls = co.kron_decompose(kf)
-        assert rel(f_var, co.functional_variance_kron(Js64, Qs, ls, 0.5)) < 1e-4
-        ld = HipLaplace(model, "classification", "all", "diag", prior_precision=0.5)
-        ld.fit(loader)
-        _, f_var_d = ld._glm_predictive_distribution(X)
-        post_var = 1.0 / (co.ggn_diag(Js64, co.functional_hessian(f64, "classification")) + 0.5)
-        assert rel(f_var_d, co.functional_variance_diag(Js64, post_var)) < 1e-4
+        _run_many_outputs("cpu", seq)
     finally:
         _lib.set_kernels_for_testing(prev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seq", [True, False])
+def test_more_outputs_than_accumulators_gpu(seq):
+    _run_many_outputs("cuda", seq)
