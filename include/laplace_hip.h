@@ -46,19 +46,27 @@ const char* lk_last_error(void);
  *   S[c][n][j] = delta_jc*sqrt(p_nc) - p_nj*sqrt(p_nc)   (column c of a root of diag(p)-pp^T)
  *   loss_accum[0] += sum_n -log p_n[y_n]                  (skipped when y or loss_accum is NULL)
  * f: [B][C] logits; S: [C][B][C] (one backward seed per class, `is_grads_batched` layout).
+ *
+ * The loss is reduced in a FIXED order (per-workgroup partials in `ws`, then one wave sums them in index order):
+ * run-to-run deterministic, no floating-point atomics.  `ws`: lk_loss_workspace_bytes(B) bytes, needed whenever the
+ * loss is requested.  Labels outside [0, C) contribute nothing to the loss (CrossEntropyLoss's ignore_index).
  * ------------------------------------------------------------------------------------------- */
+size_t lk_loss_workspace_bytes(int64_t B);
 int lk_softmax_hess_sqrt_f32(const float* f, const int64_t* y, int64_t B, int64_t C, float* S,
-                             float* loss_accum, void* stream);
+                             float* loss_accum, float* ws, void* stream);
 
 /* Same contract with the rank-revealing root: the softmax Hessian has rank C-1, and its closed-form Cholesky
  * factor  L[j][j] = sqrt(p_j s_{j+1}/s_j),  L[i][j] = -p_i sqrt(p_j/(s_j s_{j+1})) (i > j),  s_j = sum_{k>=j} p_k
- * has only C-1 non-zero columns: S is [C-1][B][C] and the fit needs one reverse pass fewer.  2 <= C <= 4096. */
+ * has only C-1 non-zero columns: S is [C-1][B][C] and the fit needs one reverse pass fewer.
+ * 2 <= C <= LK_SOFTMAX_CHOL_MAX_C (4 waves x (2C+1) floats of LDS per workgroup). */
+#define LK_SOFTMAX_CHOL_MAX_C 2000
 int lk_softmax_hess_chol_f32(const float* f, const int64_t* y, int64_t B, int64_t C, float* S,
-                             float* loss_accum, void* stream);
+                             float* loss_accum, float* ws, void* stream);
 
-/* loss_accum[0] += scale * sum (f - y)^2 over `numel` elements (MSELoss(sum) * factor). */
+/* loss_accum[0] += scale * sum (f - y)^2 over `numel` elements (MSELoss(sum) * factor); fixed-order reduction
+ * through `ws` (>= 4 KiB). */
 int lk_sq_err_sum_f32(const float* f, const float* y, int64_t numel, float scale, float* loss_accum,
-                      void* stream);
+                      float* ws, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Gram / factor accumulation:  C += alpha * X^T X   (fp32 MFMA, split-K, deterministic).

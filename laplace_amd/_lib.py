@@ -34,9 +34,10 @@ _u32 = ctypes.c_uint
 SIGNATURES = {
     "lk_version": (_int, []),
     "lk_last_error": (ctypes.c_char_p, []),
-    "lk_softmax_hess_sqrt_f32": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),
-    "lk_softmax_hess_chol_f32": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),
-    "lk_sq_err_sum_f32": (_int, [_vp, _vp, _i64, _f32, _vp, _vp]),
+    "lk_loss_workspace_bytes": (_sz, [_i64]),
+    "lk_softmax_hess_sqrt_f32": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "lk_softmax_hess_chol_f32": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "lk_sq_err_sum_f32": (_int, [_vp, _vp, _i64, _f32, _vp, _vp, _vp]),
     "lk_gram_workspace_bytes": (_sz, [_i64, _i64]),
     "lk_gram_nt_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "lk_gram_slabs_reduce_f32": (_int, [_vp, _sz, _i64, _i64, _f32, _vp, _u32, _vp]),
@@ -130,6 +131,7 @@ class HipKernels:
     """Tensor-level wrappers; every method enqueues on torch's current stream and returns at once."""
 
     name = "hip"
+    softmax_chol_max_c = 2000  # LK_SOFTMAX_CHOL_MAX_C (include/laplace_hip.h): wider outputs use the symmetric root
 
     def __init__(self, lib: Optional[ctypes.CDLL] = None):
         self.lib = lib if lib is not None else load_library()
@@ -174,14 +176,18 @@ class HipKernels:
         (``S = C``) or, with ``cholesky=True``, the rank-revealing Cholesky root (``S = C - 1``)."""
         _check(f, "f")
         B, C = f.shape
-        if cholesky and 2 <= C <= 4096:
+        ws = None
+        if y is not None and loss_accum is not None:
+            ws = torch.empty(max(1024, (B + 3) // 4 + 1), dtype=torch.float32, device=f.device)  # per-block partials
+        if cholesky and 2 <= C <= self.softmax_chol_max_c:
             S = torch.empty(C - 1, B, C, dtype=torch.float32, device=f.device)
             if y is not None:
                 _check(y, "y", torch.int64)
             if loss_accum is not None:
                 _check(loss_accum, "loss_accum")
             self._rc(
-                self.lib.lk_softmax_hess_chol_f32(_ptr(f), _ptr(y), B, C, _ptr(S), _ptr(loss_accum), self._stream(f.device)),
+                self.lib.lk_softmax_hess_chol_f32(_ptr(f), _ptr(y), B, C, _ptr(S), _ptr(loss_accum), _ptr(ws),
+                                                  self._stream(f.device)),
                 "lk_softmax_hess_chol_f32",
             )
             return S
@@ -191,7 +197,8 @@ class HipKernels:
         if loss_accum is not None:
             _check(loss_accum, "loss_accum")
         self._rc(
-            self.lib.lk_softmax_hess_sqrt_f32(_ptr(f), _ptr(y), B, C, _ptr(S), _ptr(loss_accum), self._stream(f.device)),
+            self.lib.lk_softmax_hess_sqrt_f32(_ptr(f), _ptr(y), B, C, _ptr(S), _ptr(loss_accum), _ptr(ws),
+                                              self._stream(f.device)),
             "lk_softmax_hess_sqrt_f32",
         )
         return S
@@ -201,7 +208,9 @@ class HipKernels:
         if f.shape != y.shape:
             raise LaplaceHipError(f"sq_err_sum: shape mismatch {tuple(f.shape)} vs {tuple(y.shape)}")
         self._rc(
-            self.lib.lk_sq_err_sum_f32(_ptr(f), _ptr(y), f.numel(), float(scale), _ptr(loss_accum), self._stream(f.device)),
+            self.lib.lk_sq_err_sum_f32(_ptr(f), _ptr(y), f.numel(), float(scale), _ptr(loss_accum),
+                                       _ptr(torch.empty(1024, dtype=torch.float32, device=f.device)),
+                                       self._stream(f.device)),
             "lk_sq_err_sum_f32",
         )
 

@@ -527,6 +527,12 @@ class KronAccumulator:
         self._gslabs = {}  # tap index -> (persistent split-K slabs, n, L, alpha) of a conv G factor
         self._tap_index = {tap.name: i for i, tap in enumerate(tape.taps)}
 
+    def ensure_allocated(self, device):
+        """Zero factors for a rank that saw no minibatch (empty shard of a data-parallel fit): shapes come from the
+        modules alone, so the rank can still take part in the all-reduce."""
+        if self.factors is None:
+            self._alloc(self.backend._tape(), device)
+
     def _pix_geometry(self, tap):
         """How this tap's A factor is accumulated over the fit (3x3 / stride 1 / pad 1 convs, ``expand``):
 

@@ -10,7 +10,7 @@ namespace lk {
 __global__ __launch_bounds__(256) void softmax_hess_sqrt_kernel(const float* __restrict__ f,
                                                                 const int64_t* __restrict__ y, int B, int C,
                                                                 float* __restrict__ S,
-                                                                float* __restrict__ loss_accum) {
+                                                                float* __restrict__ partials) {
   __shared__ float red[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = blockIdx.x * 4 + wave;
@@ -25,7 +25,10 @@ __global__ __launch_bounds__(256) void softmax_hess_sqrt_kernel(const float* __r
     for (int j = lane; j < C; j += 64) z += expf(fr[j] - m);
     z = wave_sum(z);
     const float logz = logf(z) + m;
-    if (y != nullptr && lane == 0) nll = logz - fr[y[n]];
+    if (y != nullptr && lane == 0) {
+      const int64_t lab = y[n];  // labels outside [0, C) (e.g. an ignore_index of -100) contribute nothing
+      if (lab >= 0 && lab < C) nll = logz - fr[lab];
+    }
     for (int c = 0; c < C; ++c) {
       const float pc = expf(fr[c] - logz);
       const float spc = sqrtf(pc);
@@ -36,9 +39,9 @@ __global__ __launch_bounds__(256) void softmax_hess_sqrt_kernel(const float* __r
       }
     }
   }
-  if (loss_accum != nullptr && y != nullptr) {
+  if (partials != nullptr && y != nullptr) {  // fixed-order reduction: per-block partial, summed by loss_finish_kernel
     const float tot = block_sum_256(nll, red);
-    if (threadIdx.x == 0) atomicAdd(loss_accum, tot);
+    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
   }
 }
 
@@ -48,7 +51,7 @@ __global__ __launch_bounds__(256) void softmax_hess_sqrt_kernel(const float* __r
 __global__ __launch_bounds__(256) void softmax_hess_chol_kernel(const float* __restrict__ f,
                                                                 const int64_t* __restrict__ y, int B, int C,
                                                                 float* __restrict__ S,
-                                                                float* __restrict__ loss_accum) {
+                                                                float* __restrict__ partials) {
   extern __shared__ float dyn[];  // per wave: p[C], s[C+1]
   __shared__ float red[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -66,7 +69,10 @@ __global__ __launch_bounds__(256) void softmax_hess_chol_kernel(const float* __r
     for (int j = lane; j < C; j += 64) z += expf(fr[j] - m);
     z = wave_sum(z);
     const float logz = logf(z) + m;
-    if (y != nullptr && lane == 0) nll = logz - fr[y[n]];
+    if (y != nullptr && lane == 0) {
+      const int64_t lab = y[n];  // labels outside [0, C) (e.g. an ignore_index of -100) contribute nothing
+      if (lab >= 0 && lab < C) nll = logz - fr[lab];
+    }
     for (int j = lane; j < C; j += 64) p[j] = expf(fr[j] - logz);
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) {  // suffix sums of positive numbers (C is small)
@@ -89,15 +95,15 @@ __global__ __launch_bounds__(256) void softmax_hess_chol_kernel(const float* __r
       for (int i = lane; i < C; i += 64) out[i] = (i < c) ? 0.f : (i == c ? dg : -(p[i] * rs) * r0);
     }
   }
-  if (loss_accum != nullptr && y != nullptr) {
+  if (partials != nullptr && y != nullptr) {  // fixed-order reduction: per-block partial, summed by loss_finish_kernel
     const float tot = block_sum_256(nll, red);
-    if (threadIdx.x == 0) atomicAdd(loss_accum, tot);
+    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
   }
 }
 
 __global__ __launch_bounds__(256) void sq_err_sum_kernel(const float* __restrict__ f, const float* __restrict__ y,
-                                                         int64_t numel, float scale,
-                                                         float* __restrict__ loss_accum) {
+                                                         int64_t numel,
+                                                         float* __restrict__ partials) {
   __shared__ float red[4];
   float s = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256) {
@@ -105,39 +111,67 @@ __global__ __launch_bounds__(256) void sq_err_sum_kernel(const float* __restrict
     s += d * d;
   }
   const float tot = block_sum_256(s, red);
-  if (threadIdx.x == 0) atomicAdd(loss_accum, scale * tot);
+  if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
+// loss_accum[0] += scale * sum_i partials[i], summed in index order by one wave (run-to-run deterministic; the
+// per-block partials themselves are fixed-order tree sums)
+__global__ __launch_bounds__(64) void loss_finish_kernel(const float* __restrict__ partials, int n, float scale,
+                                                         float* __restrict__ loss_accum) {
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 64) s += partials[i];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) loss_accum[0] += scale * s;
 }
 
 }  // namespace lk
 
 using namespace lk;
 
+extern "C" size_t lk_loss_workspace_bytes(int64_t B) { return (size_t)((B + 3) / 4 + 1) * sizeof(float); }
+
+static int finish_loss(const float* partials, int64_t n, float scale, float* loss_accum, void* stream) {
+  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partials, (int)n, scale, loss_accum);
+  return check_launch("loss_finish_kernel");
+}
+
 extern "C" int lk_softmax_hess_sqrt_f32(const float* f, const int64_t* y, int64_t B, int64_t C, float* S,
-                                        float* loss_accum, void* stream) {
+                                        float* loss_accum, float* ws, void* stream) {
   LK_REQUIRE(f && S && B >= 0 && C >= 1 && B < (1ll << 31) && C < (1 << 24), "lk_softmax_hess_sqrt_f32: bad arguments");
+  const bool want_loss = loss_accum != nullptr && y != nullptr;
+  LK_REQUIRE(!want_loss || ws, "lk_softmax_hess_sqrt_f32: the loss needs a workspace of lk_loss_workspace_bytes(B)");
   if (B == 0) return LK_OK;
   hipLaunchKernelGGL(softmax_hess_sqrt_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, f, y,
-                     (int)B, (int)C, S, loss_accum);
-  return check_launch("softmax_hess_sqrt_kernel");
+                     (int)B, (int)C, S, want_loss ? ws : nullptr);
+  int rc = check_launch("softmax_hess_sqrt_kernel");
+  if (rc == LK_OK && want_loss) rc = finish_loss(ws, (B + 3) / 4, 1.f, loss_accum, stream);
+  return rc;
 }
 
 extern "C" int lk_softmax_hess_chol_f32(const float* f, const int64_t* y, int64_t B, int64_t C, float* S,
-                                        float* loss_accum, void* stream) {
-  LK_REQUIRE(f && S && B >= 0 && C >= 2 && B < (1ll << 31) && C <= 4096, "lk_softmax_hess_chol_f32: bad arguments");
+                                        float* loss_accum, float* ws, void* stream) {
+  // 4 waves x (2C + 1) floats of dynamic LDS must stay inside the 64 KiB a launch may request by default
+  LK_REQUIRE(f && S && B >= 0 && C >= 2 && B < (1ll << 31) && C <= LK_SOFTMAX_CHOL_MAX_C,
+             "lk_softmax_hess_chol_f32: bad arguments (2 <= C <= %d)", LK_SOFTMAX_CHOL_MAX_C);
+  const bool want_loss = loss_accum != nullptr && y != nullptr;
+  LK_REQUIRE(!want_loss || ws, "lk_softmax_hess_chol_f32: the loss needs a workspace of lk_loss_workspace_bytes(B)");
   if (B == 0) return LK_OK;
   const size_t lds = (size_t)4 * (2 * C + 1) * sizeof(float);
   hipLaunchKernelGGL(softmax_hess_chol_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), lds, (hipStream_t)stream, f, y,
-                     (int)B, (int)C, S, loss_accum);
-  return check_launch("softmax_hess_chol_kernel");
+                     (int)B, (int)C, S, want_loss ? ws : nullptr);
+  int rc = check_launch("softmax_hess_chol_kernel");
+  if (rc == LK_OK && want_loss) rc = finish_loss(ws, (B + 3) / 4, 1.f, loss_accum, stream);
+  return rc;
 }
 
 extern "C" int lk_sq_err_sum_f32(const float* f, const float* y, int64_t numel, float scale, float* loss_accum,
-                                 void* stream) {
-  LK_REQUIRE(f && y && loss_accum && numel >= 0, "lk_sq_err_sum_f32: bad arguments");
+                                 float* ws, void* stream) {
+  LK_REQUIRE(f && y && loss_accum && ws && numel >= 0, "lk_sq_err_sum_f32: bad arguments");
   if (numel == 0) return LK_OK;
   int64_t blocks = (numel + 255) / 256;
-  if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(sq_err_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, f, y, numel, scale,
-                     loss_accum);
-  return check_launch("sq_err_sum_kernel");
+  if (blocks > 1024) blocks = 1024;  // <= 1024 partials: ws of 4 KiB (lk_loss_workspace_bytes(4096))
+  hipLaunchKernelGGL(sq_err_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, f, y, numel, ws);
+  int rc = check_launch("sq_err_sum_kernel");
+  if (rc == LK_OK) rc = finish_loss(ws, blocks, scale, loss_accum, stream);
+  return rc;
 }

@@ -26,23 +26,90 @@ from laplace_amd.backend import HipGGN
 from laplace_amd.kron import HipKron
 
 
+class _StridedBatches:
+    """Batch sampler of one rank: batches ``rank, rank + world, ...`` of the wrapped batch sampler.  Only index lists
+    pass through here — the other ranks' samples are never loaded or collated."""
+
+    def __init__(self, batch_sampler, rank: int, world_size: int):
+        self.batch_sampler, self.rank, self.world_size = batch_sampler, rank, world_size
+
+    def __iter__(self):
+        for i, idx in enumerate(self.batch_sampler):
+            if i % self.world_size == self.rank:
+                yield idx
+
+    def __len__(self):
+        return (len(self.batch_sampler) - self.rank + self.world_size - 1) // self.world_size
+
+
 class ShardedLoader:
-    """Iterate minibatches ``rank, rank + world, ...`` of ``loader`` while still reporting the
-    GLOBAL dataset (``len(loader.dataset)`` is the ``N`` every rank passes to ``kron``: the A factor
-    is scaled by ``M / N``, laplace/curvature/curvlinops.py:46-53, so partial sums add up exactly)."""
+    """Minibatches ``rank, rank + world, ...`` of ``loader`` while still reporting the GLOBAL dataset
+    (``len(loader.dataset)`` is the ``N`` every rank passes to ``kron``: the A factor is scaled by ``M / N``,
+    laplace/curvature/curvlinops.py:46-53, so partial sums add up exactly).
+
+    The shard is taken where it is cheap: a ``torch.utils.data.DataLoader`` is rebuilt around a strided batch sampler
+    (a rank never loads, collates or transfers another rank's samples; with ``shuffle=True`` give the loader a
+    ``generator`` seeded identically on every rank so that all ranks cut the same permutation), an indexable
+    collection of ready batches is sliced, and only a plain iterable is walked with the foreign batches skipped."""
 
     def __init__(self, loader, rank: int, world_size: int):
         self.loader, self.rank, self.world_size = loader, rank, world_size
         self.dataset = loader.dataset
 
+    def _mine(self):
+        ld = self.loader
+        from torch.utils.data import DataLoader
+
+        if isinstance(ld, DataLoader) and ld.batch_sampler is not None:
+            return DataLoader(ld.dataset, batch_sampler=_StridedBatches(ld.batch_sampler, self.rank, self.world_size),
+                              num_workers=ld.num_workers, collate_fn=ld.collate_fn, pin_memory=ld.pin_memory,
+                              timeout=ld.timeout, worker_init_fn=ld.worker_init_fn,
+                              multiprocessing_context=ld.multiprocessing_context, generator=ld.generator,
+                              prefetch_factor=ld.prefetch_factor if ld.num_workers > 0 else None,
+                              persistent_workers=ld.persistent_workers)
+        if hasattr(ld, "__getitem__") and hasattr(ld, "__len__"):
+            return (ld[i] for i in range(self.rank, len(ld), self.world_size))
+        return (b for i, b in enumerate(ld) if i % self.world_size == self.rank)
+
     def __iter__(self):
-        for i, batch in enumerate(self.loader):
-            if i % self.world_size == self.rank:
-                yield batch
+        return iter(self._mine())
 
     def __len__(self):
         n = len(self.loader)
         return (n - self.rank + self.world_size - 1) // self.world_size
+
+
+def loader_is_sharded(loader) -> bool:
+    """Does every rank see only ITS part of the data through ``loader``?  (:class:`ShardedLoader`, or a DataLoader on
+    a ``DistributedSampler``.)"""
+    if isinstance(loader, ShardedLoader):
+        return True
+    from torch.utils.data.distributed import DistributedSampler
+
+    for attr in ("sampler", "batch_sampler"):
+        smp = getattr(loader, attr, None)
+        if isinstance(smp, DistributedSampler) or isinstance(getattr(smp, "sampler", None), DistributedSampler):
+            return True
+    return False
+
+
+def resolve_distributed(train_loader, distributed, group=None) -> bool:
+    """The all-reduce of a fit is OPT-IN: explicit ``distributed=True``, or — with ``distributed=None`` — an
+    initialised process group of more than one rank AND a loader that is visibly sharded.  A DDP-style script in which
+    every rank runs ``la.fit(full_loader)`` (how the single-process reference is used) must not have its curvature
+    silently multiplied by the world size: that case warns and stays local."""
+    if distributed is not None:
+        return bool(distributed)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return False
+    if loader_is_sharded(train_loader):
+        return True
+    import warnings
+
+    warnings.warn("torch.distributed is initialised but the training loader is not sharded (no ShardedLoader / "
+                  "DistributedSampler): fitting locally WITHOUT an all-reduce. Wrap the loader in "
+                  "laplace_amd.ShardedLoader(loader, rank, world_size) or pass distributed=True.", stacklevel=3)
+    return False
 
 
 def allreduce_curvature(tensors: list[torch.Tensor], group=None) -> None:
@@ -194,8 +261,7 @@ class _HipLaplace:
             loss_b, H_b = self._curv_closure(X, y, N)
             self.loss = self.loss + loss_b
             self.H += H_b
-        if distributed is None:
-            distributed = dist.is_available() and dist.is_initialized()
+        distributed = resolve_distributed(train_loader, distributed, process_group)
         if distributed:
             loss_t = self.loss.reshape(1).clone()
             allreduce_curvature(self._curvature_tensors() + [loss_t], group=process_group)
@@ -533,6 +599,7 @@ class HipKronLaplace(_HipLaplace):
         # online continuation (baselaplace.py:1785-1806): the A factors carry 1/N, so the old ones are discounted by
         # n_old / (n_old + n_new) and the new ones (computed with N = n_new) by n_new / (n_old + n_new)
         old = None
+        distributed = resolve_distributed(train_loader, distributed, process_group)
         if not override and self.H_facs is not None:
             n_old, n_new = self.n_data, len(train_loader.dataset)
             old = (self._rescale_factors(self.H_facs, n_old / (n_old + n_new)), self.loss, n_old, n_new)
@@ -556,9 +623,8 @@ class HipKronLaplace(_HipLaplace):
                     if self.subset_of_weights == "last_layer" and torch.is_tensor(X):
                         self.data = (X[:1].detach().cpu(), y[:1].detach().cpu())
                 acc.add_batch(X, y)
-            if distributed is None:
-                distributed = dist.is_available() and dist.is_initialized()
             if distributed:
+                acc.ensure_allocated(self._device)  # a rank whose shard is empty contributes zeros
                 allreduce_curvature(acc.tensors(), group=process_group)
             self.loss, self.H = acc.finalize()
             self.n_data = N
@@ -571,8 +637,6 @@ class HipKronLaplace(_HipLaplace):
             self.H_facs = facs
             self.loss = self.loss + loss_old
             self.n_data = n_old + n_new
-        if distributed is None:
-            distributed = dist.is_available() and dist.is_initialized()
         # HIP eigensolver per factor; after a data-parallel fit the factors are sharded over the ranks
         self.H = self.H_facs.decompose(damping=self.damping, distributed=bool(distributed), process_group=process_group)
 
@@ -775,9 +839,9 @@ def fit_kron(la, train_loader, process_group=None, distributed: bool | None = No
             setattr(la.model, "output_size", la.n_outputs)
             first = False
         acc.add_batch(X, y)
-    if distributed is None:
-        distributed = dist.is_available() and dist.is_initialized()
+    distributed = resolve_distributed(train_loader, distributed, process_group)
     if distributed:
+        acc.ensure_allocated(la._device)  # a rank whose shard is empty contributes zeros
         allreduce_curvature(acc.tensors(), group=process_group)
     la.loss, la.H_facs = acc.finalize()
     la.n_data = N

@@ -94,6 +94,10 @@ def glm_variance_kron(backend, x, post):
     fvar = torch.zeros(B, C, C, dtype=torch.float32, device=f.device)
     blk = 0
     for tap, g in zip(tape.taps, grads):
+        if len(post.eigenvalues[blk]) != 2:
+            # a 1x1 bias-free layer is stored as ONE merged block [G*A] (curvlinops.py:55-75): no kernel for it here
+            tape.release()
+            raise NotImplementedError("merged single-factor weight block: use the Jacobian route")
         (Q1, Q2), (l1, l2), delta = post.eigenvectors[blk], post.eigenvalues[blk], post.deltas[blk]
         blk += 1
         Qb = lb = delta_b = None

@@ -90,6 +90,8 @@ class SeedBatchedSweep:
                                        | {operator.add, torch.add, torch.flatten, operator.iadd, operator.getitem,
                                           torch.mean}):
                     raise SweepUnsupported(f"no VJP rule for function {getattr(node.target, '__name__', node.target)}")
+                if node.target in (operator.add, torch.add, operator.iadd) and node.kwargs.get("alpha", 1) != 1:
+                    raise SweepUnsupported("add with alpha")  # (checked here: backward() must not fail half-way)
             elif node.op == "call_method":
                 if node.target not in ("view", "reshape", "flatten", "relu", "tanh", "sigmoid", "contiguous", "size",
                                        "mean"):
@@ -254,11 +256,25 @@ class SeedBatchedSweep:
         return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
 
     @staticmethod
-    def _avgpool_vjp(g, in_shape, kernel, stride, padding, SB):
+    def _avgpool_vjp(g, in_shape, kernel, stride, padding, SB, ceil_mode=False, count_include_pad=True,
+                     divisor_override=None):
+        """VJP of ``avg_pool2d`` for the whole seed batch: non-overlapping, unpadded windows that tile the input are an
+        upsampling; every other geometry (padding, overlap, ragged edges, ceil_mode) goes through the pooling
+        operator's own backward, which needs the input only for its shape."""
         k, st = SeedBatchedSweep._pair2(kernel), SeedBatchedSweep._pair2(kernel if stride in (None, []) else stride)
-        if SeedBatchedSweep._pair2(padding) != (0, 0) or k != st or in_shape[-2] % k[0] or in_shape[-1] % k[1]:
-            raise SweepUnsupported("AvgPool2d VJP implemented for non-overlapping, unpadded windows")
-        return g.repeat_interleave(k[0], -2).repeat_interleave(k[1], -1) / (k[0] * k[1])
+        if (SeedBatchedSweep._pair2(padding) == (0, 0) and k == st and in_shape[-2] % k[0] == 0
+                and in_shape[-1] % k[1] == 0 and divisor_override is None):
+            return g.repeat_interleave(k[0], -2).repeat_interleave(k[1], -1) / (k[0] * k[1])
+        dummy = g.new_empty((SB,) + tuple(in_shape[1:]))
+        return torch.ops.aten.avg_pool2d_backward(g.contiguous(), dummy, list(k), list(st),
+                                                  list(SeedBatchedSweep._pair2(padding)), bool(ceil_mode),
+                                                  bool(count_include_pad), divisor_override)
+
+    @staticmethod
+    def _adaptive_avgpool_vjp(g, in_shape, SB):
+        if tuple(g.shape[-2:]) == (1, 1):
+            return (g / (in_shape[-1] * in_shape[-2])).expand(SB, *in_shape[1:])
+        return torch.ops.aten._adaptive_avg_pool2d_backward(g.contiguous(), g.new_empty((SB,) + tuple(in_shape[1:])))
 
     @staticmethod
     def _maxpool_vjp(g, idx, in_shape, S, B):
@@ -462,12 +478,10 @@ class SeedBatchedSweep:
                 elif isinstance(m, nn.Flatten):
                     push(src, g.reshape((S * B,) + tuple(self.saved[node][1:])))
                 elif isinstance(m, nn.AdaptiveAvgPool2d):
-                    shp = self.saved[node]
-                    if tuple(g.shape[-2:]) != (1, 1):
-                        raise SweepUnsupported("AdaptiveAvgPool2d VJP implemented for output size 1")
-                    push(src, (g / (shp[-1] * shp[-2])).expand(S * B, *shp[1:]))
+                    push(src, self._adaptive_avgpool_vjp(g, self.saved[node], S * B))
                 elif isinstance(m, nn.AvgPool2d):
-                    push(src, self._avgpool_vjp(g, self.saved[node], m.kernel_size, m.stride, m.padding, S * B))
+                    push(src, self._avgpool_vjp(g, self.saved[node], m.kernel_size, m.stride, m.padding, S * B,
+                                                m.ceil_mode, m.count_include_pad, m.divisor_override))
                 elif isinstance(m, nn.MaxPool2d):
                     idx, shp = self.saved[node]
                     push(src, self._maxpool_vjp(g, idx, shp, S, B))
@@ -489,13 +503,13 @@ class SeedBatchedSweep:
                     idx, shp = self.saved[node]
                     push(node.args[0], self._maxpool_vjp(g, idx, shp, S, B))
                 elif t is F.avg_pool2d:
-                    p = self._bind(node, ("kernel_size", "stride", "padding"), (None, None, 0))
-                    push(node.args[0], self._avgpool_vjp(g, self.saved[node], p["kernel_size"], p["stride"], p["padding"], S * B))
+                    p = self._bind(node, ("kernel_size", "stride", "padding", "ceil_mode", "count_include_pad",
+                                          "divisor_override"), (None, None, 0, False, True, None))
+                    push(node.args[0], self._avgpool_vjp(g, self.saved[node], p["kernel_size"], p["stride"], p["padding"],
+                                                         S * B, p["ceil_mode"], p["count_include_pad"],
+                                                         p["divisor_override"]))
                 elif t is F.adaptive_avg_pool2d:
-                    shp = self.saved[node]
-                    if tuple(g.shape[-2:]) != (1, 1):
-                        raise SweepUnsupported("adaptive_avg_pool2d VJP implemented for output size 1")
-                    push(node.args[0], (g / (shp[-1] * shp[-2])).expand(S * B, *shp[1:]))
+                    push(node.args[0], self._adaptive_avgpool_vjp(g, self.saved[node], S * B))
                 elif t is torch.mean:
                     push(node.args[0], self._mean_vjp(g, self.saved[node], S * B))
             elif node.op == "call_method":

@@ -455,3 +455,31 @@ def posterior_covariance_full(H: torch.Tensor, prior_prec_diag: torch.Tensor, h_
     through a Cholesky-based scale; the inverse is the same matrix)."""
     Pm = h_factor * H + torch.diag(prior_prec_diag)
     return torch.linalg.inv(Pm)
+
+
+def krondecomposed_inv_square_form_blocks(eigvecs, eigvals, deltas, W: torch.Tensor, damping: bool = False):
+    """``W P^{-1} W^T`` per batch item WITHOUT the dense ``P x P`` matrix — what the reference itself evaluates
+    (utils/matrix.py:406-461): per Kronecker block the slice ``W_p [B*K, p_in, p_out]`` is rotated into the
+    eigenbasis (``Q1^T W_p Q2``), weighted by ``(l1 (x) l2 + delta)^-1`` and contracted with the rotated slice
+    again (rotating back and contracting with ``W_p`` is the same number because ``Q1``, ``Q2`` are orthogonal).
+    Needed where ``krondecomposed_inv_square_form``'s dense route cannot be held (ResNet-18: P = 11.2 M).
+    Device-agnostic: runs where ``W`` lives."""
+    B, K, P = W.shape
+    deltas = _expand_deltas(deltas, len(eigvals), W.dtype).to(W.device)
+    out = torch.zeros(B, K, K, dtype=W.dtype, device=W.device)
+    off = 0
+    for Qs, ls, d in zip(eigvecs, eigvals, deltas):
+        lam = _block_eigvals(ls, d, damping)
+        if len(ls) == 1:
+            p = ls[0].numel()
+            R = W[:, :, off:off + p] @ Qs[0]                       # [B, K, p]
+            out += torch.einsum("bkp,p,bcp->bkc", R, 1.0 / lam, R)
+        else:
+            p_in, p_out = ls[0].numel(), ls[1].numel()
+            p = p_in * p_out
+            Wp = W[:, :, off:off + p].reshape(B * K, p_in, p_out)
+            R = (Qs[0].T @ Wp @ Qs[1]).reshape(B, K, p)
+            out += torch.einsum("bkp,p,bcp->bkc", R, 1.0 / lam.reshape(-1), R)
+        off += p
+    assert off == P
+    return out

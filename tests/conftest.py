@@ -16,6 +16,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """`gpu` tests need a ROCm device: skip them (instead of failing) on a machine without one, so that a plain
+    `pytest` is green on a CPU-only box.  On a GPU box they always run — a missing liblaplace_hip.so must FAIL there."""
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="needs a ROCm device (MI355X)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(autouse=True)
 def _default_dtype():
     torch.set_default_dtype(torch.float32)

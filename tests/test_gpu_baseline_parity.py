@@ -1,0 +1,275 @@
+"""HIP path vs the fp64 oracle at the REAL BASELINE.json shapes (-m gpu): c1 MLP 1-50-1 (diag / kron / full + GLM
+predictive), c2 LeNet-5 (KFAC factors + Kron predictive), c3 ResNet-18 last layer (dense GGN + predictive), c4
+ResNet-18 full network (every KFAC factor + Kron predictive; ReLU and tanh).  Tolerance everywhere: 1e-4 relative to
+the largest magnitude of the expected tensor (BASELINE.json north_star), fp32 kernels vs fp64 truth.
+
+The oracle (oracle/curvature_oracle.py) follows the reference call for call (curvlinops.py:46-108, curvature.py:88-433,
+utils/matrix.py:123-150,406-461, baselaplace.py:1683-1684,1834-1835,2113-2115); it runs on the host in fp64, batches are
+sized so that it finishes in seconds.  The one exception is the dense linear algebra of c4's predictive oracle
+(`torch.linalg.eigh` of the fp64 oracle factors up to 4608^2, and the block rotations of matrix.py:406-461), which is
+evaluated by the same oracle functions with their fp64 tensors placed on the device: library fp64 math, none of our
+kernels.  Mirrors tests/test_curv_backends_curvlinops.py:144-155,207-305 and tests/test_baselaplace.py:334-410 of the
+reference."""
+import copy
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL = 1e-4
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return (a - b).abs().max().item() / (b.abs().max().item() + 1e-300)
+
+
+def _oracle():
+    from oracle import curvature_oracle as co
+
+    return co
+
+
+def _pair(model32):
+    """(fp32 model on the device, fp64 copy on the host) with identical weights"""
+    m64 = copy.deepcopy(model32).double().cpu().eval()
+    return model32.to(DEV).eval(), m64
+
+
+def _assert_kfacs(kron, kf_ref, what):
+    assert len(kron.kfacs) == len(kf_ref), what
+    for i, (F_, G_) in enumerate(zip(kron.kfacs, kf_ref)):
+        assert len(F_) == len(G_)
+        for j, (a, b) in enumerate(zip(F_, G_)):
+            assert tuple(a.shape) == tuple(b.shape)
+            assert rel(a, b) < TOL, f"{what}: block {i} factor {j} (n={a.shape[0]}) rel {rel(a, b):.2e}"
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# c1: MLP 1-50-1, regression, N = 1000, batch 100 (examples/regression_example.py of the reference)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def c1():
+    from laplace_amd.nets import mlp_1_50_1
+
+    torch.manual_seed(711)
+    model = mlp_1_50_1()
+    torch.manual_seed(711)
+    X = 8 * torch.rand(1000, 1)
+    y = torch.sin(X) + 0.3 * torch.randn(1000, 1)
+    m32, m64 = _pair(model)
+    return m32, m64, X, y
+
+
+def test_c1_mlp_diag_kron_full_fit_against_the_oracle(c1):
+    from laplace_amd import HipGGN
+
+    co = _oracle()
+    m32, m64, X, y = c1
+    N = 1000
+    b = HipGGN(m32, "regression")
+    loss_d = loss_k = loss_f = 0.0
+    h = H = kron = None
+    for i in range(0, N, 100):
+        xb, yb = X[i:i + 100].to(DEV), y[i:i + 100].to(DEV)
+        l1, hb = b.diag(xb, yb, N=N)
+        l2, kb = b.kron(xb, yb, N=N)
+        l3, Hb = b.full(xb, yb, N=N)
+        h = hb if h is None else h + hb
+        H = Hb if H is None else H + Hb
+        kron = kb if kron is None else kron + kb
+        loss_d, loss_k, loss_f = loss_d + l1, loss_k + l2, loss_f + l3
+    X64, y64 = X.double(), y.double()
+    Js, f = co.jacobians(m64, X64)
+    Hl = co.functional_hessian(f, "regression")
+    assert rel(h, co.ggn_diag(Js, Hl)) < TOL
+    assert rel(H, co.ggn_full(Js, Hl)) < TOL
+    loss_ref = co.loss_sum(f, y64, "regression")  # = factor * sum (f - y)^2 (curvature.py:63-72, factor 1/2)
+    kf_ref, loss_kf = None, 0.0
+    for i in range(0, N, 100):
+        lb, kb = co.kfac_ggn(m64, X64[i:i + 100], y64[i:i + 100], N, "regression")
+        kf_ref = kb if kf_ref is None else co.kron_add(kf_ref, kb)
+        loss_kf = loss_kf + lb
+    for l_ in (loss_d, loss_k, loss_f):
+        assert rel(l_, loss_kf) < TOL
+    assert rel(loss_kf, loss_ref) < 1e-10
+    # stored factors carry the scalar split of utils/matrix.py:100-118 on both sides alike
+    _assert_kfacs(kron, kf_ref, "c1")
+    assert rel(kron.diag(), co.kron_diag(kf_ref)) < TOL
+
+
+def test_c1_mlp_glm_predictive_diag_kron_full_against_the_oracle(c1):
+    from laplace_amd.laplace import HipLaplace
+
+    co = _oracle()
+    m32, m64, X, y = c1
+    N = 1000
+
+    class L(list):
+        dataset = list(range(N))
+
+    loader = L([(X[i:i + 100], y[i:i + 100]) for i in range(0, N, 100)])
+    X64, y64 = X.double(), y.double()
+    Js, f = co.jacobians(m64, X64)
+    Hl = co.functional_hessian(f, "regression")
+    Xt = torch.linspace(-1, 9, 100).reshape(-1, 1)
+    Jt, ft = co.jacobians(m64, Xt.double())
+    # a posterior precision of moderate condition number (~1e3): fp32 storage of H alone (1.7e-7 relative) moves a
+    # variance by cond x 1.7e-7, so a 1e-4 bar on f_var is only meaningful where cond << 1e3 / 1.7e-7 x 1e-4
+    prior, sigma = 30.0, 1.0
+    hf = 1.0 / sigma ** 2
+    P = Js.shape[-1]
+    # diag
+    la = HipLaplace(m32, "regression", "all", "diag", prior_precision=prior, sigma_noise=sigma)
+    la.fit(loader)
+    f_mu, f_var = la._glm_predictive_distribution(Xt.to(DEV))
+    want = co.functional_variance_diag(Jt, 1.0 / (hf * co.ggn_diag(Js, Hl) + prior))
+    assert rel(f_mu, ft) < TOL and rel(f_var, want) < TOL
+    # full
+    la = HipLaplace(m32, "regression", "all", "full", prior_precision=prior, sigma_noise=sigma)
+    la.fit(loader)
+    _, f_var = la._glm_predictive_distribution(Xt.to(DEV))
+    Sigma = co.posterior_covariance_full(co.ggn_full(Js, Hl), torch.full((P,), prior, dtype=torch.float64), hf)
+    assert rel(f_var, co.functional_variance_full(Jt, Sigma)) < TOL
+    # kron (eigendecomposition on the device, lk_syevj)
+    la = HipLaplace(m32, "regression", "all", "kron", prior_precision=prior, sigma_noise=sigma)
+    la.fit(loader)
+    _, f_var = la._glm_predictive_distribution(Xt.to(DEV))
+    kf_ref = None
+    for i in range(0, N, 100):
+        _, kb = co.kfac_ggn(m64, X64[i:i + 100], y64[i:i + 100], N, "regression")
+        kf_ref = kb if kf_ref is None else co.kron_add(kf_ref, kb)
+    Qs, ls = co.kron_decompose(kf_ref)
+    assert rel(f_var, co.functional_variance_kron(Jt, Qs, ls, prior, hf)) < TOL
+    # marginal likelihood pieces: log det of the posterior precision
+    assert rel(la.posterior_precision.logdet(), co.krondecomposed_logdet(co.krondecomposed_scale(ls, hf), prior)) < TOL
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# c2: LeNet-5 on 3x32x32, classification, KFAC exact GGN (batch 16 for the oracle)
+# ---------------------------------------------------------------------------------------------------------------
+def test_c2_lenet5_kfac_factors_and_kron_predictive_against_the_oracle():
+    from laplace_amd import HipGGN
+    from laplace_amd import predictive as Pr
+    from laplace_amd.nets import lenet5
+
+    co = _oracle()
+    torch.manual_seed(711)
+    m32, m64 = _pair(lenet5())
+    g = torch.Generator().manual_seed(711)
+    X = torch.randn(16, 3, 32, 32, generator=g)
+    y = torch.randint(10, (16,), generator=g)
+    N = 10_000
+    b = HipGGN(m32, "classification")
+    loss, kron = b.kron(X.to(DEV), y.to(DEV), N=N)
+    loss_ref, kf_ref = co.kfac_ggn(m64, X.double(), y, N, "classification")
+    assert rel(loss, loss_ref) < TOL
+    _assert_kfacs(kron, kf_ref, "c2")
+    # fused accumulator == literal call
+    acc = b.kron_accumulator(N)
+    acc.add_batch(X.to(DEV), y.to(DEV))
+    _, kron2 = acc.finalize()
+    _assert_kfacs(kron2, kf_ref, "c2 fused")
+    # Kron GLM predictive (Jacobian-free kernels) vs matrix.py:406-461 on the oracle's Jacobians and fp64 eigenpairs
+    dec = kron.decompose()
+    dec.check_converged()
+    hf, prior = 25.0, 3.0
+    post = dec * hf + torch.tensor(prior, device=DEV)
+    Xt = X[:8]
+    f_mu, f_var = Pr.glm_variance_kron(b, Xt.to(DEV), post)
+    Jt, ft = co.jacobians(m64, Xt.double())
+    Qs, ls = co.kron_decompose(kf_ref)
+    want = co.krondecomposed_inv_square_form_blocks(Qs, co.krondecomposed_scale(ls, hf), prior, Jt)
+    assert Jt.shape[-1] == 62006
+    assert rel(f_mu, ft) < TOL
+    assert rel(f_var, want) < TOL
+    # diagonal GGN of the same batch (D1)
+    _, h = b.diag(X.to(DEV), y.to(DEV))
+    Js, f = co.jacobians(m64, X.double())
+    assert rel(h, co.ggn_diag(Js, co.functional_hessian(f, "classification"))) < TOL
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# c3: ResNet-18 backbone, last-layer dense GGN (P = 5130) + GLM predictive
+# ---------------------------------------------------------------------------------------------------------------
+def test_c3_resnet18_last_layer_dense_ggn_and_predictive_against_the_oracle():
+    from laplace_amd.laplace import HipLaplace
+    from laplace_amd.nets import ResNet18
+
+    co = _oracle()
+    torch.manual_seed(711)
+    # tanh: the fp32 device forward and the fp64 host forward of the backbone are two executions (see nets.py)
+    m32, m64 = _pair(ResNet18(10, act=torch.tanh))
+    g = torch.Generator().manual_seed(3)
+    X = torch.randn(48, 3, 32, 32, generator=g)
+    y = torch.randint(10, (48,), generator=g)
+    N = 50_000
+
+    class L(list):
+        dataset = list(range(N))
+
+    la = HipLaplace(m32, "classification", "last_layer", "full", last_layer_name="fc", prior_precision=1.5)
+    la.fit(L([(X[:32], y[:32]), (X[32:], y[32:])]))
+    feats = {}
+    h = m64.fc.register_forward_hook(lambda m, i, o: feats.__setitem__("phi", i[0].detach()))
+    with torch.no_grad():
+        f = m64(X.double())
+    h.remove()
+    Js = co.last_layer_jacobians(feats["phi"], 10, bias=True)
+    H_ref = co.ggn_full(Js, co.functional_hessian(f, "classification"))
+    assert la.H.shape == (5130, 5130)
+    assert rel(la.H, H_ref) < TOL
+    assert rel(la.loss, co.loss_sum(f, y, "classification")) < TOL
+    f_mu, f_var = la._glm_predictive_distribution(X[:16].to(DEV))
+    Sigma = co.posterior_covariance_full(H_ref, torch.full((5130,), 1.5, dtype=torch.float64), 1.0)
+    assert rel(f_mu, f[:16]) < TOL
+    assert rel(f_var, co.functional_variance_full(Js[:16], Sigma)) < TOL
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# c4: ResNet-18 full-network KFAC exact GGN: every factor + the Kron predictive
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("act", ["relu", "tanh"])
+def test_c4_resnet18_every_kfac_factor_and_kron_predictive_against_the_oracle(act):
+    from laplace_amd import HipGGN
+    from laplace_amd import predictive as Pr
+    from laplace_amd.nets import ResNet18
+
+    co = _oracle()
+    torch.manual_seed(711)
+    m32, m64 = _pair(ResNet18(10, act=torch.relu if act == "relu" else torch.tanh))
+    g = torch.Generator().manual_seed(11)
+    B = 8
+    X = torch.randn(B, 3, 32, 32, generator=g)
+    y = torch.randint(10, (B,), generator=g)
+    N = 50_000
+    b = HipGGN(m32, "classification")
+    loss, kron = b.kron(X.to(DEV), y.to(DEV), N=N)                       # the drop-in call (literal loop)
+    acc = b.kron_accumulator(N)                                          # the fused accumulator of the bench
+    acc.add_batch(X.to(DEV), y.to(DEV))
+    loss2, kron2 = acc.finalize()
+    loss_ref, kf_ref = co.kfac_ggn(m64, X.double(), y, N, "classification")
+    assert len(kf_ref) == 22
+    assert rel(loss, loss_ref) < TOL and rel(loss2, loss_ref) < TOL
+    # ReLU: individual gradients may flip where a pre-activation sits within fp32 rounding of zero; the
+    # factors — sums over 8 x 9 x L outer products — still agree to the bar
+    _assert_kfacs(kron, kf_ref, f"c4/{act}")
+    _assert_kfacs(kron2, kf_ref, f"c4/{act} fused")
+    # GLM predictive under this posterior: device eigendecomposition + Jacobian-free quadratic-form kernels vs the
+    # oracle's Jacobians (host, fp64) pushed through matrix.py:406-461 with fp64 eigenpairs of the ORACLE's factors
+    dec = kron.decompose()
+    dec.check_converged()
+    hf, prior = float(N) / B, 1.0                                         # curvature and prior of comparable size
+    post = dec * hf + torch.tensor(prior, device=DEV)
+    Xt = X[:2]
+    f_mu, f_var = Pr.glm_variance_kron(b, Xt.to(DEV), post)
+    Jt, ft = co.jacobians(m64, Xt.double())
+    assert Jt.shape[-1] == 11_164_362
+    kf_dev = [[M.to(DEV) for M in F_] for F_ in kf_ref]
+    Qs, ls = co.kron_decompose(kf_dev)                                     # fp64 torch.linalg.eigh (library math)
+    want = co.krondecomposed_inv_square_form_blocks(Qs, co.krondecomposed_scale(ls, hf), prior, Jt.to(DEV))
+    assert rel(f_mu, ft) < TOL
+    assert rel(f_var, want) < TOL, f"c4/{act} f_var rel {rel(f_var, want):.2e}"
+    assert math.isfinite(float(post.logdet()))

@@ -342,3 +342,30 @@ def test_seed_chunking_for_many_output_models():
         assert torch.allclose(b.jacobians(X)[0], J0, rtol=1e-4, atol=1e-6)
     finally:
         _lib.set_kernels_for_testing(prev)
+
+
+@pytest.mark.parametrize("pool", [nn.AvgPool2d(3, 2, 1), nn.AvgPool2d(2, 2, 0, ceil_mode=True), nn.AvgPool2d(3, 1),
+                                  nn.AdaptiveAvgPool2d(2), nn.AvgPool2d(3, 2, 1, count_include_pad=False)])
+def test_general_avgpool_geometries_go_through_the_sweep(pool):
+    """Padded / overlapping / ragged average pooling (and adaptive pooling to more than one cell) used to raise
+    SweepUnsupported from INSIDE backward(), i.e. after the forward had succeeded and with no fallback left."""
+    torch.manual_seed(0)
+    model = nn.Sequential(nn.Conv2d(2, 4, 3, padding=1), nn.ReLU(), pool, nn.Flatten(), nn.LazyLinear(3)).double().eval()
+    x = torch.randn(5, 2, 7, 7, dtype=torch.float64)
+    model(x)
+    taps = {n: m for n, m in model.named_modules() if isinstance(m, (nn.Conv2d, nn.Linear))}
+    sw = SeedBatchedSweep(model, taps)
+    f = sw.forward(x)
+    seeds = torch.randn(3, 5, 3, dtype=torch.float64)
+    got = sw.backward(seeds)
+    # reference: one autograd pass per seed
+    outs = {}
+    hs = [m.register_forward_hook(lambda m_, i, o, n=n: outs.__setitem__(n, o)) for n, m in taps.items()]
+    f2 = model(x)
+    for h in hs:
+        h.remove()
+    assert torch.allclose(f, f2)
+    for s in range(3):
+        grads = torch.autograd.grad(f2, [outs[n] for n in taps], grad_outputs=seeds[s], retain_graph=True)
+        for n, g in zip(taps, grads):
+            assert torch.allclose(got[n][s], g, atol=1e-12), n
