@@ -150,6 +150,38 @@ int lk_symmetrize_f32(float* C, int64_t n, void* stream);
 int lk_permute_sym_f32(const float* src, int64_t Cin, int64_t KK, float* dst, int accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Convolution of the seed-batched reverse sweep (csrc/lk_conv.hip): implicit GEMM on NHWC tensors, fp32-level
+ * products from two-piece fp16 operands (three v_mfma_f32_32x32x16_f16 per fp32 product block).
+ * Replaces the backward-data convolutions inside the C reverse passes of curvlinops' KFACLinearOperator._compute_kfac
+ * as driven by CurvlinopsInterface.kron (laplace/curvature/curvlinops.py:87-100); the same GEMM is the forward conv.
+ *
+ * A "split tensor" is a pair of fp16 planes (h, l) of the tensor's layout plus a device int `sexp`:
+ *     x * 2^sexp = h + l (+ e, |e| <= max(2^-22 |x 2^sexp|, 2^-25)),   max|x| * 2^sexp < 2^15.
+ * ------------------------------------------------------------------------------------------- */
+/* out[0] = bit pattern of max_i |x[i] * cscale[(i / inner) % C]| (cscale may be NULL); deterministic. */
+int lk_absmax_f32(const float* x, int64_t n, const float* cscale, int64_t inner, int64_t C, unsigned* out, void* stream);
+/* fp32 -> split tensor; the scale comes from the DEVICE value amax[0] * bound_mul (any upper bound of max|x|).
+ * n % 8 == 0. */
+int lk_split_f16x2(const float* x, int64_t n, const float* amax, float bound_mul, void* planes_h, void* planes_l,
+                   int* sexp, void* stream);
+/* W[Co][Ci][taps] (* cscale[co], e.g. a folded BatchNorm scale) -> planes[2][taps][N][K] fp16 + sexp;
+ * transpose = 1 (backward-data): n = ci, k = co; 0 (forward): n = co, k = ci.  amax_ws: one device word. */
+int lk_conv_prep_weights_f16x2(const float* W, int64_t Co, int64_t Ci, int64_t taps, int transpose, const float* cscale,
+                               unsigned* amax_ws, void* planes, int* sexp, void* stream);
+/* One launch of the implicit GEMM
+ *     out[n][i*out_step + oh0][j*out_step + ow0][co] (+)= sum_t sum_c in[n][i*in_mul + dh_t][j*in_mul + dw_t][c] * Wt[wt_t][co][c]
+ * for i < Hc, j < Wc (taps outside the [Hi][Wi] image contribute zero).  in: split tensor [N][Hi][Wi][Ci], Ci % 32 == 0;
+ * w: split planes [.][Co][Ci]; taps: T x {dh, dw, wt} (T <= 9, host array); zero16: >= 16 zero bytes on the device;
+ * out: fp32 [N][Ho][Wo][Co]; accumulate != 0 adds into out; amax_out (may be NULL): atomicMax of the bit patterns of
+ * |out| (zero it first).  Stride-1 backward-data and forward convs are one launch, a stride-s backward-data is one
+ * launch per output-pixel residue class.  config bit 0: 64-deep K chunks. */
+int lk_conv_nhwc_f16x2(const void* in_h, const void* in_l, const int* in_sexp, int64_t N, int64_t Hi, int64_t Wi,
+                       int64_t Ci, const void* w_h, const void* w_l, const int* w_sexp, int64_t Co, int64_t Hc,
+                       int64_t Wc, int64_t in_mul, int64_t Ho, int64_t Wo, int64_t out_step, int64_t oh0, int64_t ow0,
+                       int64_t T, const int* taps, const void* zero16, float* out, int accumulate, unsigned* amax_out,
+                       int config, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Diagonal GGN / EF.  Replaces GGNInterface.diag / EFInterface.diag (curvature.py:413-433,494-505)
  * for nn.Linear layers:  h_w[o][i] += alpha * sum_n (sum_c g[c][n][o]^2) a[n][i]^2,
  *                        h_b[o]    += alpha * sum_n  sum_c g[c][n][o]^2          (h_b may be NULL)

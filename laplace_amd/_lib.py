@@ -56,6 +56,11 @@ SIGNATURES = {
     "lk_conv3x3_pixpair_accumulate_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _f32, _vp, _vp, _i64, _vp]),
     "lk_conv3x3_pixpair_assemble_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _f32, _vp, _vp]),
     "lk_nchw_to_nhwc_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
+    "lk_absmax_f32": (_int, [_vp, _i64, _vp, _i64, _i64, _vp, _vp]),
+    "lk_split_f16x2": (_int, [_vp, _i64, _vp, _f32, _vp, _vp, _vp, _vp]),
+    "lk_conv_prep_weights_f16x2": (_int, [_vp, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp]),
+    "lk_conv_nhwc_f16x2": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64,
+                                  _i64, _i64, _i64, _i64, _vp, _vp, _vp, _int, _vp, _int, _vp]),
     "lk_symmetrize_f32": (_int, [_vp, _i64, _vp]),
     "lk_permute_sym_f32": (_int, [_vp, _i64, _i64, _vp, _int, _vp]),
     "lk_diag_ggn_linear_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp, _vp, _vp]),
@@ -91,6 +96,23 @@ SIGNATURES = {
 
 class LaplaceHipError(RuntimeError):
     pass
+
+
+class SplitTensor:
+    """Two fp16 planes ``planes[0] + planes[1] ~= x * 2**sexp`` of a tensor (include/laplace_hip.h, lk_split_f16x2)."""
+
+    __slots__ = ("planes", "sexp")
+
+    def __init__(self, planes: torch.Tensor, sexp: torch.Tensor):
+        self.planes, self.sexp = planes, sexp
+
+    @property
+    def shape(self):
+        return self.planes.shape[1:]
+
+    def float(self) -> torch.Tensor:
+        """fp32 reconstruction (tests / fallbacks)"""
+        return (self.planes[0].float() + self.planes[1].float()) * torch.exp2(-self.sexp.float())
 
 
 def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
@@ -131,6 +153,7 @@ class HipKernels:
     """Tensor-level wrappers; every method enqueues on torch's current stream and returns at once."""
 
     name = "hip"
+    conv_config = int(os.environ.get("LK_CONV_CONFIG", "0"))  # bit 0: 64-deep K chunks in lk_conv_nhwc_f16x2
     softmax_chol_max_c = 2000  # LK_SOFTMAX_CHOL_MAX_C (include/laplace_hip.h): wider outputs use the symmetric root
 
     def __init__(self, lib: Optional[ctypes.CDLL] = None):
@@ -283,6 +306,69 @@ class HipKernels:
         if B:
             self._rc(self.lib.lk_nchw_to_nhwc_f32(_ptr(x), B, C, H * W, _ptr(out), self._stream(x.device)),
                      "lk_nchw_to_nhwc_f32")
+        return out
+
+    # ---- split-fp16 convolution (lk_conv.hip) ---------------------------------------------------------
+    def absmax(self, x, out=None):
+        """device word holding the bit pattern of ``max |x|`` (a [1] float32 tensor: the bits ARE that float)"""
+        _check(x, "x")
+        if out is None:
+            out = torch.empty(1, dtype=torch.float32, device=x.device)
+        self._rc(self.lib.lk_absmax_f32(_ptr(x), x.numel(), None, 1, 1, _ptr(out), self._stream(x.device)), "lk_absmax_f32")
+        return out
+
+    def split_f16x2(self, x, amax=None, bound_mul=1.0):
+        """fp32 tensor -> :class:`SplitTensor` of the same shape (scale from ``amax[0] * bound_mul``, measured if absent)"""
+        _check(x, "x")
+        if x.numel() % 8:
+            raise LaplaceHipError("split_f16x2: numel % 8 != 0")
+        if amax is None:
+            amax = self.absmax(x)
+        planes = torch.empty((2,) + tuple(x.shape), dtype=torch.float16, device=x.device)
+        sexp = torch.empty(1, dtype=torch.int32, device=x.device)
+        self._rc(self.lib.lk_split_f16x2(_ptr(x), x.numel(), _ptr(amax), float(bound_mul), _ptr(planes[0]), _ptr(planes[1]),
+                                         _ptr(sexp), self._stream(x.device)), "lk_split_f16x2")
+        return SplitTensor(planes, sexp)
+
+    def conv_prep_weights(self, W, transpose, cscale=None):
+        """conv weight ``[Co, Ci, KH, KW]`` -> (planes ``[2, T, N, K]`` fp16, sexp); see lk_conv_prep_weights_f16x2"""
+        _check(W, "W")
+        Co, Ci = W.shape[0], W.shape[1]
+        T = W[0, 0].numel()
+        N, Kd = (Ci, Co) if transpose else (Co, Ci)
+        planes = torch.empty(2, T, N, Kd, dtype=torch.float16, device=W.device)
+        sexp = torch.empty(1, dtype=torch.int32, device=W.device)
+        ws = torch.empty(1, dtype=torch.int32, device=W.device)
+        if cscale is not None:
+            _check(cscale, "cscale")
+        self._rc(self.lib.lk_conv_prep_weights_f16x2(_ptr(W), Co, Ci, T, 1 if transpose else 0, _ptr(cscale), _ptr(ws),
+                                                     _ptr(planes), _ptr(sexp), self._stream(W.device)),
+                 "lk_conv_prep_weights_f16x2")
+        return planes, sexp
+
+    def _zero16(self, dev):
+        z = self._zeros.get(dev.index) if hasattr(self, "_zeros") else None
+        if z is None:
+            if not hasattr(self, "_zeros"):
+                self._zeros = {}
+            z = self._zeros[dev.index] = torch.zeros(64, dtype=torch.uint8, device=dev)
+        return z
+
+    def conv_nhwc_f16x2(self, x, wplanes, wsexp, Hc, Wc, in_mul, out, out_step, oh0, ow0, taps, accumulate=False,
+                        amax_out=None, config=None):
+        """one launch of lk_conv_nhwc_f16x2; ``x``: SplitTensor [N, Hi, Wi, Ci]; ``wplanes`` [2, T, Co, Ci];
+        ``out`` fp32 [N, Ho, Wo, Co]; ``taps``: list of (dh, dw, weight slice)"""
+        N, Hi, Wi, Ci = x.planes.shape[1:]
+        _check(out, "out")
+        Co = wplanes.shape[2]
+        assert wplanes.shape[3] == Ci and out.shape[0] == N and out.shape[3] == Co
+        flat = (ctypes.c_int * (3 * len(taps)))(*[int(v) for t in taps for v in t])
+        cfg = self.conv_config if config is None else config
+        self._rc(self.lib.lk_conv_nhwc_f16x2(_ptr(x.planes[0]), _ptr(x.planes[1]), _ptr(x.sexp), N, Hi, Wi, Ci,
+                                             _ptr(wplanes[0]), _ptr(wplanes[1]), _ptr(wsexp), Co, Hc, Wc, in_mul,
+                                             out.shape[1], out.shape[2], out_step, oh0, ow0, len(taps), flat,
+                                             _ptr(self._zero16(out.device)), _ptr(out), 1 if accumulate else 0,
+                                             _ptr(amax_out), int(cfg), self._stream(out.device)), "lk_conv_nhwc_f16x2")
         return out
 
     def gram_conv(self, x, kernel_size, stride, padding, dilation, alpha, out, upper_only=False, native=False):

@@ -1,0 +1,106 @@
+"""Host side of the split-fp16 convolution kernels (csrc/lk_conv.hip): tap tables and launch plans for the
+backward-data and forward forms of an ``nn.Conv2d`` on NHWC tensors.
+
+The reverse passes of curvlinops' KFAC (laplace/curvature/curvlinops.py:87-100) are, for a convolution layer,
+backward-data convolutions of the output cotangent; the seed-batched sweep (laplace_amd/sweep.py) runs them for all
+seeds at once through :func:`conv_backward_data`.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from laplace_amd._lib import SplitTensor, get_kernels
+
+
+def supported(m: nn.Conv2d) -> bool:
+    """what the implicit-GEMM kernel covers: dense (groups = 1), undilated, zero padding, at most 9 taps, both channel
+    counts multiples of 32 (a lane of the 16-bit MFMA reads 8 consecutive channels; K chunks are 32 deep)"""
+    return (isinstance(m, nn.Conv2d) and m.groups == 1 and tuple(m.dilation) == (1, 1) and not isinstance(m.padding, str)
+            and m.padding_mode == "zeros" and m.kernel_size[0] * m.kernel_size[1] <= 9
+            and m.in_channels % 32 == 0 and m.out_channels % 32 == 0 and m.stride[0] == m.stride[1])
+
+
+class PreparedConv:
+    """Split, tap-major copies of a conv weight for the two GEMM forms; rebuilt when the weight (or the per-output-channel
+    scale folded into it, e.g. a deferred BatchNorm scale) changes."""
+
+    def __init__(self, m: nn.Conv2d):
+        self.m = m
+        self._bwd = None  # (key, planes, sexp)
+        self._fwd = None
+
+    def _key(self, cscale):
+        w = self.m.weight
+        return (w._version, w.data_ptr(), None if cscale is None else (cscale._version, cscale.data_ptr()))
+
+    def backward_planes(self, cscale=None):
+        key = self._key(cscale)
+        if self._bwd is None or self._bwd[0] != key:
+            planes, sexp = get_kernels().conv_prep_weights(self.m.weight.detach().contiguous(), True, cscale)
+            self._bwd = (key, planes, sexp)
+        return self._bwd[1], self._bwd[2]
+
+    def forward_planes(self):
+        key = self._key(None)
+        if self._fwd is None or self._fwd[0] != key:
+            planes, sexp = get_kernels().conv_prep_weights(self.m.weight.detach().contiguous(), False, None)
+            self._fwd = (key, planes, sexp)
+        return self._fwd[1], self._fwd[2]
+
+
+def backward_plan(m: nn.Conv2d, Hin: int, Win: int):
+    """Launches of the backward-data of ``m`` for an input of ``Hin x Win`` pixels: one per residue class
+    ``(h % s, w % s)`` of the input-gradient pixels, ``(Hc, Wc, oh0, ow0, taps)`` with ``taps = [(dh, dw, slice)]``:
+    ``dX[i*s + oh0, j*s + ow0] = sum_taps g[i + dh, j + dw] W[:, :, kh, kw]``, where ``kh = oh0 + p - dh*s``."""
+    s, (ph, pw), (KH, KW) = m.stride[0], m.padding, m.kernel_size
+    plans = []
+    for rh in range(min(s, Hin)):
+        for rw in range(min(s, Win)):
+            taps = []
+            for kh in range(KH):
+                if (rh + ph - kh) % s:
+                    continue
+                for kw in range(KW):
+                    if (rw + pw - kw) % s:
+                        continue
+                    taps.append(((rh + ph - kh) // s, (rw + pw - kw) // s, kh * KW + kw))
+            plans.append(((Hin - rh + s - 1) // s, (Win - rw + s - 1) // s, rh, rw, taps))
+    return plans
+
+
+def conv_backward_data(prep: PreparedConv, g: SplitTensor, in_hw, cscale=None, out=None, accumulate=False, amax_out=None):
+    """``dX [N, Hin, Win, Cin]`` (fp32, NHWC) of ``prep.m`` from the split output cotangent ``g [N, Hout, Wout, Cout]``.
+    ``accumulate``: add into ``out`` (the other branch of a residual connection already wrote it).  ``amax_out``: device
+    word that receives max |dX| (bit pattern; must be zeroed by the caller when not accumulating over launches)."""
+    K = get_kernels()
+    m = prep.m
+    N = g.shape[0]
+    Hin, Win = in_hw
+    planes, sexp = prep.backward_planes(cscale)
+    if out is None:
+        out = torch.empty(N, Hin, Win, m.in_channels, dtype=torch.float32, device=g.planes.device)
+        accumulate = False
+    plans = backward_plan(m, Hin, Win)
+    if not accumulate and any(not p[4] for p in plans):
+        out.zero_()  # residue classes no tap reaches (1x1 stride-2: three of the four)
+    for Hc, Wc, oh0, ow0, taps in plans:
+        if taps and Hc and Wc:
+            K.conv_nhwc_f16x2(g, planes, sexp, Hc, Wc, 1, out, m.stride[0], oh0, ow0, taps, accumulate=accumulate,
+                              amax_out=amax_out)
+    return out
+
+
+def conv_forward(prep: PreparedConv, x: SplitTensor, out=None, amax_out=None):
+    """``y [N, Hout, Wout, Cout]`` (fp32, NHWC, no bias) of ``prep.m`` from the split input ``x [N, Hin, Win, Cin]``"""
+    K = get_kernels()
+    m = prep.m
+    N, Hin, Win, _ = x.shape
+    s, (ph, pw), (KH, KW) = m.stride[0], m.padding, m.kernel_size
+    Ho, Wo = (Hin + 2 * ph - KH) // s + 1, (Win + 2 * pw - KW) // s + 1
+    planes, sexp = prep.forward_planes()
+    if out is None:
+        out = torch.empty(N, Ho, Wo, m.out_channels, dtype=torch.float32, device=x.planes.device)
+    taps = [(kh - ph, kw - pw, kh * KW + kw) for kh in range(KH) for kw in range(KW)]
+    K.conv_nhwc_f16x2(x, planes, sexp, Ho, Wo, s, out, 1, 0, 0, taps, amax_out=amax_out)
+    return out

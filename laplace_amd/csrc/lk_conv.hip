@@ -1,0 +1,402 @@
+// Convolution as an implicit GEMM on NHWC tensors with fp32-level products from TWO-PIECE fp16 operands.
+//
+// What it replaces: the C reverse passes of curvlinops' KFACLinearOperator._compute_kfac as driven by
+// CurvlinopsInterface.kron (laplace/curvature/curvlinops.py:87-100) — for a convolution layer each of them is a
+// backward-data convolution; the seed-batched sweep (laplace_amd/sweep.py) folds all seeds into one batch, and this
+// kernel is that sweep's convolution: backward-data of stride-1 and stride-2 convs (and the forward form, same GEMM).
+//
+// Arithmetic.  gfx950 has no reduced-precision fast path for fp32 inputs, and the exact fp32 MFMA runs at the vector
+// rate (157 TFLOP/s).  Every operand tensor is therefore scaled by a power of two and split ONCE, by its producer, into
+// two fp16 planes:   x * 2^s = h + l + e,   h = fp16(x 2^s),  l = fp16(x 2^s - h),
+//   |e| <= max(2^-22 |x 2^s|, 2^-25)           (fp16 keeps 11 significant bits; l is exact down to the subnormals),
+// with s chosen so that the tensor's largest magnitude lands in [2^14, 2^15): a 22-bit significand for every element
+// within 2^-17 of the largest one and a fixed-point floor of 2^-39 of the largest one below that.  A product is then
+//   x y 2^(s+s') ~= h h' + h l' + l h'          (dropped: l l' <= 2^-22 |x y 2^(s+s')|)
+// i.e. THREE v_mfma_f32_32x32x16_f16 (32 cycles each, K = 16, fp32 accumulation) in place of eight
+// v_mfma_f32_32x32x2_f32 (64 cycles each): 96 instead of 512 matrix-pipe cycles per 32x32x16 block, a ceiling of
+// 2500 / 3 = 833 TFLOP/s fp32-equivalent.  Parity (1e-4 of the largest element, BASELINE.json) is tested against fp64.
+//
+// GEMM view:  out[p][n] = sum_t sum_c in[pix(p, t)][c] * Wt[t][n][c]   (p: output pixel, t: tap, out-of-image taps = 0)
+//   backward-data, stride 1:  in = cotangent of the conv output, n = conv input channel, Wt[t][ci][co] = W[co][ci][kh][kw]
+//   backward-data, stride 2:  one launch per output-pixel parity class (each class sees a fixed subset of the taps)
+//   forward:                  in = conv input, n = conv output channel, Wt[t][co][ci] = W[co][ci][kh][kw]
+// Both operands have k (channels) contiguous in memory — what a lane of the 16-bit MFMA reads (8 consecutive k = 16 B) —
+// and a tap shift moves the A operand by whole channel vectors, so every load is an aligned 16-byte load.
+//
+// Data path: global_load_lds (16 B per lane, straight into LDS, no VGPR round trip) into a double-buffered stage of
+// [A_h | A_l | B_h | B_l], each [rows][BK] fp16 with the 16-byte slots of a row XOR-swizzled (on the SOURCE address, as
+// the LDS destination of an LDS-DMA is lane-linear) so that the ds_read_b128 fragment reads are conflict-free; taps that
+// fall outside the image read a zero block.  One workgroup = 4 waves, each 64 x 64 (2 x 2 MFMA tiles) of a 128 x 128
+// (or 256 x 64) output tile; the epilogue un-scales, optionally accumulates into `out`, and folds max|out| into a
+// device word (what the next producer needs to choose ITS scale).
+#include "lk_common.h"
+
+namespace lk {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- power-of-two scaling -------------------------------------------------------------------------------------------
+// exponent s such that amax * 2^s lies in [2^14, 2^15)  (clamped so that 2^s and every scaled element stay finite)
+__device__ __forceinline__ int scale_exp_for(float amax) {
+  int be = (int)((__float_as_uint(amax) >> 23) & 0xffu);
+  if (be == 0) be = 1;  // zero / subnormal tensors: largest scale that is safe for anything below 2^-126
+  int s = 14 - (be - 127);
+  return s > 120 ? 120 : s;
+}
+__device__ __forceinline__ float exp2i(int s) {  // 2^s, -126 <= s <= 127
+  return __uint_as_float((unsigned)(127 + s) << 23);
+}
+__device__ __forceinline__ void split2(float xs, _Float16& h, _Float16& l) {
+  h = (_Float16)xs;
+  l = (_Float16)(xs - (float)h);
+}
+
+// ---- max |x| of a tensor as the bit pattern of a non-negative float (order-preserving as unsigned; atomicMax is
+//      order-independent, so the result is run-to-run deterministic) ----------------------------------------------------
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t n, const float* __restrict__ cscale,
+                                                     int64_t inner, int C, unsigned* __restrict__ out) {
+  unsigned m = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float v = x[i];
+    if (cscale) v *= cscale[(i / inner) % C];
+    m = max(m, __float_as_uint(v) & 0x7fffffffu);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+// ---- fp32 [rows][C] (NHWC) -> two fp16 planes, scale from the device-side bound `amax[0]` (* bound_mul) --------------
+__global__ __launch_bounds__(256) void split_f16x2_kernel(const float* __restrict__ x, int64_t n8,
+                                                          const float* __restrict__ amax, float bound_mul,
+                                                          _Float16* __restrict__ ph, _Float16* __restrict__ pl,
+                                                          int* __restrict__ sexp) {
+  const int s = scale_exp_for(amax[0] * bound_mul);
+  if (blockIdx.x == 0 && threadIdx.x == 0) sexp[0] = s;
+  const float sc = exp2i(s);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    const float4 a = reinterpret_cast<const float4*>(x)[2 * i], b = reinterpret_cast<const float4*>(x)[2 * i + 1];
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    f16x8 h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      _Float16 hh, ll;
+      split2(v[j] * sc, hh, ll);
+      h[j] = hh, l[j] = ll;
+    }
+    reinterpret_cast<f16x8*>(ph)[i] = h;
+    reinterpret_cast<f16x8*>(pl)[i] = l;
+  }
+}
+
+// ---- weights: W[co][ci][kh][kw] (* cscale[co]) -> planes [2][T][N][K] fp16 ---------------------------------------------
+// transpose = 1 (backward-data): n = ci, k = co;  transpose = 0 (forward): n = co, k = ci.  Tap t = kh * KW + kw.
+__global__ __launch_bounds__(256) void conv_prep_weights_kernel(const float* __restrict__ W, int Co, int Ci, int T,
+                                                                int transpose, const float* __restrict__ cscale,
+                                                                const unsigned* __restrict__ amax,
+                                                                _Float16* __restrict__ planes, int* __restrict__ sexp) {
+  const int s = scale_exp_for(__uint_as_float(amax[0]));
+  if (blockIdx.x == 0 && threadIdx.x == 0) sexp[0] = s;
+  const float sc = exp2i(s);
+  const int N = transpose ? Ci : Co, K = transpose ? Co : Ci;
+  const int64_t total = (int64_t)T * N * K;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int k = (int)(i % K), n = (int)((i / K) % N), t = (int)(i / ((int64_t)K * N));
+    const int co = transpose ? k : n, ci = transpose ? n : k;
+    float v = W[((int64_t)co * Ci + ci) * T + t];
+    if (cscale) v *= cscale[co];
+    _Float16 h, l;
+    split2(v * sc, h, l);
+    planes[i] = h;
+    planes[total + i] = l;
+  }
+}
+
+// ---- the implicit GEMM -------------------------------------------------------------------------------------------------
+struct ConvGeom {
+  int N, Hi, Wi, Ci;   // input tensor [N][Hi][Wi][Ci] (Ci = GEMM K per tap)
+  int Hc, Wc;          // output class grid: GEMM rows m = (n, i, j), i < Hc, j < Wc
+  int Ho, Wo, Co;      // output tensor [N][Ho][Wo][Co] (Co = GEMM N); output pixel = (i * os + oh0, j * os + ow0)
+  int os, oh0, ow0;
+  int im;              // input pixel of tap t = (i * im + dh[t], j * im + dw[t])
+  int T;               // taps of this launch
+  int dh[9], dw[9], wt[9];  // per tap: offsets and the weight slice (index into the [T_w][Co][Ci] planes)
+};
+
+template <int BM_, int BN_, int BK_, int WM_, int WN_>
+struct ConvCfg {
+  static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_;
+  static constexpr int Q = BK / 8;                       // 16-byte slots per row
+  static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;  // MFMA tiles per wave
+  static constexpr int A_PLANE = BM * BK * 2, B_PLANE = BN * BK * 2;  // bytes
+  static constexpr int STAGE = 2 * A_PLANE + 2 * B_PLANE;
+  static constexpr int A_SLOTS = BM * Q, B_SLOTS = BN * Q;   // per plane
+  static constexpr int A_LD = 2 * A_SLOTS / 256, B_LD = 2 * B_SLOTS / 256;  // LDS-DMA instructions per thread and stage
+  static_assert(WM * WN == 4, "four waves");
+  static_assert(A_SLOTS % 256 == 0 && B_SLOTS % 256 == 0, "whole instructions");
+};
+
+// swizzle of the 16-byte slot index within a row: a 16-lane group of ds_read_b128 touches 16 distinct rows (mod 16) at
+// one logical slot; physical = logical ^ f(row) spreads them over all 16 slots of the 256-byte bank row
+template <int Q>
+__device__ __forceinline__ int swz(int row) {
+  return Q == 4 ? ((row >> 2) & 3) : Q == 8 ? ((row >> 1) & 7) : (row & (Q - 1));
+}
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_void;
+
+template <typename CFG>
+__global__ __launch_bounds__(256) void conv_f16x2_kernel(const ConvGeom g, const _Float16* __restrict__ Ah,
+                                                         const _Float16* __restrict__ Al, const _Float16* __restrict__ Wh,
+                                                         const _Float16* __restrict__ Wl, const int* __restrict__ a_sexp,
+                                                         const int* __restrict__ w_sexp, const _Float16* __restrict__ zero16,
+                                                         float* __restrict__ out, int accumulate,
+                                                         unsigned* __restrict__ amax_out, int nb_m) {
+  constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK, Q = CFG::Q, TM = CFG::TM, TN = CFG::TN;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // XCD-aware tile order: consecutive block ids run on different XCDs (id % 8); give every XCD a contiguous range of
+  // (n-tile major, m-tile minor) tiles so that the blocks sharing an L2 share one weight panel and neighbouring pixels
+  const int nblk = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk / 8, r = nblk % 8, x = bid % 8, j = bid / 8;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+  }
+  const int tile_n = bid / nb_m, tile_m = bid % nb_m;
+  const int M = g.N * g.Hc * g.Wc;
+  const int KC = g.Ci / BK;
+  const int nstage = g.T * KC;
+
+  // ---- per-thread staging context: which rows / slots this thread feeds, fixed for the whole K loop
+  // A: A_LD instructions; instruction i covers slots [i*256, i*256+256) of the concatenated [plane h | plane l] image
+  int64_t a_off[CFG::A_LD / 2];   // element offset of (pixel (i*im, j*im), channel 0) per handled row
+  unsigned a_valid[CFG::A_LD / 2];  // bit t: tap t is inside the image (and the row exists)
+  int a_lq[CFG::A_LD / 2];
+  static_assert(CFG::A_LD % 2 == 0, "the two planes are fed by the same threads");
+#pragma unroll
+  for (int i = 0; i < CFG::A_LD / 2; ++i) {
+    const int slot = i * 256 + tid;  // within a plane
+    const int row = slot / Q, pq = slot % Q;
+    a_lq[i] = pq ^ swz<Q>(row);
+    const int m = tile_m * BM + row;
+    unsigned valid = 0;
+    int64_t off = 0;
+    if (m < M) {
+      const int n = m / (g.Hc * g.Wc), rem = m % (g.Hc * g.Wc);
+      const int ih = (rem / g.Wc) * g.im, iw = (rem % g.Wc) * g.im;
+      off = (((int64_t)n * g.Hi + ih) * g.Wi + iw) * g.Ci;
+      for (int t = 0; t < g.T; ++t) {
+        const int hh = ih + g.dh[t], ww = iw + g.dw[t];
+        if (hh >= 0 && hh < g.Hi && ww >= 0 && ww < g.Wi) valid |= 1u << t;
+      }
+    }
+    a_off[i] = off, a_valid[i] = valid;
+  }
+  int64_t b_off[CFG::B_LD / 2];
+  bool b_ok[CFG::B_LD / 2];
+#pragma unroll
+  for (int i = 0; i < CFG::B_LD / 2; ++i) {
+    const int slot = i * 256 + tid;
+    const int row = slot / Q, pq = slot % Q;
+    const int n = tile_n * BN + row;
+    b_ok[i] = n < g.Co;
+    b_off[i] = (int64_t)n * g.Ci + (pq ^ swz<Q>(row)) * 8;
+  }
+  const int64_t w_tap = (int64_t)g.Co * g.Ci;
+
+  auto stage = [&](int s, int buf) {
+    const int t = s / KC, kc = s - t * KC;
+    char* base = smem + buf * CFG::STAGE;
+    const int64_t tap_off = ((int64_t)g.dh[t] * g.Wi + g.dw[t]) * g.Ci + kc * BK;
+#pragma unroll
+    for (int i = 0; i < CFG::A_LD / 2; ++i) {
+      const bool ok = (a_valid[i] >> t) & 1u;
+      const int64_t e = a_off[i] + tap_off + a_lq[i] * 8;
+      const _Float16* sh = ok ? Ah + e : zero16;
+      const _Float16* sl = ok ? Al + e : zero16;
+      char* dh_ = base + (i * 256 + wave * 64) * 16;
+      __builtin_amdgcn_global_load_lds((gbl_void*)sh, (lds_void*)dh_, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void*)sl, (lds_void*)(dh_ + CFG::A_PLANE), 16, 0, 0);
+    }
+    const int64_t wbase = (int64_t)g.wt[t] * w_tap + kc * BK;
+#pragma unroll
+    for (int i = 0; i < CFG::B_LD / 2; ++i) {
+      const int64_t e = wbase + b_off[i];
+      const _Float16* sh = b_ok[i] ? Wh + e : zero16;
+      const _Float16* sl = b_ok[i] ? Wl + e : zero16;
+      char* db = base + 2 * CFG::A_PLANE + (i * 256 + wave * 64) * 16;
+      __builtin_amdgcn_global_load_lds((gbl_void*)sh, (lds_void*)db, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void*)sl, (lds_void*)(db + CFG::B_PLANE), 16, 0, 0);
+    }
+  };
+
+  // ---- fragment addresses: lane reads row (tile*32 + lane&31), logical slot k16*2 + (lane>>5)
+  const int wm = wave / CFG::WN, wn = wave % CFG::WN;
+  const int lr = lane & 31, lh = lane >> 5;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  stage(0, 0);
+  for (int s = 0; s < nstage; ++s) {
+    const int buf = s & 1;
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0), lgkmcnt / expcnt unconstrained: this wave's part of stage s has landed
+    __syncthreads();                                        // ... for every wave; and everyone is done with buf^1
+    if (s + 1 < nstage) stage(s + 1, buf ^ 1);
+    const char* base = smem + buf * CFG::STAGE;
+#pragma unroll
+    for (int k16 = 0; k16 < BK / 16; ++k16) {
+      f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int a = 0; a < TM; ++a) {
+        const int row = (wm * TM + a) * 32 + lr;
+        const int off = (row * Q + ((k16 * 2 + lh) ^ swz<Q>(row))) * 16;
+        ah[a] = *reinterpret_cast<const f16x8*>(base + off);
+        al[a] = *reinterpret_cast<const f16x8*>(base + CFG::A_PLANE + off);
+      }
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const int row = (wn * TN + b) * 32 + lr;
+        const int off = (row * Q + ((k16 * 2 + lh) ^ swz<Q>(row))) * 16;
+        bh[b] = *reinterpret_cast<const f16x8*>(base + 2 * CFG::A_PLANE + off);
+        bl[b] = *reinterpret_cast<const f16x8*>(base + 2 * CFG::A_PLANE + CFG::B_PLANE + off);
+      }
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          f32x16 c = acc[a][b];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], c, 0, 0, 0);  // small terms first
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], c, 0, 0, 0);
+          acc[a][b] = c;
+        }
+    }
+  }
+
+  // ---- epilogue: un-scale, store NHWC (a half-wave writes 32 consecutive channels = 128 B), max|out|
+  const float inv_a = exp2i(-a_sexp[0] < -126 ? -126 : -a_sexp[0]), inv_w = exp2i(-w_sexp[0] < -126 ? -126 : -w_sexp[0]);
+  unsigned vmax = 0;
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int m = tile_m * BM + row;
+      if (m >= M) continue;
+      const int n = m / (g.Hc * g.Wc), rem = m % (g.Hc * g.Wc);
+      const int oh = (rem / g.Wc) * g.os + g.oh0, ow = (rem % g.Wc) * g.os + g.ow0;
+      float* orow = out + (((int64_t)n * g.Ho + oh) * g.Wo + ow) * g.Co;
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const int col = tile_n * BN + (wn * TN + b) * 32 + lr;
+        if (col < g.Co) {
+          float v = acc[a][b][r] * inv_a * inv_w;
+          if (accumulate) v += orow[col];
+          orow[col] = v;
+          vmax = max(vmax, __float_as_uint(v) & 0x7fffffffu);
+        }
+      }
+    }
+  }
+  if (amax_out) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) vmax = max(vmax, (unsigned)__shfl_xor((int)vmax, off, 64));
+    if (lane == 0 && vmax) atomicMax(amax_out, vmax);
+  }
+}
+
+}  // namespace lk
+
+using namespace lk;
+
+extern "C" int lk_absmax_f32(const float* x, int64_t n, const float* cscale, int64_t inner, int64_t C, unsigned* out,
+                             void* stream) {
+  LK_REQUIRE(x && out && n >= 0 && (!cscale || (inner >= 1 && C >= 1)), "lk_absmax_f32: bad arguments");
+  hipError_t e = hipMemsetAsync(out, 0, sizeof(unsigned), (hipStream_t)stream);
+  if (e != hipSuccess) {
+    set_error("lk_absmax_f32: memset: %s", hipGetErrorString(e));
+    return LK_ELAUNCH;
+  }
+  if (n == 0) return LK_OK;
+  int64_t blocks = (n + 2047) / 2048;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, cscale,
+                     cscale ? inner : 1, cscale ? (int)C : 1, out);
+  return check_launch("absmax_kernel");
+}
+
+extern "C" int lk_split_f16x2(const float* x, int64_t n, const float* amax, float bound_mul, void* planes_h,
+                              void* planes_l, int* sexp, void* stream) {
+  LK_REQUIRE(x && amax && planes_h && planes_l && sexp && n >= 0 && n % 8 == 0, "lk_split_f16x2: bad arguments (n % 8 == 0)");
+  if (n == 0) return LK_OK;
+  int64_t blocks = (n / 8 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(split_f16x2_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n / 8, amax,
+                     bound_mul, (_Float16*)planes_h, (_Float16*)planes_l, sexp);
+  return check_launch("split_f16x2_kernel");
+}
+
+extern "C" int lk_conv_prep_weights_f16x2(const float* W, int64_t Co, int64_t Ci, int64_t taps, int transpose,
+                                          const float* cscale, unsigned* amax_ws, void* planes, int* sexp, void* stream) {
+  LK_REQUIRE(W && amax_ws && planes && sexp && Co >= 1 && Ci >= 1 && taps >= 1 && taps <= 9,
+             "lk_conv_prep_weights_f16x2: bad arguments");
+  const int64_t total = Co * Ci * taps;
+  int rc = lk_absmax_f32(W, total, cscale, Ci * taps, Co, amax_ws, stream);
+  if (rc != LK_OK) return rc;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(conv_prep_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, W, (int)Co,
+                     (int)Ci, (int)taps, transpose, cscale, amax_ws, (_Float16*)planes, sexp);
+  return check_launch("conv_prep_weights_kernel");
+}
+
+template <typename CFG>
+static int launch_conv(const ConvGeom& g, const void* Ah, const void* Al, const void* Wh, const void* Wl, const int* a_sexp,
+                       const int* w_sexp, const void* zero16, float* out, int accumulate, unsigned* amax_out,
+                       hipStream_t stream) {
+  const int64_t M = (int64_t)g.N * g.Hc * g.Wc;
+  const int nb_m = (int)((M + CFG::BM - 1) / CFG::BM), nb_n = (g.Co + CFG::BN - 1) / CFG::BN;
+  const size_t lds = 2 * (size_t)CFG::STAGE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv_f16x2_kernel<CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv_f16x2_kernel<CFG>, dim3((unsigned)(nb_m * nb_n)), dim3(256), lds, stream, g, (const _Float16*)Ah,
+                     (const _Float16*)Al, (const _Float16*)Wh, (const _Float16*)Wl, a_sexp, w_sexp, (const _Float16*)zero16,
+                     out, accumulate, amax_out, nb_m);
+  return check_launch("conv_f16x2_kernel");
+}
+
+// One launch of the implicit GEMM.  `taps`: T x {dh, dw, weight slice}.
+extern "C" int lk_conv_nhwc_f16x2(const void* in_h, const void* in_l, const int* in_sexp, int64_t N, int64_t Hi, int64_t Wi,
+                                  int64_t Ci, const void* w_h, const void* w_l, const int* w_sexp, int64_t Co,
+                                  int64_t Hc, int64_t Wc, int64_t in_mul, int64_t Ho, int64_t Wo, int64_t out_step,
+                                  int64_t oh0, int64_t ow0, int64_t T, const int* taps, const void* zero16, float* out,
+                                  int accumulate, unsigned* amax_out, int config, void* stream) {
+  LK_REQUIRE(in_h && in_l && in_sexp && w_h && w_l && w_sexp && zero16 && out && taps, "lk_conv_nhwc_f16x2: null pointer");
+  LK_REQUIRE(T >= 1 && T <= 9 && Ci >= 32 && Ci % 32 == 0 && Co >= 1 && N >= 1, "lk_conv_nhwc_f16x2: Ci % 32 == 0, 1..9 taps");
+  LK_REQUIRE(N * Hc * Wc < (1ll << 31) && N * Hi * Wi * Ci < (1ll << 40), "lk_conv_nhwc_f16x2: tensor too large");
+  if (Hc == 0 || Wc == 0) return LK_OK;
+  ConvGeom g;
+  g.N = (int)N, g.Hi = (int)Hi, g.Wi = (int)Wi, g.Ci = (int)Ci, g.Hc = (int)Hc, g.Wc = (int)Wc, g.Ho = (int)Ho,
+  g.Wo = (int)Wo, g.Co = (int)Co, g.os = (int)out_step, g.oh0 = (int)oh0, g.ow0 = (int)ow0, g.im = (int)in_mul, g.T = (int)T;
+  for (int t = 0; t < 9; ++t) g.dh[t] = g.dw[t] = g.wt[t] = 0;
+  for (int t = 0; t < T; ++t) g.dh[t] = taps[3 * t], g.dw[t] = taps[3 * t + 1], g.wt[t] = taps[3 * t + 2];
+  hipStream_t st = (hipStream_t)stream;
+  const bool bk64 = (Ci % 64 == 0) && (config & 1);
+  if (Co <= 64) {
+    return bk64 ? launch_conv<ConvCfg<256, 64, 64, 4, 1>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st)
+                : launch_conv<ConvCfg<256, 64, 32, 4, 1>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st);
+  }
+  return bk64 ? launch_conv<ConvCfg<128, 128, 64, 2, 2>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st)
+              : launch_conv<ConvCfg<128, 128, 32, 2, 2>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st);
+}

@@ -1,0 +1,127 @@
+"""The split-fp16 implicit-GEMM convolution (csrc/lk_conv.hip, laplace_amd/conv.py) against fp64 convolutions of the
+same operands: backward-data on the ten convolution shapes of ResNet-18 (config c4: 3x3 stride 1 and 2, 1x1 stride 2,
+64...512 channels, 32x32...4x4 maps), the forward form, the residual accumulate mode, and the split itself.
+Tolerance: 1e-4 of the largest element (BASELINE.json); the measured errors are ~1e-6.  -m gpu only."""
+import pytest
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+# (Cin, Cout, k, stride, pad, H) of the input map: every conv of ResNet-18 (CIFAR stem) that needs a backward-data pass
+C4_SHAPES = [
+    (64, 64, 3, 1, 1, 32), (64, 128, 3, 2, 1, 32), (128, 128, 3, 1, 1, 16), (64, 128, 1, 2, 0, 32),
+    (128, 256, 3, 2, 1, 16), (256, 256, 3, 1, 1, 8), (128, 256, 1, 2, 0, 16), (256, 512, 3, 2, 1, 8),
+    (512, 512, 3, 1, 1, 4), (256, 512, 1, 2, 0, 8),
+]
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return (a - b).abs().max().item() / (b.abs().max().item() + 1e-300)
+
+
+def _conv(cin, cout, k, s, p):
+    torch.manual_seed(cin * 7 + cout + k + s)
+    return nn.Conv2d(cin, cout, k, s, p, bias=False).to(DEV)
+
+
+def test_split_reconstructs_to_22_bits_and_survives_wide_dynamic_range():
+    from laplace_amd._lib import get_kernels
+
+    K = get_kernels()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(64, 8, 8, 32, generator=g) * torch.exp(4 * torch.randn(64, 1, 1, 1, generator=g))  # e^±12 spread
+    x[0, 0, 0, :8] = 0.0
+    xs = K.split_f16x2(x.to(DEV).contiguous())
+    back = xs.float().cpu()
+    amax = x.abs().max()
+    err = (back - x).abs()
+    # elements within 2^-17 of the largest: 22-bit relative accuracy; everything else: 2^-39 of the largest
+    assert (err <= torch.maximum(x.abs() * 2.0 ** -21, amax * 2.0 ** -38)).all()
+    assert torch.isfinite(xs.planes.float()).all()
+    assert xs.planes[0].abs().max().item() < 2.0 ** 15
+    # bound_mul: a looser (guaranteed) bound only costs fixed-point range
+    xs2 = K.split_f16x2(x.to(DEV).contiguous(), bound_mul=64.0)
+    assert int(xs2.sexp.item()) == int(xs.sexp.item()) - 6
+    assert ((xs2.float().cpu() - x).abs() <= torch.maximum(x.abs() * 2.0 ** -21, amax * 2.0 ** -32)).all()
+    z = K.split_f16x2(torch.zeros(16, 32, device=DEV))
+    assert torch.equal(z.float(), torch.zeros(16, 32, device=DEV))
+
+
+@pytest.mark.parametrize("shape", C4_SHAPES, ids=[f"{c[0]}-{c[1]}-k{c[2]}s{c[3]}-{c[5]}x{c[5]}" for c in C4_SHAPES])
+@pytest.mark.parametrize("config", [0, 1])
+def test_backward_data_on_the_c4_layer_shapes(shape, config):
+    from laplace_amd import conv as cv
+    from laplace_amd._lib import get_kernels
+
+    K = get_kernels()
+    cin, cout, k, s, p, H = shape
+    m = _conv(cin, cout, k, s, p)
+    Ho = (H + 2 * p - k) // s + 1
+    N = 19  # odd: the last pixel tile is ragged
+    g = torch.randn(N, cout, Ho, Ho, device=DEV)
+    want = torch.nn.grad.conv2d_input((N, cin, H, H), m.weight.double().cpu(), g.double().cpu(), stride=s, padding=p)
+    gs = K.split_f16x2(g.permute(0, 2, 3, 1).contiguous())
+    prep = cv.PreparedConv(m)
+    amax = torch.zeros(1, dtype=torch.float32, device=DEV)
+    prev = K.conv_config
+    K.conv_config = config
+    try:
+        dx = cv.conv_backward_data(prep, gs, (H, H), amax_out=amax)
+    finally:
+        K.conv_config = prev
+    got = dx.permute(0, 3, 1, 2)
+    assert rel(got, want) < 1e-5, rel(got, want)
+    assert abs(amax.item() - got.abs().max().item()) <= 1e-6 * amax.item()
+    # deferred BatchNorm scale folded into the weights: backward-data of `scale[co] * W`
+    sc = (torch.rand(cout, device=DEV) + 0.5).contiguous()
+    want2 = torch.nn.grad.conv2d_input((N, cin, H, H), (m.weight * sc.reshape(-1, 1, 1, 1)).double().cpu(),
+                                       g.double().cpu(), stride=s, padding=p)
+    dx2 = cv.conv_backward_data(prep, gs, (H, H), cscale=sc)
+    assert rel(dx2.permute(0, 3, 1, 2), want2) < 1e-5
+    # residual accumulate: out += backward-data (the down-sampling branch adds into the main branch's cotangent)
+    base = torch.randn_like(dx)
+    acc = base.clone()
+    cv.conv_backward_data(prep, gs, (H, H), out=acc, accumulate=True)
+    assert rel(acc - base, dx) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(64, 64, 3, 1, 1, 32), (64, 128, 3, 2, 1, 32), (64, 128, 1, 2, 0, 32), (512, 512, 3, 1, 1, 4),
+                                   (96, 160, 3, 1, 1, 7), (32, 32, 2, 1, 0, 9), (32, 64, 3, 3, 1, 11)])
+def test_forward_and_odd_geometries(shape):
+    from laplace_amd import conv as cv
+    from laplace_amd._lib import get_kernels
+
+    K = get_kernels()
+    cin, cout, k, s, p, H = shape
+    m = _conv(cin, cout, k, s, p)
+    N = 5
+    x = torch.randn(N, cin, H, H + 1, device=DEV)
+    want = F.conv2d(x.double().cpu(), m.weight.double().cpu(), None, s, p)
+    prep = cv.PreparedConv(m)
+    y = cv.conv_forward(prep, K.split_f16x2(x.permute(0, 2, 3, 1).contiguous()))
+    assert rel(y.permute(0, 3, 1, 2), want) < 1e-5
+    # and the matching backward-data (non-square map, stride that does not divide the size)
+    g = torch.randn_like(y)
+    wantb = torch.nn.grad.conv2d_input((N, cin, H, H + 1), m.weight.double().cpu(), g.permute(0, 3, 1, 2).double().cpu(),
+                                       stride=s, padding=p)
+    dx = cv.conv_backward_data(prep, K.split_f16x2(g), (H, H + 1))
+    assert rel(dx.permute(0, 3, 1, 2), wantb) < 1e-5
+
+
+def test_tiny_and_huge_magnitudes_keep_fp32_level_accuracy():
+    """cotangents of 1e-20 and weights of 1e+6: the power-of-two scales keep both inside fp16's range"""
+    from laplace_amd import conv as cv
+    from laplace_amd._lib import get_kernels
+
+    K = get_kernels()
+    m = _conv(64, 64, 3, 1, 1)
+    with torch.no_grad():
+        m.weight.mul_(1e6)
+    g = torch.randn(3, 64, 8, 8, device=DEV) * 1e-20
+    want = torch.nn.grad.conv2d_input((3, 64, 8, 8), m.weight.double().cpu(), g.double().cpu(), stride=1, padding=1)
+    dx = cv.conv_backward_data(cv.PreparedConv(m), K.split_f16x2(g.permute(0, 2, 3, 1).contiguous()), (8, 8))
+    assert rel(dx.permute(0, 3, 1, 2), want) < 1e-5
