@@ -181,6 +181,23 @@ int lk_conv_nhwc_f16x2(const void* in_h, const void* in_l, const int* in_sexp, i
                        int64_t T, const int* taps, const void* zero16, float* out, int accumulate, unsigned* amax_out,
                        int config, void* stream);
 
+/* Element-wise VJP of the NHWC sweep with a split result (csrc/lk_sweep16.hip):
+ *     out[s][e] = (g[s][e] + g2[s][e]) * M[e] * scale[e % C]      e < per = B*H*W*C,  s < S
+ * g: fp32 addend with the bit pattern of max|g| in g_amax (both may be NULL); g2: split addend (may be NULL);
+ * M: per-sample multiplier, uint8 mask or fp32 (m_amax: bit pattern of max|M| for fp32, NULL = 1), may be NULL;
+ * scale: per-channel (scale_amax: bit pattern of max|scale|), may be NULL.  The output scale is derived on the device
+ * from the guaranteed bound (max|g| + max|g2|) max|M| max|scale| — no pass over the data to find it. */
+int lk_vjp_nhwc_split_f16x2(const float* g, const unsigned* g_amax, const void* g2_h, const void* g2_l, const int* g2_sexp,
+                            const void* m, int m_is_float, const unsigned* m_amax, const float* scale,
+                            const unsigned* scale_amax, int64_t C, int64_t S, int64_t per, void* out_h, void* out_l,
+                            int* out_sexp, void* stream);
+/* G[C][C] += alpha * X^T X for a split tensor X [R][C] (rows = (seed, sample, position) of an NHWC cotangent): the
+ * G factor of a convolution layer (curvlinops.py:87-100).  Only the 32x32 tiles on or above the diagonal are written
+ * (lk_symmetrize_f32 mirrors).  C = 64 or a multiple of 128.  Deterministic (workspace partials, fixed-order sum). */
+size_t lk_gram_tn_f16x2_workspace_bytes(int64_t R, int64_t C);
+int lk_gram_tn_f16x2(const void* x_h, const void* x_l, const int* sexp, int64_t R, int64_t C, float alpha, float* G,
+                     const void* zero16, void* ws, size_t ws_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Diagonal GGN / EF.  Replaces GGNInterface.diag / EFInterface.diag (curvature.py:413-433,494-505)
  * for nn.Linear layers:  h_w[o][i] += alpha * sum_n (sum_c g[c][n][o]^2) a[n][i]^2,

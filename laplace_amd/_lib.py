@@ -61,6 +61,9 @@ SIGNATURES = {
     "lk_conv_prep_weights_f16x2": (_int, [_vp, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp]),
     "lk_conv_nhwc_f16x2": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64,
                                   _i64, _i64, _i64, _i64, _vp, _vp, _vp, _int, _vp, _int, _vp]),
+    "lk_vjp_nhwc_split_f16x2": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "lk_gram_tn_f16x2_workspace_bytes": (_sz, [_i64, _i64]),
+    "lk_gram_tn_f16x2": (_int, [_vp, _vp, _vp, _i64, _i64, _f32, _vp, _vp, _vp, _sz, _vp]),
     "lk_symmetrize_f32": (_int, [_vp, _i64, _vp]),
     "lk_permute_sym_f32": (_int, [_vp, _i64, _i64, _vp, _int, _vp]),
     "lk_diag_ggn_linear_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp, _vp, _vp]),
@@ -369,6 +372,46 @@ class HipKernels:
                                              out.shape[1], out.shape[2], out_step, oh0, ow0, len(taps), flat,
                                              _ptr(self._zero16(out.device)), _ptr(out), 1 if accumulate else 0,
                                              _ptr(amax_out), int(cfg), self._stream(out.device)), "lk_conv_nhwc_f16x2")
+        return out
+
+    def vjp_nhwc_split(self, g, g_amax, g2, mult, mult_amax, scale, scale_amax, S, out_shape):
+        """``(g + g2) * mult * scale[channel]`` for all ``S`` seeds -> SplitTensor of ``out_shape`` ([S*B, H, W, C]).
+        ``g``: fp32 NHWC with ``g_amax`` (device word, lk_absmax / conv epilogue) or None; ``g2``: SplitTensor or None;
+        ``mult``: [B, H, W, C] uint8 / bool mask or fp32 multiplier (``mult_amax`` for fp32) or None."""
+        dev = (g if g is not None else g2.planes).device
+        planes = torch.empty((2,) + tuple(out_shape), dtype=torch.float16, device=dev)
+        sexp = torch.empty(1, dtype=torch.int32, device=dev)
+        n = planes[0].numel()
+        per = n // S
+        C = out_shape[-1]
+        m_is_float = 0
+        if mult is not None:
+            if mult.dtype == torch.bool:
+                mult = mult.view(torch.uint8)
+            m_is_float = 1 if mult.dtype == torch.float32 else 0
+            if not mult.is_contiguous() or mult.numel() != per or mult.dtype not in (torch.uint8, torch.float32):
+                raise LaplaceHipError("vjp_nhwc_split: multiplier must be a contiguous [B, H, W, C] uint8 / float32 tensor")
+        if g is not None:
+            _check(g, "g")
+        self._rc(self.lib.lk_vjp_nhwc_split_f16x2(
+            _ptr(g), _ptr(g_amax), None if g2 is None else _ptr(g2.planes[0]), None if g2 is None else _ptr(g2.planes[1]),
+            None if g2 is None else _ptr(g2.sexp), _ptr(mult), m_is_float, _ptr(mult_amax), _ptr(scale), _ptr(scale_amax),
+            C, S, per, _ptr(planes[0]), _ptr(planes[1]), _ptr(sexp), self._stream(dev)), "lk_vjp_nhwc_split_f16x2")
+        return SplitTensor(planes, sexp)
+
+    def gram_tn_f16x2(self, x, alpha, out):
+        """``out[upper tiles] += alpha * X^T X`` for a SplitTensor ``x`` viewed as ``[rows, C]``"""
+        _check(out, "out")
+        C = x.planes.shape[-1]
+        R = x.planes[0].numel() // C
+        nbytes = int(self.lib.lk_gram_tn_f16x2_workspace_bytes(R, C))
+        if nbytes == 0 and R:
+            raise LaplaceHipError(f"gram_tn_f16x2: C = {C} not supported (64 or a multiple of 128)")
+        ws = self._workspace(nbytes, out.device)
+        z = self._zero16(out.device)
+        self._rc(self._timed("gram16", float(R) * C * (C + 1), out.device, lambda: self.lib.lk_gram_tn_f16x2(
+            _ptr(x.planes[0]), _ptr(x.planes[1]), _ptr(x.sexp), R, C, float(alpha), _ptr(out), _ptr(z), _ptr(ws),
+            ws.numel(), self._stream(out.device))), "lk_gram_tn_f16x2")
         return out
 
     def gram_conv(self, x, kernel_size, stride, padding, dilation, alpha, out, upper_only=False, native=False):

@@ -31,9 +31,10 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from laplace_amd._lib import get_kernels
+from laplace_amd._lib import SplitTensor, get_kernels
 from laplace_amd.capture import Tape
 from laplace_amd.sweep import SeedBatchedSweep, SweepUnsupported
+from laplace_amd.sweep_nhwc import SplitSweep
 from laplace_amd.kron import HipKron
 from laplace_amd.refapi import EFInterface, GGNInterface
 
@@ -136,6 +137,8 @@ class _HipCurvatureMixin:
 
     #: ``False`` forces the autograd tape (one reverse pass per seed); env LK_SWEEP=0 does the same.
     use_sweep = os.environ.get("LK_SWEEP", "1") != "0"
+    #: ``False`` (env LK_SPLIT_SWEEP=0) keeps the reverse sweep on NCHW fp32 cotangents and the library's backward-data
+    use_split_sweep = os.environ.get("LK_SPLIT_SWEEP", "1") != "0"
     #: largest batch (seeds x samples) of one reverse sweep and the memory its cotangents may take (4 live tensors of
     #: the largest activation are assumed); more seeds are processed in chunks
     sweep_max_rows = 8192
@@ -184,7 +187,9 @@ class _HipCurvatureMixin:
         sweep = getattr(tape, "sweep", None)
         if sweep is None:
             try:
-                sweep = SeedBatchedSweep(self._model, {t.name: t.module for t in tape.taps}, kernels=get_kernels)
+                # NHWC split-fp16 sweep (own convolution kernels) where the graph allows it, else the NCHW sweep
+                cls = SplitSweep if self.use_split_sweep else SeedBatchedSweep
+                sweep = cls(self._model, {t.name: t.module for t in tape.taps}, kernels=get_kernels)
             except SweepUnsupported as e:
                 sweep = False
                 tape.sweep_reason = str(e)
@@ -340,6 +345,17 @@ class _HipCurvatureMixin:
         """``G += alpha * sum g g^T`` (output side; ``g`` is ``[S, B, ...]`` or the unstacked per-seed list)."""
         K = get_kernels()
         m = tap.module
+        if isinstance(g, SplitTensor):  # NHWC split cotangent [S*B, H, W, Do] of the split-fp16 sweep
+            Do = g.shape[-1]
+            if kfac_approx == "expand" and (Do == 64 or Do % 128 == 0):
+                K.gram_tn_f16x2(g, alpha_g, G)  # upper 32x32 tiles; mirrored by the caller (symmetrize)
+                if not fused:
+                    K.symmetrize(G)
+                return G
+            gf = g.float()
+            rows = gf.reshape(-1, Do) if kfac_approx == "expand" else gf.sum((1, 2))
+            K.gram_tn(rows.contiguous(), alpha_g, G, upper_only=fused)
+            return G
         L = self._positions(tap, tap.a)
         if isinstance(g, (list, tuple)):  # conv tap, per-seed gradients left unstacked
             S, B = len(g), g[0].shape[0]
@@ -671,7 +687,7 @@ class KronAccumulator:
 
             def on_tap(name, g):
                 tap, F = by_name[name]
-                persist = self._g_slabs(tap, g, rt * hs)
+                persist = None if isinstance(g, SplitTensor) else self._g_slabs(tap, g, rt * hs)
                 if side is None:
                     b._factor_G(tap, g, rt * hs, self.kfac_approx, F[0], fused=True, persist=persist)
                     return
@@ -680,7 +696,7 @@ class KronAccumulator:
                 side.wait_event(ev)
                 with torch.cuda.stream(side):
                     b._factor_G(tap, g, rt * hs, self.kfac_approx, F[0], fused=True, persist=persist)
-                g.record_stream(side)  # allocated on the main stream, read on the side stream
+                (g.planes if isinstance(g, SplitTensor) else g).record_stream(side)  # allocated on main, read on side
 
             grad_fn(seeds, stack=False, on_tap=on_tap, defer_bn_scale=defer)
         else:

@@ -47,7 +47,11 @@ __device__ __forceinline__ int scale_exp_for(float amax) {
 __device__ __forceinline__ float exp2i(int s) {  // 2^s, -126 <= s <= 127
   return __uint_as_float((unsigned)(127 + s) << 23);
 }
-__device__ __forceinline__ void split2(float xs, _Float16& h, _Float16& l) {
+__device__ __forceinline__ void split2(float x, float sc, _Float16& h, _Float16& l) {
+  // the scaled value is made opaque first: h and the residual must come from the SAME fp32 value (hipcc otherwise fuses
+  // the residual into fp16(x * sc - h') with h' rounded from the exact product, see lk_sweep16.hip)
+  float xs = x * sc;
+  asm volatile("" : "+v"(xs));
   h = (_Float16)xs;
   l = (_Float16)(xs - (float)h);
 }
@@ -82,7 +86,7 @@ __global__ __launch_bounds__(256) void split_f16x2_kernel(const float* __restric
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       _Float16 hh, ll;
-      split2(v[j] * sc, hh, ll);
+      split2(v[j], sc, hh, ll);
       h[j] = hh, l[j] = ll;
     }
     reinterpret_cast<f16x8*>(ph)[i] = h;
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(256) void conv_prep_weights_kernel(const float* __r
     float v = W[((int64_t)co * Ci + ci) * T + t];
     if (cscale) v *= cscale[co];
     _Float16 h, l;
-    split2(v * sc, h, l);
+    split2(v, sc, h, l);
     planes[i] = h;
     planes[total + i] = l;
   }

@@ -1,0 +1,415 @@
+// NHWC / split-fp16 side of the seed-batched reverse sweep (laplace_amd/sweep_nhwc.py): the element-wise VJP that
+// PRODUCES split tensors for the convolution kernel (lk_conv.hip), and the G-factor Gram that CONSUMES them.
+//
+// Reference: the per-layer output gradients of curvlinops' KFACLinearOperator._compute_kfac and their Gram
+// G = sum_{n,l,c} g g^T (laplace/curvature/curvlinops.py:87-100).  Stock autograd runs one
+// activation / BatchNorm backward kernel per seed and layer; here all seeds of a layer go through one pass.
+#include "lk_common.h"
+
+namespace lk {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int scale_exp_for16(float amax) {  // as in lk_conv.hip: amax * 2^s in [2^14, 2^15)
+  int be = (int)((__float_as_uint(amax) >> 23) & 0xffu);
+  if (be == 0) be = 1;
+  int s = 14 - (be - 127);
+  return s > 120 ? 120 : s;
+}
+__device__ __forceinline__ float exp2i16(int s) {
+  s = s < -126 ? -126 : (s > 127 ? 127 : s);
+  return __uint_as_float((unsigned)(127 + s) << 23);
+}
+
+// ---- element-wise VJP, NHWC, split output -------------------------------------------------------------------------------
+//   out[s][e] = (g[s][e] + g2[s][e]) * M[e] * scale[e % C]        e < per = B*H*W*C, all S seeds in one pass
+// g: fp32 (the convolution kernel's output) with its max|.| in a device word; g2: a split tensor (the cotangent of a
+// residual join, produced by this kernel earlier); either may be absent.  The output is split with a scale derived from
+// a GUARANTEED bound of max|out| — (max|g| + max|g2|) * max|M| * max|scale|, every factor a device word — so no extra
+// pass over the data is needed to find the scale; a loose bound only costs fixed-point range (lk_conv.hip).
+template <bool MFLOAT>
+__global__ __launch_bounds__(256) void vjp_nhwc_split_kernel(
+    const float* __restrict__ g, const unsigned* __restrict__ g_amax, const _Float16* __restrict__ g2h,
+    const _Float16* __restrict__ g2l, const int* __restrict__ g2_sexp, const void* __restrict__ m,
+    const unsigned* __restrict__ m_amax, const float* __restrict__ scale, const unsigned* __restrict__ scale_amax, int C,
+    int S, int64_t per8, _Float16* __restrict__ oh, _Float16* __restrict__ ol, int* __restrict__ out_sexp) {
+  float bound = 0.f, inv2 = 0.f;
+  if (g) bound += __uint_as_float(g_amax[0]);
+  if (g2h) {
+    const int s2 = g2_sexp[0];
+    bound += exp2i16(15 - s2);  // max|g2| * 2^s2 < 2^15
+    inv2 = exp2i16(-s2);
+  }
+  if (m && MFLOAT && m_amax) bound *= __uint_as_float(m_amax[0]);
+  if (scale) bound *= __uint_as_float(scale_amax[0]);
+  const int so = scale_exp_for16(bound);
+  if (blockIdx.x == 0 && threadIdx.x == 0) out_sexp[0] = so;
+  const float sc_out = exp2i16(so);
+  const int64_t e8 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e8 >= per8) return;
+  float mult[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) mult[j] = sc_out;
+  if (m) {
+    if (MFLOAT) {
+      const float4 a = reinterpret_cast<const float4*>(m)[2 * e8], b = reinterpret_cast<const float4*>(m)[2 * e8 + 1];
+      mult[0] *= a.x, mult[1] *= a.y, mult[2] *= a.z, mult[3] *= a.w, mult[4] *= b.x, mult[5] *= b.y, mult[6] *= b.z, mult[7] *= b.w;
+    } else {
+      const uint2 u = reinterpret_cast<const uint2*>(m)[e8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (!((u.x >> (8 * j)) & 0xffu)) mult[j] = 0.f;
+        if (!((u.y >> (8 * j)) & 0xffu)) mult[4 + j] = 0.f;
+      }
+    }
+  }
+  if (scale) {
+    const int c0 = (int)((e8 * 8) % C);
+    const float4 a = *reinterpret_cast<const float4*>(scale + c0), b = *reinterpret_cast<const float4*>(scale + c0 + 4);
+    mult[0] *= a.x, mult[1] *= a.y, mult[2] *= a.z, mult[3] *= a.w, mult[4] *= b.x, mult[5] *= b.y, mult[6] *= b.z, mult[7] *= b.w;
+  }
+#pragma unroll 2
+  for (int s = 0; s < S; ++s) {
+    const int64_t i8 = (int64_t)s * per8 + e8;
+    float v[8];
+    if (g) {
+      const float4 a = reinterpret_cast<const float4*>(g)[2 * i8], b = reinterpret_cast<const float4*>(g)[2 * i8 + 1];
+      v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    }
+    if (g2h) {
+      const f16x8 h2 = reinterpret_cast<const f16x8*>(g2h)[i8], l2 = reinterpret_cast<const f16x8*>(g2l)[i8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += ((float)h2[j] + (float)l2[j]) * inv2;
+    }
+    f16x8 h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      // The product is made opaque before it is split.  Left to itself hipcc forms the stored h from the fp32-rounded
+      // product but the residual from a fused fp16(v * mult - h') with h' = fp16 of the EXACT product (v_fma_mix); the
+      // two h differ at rounding ties and the pair then misses the value by a whole fp16 ulp.
+      float xs = v[j] * mult[j];
+      asm volatile("" : "+v"(xs));
+      const _Float16 hh = (_Float16)xs;
+      h[j] = hh;
+      l[j] = (_Float16)(xs - (float)hh);
+    }
+    reinterpret_cast<f16x8*>(oh)[i8] = h;
+    reinterpret_cast<f16x8*>(ol)[i8] = l;
+  }
+}
+
+// ---- Gram of a split tensor:  ws partials of  X^T X,  X = planes [R][C] (rows = (seed, sample, pixel), C contiguous) -----
+// k (rows) is the STRIDED direction of both MFMA operands, so fragments come out of LDS through the transposing read
+// ds_read_b64_tr_b16: a 16-lane group hands in the addresses of a [4 k][16 channel] block (lane r: row k0 + r/4,
+// channels c0 + 4 (r%4) ..+3) and lane r receives channel c0 + r for k0..k0+3 — two of them make the 8 consecutive k of
+// one lane of v_mfma_f32_32x32x16_f16, for the A (row-channel) and the B (column-channel) operand alike.
+// The stage image [rows][NB channels] is filled by LDS-DMA (lane-linear), with the 64-byte chunks of a row XOR-swizzled by
+// the row so that the four rows a half-wave reads together sit in different banks.
+// Workgroup = one (bi <= bj) pair of NB-channel blocks and one slice of the rows:
+//   NB = 64  (C = 64):  the four waves split the k16 steps of a stage between them (the tensor is huge, the output tiny);
+//   NB = 128 (C >= 128): 2 x 2 waves, each a 64 x 64 quadrant; lower-triangle quadrant / tiles of diagonal blocks idle.
+// Every wave writes its partial tiles to the workspace; gram16_reduce_kernel sums them in a fixed order.
+template <int NB, int BKR, int KW>  // KW = waves that split k inside the workgroup (4 or 1)
+struct Gram16Cfg {
+  static constexpr int PITCH = NB * 2;                   // bytes per row of a plane image
+  static constexpr int PLANE = BKR * PITCH;              // bytes
+  static constexpr int PANEL = 2 * PLANE;                // h + l
+  static constexpr int STAGE = 2 * PANEL;                // row panel + column panel
+  static constexpr int SLOTS = BKR * NB / 8;             // 16-byte slots per plane image
+  static constexpr int LD = SLOTS / 256;                 // LDS-DMA instructions per thread, plane and panel
+  static constexpr int TW = KW == 4 ? NB / 32 : NB / 64; // MFMA tiles per wave and side
+  static_assert(SLOTS % 256 == 0, "whole instructions");
+};
+
+template <int NB>
+__device__ __forceinline__ int gram16_swz(int row) {  // XOR on the 64-byte chunk index of a row
+  return NB == 64 ? ((row >> 1) & 1) : (row & 3);
+}
+
+typedef __attribute__((address_space(3))) void lds_void16;
+typedef __attribute__((address_space(1))) const void gbl_void16;
+
+template <int NB, int BKR, int KW>
+__global__ __launch_bounds__(256) void gram16_kernel(const _Float16* __restrict__ Xh, const _Float16* __restrict__ Xl,
+                                                     int64_t R, int C, int64_t rows_per_split,
+                                                     const _Float16* __restrict__ zero16, float* __restrict__ ws,
+                                                     int nbc) {
+  using G = Gram16Cfg<NB, BKR, KW>;
+  constexpr int TW = G::TW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // block pair (bi <= bj) from the linear index
+  int bi = 0, bj = 0;
+  {
+    int p = blockIdx.x;
+    while (p >= nbc - bi) p -= nbc - bi, ++bi;
+    bj = bi + p;
+  }
+  const bool diag = bi == bj;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_split;
+  const int64_t r1 = r0 + rows_per_split < R ? r0 + rows_per_split : R;
+  const int nstage = r1 > r0 ? (int)((r1 - r0 + BKR - 1) / BKR) : 0;
+
+  // staging context: slot -> (row, physical 16-byte slot); the source is the logical slot of that row
+  int st_row[G::LD], st_col[G::LD];
+#pragma unroll
+  for (int i = 0; i < G::LD; ++i) {
+    const int slot = i * 256 + tid;
+    const int row = slot / (NB / 8), pq = slot % (NB / 8);
+    st_row[i] = row;
+    st_col[i] = (pq ^ (gram16_swz<NB>(row) << 2)) * 8;  // logical channel offset inside the panel
+  }
+  auto stage = [&](int s, int buf) {
+    char* base = smem + buf * G::STAGE;
+    const int64_t rb = r0 + (int64_t)s * BKR;
+#pragma unroll
+    for (int pnl = 0; pnl < 2; ++pnl) {
+      if (pnl == 1 && diag) break;
+      const int cb = (pnl ? bj : bi) * NB;
+#pragma unroll
+      for (int i = 0; i < G::LD; ++i) {
+        const int64_t r = rb + st_row[i];
+        const bool ok = r < r1;
+        const int64_t e = r * C + cb + st_col[i];
+        char* d = base + pnl * G::PANEL + (i * 256 + wave * 64) * 16;
+        __builtin_amdgcn_global_load_lds((gbl_void16*)(ok ? Xh + e : zero16), (lds_void16*)d, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void16*)(ok ? Xl + e : zero16), (lds_void16*)(d + G::PLANE), 16, 0, 0);
+      }
+    }
+  };
+
+  // which tiles this wave owns
+  const int wr = KW == 4 ? 0 : (wave >> 1), wc = KW == 4 ? 0 : (wave & 1);  // quadrant of the NB x NB block
+  const bool wave_active = !(KW == 1 && diag && wr > wc);
+  f32x16 acc[TW][TW];
+#pragma unroll
+  for (int a = 0; a < TW; ++a)
+#pragma unroll
+    for (int b = 0; b < TW; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // fragment geometry of this lane
+  const int grp = lane >> 4, r16 = lane & 15;
+  const int f_row = (grp >> 1) * 8 + (r16 >> 2);        // + j * 4 + k16 * 16
+  const int f_col = (grp & 1) * 16 + (r16 & 3) * 4;     // + tile * 32 (+ quadrant * 64)
+
+  auto load_frag = [&](const char* plane, int k16, int col0) -> f16x8 {
+    f16x8 out;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = k16 * 16 + f_row + j * 4;
+      const int col = col0 + f_col;
+      const int off = row * G::PITCH + (((col >> 5) ^ gram16_swz<NB>(row)) << 6) + (col & 31) * 2;
+      const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(plane + off));
+      const f16x4 f = __builtin_bit_cast(f16x4, v);
+      out[4 * j] = f[0], out[4 * j + 1] = f[1], out[4 * j + 2] = f[2], out[4 * j + 3] = f[3];
+    }
+    return out;
+  };
+
+  if (nstage > 0) stage(0, 0);
+  for (int s = 0; s < nstage; ++s) {
+    const int buf = s & 1;
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+    __syncthreads();
+    if (s + 1 < nstage) stage(s + 1, buf ^ 1);
+    if (!wave_active) continue;
+    const char* pa = smem + buf * G::STAGE;
+    const char* pb = diag ? pa : pa + G::PANEL;
+#pragma unroll
+    for (int kk = 0; kk < (KW == 4 ? 1 : BKR / 16); ++kk) {
+      const int k16 = KW == 4 ? wave : kk;
+      f16x8 ah[TW], al[TW], bh[TW], bl[TW];
+#pragma unroll
+      for (int a = 0; a < TW; ++a) {
+        ah[a] = load_frag(pa, k16, wr * 64 + a * 32);
+        al[a] = load_frag(pa + G::PLANE, k16, wr * 64 + a * 32);
+      }
+#pragma unroll
+      for (int b = 0; b < TW; ++b) {
+        bh[b] = load_frag(pb, k16, wc * 64 + b * 32);
+        bl[b] = load_frag(pb + G::PLANE, k16, wc * 64 + b * 32);
+      }
+#pragma unroll
+      for (int a = 0; a < TW; ++a)
+#pragma unroll
+        for (int b = 0; b < TW; ++b) {
+          if (diag && wr == wc && a > b) continue;  // lower-triangle tile of a diagonal quadrant
+          f32x16 c = acc[a][b];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], c, 0, 0, 0);
+          acc[a][b] = c;
+        }
+    }
+  }
+
+  // partial block of this workgroup: ws[(split * npairs + pair)][NB][NB].  KW = 4: the four waves hold partial sums
+  // of the SAME tiles (they split k); they are added in wave order through LDS (the stage buffers are free now).
+  const int lr = lane & 31, lh = lane >> 5;
+  float* blk = ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (NB * NB);
+  if (KW == 4) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);  // [wave][tile (a, b)][32 x 32]
+#pragma unroll
+    for (int a = 0; a < TW; ++a)
+#pragma unroll
+      for (int b = 0; b < TW; ++b) {
+        if (a > b) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          red[((wave * TW + a) * TW + b) * 1024 + row * 32 + lr] = acc[a][b][r];
+        }
+      }
+    __syncthreads();
+    for (int e = tid; e < TW * TW * 1024; e += 256) {
+      const int t = e >> 10, a = t / TW, b = t % TW;
+      if (a > b) continue;
+      const float v = ((red[e] + red[TW * TW * 1024 + e]) + red[2 * TW * TW * 1024 + e]) + red[3 * TW * TW * 1024 + e];
+      const int row = (e >> 5) & 31, col = e & 31;
+      blk[(a * 32 + row) * NB + b * 32 + col] = v;
+    }
+    return;
+  }
+  if (!wave_active) return;
+#pragma unroll
+  for (int a = 0; a < TW; ++a)
+#pragma unroll
+    for (int b = 0; b < TW; ++b) {
+      if (diag && wr == wc && a > b) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int col = wc * 64 + b * 32 + lr;
+        blk[row * NB + col] = acc[a][b][r];
+      }
+    }
+}
+
+// G[upper tiles] += alpha * 2^(-2 sexp) * sum_partials, in a FIXED order: a workgroup owns 32 consecutive elements of one
+// tile row; its 8 lane groups each sum every 8th partial (coalesced 128-byte reads), then the 8 sums are added in order.
+template <int NB>
+__global__ __launch_bounds__(256) void gram16_reduce_kernel(const float* __restrict__ ws, int nparts, int npairs, int nbc,
+                                                            int C, const int* __restrict__ sexp, float alpha,
+                                                            float* __restrict__ Gm) {
+  __shared__ float red[8][32];
+  const int pair = blockIdx.y;
+  int bi = 0, bj = 0;
+  {
+    int p = pair;
+    while (p >= nbc - bi) p -= nbc - bi, ++bi;
+    bj = bi + p;
+  }
+  const int el = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  const int e = blockIdx.x * 32 + el;  // element of the NB x NB block; the 32 of a workgroup share one tile row
+  const int row = e / NB, col = e % NB;
+  if (bi == bj && (row >> 5) > (col >> 5)) return;  // tile below the diagonal of a diagonal block: never computed
+  float s = 0.f;
+  for (int p = pl; p < nparts; p += 8) s += ws[((int64_t)p * npairs + pair) * (NB * NB) + e];
+  red[pl][el] = s;
+  __syncthreads();
+  if (pl == 0) {
+    float t = red[0][el];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += red[k][el];
+    const float inv = exp2i16(-sexp[0]);
+    Gm[(int64_t)(bi * NB + row) * C + bj * NB + col] += alpha * (t * inv) * inv;
+  }
+}
+
+}  // namespace lk
+
+using namespace lk;
+
+extern "C" int lk_vjp_nhwc_split_f16x2(const float* g, const unsigned* g_amax, const void* g2_h, const void* g2_l,
+                                       const int* g2_sexp, const void* m, int m_is_float, const unsigned* m_amax,
+                                       const float* scale, const unsigned* scale_amax, int64_t C, int64_t S, int64_t per,
+                                       void* out_h, void* out_l, int* out_sexp, void* stream) {
+  LK_REQUIRE((g || g2_h) && out_h && out_l && out_sexp && S >= 0 && per >= 0, "lk_vjp_nhwc_split_f16x2: bad arguments");
+  LK_REQUIRE(!g || g_amax, "lk_vjp_nhwc_split_f16x2: the fp32 addend needs its max|.| word");
+  LK_REQUIRE(!g2_h || (g2_l && g2_sexp), "lk_vjp_nhwc_split_f16x2: incomplete split addend");
+  LK_REQUIRE(!scale || (scale_amax && C >= 8 && C % 8 == 0 && per % C == 0), "lk_vjp_nhwc_split_f16x2: scale needs C % 8 == 0");
+  LK_REQUIRE(per % 8 == 0 && S < (1 << 30), "lk_vjp_nhwc_split_f16x2: per % 8 == 0");
+  if (S == 0 || per == 0) return LK_OK;
+  const int64_t per8 = per / 8, nb = (per8 + 255) / 256;
+  LK_REQUIRE(nb < (1ll << 31), "lk_vjp_nhwc_split_f16x2: grid too large");
+  hipStream_t st = (hipStream_t)stream;
+  if (m && m_is_float)
+    hipLaunchKernelGGL(vjp_nhwc_split_kernel<true>, dim3((unsigned)nb), dim3(256), 0, st, g, g_amax, (const _Float16*)g2_h,
+                       (const _Float16*)g2_l, g2_sexp, m, m_amax, scale, scale_amax, (int)(scale ? C : 8), (int)S, per8,
+                       (_Float16*)out_h, (_Float16*)out_l, out_sexp);
+  else
+    hipLaunchKernelGGL(vjp_nhwc_split_kernel<false>, dim3((unsigned)nb), dim3(256), 0, st, g, g_amax, (const _Float16*)g2_h,
+                       (const _Float16*)g2_l, g2_sexp, m, m_amax, scale, scale_amax, (int)(scale ? C : 8), (int)S, per8,
+                       (_Float16*)out_h, (_Float16*)out_l, out_sexp);
+  return check_launch("vjp_nhwc_split_kernel");
+}
+
+namespace {
+struct Gram16Plan {
+  int nb, nbc, npairs, kw, bkr;
+  int64_t nsplit, rows_per_split, nparts;
+};
+Gram16Plan gram16_plan(int64_t R, int64_t C) {
+  Gram16Plan p;
+  p.nb = C == 64 ? 64 : 128;
+  p.kw = C == 64 ? 4 : 1;
+  p.bkr = C == 64 ? 64 : 32;
+  p.nbc = (int)(C / p.nb);
+  p.npairs = p.nbc * (p.nbc + 1) / 2;
+  // two workgroups per CU, slices of whole stages, at least 8 stages per slice
+  int64_t want = (512 + p.npairs - 1) / p.npairs;
+  int64_t stages = (R + p.bkr - 1) / p.bkr;
+  int64_t per = (stages + want - 1) / want;
+  if (per < 8) per = 8;
+  p.rows_per_split = per * p.bkr;
+  p.nsplit = (R + p.rows_per_split - 1) / p.rows_per_split;
+  if (p.nsplit < 1) p.nsplit = 1;
+  p.nparts = p.nsplit;  // (the k-waves of a workgroup are summed inside it)
+  return p;
+}
+}  // namespace
+
+extern "C" size_t lk_gram_tn_f16x2_workspace_bytes(int64_t R, int64_t C) {
+  if (C < 64 || (C != 64 && C % 128)) return 0;
+  const Gram16Plan p = gram16_plan(R, C);
+  return (size_t)p.nparts * p.npairs * p.nb * p.nb * sizeof(float);
+}
+
+// G[C][C] (upper 32x32 tiles) += alpha * X^T X for the split tensor X [R][C]; C = 64 or a multiple of 128.
+extern "C" int lk_gram_tn_f16x2(const void* x_h, const void* x_l, const int* sexp, int64_t R, int64_t C, float alpha,
+                                float* Gm, const void* zero16, void* ws, size_t ws_bytes, void* stream) {
+  LK_REQUIRE(x_h && x_l && sexp && Gm && zero16 && ws && R >= 0, "lk_gram_tn_f16x2: null pointer");
+  LK_REQUIRE(C == 64 || (C >= 128 && C % 128 == 0 && C <= 4096), "lk_gram_tn_f16x2: C must be 64 or a multiple of 128");
+  if (R == 0) return LK_OK;
+  const Gram16Plan p = gram16_plan(R, C);
+  LK_REQUIRE(ws_bytes >= lk_gram_tn_f16x2_workspace_bytes(R, C), "lk_gram_tn_f16x2: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)p.npairs, (unsigned)p.nsplit);
+  if (C == 64) {
+    using Gc = Gram16Cfg<64, 64, 4>;
+    hipLaunchKernelGGL((gram16_kernel<64, 64, 4>), grid, dim3(256), 2 * Gc::STAGE, st, (const _Float16*)x_h,
+                       (const _Float16*)x_l, R, (int)C, p.rows_per_split, (const _Float16*)zero16, (float*)ws, p.nbc);
+  } else {
+    using Gc = Gram16Cfg<128, 32, 1>;
+    hipLaunchKernelGGL((gram16_kernel<128, 32, 1>), grid, dim3(256), 2 * Gc::STAGE, st, (const _Float16*)x_h,
+                       (const _Float16*)x_l, R, (int)C, p.rows_per_split, (const _Float16*)zero16, (float*)ws, p.nbc);
+  }
+  int rc = check_launch("gram16_kernel");
+  if (rc != LK_OK) return rc;
+  dim3 rgrid((unsigned)(p.nb * p.nb / 32), (unsigned)p.npairs);
+  if (C == 64)
+    hipLaunchKernelGGL(gram16_reduce_kernel<64>, rgrid, dim3(256), 0, st, (const float*)ws, (int)p.nparts, p.npairs, p.nbc,
+                       (int)C, sexp, alpha, Gm);
+  else
+    hipLaunchKernelGGL(gram16_reduce_kernel<128>, rgrid, dim3(256), 0, st, (const float*)ws, (int)p.nparts, p.npairs, p.nbc,
+                       (int)C, sexp, alpha, Gm);
+  return check_launch("gram16_reduce_kernel");
+}

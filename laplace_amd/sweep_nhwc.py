@@ -1,0 +1,336 @@
+"""The reverse sweep on NHWC split-fp16 cotangents: our own convolution kernels instead of MIOpen's.
+
+:class:`laplace_amd.sweep.SeedBatchedSweep` walks the traced graph backwards with ONE cotangent of batch ``S*B`` and
+hands every convolution to the library's fp32 backward-data (60 % of a ResNet-18 KFAC step).  This subclass keeps the
+graph walk and replaces the data path (SURVEY.md §8f-1 "our own layer-local backward"; the reverse passes of
+laplace/curvature/curvlinops.py:87-100):
+
+* cotangents of feature maps live in HBM as NHWC *split tensors* — two fp16 planes and a power-of-two scale
+  (csrc/lk_conv.hip) — produced by the element-wise VJP kernel ``lk_vjp_nhwc_split_f16x2`` (activation mask x folded
+  BatchNorm scale x residual add, all seeds in one pass);
+* a convolution's backward-data is ``lk_conv_nhwc_f16x2`` (implicit GEMM, three fp16 MFMAs per fp32 product block),
+  writing fp32 NHWC plus max|.| for the next producer's scale; a strided 1x1 down-sampling branch ACCUMULATES into
+  the main branch's result instead of materialising its three-quarters-zero cotangent;
+* the G factor of a convolution layer is the Gram of the split tensor itself (``lk_gram_tn_f16x2``).
+
+Graphs with nodes this path has no rule for (pooling other than the global average, convolutions whose channel counts
+are not multiples of 32, ...) run through the parent class unchanged.
+"""
+from __future__ import annotations
+
+import operator
+
+import torch
+import torch.fx as fx
+import torch.nn.functional as F
+from torch import nn
+
+from laplace_amd import conv as cv
+from laplace_amd._lib import SplitTensor
+from laplace_amd.sweep import SeedBatchedSweep, SweepUnsupported
+
+
+class _F32:
+    """fp32 NHWC cotangent ``[S*B, H, W, C]`` + device word with the bit pattern of max|.|"""
+
+    __slots__ = ("t", "amax")
+
+    def __init__(self, t, amax):
+        self.t, self.amax = t, amax
+
+
+class SplitSweep(SeedBatchedSweep):
+    """Seed-batched reverse sweep whose feature-map cotangents are NHWC split tensors (needs the HIP kernels)."""
+
+    def __init__(self, model, tap_modules, kernels=None):
+        super().__init__(model, tap_modules, kernels)
+        self._prep: dict[str, cv.PreparedConv] = {}
+        self._amax_cache: dict = {}
+        self.split_reason = self._split_eligible()
+        self.split_ok = self.split_reason is None
+
+    # ---- static eligibility ---------------------------------------------------------------------------------------
+    def _split_eligible(self):
+        if self.kernels is None or not hasattr(self.kernels(), "conv_nhwc_f16x2"):
+            return "kernels without the split-fp16 convolution"
+        n_conv = 0
+        for node in self.gm.graph.nodes:
+            if node.op == "call_module":
+                m = self.modules[node.target]
+                if isinstance(m, nn.Conv2d):
+                    src = node.args[0]
+                    first = isinstance(src, fx.Node) and src.op == "placeholder"
+                    if not cv.supported(m) and not (first and node.target in self.tap_names and m.out_channels % 8 == 0):
+                        return f"{node.target}: convolution outside the implicit-GEMM kernel's coverage"
+                    n_conv += 1
+                elif isinstance(m, (nn.MaxPool2d, nn.AvgPool2d, nn.BatchNorm1d)):
+                    return f"{node.target}: {type(m).__name__} has no NHWC rule"
+                elif isinstance(m, nn.AdaptiveAvgPool2d) and tuple(self._pair2(m.output_size)) != (1, 1):
+                    return f"{node.target}: adaptive pooling to more than one cell"
+            elif node.op == "call_function":
+                if node.target in (F.max_pool2d, F.avg_pool2d, torch.mean, operator.getitem):
+                    return f"{getattr(node.target, '__name__', node.target)} has no NHWC rule"
+            elif node.op == "call_method" and node.target in ("mean", "size"):
+                return f"method {node.target} has no NHWC rule"
+        return None if n_conv else "no convolution in the graph"
+
+    # ---- helpers ----------------------------------------------------------------------------------------------------
+    def _amax_of(self, key, t):
+        """device word with max|t| of a per-model constant (BatchNorm scale), cached until it changes"""
+        k = (t._version, t.data_ptr())
+        hit = self._amax_cache.get(key)
+        if hit is None or hit[0] != k:
+            hit = (k, self.kernels().absmax(t.contiguous()))
+            self._amax_cache[key] = hit
+        return hit[1]
+
+    def _nhwc_mult(self, node, kind):
+        """per-sample multiplier of an activation as an NHWC tensor (+ its max| | word for generic derivatives)"""
+        hit = self._mult_cache.get(node)
+        if hit is None:
+            saved = self.saved[node]
+            mult = self._act_mult(kind, saved)
+            if mult.dim() != 4:
+                raise SweepUnsupported("activation on a non-feature-map tensor inside the NHWC region")
+            amax = None
+            if mult.dtype == torch.bool:
+                mult = mult.permute(0, 2, 3, 1).contiguous().view(torch.uint8)
+            else:
+                mult = mult.to(torch.float32).permute(0, 2, 3, 1).contiguous()
+                generic = isinstance(kind, self._GENERIC_ACT_MODULES) or (callable(kind) and kind in self._GENERIC_ACT_FN)
+                if generic:  # tanh' and sigmoid' are bounded by 1; anything else is measured
+                    amax = self.kernels().absmax(mult)
+            hit = (mult, amax)
+            self._mult_cache[node] = hit
+        return hit
+
+    def _to_split(self, parts, S, mult=None, mult_amax=None, scale=None, scale_amax=None):
+        """sum of cotangent parts (x multiplier x channel scale) -> one SplitTensor"""
+        K = self.kernels()
+        f32 = [p for p in parts if isinstance(p, _F32)]
+        spl = [p for p in parts if isinstance(p, SplitTensor)]
+        if len(f32) > 1:  # (no graph of the supported families gets here: two un-activated conv branches joining)
+            t = f32[0].t
+            for p in f32[1:]:
+                t = t + p.t
+            f32 = [_F32(t, K.absmax(t))]
+        if len(spl) > 1:  # several split addends (rare: joins of more than two branches): fold them through fp32
+            t = spl[0].float()
+            for p in spl[1:]:
+                t = t + p.float()
+            if f32:
+                t = t + f32[0].t
+            t = t.contiguous()
+            f32, spl = [_F32(t, K.absmax(t))], []
+        g = f32[0] if f32 else None
+        g2 = spl[0] if spl else None
+        if g is None and mult is None and scale is None:
+            return g2
+        shape = g.t.shape if g is not None else g2.shape
+        return K.vjp_nhwc_split(None if g is None else g.t, None if g is None else g.amax, g2, mult, mult_amax, scale,
+                                scale_amax, S, tuple(shape))
+
+    # ---- reverse sweep ------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def backward(self, seeds, on_tap=None, defer_bn_scale: bool = False):
+        if not self.split_ok:
+            return super().backward(seeds, on_tap=on_tap, defer_bn_scale=defer_bn_scale)
+        K = self.kernels()
+        self.grad_scale = {}
+        self._mult_cache = {}
+        pending_scale: dict[fx.Node, torch.Tensor] = {}
+        deferred: dict[fx.Node, list] = {}
+        S, B = seeds.shape[0], seeds.shape[1]
+        SB = S * B
+        cot: dict[fx.Node, list] = {self.out_node: [seeds.reshape(SB, *seeds.shape[2:])]}
+        grads: dict = {}
+        remaining = set(self.tap_names)
+        words = torch.zeros(64, dtype=torch.float32, device=seeds.device)  # max|.| words of this sweep's conv outputs
+        word_i = [0]
+
+        def new_word():
+            nonlocal words
+            if word_i[0] == words.numel():
+                words = torch.zeros(64, dtype=torch.float32, device=seeds.device)
+                word_i[0] = 0
+            w = words[word_i[0]:word_i[0] + 1]
+            word_i[0] += 1
+            return w
+
+        def push(n, part):
+            if not isinstance(n, fx.Node) or n.op == "placeholder":
+                return
+            if isinstance(part, _F32) and n in deferred:
+                for fn in deferred.pop(n):  # strided 1x1 branches waiting for the main branch's tensor: add into it
+                    fn(part)
+            cot.setdefault(n, []).append(part)
+
+        def feature_f32(t4_nchw_like):
+            """fp32 [S*B, C, H, W]-shaped tensor -> NHWC _F32"""
+            t = t4_nchw_like.permute(0, 2, 3, 1).contiguous()
+            return _F32(t, K.absmax(t))
+
+        def is4(node):
+            shp = self.saved.get(node)
+            return shp is not None
+
+        for node in reversed(list(self.gm.graph.nodes)):
+            if node.op in ("placeholder", "output"):
+                continue
+            if node in deferred and node not in cot:
+                # nothing else reached this node: the deferred branches produce the cotangent on their own
+                fns = deferred.pop(node)
+                part = fns[0](None)
+                for fn in fns[1:]:
+                    fn(part)
+                cot[node] = [part]
+            if node not in cot:
+                continue
+            parts = cot.pop(node)
+            if node in deferred:
+                f32p = [p for p in parts if isinstance(p, _F32)]
+                fns = deferred.pop(node)
+                if f32p:
+                    for fn in fns:
+                        fn(f32p[0])
+                else:
+                    part = fns[0](None)
+                    for fn in fns[1:]:
+                        fn(part)
+                    parts.append(part)
+            flat = all(torch.is_tensor(p) for p in parts)  # still in the head (Linear / flatten) region
+            if node.op == "call_module":
+                m = self.modules[node.target]
+                src = node.args[0]
+                if isinstance(m, nn.Conv2d):
+                    g = self._to_split(parts, S)
+                    if node.target in self.tap_names:
+                        grads[node.target] = g
+                        if node in pending_scale:
+                            self.grad_scale[node.target] = pending_scale[node]
+                        if on_tap is not None:
+                            on_tap(node.target, g)
+                        remaining.discard(node.target)
+                        if not remaining:
+                            break
+                    if not (isinstance(src, fx.Node) and src.op != "placeholder"):
+                        continue
+                    prep = self._prep.get(node.target)
+                    if prep is None:
+                        prep = self._prep[node.target] = cv.PreparedConv(m)
+                    in_shape = self.saved[node]  # [B, Cin, Hin, Win]
+                    hw = (int(in_shape[2]), int(in_shape[3]))
+                    cscale = pending_scale.get(node)
+                    sparse = any(not p[4] for p in cv.backward_plan(m, *hw))
+
+                    def run(into, g=g, prep=prep, hw=hw, cscale=cscale):
+                        if into is None:
+                            w = new_word()
+                            out = cv.conv_backward_data(prep, g, hw, cscale=cscale, amax_out=w)
+                            return _F32(out, w)
+                        cv.conv_backward_data(prep, g, hw, cscale=cscale, out=into.t, accumulate=True, amax_out=into.amax)
+                        return into
+
+                    existing = [p for p in cot.get(src, []) if isinstance(p, _F32)]
+                    if existing:
+                        run(existing[0])
+                    elif sparse and len(src.users) > 1:
+                        deferred.setdefault(src, []).append(run)  # wait for the dense branch, then add into it
+                    else:
+                        push(src, run(None))
+                elif isinstance(m, nn.Linear):
+                    g = parts[0] if len(parts) == 1 else sum(parts[1:], parts[0])
+                    if not torch.is_tensor(g):
+                        raise SweepUnsupported("Linear layer inside the NHWC region")
+                    if node.target in self.tap_names:
+                        grads[node.target] = g.reshape(S, B, *g.shape[1:])
+                        if on_tap is not None:
+                            on_tap(node.target, grads[node.target])
+                        remaining.discard(node.target)
+                        if not remaining:
+                            break
+                    push(src, g @ m.weight)
+                elif isinstance(m, nn.BatchNorm2d):
+                    scale = self._bn_scale(node.target, m)
+                    if (defer_bn_scale and isinstance(src, fx.Node) and src.op == "call_module" and len(src.users) == 1
+                            and isinstance(self.modules[src.target], nn.Conv2d) and src.target in self.tap_names
+                            and src not in cot and len(parts) == 1 and isinstance(parts[0], SplitTensor)):
+                        pending_scale[src] = scale
+                        push(src, parts[0])
+                    else:
+                        push(src, self._to_split(parts, S, scale=scale, scale_amax=self._amax_of(node.target, scale)))
+                elif isinstance(m, (nn.ReLU, nn.Tanh, nn.Sigmoid) + self._GENERIC_ACT_MODULES):
+                    self._activation(node, m, src, parts, S, push, flat)
+                elif isinstance(m, (nn.Identity, nn.Dropout)):
+                    for p in parts:
+                        push(src, p)
+                elif isinstance(m, nn.Flatten):
+                    self._unflatten(node, src, parts, SB, push, feature_f32)
+                elif isinstance(m, nn.AdaptiveAvgPool2d):
+                    self._global_pool(node, src, parts, SB, push, K)
+                else:
+                    raise SweepUnsupported(f"no NHWC rule for {type(m).__name__}")
+            elif node.op == "call_function":
+                t = node.target
+                if t in (operator.add, torch.add, operator.iadd):
+                    for a in node.args[:2]:
+                        for p in parts:
+                            push(a, p)
+                elif t in self._ELEMENTWISE_FN or t in self._GENERIC_ACT_FN:
+                    self._activation(node, t, node.args[0], parts, S, push, flat)
+                elif t is torch.flatten:
+                    self._unflatten(node, node.args[0], parts, SB, push, feature_f32)
+                elif t is F.adaptive_avg_pool2d:
+                    self._global_pool(node, node.args[0], parts, SB, push, K)
+                else:
+                    raise SweepUnsupported(f"no NHWC rule for {getattr(t, '__name__', t)}")
+            elif node.op == "call_method":
+                t = node.target
+                if t in ("relu", "tanh", "sigmoid"):
+                    self._activation(node, t, node.args[0], parts, S, push, flat)
+                elif t in ("view", "reshape", "flatten"):
+                    self._unflatten(node, node.args[0], parts, SB, push, feature_f32)
+                elif t == "contiguous":
+                    for p in parts:
+                        push(node.args[0], p)
+                else:
+                    raise SweepUnsupported(f"no NHWC rule for method {t}")
+        if remaining:
+            raise SweepUnsupported(f"no cotangent reached {sorted(remaining)}")
+        if on_tap is None:
+            # consumers that read the gradients as tensors (Jacobians, diagonal, predictive): [S, B, C, H, W] fp32
+            for name, g in list(grads.items()):
+                if isinstance(g, SplitTensor):
+                    grads[name] = g.float().reshape(S, B, *g.shape[1:]).permute(0, 1, 4, 2, 3).contiguous()
+        return grads
+
+    # ---- node rules ---------------------------------------------------------------------------------------------------
+    def _activation(self, node, kind, src, parts, S, push, flat):
+        if flat:  # activation in the head region (MLP head after the flatten): parent-class math on plain tensors
+            g = parts[0] if len(parts) == 1 else sum(parts[1:], parts[0])
+            scale, dst = self._fold_bn(src)
+            push(dst, self._scale_mask(g, S, self._act_mult(kind, self.saved[node]), scale))
+            return
+        mult, mult_amax = self._nhwc_mult(node, kind)
+        scale, dst = self._fold_bn(src)
+        scale_amax = None
+        if scale is not None:
+            scale_amax = self._amax_of(src.target, scale)
+        push(dst, self._to_split(parts, S, mult=mult, mult_amax=mult_amax, scale=scale, scale_amax=scale_amax))
+
+    def _unflatten(self, node, src, parts, SB, push, feature_f32):
+        g = parts[0] if len(parts) == 1 else sum(parts[1:], parts[0])
+        if not torch.is_tensor(g):
+            raise SweepUnsupported("reshape inside the NHWC region")
+        shp = tuple(self.saved[node])
+        g = g.reshape((SB,) + shp[1:])
+        push(src, feature_f32(g) if g.dim() == 4 else g)
+
+    def _global_pool(self, node, src, parts, SB, push, K):
+        shp = self.saved[node]  # [B, C, H, W]
+        p = parts[0]
+        if len(parts) != 1 or not isinstance(p, _F32):
+            raise SweepUnsupported("global average pooling expects one fp32 cotangent")
+        H, W = int(shp[-2]), int(shp[-1])
+        t = (p.t / (H * W)).expand(SB, H, W, p.t.shape[-1]).contiguous()
+        push(src, _F32(t, K.absmax(t)))

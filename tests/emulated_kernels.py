@@ -42,6 +42,99 @@ class EmulatedKernels:
     def sq_err_sum(self, f, y, scale, loss_accum):
         loss_accum += scale * ((f - y) ** 2).sum()
 
+    # split-fp16 convolution family (csrc/lk_conv.hip, lk_sweep16.hip): same splits, fp32 products
+    conv_config = 0
+
+    @staticmethod
+    def _sexp_for(amax):
+        import math
+
+        a = float(amax)
+        if not (a > 0) or a < 2.0 ** -126:
+            return 120
+        return min(120, 14 - math.floor(math.log2(a)))
+
+    @staticmethod
+    def _split(x, s):
+        from laplace_amd._lib import SplitTensor
+
+        xs = x.float() * (2.0 ** s)
+        h = xs.half()
+        l = (xs - h.float()).half()
+        return SplitTensor(torch.stack([h, l]), torch.tensor([s], dtype=torch.int32))
+
+    def absmax(self, x, out=None):
+        v = x.abs().max().reshape(1).float() if x.numel() else torch.zeros(1)
+        if out is not None:
+            out.copy_(v)
+            return out
+        return v
+
+    def split_f16x2(self, x, amax=None, bound_mul=1.0):
+        if amax is None:
+            amax = self.absmax(x)
+        return self._split(x, self._sexp_for(float(amax[0]) * bound_mul))
+
+    def conv_prep_weights(self, W, transpose, cscale=None):
+        Wf = W.float()
+        if cscale is not None:
+            Wf = Wf * cscale.reshape(-1, 1, 1, 1)
+        Co, Ci = Wf.shape[:2]
+        Wt = Wf.reshape(Co, Ci, -1).permute(2, 1, 0) if transpose else Wf.reshape(Co, Ci, -1).permute(2, 0, 1)
+        st = self._split(Wt.contiguous(), self._sexp_for(Wt.abs().max()))
+        return st.planes, st.sexp
+
+    def conv_nhwc_f16x2(self, x, wplanes, wsexp, Hc, Wc, in_mul, out, out_step, oh0, ow0, taps, accumulate=False,
+                        amax_out=None, config=None):
+        xin = x.float()                                               # [N, Hi, Wi, Ci]
+        w = (wplanes[0].float() + wplanes[1].float()) * 2.0 ** (-int(wsexp[0]))  # [T, Co, Ci]
+        N, Hi, Wi, Ci = xin.shape
+        res = torch.zeros(N, Hc, Wc, w.shape[1])
+        ii, jj = torch.arange(Hc) * in_mul, torch.arange(Wc) * in_mul
+        for dh, dw, wt in taps:
+            hh, ww = ii + dh, jj + dw
+            vh, vw = (hh >= 0) & (hh < Hi), (ww >= 0) & (ww < Wi)
+            xt = xin[:, hh.clamp(0, Hi - 1)][:, :, ww.clamp(0, Wi - 1)]
+            xt = xt * (vh[:, None] & vw[None, :])[None, :, :, None]
+            res += torch.einsum("nijc,oc->nijo", xt, w[wt])
+        view = out[:, oh0::out_step, ow0::out_step][:, :Hc, :Wc]
+        if accumulate:
+            view += res
+        else:
+            view.copy_(res)
+        if amax_out is not None:
+            amax_out.copy_(torch.maximum(amax_out, view.abs().max().reshape(1)))
+        return out
+
+    def vjp_nhwc_split(self, g, g_amax, g2, mult, mult_amax, scale, scale_amax, S, out_shape):
+        bound = 0.0
+        v = torch.zeros(out_shape)
+        if g is not None:
+            v = v + g
+            bound += float(g_amax[0])
+        if g2 is not None:
+            v = v + g2.float()
+            bound += 2.0 ** (15 - int(g2.sexp[0]))
+        if mult is not None:
+            mf = mult.float() if mult.dtype != torch.uint8 else (mult != 0).float()
+            v = (v.reshape(S, *mf.shape) * mf).reshape(out_shape)
+            if mult.dtype == torch.float32 and mult_amax is not None:
+                bound *= float(mult_amax[0])
+        if scale is not None:
+            v = v * scale
+            bound *= float(scale_amax[0])
+        assert float(v.abs().max()) <= bound * (1 + 1e-6) + 1e-30, "the guaranteed bound of the VJP output does not hold"
+        return self._split(v, self._sexp_for(bound))
+
+    def gram_tn_f16x2(self, x, alpha, out):
+        C = x.planes.shape[-1]
+        X = x.float().reshape(-1, C)
+        Gm = X.T @ X
+        idx = torch.arange(C) // 32
+        upper = idx[:, None] <= idx[None, :]
+        out += alpha * Gm * upper
+        return out
+
     # Gram family
     def gram_tn(self, X, alpha, out, upper_only=False):
         out += alpha * (X.T @ X)

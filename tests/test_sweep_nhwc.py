@@ -1,0 +1,113 @@
+"""Host logic of the NHWC split-fp16 reverse sweep (laplace_amd/sweep_nhwc.py) on the CPU emulation of its kernels:
+graph walk, residual joins (identity and strided 1x1 down-sampling with accumulate-into), deferred BatchNorm scales,
+the guaranteed scale bounds of the element-wise VJP, and the hand-over of split tensors to the consumers — against one
+stock autograd pass per seed.  (The kernels themselves: tests/test_gpu_conv.py, tests/test_gpu_sweep_nhwc.py.)"""
+import pytest
+import torch
+from torch import nn
+
+from laplace_amd import _lib
+from laplace_amd._lib import SplitTensor, get_kernels
+from laplace_amd.nets import BasicBlock
+from laplace_amd.sweep_nhwc import SplitSweep
+from tests.emulated_kernels import EmulatedKernels
+
+
+@pytest.fixture(autouse=True)
+def _emulated():
+    prev = _lib.set_kernels_for_testing(EmulatedKernels())
+    yield
+    _lib.set_kernels_for_testing(prev)
+
+
+class TinyResNet(nn.Module):
+    def __init__(self, act=torch.relu, width=32, num_classes=5):
+        super().__init__()
+        self.act = act
+        self.conv1 = nn.Conv2d(3, width, 3, 1, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(width)
+        self.layers = nn.Sequential(BasicBlock(width, width, 1, act), BasicBlock(width, 2 * width, 2, act),
+                                    BasicBlock(2 * width, 2 * width, 1, act))
+        self.pool = nn.AdaptiveAvgPool2d(1)
+        self.fc = nn.Linear(2 * width, num_classes)
+
+    def forward(self, x):
+        x = self.act(self.bn1(self.conv1(x)))
+        x = self.layers(x)
+        return self.fc(torch.flatten(self.pool(x), 1))
+
+
+def _model(act):
+    torch.manual_seed(3)
+    m = TinyResNet(act).eval()
+    for mod in m.modules():
+        if isinstance(mod, nn.BatchNorm2d):  # non-trivial eval-mode statistics and affine maps
+            mod.running_mean.normal_(0, 0.3)
+            mod.running_var.uniform_(0.5, 2.0)
+            mod.weight.data.uniform_(0.5, 1.5)
+            mod.bias.data.normal_(0, 0.2)
+            mod.weight.requires_grad_(False), mod.bias.requires_grad_(False)
+    return m
+
+
+def _autograd_tap_grads(model, taps, x, seeds):
+    outs = {}
+    hs = [m.register_forward_hook(lambda m_, i, o, n=n: outs.__setitem__(n, o)) for n, m in taps.items()]
+    f = model(x)
+    for h in hs:
+        h.remove()
+    res = {n: [] for n in taps}
+    for s in range(seeds.shape[0]):
+        grads = torch.autograd.grad(f, [outs[n] for n in taps], grad_outputs=seeds[s], retain_graph=True)
+        for n, g in zip(taps, grads):
+            res[n].append(g)
+    return f.detach(), {n: torch.stack(v) for n, v in res.items()}
+
+
+@pytest.mark.parametrize("act", [torch.relu, torch.tanh])
+@pytest.mark.parametrize("defer", [False, True])
+def test_split_sweep_matches_per_seed_autograd(act, defer):
+    model = _model(act)
+    taps = {n: m for n, m in model.named_modules() if isinstance(m, (nn.Conv2d, nn.Linear))}
+    sw = SplitSweep(model, taps, kernels=get_kernels)
+    assert sw.split_ok, sw.split_reason
+    torch.manual_seed(0)
+    x = torch.randn(4, 3, 8, 8)
+    seeds = torch.randn(3, 4, 5)
+    f = sw.forward(x)
+    seen = []
+    got = sw.backward(seeds, on_tap=lambda n, g: seen.append(n), defer_bn_scale=defer)
+    f_ref, want = _autograd_tap_grads(model, taps, x, seeds)
+    assert torch.allclose(f, f_ref, atol=1e-5)
+    assert set(seen) == set(taps)
+    for n in taps:
+        g = got[n]
+        if isinstance(g, SplitTensor):
+            g = g.float().reshape(3, 4, *g.shape[1:]).permute(0, 1, 4, 2, 3)
+        if defer and n in sw.grad_scale:  # the caller owes diag(s) G diag(s): the tap holds the unscaled gradient
+            g = g * sw.grad_scale[n].reshape(1, 1, -1, 1, 1)
+        err = (g - want[n]).abs().max() / want[n].abs().max()
+        assert err < 2e-5, (n, float(err))
+    if defer:
+        assert sw.grad_scale, "no BatchNorm scale was deferred"
+    # consumers that want plain tensors get [S, B, C, H, W] fp32
+    got2 = sw.backward(seeds)
+    for n in taps:
+        assert torch.is_tensor(got2[n]) and got2[n].shape == want[n].shape
+        assert (got2[n] - want[n]).abs().max() / want[n].abs().max() < 2e-5
+
+
+def test_unsupported_graphs_fall_back_to_the_parent_sweep():
+    from laplace_amd.nets import lenet5
+
+    model = lenet5().eval()  # 6- and 16-channel convs, max pooling
+    taps = {n: m for n, m in model.named_modules() if isinstance(m, (nn.Conv2d, nn.Linear))}
+    sw = SplitSweep(model, taps, kernels=get_kernels)
+    assert not sw.split_ok and "convolution" in sw.split_reason
+    x = torch.randn(3, 3, 32, 32)
+    seeds = torch.randn(2, 3, 10)
+    sw.forward(x)
+    got = sw.backward(seeds)
+    _, want = _autograd_tap_grads(model, taps, x, seeds)
+    for n in taps:
+        assert torch.allclose(got[n], want[n], atol=1e-5)
