@@ -174,7 +174,8 @@ int lk_conv_prep_weights_f16x2(const float* W, int64_t Co, int64_t Ci, int64_t t
  * w: split planes [.][Co][Ci]; taps: T x {dh, dw, wt} (T <= 9, host array); zero16: >= 16 zero bytes on the device;
  * out: fp32 [N][Ho][Wo][Co]; accumulate != 0 adds into out; amax_out (may be NULL): atomicMax of the bit patterns of
  * |out| (zero it first).  Stride-1 backward-data and forward convs are one launch, a stride-s backward-data is one
- * launch per output-pixel residue class.  config bit 0: 64-deep K chunks. */
+ * launch per output-pixel residue class.  config bit 0: 64-deep K chunks; bit 1: never use the form that keeps
+ * the input patch of a tile resident in LDS across the taps (used when the output grid is the input grid). */
 int lk_conv_nhwc_f16x2(const void* in_h, const void* in_l, const int* in_sexp, int64_t N, int64_t Hi, int64_t Wi,
                        int64_t Ci, const void* w_h, const void* w_l, const int* w_sexp, int64_t Co, int64_t Hc,
                        int64_t Wc, int64_t in_mul, int64_t Ho, int64_t Wo, int64_t out_step, int64_t oh0, int64_t ow0,

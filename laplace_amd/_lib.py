@@ -156,7 +156,7 @@ class HipKernels:
     """Tensor-level wrappers; every method enqueues on torch's current stream and returns at once."""
 
     name = "hip"
-    conv_config = int(os.environ.get("LK_CONV_CONFIG", "0"))  # bit 0: 64-deep K chunks in lk_conv_nhwc_f16x2
+    conv_config = int(os.environ.get("LK_CONV_CONFIG", "0"))  # lk_conv_nhwc_f16x2: bit 0 = 64-deep K chunks (generic form), bit 1 = never use the patch form
     softmax_chol_max_c = 2000  # LK_SOFTMAX_CHOL_MAX_C (include/laplace_hip.h): wider outputs use the symmetric root
 
     def __init__(self, lib: Optional[ctypes.CDLL] = None):

@@ -126,6 +126,8 @@ struct ConvGeom {
   int im;              // input pixel of tap t = (i * im + dh[t], j * im + dw[t])
   int T;               // taps of this launch
   int dh[9], dw[9], wt[9];  // per tap: offsets and the weight slice (index into the [T_w][Co][Ci] planes)
+  FastDiv div_hw, div_w;    // GEMM row m -> (n, i, j):  n = m / (Hc*Wc), i = rem / Wc
+  int dense;                // the output grid is the output tensor (os = 1, Hc = Ho, Wc = Wo): output pixel = m
 };
 
 template <int BM_, int BN_, int BK_, int WM_, int WN_>
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(256) void conv_f16x2_kernel(const ConvGeom g, const
                                                          const _Float16* __restrict__ Wl, const int* __restrict__ a_sexp,
                                                          const int* __restrict__ w_sexp, const _Float16* __restrict__ zero16,
                                                          float* __restrict__ out, int accumulate,
-                                                         unsigned* __restrict__ amax_out, int nb_m) {
+                                                         unsigned* __restrict__ amax_out, int nb_m, int ablate) {
   constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK, Q = CFG::Q, TM = CFG::TM, TN = CFG::TN;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -189,8 +191,9 @@ __global__ __launch_bounds__(256) void conv_f16x2_kernel(const ConvGeom g, const
     unsigned valid = 0;
     int64_t off = 0;
     if (m < M) {
-      const int n = m / (g.Hc * g.Wc), rem = m % (g.Hc * g.Wc);
-      const int ih = (rem / g.Wc) * g.im, iw = (rem % g.Wc) * g.im;
+      const int n = fdiv(m, g.div_hw), rem = m - n * (g.Hc * g.Wc);
+      const int ci_ = fdiv(rem, g.div_w);
+      const int ih = ci_ * g.im, iw = (rem - ci_ * g.Wc) * g.im;
       off = (((int64_t)n * g.Hi + ih) * g.Wi + iw) * g.Ci;
       for (int t = 0; t < g.T; ++t) {
         const int hh = ih + g.dh[t], ww = iw + g.dw[t];
@@ -253,7 +256,8 @@ __global__ __launch_bounds__(256) void conv_f16x2_kernel(const ConvGeom g, const
     const int buf = s & 1;
     __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0), lgkmcnt / expcnt unconstrained: this wave's part of stage s has landed
     __syncthreads();                                        // ... for every wave; and everyone is done with buf^1
-    if (s + 1 < nstage) stage(s + 1, buf ^ 1);
+    if (s + 1 < nstage && !(ablate & 4)) stage(s + 1, buf ^ 1);
+    if (ablate & 2) continue;
     const char* base = smem + buf * CFG::STAGE;
 #pragma unroll
     for (int k16 = 0; k16 < BK / 16; ++k16) {
@@ -295,16 +299,221 @@ __global__ __launch_bounds__(256) void conv_f16x2_kernel(const ConvGeom g, const
       const int row = (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       const int m = tile_m * BM + row;
       if (m >= M) continue;
-      const int n = m / (g.Hc * g.Wc), rem = m % (g.Hc * g.Wc);
-      const int oh = (rem / g.Wc) * g.os + g.oh0, ow = (rem % g.Wc) * g.os + g.ow0;
-      float* orow = out + (((int64_t)n * g.Ho + oh) * g.Wo + ow) * g.Co;
+      int64_t opix = m;
+      if (!g.dense) {
+        const int n = fdiv(m, g.div_hw), rem = m - n * (g.Hc * g.Wc);
+        const int ci_ = fdiv(rem, g.div_w);
+        opix = ((int64_t)n * g.Ho + ci_ * g.os + g.oh0) * g.Wo + (rem - ci_ * g.Wc) * g.os + g.ow0;
+      }
+      float* orow = out + opix * g.Co;
 #pragma unroll
       for (int b = 0; b < TN; ++b) {
         const int col = tile_n * BN + (wn * TN + b) * 32 + lr;
         if (col < g.Co) {
           float v = acc[a][b][r] * inv_a * inv_w;
           if (accumulate) v += orow[col];
-          orow[col] = v;
+          if (!(ablate & 1)) orow[col] = v;
+          vmax = max(vmax, __float_as_uint(v) & 0x7fffffffu);
+        }
+      }
+    }
+  }
+  if (amax_out) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) vmax = max(vmax, (unsigned)__shfl_xor((int)vmax, off, 64));
+    if (lane == 0 && vmax) atomicMax(amax_out, vmax);
+  }
+}
+
+
+// ---- the same GEMM with the A operand RESIDENT in LDS across the taps ("patch" form) ----------------------------------
+// The generic kernel re-stages the A tile for every tap: 9 x the input from L2 / Infinity Cache, and with 2 x 32 CUs per
+// XCD streaming 64 KB tiles the 4 MB L2 does not hold them — measured, it runs at the L2-miss rate (~12 B/clk/CU), the
+// matrix pipe 23-40 % busy.  When the output grid IS the input grid (stride-1 forward / backward-data, and the residue
+// classes of a stride-2 backward-data), tap (dh, dw) of GEMM row m is raster pixel m + dh*Wi + dw: a tile of 256
+// consecutive raster pixels needs the contiguous range [m0 - Wi - 1, m0 + 256 + Wi + 1) for ALL taps.  That patch is
+// brought into LDS once per 32-channel chunk (double-buffered, its loads spread over the tap stages of the previous
+// chunk) and the taps read it at shifted rows; only the weight tile is re-staged per tap.  Out-of-image taps read a zero
+// block.  8 waves (2 per SIMD), one workgroup per CU, 256 x BN output tile.
+template <int BN_, int WM_, int WN_>
+struct PatchCfg {
+  static constexpr int BM = 256, BN = BN_, CK = 32, WM = WM_, WN = WN_;
+  static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  static constexpr int PP = 384;                      // patch pixels incl. padding: BM + 2 Wi + 2 <= PP
+  static constexpr int PATCH_PLANE = PP * CK * 2;     // bytes
+  static constexpr int PATCH = 2 * PATCH_PLANE;       // h + l
+  static constexpr int B_PLANE = BN * CK * 2;
+  static constexpr int BSTAGE = 2 * B_PLANE;
+  static constexpr int ZERO_OFF = 2 * PATCH + 2 * BSTAGE;
+  static constexpr int LDS = ZERO_OFF + 64;
+  static constexpr int P_LD = PP * 4 / 512;           // LDS-DMA instructions per thread, plane and chunk (3)
+  static constexpr int B_ROWS_PER_INST = 512 / 4;     // 128 weight rows per instruction and plane
+  static_assert(WM * WN == 8 && (PP * 4) % 512 == 0, "eight waves, whole instructions");
+};
+
+template <typename CFG>
+__global__ __launch_bounds__(512) void conv_patch_f16x2_kernel(const ConvGeom g, const _Float16* __restrict__ Ah,
+                                                               const _Float16* __restrict__ Al,
+                                                               const _Float16* __restrict__ Wh,
+                                                               const _Float16* __restrict__ Wl,
+                                                               const int* __restrict__ a_sexp, const int* __restrict__ w_sexp,
+                                                               const _Float16* __restrict__ zero16, float* __restrict__ out,
+                                                               int accumulate, unsigned* __restrict__ amax_out, int nb_m,
+                                                               int ablate) {
+  constexpr int BM = CFG::BM, BN = CFG::BN, TM = CFG::TM, TN = CFG::TN;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nblk = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk / 8, r = nblk % 8, x = bid % 8, j = bid / 8;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+  }
+  const int tile_n = bid / nb_m, tile_m = bid % nb_m;
+  const int M = g.N * g.Hi * g.Wi;
+  const int KC = g.Ci / 32;
+  const int T = g.T;
+  const int nstage = KC * T;
+  const int m0 = tile_m * BM;
+
+  if (tid < 16) reinterpret_cast<unsigned*>(smem + CFG::ZERO_OFF)[tid] = 0u;
+
+  // ---- patch staging context (per plane: P_LD instructions; instruction j covers slots [j*512, j*512+512))
+  int64_t p_off[CFG::P_LD];
+  bool p_ok[CFG::P_LD];
+#pragma unroll
+  for (int j = 0; j < CFG::P_LD; ++j) {
+    const int slot = j * 512 + tid;
+    const int px = slot >> 2, pq = slot & 3;
+    const int64_t raster = (int64_t)m0 - (g.Wi + 1) + px;
+    p_ok[j] = raster >= 0 && raster < M;
+    p_off[j] = raster * g.Ci + ((pq ^ ((px >> 2) & 3)) << 3);
+  }
+  auto patch_piece = [&](int kc, int i) {  // piece i of 2 * P_LD: plane i / P_LD, instruction i % P_LD
+    const int plane = i / CFG::P_LD, j = i % CFG::P_LD;
+    const _Float16* src = plane ? Al : Ah;
+    const _Float16* sp = p_ok[j] ? src + p_off[j] + kc * 32 : zero16;
+    char* d = smem + (kc & 1) * CFG::PATCH + plane * CFG::PATCH_PLANE + (j * 512 + wave * 64) * 16;
+    __builtin_amdgcn_global_load_lds((gbl_void*)sp, (lds_void*)d, 16, 0, 0);
+  };
+  // ---- weight staging context: one instruction covers 128 rows of one plane
+  const int b_row = tid >> 2, b_pq = tid & 3;
+  const int64_t w_tap = (int64_t)g.Co * g.Ci;
+  auto stage_b = [&](int s) {
+    const int kc = s / T, t = s - kc * T;
+    char* base = smem + 2 * CFG::PATCH + (s & 1) * CFG::BSTAGE;
+#pragma unroll
+    for (int jj = 0; jj < (BN + 127) / 128; ++jj) {
+      const int row = jj * 128 + b_row;
+      if (BN < 128 && wave * 16 >= BN) break;  // (BN = 64: the upper four waves have no weight rows)
+      const int n = tile_n * BN + row;
+      const int64_t e = (int64_t)g.wt[t] * w_tap + (int64_t)n * g.Ci + kc * 32 + ((b_pq ^ ((row >> 2) & 3)) << 3);
+      const bool ok = n < g.Co;
+      char* d = base + (jj * 512 + wave * 64) * 16;
+      __builtin_amdgcn_global_load_lds((gbl_void*)(ok ? Wh + e : zero16), (lds_void*)d, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void*)(ok ? Wl + e : zero16), (lds_void*)(d + CFG::B_PLANE), 16, 0, 0);
+    }
+  };
+
+  // ---- fragment geometry
+  const int wm = wave / CFG::WN, wn = wave % CFG::WN;
+  const int lr = lane & 31, lh = lane >> 5;
+  unsigned vmask[TM];  // bit t: tap t of this lane's row (tile a) lies inside the image
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+    const int m = m0 + (wm * TM + a) * 32 + lr;
+    unsigned v = 0;
+    if (m < M) {
+      const int rem = m - fdiv(m, g.div_hw) * (g.Hi * g.Wi);
+      const int h = fdiv(rem, g.div_w), w = rem - h * g.Wi;
+      for (int t = 0; t < T; ++t) {
+        const int hh = h + g.dh[t], ww = w + g.dw[t];
+        if (hh >= 0 && hh < g.Hi && ww >= 0 && ww < g.Wi) v |= 1u << t;
+      }
+    }
+    vmask[a] = v;
+  }
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // prologue: the whole first patch and the first weight tile
+#pragma unroll
+  for (int i = 0; i < 2 * CFG::P_LD; ++i) patch_piece(0, i);
+  stage_b(0);
+
+  for (int s = 0; s < nstage; ++s) {
+    const int kc = s / T, t = s - kc * T;
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+    __syncthreads();
+    if (s + 1 < nstage && !(ablate & 4)) stage_b(s + 1);
+    if (kc + 1 < KC && !(ablate & 4)) {  // the next chunk's patch, spread over this chunk's tap stages
+#pragma unroll
+      for (int i = 0; i < 2 * CFG::P_LD; ++i)
+        if (i % T == t) patch_piece(kc + 1, i);
+    }
+    if (ablate & 2) continue;
+    const char* pa = smem + (kc & 1) * CFG::PATCH;
+    const char* pb = smem + 2 * CFG::PATCH + (s & 1) * CFG::BSTAGE;
+    const int shift = (g.dh[t] + 1) * g.Wi + g.dw[t] + 1;
+#pragma unroll
+    for (int k16 = 0; k16 < 2; ++k16) {
+      f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int a = 0; a < TM; ++a) {
+        const int px = (wm * TM + a) * 32 + lr + shift;
+        const int off = ((vmask[a] >> t) & 1u) ? (px * 4 + ((k16 * 2 + lh) ^ ((px >> 2) & 3))) * 16 : -1;
+        ah[a] = *reinterpret_cast<const f16x8*>(off >= 0 ? pa + off : smem + CFG::ZERO_OFF);
+        al[a] = *reinterpret_cast<const f16x8*>(off >= 0 ? pa + CFG::PATCH_PLANE + off : smem + CFG::ZERO_OFF);
+      }
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const int row = (wn * TN + b) * 32 + lr;
+        const int off = (row * 4 + ((k16 * 2 + lh) ^ ((row >> 2) & 3))) * 16;
+        bh[b] = *reinterpret_cast<const f16x8*>(pb + off);
+        bl[b] = *reinterpret_cast<const f16x8*>(pb + CFG::B_PLANE + off);
+      }
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          f32x16 c = acc[a][b];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], c, 0, 0, 0);
+          acc[a][b] = c;
+        }
+    }
+  }
+
+  // ---- epilogue (as the generic kernel; dense output grids need no index arithmetic)
+  const float inv_a = exp2i(-a_sexp[0] < -126 ? -126 : -a_sexp[0]), inv_w = exp2i(-w_sexp[0] < -126 ? -126 : -w_sexp[0]);
+  unsigned vmax = 0;
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int m = m0 + row;
+      if (m >= M) continue;
+      int64_t opix = m;
+      if (!g.dense) {
+        const int n = fdiv(m, g.div_hw), rem = m - n * (g.Hi * g.Wi);
+        const int ci_ = fdiv(rem, g.div_w);
+        opix = ((int64_t)n * g.Ho + ci_ * g.os + g.oh0) * g.Wo + (rem - ci_ * g.Wi) * g.os + g.ow0;
+      }
+      float* orow = out + opix * g.Co;
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const int col = tile_n * BN + (wn * TN + b) * 32 + lr;
+        if (col < g.Co) {
+          float v = acc[a][b][r] * inv_a * inv_w;
+          if (accumulate) v += orow[col];
+          if (!(ablate & 1)) orow[col] = v;
           vmax = max(vmax, __float_as_uint(v) & 0x7fffffffu);
         }
       }
@@ -362,6 +571,8 @@ extern "C" int lk_conv_prep_weights_f16x2(const float* W, int64_t Co, int64_t Ci
   return check_launch("conv_prep_weights_kernel");
 }
 
+static int g_ablate = 0;  // development switch (config bits 8..10 of lk_conv_nhwc_f16x2): skip stores / MFMAs / staging
+
 template <typename CFG>
 static int launch_conv(const ConvGeom& g, const void* Ah, const void* Al, const void* Wh, const void* Wl, const int* a_sexp,
                        const int* w_sexp, const void* zero16, float* out, int accumulate, unsigned* amax_out,
@@ -376,8 +587,25 @@ static int launch_conv(const ConvGeom& g, const void* Ah, const void* Al, const 
   }
   hipLaunchKernelGGL(conv_f16x2_kernel<CFG>, dim3((unsigned)(nb_m * nb_n)), dim3(256), lds, stream, g, (const _Float16*)Ah,
                      (const _Float16*)Al, (const _Float16*)Wh, (const _Float16*)Wl, a_sexp, w_sexp, (const _Float16*)zero16,
-                     out, accumulate, amax_out, nb_m);
+                     out, accumulate, amax_out, nb_m, g_ablate);
   return check_launch("conv_f16x2_kernel");
+}
+
+template <typename CFG>
+static int launch_patch(const ConvGeom& g, const void* Ah, const void* Al, const void* Wh, const void* Wl, const int* a_sexp,
+                        const int* w_sexp, const void* zero16, float* out, int accumulate, unsigned* amax_out,
+                        hipStream_t stream) {
+  const int64_t M = (int64_t)g.N * g.Hi * g.Wi;
+  const int nb_m = (int)((M + CFG::BM - 1) / CFG::BM), nb_n = (g.Co + CFG::BN - 1) / CFG::BN;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv_patch_f16x2_kernel<CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv_patch_f16x2_kernel<CFG>, dim3((unsigned)(nb_m * nb_n)), dim3(512), CFG::LDS, stream, g,
+                     (const _Float16*)Ah, (const _Float16*)Al, (const _Float16*)Wh, (const _Float16*)Wl, a_sexp, w_sexp,
+                     (const _Float16*)zero16, out, accumulate, amax_out, nb_m, g_ablate);
+  return check_launch("conv_patch_f16x2_kernel");
 }
 
 // One launch of the implicit GEMM.  `taps`: T x {dh, dw, weight slice}.
@@ -395,7 +623,18 @@ extern "C" int lk_conv_nhwc_f16x2(const void* in_h, const void* in_l, const int*
   g.Wo = (int)Wo, g.Co = (int)Co, g.os = (int)out_step, g.oh0 = (int)oh0, g.ow0 = (int)ow0, g.im = (int)in_mul, g.T = (int)T;
   for (int t = 0; t < 9; ++t) g.dh[t] = g.dw[t] = g.wt[t] = 0;
   for (int t = 0; t < T; ++t) g.dh[t] = taps[3 * t], g.dw[t] = taps[3 * t + 1], g.wt[t] = taps[3 * t + 2];
+  g.div_hw = make_fastdiv((int)(Hc * Wc)), g.div_w = make_fastdiv((int)Wc);
+  g.dense = out_step == 1 && oh0 == 0 && ow0 == 0 && Hc == Ho && Wc == Wo;
   hipStream_t st = (hipStream_t)stream;
+  g_ablate = (config >> 8) & 7;
+  // "patch" form (A operand resident in LDS across the taps) where the output grid is the input grid
+  bool patch = !(config & 2) && in_mul == 1 && Hc == Hi && Wc == Wi && 256 + 2 * Wi + 2 <= 384 && N * Hi * Wi >= 256;
+  for (int t = 0; t < T && patch; ++t) patch = g.dh[t] >= -1 && g.dh[t] <= 1 && g.dw[t] >= -1 && g.dw[t] <= 1;
+  if (patch) {
+    if (Co <= 64)
+      return launch_patch<PatchCfg<64, 4, 2>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st);
+    return launch_patch<PatchCfg<128, 4, 2>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st);
+  }
   const bool bk64 = (Ci % 64 == 0) && (config & 1);
   if (Co <= 64) {
     return bk64 ? launch_conv<ConvCfg<256, 64, 64, 4, 1>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st)

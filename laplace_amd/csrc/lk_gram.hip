@@ -38,26 +38,6 @@ __device__ long long g_gram_trace[5];
 #endif
 constexpr int MAX_SEG = 16;
 
-// Exact unsigned division of n < 2^31 by a run-time constant d >= 1 without a divide:
-// q = (n * M) >> (32 + s),  s = ceil(log2 d),  M = ceil(2^(32+s) / d)  (fits 34 bits; product < 2^64).
-struct FastDiv {
-  uint64_t M;
-  int s;
-  int d;
-};
-static FastDiv make_fastdiv(int d) {
-  FastDiv f;
-  f.d = d;
-  f.s = 0;
-  while ((1ll << f.s) < d) ++f.s;
-  const unsigned __int128 one = 1;
-  f.M = (uint64_t)(((one << (32 + f.s)) + (unsigned)d - 1) / (unsigned)d);
-  return f;
-}
-__device__ __forceinline__ int fdiv(int n, const FastDiv& f) {
-  return (int)(((uint64_t)(uint32_t)n * f.M) >> (32 + f.s));
-}
-
 struct GramGeom {
   const float* x;
   int64_t K;    // virtual rows

@@ -8,6 +8,9 @@ from collections import defaultdict
 
 def short(name):
     name = re.sub(r"\(.*", "", name)
+    m = re.match(r"_ZN2lk\d+([a-z0-9_]+)INS_\d+[A-Za-z0-9]*Cfg((?:ILi|Li)[0-9ELi]*)", name)
+    if m:  # templated on a config struct: keep the kernel name and the integer template arguments
+        name = "lk::" + m.group(1) + "<" + ",".join(re.findall(r"Li(\d+)E", m.group(2))) + ">"
     return name if len(name) < 90 else name[:87] + "..."
 
 
@@ -17,7 +20,7 @@ def main(out, dbs):
     for db in dbs:
         con = sqlite3.connect(db)
         for name, cname, val, d in con.execute("select name, counter_name, counter_value, duration from pmc_events"):
-            if not name.startswith(("lk::", "void lk::")):
+            if not name.startswith(("lk::", "void lk::", "_ZN2lk")):
                 continue
             table[short(name)][cname].append(val)
             dur[short(name)].append(d)
