@@ -130,9 +130,10 @@ struct ConvGeom {
   int dense;                // the output grid is the output tensor (os = 1, Hc = Ho, Wc = Wo): output pixel = m
 };
 
-template <int BM_, int BN_, int BK_, int WM_, int WN_>
+template <int BM_, int BN_, int BK_, int WM_, int WN_, int NBUF_ = 2>
 struct ConvCfg {
   static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_;
+  static constexpr int NBUF = NBUF_;                      // LDS stages: NBUF - 1 stages of loads are in flight
   static constexpr int Q = BK / 8;                       // 16-byte slots per row
   static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;  // MFMA tiles per wave
   static constexpr int A_PLANE = BM * BK * 2, B_PLANE = BN * BK * 2;  // bytes
@@ -140,14 +141,14 @@ struct ConvCfg {
   static constexpr int A_SLOTS = BM * Q, B_SLOTS = BN * Q;   // per plane
   static constexpr int A_LD = 2 * A_SLOTS / 256, B_LD = 2 * B_SLOTS / 256;  // LDS-DMA instructions per thread and stage
   static_assert(WM * WN == 4, "four waves");
-  static_assert(A_SLOTS % 256 == 0 && B_SLOTS % 256 == 0, "whole instructions");
+  static_assert(A_SLOTS % 256 == 0 && (2 * B_SLOTS) % 256 == 0 && B_SLOTS % 64 == 0, "whole instructions, waves inside a plane");
 };
 
 // swizzle of the 16-byte slot index within a row: a 16-lane group of ds_read_b128 touches 16 distinct rows (mod 16) at
 // one logical slot; physical = logical ^ f(row) spreads them over all 16 slots of the 256-byte bank row
 template <int Q>
 __device__ __forceinline__ int swz(int row) {
-  return Q == 4 ? ((row >> 2) & 3) : Q == 8 ? ((row >> 1) & 7) : (row & (Q - 1));
+  return Q == 4 ? ((row >> 2) & 3) : Q == 8 ? ((row >> 1) & 7) : Q == 2 ? ((row >> 3) & 1) : (row & (Q - 1));
 }
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -202,13 +203,18 @@ __global__ __launch_bounds__(256) void conv_f16x2_kernel(const ConvGeom g, const
     }
     a_off[i] = off, a_valid[i] = valid;
   }
-  int64_t b_off[CFG::B_LD / 2];
-  bool b_ok[CFG::B_LD / 2];
+  // B: instruction i covers slots [i*256, i*256+256) of the concatenated [plane h | plane l] image (a plane may be
+  // smaller than one instruction: BN * Q slots)
+  int64_t b_off[CFG::B_LD];
+  bool b_ok[CFG::B_LD];
+  bool b_low[CFG::B_LD];
 #pragma unroll
-  for (int i = 0; i < CFG::B_LD / 2; ++i) {
-    const int slot = i * 256 + tid;
+  for (int i = 0; i < CFG::B_LD; ++i) {
+    const int cs = i * 256 + tid;
+    const int slot = cs % CFG::B_SLOTS;
     const int row = slot / Q, pq = slot % Q;
     const int n = tile_n * BN + row;
+    b_low[i] = cs >= CFG::B_SLOTS;
     b_ok[i] = n < g.Co;
     b_off[i] = (int64_t)n * g.Ci + (pq ^ swz<Q>(row)) * 8;
   }
@@ -230,13 +236,11 @@ __global__ __launch_bounds__(256) void conv_f16x2_kernel(const ConvGeom g, const
     }
     const int64_t wbase = (int64_t)g.wt[t] * w_tap + kc * BK;
 #pragma unroll
-    for (int i = 0; i < CFG::B_LD / 2; ++i) {
+    for (int i = 0; i < CFG::B_LD; ++i) {
       const int64_t e = wbase + b_off[i];
-      const _Float16* sh = b_ok[i] ? Wh + e : zero16;
-      const _Float16* sl = b_ok[i] ? Wl + e : zero16;
+      const _Float16* sp = b_ok[i] ? (b_low[i] ? Wl : Wh) + e : zero16;
       char* db = base + 2 * CFG::A_PLANE + (i * 256 + wave * 64) * 16;
-      __builtin_amdgcn_global_load_lds((gbl_void*)sh, (lds_void*)db, 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gbl_void*)sl, (lds_void*)(db + CFG::B_PLANE), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void*)sp, (lds_void*)db, 16, 0, 0);
     }
   };
 
@@ -251,14 +255,29 @@ __global__ __launch_bounds__(256) void conv_f16x2_kernel(const ConvGeom g, const
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  stage(0, 0);
+  // Software pipeline over NBUF LDS stages: the loads of stages s+1 .. s+NBUF-1 are in flight while stage s is
+  // computed (an L2 hit takes ~1.6k cycles here, two to three stage times).  vmcnt counts this wave's LDS-DMA
+  // instructions in issue order, every stage issues exactly LD_PER_STAGE of them, so "stage s has landed" is
+  // vmcnt(LD_PER_STAGE * (NBUF - 2)); the raw s_barrier (no implicit vmcnt(0) as __syncthreads would add) then makes it
+  // true for every wave and also says that everybody has finished reading the buffer stage s+NBUF-1 is loaded into.
+  constexpr int NBUF = CFG::NBUF, LD_PER_STAGE = CFG::A_LD + CFG::B_LD;
+  static_assert(LD_PER_STAGE * (NBUF - 2) <= 63, "vmcnt is a 6-bit counter");
+  constexpr int WAIT_STEADY = 0x0f70 | ((LD_PER_STAGE * (NBUF - 2)) & 15) | (((LD_PER_STAGE * (NBUF - 2)) >> 4) << 14);
+#pragma unroll
+  for (int i = 0; i < NBUF - 1; ++i)
+    if (i < nstage) stage(i, i);
+  int buf = 0;
   for (int s = 0; s < nstage; ++s) {
-    const int buf = s & 1;
-    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0), lgkmcnt / expcnt unconstrained: this wave's part of stage s has landed
-    __syncthreads();                                        // ... for every wave; and everyone is done with buf^1
-    if (s + 1 < nstage && !(ablate & 4)) stage(s + 1, buf ^ 1);
+    if (s + NBUF - 1 <= nstage)  // NBUF - 2 younger stages are outstanding behind stage s
+      __builtin_amdgcn_s_waitcnt(WAIT_STEADY);
+    else
+      __builtin_amdgcn_s_waitcnt(0x0f70);  // tail: fewer stages in flight
+    __builtin_amdgcn_s_barrier();
+    if (s + NBUF - 1 < nstage && !(ablate & 4)) stage(s + NBUF - 1, buf == 0 ? NBUF - 1 : buf - 1);
+    const int cur = buf;
+    buf = buf + 1 == NBUF ? 0 : buf + 1;
     if (ablate & 2) continue;
-    const char* base = smem + buf * CFG::STAGE;
+    const char* base = smem + cur * CFG::STAGE;
 #pragma unroll
     for (int k16 = 0; k16 < BK / 16; ++k16) {
       f16x8 ah[TM], al[TM], bh[TN], bl[TN];
@@ -579,7 +598,7 @@ static int launch_conv(const ConvGeom& g, const void* Ah, const void* Al, const 
                        hipStream_t stream) {
   const int64_t M = (int64_t)g.N * g.Hc * g.Wc;
   const int nb_m = (int)((M + CFG::BM - 1) / CFG::BM), nb_n = (g.Co + CFG::BN - 1) / CFG::BN;
-  const size_t lds = 2 * (size_t)CFG::STAGE;
+  const size_t lds = (size_t)CFG::NBUF * CFG::STAGE;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)conv_f16x2_kernel<CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -636,6 +655,11 @@ extern "C" int lk_conv_nhwc_f16x2(const void* in_h, const void* in_l, const int*
     return launch_patch<PatchCfg<128, 4, 2>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st);
   }
   const bool bk64 = (Ci % 64 == 0) && (config & 1);
+  if (config & 4) {  // 16-deep chunks, four LDS stages (three stages of loads in flight)
+    if (Co <= 64)
+      return launch_conv<ConvCfg<256, 64, 16, 4, 1, 4>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st);
+    return launch_conv<ConvCfg<128, 128, 16, 2, 2, 4>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st);
+  }
   if (Co <= 64) {
     return bk64 ? launch_conv<ConvCfg<256, 64, 64, 4, 1>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st)
                 : launch_conv<ConvCfg<256, 64, 32, 4, 1>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st);
