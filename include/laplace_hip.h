@@ -192,6 +192,16 @@ int lk_vjp_nhwc_split_f16x2(const float* g, const unsigned* g_amax, const void* 
                             const void* m, int m_is_float, const unsigned* m_amax, const float* scale,
                             const unsigned* scale_amax, int64_t C, int64_t S, int64_t per, void* out_h, void* out_l,
                             int* out_sexp, void* stream);
+/* Forward of the NHWC sweep: y = act(x * scale[c] + shift[c] + addend) on fp32 NHWC tensors, act 0 none / 1 ReLU / 2 tanh
+ * (replaces BatchNorm2d-eval + add + activation, three library launches per layer, and produces in the same pass the
+ * ReLU mask as NHWC bytes, the split planes of y for the next convolution and the guaranteed bound of max|y|:
+ *     y_bound = max|x| max|scale| + max|shift| + addend_bound   (tanh: 1).
+ * x_amax / scale_amax / shift_amax: device words with bit patterns of the maxima; addend (+ addend_bound), mask, y_h / y_l
+ * may be NULL.  C % 8 == 0. */
+int lk_bn_act_fwd_nhwc_f16x2(const float* x, const unsigned* x_amax, const float* scale, const float* shift,
+                             const unsigned* scale_amax, const unsigned* shift_amax, const float* addend,
+                             const float* addend_bound, int act, int64_t C, int64_t per, float* y, void* mask, void* y_h,
+                             void* y_l, int* y_sexp, float* y_bound, void* stream);
 /* G[C][C] += alpha * X^T X for a split tensor X [R][C] (rows = (seed, sample, position) of an NHWC cotangent): the
  * G factor of a convolution layer (curvlinops.py:87-100).  Only the 32x32 tiles on or above the diagonal are written
  * (lk_symmetrize_f32 mirrors).  C = 64 or a multiple of 128.  Deterministic (workspace partials, fixed-order sum). */

@@ -62,6 +62,7 @@ SIGNATURES = {
     "lk_conv_nhwc_f16x2": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64,
                                   _i64, _i64, _i64, _i64, _vp, _vp, _vp, _int, _vp, _int, _vp]),
     "lk_vjp_nhwc_split_f16x2": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "lk_bn_act_fwd_nhwc_f16x2": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "lk_gram_tn_f16x2_workspace_bytes": (_sz, [_i64, _i64]),
     "lk_gram_tn_f16x2": (_int, [_vp, _vp, _vp, _i64, _i64, _f32, _vp, _vp, _vp, _sz, _vp]),
     "lk_symmetrize_f32": (_int, [_vp, _i64, _vp]),
@@ -146,6 +147,16 @@ def _check(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
     if not t.is_contiguous():
         raise LaplaceHipError(f"{name}: tensor must be contiguous")
     return t
+
+
+def is_channels_last(x) -> bool:
+    """logical [B, C, H, W] tensor whose memory is dense NHWC (and not also dense NCHW)"""
+    return torch.is_tensor(x) and x.dim() == 4 and not x.is_contiguous() and x.permute(0, 2, 3, 1).is_contiguous()
+
+
+def keep_layout(x):
+    """``x`` as the kernels' wrappers want it: dense NCHW, or left alone when it is dense NHWC (no transposing copy)"""
+    return x if is_channels_last(x) else x.contiguous()
 
 
 def _pair(v):
@@ -299,7 +310,15 @@ class HipKernels:
         )
         return out
 
+    is_channels_last = staticmethod(lambda x: is_channels_last(x))
+
     def nchw_to_nhwc(self, x, out=None):
+        if self.is_channels_last(x):  # already NHWC in memory (the sweep's own forward): a view, no pass over the data
+            v = x.permute(0, 2, 3, 1)
+            if out is None:
+                return v
+            out.copy_(v)
+            return out
         _check(x, "x")
         B, C, H, W = x.shape
         if out is None:
@@ -400,6 +419,26 @@ class HipKernels:
             C, S, per, _ptr(planes[0]), _ptr(planes[1]), _ptr(sexp), self._stream(dev)), "lk_vjp_nhwc_split_f16x2")
         return SplitTensor(planes, sexp)
 
+    def bn_act_forward_nhwc(self, x, x_amax, scale, shift, scale_amax, shift_amax, act, addend=None, addend_bound=None,
+                            want_mask=True, want_split=True):
+        """``y = act(x * scale[c] + shift[c] + addend)`` on fp32 NHWC ``x [B, H, W, C]`` -> ``(y, mask, split, bound)``:
+        ``mask`` NHWC uint8 (ReLU only), ``split`` the SplitTensor of ``y``, ``bound`` a device word >= max|y|"""
+        _check(x, "x")
+        C = x.shape[-1]
+        y = torch.empty_like(x)
+        mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if (act == 1 and want_mask) else None
+        planes = torch.empty((2,) + tuple(x.shape), dtype=torch.float16, device=x.device) if want_split else None
+        sexp = torch.empty(1, dtype=torch.int32, device=x.device)
+        bound = torch.empty(1, dtype=torch.float32, device=x.device)
+        if addend is not None:
+            _check(addend, "addend")
+        self._rc(self.lib.lk_bn_act_fwd_nhwc_f16x2(
+            _ptr(x), _ptr(x_amax), _ptr(scale), _ptr(shift), _ptr(scale_amax), _ptr(shift_amax), _ptr(addend),
+            _ptr(addend_bound), int(act), C, x.numel(), _ptr(y), _ptr(mask), None if planes is None else _ptr(planes[0]),
+            None if planes is None else _ptr(planes[1]), _ptr(sexp), _ptr(bound), self._stream(x.device)),
+            "lk_bn_act_fwd_nhwc_f16x2")
+        return y, mask, (SplitTensor(planes, sexp) if planes is not None else None), bound
+
     def gram_tn_f16x2(self, x, alpha, out):
         """``out[upper tiles] += alpha * X^T X`` for a SplitTensor ``x`` viewed as ``[rows, C]``"""
         _check(out, "out")
@@ -421,7 +460,9 @@ class HipKernels:
         ``native=True`` leaves ``out`` in the kernel's (kh, kw, ci) column order (fused accumulation);
         otherwise the result is delivered in F.unfold's (ci, kh, kw) order.
         """
-        _check(x, "x"), _check(out, "out")
+        _check(out, "out")
+        if not self.is_channels_last(x):
+            _check(x, "x")
         B, Cin, H, W = x.shape
         kh, kw = _pair(kernel_size)
         sh, sw = _pair(stride)
@@ -467,7 +508,7 @@ class HipKernels:
 
     def pixgram_accumulate(self, x, alpha, Cp):
         """``Cp += alpha * X^T X`` with ``X`` the NHWC images flattened to rows ``[B, H*W*Cin]`` (upper tiles only)."""
-        _check(x, "x"), _check(Cp, "Cp")
+        _check(Cp, "Cp")
         B = x.shape[0]
         xh = self.nchw_to_nhwc(x)
         return self.gram_tn(xh.reshape(B, -1), alpha, Cp, upper_only=True)
@@ -501,7 +542,6 @@ class HipKernels:
 
     def pixpair_accumulate(self, x, alpha, blocks, plan):
         """``Blk[q, D] += alpha * sum_b x[b,q,:]^T x[b,q+D,:]`` for an NCHW input ``x``."""
-        _check(x, "x")
         return self.pixpair_accumulate_nhwc(self.nchw_to_nhwc(x), alpha, blocks, plan)
 
     def pixpair_accumulate_nhwc(self, xh, alpha, blocks, plan):

@@ -31,7 +31,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from laplace_amd._lib import SplitTensor, get_kernels
+from laplace_amd._lib import SplitTensor, get_kernels, is_channels_last, keep_layout
 from laplace_amd.capture import Tape
 from laplace_amd.sweep import SeedBatchedSweep, SweepUnsupported
 from laplace_amd.sweep_nhwc import SplitSweep
@@ -331,7 +331,7 @@ class _HipCurvatureMixin:
                 K.gram_tn(a.reshape(a.shape[0], L, Di).mean(1).contiguous(), alpha_a_scale / N, A, upper_only=fused)
             return A
         if kfac_approx == "expand":
-            K.gram_conv(a.contiguous(), m.kernel_size, m.stride, m.padding, m.dilation, alpha_a_scale / (N * L), A,
+            K.gram_conv(keep_layout(a), m.kernel_size, m.stride, m.padding, m.dilation, alpha_a_scale / (N * L), A,
                         upper_only=fused, native=fused)
         else:
             cols = torch.nn.functional.unfold(a, m.kernel_size, dilation=m.dilation, padding=m.padding, stride=m.stride)
@@ -584,7 +584,7 @@ class KronAccumulator:
             return
         geo, buf = acc
         alpha = rt / (self.N * geo[1] * geo[2])
-        a = tap.a.to(torch.float32).contiguous()
+        a = keep_layout(tap.a.to(torch.float32))
         if geo[0] != "pair":
             K.pixgram_accumulate(a, alpha, buf)
         elif self.pix_group <= 1:

@@ -16,9 +16,17 @@ from laplace_amd._lib import SplitTensor, get_kernels
 def supported(m: nn.Conv2d) -> bool:
     """what the implicit-GEMM kernel covers: dense (groups = 1), undilated, zero padding, at most 9 taps, both channel
     counts multiples of 32 (a lane of the 16-bit MFMA reads 8 consecutive channels; K chunks are 32 deep)"""
+    return _geometry_ok(m) and m.in_channels % 32 == 0 and m.out_channels % 32 == 0
+
+
+def _geometry_ok(m) -> bool:
     return (isinstance(m, nn.Conv2d) and m.groups == 1 and tuple(m.dilation) == (1, 1) and not isinstance(m.padding, str)
-            and m.padding_mode == "zeros" and m.kernel_size[0] * m.kernel_size[1] <= 9
-            and m.in_channels % 32 == 0 and m.out_channels % 32 == 0 and m.stride[0] == m.stride[1])
+            and m.padding_mode == "zeros" and m.kernel_size[0] * m.kernel_size[1] <= 9 and m.stride[0] == m.stride[1])
+
+
+def forward_supported(m: nn.Conv2d) -> bool:
+    """forward form: additionally a thin input (an RGB stem) is zero-padded to 32 channels"""
+    return _geometry_ok(m) and (m.in_channels % 32 == 0 or m.in_channels < 32) and m.out_channels % 8 == 0
 
 
 class PreparedConv:
@@ -41,10 +49,21 @@ class PreparedConv:
             self._bwd = (key, planes, sexp)
         return self._bwd[1], self._bwd[2]
 
+    @property
+    def padded_in(self) -> int:
+        """input channels as the forward kernel sees them (a thin stem is zero-padded to one 32-channel chunk)"""
+        ci = self.m.in_channels
+        return ci if ci % 32 == 0 else 32
+
     def forward_planes(self):
         key = self._key(None)
         if self._fwd is None or self._fwd[0] != key:
-            planes, sexp = get_kernels().conv_prep_weights(self.m.weight.detach().contiguous(), False, None)
+            W = self.m.weight.detach()
+            if self.padded_in != W.shape[1]:
+                Wp = W.new_zeros(W.shape[0], self.padded_in, *W.shape[2:])
+                Wp[:, :W.shape[1]] = W
+                W = Wp
+            planes, sexp = get_kernels().conv_prep_weights(W.contiguous(), False, None)
             self._fwd = (key, planes, sexp)
         return self._fwd[1], self._fwd[2]
 

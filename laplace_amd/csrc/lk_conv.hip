@@ -139,9 +139,10 @@ struct ConvCfg {
   static constexpr int A_PLANE = BM * BK * 2, B_PLANE = BN * BK * 2;  // bytes
   static constexpr int STAGE = 2 * A_PLANE + 2 * B_PLANE;
   static constexpr int A_SLOTS = BM * Q, B_SLOTS = BN * Q;   // per plane
-  static constexpr int A_LD = 2 * A_SLOTS / 256, B_LD = 2 * B_SLOTS / 256;  // LDS-DMA instructions per thread and stage
-  static_assert(WM * WN == 4, "four waves");
-  static_assert(A_SLOTS % 256 == 0 && (2 * B_SLOTS) % 256 == 0 && B_SLOTS % 64 == 0, "whole instructions, waves inside a plane");
+  static constexpr int NT = 64 * WM * WN;                 // threads: 4 waves (2 workgroups per CU) or 8 (one)
+  static constexpr int A_LD = 2 * A_SLOTS / NT, B_LD = 2 * B_SLOTS / NT;  // LDS-DMA instructions per thread and stage
+  static_assert(WM * WN == 4 || WM * WN == 8, "four or eight waves");
+  static_assert(A_SLOTS % NT == 0 && (2 * B_SLOTS) % NT == 0 && B_SLOTS % 64 == 0, "whole instructions, waves inside a plane");
 };
 
 // swizzle of the 16-byte slot index within a row: a 16-lane group of ds_read_b128 touches 16 distinct rows (mod 16) at
@@ -155,13 +156,13 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
 
 template <typename CFG>
-__global__ __launch_bounds__(256) void conv_f16x2_kernel(const ConvGeom g, const _Float16* __restrict__ Ah,
+__global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_f16x2_kernel(const ConvGeom g, const _Float16* __restrict__ Ah,
                                                          const _Float16* __restrict__ Al, const _Float16* __restrict__ Wh,
                                                          const _Float16* __restrict__ Wl, const int* __restrict__ a_sexp,
                                                          const int* __restrict__ w_sexp, const _Float16* __restrict__ zero16,
                                                          float* __restrict__ out, int accumulate,
                                                          unsigned* __restrict__ amax_out, int nb_m, int ablate) {
-  constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK, Q = CFG::Q, TM = CFG::TM, TN = CFG::TN;
+  constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK, Q = CFG::Q, TM = CFG::TM, TN = CFG::TN, NT = CFG::NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // XCD-aware tile order: consecutive block ids run on different XCDs (id % 8); give every XCD a contiguous range of
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(256) void conv_f16x2_kernel(const ConvGeom g, const
   static_assert(CFG::A_LD % 2 == 0, "the two planes are fed by the same threads");
 #pragma unroll
   for (int i = 0; i < CFG::A_LD / 2; ++i) {
-    const int slot = i * 256 + tid;  // within a plane
+    const int slot = i * NT + tid;  // within a plane
     const int row = slot / Q, pq = slot % Q;
     a_lq[i] = pq ^ swz<Q>(row);
     const int m = tile_m * BM + row;
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(256) void conv_f16x2_kernel(const ConvGeom g, const
   bool b_low[CFG::B_LD];
 #pragma unroll
   for (int i = 0; i < CFG::B_LD; ++i) {
-    const int cs = i * 256 + tid;
+    const int cs = i * NT + tid;
     const int slot = cs % CFG::B_SLOTS;
     const int row = slot / Q, pq = slot % Q;
     const int n = tile_n * BN + row;
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(256) void conv_f16x2_kernel(const ConvGeom g, const
       const int64_t e = a_off[i] + tap_off + a_lq[i] * 8;
       const _Float16* sh = ok ? Ah + e : zero16;
       const _Float16* sl = ok ? Al + e : zero16;
-      char* dh_ = base + (i * 256 + wave * 64) * 16;
+      char* dh_ = base + (i * NT + wave * 64) * 16;
       __builtin_amdgcn_global_load_lds((gbl_void*)sh, (lds_void*)dh_, 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gbl_void*)sl, (lds_void*)(dh_ + CFG::A_PLANE), 16, 0, 0);
     }
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(256) void conv_f16x2_kernel(const ConvGeom g, const
     for (int i = 0; i < CFG::B_LD; ++i) {
       const int64_t e = wbase + b_off[i];
       const _Float16* sp = b_ok[i] ? (b_low[i] ? Wl : Wh) + e : zero16;
-      char* db = base + 2 * CFG::A_PLANE + (i * 256 + wave * 64) * 16;
+      char* db = base + 2 * CFG::A_PLANE + (i * NT + wave * 64) * 16;
       __builtin_amdgcn_global_load_lds((gbl_void*)sp, (lds_void*)db, 16, 0, 0);
     }
   };
@@ -278,31 +279,37 @@ __global__ __launch_bounds__(256) void conv_f16x2_kernel(const ConvGeom g, const
     buf = buf + 1 == NBUF ? 0 : buf + 1;
     if (ablate & 2) continue;
     const char* base = smem + cur * CFG::STAGE;
-#pragma unroll
-    for (int k16 = 0; k16 < BK / 16; ++k16) {
-      f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+    // fragments of step k16 + 1 are requested before the MFMAs of step k16 are issued (two register sets)
+    f16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+    auto load_frags = [&](int k16, int set) {
 #pragma unroll
       for (int a = 0; a < TM; ++a) {
         const int row = (wm * TM + a) * 32 + lr;
         const int off = (row * Q + ((k16 * 2 + lh) ^ swz<Q>(row))) * 16;
-        ah[a] = *reinterpret_cast<const f16x8*>(base + off);
-        al[a] = *reinterpret_cast<const f16x8*>(base + CFG::A_PLANE + off);
+        ah[set][a] = *reinterpret_cast<const f16x8*>(base + off);
+        al[set][a] = *reinterpret_cast<const f16x8*>(base + CFG::A_PLANE + off);
       }
 #pragma unroll
       for (int b = 0; b < TN; ++b) {
         const int row = (wn * TN + b) * 32 + lr;
         const int off = (row * Q + ((k16 * 2 + lh) ^ swz<Q>(row))) * 16;
-        bh[b] = *reinterpret_cast<const f16x8*>(base + 2 * CFG::A_PLANE + off);
-        bl[b] = *reinterpret_cast<const f16x8*>(base + 2 * CFG::A_PLANE + CFG::B_PLANE + off);
+        bh[set][b] = *reinterpret_cast<const f16x8*>(base + 2 * CFG::A_PLANE + off);
+        bl[set][b] = *reinterpret_cast<const f16x8*>(base + 2 * CFG::A_PLANE + CFG::B_PLANE + off);
       }
+    };
+    load_frags(0, 0);
+#pragma unroll
+    for (int k16 = 0; k16 < BK / 16; ++k16) {
+      const int set = k16 & 1;
+      if (k16 + 1 < BK / 16) load_frags(k16 + 1, set ^ 1);
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
           f32x16 c = acc[a][b];
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], c, 0, 0, 0);  // small terms first
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[set][a], bh[set][b], c, 0, 0, 0);  // small terms first
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[set][a], bl[set][b], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[set][a], bh[set][b], c, 0, 0, 0);
           acc[a][b] = c;
         }
     }
@@ -351,23 +358,23 @@ __global__ __launch_bounds__(256) void conv_f16x2_kernel(const ConvGeom g, const
 // matrix pipe 23-40 % busy.  When the output grid IS the input grid (stride-1 forward / backward-data, and the residue
 // classes of a stride-2 backward-data), tap (dh, dw) of GEMM row m is raster pixel m + dh*Wi + dw: a tile of 256
 // consecutive raster pixels needs the contiguous range [m0 - Wi - 1, m0 + 256 + Wi + 1) for ALL taps.  That patch is
-// brought into LDS once per 32-channel chunk (double-buffered, its loads spread over the tap stages of the previous
-// chunk) and the taps read it at shifted rows; only the weight tile is re-staged per tap.  Out-of-image taps read a zero
-// block.  8 waves (2 per SIMD), one workgroup per CU, 256 x BN output tile.
+// brought into LDS once per 32-channel chunk and the taps read it at shifted rows; only the weight tile is re-staged per
+// tap (double-buffered).  Out-of-image taps read a zero block.  8 waves, 256 x BN output tile, 76 KB of LDS: TWO
+// workgroups per CU, so that one computes while the other sits in the (single-buffered) patch reload between chunks.
 template <int BN_, int WM_, int WN_>
 struct PatchCfg {
   static constexpr int BM = 256, BN = BN_, CK = 32, WM = WM_, WN = WN_;
   static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  static constexpr int PP = 384;                      // patch pixels incl. padding: BM + 2 Wi + 2 <= PP
+  static constexpr int PP = 336;                      // patch pixels incl. padding: BM + 2 Wi + 2 <= PP
   static constexpr int PATCH_PLANE = PP * CK * 2;     // bytes
   static constexpr int PATCH = 2 * PATCH_PLANE;       // h + l
   static constexpr int B_PLANE = BN * CK * 2;
   static constexpr int BSTAGE = 2 * B_PLANE;
-  static constexpr int ZERO_OFF = 2 * PATCH + 2 * BSTAGE;
+  static constexpr int ZERO_OFF = PATCH + 2 * BSTAGE;
   static constexpr int LDS = ZERO_OFF + 64;
-  static constexpr int P_LD = PP * 4 / 512;           // LDS-DMA instructions per thread, plane and chunk (3)
-  static constexpr int B_ROWS_PER_INST = 512 / 4;     // 128 weight rows per instruction and plane
-  static_assert(WM * WN == 8 && (PP * 4) % 512 == 0, "eight waves, whole instructions");
+  static constexpr int P_SLOTS = PP * 4;              // 16-byte slots per plane
+  static constexpr int P_LD = (P_SLOTS + 511) / 512;  // LDS-DMA instructions per thread and plane (the last one partial)
+  static_assert(WM * WN == 8 && P_SLOTS % 64 == 0, "eight waves, whole waves inside the patch");
 };
 
 template <typename CFG>
@@ -412,7 +419,8 @@ __global__ __launch_bounds__(512) void conv_patch_f16x2_kernel(const ConvGeom g,
     const int plane = i / CFG::P_LD, j = i % CFG::P_LD;
     const _Float16* src = plane ? Al : Ah;
     const _Float16* sp = p_ok[j] ? src + p_off[j] + kc * 32 : zero16;
-    char* d = smem + (kc & 1) * CFG::PATCH + plane * CFG::PATCH_PLANE + (j * 512 + wave * 64) * 16;
+    if (j * 512 + wave * 64 >= CFG::P_SLOTS) return;  // (wave-uniform: the last instruction covers part of the waves)
+    char* d = smem + plane * CFG::PATCH_PLANE + (j * 512 + wave * 64) * 16;
     __builtin_amdgcn_global_load_lds((gbl_void*)sp, (lds_void*)d, 16, 0, 0);
   };
   // ---- weight staging context: one instruction covers 128 rows of one plane
@@ -420,7 +428,7 @@ __global__ __launch_bounds__(512) void conv_patch_f16x2_kernel(const ConvGeom g,
   const int64_t w_tap = (int64_t)g.Co * g.Ci;
   auto stage_b = [&](int s) {
     const int kc = s / T, t = s - kc * T;
-    char* base = smem + 2 * CFG::PATCH + (s & 1) * CFG::BSTAGE;
+    char* base = smem + CFG::PATCH + (s & 1) * CFG::BSTAGE;
 #pragma unroll
     for (int jj = 0; jj < (BN + 127) / 128; ++jj) {
       const int row = jj * 128 + b_row;
@@ -469,15 +477,18 @@ __global__ __launch_bounds__(512) void conv_patch_f16x2_kernel(const ConvGeom g,
     const int kc = s / T, t = s - kc * T;
     __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
     __syncthreads();
-    if (s + 1 < nstage && !(ablate & 4)) stage_b(s + 1);
-    if (kc + 1 < KC && !(ablate & 4)) {  // the next chunk's patch, spread over this chunk's tap stages
+    if (t == 0 && kc > 0 && !(ablate & 4)) {
+      // chunk change: everybody has left the old patch (barrier above); reload it, wait, and only then go on.  The
+      // other workgroup of the CU computes meanwhile.
 #pragma unroll
-      for (int i = 0; i < 2 * CFG::P_LD; ++i)
-        if (i % T == t) patch_piece(kc + 1, i);
+      for (int i = 0; i < 2 * CFG::P_LD; ++i) patch_piece(kc, i);
+      __builtin_amdgcn_s_waitcnt(0x0f70);
+      __syncthreads();
     }
+    if (s + 1 < nstage && !(ablate & 4)) stage_b(s + 1);
     if (ablate & 2) continue;
-    const char* pa = smem + (kc & 1) * CFG::PATCH;
-    const char* pb = smem + 2 * CFG::PATCH + (s & 1) * CFG::BSTAGE;
+    const char* pa = smem;
+    const char* pb = smem + CFG::PATCH + (s & 1) * CFG::BSTAGE;
     const int shift = (g.dh[t] + 1) * g.Wi + g.dw[t] + 1;
 #pragma unroll
     for (int k16 = 0; k16 < 2; ++k16) {
@@ -604,7 +615,7 @@ static int launch_conv(const ConvGeom& g, const void* Ah, const void* Al, const 
     (void)hipFuncSetAttribute((const void*)conv_f16x2_kernel<CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(conv_f16x2_kernel<CFG>, dim3((unsigned)(nb_m * nb_n)), dim3(256), lds, stream, g, (const _Float16*)Ah,
+  hipLaunchKernelGGL(conv_f16x2_kernel<CFG>, dim3((unsigned)(nb_m * nb_n)), dim3(CFG::NT), lds, stream, g, (const _Float16*)Ah,
                      (const _Float16*)Al, (const _Float16*)Wh, (const _Float16*)Wl, a_sexp, w_sexp, (const _Float16*)zero16,
                      out, accumulate, amax_out, nb_m, g_ablate);
   return check_launch("conv_f16x2_kernel");
@@ -647,7 +658,7 @@ extern "C" int lk_conv_nhwc_f16x2(const void* in_h, const void* in_l, const int*
   hipStream_t st = (hipStream_t)stream;
   g_ablate = (config >> 8) & 7;
   // "patch" form (A operand resident in LDS across the taps) where the output grid is the input grid
-  bool patch = !(config & 2) && in_mul == 1 && Hc == Hi && Wc == Wi && 256 + 2 * Wi + 2 <= 384 && N * Hi * Wi >= 256;
+  bool patch = !(config & 2) && in_mul == 1 && Hc == Hi && Wc == Wi && 256 + 2 * Wi + 2 <= 336 && N * Hi * Wi >= 256;
   for (int t = 0; t < T && patch; ++t) patch = g.dh[t] >= -1 && g.dh[t] <= 1 && g.dw[t] >= -1 && g.dw[t] <= 1;
   if (patch) {
     if (Co <= 64)
@@ -655,6 +666,11 @@ extern "C" int lk_conv_nhwc_f16x2(const void* in_h, const void* in_l, const int*
     return launch_patch<PatchCfg<128, 4, 2>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st);
   }
   const bool bk64 = (Ci % 64 == 0) && (config & 1);
+  if (config & 8) {  // 8 waves, one workgroup per CU: 256 x 128 (256 x 64) tile, three LDS stages (two in flight)
+    if (Co <= 64)
+      return launch_conv<ConvCfg<256, 64, 32, 4, 2, 3>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st);
+    return launch_conv<ConvCfg<256, 128, 32, 4, 2, 3>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st);
+  }
   if (config & 4) {  // 16-deep chunks, four LDS stages (three stages of loads in flight)
     if (Co <= 64)
       return launch_conv<ConvCfg<256, 64, 16, 4, 1, 4>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st);

@@ -147,17 +147,16 @@ class SeedBatchedSweep:
                         other = nxt.args[1] if nxt.args[0] is node else nxt.args[0]
                         if isinstance(other, fx.Node) and other in env and torch.is_tensor(env[other]) \
                                 and env[other].shape == inp.shape and env[other].dtype == inp.dtype:
-                            addend, add_node = env[other].contiguous(), nxt
+                            addend, add_node = env[other], nxt
                             nxt = next(iter(add_node.users)) if len(add_node.users) == 1 else None
                     relu = nxt is not None and self._is_plain_relu(nxt) and nxt.args[0] is (add_node or node)
-                    out, mask = self.kernels().bn_act_forward(inp.contiguous(), scale, shift, relu, addend,
-                                                              want_mask=need_vjp)
+                    out, mask = self._run_bn_act(node, inp, scale, shift, relu, addend, need_vjp)
                     if add_node is not None:
                         fused_relu[add_node] = (out, None)  # (the add node itself keeps nothing for its VJP)
                     if relu:
                         fused_relu[nxt] = (out, mask)
                 else:
-                    out = m(inp)
+                    out = self._run_conv(node, m, inp) if isinstance(m, nn.Conv2d) else m(inp)
                     if isinstance(m, (nn.ReLU,)):
                         self.saved[node] = (out > 0) if need_vjp else None
                     elif isinstance(m, (nn.Tanh, nn.Sigmoid)):
@@ -237,6 +236,14 @@ class SeedBatchedSweep:
         out = env[self.out_node]
         self.out_shape = tuple(out.shape[1:])
         return out
+
+    # ---- forward hooks (the NHWC sweep replaces them with its own kernels) -----------------------------------------
+    def _run_conv(self, node, m, inp):
+        return m(inp)
+
+    def _run_bn_act(self, node, inp, scale, shift, relu, addend, want_mask):
+        return self.kernels().bn_act_forward(inp.contiguous(), scale, shift, relu,
+                                             None if addend is None else addend.contiguous(), want_mask=want_mask)
 
     @staticmethod
     def _bind(node, names, defaults):

@@ -74,6 +74,83 @@ class SplitSweep(SeedBatchedSweep):
                 return f"method {node.target} has no NHWC rule"
         return None if n_conv else "no convolution in the graph"
 
+    # ---- forward: own convolution + fused BatchNorm/add/activation kernels on NHWC -----------------------------------
+    #: ``False`` (env LK_NHWC_FORWARD=0): the forward stays on the library's NCHW convolutions
+    nhwc_forward = __import__("os").environ.get("LK_NHWC_FORWARD", "1") != "0"
+
+    @torch.no_grad()
+    def forward(self, x, need_vjp: bool = True):
+        self._aux = {}  # data_ptr of a feature map produced here -> {"amax": word} / {"split": SplitTensor, "bound": word}
+        self._fwd_words = None
+        try:
+            return super().forward(x, need_vjp)
+        finally:
+            self._aux = {}  # (the split copies of the activations are only needed while the forward runs)
+
+    def _fwd_word(self, dev):
+        """a zeroed device word out of a per-forward pool (one fill launch per 64 words)"""
+        if self._fwd_words is None or self._fwd_words[1] == self._fwd_words[0].numel():
+            self._fwd_words = [torch.zeros(64, dtype=torch.float32, device=dev), 0]
+        w = self._fwd_words[0][self._fwd_words[1]:self._fwd_words[1] + 1]
+        self._fwd_words[1] += 1
+        return w
+
+    def _use_nhwc_forward(self, t) -> bool:
+        return self.split_ok and self.nhwc_forward and torch.is_tensor(t) and t.dim() == 4 and t.dtype == torch.float32 \
+            and t.shape[0] > 0
+
+    def _split_input(self, inp, pad_to=None):
+        aux = self._aux.get(inp.data_ptr())
+        if aux is not None and "split" in aux and aux["split"] is not None and pad_to is None:
+            return aux["split"]
+        K = self.kernels()
+        xh = inp.permute(0, 2, 3, 1).contiguous()  # (a view when inp is already NHWC in memory)
+        if pad_to is not None and xh.shape[-1] != pad_to:
+            xp = xh.new_zeros(*xh.shape[:3], pad_to)
+            xp[..., :xh.shape[-1]] = xh
+            xh = xp
+        return K.split_f16x2(xh)
+
+    def _run_conv(self, node, m, inp):
+        if not (self._use_nhwc_forward(inp) and cv.forward_supported(m)):
+            return m(inp)
+        prep = self._prep.get(node.target)
+        if prep is None:
+            prep = self._prep[node.target] = cv.PreparedConv(m)
+        xs = self._split_input(inp, pad_to=prep.padded_in if prep.padded_in != m.in_channels else None)
+        w = self._fwd_word(inp.device)
+        out = cv.conv_forward(prep, xs, amax_out=w)
+        if m.bias is not None:
+            out += m.bias
+            w = self.kernels().absmax(out)
+        y = out.permute(0, 3, 1, 2)  # logical [B, C, H, W] over NHWC memory
+        self._aux[y.data_ptr()] = {"amax": w}
+        return y
+
+    def _run_bn_act(self, node, inp, scale, shift, relu, addend, want_mask):
+        K = self.kernels()
+        if not (self._use_nhwc_forward(inp) and K.is_channels_last(inp) and inp.shape[1] % 8 == 0
+                and (addend is None or K.is_channels_last(addend))):
+            return super()._run_bn_act(node, inp, scale, shift, relu, addend, want_mask)
+        aux = self._aux.get(inp.data_ptr())
+        xh = inp.permute(0, 2, 3, 1)
+        x_amax = aux["amax"] if aux is not None and "amax" in aux else K.absmax(xh)
+        a_h = a_bound = None
+        if addend is not None:
+            a_h = addend.permute(0, 2, 3, 1)
+            a_aux = self._aux.get(addend.data_ptr())
+            a_bound = a_aux["bound"] if a_aux is not None and "bound" in a_aux else K.absmax(a_h)
+        scale = scale.to(torch.float32).contiguous()
+        shift = shift.to(torch.float32).contiguous()
+        y, mask, split, bound = K.bn_act_forward_nhwc(xh, x_amax, scale, shift, self._amax_of((node.target, "s"), scale),
+                                                      self._amax_of((node.target, "t"), shift), 1 if relu else 0,
+                                                      addend=a_h, addend_bound=a_bound, want_mask=want_mask)
+        out = y.permute(0, 3, 1, 2)
+        self._aux[out.data_ptr()] = {"split": split, "bound": bound}
+        if mask is not None:
+            mask = mask.view(torch.bool).permute(0, 3, 1, 2)  # logical NCHW view of the NHWC mask bytes
+        return out, mask
+
     # ---- helpers ----------------------------------------------------------------------------------------------------
     def _amax_of(self, key, t):
         """device word with max|t| of a per-model constant (BatchNorm scale), cached until it changes"""

@@ -126,6 +126,25 @@ class EmulatedKernels:
         assert float(v.abs().max()) <= bound * (1 + 1e-6) + 1e-30, "the guaranteed bound of the VJP output does not hold"
         return self._split(v, self._sexp_for(bound))
 
+    is_channels_last = staticmethod(lambda x: __import__("laplace_amd._lib", fromlist=["x"]).is_channels_last(x))
+
+    def bn_act_forward_nhwc(self, x, x_amax, scale, shift, scale_amax, shift_amax, act, addend=None, addend_bound=None,
+                            want_mask=True, want_split=True):
+        bound = float(x_amax[0]) * float(scale_amax[0]) + float(shift_amax[0])
+        y = x * scale + shift
+        if addend is not None:
+            y = y + addend
+            bound += float(addend_bound[0])
+        mask = None
+        if act == 1:
+            y = y.clamp_min(0)
+            mask = (y > 0).to(torch.uint8) if want_mask else None
+        elif act == 2:
+            y, bound = torch.tanh(y), 1.0
+        assert float(y.abs().max()) <= bound * (1 + 1e-6) + 1e-30, "the guaranteed bound of the forward does not hold"
+        split = self._split(y, self._sexp_for(bound)) if want_split else None
+        return y.contiguous(), mask, split, torch.tensor([bound], dtype=torch.float32)
+
     def gram_tn_f16x2(self, x, alpha, out):
         C = x.planes.shape[-1]
         X = x.float().reshape(-1, C)

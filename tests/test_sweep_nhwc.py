@@ -75,6 +75,10 @@ def test_split_sweep_matches_per_seed_autograd(act, defer):
     x = torch.randn(4, 3, 8, 8)
     seeds = torch.randn(3, 4, 5)
     f = sw.forward(x)
+    # the forward ran on the NHWC kernels: every tapped conv input but the RGB stem's is NHWC in memory
+    from laplace_amd._lib import is_channels_last
+
+    assert all(is_channels_last(sw.taps[n]["a"]) for n in taps if n not in ("conv1", "fc"))
     seen = []
     got = sw.backward(seeds, on_tap=lambda n, g: seen.append(n), defer_bn_scale=defer)
     f_ref, want = _autograd_tap_grads(model, taps, x, seeds)
