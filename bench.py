@@ -2,9 +2,10 @@
 
 Workload (config c4, per GPU): ResNet-18 (CIFAR stem, BN affine frozen, random init), full-network
 KFAC exact GGN, minibatch 128 of synthetic N(0,1) 3x32x32 images, 10 classes.  A "step" is one
-minibatch through the hot path: forward + ONE batched reverse pass (stock PyTorch-ROCm), then our
-HIP kernels for the likelihood root, every A/G factor (fp32 MFMA Gram engine; G factors as split-bf16 products) and the
-accumulation.  N > 1: one process per GPU, each rank its own K minibatches (weak scaling), one RCCL
+minibatch through the hot path, all of it our HIP kernels: NHWC forward (implicit-GEMM convolution on split-fp16
+operands + fused BatchNorm/add/ReLU), likelihood root, ONE seed-batched reverse sweep (the same convolution kernel as
+backward-data, element-wise VJPs emitting split tensors), every A / G factor, accumulation.  The library (rocBLAS)
+only sees the 512 x 10 head.  N > 1: one process per GPU, each rank its own K minibatches (weak scaling), one RCCL
 all-reduce of the accumulated factors inside the timed region (the fit's epoch end).
 
 Usage:  python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run)
@@ -29,6 +30,11 @@ BATCH = 128
 CLASSES = 10
 N_DATASET = 50_000  # the global N every rank passes to kron() (A factors carry 1/N)
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA
+# fp32-equivalent ceilings of the split schemes: three fp16 MFMAs (two-piece fp16 operands) / six bf16 MFMAs
+# (three-piece bf16 operands) per fp32 product block
+PEAK_F16X2_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3.0
+PEAK_BF16X3_TFLOPS = PEAK_F16_MFMA_TFLOPS / 6.0
 
 
 def parse():
@@ -136,18 +142,23 @@ def pmc_traffic(kernel_prefix: str):
     """HBM bytes per launch of the dominant kernel family from the committed rocprofv3 PMC passes over this very
     command (FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied: tools/pmc_traffic.py).
     Counters cannot be collected from inside the process, so the figure is read from profiles/; None if absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic_bench_c4.json")
-    try:
-        with open(path) as fh:
-            table = json.load(fh)
-    except (OSError, ValueError):
+    table, used = None, None
+    for name in ("r02_pmc_traffic_bench_c4", "r01_pmc_traffic_bench_c4"):
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name + ".json")
+        try:
+            with open(path) as fh:
+                table, used = json.load(fh), name
+            break
+        except (OSError, ValueError):
+            continue
+    if table is None:
         return None, None
     rows = [v for k, v in table.items() if k.startswith(kernel_prefix)]
     launches = sum(r["launches"] for r in rows)
     if not launches:
         return None, None
     total = sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows)
-    return total / launches, "profiles/r01_pmc_traffic_bench_c4.{json,md} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2x read correction)"
+    return total / launches, f"profiles/{used}.{{json,md}} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2x read correction)"
 
 
 # LK_BENCH_SELFTEST=1: control-flow check of this script without a GPU (tests/test_bench_contract.py): CPU tensors,
@@ -222,12 +233,17 @@ def main():
     # its launch stream, A-factor kernels NOT overlapped with the reverse passes so that the per-launch
     # durations are the kernels' own (the throughput above is measured without this instrumentation)
     prof = {}
-    if rank == 0 and not SELFTEST:
-        K.profile = prof
-        fit_steps(backend, batches, min(args.steps, 5), 1, overlap=False)
-        torch.cuda.synchronize()
-        K.profile = None
     prof_steps = min(args.steps, 5)
+    serial_ms = None
+    if rank == 0 and not SELFTEST:
+        fit_steps(backend, batches, 2, 1, overlap=False)  # (the accumulators of this leg warm up outside the clock)
+        torch.cuda.synchronize()
+        K.profile = prof
+        t_s = time.perf_counter()
+        fit_steps(backend, batches, prof_steps, 1, overlap=False)
+        torch.cuda.synchronize()
+        serial_ms = (time.perf_counter() - t_s) * 1e3 / prof_steps
+        K.profile = None
     if world > 1:
         t = torch.tensor([dt], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -248,11 +264,21 @@ def main():
         # factors with 13/40.5 of those multiply-adds and is bound by the read-modify-write of its blocks, so it is
         # priced on its algorithmic bytes (2 x blocks + input) against HBM.
         PEAK_HBM_GBS = 8000.0
+        F16X2 = ("fp32-level products from two-piece fp16 operands: three v_mfma_f32_32x32x16_f16 per fp32 product block; "
+                 "`achieved` = algorithmic fp32 flop / s, `peak` = 2500 / 3 TFLOP/s (the dense fp16 MFMA peak over the three "
+                 "MFMAs of the scheme), i.e. `frac` IS the fraction of the fp16 matrix peak the kernel sustains")
         fams = {
-            "gram_nt": ("lk::gram_kernel<MODE_NTB> (+ slab reduce): G-factor accumulation from the seed-batched "
-                        "cotangents; fp32-accurate products from three-piece split-bf16 operands, 6 bf16 MFMA flops per "
-                        "algorithmic fp32 flop (priced against the fp32-MFMA peak; the emulation's own ceiling is "
-                        "2500/6 = 417 TFLOP/s)", "mfma", "void lk::gram_kernel<5,"),
+            "conv16": ("lk::conv_f16x2_kernel: implicit-GEMM convolution on NHWC split tensors — backward-data of the "
+                       "seed-batched reverse sweep (batch 9 x 128) and the forward; " + F16X2, "mfma16",
+                       "lk::conv_f16x2_kernel"),
+            "gram16": ("lk::gram16_kernel (+ fixed-order reduce): G factors as Grams of the NHWC split cotangents through "
+                       "transposing LDS reads; symmetric-half flop K*n*(n+1); " + F16X2, "mfma16", "lk::gram16_kernel"),
+            "vjp16": ("lk::vjp_nhwc_split_kernel: element-wise VJP (mask x folded BatchNorm scale x residual add) of all "
+                      "seeds, emitting split tensors", "hbm", "lk::vjp_nhwc_split_kernel"),
+            "bnact16": ("lk::bn_act_fwd_nhwc_kernel: forward BatchNorm-eval + add + ReLU, emitting fp32, mask, split planes",
+                        "hbm", "lk::bn_act_fwd_nhwc_kernel"),
+            "gram_nt": ("lk::gram_kernel<MODE_NTB> (+ slab reduce): G factors from NCHW cotangents (graphs outside the NHWC "
+                        "sweep); six bf16 MFMAs per fp32 product block", "mfma", "void lk::gram_kernel<5,"),
             "pixpair": ("lk::gram_kernel<MODE_TNP>: banded pixel-pair accumulation of the 3x3-conv A factors "
                         "(block read-modify-write)", "hbm", "void lk::gram_kernel<4,"),
             "gram_conv": ("lk::gram_kernel<MODE_CONV> (+ slab reduce): implicit-im2col A-factor accumulation, "
@@ -267,6 +293,8 @@ def main():
                 continue
             if bound == "mfma":
                 achieved, peak, unit = work / (ms * 1e-3) / 1e12, PEAK_F32_MFMA_TFLOPS, "TFLOP/s"
+            elif bound == "mfma16":
+                achieved, peak, unit, bound = work / (ms * 1e-3) / 1e12, PEAK_F16X2_TFLOPS, "TFLOP/s", "mfma"
             else:
                 achieved, peak, unit = work / (ms * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
             traffic, traffic_src = pmc_traffic(prefix)
@@ -279,7 +307,17 @@ def main():
         roof = dict(fam_out[dominant]) if dominant else {"bound": "mfma", "achieved": 0.0, "peak": PEAK_F32_MFMA_TFLOPS,
                                                           "unit": "TFLOP/s", "frac": 0.0, "traffic": None}
         roof["family"] = dominant
-        roof["flop_convention"] = "mfma families: symmetric half K*n*(n+1) per launch (full-GEMM 2*K*n^2 would double it)"
+        roof["flop_convention"] = ("convolution: 2 * pixels * Cout * Cin * taps per launch (fp32 multiply-adds of the "
+                                   "algorithm); Gram families: symmetric half K*n*(n+1)")
+        own_ms = sum(v["ms_per_step"] for v in fam_out.values())
+        breakdown = None
+        if serial_ms is not None:
+            # where a step goes when nothing overlaps (the instrumented pass): our kernel families, and the rest (rocBLAS
+            # for the 512 x 10 head, torch element-wise glue, launch gaps).  No MIOpen kernel is left in the step.
+            breakdown = {"serial_ms_per_step": serial_ms, "own_kernels_ms": own_ms, "other_ms": max(serial_ms - own_ms, 0.0),
+                         "own_share": own_ms / serial_ms if serial_ms > 0 else None,
+                         "note": "measured without stream overlap; the timed region overlaps A-factor and G-factor "
+                                 "kernels with the reverse sweep"}
         result = {
             "metric": "KFAC-GGN fit samples/sec, ResNet-18",
             "value": samples / dt,
@@ -296,10 +334,33 @@ def main():
             "config": {"workload": "c4: ResNet-18 (CIFAR stem, BN frozen) full-network KFAC exact GGN fit, "
                                    "per-GPU minibatch 128, synthetic N(0,1) 3x32x32, 10 classes, N=50000",
                        "per_gpu_batch": BATCH, "parallelism": f"dp{world}"},
-            "roofline": roof,  # the family with the largest share of the step (measured without stream overlap)
+            "roofline": roof,  # the family with the largest share of the WHOLE step (measured without stream overlap)
             "roofline_families": fam_out,
+            "step_breakdown": breakdown,
         }
     # ---- untimed extras on rank 0 (separate line items per BASELINE.md) --------------------------------------
+    if rank == 0 and world == 1 and not SELFTEST:
+        # what the reference's own `fit` executes with backend=HipGGN: `self.H += backend.kron(X, y, N)` per minibatch
+        # (laplace/baselaplace.py:969-985) — one Kron per batch in the public layout, then the factor-wise add
+        from laplace_amd.kron import HipKron
+
+        def literal(n):
+            Hs = HipKron.init_from_model(backend.params, dev, torch.float32)
+            tot = torch.zeros((), device=dev)
+            for i in range(n):
+                X, y = batches[i % len(batches)]
+                lb, Hb = backend.kron(X, y, N=N_DATASET)
+                tot = tot + lb
+                Hs += Hb
+            return Hs
+
+        literal(2)
+        sync()
+        t0 = time.perf_counter()
+        n_lit = min(args.steps, 10)
+        literal(n_lit)
+        sync()
+        result["dropin_fit_samples_per_s"] = n_lit * BATCH / (time.perf_counter() - t0)
     if rank == 0 and world == 1:
         if not args.no_eigh:
             sync()
@@ -321,9 +382,29 @@ def main():
                 for _ in range(3):
                     f_mu, f_var = _pred.glm_variance_kron(backend, Xp, post)
                 sync()
+                pred_rate = 3 * len(Xp) / (time.perf_counter() - t0)
+                pprof = {}
+                K.profile = pprof
+                _pred.glm_variance_kron(backend, Xp, post)
+                sync()
+                K.profile = None
+                pred_ms = len(Xp) / pred_rate * 1e3
+                pfam = {}
+                for key, peak, what in (("quadconv", PEAK_BF16X3_TFLOPS, "lk::quadform_conv_kernel: per-layer quadratic form of "
+                                         "the weight-sharing Jacobian, six bf16 MFMAs per fp32 product block"),
+                                        ("conv16", PEAK_F16X2_TFLOPS, "lk::conv_f16x2_kernel (forward + reverse sweep of the "
+                                         "10 identity seeds)")):
+                    evs = pprof.get(key, [])
+                    ms_k = sum(e0.elapsed_time(e1) for e0, e1, _ in evs)
+                    if evs and ms_k > 0:
+                        tf = sum(w for _, _, w in evs) / (ms_k * 1e-3) / 1e12
+                        pfam[key] = {"kernel": what, "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s",
+                                     "frac": tf / peak, "ms_per_call": ms_k, "launches": len(evs)}
+                dom = max(pfam, key=lambda k: pfam[k]["ms_per_call"]) if pfam else None
                 result["predictive_kron_c4"] = {
                     "workload": "c4 posterior: ResNet-18 full-network KFAC, GLM predictive variance [B,10,10], batch 128",
-                    "samples_per_s": 3 * len(Xp) / (time.perf_counter() - t0), "finite": bool(torch.isfinite(f_var).all())}
+                    "samples_per_s": pred_rate, "ms_per_call": pred_ms, "finite": bool(torch.isfinite(f_var).all()),
+                    "roofline": dict(pfam[dom], family=dom) if dom else None, "roofline_families": pfam}
             del dec
         if not args.no_predictive and not SELFTEST:
             result["predictive"] = predictive_leg(dev)

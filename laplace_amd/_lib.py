@@ -387,11 +387,12 @@ class HipKernels:
         assert wplanes.shape[3] == Ci and out.shape[0] == N and out.shape[3] == Co
         flat = (ctypes.c_int * (3 * len(taps)))(*[int(v) for t in taps for v in t])
         cfg = self.conv_config if config is None else config
-        self._rc(self.lib.lk_conv_nhwc_f16x2(_ptr(x.planes[0]), _ptr(x.planes[1]), _ptr(x.sexp), N, Hi, Wi, Ci,
-                                             _ptr(wplanes[0]), _ptr(wplanes[1]), _ptr(wsexp), Co, Hc, Wc, in_mul,
-                                             out.shape[1], out.shape[2], out_step, oh0, ow0, len(taps), flat,
-                                             _ptr(self._zero16(out.device)), _ptr(out), 1 if accumulate else 0,
-                                             _ptr(amax_out), int(cfg), self._stream(out.device)), "lk_conv_nhwc_f16x2")
+        z = self._zero16(out.device)
+        # algorithmic work: the fp32 multiply-adds of the convolution (each is three fp16 MFMA multiply-adds on the chip)
+        self._rc(self._timed("conv16", 2.0 * N * Hc * Wc * Co * Ci * len(taps), out.device, lambda: self.lib.lk_conv_nhwc_f16x2(
+            _ptr(x.planes[0]), _ptr(x.planes[1]), _ptr(x.sexp), N, Hi, Wi, Ci, _ptr(wplanes[0]), _ptr(wplanes[1]),
+            _ptr(wsexp), Co, Hc, Wc, in_mul, out.shape[1], out.shape[2], out_step, oh0, ow0, len(taps), flat, _ptr(z),
+            _ptr(out), 1 if accumulate else 0, _ptr(amax_out), int(cfg), self._stream(out.device))), "lk_conv_nhwc_f16x2")
         return out
 
     def vjp_nhwc_split(self, g, g_amax, g2, mult, mult_amax, scale, scale_amax, S, out_shape):
@@ -413,10 +414,12 @@ class HipKernels:
                 raise LaplaceHipError("vjp_nhwc_split: multiplier must be a contiguous [B, H, W, C] uint8 / float32 tensor")
         if g is not None:
             _check(g, "g")
-        self._rc(self.lib.lk_vjp_nhwc_split_f16x2(
+        # HBM-bound: algorithmic bytes = every addend read once, the planes written once, the multiplier once per sample
+        nbytes = 4.0 * n * ((g is not None) + (g2 is not None) + 1) + (per * (4 if m_is_float else 1) if mult is not None else 0)
+        self._rc(self._timed("vjp16", nbytes, dev, lambda: self.lib.lk_vjp_nhwc_split_f16x2(
             _ptr(g), _ptr(g_amax), None if g2 is None else _ptr(g2.planes[0]), None if g2 is None else _ptr(g2.planes[1]),
             None if g2 is None else _ptr(g2.sexp), _ptr(mult), m_is_float, _ptr(mult_amax), _ptr(scale), _ptr(scale_amax),
-            C, S, per, _ptr(planes[0]), _ptr(planes[1]), _ptr(sexp), self._stream(dev)), "lk_vjp_nhwc_split_f16x2")
+            C, S, per, _ptr(planes[0]), _ptr(planes[1]), _ptr(sexp), self._stream(dev))), "lk_vjp_nhwc_split_f16x2")
         return SplitTensor(planes, sexp)
 
     def bn_act_forward_nhwc(self, x, x_amax, scale, shift, scale_amax, shift_amax, act, addend=None, addend_bound=None,
@@ -432,10 +435,12 @@ class HipKernels:
         bound = torch.empty(1, dtype=torch.float32, device=x.device)
         if addend is not None:
             _check(addend, "addend")
-        self._rc(self.lib.lk_bn_act_fwd_nhwc_f16x2(
+        nbytes = x.numel() * (4.0 + 4.0 + (4.0 if addend is not None else 0.0) + (4.0 if want_split else 0.0)
+                              + (1.0 if mask is not None else 0.0))
+        self._rc(self._timed("bnact16", nbytes, x.device, lambda: self.lib.lk_bn_act_fwd_nhwc_f16x2(
             _ptr(x), _ptr(x_amax), _ptr(scale), _ptr(shift), _ptr(scale_amax), _ptr(shift_amax), _ptr(addend),
             _ptr(addend_bound), int(act), C, x.numel(), _ptr(y), _ptr(mask), None if planes is None else _ptr(planes[0]),
-            None if planes is None else _ptr(planes[1]), _ptr(sexp), _ptr(bound), self._stream(x.device)),
+            None if planes is None else _ptr(planes[1]), _ptr(sexp), _ptr(bound), self._stream(x.device))),
             "lk_bn_act_fwd_nhwc_f16x2")
         return y, mask, (SplitTensor(planes, sexp) if planes is not None else None), bound
 
@@ -831,8 +836,9 @@ class HipKernels:
         Dk = v.shape[1]
         ws = self._workspace(self.lib.lk_quadform_shared_workspace_bytes(B, C, Do, Dk), u.device)
         self._rc(
-            self.lib.lk_kron_quadform_shared_f32(_ptr(u), _ptr(v), _ptr(l1), _ptr(l2), _ptr(delta), B, C, Do, Dk, L,
-                                                 _ptr(fvar), _ptr(ws), ws.numel(), self._stream(u.device)),
+            self._timed("quadconv", 2.0 * B * C * L * Do * Dk, u.device, lambda: self.lib.lk_kron_quadform_shared_f32(
+                _ptr(u), _ptr(v), _ptr(l1), _ptr(l2), _ptr(delta), B, C, Do, Dk, L, _ptr(fvar), _ptr(ws), ws.numel(),
+                self._stream(u.device))),
             "lk_kron_quadform_shared_f32",
         )
         return fvar

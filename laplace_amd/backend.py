@@ -517,7 +517,7 @@ class KronAccumulator:
         self._persist_slabs = os.environ.get("LK_PERSIST_SLABS", "1") != "0"
         #: minibatches stacked per pixel-pair launch: the kernel is bound by the read-modify-write of its blocks, which
         #: happens once per LAUNCH, so stacking the NHWC inputs of consecutive minibatches divides that traffic
-        self.pix_group = max(1, int(os.environ.get("LK_PIX_GROUP", "2")))
+        self.pix_group = max(1, int(os.environ.get("LK_PIX_GROUP", "4")))
         self._side = None
         self.factors = None  # per tap: [G, A]
         self.loss = None

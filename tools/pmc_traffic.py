@@ -10,7 +10,13 @@ from collections import defaultdict
 
 
 def short(name):
-    return re.sub(r"\(.*", "", name)
+    name = re.sub(r"\(.*", "", name)
+    m = re.match(r"_ZN2lk\d+([a-z0-9_]+?)(?:I(.*))?E[vPK]", name)
+    if m:  # mangled (templated on a config struct, or a plain lk:: kernel): readable name + integer template arguments
+        ints = re.findall(r"Li(\d+)E", m.group(2) or "")
+        b = re.findall(r"Lb([01])E", m.group(2) or "")
+        name = "lk::" + m.group(1) + ("<" + ",".join(ints + b) + ">" if (ints or b) else "")
+    return name
 
 
 def collect(db, counter):
@@ -18,7 +24,7 @@ def collect(db, counter):
     acc = defaultdict(list)
     dur = defaultdict(list)
     for name, cname, val, d in con.execute("select name, counter_name, counter_value, duration from pmc_events"):
-        if cname == counter and name.startswith(("lk::", "void lk::")):
+        if cname == counter and name.startswith(("lk::", "void lk::", "_ZN2lk")):
             acc[short(name)].append(val)
             dur[short(name)].append(d)
     return acc, dur

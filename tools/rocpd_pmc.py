@@ -8,9 +8,11 @@ from collections import defaultdict
 
 def short(name):
     name = re.sub(r"\(.*", "", name)
-    m = re.match(r"_ZN2lk\d+([a-z0-9_]+)INS_\d+[A-Za-z0-9]*Cfg((?:ILi|Li)[0-9ELi]*)", name)
-    if m:  # templated on a config struct: keep the kernel name and the integer template arguments
-        name = "lk::" + m.group(1) + "<" + ",".join(re.findall(r"Li(\d+)E", m.group(2))) + ">"
+    m = re.match(r"_ZN2lk\d+([a-z0-9_]+?)(?:I(.*))?E[vPK]", name)
+    if m:  # mangled (templated on a config struct, or a plain lk:: kernel): readable name + integer template arguments
+        ints = re.findall(r"Li(\d+)E", m.group(2) or "")
+        b = re.findall(r"Lb([01])E", m.group(2) or "")
+        name = "lk::" + m.group(1) + ("<" + ",".join(ints + b) + ">" if (ints or b) else "")
     return name if len(name) < 90 else name[:87] + "..."
 
 
