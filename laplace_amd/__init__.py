@@ -21,5 +21,13 @@ def glm_predictive(la, X, diagonal_output=False):
     return _glm(la, X, diagonal_output=diagonal_output)
 
 
-__all__ = ["HipGGN", "HipEF", "HipKron", "HipKronDecomposed", "HAVE_REFERENCE", "fit_kron", "glm_predictive"]
+def Laplace(model, likelihood, subset_of_weights="last_layer", hessian_structure="kron", *args, **kwargs):
+    """``laplace.Laplace``'s call shape, returning the fused subclasses of the reference's classes — see
+    :mod:`laplace_amd.dropin`."""
+    from laplace_amd.dropin import Laplace as _L
+
+    return _L(model, likelihood, subset_of_weights, hessian_structure, *args, **kwargs)
+
+
+__all__ = ["HipGGN", "HipEF", "HipKron", "HipKronDecomposed", "HAVE_REFERENCE", "fit_kron", "glm_predictive", "Laplace"]
 __version__ = "0.1.0"

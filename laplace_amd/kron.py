@@ -189,7 +189,8 @@ class HipKron(_KronBase):
             eigvecs.append(Qs)
             eigvals.append(ls)
         out = HipKronDecomposed(eigvecs, eigvals, damping=damping)
-        out._eig_info = infos  # device flags; checked lazily by `check_converged`
+        out._eig_info = infos  # device flags: read (one synchronisation) at the first use of the decomposition
+        out._conv = {"checked": False, "source": self, "slots": [(bi, fi) for _, bi, fi in all_dense]}
         return out
 
     # -- generic algebra (plumbing; torch ops) ------------------------------------------------------
@@ -322,6 +323,8 @@ class HipKronDecomposed(_KronDecomposedBase):
     fused_logdet = True
 
     def __init__(self, eigenvectors, eigenvalues, deltas: torch.Tensor | None = None, damping: bool = False):
+        self._conv = {"checked": True}  # shared by everything derived from one decomposition (`_like`)
+        self._eig_info = []
         self.eigenvectors = eigenvectors
         self.eigenvalues = eigenvalues
         device, dtype = eigenvectors[0][0].device, eigenvectors[0][0].dtype
@@ -331,10 +334,15 @@ class HipKronDecomposed(_KronDecomposedBase):
             self._check_deltas(deltas)
             self.deltas = deltas
         self.damping = damping
-        self._eig_info = []
 
     # ``H * scalar`` (matrix.py:366-376) is kept as a pending scalar on the eigenvalue PRODUCT of every block: the
     # fused logdet takes it as a kernel argument, everything else sees the materialised ``scalar^(1/len) * l``.
+    @property
+    def _base_eigenvalues(self):
+        if not self._conv["checked"]:
+            self._ensure_converged()
+        return self._base_ev
+
     @property
     def eigenvalues(self):
         if self._scale is None:
@@ -347,16 +355,46 @@ class HipKronDecomposed(_KronDecomposedBase):
 
     @eigenvalues.setter
     def eigenvalues(self, value):
-        self._base_eigenvalues = value
+        self._base_ev = value
         self._scale = None
         self._scaled = None
 
     def check_converged(self) -> None:
-        """Raise (never ``exit()``, cf. utils/utils.py:208-222) if an eigensolve ran out of sweeps.
-        Synchronises with the device; call it once after ``fit`` if a hard guarantee is wanted."""
-        for info in self._eig_info:
-            if int(info[0].item()) != 0:
-                raise RuntimeError("lk_syevj_f32: eigendecomposition did not converge")
+        """Raise (never ``exit()``, cf. utils/utils.py:208-222) if an eigensolve ran out of sweeps, after the
+        reference's own remedy has been tried.  Synchronises with the device once."""
+        self._conv["checked"] = False
+        self._ensure_converged()
+
+    def _ensure_converged(self) -> None:
+        """The solver's status words are read at the FIRST use of the decomposition (one host read of a packed flag
+        vector).  A factor that ran out of sweeps gets the reference's treatment (utils/utils.py:208-222): solve
+        ``M + I`` instead, subtract 1 from the eigenvalues; if that fails too: RuntimeError — the reference's prior
+        gridsearch catches RuntimeError (baselaplace.py:545-551); it never exits the process."""
+        conv = self._conv
+        conv["checked"] = True
+        infos = self._eig_info
+        if not infos:
+            return
+        flags = torch.stack([i.reshape(-1)[0].to(torch.float32) for i in infos]).cpu()
+        bad = [k for k in range(len(infos)) if float(flags[k]) != 0.0]
+        if not bad:
+            return
+        src, slots = conv.get("source"), conv.get("slots")
+        if src is None or slots is None:
+            raise RuntimeError("lk_syevj_f32: eigendecomposition did not converge")
+        K = get_kernels()
+        for k in bad:
+            bi, fi = slots[k]
+            M = src.kfacs[bi][fi]
+            Mj = (M + torch.eye(M.shape[0], device=M.device, dtype=M.dtype)).contiguous()
+            (l, Q, info), = K.syevj_batched([Mj], clamp=False)
+            if int(info.reshape(-1)[0].item()) != 0:
+                raise RuntimeError(f"lk_syevj_f32: eigendecomposition of a {M.shape[0]} x {M.shape[0]} factor did not "
+                                   "converge, also not with jitter")
+            l = torch.nan_to_num((l - 1.0).clamp(min=0.0))
+            self._base_ev[bi][fi].copy_(l)
+            self.eigenvectors[bi][fi].copy_(torch.nan_to_num(Q))
+            infos[k].zero_()
 
     def detach(self):
         self.deltas = self.deltas.detach()
@@ -370,9 +408,10 @@ class HipKronDecomposed(_KronDecomposedBase):
         raise ValueError("Invalid shape of delta added to KronDecomposed.")
 
     def _like(self, deltas, scale=None):
-        out = HipKronDecomposed(self.eigenvectors, self._base_eigenvalues, deltas, self.damping)
+        out = HipKronDecomposed(self.eigenvectors, self._base_ev, deltas, self.damping)
         out._scale = scale
         out._eig_info = self._eig_info
+        out._conv = self._conv
         return out
 
     def __add__(self, deltas: torch.Tensor):

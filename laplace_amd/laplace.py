@@ -849,7 +849,7 @@ def fit_kron(la, train_loader, process_group=None, distributed: bool | None = No
     return la
 
 
-def glm_predictive(la, X, diagonal_output: bool = False):
+def glm_predictive(la, X, diagonal_output: bool = False, fallback=None):
     """Fused GLM predictive ``(f_mu, f_var)`` for the REFERENCE's own Laplace objects built with ``backend=HipGGN``::
 
         f_mu, f_var = laplace_amd.glm_predictive(la, x_test)     # instead of la._glm_predictive_distribution(x_test)
@@ -871,7 +871,7 @@ def glm_predictive(la, X, diagonal_output: bool = False):
         else:
             f_mu, f_var = _pred.glm_variance_full_last_layer(backend, X, la.posterior_covariance)
     except NotImplementedError:
-        return la._glm_predictive_distribution(X, diagonal_output=diagonal_output)
+        return (fallback or la._glm_predictive_distribution)(X, diagonal_output=diagonal_output)
     if diagonal_output:
         f_var = torch.diagonal(f_var, dim1=-2, dim2=-1)
     return f_mu.detach(), f_var.detach()

@@ -194,3 +194,50 @@ def test_link_approximations_match_the_reference(ref, hs, link):
     got = lean(X, pred_type="glm", link_approx=link)
     assert rel(got, want) < 1e-4
     assert torch.allclose(got.sum(-1), torch.ones(len(X)), atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["mlp", "bnres"])
+@pytest.mark.parametrize("lik", ["classification", "regression"])
+@pytest.mark.parametrize("sow,hs", [("all", "kron"), ("all", "diag"), ("all", "full"), ("last_layer", "kron"),
+                                    ("last_layer", "full"), ("last_layer", "diag")])
+def test_fused_subclasses_of_the_reference_classes(ref, name, lik, sow, hs):
+    """laplace_amd.Laplace(...) -> subclasses of the reference's KronLaplace / DiagLaplace / ... whose `fit` and
+    `_glm_predictive_distribution` take the fused paths (SURVEY.md §8b tertiary seam): same numbers as the goldens of the
+    unmodified reference, through `la.fit(loader)` and `la(x)` themselves; and the reference's factory is undisturbed."""
+    import laplace
+    from laplace.baselaplace import ParametricLaplace
+
+    import laplace_amd
+    from laplace_amd import HipGGN, predictive as P
+    from oracle.make_golden import PRIOR_PREC, SIGMA_NOISE
+
+    g = load_golden(name, lik)
+    model, X, y = golden_model(name, g, dtype=torch.float32)
+    sig = SIGMA_NOISE if lik == "regression" else 1.0
+    la = laplace_amd.Laplace(model, lik, subset_of_weights=sow, hessian_structure=hs, prior_precision=PRIOR_PREC,
+                             sigma_noise=sig)
+    assert isinstance(la, ParametricLaplace) and la._backend_cls is HipGGN and type(la).__name__.startswith("Hip")
+    calls = {"jac": 0}
+    la.fit(DataLoader(TensorDataset(X, y), batch_size=5))
+    orig = type(la.backend).jacobians
+
+    def counting(self, *a, **k):
+        calls["jac"] += 1
+        return orig(self, *a, **k)
+
+    type(la.backend).jacobians = counting
+    try:
+        tag = f"la.{sow}.{hs}"
+        f_mu, f_var = la._glm_predictive_distribution(X)
+        if hs != "full" or sow == "last_layer":
+            assert calls["jac"] == 0, "the fused predictive materialised the Jacobian"
+        assert rel(f_mu, g[f"{tag}.f_mu"]) < 1e-4 and rel(f_var, g[f"{tag}.f_var"]) < 1e-4
+        assert rel(la.loss, g[f"{tag}.loss"]) < 1e-4
+        assert rel(la.log_marginal_likelihood(), g[f"{tag}.marglik"]) < 1e-4
+        out = la(X, pred_type="glm", link_approx="probit") if lik == "classification" else la(X, pred_type="glm")
+        assert torch.isfinite(out[0] if isinstance(out, tuple) else out).all()
+    finally:
+        type(la.backend).jacobians = orig
+    # the reference's factory still hands out the reference's own classes
+    ref_la = laplace.Laplace(model, lik, subset_of_weights=sow, hessian_structure=hs, backend=HipGGN)
+    assert not type(ref_la).__name__.startswith("Hip")
