@@ -202,6 +202,18 @@ int lk_bn_act_fwd_nhwc_f16x2(const float* x, const unsigned* x_amax, const float
                              const unsigned* scale_amax, const unsigned* shift_amax, const float* addend,
                              const float* addend_bound, int act, int64_t C, int64_t per, float* y, void* mask, void* y_h,
                              void* y_l, int* y_sexp, float* y_bound, void* stream);
+/* Eigenbasis algebra of KronDecomposed (laplace/utils/matrix.py:406-461: `_bmm` at exponents -1 / -1/2, i.e. the
+ * materialised-Jacobian GLM predictive `inv_square_form` and the posterior samples of baselaplace.py:1845-1858).
+ * lk_gemm_f32: batched  C[b] = alpha (op(A[b]) . op(B[b])) (.) E  (+ C[b] if accumulate) on the exact-fp32 MFMA; matrices
+ * row-major with leading dimensions, batch strides (0 = shared operand), op = transpose if trans_x != 0 (A stored K x M,
+ * B stored N x K), E optional M x N weight (lde = 0: one row broadcast).
+ * lk_kron_pow_f32: lam[i][j] = (l1[i] l2[j] + delta)^e (damping: ((l1[i] + sqrt delta)(l2[j] + sqrt delta))^e;
+ * l2 == NULL: (l1[i] + delta)^e); delta is a device scalar. */
+int lk_gemm_f32(const float* A, const float* B, const float* E, float* C, int64_t batch, int64_t M, int64_t N, int64_t K,
+                int64_t lda, int64_t ldb, int64_t ldc, int64_t lde, int64_t stride_a, int64_t stride_b, int64_t stride_c,
+                int trans_a, int trans_b, float alpha, int accumulate, void* stream);
+int lk_kron_pow_f32(const float* l1, int64_t n1, const float* l2, int64_t n2, const float* delta, float exponent,
+                    int damping, float* lam, void* stream);
 /* G[C][C] += alpha * X^T X for a split tensor X [R][C] (rows = (seed, sample, position) of an NHWC cotangent): the
  * G factor of a convolution layer (curvlinops.py:87-100).  Only the 32x32 tiles on or above the diagonal are written
  * (lk_symmetrize_f32 mirrors).  C = 64 or a multiple of 128.  Deterministic (workspace partials, fixed-order sum). */

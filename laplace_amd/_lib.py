@@ -65,6 +65,9 @@ SIGNATURES = {
     "lk_bn_act_fwd_nhwc_f16x2": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "lk_gram_tn_f16x2_workspace_bytes": (_sz, [_i64, _i64]),
     "lk_gram_tn_f16x2": (_int, [_vp, _vp, _vp, _i64, _i64, _f32, _vp, _vp, _vp, _sz, _vp]),
+    "lk_gemm_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _int, _int, _f32,
+                           _int, _vp]),
+    "lk_kron_pow_f32": (_int, [_vp, _i64, _vp, _i64, _vp, _f32, _int, _vp, _vp]),
     "lk_symmetrize_f32": (_int, [_vp, _i64, _vp]),
     "lk_permute_sym_f32": (_int, [_vp, _i64, _i64, _vp, _int, _vp]),
     "lk_diag_ggn_linear_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp, _vp, _vp]),
@@ -457,6 +460,48 @@ class HipKernels:
         self._rc(self._timed("gram16", float(R) * C * (C + 1), out.device, lambda: self.lib.lk_gram_tn_f16x2(
             _ptr(x.planes[0]), _ptr(x.planes[1]), _ptr(x.sexp), R, C, float(alpha), _ptr(out), _ptr(z), _ptr(ws),
             ws.numel(), self._stream(out.device))), "lk_gram_tn_f16x2")
+        return out
+
+    # ---- eigenbasis algebra of KronDecomposed (lk_gemm.hip) ------------------------------------------------
+    def gemm(self, A, B, C, batch, M, N, Kd, lda, ldb, ldc, sa=0, sb=0, sc=0, ta=False, tb=False, E=None, lde=0,
+             alpha=1.0, accumulate=False):
+        """raw batched ``C[b] = alpha op(A[b]) op(B[b]) (.) E`` on device pointers / offsets of fp32 tensors (see
+        lk_gemm_f32); ``A``, ``B``, ``C``, ``E`` are tensors whose ``data_ptr()`` is the first element"""
+        self._rc(self.lib.lk_gemm_f32(_ptr(A), _ptr(B), _ptr(E), _ptr(C), batch, M, N, Kd, lda, ldb, ldc, lde, sa, sb, sc,
+                                      1 if ta else 0, 1 if tb else 0, float(alpha), 1 if accumulate else 0,
+                                      self._stream(C.device)), "lk_gemm_f32")
+
+    def kron_pow(self, l1, l2, delta, exponent, damping=False):
+        """``(l1 (x) l2 + delta) ** exponent`` as an ``[n1, n2]`` table (``l2`` None: ``[n1]``)"""
+        _check(l1, "l1")
+        n1 = l1.numel()
+        n2 = 0 if l2 is None else l2.numel()
+        lam = torch.empty((n1, n2) if l2 is not None else (n1,), dtype=torch.float32, device=l1.device)
+        d = delta.detach().reshape(-1)[:1].to(torch.float32).contiguous()
+        self._rc(self.lib.lk_kron_pow_f32(_ptr(l1), n1, _ptr(l2), n2, _ptr(d), float(exponent), 1 if damping else 0,
+                                          _ptr(lam), self._stream(l1.device)), "lk_kron_pow_f32")
+        return lam
+
+    def kron_sandwich(self, W, col0, P, R, Q1, Q2, lam, out):
+        """``out[r, col0:col0+p] = vec(Q1 ((Q1^T W_r Q2) (.) lam) Q2^T)`` for the ``R`` rows of ``W [R, P]`` (block of
+        ``p = p_in * p_out`` columns at ``col0``); ``Q2`` None: the single-factor block ``((W_r Q1) (.) lam) Q1^T``.
+        Operands are read and written in place (leading dimension ``P``)."""
+        _check(W, "W"), _check(out, "out"), _check(Q1, "Q1"), _check(lam, "lam")
+        Wv, Ov = W.reshape(-1)[col0:], out.reshape(-1)[col0:]
+        if Q2 is None:
+            p = Q1.shape[0]
+            T = torch.empty(R, p, dtype=torch.float32, device=W.device)
+            self.gemm(Wv, Q1, T, 1, R, p, p, P, p, p, E=lam, lde=0)
+            self.gemm(T, Q1, Ov, 1, R, p, p, p, p, P, tb=True)
+            return out
+        _check(Q2, "Q2")
+        pi, po = Q1.shape[0], Q2.shape[0]
+        T = torch.empty(R, pi, po, dtype=torch.float32, device=W.device)
+        U = torch.empty(R, pi, po, dtype=torch.float32, device=W.device)
+        self.gemm(Wv, Q2, T, R, pi, po, po, po, po, po, sa=P, sc=pi * po)                       # T_r = W_r Q2
+        self.gemm(Q1, T, U, R, pi, po, pi, pi, po, po, sb=pi * po, sc=pi * po, ta=True, E=lam, lde=po)  # (Q1^T T_r) . lam
+        self.gemm(Q1, U, T, R, pi, po, pi, pi, po, po, sb=pi * po, sc=pi * po)                  # Q1 M_r
+        self.gemm(T, Q2, Ov, R, pi, po, po, po, po, po, sa=pi * po, sc=P, tb=True)              # ... Q2^T -> out
         return out
 
     def gram_conv(self, x, kernel_size, stride, padding, dilation, alpha, out, upper_only=False, native=False):

@@ -465,8 +465,28 @@ class HipKronDecomposed(_KronDecomposedBase):
         return torch.pow(torch.outer(l1, l2) + delta, exponent)
 
     def _bmm(self, W: torch.Tensor, exponent: float = -1) -> torch.Tensor:
+        """``self ** exponent @ W`` row-wise (matrix.py:406-456) on ``lk_gemm_f32``: per Kronecker block the slice of
+        every row is rotated into the eigenbasis, weighted by ``(l1 (x) l2 + delta) ** exponent`` in the epilogue of the
+        second product and rotated back, operands addressed in place.  Differentiable operands (marginal-likelihood
+        training through the predictive) and non-fp32 / CPU tensors take the same algebra through torch."""
         assert W.ndim == 3
         B, K_, P = W.shape
+        K = get_kernels()
+        if hasattr(K, "kron_sandwich") and W.dtype == torch.float32 and not (
+                torch.is_grad_enabled() and (W.requires_grad or self.deltas.requires_grad)):
+            Wc = W.reshape(B * K_, P).contiguous()
+            out = torch.empty_like(Wc)
+            cur = 0
+            for ls, Qs, delta in zip(self.eigenvalues, self.eigenvectors, self.deltas):
+                if len(ls) == 1:
+                    lam = K.kron_pow(ls[0].contiguous(), None, delta, exponent)
+                    K.kron_sandwich(Wc, cur, P, B * K_, Qs[0].contiguous(), None, lam, out)
+                    cur += len(ls[0])
+                else:
+                    lam = K.kron_pow(ls[0].contiguous(), ls[1].contiguous(), delta, exponent, self.damping)
+                    K.kron_sandwich(Wc, cur, P, B * K_, Qs[0].contiguous(), Qs[1].contiguous(), lam, out)
+                    cur += len(ls[0]) * len(ls[1])
+            return out.reshape(B, K_, P)
         W = W.reshape(B * K_, P)
         cur, SW = 0, []
         for ls, Qs, delta in zip(self.eigenvalues, self.eigenvectors, self.deltas):
