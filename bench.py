@@ -70,7 +70,7 @@ def fit_steps(backend, batches, n_steps, world, overlap=True):
         X, y = batches[i % len(batches)]
         acc.add_batch(X, y)
     if world > 1:
-        allreduce_curvature(acc.tensors())
+        allreduce_curvature(acc.tensors(), mirror=False)  # packed upper triangles; finalize() mirrors
     loss, H = acc.finalize()
     return loss, H
 

@@ -202,6 +202,11 @@ int lk_bn_act_fwd_nhwc_f16x2(const float* x, const unsigned* x_amax, const float
                              const unsigned* scale_amax, const unsigned* shift_amax, const float* addend,
                              const float* addend_bound, int act, int64_t C, int64_t per, float* y, void* mask, void* y_h,
                              void* y_l, int* y_sexp, float* y_bound, void* stream);
+/* Row-major packed upper triangle of a symmetric n x n factor (what the ranks of a data-parallel fit exchange: half the
+ * bytes of the square): packed[i n - i (i - 1) / 2 + (j - i)] = A[i][j], j >= i.  Unpacking writes the upper triangle only. */
+int lk_pack_upper_f32(const float* A, int64_t n, float* packed, void* stream);
+int lk_unpack_upper_f32(const float* packed, int64_t n, float* A, void* stream);
+
 /* Eigenbasis algebra of KronDecomposed (laplace/utils/matrix.py:406-461: `_bmm` at exponents -1 / -1/2, i.e. the
  * materialised-Jacobian GLM predictive `inv_square_form` and the posterior samples of baselaplace.py:1845-1858).
  * lk_gemm_f32: batched  C[b] = alpha (op(A[b]) . op(B[b])) (.) E  (+ C[b] if accumulate) on the exact-fp32 MFMA; matrices

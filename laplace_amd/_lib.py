@@ -68,6 +68,8 @@ SIGNATURES = {
     "lk_gemm_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _int, _int, _f32,
                            _int, _vp]),
     "lk_kron_pow_f32": (_int, [_vp, _i64, _vp, _i64, _vp, _f32, _int, _vp, _vp]),
+    "lk_pack_upper_f32": (_int, [_vp, _i64, _vp, _vp]),
+    "lk_unpack_upper_f32": (_int, [_vp, _i64, _vp, _vp]),
     "lk_symmetrize_f32": (_int, [_vp, _i64, _vp]),
     "lk_permute_sym_f32": (_int, [_vp, _i64, _i64, _vp, _int, _vp]),
     "lk_diag_ggn_linear_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp, _vp, _vp]),
@@ -461,6 +463,16 @@ class HipKernels:
             _ptr(x.planes[0]), _ptr(x.planes[1]), _ptr(x.sexp), R, C, float(alpha), _ptr(out), _ptr(z), _ptr(ws),
             ws.numel(), self._stream(out.device))), "lk_gram_tn_f16x2")
         return out
+
+    # ---- packed upper triangles (lk_pack.hip) ---------------------------------------------------------------
+    def pack_upper(self, A, packed):
+        """upper triangle of the square ``A`` -> ``packed [n (n + 1) / 2]`` (a slice of the exchange buffer)"""
+        _check(A, "A"), _check(packed, "packed")
+        self._rc(self.lib.lk_pack_upper_f32(_ptr(A), A.shape[0], _ptr(packed), self._stream(A.device)), "lk_pack_upper_f32")
+
+    def unpack_upper(self, packed, A):
+        _check(A, "A"), _check(packed, "packed")
+        self._rc(self.lib.lk_unpack_upper_f32(_ptr(packed), A.shape[0], _ptr(A), self._stream(A.device)), "lk_unpack_upper_f32")
 
     # ---- eigenbasis algebra of KronDecomposed (lk_gemm.hip) ------------------------------------------------
     def gemm(self, A, B, C, batch, M, N, Kd, lda, ldb, ldc, sa=0, sb=0, sc=0, ta=False, tb=False, E=None, lde=0,

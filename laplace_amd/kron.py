@@ -156,24 +156,42 @@ class HipKron(_KronBase):
                 for st in streams:
                     main.wait_stream(st)
         if world > 1 and all_dense:
-            # packed exchange: [eigenvalues | eigenvectors | not-converged flag] per factor, owners fill their slots
+            # exchange: every owner packs [eigenvalues | eigenvectors | status] of ITS factors into one buffer and
+            # broadcasts it; a rank receives exactly the bytes it does not have (an all-gather with unequal shares),
+            # nothing is zero-padded or summed
             ref_t = self.kfacs[all_dense[0][1]][all_dense[0][2]]
-            total = sum(n + n * n + 1 for n, _, _ in all_dense)
-            flat = torch.zeros(total, dtype=ref_t.dtype, device=ref_t.device)
-            off, slots = 0, {}
-            for n, bi, fi in all_dense:
-                slots[(bi, fi)] = off
-                if (bi, fi) in results:
-                    l, Q = results[(bi, fi)]
-                    flat[off:off + n] = l
-                    flat[off + n:off + n + n * n] = Q.reshape(-1)
+            by_owner: dict[int, list] = {r: [] for r in range(world)}
+            for d, o in zip(all_dense, owner):
+                by_owner[o].append(d)
+            bufs = {}
+            for r in range(world):
+                total = sum(n + n * n + 1 for n, _, _ in by_owner[r])
+                bufs[r] = torch.empty(total, dtype=ref_t.dtype, device=ref_t.device)
+            off = 0
+            info_of = {(bi, fi): info for (_, bi, fi), info in zip(dense, infos)}
+            for n, bi, fi in by_owner[rank]:
+                l, Q = results[(bi, fi)]
+                bufs[rank][off:off + n] = l
+                bufs[rank][off + n:off + n + n * n] = Q.reshape(-1)
+                bufs[rank][off + n + n * n] = info_of[(bi, fi)][0].to(ref_t.dtype)
                 off += n + n * n + 1
-            for (n, bi, fi), info in zip(dense, infos):
-                flat[slots[(bi, fi)] + n + n * n] = info[0].to(flat.dtype)
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=process_group)
+            works = []
+            for r in range(world):
+                if bufs[r].numel():
+                    src = dist.get_global_rank(process_group, r) if process_group is not None else r
+                    works.append(dist.broadcast(bufs[r], src=src, group=process_group, async_op=True))
+            for w in works:
+                w.wait()
             results, infos = {}, []
+            slot = {}
+            for r in range(world):
+                off = 0
+                for n, bi, fi in by_owner[r]:
+                    slot[(bi, fi)] = (r, off)
+                    off += n + n * n + 1
             for n, bi, fi in all_dense:
-                off = slots[(bi, fi)]
+                r, off = slot[(bi, fi)]
+                flat = bufs[r]
                 results[(bi, fi)] = (flat[off:off + n], flat[off + n:off + n + n * n].view(n, n))
                 infos.append(flat[off + n + n * n:off + n + n * n + 1])
         eigvecs, eigvals = [], []

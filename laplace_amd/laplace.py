@@ -112,17 +112,37 @@ def resolve_distributed(train_loader, distributed, group=None) -> bool:
     return False
 
 
-def allreduce_curvature(tensors: list[torch.Tensor], group=None) -> None:
-    """Sum the accumulated curvature over ranks with ONE collective on a packed fp32 buffer
-    (RCCL over xGMI when the backend is "nccl"; gloo in the CPU tests)."""
+def allreduce_curvature(tensors: list[torch.Tensor], group=None, mirror: bool = True) -> None:
+    """Sum the accumulated curvature over ranks with ONE collective (RCCL over xGMI when the backend is "nccl"; gloo in
+    the CPU tests).  Square fp32 matrices are symmetric factors: only their packed upper triangles travel (half the
+    bytes; ``lk_pack_upper_f32`` writes them straight into the exchange buffer, the all-reduce runs on that buffer in
+    place, ``lk_unpack_upper_f32`` writes the sums back) — no concatenated copy of the squares.  ``mirror``: restore the
+    lower triangles afterwards (callers that symmetrise later anyway pass ``False``)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return
-    flat = torch.cat([t.reshape(-1) for t in tensors])
+    from laplace_amd._lib import get_kernels
+
+    K = get_kernels()
+    sym = [t.dim() == 2 and t.shape[0] == t.shape[1] and t.shape[0] > 1 and t.dtype == torch.float32 and t.is_contiguous()
+           for t in tensors]
+    sizes = [t.shape[0] * (t.shape[0] + 1) // 2 if s_ else t.numel() for t, s_ in zip(tensors, sym)]
+    flat = torch.empty(sum(sizes), dtype=tensors[0].dtype, device=tensors[0].device)
+    off = 0
+    for t, s_, n in zip(tensors, sym, sizes):
+        if s_:
+            K.pack_upper(t, flat[off:off + n])
+        else:
+            flat[off:off + n].copy_(t.reshape(-1))
+        off += n
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     off = 0
-    for t in tensors:
-        n = t.numel()
-        t.copy_(flat[off:off + n].view_as(t))
+    for t, s_, n in zip(tensors, sym, sizes):
+        if s_:
+            K.unpack_upper(flat[off:off + n], t)
+            if mirror:
+                K.symmetrize(t)
+        else:
+            t.copy_(flat[off:off + n].view_as(t))
         off += n
 
 
@@ -625,7 +645,7 @@ class HipKronLaplace(_HipLaplace):
                 acc.add_batch(X, y)
             if distributed:
                 acc.ensure_allocated(self._device)  # a rank whose shard is empty contributes zeros
-                allreduce_curvature(acc.tensors(), group=process_group)
+                allreduce_curvature(acc.tensors(), group=process_group, mirror=False)  # finalize() mirrors
             self.loss, self.H = acc.finalize()
             self.n_data = N
             self._posterior_cache = None
@@ -842,7 +862,7 @@ def fit_kron(la, train_loader, process_group=None, distributed: bool | None = No
     distributed = resolve_distributed(train_loader, distributed, process_group)
     if distributed:
         acc.ensure_allocated(la._device)  # a rank whose shard is empty contributes zeros
-        allreduce_curvature(acc.tensors(), group=process_group)
+        allreduce_curvature(acc.tensors(), group=process_group, mirror=False)  # finalize() mirrors
     la.loss, la.H_facs = acc.finalize()
     la.n_data = N
     la.H = la.H_facs.decompose(damping=la.damping, distributed=bool(distributed), process_group=process_group)

@@ -154,6 +154,14 @@ class EmulatedKernels:
         out += alpha * Gm * upper
         return out
 
+    def pack_upper(self, A, packed):
+        i, j = torch.triu_indices(A.shape[0], A.shape[0])
+        packed.copy_(A[i, j])
+
+    def unpack_upper(self, packed, A):
+        i, j = torch.triu_indices(A.shape[0], A.shape[0])
+        A[i, j] = packed
+
     # Gram family
     def gram_tn(self, X, alpha, out, upper_only=False):
         out += alpha * (X.T @ X)

@@ -20,7 +20,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, hs, out_path):
+def _worker(rank, world, port, hs, out_path, bs=2):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -32,7 +32,7 @@ def _worker(rank, world, port, hs, out_path):
         _lib.set_kernels_for_testing(EmulatedKernels())
         g = load_golden("resnetish", "classification")
         model, X, y = golden_model("resnetish", g, dtype=torch.float32)
-        loader = ShardedLoader(DataLoader(TensorDataset(X, y), batch_size=2), rank, world)
+        loader = ShardedLoader(DataLoader(TensorDataset(X, y), batch_size=bs), rank, world)
         la = HipLaplace(model, "classification", "all", hs, prior_precision=0.7)
         la.fit(loader)
         if hs == "kron":  # every rank keeps the FULL decomposition although it solved only its share
@@ -49,14 +49,17 @@ def _worker(rank, world, port, hs, out_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("hs", ["kron", "diag", "full"])
-def test_sharded_fit_equals_single_process(tmp_path, hs):
+@pytest.mark.parametrize("hs,world,bs", [("kron", 2, 2), ("diag", 2, 2), ("full", 2, 2),
+                                         ("kron", 3, 3),   # ragged last batch (3 + 3 + 3 + 1), uneven shards (2, 1, 1)
+                                         ("kron", 3, 5),   # two batches for three ranks: rank 2 has an EMPTY shard
+                                         ("full", 3, 3)])
+def test_sharded_fit_equals_single_process(tmp_path, hs, world, bs):
     from laplace_amd import _lib
     from laplace_amd.laplace import HipLaplace
     from tests.emulated_kernels import EmulatedKernels
 
     out = str(tmp_path / "rank0.pt")
-    mp.spawn(_worker, args=(2, _free_port(), hs, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), hs, out, bs), nprocs=world, join=True)
     got = torch.load(out, weights_only=False)
 
     prev = _lib.set_kernels_for_testing(EmulatedKernels())
@@ -64,7 +67,7 @@ def test_sharded_fit_equals_single_process(tmp_path, hs):
         g = load_golden("resnetish", "classification")
         model, X, y = golden_model("resnetish", g, dtype=torch.float32)
         la = HipLaplace(model, "classification", "all", hs, prior_precision=0.7)
-        la.fit(DataLoader(TensorDataset(X, y), batch_size=2), distributed=False)
+        la.fit(DataLoader(TensorDataset(X, y), batch_size=bs), distributed=False)
         ref_marglik = la.log_marginal_likelihood() if hs == "kron" else None
     finally:
         _lib.set_kernels_for_testing(prev)
@@ -78,7 +81,7 @@ def test_sharded_fit_equals_single_process(tmp_path, hs):
         # sharded eigendecomposition: identical on both ranks (it is exchanged, not recomputed), and a valid
         # decomposition of every factor
         e0 = torch.load(out + ".eig0", weights_only=False)
-        e1 = torch.load(out + ".eig1", weights_only=False)
+        e1 = torch.load(out + f".eig{world - 1}", weights_only=False)
         for F_, ls0, ls1, Qs0, Qs1 in zip(la.H_facs.kfacs, e0["l"], e1["l"], e0["Q"], e1["Q"]):
             for Hi, l0, l1, Q0, Q1 in zip(F_, ls0, ls1, Qs0, Qs1):
                 assert torch.equal(l0, l1) and torch.equal(Q0, Q1)
@@ -101,3 +104,53 @@ def test_factor_sharding_is_balanced_and_deterministic():
         assert max(load) <= sum(load) / world + float(max(sizes)) ** 3
     owner = HipKron.shard_factors(sizes, 8)
     assert len({owner[0], owner[1], owner[2]}) == 3  # the three 4608-factors land on different GPUs
+
+
+def _ddp_style_worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import warnings
+
+        from laplace_amd import _lib
+        from laplace_amd.laplace import HipLaplace
+        from tests.emulated_kernels import EmulatedKernels
+
+        _lib.set_kernels_for_testing(EmulatedKernels())
+        g = load_golden("mlp", "classification")
+        model, X, y = golden_model("mlp", g, dtype=torch.float32)
+        la = HipLaplace(model, "classification", "all", "kron", prior_precision=0.7)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            la.fit(DataLoader(TensorDataset(X, y), batch_size=5))  # every rank sees the FULL loader, as in a DDP script
+        if rank == 0:
+            torch.save({"loss": la.loss, "warned": any("not sharded" in str(x.message) for x in w),
+                        "H": [[Hi.clone() for Hi in F] for F in la.H_facs.kfacs]}, out_path)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_unsharded_loader_under_an_initialised_process_group_stays_local(tmp_path):
+    """with torch.distributed initialised but the loader NOT sharded, an automatic all-reduce would multiply
+    the curvature by the world size.  The collective is opt-in: it warns and fits locally."""
+    from laplace_amd import _lib
+    from laplace_amd.laplace import HipLaplace
+    from tests.emulated_kernels import EmulatedKernels
+
+    out = str(tmp_path / "ddp.pt")
+    mp.spawn(_ddp_style_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out, weights_only=False)
+    prev = _lib.set_kernels_for_testing(EmulatedKernels())
+    try:
+        g = load_golden("mlp", "classification")
+        model, X, y = golden_model("mlp", g, dtype=torch.float32)
+        la = HipLaplace(model, "classification", "all", "kron", prior_precision=0.7)
+        la.fit(DataLoader(TensorDataset(X, y), batch_size=5))
+    finally:
+        _lib.set_kernels_for_testing(prev)
+    assert got["warned"]
+    torch.testing.assert_close(got["loss"], la.loss)
+    for F_, G_ in zip(got["H"], la.H_facs.kfacs):
+        for a, b in zip(F_, G_):
+            torch.testing.assert_close(a, b)

@@ -115,3 +115,19 @@ def test_posterior_samples_and_joint_predictive_on_the_device(lik):
     want_cov = co.krondecomposed_inv_square_form(Qs, ls, 0.7, Js.reshape(1, n * c, p)).squeeze(0)
     assert rel(f_cov, want_cov) < 1e-4
     assert rel(f_mu, f.flatten()) < 1e-4
+
+
+@pytest.mark.parametrize("n", [1, 2, 10, 257, 576])
+def test_packed_upper_triangle_round_trip(n):
+    from laplace_amd._lib import get_kernels
+
+    K = get_kernels()
+    A = torch.randn(n, n, device=DEV)
+    packed = torch.empty(n * (n + 1) // 2, device=DEV)
+    K.pack_upper(A, packed)
+    i, j = torch.triu_indices(n, n)
+    assert torch.equal(packed.cpu(), A.cpu()[i, j])
+    B = torch.full((n, n), -1.0, device=DEV)
+    K.unpack_upper(packed, B)
+    assert torch.equal(torch.triu(B), torch.triu(A))
+    assert (torch.tril(B, -1) == torch.tril(torch.full((n, n), -1.0, device=DEV), -1)).all()
