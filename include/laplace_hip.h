@@ -175,7 +175,8 @@ int lk_conv_prep_weights_f16x2(const float* W, int64_t Co, int64_t Ci, int64_t t
  * out: fp32 [N][Ho][Wo][Co]; accumulate != 0 adds into out; amax_out (may be NULL): atomicMax of the bit patterns of
  * |out| (zero it first).  Stride-1 backward-data and forward convs are one launch, a stride-s backward-data is one
  * launch per output-pixel residue class.  config bit 0: 64-deep K chunks; bit 1: never use the form that keeps
- * the input patch of a tile resident in LDS across the taps (used when the output grid is the input grid). */
+ * the input patch of a tile resident in LDS across the taps (used when the output grid is the input grid);
+ * bit 4: write the output position-contiguous, out[n][co][pixel] (dense grids, Ho*Wo % 4 == 0, no accumulate). */
 int lk_conv_nhwc_f16x2(const void* in_h, const void* in_l, const int* in_sexp, int64_t N, int64_t Hi, int64_t Wi,
                        int64_t Ci, const void* w_h, const void* w_l, const int* w_sexp, int64_t Co, int64_t Hc,
                        int64_t Wc, int64_t in_mul, int64_t Ho, int64_t Wo, int64_t out_step, int64_t oh0, int64_t ow0,
@@ -219,6 +220,10 @@ int lk_gemm_f32(const float* A, const float* B, const float* E, float* C, int64_
                 int trans_a, int trans_b, float alpha, int accumulate, void* stream);
 int lk_kron_pow_f32(const float* l1, int64_t n1, const float* l2, int64_t n2, const float* delta, float exponent,
                     int damping, float* lam, void* stream);
+/* Split NHWC cotangent x [S*B][L][C] (seed-major batch) -> fp32 out[b][s][c][l]: position-contiguous and sample-major,
+ * the `u` operand of lk_kron_quadform_shared_f32 / lk_diag_quadform_shared_f32. */
+int lk_unsplit_transpose_f32(const void* x_h, const void* x_l, const int* sexp, int64_t S, int64_t B, int64_t L, int64_t C,
+                             float* out, void* stream);
 /* G[C][C] += alpha * X^T X for a split tensor X [R][C] (rows = (seed, sample, position) of an NHWC cotangent): the
  * G factor of a convolution layer (curvlinops.py:87-100).  Only the 32x32 tiles on or above the diagonal are written
  * (lk_symmetrize_f32 mirrors).  C = 64 or a multiple of 128.  Deterministic (workspace partials, fixed-order sum). */

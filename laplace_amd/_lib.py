@@ -63,6 +63,7 @@ SIGNATURES = {
                                   _i64, _i64, _i64, _i64, _vp, _vp, _vp, _int, _vp, _int, _vp]),
     "lk_vjp_nhwc_split_f16x2": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "lk_bn_act_fwd_nhwc_f16x2": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "lk_unsplit_transpose_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "lk_gram_tn_f16x2_workspace_bytes": (_sz, [_i64, _i64]),
     "lk_gram_tn_f16x2": (_int, [_vp, _vp, _vp, _i64, _i64, _f32, _vp, _vp, _vp, _sz, _vp]),
     "lk_gemm_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _int, _int, _f32,
@@ -448,6 +449,15 @@ class HipKernels:
             None if planes is None else _ptr(planes[1]), _ptr(sexp), _ptr(bound), self._stream(x.device))),
             "lk_bn_act_fwd_nhwc_f16x2")
         return y, mask, (SplitTensor(planes, sexp) if planes is not None else None), bound
+
+    def unsplit_transpose(self, x, S, B):
+        """SplitTensor ``[S*B, H, W, C]`` (seed-major) -> fp32 ``[B, S, C, H*W]``"""
+        N, H, W, C = x.shape
+        assert N == S * B
+        out = torch.empty(B, S, C, H * W, dtype=torch.float32, device=x.planes.device)
+        self._rc(self.lib.lk_unsplit_transpose_f32(_ptr(x.planes[0]), _ptr(x.planes[1]), _ptr(x.sexp), S, B, H * W, C,
+                                                   _ptr(out), self._stream(out.device)), "lk_unsplit_transpose_f32")
+        return out
 
     def gram_tn_f16x2(self, x, alpha, out):
         """``out[upper tiles] += alpha * X^T X`` for a SplitTensor ``x`` viewed as ``[rows, C]``"""

@@ -39,6 +39,10 @@ from laplace_amd.kron import HipKron
 from laplace_amd.refapi import EFInterface, GGNInterface
 
 
+#: ``LK_ROT_CONV=0``: the Kron predictive's eigenbasis rotation of the unfolded inputs stays a library convolution
+_OWN_ROTATION = os.environ.get("LK_ROT_CONV", "1") != "0"
+
+
 def shared_operands(tap, g, B, C, Q1=None, Q2=None):
     """``u [B, C, Do, L]`` and ``v [B, Dk, L]`` (both position-contiguous) of a weight-sharing layer (Conv2d, or Linear
     along a sequence), whose per-sample Jacobian of output / seed ``c`` is ``sum_l u[n, c, :, l] v[n, :, l]^T``
@@ -47,19 +51,33 @@ def shared_operands(tap, g, B, C, Q1=None, Q2=None):
     m = tap.module
     a = tap.a.to(torch.float32)
     if tap.kind == "conv2d":
+        from laplace_amd import conv as cv
+
+        K = get_kernels()
         Do = m.out_channels
-        g4 = g.reshape(C, B, Do, -1)                                  # [C, B, Do, L]
-        L = g4.shape[-1]
         Dk = m.weight[0].numel()
+        if isinstance(g, SplitTensor):      # NHWC split cotangent [C*B, H, W, Do] straight from the sweep: one pass
+            u = K.unsplit_transpose(g, C, B)                           # [B, C, Do, L]
+            L = u.shape[-1]
+            gsum = u.sum(-1).permute(1, 0, 2)                          # [C, B, Do]
+        else:
+            g4 = g.reshape(C, B, Do, -1)                               # [C, B, Do, L]
+            L = g4.shape[-1]
+            gsum = g4.sum(-1)
+            u = g4.permute(1, 0, 2, 3)                                 # [B, C, Do, L]
         if Q2 is None:
             v = F.unfold(a, m.kernel_size, m.dilation, m.padding, m.stride)          # [B, Dk, L]
         else:
             # unfolded patches (x) Q2 = one convolution whose filters are the eigenvectors (rows of the A factor
-            # follow F.unfold's (c_in, kh, kw) order = the weight layout); its NCHW output IS [B, Dk, L]
+            # follow F.unfold's (c_in, kh, kw) order = the weight layout); its position-contiguous output IS [B, Dk, L]
             filt = Q2.T.reshape(Dk, *m.weight.shape[1:])
-            v = F.conv2d(a, filt, None, m.stride, m.padding, m.dilation).reshape(B, Dk, L)
-        gsum = g4.sum(-1)
-        u = g4.permute(1, 0, 2, 3)                                     # [B, C, Do, L]
+            if (_OWN_ROTATION and hasattr(K, "conv_nhwc_f16x2") and a.is_cuda and cv._geometry_ok(m) and m.in_channels % 32 == 0 and Dk % 8 == 0
+                    and L % 4 == 0):
+                # our implicit-GEMM convolution (fp32-level products on the fp16 matrix cores), eigenvector filters
+                # kept as split planes per decomposition
+                v = cv.conv_forward_filters(m, a, filt, Q2).reshape(B, Dk, L)
+            else:
+                v = F.conv2d(a, filt, None, m.stride, m.padding, m.dilation).reshape(B, Dk, L)
         if Q1 is not None:
             u = torch.matmul(Q1.T, u)
     else:                                                              # Linear over [B, ..., Di]
@@ -209,7 +227,7 @@ class _HipCurvatureMixin:
         for t in tape.taps:
             t.a = sweep.taps[t.name]["a"]
 
-        def grad_fn(seeds, stack=True, on_tap=None, defer_bn_scale=False):
+        def grad_fn(seeds, stack=True, on_tap=None, defer_bn_scale=False, keep_split=False):
             """All seeds in one sweep while ``S*B`` stays below ``sweep_max_rows`` images; many-output models
             (C = 1000 -> 999 seeds) go through in seed chunks of that size.  With ``on_tap`` every chunk's gradients
             are handed over layer by layer (additive consumers such as the KFAC accumulator) and nothing is returned."""
@@ -219,7 +237,10 @@ class _HipCurvatureMixin:
             rows = min(int(self.sweep_max_rows), int(self.sweep_mem_bytes) // (16 * max(sweep.max_act_numel, 1)))
             chunk = max(1, rows // max(B, 1))
             if S <= chunk:
-                grads = sweep.backward(seeds, on_tap=on_tap, defer_bn_scale=defer_bn_scale)
+                if keep_split and isinstance(sweep, SplitSweep):  # NHWC SplitTensors for consumers that take them
+                    grads = sweep.backward(seeds, on_tap=on_tap, defer_bn_scale=defer_bn_scale, keep_split=True)
+                else:
+                    grads = sweep.backward(seeds, on_tap=on_tap, defer_bn_scale=defer_bn_scale)
                 return [grads[t.name] for t in tape.taps]
             parts = []
             for s0 in range(0, S, chunk):

@@ -123,3 +123,31 @@ def conv_forward(prep: PreparedConv, x: SplitTensor, out=None, amax_out=None):
     taps = [(kh - ph, kw - pw, kh * KW + kw) for kh in range(KH) for kw in range(KW)]
     K.conv_nhwc_f16x2(x, planes, sexp, Ho, Wo, s, out, 1, 0, 0, taps, amax_out=amax_out)
     return out
+
+
+def conv_forward_filters(m: nn.Conv2d, a: torch.Tensor, filt: torch.Tensor, key_tensor: torch.Tensor) -> torch.Tensor:
+    """``conv2d(a, filt)`` with the geometry of ``m`` and an arbitrary filter bank ``filt [Dk, Cin, kh, kw]`` (the
+    eigenvectors of an A factor: the Kron predictive's rotation of the unfolded inputs, matrix.py:406-456) on the
+    implicit-GEMM kernel; returns ``[B, Dk, Ho, Wo]`` fp32 with POSITIONS contiguous.  The split planes of the filters
+    are cached ON ``key_tensor`` (the eigenvector matrix they were cut from; an attribute of that tensor object, so the
+    cache lives exactly as long as the decomposition — a table keyed by address would serve stale planes to the next
+    decomposition allocated at the same place)."""
+    K = get_kernels()
+    key = (key_tensor._version, tuple(filt.shape))
+    hit = getattr(key_tensor, "_lk_filter_planes", None)
+    if hit is None or hit[0] != key:
+        hit = (key, K.conv_prep_weights(filt.contiguous(), False, None))
+        key_tensor._lk_filter_planes = hit
+    planes, sexp = hit[1]
+    xh = a.permute(0, 2, 3, 1).contiguous()  # (a view when `a` is NHWC in memory already)
+    xs = K.split_f16x2(xh)
+    N, Hin, Win, _ = xs.shape
+    s, (ph, pw), (KH, KW) = m.stride[0], m.padding, m.kernel_size
+    Ho, Wo = (Hin + 2 * ph - KH) // s + 1, (Win + 2 * pw - KW) // s + 1
+    Dk = filt.shape[0]
+    out = torch.empty(N, Dk, Ho, Wo, dtype=torch.float32, device=a.device)
+    taps = [(kh - ph, kw - pw, kh * KW + kw) for kh in range(KH) for kw in range(KW)]
+    # config bit 4: position-contiguous output; the wrapper reads shapes off an NHWC-shaped view of the same memory
+    K.conv_nhwc_f16x2(xs, planes, sexp, Ho, Wo, s, out.view(N, Ho, Wo, Dk), 1, 0, 0, taps,
+                      config=(K.conv_config | 2 | 16))
+    return out

@@ -128,6 +128,7 @@ struct ConvGeom {
   int dh[9], dw[9], wt[9];  // per tap: offsets and the weight slice (index into the [T_w][Co][Ci] planes)
   FastDiv div_hw, div_w;    // GEMM row m -> (n, i, j):  n = m / (Hc*Wc), i = rem / Wc
   int dense;                // the output grid is the output tensor (os = 1, Hc = Ho, Wc = Wo): output pixel = m
+  int out_nchw;             // write out[n][co][pixel] (dense grids with Ho*Wo % 4 == 0 only): float4 along the pixels
 };
 
 template <int BM_, int BN_, int BK_, int WM_, int WN_, int NBUF_ = 2>
@@ -318,6 +319,31 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(2, 2)))
   // ---- epilogue: un-scale, store NHWC (a half-wave writes 32 consecutive channels = 128 B), max|out|
   const float inv_a = exp2i(-a_sexp[0] < -126 ? -126 : -a_sexp[0]), inv_w = exp2i(-w_sexp[0] < -126 ? -126 : -w_sexp[0]);
   unsigned vmax = 0;
+  if (g.out_nchw) {
+    // position-contiguous output [n][co][pixel] (what the predictive's quadratic-form kernel reads): a lane owns one
+    // channel, registers r = 4q .. 4q+3 are four consecutive pixels of it -> one 16-byte store
+    const int HW = g.Hc * g.Wc;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = tile_m * BM + (wm * TM + a) * 32 + 8 * q + 4 * lh;
+        if (m >= M) continue;
+        const int n = fdiv(m, g.div_hw), pix = m - n * HW;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          const int col = tile_n * BN + (wn * TN + b) * 32 + lr;
+          if (col >= g.Co) continue;
+          f32x4 v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[j] = acc[a][b][4 * q + j] * inv_a * inv_w;
+            vmax = max(vmax, __float_as_uint(v[j]) & 0x7fffffffu);
+          }
+          *reinterpret_cast<f32x4*>(out + ((int64_t)n * g.Co + col) * HW + pix) = v;
+        }
+      }
+  } else
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
 #pragma unroll
@@ -655,10 +681,13 @@ extern "C" int lk_conv_nhwc_f16x2(const void* in_h, const void* in_l, const int*
   for (int t = 0; t < T; ++t) g.dh[t] = taps[3 * t], g.dw[t] = taps[3 * t + 1], g.wt[t] = taps[3 * t + 2];
   g.div_hw = make_fastdiv((int)(Hc * Wc)), g.div_w = make_fastdiv((int)Wc);
   g.dense = out_step == 1 && oh0 == 0 && ow0 == 0 && Hc == Ho && Wc == Wo;
+  g.out_nchw = (config & 16) ? 1 : 0;
+  LK_REQUIRE(!g.out_nchw || (g.dense && (Ho * Wo) % 4 == 0 && !accumulate),
+             "lk_conv_nhwc_f16x2: position-contiguous output needs a dense grid with Ho*Wo % 4 == 0 and no accumulate");
   hipStream_t st = (hipStream_t)stream;
   g_ablate = (config >> 8) & 7;
   // "patch" form (A operand resident in LDS across the taps) where the output grid is the input grid
-  bool patch = !(config & 2) && in_mul == 1 && Hc == Hi && Wc == Wi && 256 + 2 * Wi + 2 <= 336 && N * Hi * Wi >= 256;
+  bool patch = !(config & 2) && !(config & 16) && in_mul == 1 && Hc == Hi && Wc == Wi && 256 + 2 * Wi + 2 <= 336 && N * Hi * Wi >= 256;
   for (int t = 0; t < T && patch; ++t) patch = g.dh[t] >= -1 && g.dh[t] <= 1 && g.dw[t] >= -1 && g.dw[t] <= 1;
   if (patch) {
     if (Co <= 64)

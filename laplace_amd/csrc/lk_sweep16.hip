@@ -166,6 +166,33 @@ __global__ __launch_bounds__(256) void bn_act_fwd_nhwc_kernel(
   }
 }
 
+// ---- split NHWC cotangent -> fp32, position-contiguous, sample-major:  out[b][s][c][l] = x[s*B + b][l][c] -----------
+// (what the Jacobian-free predictive kernels read: `u [B, C_out, Do, L]`); 32 x 32 tiles transposed through LDS.
+__global__ __launch_bounds__(256) void unsplit_transpose_kernel(const _Float16* __restrict__ xh,
+                                                                const _Float16* __restrict__ xl,
+                                                                const int* __restrict__ sexp, int S, int B, int L, int C,
+                                                                float* __restrict__ out) {
+  __shared__ float tile[32][33];
+  const int n = blockIdx.z, s = n / B, b = n - s * B;
+  const int c0 = blockIdx.x * 32, l0 = blockIdx.y * 32;
+  const float inv = exp2i16(-sexp[0]);
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int l = l0 + i, c = c0 + tx;
+    float v = 0.f;
+    if (l < L && c < C) {
+      const int64_t e = ((int64_t)n * L + l) * C + c;
+      v = ((float)xh[e] + (float)xl[e]) * inv;
+    }
+    tile[i][tx] = v;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, l = l0 + tx;
+    if (l < L && c < C) out[(((int64_t)b * S + s) * C + c) * L + l] = tile[tx][i];
+  }
+}
+
 // ---- Gram of a split tensor:  ws partials of  X^T X,  X = planes [R][C] (rows = (seed, sample, pixel), C contiguous) -----
 // k (rows) is the STRIDED direction of both MFMA operands, so fragments come out of LDS through the transposing read
 // ds_read_b64_tr_b16: a 16-lane group hands in the addresses of a [4 k][16 channel] block (lane r: row k0 + r/4,
@@ -431,6 +458,17 @@ extern "C" int lk_bn_act_fwd_nhwc_f16x2(const float* x, const unsigned* x_amax, 
                      scale_amax, shift_amax, addend, addend_bound, act, (int)C, per8, y, (unsigned char*)mask,
                      (_Float16*)y_h, (_Float16*)y_l, y_sexp, y_bound);
   return check_launch("bn_act_fwd_nhwc_kernel");
+}
+
+extern "C" int lk_unsplit_transpose_f32(const void* x_h, const void* x_l, const int* sexp, int64_t S, int64_t B, int64_t L,
+                                       int64_t C, float* out, void* stream) {
+  LK_REQUIRE(x_h && x_l && sexp && out && S >= 0 && B >= 0 && L >= 0 && C >= 0 && S * B <= 65535,
+             "lk_unsplit_transpose_f32: bad arguments (S * B <= 65535)");
+  if (S * B == 0 || L == 0 || C == 0) return LK_OK;
+  hipLaunchKernelGGL(unsplit_transpose_kernel, dim3((unsigned)((C + 31) / 32), (unsigned)((L + 31) / 32), (unsigned)(S * B)),
+                     dim3(256), 0, (hipStream_t)stream, (const _Float16*)x_h, (const _Float16*)x_l, sexp, (int)S, (int)B,
+                     (int)L, (int)C, out);
+  return check_launch("unsplit_transpose_kernel");
 }
 
 namespace {

@@ -35,7 +35,25 @@ def _identity_seeds(f: torch.Tensor) -> torch.Tensor:
     return eye[:, None, :].expand(C, B, C).contiguous()
 
 
+def _grads(grad_fn, seeds):
+    """output gradients of all taps; the NHWC sweep hands conv taps over as split tensors (no layout conversion)"""
+    try:
+        return grad_fn(seeds, keep_split=True)
+    except TypeError:  # autograd-tape grad_fn
+        return grad_fn(seeds)
+
+
+def _as_nchw(g, B, C):
+    """split NHWC cotangent -> [C, B, Do, H, W] fp32 for the routes that still read plain tensors"""
+    from laplace_amd._lib import SplitTensor
+
+    if isinstance(g, SplitTensor):
+        return g.float().reshape(C, B, *g.shape[1:]).permute(0, 1, 4, 2, 3).contiguous()
+    return g
+
+
 def _conv_block_jacobian(tap, g, B, C):
+    g = _as_nchw(g, B, C)
     K = get_kernels()
     m = tap.module
     width = m.weight.numel()
@@ -90,7 +108,7 @@ def glm_variance_kron(backend, x, post):
     if tape.uncovered or post.damping:
         raise NotImplementedError("fused Kron predictive needs Linear/Conv2d-only models and damping=False")
     B, C = f.shape
-    grads = grad_fn(_identity_seeds(f))
+    grads = _grads(grad_fn, _identity_seeds(f))
     fvar = torch.zeros(B, C, C, dtype=torch.float32, device=f.device)
     blk = 0
     for tap, g in zip(tape.taps, grads):

@@ -209,7 +209,9 @@ class SplitSweep(SeedBatchedSweep):
 
     # ---- reverse sweep ------------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def backward(self, seeds, on_tap=None, defer_bn_scale: bool = False):
+    def backward(self, seeds, on_tap=None, defer_bn_scale: bool = False, keep_split: bool = False):
+        """``keep_split``: hand conv-tap gradients back as NHWC SplitTensors (consumers with their own kernels for
+        them) instead of converting to ``[S, B, C, H, W]`` fp32."""
         if not self.split_ok:
             return super().backward(seeds, on_tap=on_tap, defer_bn_scale=defer_bn_scale)
         K = self.kernels()
@@ -374,7 +376,7 @@ class SplitSweep(SeedBatchedSweep):
                     raise SweepUnsupported(f"no NHWC rule for method {t}")
         if remaining:
             raise SweepUnsupported(f"no cotangent reached {sorted(remaining)}")
-        if on_tap is None:
+        if on_tap is None and not keep_split:
             # consumers that read the gradients as tensors (Jacobians, diagonal, predictive): [S, B, C, H, W] fp32
             for name, g in list(grads.items()):
                 if isinstance(g, SplitTensor):

@@ -145,6 +145,10 @@ class EmulatedKernels:
         split = self._split(y, self._sexp_for(bound)) if want_split else None
         return y.contiguous(), mask, split, torch.tensor([bound], dtype=torch.float32)
 
+    def unsplit_transpose(self, x, S, B):
+        N, H, W, C = x.shape
+        return x.float().reshape(S, B, H * W, C).permute(1, 0, 3, 2).contiguous()
+
     def gram_tn_f16x2(self, x, alpha, out):
         C = x.planes.shape[-1]
         X = x.float().reshape(-1, C)

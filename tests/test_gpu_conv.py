@@ -126,3 +126,35 @@ def test_tiny_and_huge_magnitudes_keep_fp32_level_accuracy():
     want = torch.nn.grad.conv2d_input((3, 64, 8, 8), m.weight.double().cpu(), g.double().cpu(), stride=1, padding=1)
     dx = cv.conv_backward_data(cv.PreparedConv(m), K.split_f16x2(g.permute(0, 2, 3, 1).contiguous()), (8, 8))
     assert rel(dx.permute(0, 3, 1, 2), want) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(64, 3, 1, 1, 32), (128, 3, 1, 1, 16), (64, 3, 2, 1, 32), (512, 3, 1, 1, 4), (64, 1, 2, 0, 32)])
+def test_rotation_convolution_with_position_contiguous_output(shape):
+    """conv2d with an arbitrary filter bank (the eigenvectors of an A factor) and [B, Dk, L] output — the Kron
+    predictive's rotation of the unfolded inputs (matrix.py:406-456) on the implicit-GEMM kernel."""
+    from laplace_amd import conv as cv
+
+    cin, k, s, p, H = shape
+    m = _conv(cin, 32, k, s, p)
+    Dk = cin * k * k
+    torch.manual_seed(1)
+    Q2 = torch.linalg.qr(torch.randn(Dk, Dk, device=DEV))[0].contiguous()
+    filt = Q2.T.reshape(Dk, cin, k, k)
+    a = torch.randn(6, cin, H, H, device=DEV)
+    want = F.conv2d(a.double().cpu(), filt.double().cpu(), None, s, p)
+    for layout in ("nchw", "nhwc"):
+        x = a if layout == "nchw" else a.to(memory_format=torch.channels_last)
+        got = cv.conv_forward_filters(m, x, filt, Q2)
+        assert got.shape == want.shape and got.is_contiguous()
+        assert rel(got, want) < 1e-5
+
+
+def test_unsplit_transpose_of_a_seed_batched_cotangent():
+    from laplace_amd._lib import get_kernels
+
+    K = get_kernels()
+    S, B, H, W, C = 3, 5, 6, 7, 40
+    x = torch.randn(S * B, H, W, C, device=DEV)
+    u = K.unsplit_transpose(K.split_f16x2(x), S, B)
+    want = x.reshape(S, B, H * W, C).permute(1, 0, 3, 2)
+    assert u.shape == (B, S, C, H * W) and rel(u, want) < 1e-6
