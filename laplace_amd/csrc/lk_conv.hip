@@ -131,8 +131,9 @@ struct ConvGeom {
   int out_nchw;             // write out[n][co][pixel] (dense grids with Ho*Wo % 4 == 0 only): float4 along the pixels
 };
 
-template <int BM_, int BN_, int BK_, int WM_, int WN_, int NBUF_ = 2>
+template <int BM_, int BN_, int BK_, int WM_, int WN_, int NBUF_ = 2, int WPE_ = 2>
 struct ConvCfg {
+  static constexpr int WPE = WPE_;                        // waves per SIMD the register allocation is sized for
   static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_;
   static constexpr int NBUF = NBUF_;                      // LDS stages: NBUF - 1 stages of loads are in flight
   static constexpr int Q = BK / 8;                       // 16-byte slots per row
@@ -157,7 +158,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
 
 template <typename CFG>
-__global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_f16x2_kernel(const ConvGeom g, const _Float16* __restrict__ Ah,
+__global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WPE, CFG::WPE))) void conv_f16x2_kernel(const ConvGeom g, const _Float16* __restrict__ Ah,
                                                          const _Float16* __restrict__ Al, const _Float16* __restrict__ Wh,
                                                          const _Float16* __restrict__ Wl, const int* __restrict__ a_sexp,
                                                          const int* __restrict__ w_sexp, const _Float16* __restrict__ zero16,
@@ -699,6 +700,16 @@ extern "C" int lk_conv_nhwc_f16x2(const void* in_h, const void* in_l, const int*
     if (Co <= 64)
       return launch_conv<ConvCfg<256, 64, 32, 4, 2, 3>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st);
     return launch_conv<ConvCfg<256, 128, 32, 4, 2, 3>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st);
+  }
+  if (config & 32) {  // 16-deep chunks, two or three LDS stages, registers sized for three waves per SIMD: 3+ workgroups per CU
+    if (config & 64) {
+      if (Co <= 64)
+        return launch_conv<ConvCfg<256, 64, 16, 4, 1, 3, 3>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st);
+      return launch_conv<ConvCfg<128, 128, 16, 2, 2, 3, 3>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st);
+    }
+    if (Co <= 64)
+      return launch_conv<ConvCfg<256, 64, 16, 4, 1, 2, 3>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st);
+    return launch_conv<ConvCfg<128, 128, 16, 2, 2, 2, 3>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st);
   }
   if (config & 4) {  // 16-deep chunks, four LDS stages (three stages of loads in flight)
     if (Co <= 64)

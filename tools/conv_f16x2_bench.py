@@ -44,7 +44,7 @@ for cin, cout, k, s, p, H, cnt in SHAPES:
     out = torch.empty(N, H, H, cin, device=dev)
     flop = 2.0 * N * Ho * Ho * cout * cin * k * k
     res = {"shape": [cin, cout, k, s, H], "gflop": flop / 1e9}
-    for cfg in (2, 0):  # 2: generic form; 0: patch form where eligible  # 0: patch form where eligible, 2: generic form, 6: generic, 16-deep chunks x 4 stages
+    for cfg in (2, 0):  # 2: generic form (default); 0: patch form where eligible
         K.conv_config = cfg
         ms = timeit(lambda: cv.conv_backward_data(prep, gs, (H, H), out=out))
         res[f"ours{cfg}_ms"] = ms
