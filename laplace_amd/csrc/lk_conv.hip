@@ -131,8 +131,9 @@ struct ConvGeom {
   int out_nchw;             // write out[n][co][pixel] (dense grids with Ho*Wo % 4 == 0 only): float4 along the pixels
 };
 
-template <int BM_, int BN_, int BK_, int WM_, int WN_, int NBUF_ = 2, int WPE_ = 2>
+template <int BM_, int BN_, int BK_, int WM_, int WN_, int NBUF_ = 2, int WPE_ = 2, bool MIDBAR_ = false>
 struct ConvCfg {
+  static constexpr bool MIDBAR = MIDBAR_;                 // hand over to the next stage in the MIDDLE of a stage's MFMAs
   static constexpr int WPE = WPE_;                        // waves per SIMD the register allocation is sized for
   static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_;
   static constexpr int NBUF = NBUF_;                      // LDS stages: NBUF - 1 stages of loads are in flight
@@ -258,6 +259,109 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+  if constexpr (CFG::MIDBAR) {
+    // Two workgroups of a CU run the same code from the same start: they reach their LDS-read phase together, so the
+    // partner wave on a SIMD cannot cover a fragment read with its MFMAs, and each wave has to hide its own LDS latency.
+    // Fragments therefore run one k16 step ahead in a second register set, ACROSS stages: the barrier that hands over
+    // to the next stage sits in the middle of a stage — before the MFMAs of its last k16 step, whose operands are
+    // already in registers — followed by the next stage's loads and the first fragment reads of the next stage, all of
+    // which the 12 MFMAs behind them cover.
+    static_assert(CFG::NBUF == 2 && (BK / 16) % 2 == 0, "two LDS stages, an even number of k16 steps");
+    constexpr int K16 = BK / 16, LDS_PER = CFG::A_LD + CFG::B_LD;
+    constexpr int WAIT_ONE_BEHIND = 0x0f70 | (LDS_PER & 15) | ((LDS_PER >> 4) << 14);
+    f16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+    // The fragment reads are issued as asm: hipcc books an LDS-DMA load as a "flat" access that may return out of
+    // order with LDS reads and then waits lgkmcnt(0) at every dependency behind it — which serialises exactly the
+    // read/MFMA overlap this loop is for.  With asm reads the counter is ours: wait_set() waits until at most
+    // `younger` reads issued after the wanted set are outstanding, and ties the set's registers to the wait so that
+    // no use of them can be placed above it.
+    static_assert(TM == 2 && TN == 2, "wait_set names eight registers");
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    unsigned fa[TM], fb[TN];   // byte address of (row, slot 0 ^ swizzle) — the k16 / half / plane parts are XORed or added
+    int fswz_a[TM], fswz_b[TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      const int row = (wm * TM + a) * 32 + lr;
+      fa[a] = lds0 + row * Q * 16, fswz_a[a] = swz<Q>(row);
+    }
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int row = (wn * TN + b) * 32 + lr;
+      fb[b] = lds0 + 2 * CFG::A_PLANE + row * Q * 16, fswz_b[b] = swz<Q>(row);
+    }
+    auto lds_read = [&](f16x8& dst, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr)); };
+    auto load_frags = [&](int buf, int k16, int set) {
+#pragma unroll
+      for (int a = 0; a < TM; ++a) {
+        const unsigned ad = fa[a] + buf * CFG::STAGE + (((k16 * 2 + lh) ^ fswz_a[a]) * 16);
+        lds_read(ah[set][a], ad);
+        lds_read(al[set][a], ad + CFG::A_PLANE);
+      }
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const unsigned ad = fb[b] + buf * CFG::STAGE + (((k16 * 2 + lh) ^ fswz_b[b]) * 16);
+        lds_read(bh[set][b], ad);
+        lds_read(bl[set][b], ad + CFG::B_PLANE);
+      }
+    };
+    constexpr int READS_PER_SET = 2 * TM + 2 * TN;
+    auto wait_set = [&](int set, bool younger) {
+      if (younger)
+        asm volatile("s_waitcnt lgkmcnt(%8)"
+                     : "+v"(ah[set][0]), "+v"(ah[set][1]), "+v"(al[set][0]), "+v"(al[set][1]), "+v"(bh[set][0]),
+                       "+v"(bh[set][1]), "+v"(bl[set][0]), "+v"(bl[set][1])
+                     : "n"(READS_PER_SET));
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(ah[set][0]), "+v"(ah[set][1]), "+v"(al[set][0]), "+v"(al[set][1]), "+v"(bh[set][0]),
+                       "+v"(bh[set][1]), "+v"(bl[set][0]), "+v"(bl[set][1]));
+    };
+    auto mfmas = [&](int set) {
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          f32x16 c = acc[a][b];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[set][a], bh[set][b], c, 0, 0, 0);  // small terms first
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[set][a], bl[set][b], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[set][a], bh[set][b], c, 0, 0, 0);
+          acc[a][b] = c;
+        }
+    };
+    static_assert(K16 == 2, "the loop below is written for two k16 steps per stage");
+    // The loop boundary sits AT the hand-over barrier (no LDS read is pending there), so that inside the body the
+    // compiler's own lgkmcnt bookkeeping can wait for the older fragment set only.
+    stage(0, 0);
+    if (nstage > 1) {
+      stage(1, 1);
+      __builtin_amdgcn_s_waitcnt(WAIT_ONE_BEHIND);  // stage 0 has landed, stage 1 may still be in flight
+    } else {
+      __builtin_amdgcn_s_waitcnt(0x0f70);
+    }
+    __builtin_amdgcn_s_barrier();
+    load_frags(0, 0, 0);
+    load_frags(0, 1, 1);
+    wait_set(0, true);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(0);                                        // k16 step 0 of stage 0
+    for (int s = 0; s + 1 < nstage; ++s) {
+      wait_set(1, false);                            // lgkmcnt(0): every fragment of stage s is in registers
+      __builtin_amdgcn_s_waitcnt(0x0f70);            // vmcnt(0): this wave's part of stage s+1 has landed
+      __builtin_amdgcn_s_barrier();                  // ... everybody's; and nobody reads buffer s & 1 any more
+      const int nb = (s + 1) & 1;
+      if (s + 2 < nstage && !(ablate & 4)) stage(s + 2, s & 1);
+      load_frags(nb, 0, 0);                          // stage s+1, step 0 -> set 0
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(1);                                      // stage s, step 1 (covers the reads above and the loads)
+      __builtin_amdgcn_sched_barrier(0);
+      load_frags(nb, 1, 1);                          // stage s+1, step 1 -> set 1 (its old contents have been issued)
+      wait_set(0, true);                             // set 0 has arrived; set 1 stays in flight behind the MFMAs below
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(0);                                      // stage s+1, step 0
+    }
+    wait_set(1, false);
+    mfmas(1);                                        // step 1 of the last stage
+  } else {
   // Software pipeline over NBUF LDS stages: the loads of stages s+1 .. s+NBUF-1 are in flight while stage s is
   // computed (an L2 hit takes ~1.6k cycles here, two to three stage times).  vmcnt counts this wave's LDS-DMA
   // instructions in issue order, every stage issues exactly LD_PER_STAGE of them, so "stage s has landed" is
@@ -316,6 +420,7 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
         }
     }
   }
+  }  // (pipeline form)
 
   // ---- epilogue: un-scale, store NHWC (a half-wave writes 32 consecutive channels = 128 B), max|out|
   const float inv_a = exp2i(-a_sexp[0] < -126 ? -126 : -a_sexp[0]), inv_w = exp2i(-w_sexp[0] < -126 ? -126 : -w_sexp[0]);
@@ -700,6 +805,11 @@ extern "C" int lk_conv_nhwc_f16x2(const void* in_h, const void* in_l, const int*
     if (Co <= 64)
       return launch_conv<ConvCfg<256, 64, 32, 4, 2, 3>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st);
     return launch_conv<ConvCfg<256, 128, 32, 4, 2, 3>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st);
+  }
+  if (config & 2048) {  // hand-over barrier in the middle of a stage, fragments one k16 step ahead across stages
+    if (Co <= 64)
+      return launch_conv<ConvCfg<256, 64, 32, 4, 1, 2, 2, true>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st);
+    return launch_conv<ConvCfg<128, 128, 32, 2, 2, 2, 2, true>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st);
   }
   if (config & 32) {  // 16-deep chunks, two or three LDS stages, registers sized for three waves per SIMD: 3+ workgroups per CU
     if (config & 64) {

@@ -22,7 +22,8 @@ N = int(os.environ.get("NB", 1152))
 dev = "cuda"
 K = get_kernels()
 rows = []
-tot = {"ours2": 0.0, "ours0": 0.0, "miopen": 0.0}
+CFGS = [int(c) for c in os.environ.get("CFGS", "2,0").split(",")]
+tot = {**{f"ours{c}": 0.0 for c in CFGS}, "miopen": 0.0}
 
 
 def timeit(fn, reps=10):
@@ -44,7 +45,7 @@ for cin, cout, k, s, p, H, cnt in SHAPES:
     out = torch.empty(N, H, H, cin, device=dev)
     flop = 2.0 * N * Ho * Ho * cout * cin * k * k
     res = {"shape": [cin, cout, k, s, H], "gflop": flop / 1e9}
-    for cfg in (2, 0):  # 2: generic form (default); 0: patch form where eligible
+    for cfg in CFGS:  # 2: generic form (default); 0: patch form where eligible
         K.conv_config = cfg
         ms = timeit(lambda: cv.conv_backward_data(prep, gs, (H, H), out=out))
         res[f"ours{cfg}_ms"] = ms
