@@ -176,7 +176,10 @@ int lk_conv_prep_weights_f16x2(const float* W, int64_t Co, int64_t Ci, int64_t t
  * |out| (zero it first).  Stride-1 backward-data and forward convs are one launch, a stride-s backward-data is one
  * launch per output-pixel residue class.  config bit 0: 64-deep K chunks; bit 1: never use the form that keeps
  * the input patch of a tile resident in LDS across the taps (used when the output grid is the input grid);
- * bit 4: write the output position-contiguous, out[n][co][pixel] (dense grids, Ho*Wo % 4 == 0, no accumulate). */
+ * bit 4: write the output position-contiguous, out[n][co][pixel] (dense grids, Ho*Wo % 4 == 0, no accumulate);
+ * bits 12..14: tile shape of the generic form — 0: chosen from the shapes by occupancy (a pure function of the arguments),
+ * 1: 64x64, 2: 128x64, 3: 64x128, 4: 128x128, 5: 256x64, 6: the big tile by output width only; the remaining bits select
+ * development variants of the K pipeline (csrc/lk_conv.hip).  Every choice computes the same sums in the same order. */
 int lk_conv_nhwc_f16x2(const void* in_h, const void* in_l, const int* in_sexp, int64_t N, int64_t Hi, int64_t Wi,
                        int64_t Ci, const void* w_h, const void* w_l, const int* w_sexp, int64_t Co, int64_t Hc,
                        int64_t Wc, int64_t in_mul, int64_t Ho, int64_t Wo, int64_t out_step, int64_t oh0, int64_t ow0,
@@ -391,6 +394,12 @@ int lk_diag_ggn_shared_f32(const float* u, const float* v, int64_t B, int64_t S,
  *   fvar[n][c][k] = sum_p Js[n][c][p] var[p] Js[n][k][p] */
 int lk_diag_quadform_js_f32(const float* Js, const float* var, int64_t B, int64_t C, int64_t P, float* fvar,
                             void* stream);
+
+/* Last-layer Jacobians (CurvatureInterface.last_layer_jacobians, laplace/curvature/curvature.py:131-167, for a Linear head):
+ *   Js[n][c][:] = e_c (x) [phi_n, 1]  — [B][C][P], P = C*D (+ C with a bias), parameter order weight [C][D] row-major then bias.
+ * The fused consumers (lk_ll_ggn_full_f32, lk_dense_quadform_ll_f32) never form it; this is for callers of the drop-in seam that
+ * ask for the Jacobian itself (la(x) of the reference's last-layer flavours). */
+int lk_jac_last_layer_f32(const float* phi, int64_t B, int64_t C, int64_t D, int has_bias, float* Js, void* stream);
 
 /* Dense last-layer posterior (FullLaplace.functional_variance with J = I (x) [phi,1],
  * baselaplace.py:1683-1684, lllaplace.py:212-237):

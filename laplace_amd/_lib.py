@@ -100,6 +100,7 @@ SIGNATURES = {
     "lk_diag_ggn_shared_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_float, _vp, _vp, _sz, _vp]),
     "lk_diag_quadform_js_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "lk_dense_quadform_ll_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "lk_jac_last_layer_f32": (_int, [_vp, _i64, _i64, _i64, _int, _vp, _vp]),
     "lk_dense_quadform_ll_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _vp, _vp, _sz, _vp]),
 }
 
@@ -959,6 +960,15 @@ class HipKernels:
         self._rc(self.lib.lk_diag_quadform_js_f32(_ptr(Js), _ptr(var), B, C, P, _ptr(fvar), self._stream(Js.device)),
                  "lk_diag_quadform_js_f32")
         return fvar
+
+    def jac_last_layer(self, phi, C, has_bias):
+        """Js [B, C, P] = e_c (x) [phi_n, 1] (curvature.py:131-167 for a Linear head)."""
+        _check(phi, "phi")
+        B, D = phi.shape
+        Js = torch.empty(B, C, C * D + (C if has_bias else 0), dtype=torch.float32, device=phi.device)
+        self._rc(self.lib.lk_jac_last_layer_f32(_ptr(phi), B, C, D, 1 if has_bias else 0, _ptr(Js), self._stream(phi.device)),
+                 "lk_jac_last_layer_f32")
+        return Js
 
     def dense_quadform_ll(self, phi, Sigma, C, has_bias):
         _check(phi, "phi"), _check(Sigma, "Sigma")

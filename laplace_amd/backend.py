@@ -870,6 +870,22 @@ class HipGGN(_HipCurvatureMixin, GGNInterface):
         Z, _ = self._rows(x, seeds_fn)
         return loss[0], self._full_from_rows(Z, 1.0)
 
+    # last-layer Jacobians — replaces CurvatureInterface.last_layer_jacobians (curvature.py:131-167) for a Linear head:
+    # the feature pass of the backend + one store-stream kernel; with enable_backprop the autograd form is needed
+    def last_layer_jacobians(self, x, enable_backprop: bool = False):
+        if enable_backprop or not self._supported() or not self.last_layer:
+            return super().last_layer_jacobians(x, enable_backprop)
+        try:
+            f, tape, _ = self._forward(x)
+        except NotImplementedError:
+            return super().last_layer_jacobians(x, enable_backprop)
+        tap = tape.taps[0]
+        phi = tap.a.reshape(tap.a.shape[0], -1).contiguous()
+        tap.a = None
+        C = f.shape[1]
+        Js = get_kernels().jac_last_layer(phi, C, tap.module.bias is not None)
+        return Js, f
+
     # per-sample output Jacobians — replaces CurvatureInterface.jacobians (curvature.py:88-129)
     def jacobians(self, x, enable_backprop: bool = False):
         if enable_backprop or self.last_layer or not self._supported():

@@ -801,6 +801,36 @@ extern "C" int lk_conv_nhwc_f16x2(const void* in_h, const void* in_l, const int*
     return launch_patch<PatchCfg<128, 4, 2>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st);
   }
   const bool bk64 = (Ci % 64 == 0) && (config & 1);
+#define LK_CONV_GO(...) return launch_conv<ConvCfg<__VA_ARGS__>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st)
+  switch ((config >> 12) & 7) {  // explicit tile shape (bits 12..14); 0: chosen below
+    case 1: LK_CONV_GO(64, 64, 32, 2, 2, 2, 4);
+    case 2: LK_CONV_GO(128, 64, 32, 2, 2, 2, 3);
+    case 3: LK_CONV_GO(64, 128, 32, 2, 2, 2, 3);
+    case 4: LK_CONV_GO(128, 128, 32, 2, 2);
+    case 5: LK_CONV_GO(256, 64, 32, 4, 1);
+    case 6: break;  // the big tile by output width only (the choice before the occupancy rule)
+    default: break;
+  }
+  if (((config >> 12) & 7) == 0 && !(config & (1 | 4 | 8 | 32 | 2048))) {
+    // Tile shape by occupancy (measured on the c4 layer shapes, profiles/r02_conv_tile_sweep.json): the big tile
+    // (2 workgroups per CU = 512 slots) when it fills the chip and its last round is not mostly idle; otherwise the
+    // half tile (3 per CU) if that gives >= 512 tiles; otherwise 64 x 64 (the forward of the deep, small-map layers at
+    // batch 128 has only 64-128 big tiles).  A pure function of the shapes: the same launch always takes the same tile.
+    const int64_t M = N * Hc * Wc;
+    auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((Co + bn - 1) / bn); };
+    const bool narrow = Co <= 64;
+    const int64_t tb = narrow ? tiles(256, 64) : tiles(128, 128);
+    const int64_t rounds = (tb + 511) / 512;
+    const bool big_ok = tb >= 512 && tb * 100 >= rounds * 512 * 74;
+    if (!big_ok) {
+      const int64_t tm = narrow ? tiles(128, 64) : tiles(64, 128);
+      if (tm >= 512) {
+        if (narrow) LK_CONV_GO(128, 64, 32, 2, 2, 2, 3);
+        LK_CONV_GO(64, 128, 32, 2, 2, 2, 3);
+      }
+      LK_CONV_GO(64, 64, 32, 2, 2, 2, 4);
+    }
+  }
   if (config & 8) {  // 8 waves, one workgroup per CU: 256 x 128 (256 x 64) tile, three LDS stages (two in flight)
     if (Co <= 64)
       return launch_conv<ConvCfg<256, 64, 32, 4, 2, 3>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st);

@@ -295,6 +295,50 @@ extern "C" int lk_ll_ggn_full_f32(const float* phi, const float* probs, int64_t 
   return check_launch("lk_ll_ggn_full_f32");
 }
 
+// ---- last-layer Jacobians (J2): Js[n][c][:] = e_c (x) [phi_n, 1] in the reference's parameter order (weight [C][D] row-major, then
+// bias [C]).  Pure store stream: one thread per 4 consecutive parameters of one (sample, output) row.
+namespace lk {
+__global__ __launch_bounds__(256) void jac_last_layer_kernel(const float* __restrict__ phi, int64_t rows, int C, int D, int has_bias,
+                                                             int64_t P, float* __restrict__ Js) {
+  const int64_t per_row = (P + 3) / 4;
+  const int64_t total = rows * per_row;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / per_row;                 // (sample n, output c)
+    const int64_t p0 = (i - row * per_row) * 4;
+    const int64_t n = row / C;
+    const int c = (int)(row - n * C);
+    const int64_t lo = (int64_t)c * D, hi = lo + D;  // the weight row of output c
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t p = p0 + j;
+      float x = 0.f;
+      if (p >= lo && p < hi) x = phi[n * D + (p - lo)];
+      else if (has_bias && p == (int64_t)C * D + c) x = 1.f;
+      v[j] = x;
+    }
+    float* dst = Js + row * P + p0;
+    if ((P & 3) == 0) {
+      *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (p0 + j < P) dst[j] = v[j];
+    }
+  }
+}
+}  // namespace lk
+
+extern "C" int lk_jac_last_layer_f32(const float* phi, int64_t B, int64_t C, int64_t D, int has_bias, float* Js, void* stream) {
+  LK_REQUIRE(phi && Js && B >= 0 && C >= 1 && D >= 1, "lk_jac_last_layer_f32: bad arguments");
+  if (B == 0) return LK_OK;
+  const int64_t P = C * D + (has_bias ? C : 0);
+  const int64_t work = B * C * ((P + 3) / 4);
+  hipLaunchKernelGGL(lk::jac_last_layer_kernel, dim3(grid_for(work)), dim3(256), 0, (hipStream_t)stream, phi, B * C, (int)C, (int)D,
+                     has_bias, P, Js);
+  return check_launch("jac_last_layer_kernel");
+}
+
 extern "C" size_t lk_dense_quadform_ll_workspace_bytes(int64_t B, int64_t C, int64_t D) {
   (void)B; (void)C; (void)D;
   return 0;

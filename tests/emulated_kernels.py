@@ -434,6 +434,12 @@ class EmulatedKernels:
     def diag_quadform_js(self, Js, var):
         return torch.einsum("ncp,p,nkp->nck", Js, var, Js)
 
+    def jac_last_layer(self, phi, C, has_bias):
+        B, D = phi.shape
+        eye = torch.eye(C, dtype=phi.dtype)
+        Js = (eye[None, :, :, None] * phi[:, None, None, :]).reshape(B, C, -1)
+        return torch.cat([Js, eye.expand(B, C, C)], 2) if has_bias else Js
+
     def dense_quadform_ll(self, phi, Sigma, C, has_bias):
         B, D = phi.shape
         eye = torch.eye(C, dtype=phi.dtype)

@@ -168,6 +168,23 @@ def test_last_layer_modes(name, lik):
             check(a, w, what="LL kron factors")
     loss = b.full(X, y)[0]
     check(loss, g["la.last_layer.full.loss"], what="LL loss")
+    # J2 (curvature.py:131-167): the Jacobian itself, from lk_jac_last_layer_f32, against the as-written construction
+    from laplace_amd._lib import get_kernels
+    from laplace_amd.refapi import GGNInterface
+
+    K = get_kernels()
+    calls = []
+    orig = K.jac_last_layer
+    K.jac_last_layer = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        Js, f = b.last_layer_jacobians(X)
+    finally:
+        del K.jac_last_layer
+    assert calls, "last_layer_jacobians did not run on the kernel"
+    Jw, fw = GGNInterface.last_layer_jacobians(b, X)
+    assert Js.shape == Jw.shape
+    check(Js, Jw, tol=1e-6, what="last-layer Jacobians")
+    check(f, g["f"], what="LL f")
 
 
 # ---- KFAC relations on the HIP path -------------------------------------------------

@@ -52,7 +52,7 @@ def test_split_reconstructs_to_22_bits_and_survives_wide_dynamic_range():
 
 
 @pytest.mark.parametrize("shape", C4_SHAPES, ids=[f"{c[0]}-{c[1]}-k{c[2]}s{c[3]}-{c[5]}x{c[5]}" for c in C4_SHAPES])
-@pytest.mark.parametrize("config", [0, 2, 3, 6, 10, 34, 98, 2050])  # 0: patch form where eligible; generic form: 2 / 3 = 32- / 64-deep chunks
+@pytest.mark.parametrize("config", [0, 2, 3, 6, 10, 34, 98, 2050] + [2 | (t << 12) for t in range(1, 7)])  # 0: patch form where eligible; generic form: 2 / 3 = 32- / 64-deep chunks
 # in two LDS stages, 6 = 16-deep chunks in four stages, 10 = 8 waves / 256 x 128 tile / three stages
 def test_backward_data_on_the_c4_layer_shapes(shape, config):
     from laplace_amd import conv as cv
