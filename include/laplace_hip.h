@@ -186,6 +186,23 @@ int lk_conv_nhwc_f16x2(const void* in_h, const void* in_l, const int* in_sexp, i
                        int64_t T, const int* taps, const void* zero16, float* out, int accumulate, unsigned* amax_out,
                        int config, void* stream);
 
+/* lk_conv_nhwc_f16x2 with the element-wise VJP of the sweep fused into its epilogue (one dense launch: forward / stride-1
+ * backward-data; Co % 8 == 0):
+ *     o[n][i][j][c] = (conv[n][i][j][c] + add[n][i][j][c]) * M[(n,i,j) mod mask_rows][c] * scale[c]
+ * emitted as a split tensor out_h / out_l / out_sexp — what lk_vjp_nhwc_split_f16x2 would make of the fp32 output, without
+ * that tensor's round trip through HBM (the backward passes of laplace/curvature/curvlinops.py:87-100 through an
+ * activation / folded BatchNorm / residual join).  The result's scale is derived before the launch from a guaranteed
+ * bound: max|in| (in_amax: measured, device word, or NULL = 2^(15 - in_sexp)) * w_l1 (device word: max_n sum_{t,k}
+ * |Wt[t][n][k]| of the prepared weights) + 2^(15 - add_sexp), times max|M| (mult_amax, fp32 multipliers only) and
+ * max|scale|; out_amax (zeroed by the caller) receives the MEASURED max|o|, which the next launch takes as its in_amax.
+ * add / mask / scale may be NULL.  mask: uint8 (mask_is_float = 0) or fp32 [mask_rows][Co]. */
+int lk_conv_nhwc_f16x2_vjp(const void* in_h, const void* in_l, const int* in_sexp, const void* in_amax, int64_t N, int64_t Hi,
+                           int64_t Wi, int64_t Ci, const void* w_h, const void* w_l, const int* w_sexp, const float* w_l1,
+                           int64_t Co, int64_t Ho, int64_t Wo, int64_t T, const int* taps, const void* zero16,
+                           const void* add_h, const void* add_l, const int* add_sexp, const void* mask, int mask_is_float,
+                           const void* mult_amax, int64_t mask_rows, const float* scale, const void* scale_amax, void* out_h,
+                           void* out_l, int* out_sexp, void* out_amax, int config, void* stream);
+
 /* Element-wise VJP of the NHWC sweep with a split result (csrc/lk_sweep16.hip):
  *     out[s][e] = (g[s][e] + g2[s][e]) * M[e] * scale[e % C]      e < per = B*H*W*C,  s < S
  * g: fp32 addend with the bit pattern of max|g| in g_amax (both may be NULL); g2: split addend (may be NULL);

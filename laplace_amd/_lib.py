@@ -61,6 +61,9 @@ SIGNATURES = {
     "lk_conv_prep_weights_f16x2": (_int, [_vp, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp]),
     "lk_conv_nhwc_f16x2": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64,
                                   _i64, _i64, _i64, _i64, _vp, _vp, _vp, _int, _vp, _int, _vp]),
+    "lk_conv_nhwc_f16x2_vjp": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64,
+                                      _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _i64, _vp, _vp, _vp, _vp, _vp,
+                                      _vp, _int, _vp]),
     "lk_vjp_nhwc_split_f16x2": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "lk_bn_act_fwd_nhwc_f16x2": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "lk_unsplit_transpose_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
@@ -112,10 +115,12 @@ class LaplaceHipError(RuntimeError):
 class SplitTensor:
     """Two fp16 planes ``planes[0] + planes[1] ~= x * 2**sexp`` of a tensor (include/laplace_hip.h, lk_split_f16x2)."""
 
-    __slots__ = ("planes", "sexp")
+    __slots__ = ("planes", "sexp", "amax")
 
-    def __init__(self, planes: torch.Tensor, sexp: torch.Tensor):
-        self.planes, self.sexp = planes, sexp
+    def __init__(self, planes: torch.Tensor, sexp: torch.Tensor, amax: torch.Tensor | None = None):
+        #: ``amax``: device word with the MEASURED max|x| when the producer provides one (fused convolution epilogue);
+        #: consumers that need a bound otherwise use 2**(15 - sexp)
+        self.planes, self.sexp, self.amax = planes, sexp, amax
 
     @property
     def shape(self):
@@ -401,6 +406,42 @@ class HipKernels:
             _ptr(wsexp), Co, Hc, Wc, in_mul, out.shape[1], out.shape[2], out_step, oh0, ow0, len(taps), flat, _ptr(z),
             _ptr(out), 1 if accumulate else 0, _ptr(amax_out), int(cfg), self._stream(out.device))), "lk_conv_nhwc_f16x2")
         return out
+
+    def conv_nhwc_f16x2_vjp(self, x, wplanes, wsexp, w_l1, Ho, Wo, taps, add=None, mult=None, mult_amax=None, scale=None,
+                            scale_amax=None, config=None):
+        """one dense launch of the convolution with the element-wise VJP fused into its epilogue (lk_conv_nhwc_f16x2_vjp):
+        ``(conv(x) + add) * mult * scale[channel]`` -> SplitTensor [N, Ho, Wo, Co] carrying its measured ``amax``.
+        ``mult``: [B, Ho, Wo, Co] uint8 / bool mask or fp32 multiplier (``mult_amax``: its bound, fp32 only), shared by
+        the N / B seeds; ``add``: SplitTensor of the output's shape; ``w_l1``: device word, see conv.PreparedConv."""
+        N, Hi, Wi, Ci = x.planes.shape[1:]
+        Co = wplanes.shape[2]
+        dev = x.planes.device
+        assert wplanes.shape[3] == Ci
+        planes = torch.empty((2, N, Ho, Wo, Co), dtype=torch.float16, device=dev)
+        sexp = torch.empty(1, dtype=torch.int32, device=dev)
+        amax = torch.zeros(1, dtype=torch.float32, device=dev)
+        m_is_float, mask_rows = 0, 0
+        if mult is not None:
+            if mult.dtype == torch.bool:
+                mult = mult.view(torch.uint8)
+            m_is_float = 1 if mult.dtype == torch.float32 else 0
+            if (not mult.is_contiguous() or mult.dtype not in (torch.uint8, torch.float32) or mult.dim() != 4
+                    or tuple(mult.shape[1:]) != (Ho, Wo, Co) or N % mult.shape[0]):
+                raise LaplaceHipError("conv_nhwc_f16x2_vjp: multiplier must be a contiguous [B, Ho, Wo, Co] uint8 / float32 tensor")
+            mask_rows = mult.shape[0] * Ho * Wo
+        if add is not None and tuple(add.shape) != (N, Ho, Wo, Co):
+            raise LaplaceHipError("conv_nhwc_f16x2_vjp: addend shape")
+        flat = (ctypes.c_int * (3 * len(taps)))(*[int(v) for t in taps for v in t])
+        cfg = self.conv_config if config is None else config
+        z = self._zero16(dev)
+        self._rc(self._timed("conv16", 2.0 * N * Ho * Wo * Co * Ci * len(taps), dev, lambda: self.lib.lk_conv_nhwc_f16x2_vjp(
+            _ptr(x.planes[0]), _ptr(x.planes[1]), _ptr(x.sexp), _ptr(x.amax), N, Hi, Wi, Ci, _ptr(wplanes[0]), _ptr(wplanes[1]),
+            _ptr(wsexp), _ptr(w_l1), Co, Ho, Wo, len(taps), flat, _ptr(z),
+            None if add is None else _ptr(add.planes[0]), None if add is None else _ptr(add.planes[1]),
+            None if add is None else _ptr(add.sexp), _ptr(mult), m_is_float, _ptr(mult_amax), mask_rows, _ptr(scale),
+            _ptr(scale_amax), _ptr(planes[0]), _ptr(planes[1]), _ptr(sexp), _ptr(amax), int(cfg), self._stream(dev))),
+            "lk_conv_nhwc_f16x2_vjp")
+        return SplitTensor(planes, sexp, amax)
 
     def vjp_nhwc_split(self, g, g_amax, g2, mult, mult_amax, scale, scale_amax, S, out_shape):
         """``(g + g2) * mult * scale[channel]`` for all ``S`` seeds -> SplitTensor of ``out_shape`` ([S*B, H, W, C]).

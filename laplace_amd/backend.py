@@ -540,6 +540,9 @@ class KronAccumulator:
         #: happens once per LAUNCH, so stacking the NHWC inputs of consecutive minibatches divides that traffic
         self.pix_group = max(1, int(os.environ.get("LK_PIX_GROUP", "4")))
         self._side = None
+        self._side_done = None  # event at the end of the previous minibatch's side-stream work (lagged join)
+        #: ``False`` (env LK_LAG_JOIN=0): the main stream waits for the factor kernels at the end of every minibatch
+        self.lag_join = os.environ.get("LK_LAG_JOIN", "1") != "0"
         self.factors = None  # per tap: [G, A]
         self.loss = None
         self._taps_meta = None
@@ -663,6 +666,7 @@ class KronAccumulator:
     def _flush_pixgrams(self, only=None):
         """fold the pixel-pair accumulators into the (native-order) A factors; idempotent"""
         K = get_kernels()
+        self._join_side()
         for idx in ([only] if only is not None else list(self._pix)):
             self._drain_pixpair(idx)
             geo, buf = self._pix.pop(idx)
@@ -718,6 +722,8 @@ class KronAccumulator:
                 with torch.cuda.stream(side):
                     b._factor_G(tap, g, rt * hs, self.kfac_approx, F[0], fused=True, persist=persist)
                 (g.planes if isinstance(g, SplitTensor) else g).record_stream(side)  # allocated on main, read on side
+                if isinstance(g, SplitTensor) and torch.is_tensor(g.sexp):
+                    g.sexp.record_stream(side)
 
             grad_fn(seeds, stack=False, on_tap=on_tap, defer_bn_scale=defer)
         else:
@@ -727,7 +733,20 @@ class KronAccumulator:
         if defer:
             self._note_grad_scales(tape, grad_fn.grad_scale())
         if side is not None:
-            torch.cuda.current_stream(f.device).wait_stream(side)
+            if self.lag_join:
+                # The factor kernels of this minibatch may run on into the next one: its forward pass (small grids at
+                # batch 128) leaves most of the chip idle.  The main stream waits only for the minibatch BEFORE this one
+                # (at most one step of lag, so the memory held for the side stream stays bounded); everything the side
+                # stream reads that was allocated on the main stream is marked, so the allocator keeps it until then.
+                for tap in tape.taps:
+                    if torch.is_tensor(tap.a) and tap.a.is_cuda:
+                        tap.a.record_stream(side)
+                if self._side_done is not None:
+                    main.wait_event(self._side_done)
+                self._side_done = torch.cuda.Event()
+                self._side_done.record(side)
+            else:
+                main.wait_stream(side)
         tape.release()
 
     def _g_slabs(self, tap, g, alpha):
@@ -751,8 +770,16 @@ class KronAccumulator:
             self._gslabs[idx] = cur
         return cur[0]
 
+    def _join_side(self):
+        """the calling stream waits for everything the factor kernels have been asked to do so far"""
+        if self._side is not None:
+            torch.cuda.current_stream(self._side.device).wait_stream(self._side)
+            self._side_done = None
+
     def _flush_g_slabs(self, only=None):
         K = get_kernels()
+        if self._gslabs:
+            self._join_side()
         for idx in ([only] if only is not None else list(self._gslabs)):
             buf, n, L, alpha = self._gslabs.pop(idx)
             K.gram_slabs_reduce(buf, n, L, alpha, self.factors[idx][0], upper_only=True)
@@ -771,6 +798,7 @@ class KronAccumulator:
                 raise RuntimeError(f"{tap.name}: the BatchNorm scale changed during the fit (model not in eval mode?)")
 
     def _apply_grad_scales(self):
+        self._join_side()
         for idx, s_ in self._gscale.items():
             G = self.factors[idx][0]
             G.mul_(s_.reshape(-1, 1) * s_.reshape(1, -1))

@@ -45,9 +45,20 @@ class PreparedConv:
     def backward_planes(self, cscale=None):
         key = self._key(cscale)
         if self._bwd is None or self._bwd[0] != key:
-            planes, sexp = get_kernels().conv_prep_weights(self.m.weight.detach().contiguous(), True, cscale)
-            self._bwd = (key, planes, sexp)
+            W = self.m.weight.detach()
+            planes, sexp = get_kernels().conv_prep_weights(W.contiguous(), True, cscale)
+            # l1 bound of the backward-data GEMM (lk_conv_nhwc_f16x2_vjp): max|dX| <= max|g| * max_ci sum_{co,kh,kw} |W s_co|.
+            # A per-layer constant, built with the planes (torch reductions: preparation, not the hot path).
+            Wa = W.abs().float()
+            if cscale is not None:
+                Wa = Wa * cscale.abs().reshape(-1, 1, 1, 1)
+            l1 = Wa.sum(dim=(0, 2, 3)).max().reshape(1).contiguous()
+            self._bwd = (key, planes, sexp, l1)
         return self._bwd[1], self._bwd[2]
+
+    def backward_l1(self, cscale=None):
+        self.backward_planes(cscale)
+        return self._bwd[3]
 
     @property
     def padded_in(self) -> int:
@@ -108,6 +119,25 @@ def conv_backward_data(prep: PreparedConv, g: SplitTensor, in_hw, cscale=None, o
             K.conv_nhwc_f16x2(g, planes, sexp, Hc, Wc, 1, out, m.stride[0], oh0, ow0, taps, accumulate=accumulate,
                               amax_out=amax_out)
     return out
+
+
+def fused_backward_ok(m: nn.Conv2d) -> bool:
+    """the backward-data of ``m`` is ONE dense launch with an 8-aligned channel count: the VJP epilogue applies"""
+    return m.stride[0] == 1 and m.stride[1] == 1 and m.in_channels % 8 == 0
+
+
+def conv_backward_data_vjp(prep: PreparedConv, g: SplitTensor, in_hw, cscale=None, add=None, mult=None, mult_amax=None,
+                           scale=None, scale_amax=None) -> SplitTensor:
+    """``(dX + add) * mult * scale[channel]`` as a SplitTensor (with its measured ``amax``): :func:`conv_backward_data`
+    followed by the sweep's element-wise VJP, in one launch (stride-1 convs, see :func:`fused_backward_ok`)."""
+    K = get_kernels()
+    m = prep.m
+    Hin, Win = in_hw
+    planes, sexp = prep.backward_planes(cscale)
+    (Hc, Wc, oh0, ow0, taps), = backward_plan(m, Hin, Win)
+    assert (Hc, Wc, oh0, ow0) == (Hin, Win, 0, 0)
+    return K.conv_nhwc_f16x2_vjp(g, planes, sexp, prep.backward_l1(cscale), Hin, Win, taps, add=add, mult=mult,
+                                 mult_amax=mult_amax, scale=scale, scale_amax=scale_amax)
 
 
 def conv_forward(prep: PreparedConv, x: SplitTensor, out=None, amax_out=None):

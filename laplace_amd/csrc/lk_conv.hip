@@ -134,6 +134,8 @@ struct ConvGeom {
 template <int BM_, int BN_, int BK_, int WM_, int WN_, int NBUF_ = 2, int WPE_ = 2, bool MIDBAR_ = false>
 struct ConvCfg {
   static constexpr bool MIDBAR = MIDBAR_;                 // hand over to the next stage in the MIDDLE of a stage's MFMAs
+  static constexpr int EPI_LDS = WM_ * WN_ * (BM_ / WM_) * (BN_ / WN_ + 4) * 4;  // staging image of the fused (VJP) epilogue
+  static constexpr bool FUSABLE = NBUF_ == 2 && BK_ == 32 && !MIDBAR_ && WM_ * WN_ == 4;  // shapes the VJP epilogue is built for
   static constexpr int WPE = WPE_;                        // waves per SIMD the register allocation is sized for
   static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_;
   static constexpr int NBUF = NBUF_;                      // LDS stages: NBUF - 1 stages of loads are in flight
@@ -158,13 +160,37 @@ __device__ __forceinline__ int swz(int row) {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
 
-template <typename CFG>
+// Fused epilogue ("VJP form"): instead of the fp32 tensor the launch emits what the element-wise VJP kernel
+// (lk_sweep16.hip: vjp_nhwc_split_kernel) would make of it,
+//   o = (conv + add) * M * scale[channel]      add: split tensor (cotangent of a residual join), M: activation multiplier
+// as a split tensor.  Its scale comes from a GUARANTEED bound known before the launch,
+//   max|conv| <= max|in| * l1(W),   l1(W) = max_n sum_{t,k} |Wt[t][n][k]|   (a per-layer constant, device word)
+// times the bounds of the other factors — loose by a few bits, which only costs fixed-point range (see the header of this
+// file) — and the launch also measures max|o| itself (amax_out): the NEXT launch derives its bound from that measured
+// value, so the slack does not compound along the sweep.
+struct ConvVjp {
+  const unsigned* in_amax;   // measured max|in| (bit pattern) or NULL: 2^(15 - in_sexp)
+  const float* w_l1;         // l1(W) of the prepared weights (including their folded channel scale)
+  const _Float16 *add_h, *add_l;
+  const int* add_sexp;
+  const void* mask;          // uint8 (mask_float = 0) or fp32 multiplier, [mask_rows][Co]; row of output pixel m: m % mask_rows
+  int mask_float;
+  const unsigned* mult_amax; // max|M| for fp32 multipliers (NULL: 1)
+  int64_t mask_rows;
+  const float* scale;        // [Co] or NULL
+  const unsigned* scale_amax;
+  _Float16 *out_h, *out_l;
+  int* out_sexp;
+};
+
+template <typename CFG, bool FUSE>
 __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WPE, CFG::WPE))) void conv_f16x2_kernel(const ConvGeom g, const _Float16* __restrict__ Ah,
                                                          const _Float16* __restrict__ Al, const _Float16* __restrict__ Wh,
                                                          const _Float16* __restrict__ Wl, const int* __restrict__ a_sexp,
                                                          const int* __restrict__ w_sexp, const _Float16* __restrict__ zero16,
                                                          float* __restrict__ out, int accumulate,
-                                                         unsigned* __restrict__ amax_out, int nb_m, int ablate) {
+                                                         unsigned* __restrict__ amax_out, int nb_m, int ablate,
+                                                         const ConvVjp fz) {
   constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK, Q = CFG::Q, TM = CFG::TM, TN = CFG::TN, NT = CFG::NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -425,6 +451,100 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
   // ---- epilogue: un-scale, store NHWC (a half-wave writes 32 consecutive channels = 128 B), max|out|
   const float inv_a = exp2i(-a_sexp[0] < -126 ? -126 : -a_sexp[0]), inv_w = exp2i(-w_sexp[0] < -126 ? -126 : -w_sexp[0]);
   unsigned vmax = 0;
+  if constexpr (FUSE) {
+    // scale of the result from the guaranteed bound (every thread computes the same few flops; one writes the word)
+    float bound = fz.in_amax ? __uint_as_float(fz.in_amax[0]) : exp2i(15 - a_sexp[0] < -126 ? -126 : (15 - a_sexp[0] > 127 ? 127 : 15 - a_sexp[0]));
+    bound *= fz.w_l1[0];
+    float inv2 = 0.f;
+    if (fz.add_h) {
+      const int s2 = fz.add_sexp[0];
+      bound += exp2i(15 - s2 < -126 ? -126 : (15 - s2 > 127 ? 127 : 15 - s2));
+      inv2 = exp2i(-s2 < -126 ? -126 : -s2);
+    }
+    if (fz.mask && fz.mask_float && fz.mult_amax) bound *= __uint_as_float(fz.mult_amax[0]);
+    if (fz.scale) bound *= __uint_as_float(fz.scale_amax[0]);
+    const int so = scale_exp_for(bound);
+    if (blockIdx.x == 0 && tid == 0) fz.out_sexp[0] = so;
+    const float sc_out = exp2i(so);
+    // the wave's 64 x 64 (32 x 32, ...) block goes through LDS: MFMA layout (lane = channel, registers = pixels) ->
+    // lane = 8 consecutive channels of one pixel, i.e. 16-byte loads of the addend / mask and 16-byte stores of each plane
+    constexpr int ROWS_W = TM * 32, COLS_W = TN * 32, PITCH = COLS_W + 4, C8 = COLS_W / 8;
+    static_assert(CFG::EPI_LDS == CFG::WM * CFG::WN * ROWS_W * PITCH * 4 && CFG::EPI_LDS <= 80 * 1024, "staging image: two workgroups per CU");
+    __syncthreads();  // every wave is done with the K loop's stage buffers
+    float* img = reinterpret_cast<float*>(smem) + wave * (ROWS_W * PITCH);
+    const float inv = inv_a * inv_w;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          img[(a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * PITCH + b * 32 + lr] = acc[a][b][r] * inv;
+    // (LDS operations of one wave execute in order: no barrier between its own writes and reads)
+    const int HWc = g.Hc * g.Wc;
+#pragma unroll 2
+    for (int it = 0; it < ROWS_W * C8 / 64; ++it) {
+      const int idx = it * 64 + lane;
+      const int row = idx / C8, c8 = idx - row * C8;
+      const int m = tile_m * BM + wm * ROWS_W + row;
+      const int col0 = tile_n * BN + wn * COLS_W + c8 * 8;
+      if (m >= M || col0 >= g.Co) continue;
+      const f32x4 p0 = *reinterpret_cast<const f32x4*>(img + row * PITCH + c8 * 8);
+      const f32x4 p1 = *reinterpret_cast<const f32x4*>(img + row * PITCH + c8 * 8 + 4);
+      float v[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+      const int64_t e = (int64_t)m * g.Co + col0;
+      if (fz.add_h) {
+        const f16x8 h2 = *reinterpret_cast<const f16x8*>(fz.add_h + e), l2 = *reinterpret_cast<const f16x8*>(fz.add_l + e);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += ((float)h2[j] + (float)l2[j]) * inv2;
+      }
+      float mult[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) mult[j] = sc_out;
+      if (fz.mask) {
+        const int64_t em = (int64_t)(m % fz.mask_rows) * g.Co + col0;
+        if (fz.mask_float) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>((const float*)fz.mask + em);
+          const f32x4 b = *reinterpret_cast<const f32x4*>((const float*)fz.mask + em + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) mult[j] *= a[j], mult[4 + j] *= b[j];
+        } else {
+          const uint2 u = *reinterpret_cast<const uint2*>((const unsigned char*)fz.mask + em);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (!((u.x >> (8 * j)) & 0xffu)) mult[j] = 0.f;
+            if (!((u.y >> (8 * j)) & 0xffu)) mult[4 + j] = 0.f;
+          }
+        }
+      }
+      if (fz.scale) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(fz.scale + col0), b = *reinterpret_cast<const f32x4*>(fz.scale + col0 + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mult[j] *= a[j], mult[4 + j] *= b[j];
+      }
+      f16x8 h, l;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float xs = v[j] * mult[j];
+        asm volatile("" : "+v"(xs));  // h and the residual from the SAME fp32 value (see split2)
+        const _Float16 hh = (_Float16)xs;
+        h[j] = hh;
+        l[j] = (_Float16)(xs - (float)hh);
+        vmax = max(vmax, __float_as_uint(xs) & 0x7fffffffu);
+      }
+      *reinterpret_cast<f16x8*>(fz.out_h + e) = h;
+      *reinterpret_cast<f16x8*>(fz.out_l + e) = l;
+    }
+    (void)HWc;
+    if (amax_out) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) vmax = max(vmax, (unsigned)__shfl_xor((int)vmax, off, 64));
+      // max|o| = max|o 2^so| * 2^-so (exact: a power of two), kept as the bit pattern of a non-negative float
+      const int back = -so < -126 ? -126 : -so;
+      if (lane == 0 && vmax) atomicMax(amax_out, __float_as_uint(__uint_as_float(vmax) * exp2i(back)));
+    }
+    return;
+  }
   if (g.out_nchw) {
     // position-contiguous output [n][co][pixel] (what the predictive's quadratic-form kernel reads): a lane owns one
     // channel, registers r = 4q .. 4q+3 are four consecutive pixels of it -> one 16-byte store
@@ -738,21 +858,37 @@ static int g_ablate = 0;  // development switch (config bits 8..10 of lk_conv_nh
 template <typename CFG>
 static int launch_conv(const ConvGeom& g, const void* Ah, const void* Al, const void* Wh, const void* Wl, const int* a_sexp,
                        const int* w_sexp, const void* zero16, float* out, int accumulate, unsigned* amax_out,
-                       hipStream_t stream) {
+                       hipStream_t stream, const ConvVjp* fz = nullptr) {
   const int64_t M = (int64_t)g.N * g.Hc * g.Wc;
   const int nb_m = (int)((M + CFG::BM - 1) / CFG::BM), nb_n = (g.Co + CFG::BN - 1) / CFG::BN;
   const size_t lds = (size_t)CFG::NBUF * CFG::STAGE;
+  if (fz) {
+    if constexpr (CFG::FUSABLE) {
+      const size_t lds_f = lds > (size_t)CFG::EPI_LDS ? lds : (size_t)CFG::EPI_LDS;
+      static bool attr_set_f = false;
+      if (!attr_set_f) {
+        (void)hipFuncSetAttribute((const void*)conv_f16x2_kernel<CFG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);
+        attr_set_f = true;
+      }
+      hipLaunchKernelGGL((conv_f16x2_kernel<CFG, true>), dim3((unsigned)(nb_m * nb_n)), dim3(CFG::NT), lds_f, stream, g,
+                         (const _Float16*)Ah, (const _Float16*)Al, (const _Float16*)Wh, (const _Float16*)Wl, a_sexp, w_sexp,
+                         (const _Float16*)zero16, out, accumulate, amax_out, nb_m, g_ablate, *fz);
+      return check_launch("conv_f16x2_kernel(vjp)");
+    } else {
+      set_error("lk_conv_nhwc_f16x2_vjp: this K-pipeline variant has no fused epilogue");
+      return LK_EINVAL;
+    }
+  }
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_f16x2_kernel<CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv_f16x2_kernel<CFG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(conv_f16x2_kernel<CFG>, dim3((unsigned)(nb_m * nb_n)), dim3(CFG::NT), lds, stream, g, (const _Float16*)Ah,
+  hipLaunchKernelGGL((conv_f16x2_kernel<CFG, false>), dim3((unsigned)(nb_m * nb_n)), dim3(CFG::NT), lds, stream, g, (const _Float16*)Ah,
                      (const _Float16*)Al, (const _Float16*)Wh, (const _Float16*)Wl, a_sexp, w_sexp, (const _Float16*)zero16,
-                     out, accumulate, amax_out, nb_m, g_ablate);
+                     out, accumulate, amax_out, nb_m, g_ablate, ConvVjp{});
   return check_launch("conv_f16x2_kernel");
 }
-
 template <typename CFG>
 static int launch_patch(const ConvGeom& g, const void* Ah, const void* Al, const void* Wh, const void* Wl, const int* a_sexp,
                         const int* w_sexp, const void* zero16, float* out, int accumulate, unsigned* amax_out,
@@ -771,12 +907,12 @@ static int launch_patch(const ConvGeom& g, const void* Ah, const void* Al, const
 }
 
 // One launch of the implicit GEMM.  `taps`: T x {dh, dw, weight slice}.
-extern "C" int lk_conv_nhwc_f16x2(const void* in_h, const void* in_l, const int* in_sexp, int64_t N, int64_t Hi, int64_t Wi,
-                                  int64_t Ci, const void* w_h, const void* w_l, const int* w_sexp, int64_t Co,
-                                  int64_t Hc, int64_t Wc, int64_t in_mul, int64_t Ho, int64_t Wo, int64_t out_step,
-                                  int64_t oh0, int64_t ow0, int64_t T, const int* taps, const void* zero16, float* out,
-                                  int accumulate, unsigned* amax_out, int config, void* stream) {
-  LK_REQUIRE(in_h && in_l && in_sexp && w_h && w_l && w_sexp && zero16 && out && taps, "lk_conv_nhwc_f16x2: null pointer");
+static int conv_dispatch(const void* in_h, const void* in_l, const int* in_sexp, int64_t N, int64_t Hi, int64_t Wi,
+                         int64_t Ci, const void* w_h, const void* w_l, const int* w_sexp, int64_t Co,
+                         int64_t Hc, int64_t Wc, int64_t in_mul, int64_t Ho, int64_t Wo, int64_t out_step,
+                         int64_t oh0, int64_t ow0, int64_t T, const int* taps, const void* zero16, float* out,
+                         int accumulate, unsigned* amax_out, int config, void* stream, const ConvVjp* fz) {
+  LK_REQUIRE(in_h && in_l && in_sexp && w_h && w_l && w_sexp && zero16 && (out || fz) && taps, "lk_conv_nhwc_f16x2: null pointer");
   LK_REQUIRE(T >= 1 && T <= 9 && Ci >= 32 && Ci % 32 == 0 && Co >= 1 && N >= 1, "lk_conv_nhwc_f16x2: Ci % 32 == 0, 1..9 taps");
   LK_REQUIRE(N * Hc * Wc < (1ll << 31) && N * Hi * Wi * Ci < (1ll << 40), "lk_conv_nhwc_f16x2: tensor too large");
   if (Hc == 0 || Wc == 0) return LK_OK;
@@ -793,7 +929,7 @@ extern "C" int lk_conv_nhwc_f16x2(const void* in_h, const void* in_l, const int*
   hipStream_t st = (hipStream_t)stream;
   g_ablate = (config >> 8) & 7;
   // "patch" form (A operand resident in LDS across the taps) where the output grid is the input grid
-  bool patch = !(config & 2) && !(config & 16) && in_mul == 1 && Hc == Hi && Wc == Wi && 256 + 2 * Wi + 2 <= 336 && N * Hi * Wi >= 256;
+  bool patch = !fz && !(config & 2) && !(config & 16) && in_mul == 1 && Hc == Hi && Wc == Wi && 256 + 2 * Wi + 2 <= 336 && N * Hi * Wi >= 256;
   for (int t = 0; t < T && patch; ++t) patch = g.dh[t] >= -1 && g.dh[t] <= 1 && g.dw[t] >= -1 && g.dw[t] <= 1;
   if (patch) {
     if (Co <= 64)
@@ -801,7 +937,7 @@ extern "C" int lk_conv_nhwc_f16x2(const void* in_h, const void* in_l, const int*
     return launch_patch<PatchCfg<128, 4, 2>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st);
   }
   const bool bk64 = (Ci % 64 == 0) && (config & 1);
-#define LK_CONV_GO(...) return launch_conv<ConvCfg<__VA_ARGS__>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st)
+#define LK_CONV_GO(...) return launch_conv<ConvCfg<__VA_ARGS__>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz)
   switch ((config >> 12) & 7) {  // explicit tile shape (bits 12..14); 0: chosen below
     case 1: LK_CONV_GO(64, 64, 32, 2, 2, 2, 4);
     case 2: LK_CONV_GO(128, 64, 32, 2, 2, 2, 3);
@@ -833,33 +969,66 @@ extern "C" int lk_conv_nhwc_f16x2(const void* in_h, const void* in_l, const int*
   }
   if (config & 8) {  // 8 waves, one workgroup per CU: 256 x 128 (256 x 64) tile, three LDS stages (two in flight)
     if (Co <= 64)
-      return launch_conv<ConvCfg<256, 64, 32, 4, 2, 3>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st);
-    return launch_conv<ConvCfg<256, 128, 32, 4, 2, 3>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st);
+      return launch_conv<ConvCfg<256, 64, 32, 4, 2, 3>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz);
+    return launch_conv<ConvCfg<256, 128, 32, 4, 2, 3>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz);
   }
   if (config & 2048) {  // hand-over barrier in the middle of a stage, fragments one k16 step ahead across stages
     if (Co <= 64)
-      return launch_conv<ConvCfg<256, 64, 32, 4, 1, 2, 2, true>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st);
-    return launch_conv<ConvCfg<128, 128, 32, 2, 2, 2, 2, true>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st);
+      return launch_conv<ConvCfg<256, 64, 32, 4, 1, 2, 2, true>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz);
+    return launch_conv<ConvCfg<128, 128, 32, 2, 2, 2, 2, true>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz);
   }
   if (config & 32) {  // 16-deep chunks, two or three LDS stages, registers sized for three waves per SIMD: 3+ workgroups per CU
     if (config & 64) {
       if (Co <= 64)
-        return launch_conv<ConvCfg<256, 64, 16, 4, 1, 3, 3>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st);
-      return launch_conv<ConvCfg<128, 128, 16, 2, 2, 3, 3>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st);
+        return launch_conv<ConvCfg<256, 64, 16, 4, 1, 3, 3>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz);
+      return launch_conv<ConvCfg<128, 128, 16, 2, 2, 3, 3>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz);
     }
     if (Co <= 64)
-      return launch_conv<ConvCfg<256, 64, 16, 4, 1, 2, 3>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st);
-    return launch_conv<ConvCfg<128, 128, 16, 2, 2, 2, 3>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st);
+      return launch_conv<ConvCfg<256, 64, 16, 4, 1, 2, 3>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz);
+    return launch_conv<ConvCfg<128, 128, 16, 2, 2, 2, 3>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz);
   }
   if (config & 4) {  // 16-deep chunks, four LDS stages (three stages of loads in flight)
     if (Co <= 64)
-      return launch_conv<ConvCfg<256, 64, 16, 4, 1, 4>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st);
-    return launch_conv<ConvCfg<128, 128, 16, 2, 2, 4>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st);
+      return launch_conv<ConvCfg<256, 64, 16, 4, 1, 4>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz);
+    return launch_conv<ConvCfg<128, 128, 16, 2, 2, 4>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz);
   }
   if (Co <= 64) {
-    return bk64 ? launch_conv<ConvCfg<256, 64, 64, 4, 1>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st)
-                : launch_conv<ConvCfg<256, 64, 32, 4, 1>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st);
+    return bk64 ? launch_conv<ConvCfg<256, 64, 64, 4, 1>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz)
+                : launch_conv<ConvCfg<256, 64, 32, 4, 1>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz);
   }
-  return bk64 ? launch_conv<ConvCfg<128, 128, 64, 2, 2>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st)
-              : launch_conv<ConvCfg<128, 128, 32, 2, 2>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st);
+  return bk64 ? launch_conv<ConvCfg<128, 128, 64, 2, 2>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz)
+              : launch_conv<ConvCfg<128, 128, 32, 2, 2>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz);
+}
+
+extern "C" int lk_conv_nhwc_f16x2(const void* in_h, const void* in_l, const int* in_sexp, int64_t N, int64_t Hi, int64_t Wi,
+                                  int64_t Ci, const void* w_h, const void* w_l, const int* w_sexp, int64_t Co,
+                                  int64_t Hc, int64_t Wc, int64_t in_mul, int64_t Ho, int64_t Wo, int64_t out_step,
+                                  int64_t oh0, int64_t ow0, int64_t T, const int* taps, const void* zero16, float* out,
+                                  int accumulate, unsigned* amax_out, int config, void* stream) {
+  return conv_dispatch(in_h, in_l, in_sexp, N, Hi, Wi, Ci, w_h, w_l, w_sexp, Co, Hc, Wc, in_mul, Ho, Wo, out_step, oh0, ow0, T,
+                       taps, zero16, out, accumulate, amax_out, config, stream, nullptr);
+}
+
+// The same launch with the fused VJP epilogue (see ConvVjp): dense output grid (the output tensor IS the class grid), no
+// accumulate, Co % 8 == 0.  Emits the split tensor out_h / out_l / out_sexp and max|result| (out_amax, zeroed by the caller).
+extern "C" int lk_conv_nhwc_f16x2_vjp(const void* in_h, const void* in_l, const int* in_sexp, const void* in_amax, int64_t N,
+                                      int64_t Hi, int64_t Wi, int64_t Ci, const void* w_h, const void* w_l, const int* w_sexp,
+                                      const float* w_l1, int64_t Co, int64_t Ho, int64_t Wo, int64_t T, const int* taps,
+                                      const void* zero16, const void* add_h, const void* add_l, const int* add_sexp,
+                                      const void* mask, int mask_is_float, const void* mult_amax, int64_t mask_rows,
+                                      const float* scale, const void* scale_amax, void* out_h, void* out_l, int* out_sexp,
+                                      void* out_amax, int config, void* stream) {
+  LK_REQUIRE(w_l1 && out_h && out_l && out_sexp && out_amax, "lk_conv_nhwc_f16x2_vjp: null pointer");
+  LK_REQUIRE(Co % 8 == 0, "lk_conv_nhwc_f16x2_vjp: Co % 8 == 0");
+  LK_REQUIRE(!add_h || (add_l && add_sexp), "lk_conv_nhwc_f16x2_vjp: incomplete addend");
+  LK_REQUIRE(!mask || mask_rows > 0, "lk_conv_nhwc_f16x2_vjp: mask_rows");
+  LK_REQUIRE(!scale || scale_amax, "lk_conv_nhwc_f16x2_vjp: scale needs its bound");
+  ConvVjp fz;
+  fz.in_amax = (const unsigned*)in_amax, fz.w_l1 = w_l1;
+  fz.add_h = (const _Float16*)add_h, fz.add_l = (const _Float16*)add_l, fz.add_sexp = add_sexp;
+  fz.mask = mask, fz.mask_float = mask_is_float, fz.mult_amax = (const unsigned*)mult_amax, fz.mask_rows = mask ? mask_rows : 1;
+  fz.scale = scale, fz.scale_amax = (const unsigned*)scale_amax;
+  fz.out_h = (_Float16*)out_h, fz.out_l = (_Float16*)out_l, fz.out_sexp = out_sexp;
+  return conv_dispatch(in_h, in_l, in_sexp, N, Hi, Wi, Ci, w_h, w_l, w_sexp, Co, Ho, Wo, 1, Ho, Wo, 1, 0, 0, T, taps, zero16,
+                       nullptr, 0, (unsigned*)out_amax, config & ~(1 | 4 | 8 | 16 | 32 | 64 | 2048), stream, &fz);
 }

@@ -19,6 +19,7 @@ are not multiples of 32, ...) run through the parent class unchanged.
 from __future__ import annotations
 
 import operator
+import os
 
 import torch
 import torch.fx as fx
@@ -39,6 +40,30 @@ class _F32:
         self.t, self.amax = t, amax
 
 
+class _LazyConv:
+    """A stride-1 convolution's backward-data that has not run yet: whoever consumes the cotangent decides whether it is
+    materialised as an fp32 tensor (``f32()``) or comes out of the convolution kernel already multiplied / joined / split
+    (``fused(...)``, lk_conv_nhwc_f16x2_vjp) — the element-wise VJP kernel and the fp32 tensor's round trip then vanish."""
+
+    __slots__ = ("_f32", "_fused", "_done")
+
+    def __init__(self, f32, fused):
+        self._f32, self._fused, self._done = f32, fused, None
+
+    def f32(self) -> "_F32":
+        if self._done is None:
+            self._done = self._f32()
+        return self._done
+
+    def fused(self, **kw) -> SplitTensor:
+        assert self._done is None
+        return self._fused(**kw)
+
+
+def _materialize(parts):
+    return [p.f32() if isinstance(p, _LazyConv) else p for p in parts]
+
+
 class SplitSweep(SeedBatchedSweep):
     """Seed-batched reverse sweep whose feature-map cotangents are NHWC split tensors (needs the HIP kernels)."""
 
@@ -48,6 +73,21 @@ class SplitSweep(SeedBatchedSweep):
         self._amax_cache: dict = {}
         self.split_reason = self._split_eligible()
         self.split_ok = self.split_reason is None
+
+    #: ``False`` (env LK_FUSE_VJP=0): every backward-data writes fp32 and the element-wise VJP kernel runs on it
+    fuse_vjp = os.environ.get("LK_FUSE_VJP", "1") != "0"
+
+    def _consumes_lazily(self, node) -> bool:
+        """nodes whose rule hands all incoming cotangent parts to ``_to_split`` (which can fuse a pending convolution)"""
+        if node.op == "call_module":
+            m = self.modules[node.target]
+            return isinstance(m, (nn.Conv2d, nn.BatchNorm2d, nn.ReLU, nn.Tanh, nn.Sigmoid, nn.Identity, nn.Dropout)
+                              + self._GENERIC_ACT_MODULES)
+        if node.op == "call_function":
+            return node.target in self._ELEMENTWISE_FN or node.target in self._GENERIC_ACT_FN
+        if node.op == "call_method":
+            return node.target in ("relu", "tanh", "sigmoid", "contiguous")
+        return False
 
     # ---- static eligibility ---------------------------------------------------------------------------------------
     def _split_eligible(self):
@@ -184,6 +224,13 @@ class SplitSweep(SeedBatchedSweep):
     def _to_split(self, parts, S, mult=None, mult_amax=None, scale=None, scale_amax=None):
         """sum of cotangent parts (x multiplier x channel scale) -> one SplitTensor"""
         K = self.kernels()
+        lazy = [p for p in parts if isinstance(p, _LazyConv)]
+        if lazy:
+            rest = [p for p in parts if not isinstance(p, _LazyConv)]
+            if len(lazy) == 1 and lazy[0]._done is None and len(rest) <= 1 and all(isinstance(p, SplitTensor) for p in rest):
+                return lazy[0].fused(add=rest[0] if rest else None, mult=mult, mult_amax=mult_amax, scale=scale,
+                                     scale_amax=scale_amax)
+            parts = _materialize(parts)
         f32 = [p for p in parts if isinstance(p, _F32)]
         spl = [p for p in parts if isinstance(p, SplitTensor)]
         if len(f32) > 1:  # (no graph of the supported families gets here: two un-activated conv branches joining)
@@ -239,6 +286,8 @@ class SplitSweep(SeedBatchedSweep):
         def push(n, part):
             if not isinstance(n, fx.Node) or n.op == "placeholder":
                 return
+            if isinstance(part, _LazyConv) and n in deferred:
+                part = part.f32()
             if isinstance(part, _F32) and n in deferred:
                 for fn in deferred.pop(n):  # strided 1x1 branches waiting for the main branch's tensor: add into it
                     fn(part)
@@ -266,6 +315,8 @@ class SplitSweep(SeedBatchedSweep):
             if node not in cot:
                 continue
             parts = cot.pop(node)
+            if node in deferred or not self._consumes_lazily(node):
+                parts = _materialize(parts)
             if node in deferred:
                 f32p = [p for p in parts if isinstance(p, _F32)]
                 fns = deferred.pop(node)
@@ -310,11 +361,18 @@ class SplitSweep(SeedBatchedSweep):
                         cv.conv_backward_data(prep, g, hw, cscale=cscale, out=into.t, accumulate=True, amax_out=into.amax)
                         return into
 
+                    if src in cot:
+                        cot[src] = _materialize(cot[src])
                     existing = [p for p in cot.get(src, []) if isinstance(p, _F32)]
                     if existing:
                         run(existing[0])
                     elif sparse and len(src.users) > 1:
                         deferred.setdefault(src, []).append(run)  # wait for the dense branch, then add into it
+                    elif self.fuse_vjp and cv.fused_backward_ok(m) and hasattr(K, "conv_nhwc_f16x2_vjp"):
+                        def run_fused(g=g, prep=prep, hw=hw, cscale=cscale, **kw):
+                            return cv.conv_backward_data_vjp(prep, g, hw, cscale=cscale, **kw)
+
+                        push(src, _LazyConv(lambda run=run: run(None), run_fused))
                     else:
                         push(src, run(None))
                 elif isinstance(m, nn.Linear):

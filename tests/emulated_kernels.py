@@ -106,6 +106,34 @@ class EmulatedKernels:
             amax_out.copy_(torch.maximum(amax_out, view.abs().max().reshape(1)))
         return out
 
+    def conv_nhwc_f16x2_vjp(self, x, wplanes, wsexp, w_l1, Ho, Wo, taps, add=None, mult=None, mult_amax=None, scale=None,
+                            scale_amax=None, config=None):
+        """lk_conv_nhwc_f16x2_vjp: the convolution, then (conv + add) * mult * scale split with the scale of the
+        guaranteed bound max|in| * l1(W) (+ ...); the measured max|.| rides along as ``amax``"""
+        N = x.shape[0]
+        Co = wplanes.shape[2]
+        conv = self.conv_nhwc_f16x2(x, wplanes, wsexp, Ho, Wo, 1, torch.zeros(N, Ho, Wo, Co), 1, 0, 0, taps)
+        in_amax = float(x.amax[0]) if getattr(x, "amax", None) is not None else 2.0 ** (15 - int(x.sexp[0]))
+        bound = in_amax * float(w_l1[0])
+        assert float(conv.abs().max()) <= bound * (1 + 1e-5) + 1e-30, "max|in| * l1(W) does not bound the convolution"
+        v = conv
+        if add is not None:
+            v = v + add.float()
+            bound += 2.0 ** (15 - int(add.sexp[0]))
+        if mult is not None:
+            mf = mult.float() if mult.dtype not in (torch.uint8, torch.bool) else (mult != 0).float()
+            S = N // mf.shape[0]
+            v = (v.reshape(S, *mf.shape) * mf).reshape(v.shape)
+            if mult.dtype == torch.float32 and mult_amax is not None:
+                bound *= float(mult_amax[0])
+        if scale is not None:
+            v = v * scale
+            bound *= float(scale_amax[0])
+        assert float(v.abs().max()) <= bound * (1 + 1e-6) + 1e-30, "the guaranteed bound of the fused epilogue does not hold"
+        out = self._split(v, self._sexp_for(bound))
+        out.amax = out.float().abs().max().reshape(1).float()
+        return out
+
     def vjp_nhwc_split(self, g, g_amax, g2, mult, mult_amax, scale, scale_amax, S, out_shape):
         bound = 0.0
         v = torch.zeros(out_shape)

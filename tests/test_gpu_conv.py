@@ -158,3 +158,64 @@ def test_unsplit_transpose_of_a_seed_batched_cotangent():
     u = K.unsplit_transpose(K.split_f16x2(x), S, B)
     want = x.reshape(S, B, H * W, C).permute(1, 0, 3, 2)
     assert u.shape == (B, S, C, H * W) and rel(u, want) < 1e-6
+
+
+FUSED_SHAPES = [(64, 64, 3, 1, 1, 32), (128, 128, 3, 1, 1, 16), (256, 256, 3, 1, 1, 8), (512, 512, 3, 1, 1, 4),
+                (96, 160, 3, 1, 1, 7), (64, 32, 1, 1, 0, 5)]
+
+
+@pytest.mark.parametrize("shape", FUSED_SHAPES, ids=[f"{c[0]}-{c[1]}-k{c[2]}-{c[5]}x{c[5]}" for c in FUSED_SHAPES])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", ["mask+scale", "mask+add", "float-mult+add+scale", "plain"])
+def test_backward_data_with_the_fused_vjp_epilogue(shape, tile, variant):
+    """lk_conv_nhwc_f16x2_vjp against the fp64 composition it replaces — backward-data, residual add, activation
+    multiplier, channel scale, split — on the stride-1 convolution shapes of c4 (and two odd ones), every tile shape."""
+    from laplace_amd import conv as cv
+    from laplace_amd._lib import get_kernels
+
+    K = get_kernels()
+    cin, cout, k, s, p, H = shape
+    m = _conv(cin, cout, k, s, p)
+    Ho = (H + 2 * p - k) // s + 1
+    S, B = 3, 5  # three seeds of five samples: the multiplier is shared by the seeds; 15 images: ragged last tile
+    N = S * B
+    torch.manual_seed(11)
+    g = torch.randn(N, cout, Ho, Ho, device=DEV) * 3e-3
+    want = torch.nn.grad.conv2d_input((N, cin, H, H), m.weight.double().cpu(), g.double().cpu(), stride=s, padding=p)
+    want = want.permute(0, 2, 3, 1)  # NHWC
+    gs = K.split_f16x2(g.permute(0, 2, 3, 1).contiguous())
+    kw = {}
+    if "add" in variant:
+        addend = torch.randn(N, H, H, cin, device=DEV) * 0.02
+        kw["add"] = K.split_f16x2(addend)
+        want = want + kw["add"].float().double().cpu()
+    if variant.startswith("mask"):
+        mask = (torch.rand(B, H, H, cin, device=DEV) > 0.4)
+        kw["mult"] = mask.to(torch.uint8)
+        want = (want.reshape(S, B, H, H, cin) * mask.double().cpu()).reshape(N, H, H, cin)
+    elif variant.startswith("float-mult"):
+        mult = (torch.rand(B, H, H, cin, device=DEV) * 0.9 + 0.05).contiguous()
+        kw["mult"], kw["mult_amax"] = mult, K.absmax(mult)
+        want = (want.reshape(S, B, H, H, cin) * mult.double().cpu()).reshape(N, H, H, cin)
+    if "scale" in variant:
+        sc = (torch.rand(cin, device=DEV) * 1.5 + 0.25).contiguous()
+        kw["scale"], kw["scale_amax"] = sc, K.absmax(sc)
+        want = want * sc.double().cpu()
+    prep = cv.PreparedConv(m)
+    prev = K.conv_config
+    K.conv_config = 2 | (tile << 12)
+    try:
+        out = cv.conv_backward_data_vjp(prep, gs, (H, H), **kw)
+    finally:
+        K.conv_config = prev
+    got = out.float()
+    assert rel(got, want) < 1e-5, rel(got, want)
+    # the measured max rides along (it is the next launch's bound), and the planes respect the fixed-point range
+    assert abs(out.amax.item() - got.abs().max().item()) <= 1e-5 * out.amax.item()
+    assert out.planes[0].float().abs().max().item() < 2.0 ** 15
+    # chained: the fused result as the input of another fused launch (bound from the measured max, not 2^(15 - sexp))
+    if cin == cout and k == 3:
+        out2 = cv.conv_backward_data_vjp(prep, out, (H, H))
+        want2 = torch.nn.grad.conv2d_input((N, cin, H, H), m.weight.double().cpu(), want.permute(0, 3, 1, 2).contiguous(),
+                                           stride=s, padding=p).permute(0, 2, 3, 1)
+        assert rel(out2.float(), want2) < 1e-5

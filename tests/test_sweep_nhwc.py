@@ -66,11 +66,18 @@ def _autograd_tap_grads(model, taps, x, seeds):
 
 @pytest.mark.parametrize("act", [torch.relu, torch.tanh])
 @pytest.mark.parametrize("defer", [False, True])
-def test_split_sweep_matches_per_seed_autograd(act, defer):
+@pytest.mark.parametrize("fuse", [True, False])
+def test_split_sweep_matches_per_seed_autograd(act, defer, fuse):
     model = _model(act)
     taps = {n: m for n, m in model.named_modules() if isinstance(m, (nn.Conv2d, nn.Linear))}
     sw = SplitSweep(model, taps, kernels=get_kernels)
+    sw.fuse_vjp = fuse
     assert sw.split_ok, sw.split_reason
+    K = get_kernels()
+    calls = {"vjp": 0, "fused": 0}
+    for name, key in (("vjp_nhwc_split", "vjp"), ("conv_nhwc_f16x2_vjp", "fused")):
+        orig = getattr(K, name)
+        setattr(K, name, lambda *a, _o=orig, _k=key, **k: (calls.__setitem__(_k, calls[_k] + 1), _o(*a, **k))[1])
     torch.manual_seed(0)
     x = torch.randn(4, 3, 8, 8)
     seeds = torch.randn(3, 4, 5)
@@ -94,6 +101,12 @@ def test_split_sweep_matches_per_seed_autograd(act, defer):
         assert err < 2e-5, (n, float(err))
     if defer:
         assert sw.grad_scale, "no BatchNorm scale was deferred"
+    # stride-1 backward-data passes hand their result over already multiplied / joined / split: five of the seven
+    # convolutions of the three blocks (the strided block's two branches keep the fp32 route and its accumulate-into)
+    if fuse:
+        assert calls["fused"] == 5 and calls["vjp"] < 7, calls
+    else:
+        assert calls["fused"] == 0
     # consumers that want plain tensors get [S, B, C, H, W] fp32
     got2 = sw.backward(seeds)
     for n in taps:
