@@ -127,6 +127,9 @@ struct ConvGeom {
   int T;               // taps of this launch
   int dh[9], dw[9], wt[9];  // per tap: offsets and the weight slice (index into the [T_w][Co][Ci] planes)
   FastDiv div_hw, div_w;    // GEMM row m -> (n, i, j):  n = m / (Hc*Wc), i = rem / Wc
+  FastDiv div_n;            // ... or, position-major (pmajor): pixel p = m / N, n = m % N
+  int pmajor;               // rows ordered (pixel, image): a tile of a small map holds ONE pixel position of many images,
+                            // so the taps that fall outside the image there are skipped as whole K stages
   int dense;                // the output grid is the output tensor (os = 1, Hc = Ho, Wc = Wo): output pixel = m
   int out_nchw;             // write out[n][co][pixel] (dense grids with Ho*Wo % 4 == 0 only): float4 along the pixels
 };
@@ -205,7 +208,6 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
   const int tile_n = bid / nb_m, tile_m = bid % nb_m;
   const int M = g.N * g.Hc * g.Wc;
   const int KC = g.Ci / BK;
-  const int nstage = g.T * KC;
 
   // ---- per-thread staging context: which rows / slots this thread feeds, fixed for the whole K loop
   // A: A_LD instructions; instruction i covers slots [i*256, i*256+256) of the concatenated [plane h | plane l] image
@@ -222,7 +224,9 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
     unsigned valid = 0;
     int64_t off = 0;
     if (m < M) {
-      const int n = fdiv(m, g.div_hw), rem = m - n * (g.Hc * g.Wc);
+      int n, rem;
+      if (g.pmajor) rem = fdiv(m, g.div_n), n = m - rem * g.N;
+      else n = fdiv(m, g.div_hw), rem = m - n * (g.Hc * g.Wc);
       const int ci_ = fdiv(rem, g.div_w);
       const int ih = ci_ * g.im, iw = (rem - ci_ * g.Wc) * g.im;
       off = (((int64_t)n * g.Hi + ih) * g.Wi + iw) * g.Ci;
@@ -250,8 +254,33 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
   }
   const int64_t w_tap = (int64_t)g.Co * g.Ci;
 
+  // Taps that reach no row of this tile are dropped from the K loop (position-major tiles of small maps: a corner pixel
+  // of a 4 x 4 map sees 4 of the 9 taps).  The list is uniform over the workgroup: OR of every thread's validity bits.
+  unsigned long long tap_list = 0;  // 4 bits per listed tap
+  int ntap = 0;
+  {
+    unsigned v = 0;
+#pragma unroll
+    for (int i = 0; i < CFG::A_LD / 2; ++i) v |= a_valid[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v |= (unsigned)__shfl_xor((int)v, off, 64);
+    unsigned* red = reinterpret_cast<unsigned*>(smem);
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    v = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) v |= red[w];
+    v = (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+    __syncthreads();  // the words are read before the first stage lands on them
+    for (int t = 0; t < g.T; ++t)
+      if ((v >> t) & 1u) tap_list |= (unsigned long long)t << (4 * ntap), ++ntap;
+  }
+
+  const int nstage = ntap * KC;
+
   auto stage = [&](int s, int buf) {
-    const int t = s / KC, kc = s - t * KC;
+    const int tj = s / KC, kc = s - tj * KC;
+    const int t = (int)((tap_list >> (4 * tj)) & 15ull);
     char* base = smem + buf * CFG::STAGE;
     const int64_t tap_off = ((int64_t)g.dh[t] * g.Wi + g.dw[t]) * g.Ci + kc * BK;
 #pragma unroll
@@ -492,7 +521,12 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
       const f32x4 p0 = *reinterpret_cast<const f32x4*>(img + row * PITCH + c8 * 8);
       const f32x4 p1 = *reinterpret_cast<const f32x4*>(img + row * PITCH + c8 * 8 + 4);
       float v[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
-      const int64_t e = (int64_t)m * g.Co + col0;
+      int64_t opix = m;  // dense grid: the output pixel index is the GEMM row, up to the position-major order
+      if (g.pmajor) {
+        const int rem = fdiv(m, g.div_n);
+        opix = (int64_t)(m - rem * g.N) * HWc + rem;
+      }
+      const int64_t e = opix * g.Co + col0;
       if (fz.add_h) {
         const f16x8 h2 = *reinterpret_cast<const f16x8*>(fz.add_h + e), l2 = *reinterpret_cast<const f16x8*>(fz.add_l + e);
 #pragma unroll
@@ -502,7 +536,7 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
 #pragma unroll
       for (int j = 0; j < 8; ++j) mult[j] = sc_out;
       if (fz.mask) {
-        const int64_t em = (int64_t)(m % fz.mask_rows) * g.Co + col0;
+        const int64_t em = (opix % fz.mask_rows) * g.Co + col0;
         if (fz.mask_float) {
           const f32x4 a = *reinterpret_cast<const f32x4*>((const float*)fz.mask + em);
           const f32x4 b = *reinterpret_cast<const f32x4*>((const float*)fz.mask + em + 4);
@@ -535,7 +569,6 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
       *reinterpret_cast<f16x8*>(fz.out_h + e) = h;
       *reinterpret_cast<f16x8*>(fz.out_l + e) = l;
     }
-    (void)HWc;
     if (amax_out) {
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) vmax = max(vmax, (unsigned)__shfl_xor((int)vmax, off, 64));
@@ -578,8 +611,10 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
       const int m = tile_m * BM + row;
       if (m >= M) continue;
       int64_t opix = m;
-      if (!g.dense) {
-        const int n = fdiv(m, g.div_hw), rem = m - n * (g.Hc * g.Wc);
+      if (g.pmajor || !g.dense) {
+        int n, rem;
+        if (g.pmajor) rem = fdiv(m, g.div_n), n = m - rem * g.N;
+        else n = fdiv(m, g.div_hw), rem = m - n * (g.Hc * g.Wc);
         const int ci_ = fdiv(rem, g.div_w);
         opix = ((int64_t)n * g.Ho + ci_ * g.os + g.oh0) * g.Wo + (rem - ci_ * g.Wc) * g.os + g.ow0;
       }
@@ -921,7 +956,9 @@ static int conv_dispatch(const void* in_h, const void* in_l, const int* in_sexp,
   g.Wo = (int)Wo, g.Co = (int)Co, g.os = (int)out_step, g.oh0 = (int)oh0, g.ow0 = (int)ow0, g.im = (int)in_mul, g.T = (int)T;
   for (int t = 0; t < 9; ++t) g.dh[t] = g.dw[t] = g.wt[t] = 0;
   for (int t = 0; t < T; ++t) g.dh[t] = taps[3 * t], g.dw[t] = taps[3 * t + 1], g.wt[t] = taps[3 * t + 2];
-  g.div_hw = make_fastdiv((int)(Hc * Wc)), g.div_w = make_fastdiv((int)Wc);
+  g.div_hw = make_fastdiv((int)(Hc * Wc)), g.div_w = make_fastdiv((int)Wc), g.div_n = make_fastdiv((int)N);
+  // small maps: rows ordered (pixel, image) so that border taps drop out of whole tiles (config bit 15 turns it off)
+  g.pmajor = (Hc * Wc <= 64 && N >= 64 && !(config & 16) && !(config & 32768)) ? 1 : 0;
   g.dense = out_step == 1 && oh0 == 0 && ow0 == 0 && Hc == Ho && Wc == Wo;
   g.out_nchw = (config & 16) ? 1 : 0;
   LK_REQUIRE(!g.out_nchw || (g.dense && (Ho * Wo) % 4 == 0 && !accumulate),
@@ -932,6 +969,7 @@ static int conv_dispatch(const void* in_h, const void* in_l, const int* in_sexp,
   bool patch = !fz && !(config & 2) && !(config & 16) && in_mul == 1 && Hc == Hi && Wc == Wi && 256 + 2 * Wi + 2 <= 336 && N * Hi * Wi >= 256;
   for (int t = 0; t < T && patch; ++t) patch = g.dh[t] >= -1 && g.dh[t] <= 1 && g.dw[t] >= -1 && g.dw[t] <= 1;
   if (patch) {
+    g.pmajor = 0;  // the patch form walks raster pixels
     if (Co <= 64)
       return launch_patch<PatchCfg<64, 4, 2>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st);
     return launch_patch<PatchCfg<128, 4, 2>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st);

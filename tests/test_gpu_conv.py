@@ -219,3 +219,49 @@ def test_backward_data_with_the_fused_vjp_epilogue(shape, tile, variant):
         want2 = torch.nn.grad.conv2d_input((N, cin, H, H), m.weight.double().cpu(), want.permute(0, 3, 1, 2).contiguous(),
                                            stride=s, padding=p).permute(0, 2, 3, 1)
         assert rel(out2.float(), want2) < 1e-5
+
+
+SMALL_MAPS = [(512, 512, 3, 1, 1, 4), (256, 256, 3, 1, 1, 8), (256, 512, 3, 2, 1, 8), (256, 512, 1, 2, 0, 8), (64, 96, 3, 1, 1, 2),
+              (64, 64, 3, 1, 1, 1)]
+
+
+@pytest.mark.parametrize("shape", SMALL_MAPS, ids=[f"{c[0]}-{c[1]}-k{c[2]}s{c[3]}-{c[5]}x{c[5]}" for c in SMALL_MAPS])
+@pytest.mark.parametrize("config", [2, 2 | 32768, 2 | (1 << 12), 2 | (4 << 12), 2050])
+def test_position_major_rows_on_small_maps(shape, config):
+    """Maps of at most 64 pixels with at least 64 images run with GEMM rows ordered (pixel, image), and taps that reach
+    no row of a tile leave its K loop (lk_conv.hip): backward-data, forward and the fused epilogue against fp64, with
+    an image count that is no multiple of any tile (ragged tiles straddle pixel positions); bit 15 = the plain order."""
+    from laplace_amd import conv as cv
+    from laplace_amd._lib import get_kernels
+
+    K = get_kernels()
+    cin, cout, k, s, p, H = shape
+    m = _conv(cin, cout, k, s, p)
+    Ho = (H + 2 * p - k) // s + 1
+    S, B = 2, 37
+    N = S * B
+    torch.manual_seed(5)
+    g = torch.randn(N, cout, Ho, Ho, device=DEV)
+    x = torch.randn(N, cin, H, H, device=DEV)
+    want_b = torch.nn.grad.conv2d_input((N, cin, H, H), m.weight.double().cpu(), g.double().cpu(), stride=s, padding=p)
+    want_f = F.conv2d(x.double().cpu(), m.weight.double().cpu(), stride=s, padding=p)
+    gs = K.split_f16x2(g.permute(0, 2, 3, 1).contiguous())
+    xs = K.split_f16x2(x.permute(0, 2, 3, 1).contiguous())
+    prep = cv.PreparedConv(m)
+    prev = K.conv_config
+    K.conv_config = config
+    try:
+        dx = cv.conv_backward_data(prep, gs, (H, H))
+        y = cv.conv_forward(prep, xs)
+        fused = None
+        if cv.fused_backward_ok(m) and not (config & 2048):
+            mask = (torch.rand(B, H, H, cin, device=DEV) > 0.3).to(torch.uint8)
+            addend = K.split_f16x2(torch.randn(N, H, H, cin, device=DEV))
+            fused = cv.conv_backward_data_vjp(prep, gs, (H, H), add=addend, mult=mask)
+    finally:
+        K.conv_config = prev
+    assert rel(dx.permute(0, 3, 1, 2), want_b) < 1e-5
+    assert rel(y.permute(0, 3, 1, 2), want_f) < 1e-5
+    if fused is not None:
+        want = (want_b.permute(0, 2, 3, 1) + addend.float().double().cpu()).reshape(S, B, H, H, cin) * mask.double().cpu()
+        assert rel(fused.float(), want.reshape(N, H, H, cin)) < 1e-5
