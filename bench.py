@@ -281,6 +281,9 @@ def main():
                         "sweep); six bf16 MFMAs per fp32 product block", "mfma", "void lk::gram_kernel<5,"),
             "pixpair": ("lk::gram_kernel<MODE_TNP>: banded pixel-pair accumulation of the 3x3-conv A factors "
                         "(block read-modify-write)", "hbm", "void lk::gram_kernel<4,"),
+            "pixpair16": ("lk::gram16_kernel<.., TNP>: banded pixel-pair accumulation of the 3x3-conv A factors from the split "
+                          "images (block read-modify-write once per four stacked minibatches; three fp16 MFMAs per fp32 "
+                          "product block); priced on its algorithmic bytes, 2 x blocks + input", "hbm", "lk::gram16_kernel"),
             "gram_conv": ("lk::gram_kernel<MODE_CONV> (+ slab reduce): implicit-im2col A-factor accumulation, "
                           "exact-fp32 MFMA", "mfma", "void lk::gram_kernel<2,"),
             "shiftcorr": ("lk_conv3x3_shiftcorr_f32: shift-correlation A factors", "mfma", "void lk::gram_kernel<3,"),

@@ -128,6 +128,11 @@ int lk_conv3x3_pixpair_accumulate_f32(const float* x, int64_t B, int64_t H, int6
                                       float* blocks, const int32_t* tiles_dev, int64_t n_tiles, void* stream);
 int lk_conv3x3_pixpair_assemble_f32(const float* blocks, const int32_t* slots_dev, int64_t H, int64_t W, int64_t Cin,
                                     float alpha, float* A, void* stream);
+/* _accumulate on a split tensor (csrc/lk_sweep16.hip): x as two fp16 planes with one power-of-two scale (lk_split_f16x2 of
+ * the NHWC images), three fp16 MFMAs per fp32 product block instead of the exact-fp32 MFMA; same tables, same blocks. */
+int lk_conv3x3_pixpair_accumulate_f16x2(const void* x_h, const void* x_l, const int* sexp, int64_t B, int64_t H, int64_t W,
+                                        int64_t Cin, float alpha, float* blocks, const int32_t* tiles_dev, int64_t n_tiles,
+                                        const void* zero16, void* stream);
 
 /* Same result as lk_gram_conv_nhwc_f32 for a 3x3 / stride 1 / padding 1 / dilation 1 convolution, through the
  * shift-correlation identity (the input grid equals the output grid, so the 81 (offset, offset) blocks of the

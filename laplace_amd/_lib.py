@@ -54,6 +54,7 @@ SIGNATURES = {
     "lk_conv3x3_pixpair_plan": (_int, [_i64, _i64, _i64, _vp, _vp, _vp]),
     "lk_conv3x3_pixpair_tables": (_int, [_i64, _i64, _i64, _vp, _vp]),
     "lk_conv3x3_pixpair_accumulate_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _f32, _vp, _vp, _i64, _vp]),
+    "lk_conv3x3_pixpair_accumulate_f16x2": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp, _vp, _i64, _vp, _vp]),
     "lk_conv3x3_pixpair_assemble_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _f32, _vp, _vp]),
     "lk_nchw_to_nhwc_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "lk_absmax_f32": (_int, [_vp, _i64, _vp, _i64, _i64, _vp, _vp]),
@@ -671,6 +672,26 @@ class HipKernels:
                              lambda: self.lib.lk_conv3x3_pixpair_accumulate_f32(
                                  _ptr(xh), B, H, W, Cin, float(alpha), _ptr(blocks), ctypes.c_void_p(tiles.data_ptr()),
                                  tiles.shape[0], self._stream(x.device))), "lk_conv3x3_pixpair_accumulate_f32")
+        return blocks
+
+    #: ``True`` (env LK_PIXPAIR16=1): the pixel-pair products run on the split-fp16 kernel.  Off by default: measured
+    #: equal to the exact-fp32 MFMA kernel (1.40 vs 1.39 ms per c4 step) — the product is bound by the L2 -> LDS traffic of
+    #: its panels (every pixel's panel is loaded 26 times), not by the matrix pipe
+    use_pixpair16 = os.environ.get("LK_PIXPAIR16", "0") != "0"
+
+    def pixpair_accumulate_split(self, xs, alpha, blocks, plan):
+        """:meth:`pixpair_accumulate_nhwc` on a SplitTensor ``xs [B, H, W, Cin]`` (three fp16 MFMAs per product block)."""
+        _check(blocks, "blocks")
+        B, H, W, Cin = xs.shape
+        nb, tiles, _ = plan
+        assert blocks.numel() == nb * Cin * Cin
+        dev = blocks.device
+        z = self._zero16(dev)
+        self._rc(self._timed("pixpair16", 8.0 * blocks.numel() + 4.0 * xs.planes[0].numel(), dev,
+                             lambda: self.lib.lk_conv3x3_pixpair_accumulate_f16x2(
+                                 _ptr(xs.planes[0]), _ptr(xs.planes[1]), _ptr(xs.sexp), B, H, W, Cin, float(alpha), _ptr(blocks),
+                                 ctypes.c_void_p(tiles.data_ptr()), tiles.shape[0], _ptr(z), self._stream(dev))),
+                 "lk_conv3x3_pixpair_accumulate_f16x2")
         return blocks
 
     def pixpair_assemble(self, blocks, plan, H, W, Cin, alpha, A_native):

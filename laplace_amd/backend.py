@@ -637,7 +637,12 @@ class KronAccumulator:
             geo, buf = self._pix[idx]
             xh = pend["stack"][:pend["n"] * pend["B"]]
             cur = torch.cuda.current_stream(xh.device) if xh.is_cuda else None
-            get_kernels().pixpair_accumulate_nhwc(xh, pend["alpha"], buf, geo[4])
+            K = get_kernels()
+            if getattr(K, "use_pixpair16", False) and xh.numel() % 8 == 0:
+                # one split of the stacked images (scale from their measured max), then the fp16 MFMA kernel
+                K.pixpair_accumulate_split(K.split_f16x2(xh), pend["alpha"], buf, geo[4])
+            else:
+                K.pixpair_accumulate_nhwc(xh, pend["alpha"], buf, geo[4])
             if cur is not None:
                 pend["stack"].record_stream(cur)  # filled on the side stream, possibly consumed on another one
         if keep:

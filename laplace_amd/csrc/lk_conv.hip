@@ -958,7 +958,7 @@ static int conv_dispatch(const void* in_h, const void* in_l, const int* in_sexp,
   for (int t = 0; t < T; ++t) g.dh[t] = taps[3 * t], g.dw[t] = taps[3 * t + 1], g.wt[t] = taps[3 * t + 2];
   g.div_hw = make_fastdiv((int)(Hc * Wc)), g.div_w = make_fastdiv((int)Wc), g.div_n = make_fastdiv((int)N);
   // small maps: rows ordered (pixel, image) so that border taps drop out of whole tiles (config bit 15 turns it off)
-  g.pmajor = (Hc * Wc <= 64 && N >= 64 && !(config & 16) && !(config & 32768)) ? 1 : 0;
+  g.pmajor = (Hc * Wc <= (64 << (2 * ((config >> 16) & 3))) && N >= 64 && !(config & 16) && !(config & 32768)) ? 1 : 0;
   g.dense = out_step == 1 && oh0 == 0 && ow0 == 0 && Hc == Ho && Wc == Wo;
   g.out_nchw = (config & 16) ? 1 : 0;
   LK_REQUIRE(!g.out_nchw || (g.dense && (Ho * Wo) % 4 == 0 && !accumulate),
@@ -967,6 +967,7 @@ static int conv_dispatch(const void* in_h, const void* in_l, const int* in_sexp,
   g_ablate = (config >> 8) & 7;
   // "patch" form (A operand resident in LDS across the taps) where the output grid is the input grid
   bool patch = !fz && !(config & 2) && !(config & 16) && in_mul == 1 && Hc == Hi && Wc == Wi && 256 + 2 * Wi + 2 <= 336 && N * Hi * Wi >= 256;
+  if ((config & 262144) && Co > 64) patch = false;  // development switch: the patch form for the 64-channel layers only
   for (int t = 0; t < T && patch; ++t) patch = g.dh[t] >= -1 && g.dh[t] <= 1 && g.dw[t] >= -1 && g.dw[t] <= 1;
   if (patch) {
     g.pmajor = 0;  // the patch form walks raster pixels

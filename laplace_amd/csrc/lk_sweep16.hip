@@ -224,25 +224,46 @@ __device__ __forceinline__ int gram16_swz(int row) {  // XOR on the 64-byte chun
 typedef __attribute__((address_space(3))) void lds_void16;
 typedef __attribute__((address_space(1))) const void gbl_void16;
 
-template <int NB, int BKR, int KW>
+// TNP = true: the "pixel-pair" products of a 3x3 convolution's A factor (lk_conv3x3_pixpair_*, lk_gram.hip): the workgroup
+// takes its two column panels and its output block from a table, runs over ALL rows (the images of a few stacked
+// minibatches) and adds alpha 2^(-2 sexp) X_A^T X_B into the block it alone owns:  blocks[off + r * ldc + c] += ...
+struct Gram16Tnp {
+  const int* tiles;   // [ntiles][3] = column of the A panel, column of the B panel, output offset (floats)
+  int ldc;
+  const int* sexp;
+  float alpha;
+  float* blocks;
+};
+
+template <int NB, int BKR, int KW, bool TNP>
 __global__ __launch_bounds__(256) void gram16_kernel(const _Float16* __restrict__ Xh, const _Float16* __restrict__ Xl,
-                                                     int64_t R, int C, int64_t rows_per_split,
+                                                     int64_t R, int64_t C, int64_t rows_per_split,
                                                      const _Float16* __restrict__ zero16, float* __restrict__ ws,
-                                                     int nbc) {
+                                                     int nbc, const Gram16Tnp tp) {
   using G = Gram16Cfg<NB, BKR, KW>;
   constexpr int TW = G::TW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // block pair (bi <= bj) from the linear index
   int bi = 0, bj = 0;
-  {
+  int64_t colA = 0, colB = 0, out_off = 0;
+  if constexpr (TNP) {
+    // consecutive table entries share their A panel (same pixel, the 13 shifts): give every XCD (block id % 8) a
+    // contiguous range of the table so that the sharing happens inside one L2
+    const int nblk = gridDim.x;
+    int bid = blockIdx.x;
+    const int q = nblk / 8, r = nblk % 8, x = bid % 8, j = bid / 8;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    colA = tp.tiles[3 * bid], colB = tp.tiles[3 * bid + 1], out_off = tp.tiles[3 * bid + 2];
+  } else {
     int p = blockIdx.x;
     while (p >= nbc - bi) p -= nbc - bi, ++bi;
     bj = bi + p;
+    colA = (int64_t)bi * NB, colB = (int64_t)bj * NB;
   }
-  const bool diag = bi == bj;
-  const int64_t r0 = (int64_t)blockIdx.y * rows_per_split;
-  const int64_t r1 = r0 + rows_per_split < R ? r0 + rows_per_split : R;
+  const bool diag = !TNP && bi == bj;
+  const int64_t r0 = TNP ? 0 : (int64_t)blockIdx.y * rows_per_split;
+  const int64_t r1 = TNP ? R : (r0 + rows_per_split < R ? r0 + rows_per_split : R);
   const int nstage = r1 > r0 ? (int)((r1 - r0 + BKR - 1) / BKR) : 0;
 
   // staging context: slot -> (row, physical 16-byte slot); the source is the logical slot of that row
@@ -260,7 +281,7 @@ __global__ __launch_bounds__(256) void gram16_kernel(const _Float16* __restrict_
 #pragma unroll
     for (int pnl = 0; pnl < 2; ++pnl) {
       if (pnl == 1 && diag) break;
-      const int cb = (pnl ? bj : bi) * NB;
+      const int64_t cb = pnl ? colB : colA;
 #pragma unroll
       for (int i = 0; i < G::LD; ++i) {
         const int64_t r = rb + st_row[i];
@@ -343,7 +364,7 @@ __global__ __launch_bounds__(256) void gram16_kernel(const _Float16* __restrict_
   // partial block of this workgroup: ws[(split * npairs + pair)][NB][NB].  KW = 4: the four waves hold partial sums
   // of the SAME tiles (they split k); they are added in wave order through LDS (the stage buffers are free now).
   const int lr = lane & 31, lh = lane >> 5;
-  float* blk = ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (NB * NB);
+  float* blk = TNP ? nullptr : ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (NB * NB);
   if (KW == 4) {
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);  // [wave][tile (a, b)][32 x 32]
@@ -351,7 +372,7 @@ __global__ __launch_bounds__(256) void gram16_kernel(const _Float16* __restrict_
     for (int a = 0; a < TW; ++a)
 #pragma unroll
       for (int b = 0; b < TW; ++b) {
-        if (a > b) continue;
+        if (!TNP && a > b) continue;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -359,16 +380,27 @@ __global__ __launch_bounds__(256) void gram16_kernel(const _Float16* __restrict_
         }
       }
     __syncthreads();
+    float tscale = 0.f;
+    if constexpr (TNP) {
+      const float inv = exp2i16(-tp.sexp[0]);
+      tscale = tp.alpha * inv * inv;
+    }
     for (int e = tid; e < TW * TW * 1024; e += 256) {
       const int t = e >> 10, a = t / TW, b = t % TW;
-      if (a > b) continue;
+      if (!TNP && a > b) continue;
       const float v = ((red[e] + red[TW * TW * 1024 + e]) + red[2 * TW * TW * 1024 + e]) + red[3 * TW * TW * 1024 + e];
       const int row = (e >> 5) & 31, col = e & 31;
-      blk[(a * 32 + row) * NB + b * 32 + col] = v;
+      if constexpr (TNP) tp.blocks[out_off + (int64_t)(a * 32 + row) * tp.ldc + b * 32 + col] += tscale * v;
+      else blk[(a * 32 + row) * NB + b * 32 + col] = v;
     }
     return;
   }
   if (!wave_active) return;
+  float tscale = 0.f;
+  if constexpr (TNP) {
+    const float inv = exp2i16(-tp.sexp[0]);
+    tscale = tp.alpha * inv * inv;
+  }
 #pragma unroll
   for (int a = 0; a < TW; ++a)
 #pragma unroll
@@ -378,7 +410,8 @@ __global__ __launch_bounds__(256) void gram16_kernel(const _Float16* __restrict_
       for (int r = 0; r < 16; ++r) {
         const int row = wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int col = wc * 64 + b * 32 + lr;
-        blk[row * NB + col] = acc[a][b][r];
+        if constexpr (TNP) tp.blocks[out_off + (int64_t)row * tp.ldc + col] += tscale * acc[a][b][r];
+        else blk[row * NB + col] = acc[a][b][r];
       }
     }
 }
@@ -514,12 +547,12 @@ extern "C" int lk_gram_tn_f16x2(const void* x_h, const void* x_l, const int* sex
   dim3 grid((unsigned)p.npairs, (unsigned)p.nsplit);
   if (C == 64) {
     using Gc = Gram16Cfg<64, 64, 4>;
-    hipLaunchKernelGGL((gram16_kernel<64, 64, 4>), grid, dim3(256), 2 * Gc::STAGE, st, (const _Float16*)x_h,
-                       (const _Float16*)x_l, R, (int)C, p.rows_per_split, (const _Float16*)zero16, (float*)ws, p.nbc);
+    hipLaunchKernelGGL((gram16_kernel<64, 64, 4, false>), grid, dim3(256), 2 * Gc::STAGE, st, (const _Float16*)x_h,
+                       (const _Float16*)x_l, R, C, p.rows_per_split, (const _Float16*)zero16, (float*)ws, p.nbc, Gram16Tnp{});
   } else {
     using Gc = Gram16Cfg<128, 32, 1>;
-    hipLaunchKernelGGL((gram16_kernel<128, 32, 1>), grid, dim3(256), 2 * Gc::STAGE, st, (const _Float16*)x_h,
-                       (const _Float16*)x_l, R, (int)C, p.rows_per_split, (const _Float16*)zero16, (float*)ws, p.nbc);
+    hipLaunchKernelGGL((gram16_kernel<128, 32, 1, false>), grid, dim3(256), 2 * Gc::STAGE, st, (const _Float16*)x_h,
+                       (const _Float16*)x_l, R, C, p.rows_per_split, (const _Float16*)zero16, (float*)ws, p.nbc, Gram16Tnp{});
   }
   int rc = check_launch("gram16_kernel");
   if (rc != LK_OK) return rc;
@@ -531,4 +564,31 @@ extern "C" int lk_gram_tn_f16x2(const void* x_h, const void* x_l, const int* sex
     hipLaunchKernelGGL(gram16_reduce_kernel<128>, rgrid, dim3(256), 0, st, (const float*)ws, (int)p.nparts, p.npairs, p.nbc,
                        (int)C, sexp, alpha, Gm);
   return check_launch("gram16_reduce_kernel");
+}
+
+// Pixel-pair blocks of a 3x3 convolution's A factor from a split tensor (see Gram16Tnp): x [B][H][W][Cin] as planes with
+// one scale, tables of lk_conv3x3_pixpair_tables (tile edge 64 for Cin % 128 != 0, else 128).
+extern "C" int lk_conv3x3_pixpair_accumulate_f16x2(const void* x_h, const void* x_l, const int* sexp, int64_t B, int64_t H,
+                                                   int64_t W, int64_t Cin, float alpha, float* blocks,
+                                                   const int32_t* tiles_dev, int64_t n_tiles, const void* zero16,
+                                                   void* stream) {
+  LK_REQUIRE(x_h && x_l && sexp && blocks && tiles_dev && zero16 && B >= 0 && n_tiles >= 0,
+             "lk_conv3x3_pixpair_accumulate_f16x2: bad arguments");
+  LK_REQUIRE(Cin >= 64 && Cin % 64 == 0 && n_tiles < (1ll << 31) && H * W * Cin < (1ll << 31),
+             "lk_conv3x3_pixpair_accumulate_f16x2: needs Cin % 64 == 0");
+  if (B == 0 || n_tiles == 0) return LK_OK;
+  Gram16Tnp tp;
+  tp.tiles = tiles_dev, tp.ldc = (int)Cin, tp.sexp = sexp, tp.alpha = alpha, tp.blocks = blocks;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t ld = H * W * Cin;
+  if (Cin % 128) {
+    using Gc = Gram16Cfg<64, 64, 4>;
+    hipLaunchKernelGGL((gram16_kernel<64, 64, 4, true>), dim3((unsigned)n_tiles), dim3(256), 2 * Gc::STAGE, st,
+                       (const _Float16*)x_h, (const _Float16*)x_l, B, ld, B, (const _Float16*)zero16, (float*)nullptr, 0, tp);
+  } else {
+    using Gc = Gram16Cfg<128, 32, 1>;
+    hipLaunchKernelGGL((gram16_kernel<128, 32, 1, true>), dim3((unsigned)n_tiles), dim3(256), 2 * Gc::STAGE, st,
+                       (const _Float16*)x_h, (const _Float16*)x_l, B, ld, B, (const _Float16*)zero16, (float*)nullptr, 0, tp);
+  }
+  return check_launch("gram16_kernel<pixel pairs>");
 }

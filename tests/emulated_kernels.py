@@ -369,6 +369,11 @@ class EmulatedKernels:
             blk[slot] += alpha * xh[:, q, :].T @ xh[:, q2, :]
         return blocks
 
+    use_pixpair16 = True
+
+    def pixpair_accumulate_split(self, xs, alpha, blocks, plan):
+        return self.pixpair_accumulate_nhwc(xs.float(), alpha, blocks, plan)
+
     def pixpair_assemble(self, blocks, plan, H, W, Cin, alpha, A_native):
         blk = blocks.view(plan[0], Cin, Cin)
         for d in range(9):

@@ -664,6 +664,29 @@ def test_conv3x3_banded_pixel_pair_form(K, B, Cin, H, W):
     assert_close(got, want, what="banded pixel-pair form")
 
 
+@pytest.mark.parametrize("B,Cin,H,W", [(3, 64, 4, 4), (2, 64, 5, 7), (5, 128, 3, 3), (2, 256, 2, 5), (3, 64, 1, 1), (40, 128, 8, 8),
+                                        (130, 64, 3, 2), (72, 64, 6, 6)])
+def test_conv3x3_banded_pixel_pair_form_on_split_tensors(K, B, Cin, H, W):
+    """lk_conv3x3_pixpair_accumulate_f16x2: the same blocks from the split images (fp16 MFMAs), two stacked launches of
+    different scales, == patch Gram of both (fp64)."""
+    if DEV == "cpu":
+        Cin = 8
+    x1, x2 = rnd(B, Cin, H, W, seed=B + Cin + H), 7.5 * rnd(B, Cin, H, W, seed=B + Cin + H + 1)
+    n = 9 * Cin
+    want = torch.zeros(n, n, dtype=torch.float64)
+    for x in (x1, x2):
+        EMU.gram_conv(x, 3, 1, 1, 1, 0.5, want)
+    plan = K.pixpair_plan(H, W, Cin, torch.device(DEV))
+    assert plan is not None
+    blocks = torch.zeros(plan[0] * Cin * Cin, device=DEV)
+    for x in (x1, x2):
+        xs = K.split_f16x2(x.float().to(DEV).permute(0, 2, 3, 1).contiguous())
+        K.pixpair_accumulate_split(xs, 0.5, blocks, plan)
+    nat = K.pixpair_assemble(blocks, plan, H, W, Cin, 1.0, torch.zeros(n, n, device=DEV))
+    got = K.permute_native_to_unfold(nat, Cin, 9, torch.zeros(n, n, device=DEV))
+    assert_close(got, want, 1e-5, what="banded pixel-pair form, split tensors")
+
+
 @pytest.mark.parametrize("shape", [(4, 16, 8, 8), (3, 7, 5, 3), (5, 6), (2, 64, 32, 32), (3, 5, 9)])
 @pytest.mark.parametrize("relu", [True, False])
 @pytest.mark.parametrize("with_addend", [False, True])
