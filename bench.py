@@ -310,6 +310,15 @@ def main():
         roof = dict(fam_out[dominant]) if dominant else {"bound": "mfma", "achieved": 0.0, "peak": PEAK_F32_MFMA_TFLOPS,
                                                           "unit": "TFLOP/s", "frac": 0.0, "traffic": None}
         roof["family"] = dominant
+        if dominant in ("conv16", "gram16"):
+            # what the nominal peak means on this chip (committed probes, same box type): the matrix pipe alone, fed from
+            # registers with this kernel's instruction mix, sustains 0.63-0.78 of 2.5 PFLOP/s; the vendor library's plain
+            # fp16 GEMM reaches 0.43 on 8192^3 and 0.11-0.39 on the GEMM shapes these convolutions reduce to
+            roof["peak_calibration"] = {
+                "sustained_mfma_frac_of_nominal": [0.63, 0.78],
+                "hipblaslt_fp16_gemm_frac_of_nominal": {"8192^3": 0.43, "conv_shapes_c4": [0.11, 0.19, 0.31, 0.39]},
+                "source": "profiles/r02_mfma_peak_probe.txt, profiles/r02_gemm_calib_hipblaslt_fp16.json "
+                          "(tools/probes/mfma_peak_probe.hip, tools/gemm_calib.py)"}
         roof["flop_convention"] = ("convolution: 2 * pixels * Cout * Cin * taps per launch (fp32 multiply-adds of the "
                                    "algorithm); Gram families: symmetric half K*n*(n+1)")
         own_ms = sum(v["ms_per_step"] for v in fam_out.values())

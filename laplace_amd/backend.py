@@ -43,11 +43,13 @@ from laplace_amd.refapi import EFInterface, GGNInterface
 _OWN_ROTATION = os.environ.get("LK_ROT_CONV", "1") != "0"
 
 
-def shared_operands(tap, g, B, C, Q1=None, Q2=None):
+def shared_operands(tap, g, B, C, Q1=None, Q2=None, bounds=None):
     """``u [B, C, Do, L]`` and ``v [B, Dk, L]`` (both position-contiguous) of a weight-sharing layer (Conv2d, or Linear
     along a sequence), whose per-sample Jacobian of output / seed ``c`` is ``sum_l u[n, c, :, l] v[n, :, l]^T``
     (:mod:`laplace_amd.predictive`), rotated into the eigenbases ``Q1`` / ``Q2`` if given; plus the position-summed
-    output gradient ``[C, B, Do]`` for the bias."""
+    output gradient ``[C, B, Do]`` for the bias.  ``bounds``: a dict that receives device words ``u`` / ``v`` with
+    guaranteed bounds of max|u|, max|v| when they are known without another pass over the data (the split-fp16
+    quadratic-form kernel scales its operands by them)."""
     m = tap.module
     a = tap.a.to(torch.float32)
     if tap.kind == "conv2d":
@@ -60,6 +62,11 @@ def shared_operands(tap, g, B, C, Q1=None, Q2=None):
             u = K.unsplit_transpose(g, C, B)                           # [B, C, Do, L]
             L = u.shape[-1]
             gsum = u.sum(-1).permute(1, 0, 2)                          # [C, B, Do]
+            if bounds is not None:
+                # max|g| from the split tensor itself (measured, or 2^(15 - sexp)); an orthonormal rotation of the
+                # Do channels grows the largest element by at most sqrt(Do)
+                ub = g.amax.float() if getattr(g, "amax", None) is not None else torch.exp2(15.0 - g.sexp.float())
+                bounds["u"] = (ub * (math.sqrt(Do) if Q1 is not None else 1.0)).reshape(1).contiguous()
         else:
             g4 = g.reshape(C, B, Do, -1)                               # [C, B, Do, L]
             L = g4.shape[-1]
@@ -75,7 +82,10 @@ def shared_operands(tap, g, B, C, Q1=None, Q2=None):
                     and L % 4 == 0):
                 # our implicit-GEMM convolution (fp32-level products on the fp16 matrix cores), eigenvector filters
                 # kept as split planes per decomposition
-                v = cv.conv_forward_filters(m, a, filt, Q2).reshape(B, Dk, L)
+                vb = torch.zeros(1, dtype=torch.float32, device=a.device) if bounds is not None else None
+                v = cv.conv_forward_filters(m, a, filt, Q2, amax_out=vb).reshape(B, Dk, L)
+                if vb is not None:
+                    bounds["v"] = vb  # measured by the convolution's epilogue
             else:
                 v = F.conv2d(a, filt, None, m.stride, m.padding, m.dilation).reshape(B, Dk, L)
         if Q1 is not None:

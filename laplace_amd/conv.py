@@ -155,13 +155,13 @@ def conv_forward(prep: PreparedConv, x: SplitTensor, out=None, amax_out=None):
     return out
 
 
-def conv_forward_filters(m: nn.Conv2d, a: torch.Tensor, filt: torch.Tensor, key_tensor: torch.Tensor) -> torch.Tensor:
+def conv_forward_filters(m: nn.Conv2d, a: torch.Tensor, filt: torch.Tensor, key_tensor: torch.Tensor, amax_out=None) -> torch.Tensor:
     """``conv2d(a, filt)`` with the geometry of ``m`` and an arbitrary filter bank ``filt [Dk, Cin, kh, kw]`` (the
     eigenvectors of an A factor: the Kron predictive's rotation of the unfolded inputs, matrix.py:406-456) on the
     implicit-GEMM kernel; returns ``[B, Dk, Ho, Wo]`` fp32 with POSITIONS contiguous.  The split planes of the filters
     are cached ON ``key_tensor`` (the eigenvector matrix they were cut from; an attribute of that tensor object, so the
     cache lives exactly as long as the decomposition — a table keyed by address would serve stale planes to the next
-    decomposition allocated at the same place)."""
+    decomposition allocated at the same place).  ``amax_out``: zeroed device word that receives max|result|."""
     K = get_kernels()
     key = (key_tensor._version, tuple(filt.shape))
     hit = getattr(key_tensor, "_lk_filter_planes", None)
@@ -178,6 +178,6 @@ def conv_forward_filters(m: nn.Conv2d, a: torch.Tensor, filt: torch.Tensor, key_
     out = torch.empty(N, Dk, Ho, Wo, dtype=torch.float32, device=a.device)
     taps = [(kh - ph, kw - pw, kh * KW + kw) for kh in range(KH) for kw in range(KW)]
     # config bit 4: position-contiguous output; the wrapper reads shapes off an NHWC-shaped view of the same memory
-    K.conv_nhwc_f16x2(xs, planes, sexp, Ho, Wo, s, out.view(N, Ho, Wo, Dk), 1, 0, 0, taps,
+    K.conv_nhwc_f16x2(xs, planes, sexp, Ho, Wo, s, out.view(N, Ho, Wo, Dk), 1, 0, 0, taps, amax_out=amax_out,
                       config=(K.conv_config | 2 | 16))
     return out

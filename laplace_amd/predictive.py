@@ -134,10 +134,12 @@ def glm_variance_kron(backend, x, post):
                                    None if lb is None else lb.contiguous(),
                                    None if delta_b is None else delta_b.detach().reshape(1).contiguous())
         else:
-            u, v, gsum = _shared_operands(tap, g, B, C, Q1, Q2)
+            bnd = {}
+            u, v, gsum = _shared_operands(tap, g, B, C, Q1, Q2, bounds=bnd)
             l1c, l2c = l1.contiguous(), l2.contiguous()
-            done = _shared_quadform(K, lambda uu, vv, out: K.kron_quadform_shared(uu, vv, l1c, l2c, d1, out), u, v, fvar,
-                                    weight_sharing_only=tap.kind != "conv2d")
+            ub, vb = bnd.get("u"), bnd.get("v")  # both known: the fp16x2 form of the kernel (three MFMAs per block)
+            done = _shared_quadform(K, lambda uu, vv, out: K.kron_quadform_shared(uu, vv, l1c, l2c, d1, out, ub, vb), u, v,
+                                    fvar, weight_sharing_only=tap.kind != "conv2d")
             if done:
                 if Qb is not None:
                     ub = gsum @ Qb
