@@ -279,7 +279,12 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
   const int nstage = ntap * KC;
 
   auto stage = [&](int s, int buf) {
-    const int tj = s / KC, kc = s - tj * KC;
+    // K order: taps major, channel chunks minor.  (The other order — the nine taps of one 32-channel chunk back to back,
+    // so that only a quarter-to-sixteenth-depth window has to survive in L2 between them — was measured: better on the
+    // stride-2 classes, worse on the 64- and 512-channel layers, 10.66 vs 10.50 ms per step; config bit 19 selects it.)
+    int tj, kc;
+    if (ablate & 8) kc = s / ntap, tj = s - kc * ntap;
+    else tj = s / KC, kc = s - tj * KC;
     const int t = (int)((tap_list >> (4 * tj)) & 15ull);
     char* base = smem + buf * CFG::STAGE;
     const int64_t tap_off = ((int64_t)g.dh[t] * g.Wi + g.dw[t]) * g.Ci + kc * BK;
@@ -964,7 +969,7 @@ static int conv_dispatch(const void* in_h, const void* in_l, const int* in_sexp,
   LK_REQUIRE(!g.out_nchw || (g.dense && (Ho * Wo) % 4 == 0 && !accumulate),
              "lk_conv_nhwc_f16x2: position-contiguous output needs a dense grid with Ho*Wo % 4 == 0 and no accumulate");
   hipStream_t st = (hipStream_t)stream;
-  g_ablate = (config >> 8) & 7;
+  g_ablate = ((config >> 8) & 7) | ((config & 524288) ? 8 : 0);  // bit 19: chunk-major K order
   // "patch" form (A operand resident in LDS across the taps) where the output grid is the input grid
   bool patch = !fz && !(config & 2) && !(config & 16) && in_mul == 1 && Hc == Hi && Wc == Wi && 256 + 2 * Wi + 2 <= 336 && N * Hi * Wi >= 256;
   if ((config & 262144) && Co > 64) patch = false;  // development switch: the patch form for the 64-channel layers only
