@@ -61,7 +61,7 @@ def shared_operands(tap, g, B, C, Q1=None, Q2=None, bounds=None):
         if isinstance(g, SplitTensor):      # NHWC split cotangent [C*B, H, W, Do] straight from the sweep: one pass
             u = K.unsplit_transpose(g, C, B)                           # [B, C, Do, L]
             L = u.shape[-1]
-            gsum = u.sum(-1).permute(1, 0, 2)                          # [C, B, Do]
+            gsum = u.sum(-1).permute(1, 0, 2) if tap.has_bias else None  # [C, B, Do]: only a bias block reads it
             if bounds is not None:
                 # max|g| from the split tensor itself (measured, or 2^(15 - sexp)); an orthonormal rotation of the
                 # Do channels grows the largest element by at most sqrt(Do)
@@ -83,7 +83,7 @@ def shared_operands(tap, g, B, C, Q1=None, Q2=None, bounds=None):
                 # our implicit-GEMM convolution (fp32-level products on the fp16 matrix cores), eigenvector filters
                 # kept as split planes per decomposition
                 vb = torch.zeros(1, dtype=torch.float32, device=a.device) if bounds is not None else None
-                v = cv.conv_forward_filters(m, a, filt, Q2, amax_out=vb).reshape(B, Dk, L)
+                v = cv.conv_forward_filters(m, a, filt, Q2, amax_out=vb, xs=getattr(tap, "a_split", None)).reshape(B, Dk, L)
                 if vb is not None:
                     bounds["v"] = vb  # measured by the convolution's epilogue
             else:
@@ -236,6 +236,7 @@ class _HipCurvatureMixin:
             raise NotImplementedError(f"model output must be [batch, outputs]; got {tuple(f.shape)}")
         for t in tape.taps:
             t.a = sweep.taps[t.name]["a"]
+            t.a_split = getattr(sweep, "tap_splits", {}).get(t.name)  # NHWC SplitTensor of the same activation, if any
 
         def grad_fn(seeds, stack=True, on_tap=None, defer_bn_scale=False, keep_split=False):
             """All seeds in one sweep while ``S*B`` stays below ``sweep_max_rows`` images; many-output models

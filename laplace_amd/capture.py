@@ -28,6 +28,7 @@ class Tap:
     w_off: int  # column offset of the weight in the flattened parameter vector
     b_off: int  # column offset of the bias, -1 if the module has no (tracked) bias
     a: torch.Tensor | None = None  # module input (detached)
+    a_split: object | None = None  # the same input as an NHWC SplitTensor, when the forward pass produced one
     out: object | None = None  # gradient edge of the module output in the autograd graph
 
     @property
@@ -134,6 +135,7 @@ class Tape:
     def release(self):
         for t in self.taps:
             t.a = None
+            t.a_split = None
             t.out = None
         sweep = getattr(self, "sweep", None)
         if sweep:

@@ -155,7 +155,8 @@ def conv_forward(prep: PreparedConv, x: SplitTensor, out=None, amax_out=None):
     return out
 
 
-def conv_forward_filters(m: nn.Conv2d, a: torch.Tensor, filt: torch.Tensor, key_tensor: torch.Tensor, amax_out=None) -> torch.Tensor:
+def conv_forward_filters(m: nn.Conv2d, a: torch.Tensor, filt: torch.Tensor, key_tensor: torch.Tensor, amax_out=None,
+                         xs: SplitTensor | None = None) -> torch.Tensor:
     """``conv2d(a, filt)`` with the geometry of ``m`` and an arbitrary filter bank ``filt [Dk, Cin, kh, kw]`` (the
     eigenvectors of an A factor: the Kron predictive's rotation of the unfolded inputs, matrix.py:406-456) on the
     implicit-GEMM kernel; returns ``[B, Dk, Ho, Wo]`` fp32 with POSITIONS contiguous.  The split planes of the filters
@@ -169,8 +170,9 @@ def conv_forward_filters(m: nn.Conv2d, a: torch.Tensor, filt: torch.Tensor, key_
         hit = (key, K.conv_prep_weights(filt.contiguous(), False, None))
         key_tensor._lk_filter_planes = hit
     planes, sexp = hit[1]
-    xh = a.permute(0, 2, 3, 1).contiguous()  # (a view when `a` is NHWC in memory already)
-    xs = K.split_f16x2(xh)
+    if xs is None or tuple(xs.shape) != (a.shape[0], a.shape[2], a.shape[3], a.shape[1]):
+        xh = a.permute(0, 2, 3, 1).contiguous()  # (a view when `a` is NHWC in memory already)
+        xs = K.split_f16x2(xh)               # (``xs``: the split copy the forward pass already made of ``a``)
     N, Hin, Win, _ = xs.shape
     s, (ph, pw), (KH, KW) = m.stride[0], m.padding, m.kernel_size
     Ho, Wo = (Hin + 2 * ph - KH) // s + 1, (Win + 2 * pw - KW) // s + 1

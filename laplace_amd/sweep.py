@@ -537,3 +537,4 @@ class SeedBatchedSweep:
     def release(self):
         self.saved = {}
         self.taps = {}
+        self.tap_splits = {}

@@ -121,6 +121,7 @@ class SplitSweep(SeedBatchedSweep):
     @torch.no_grad()
     def forward(self, x, need_vjp: bool = True):
         self._aux = {}  # data_ptr of a feature map produced here -> {"amax": word} / {"split": SplitTensor, "bound": word}
+        self.tap_splits = {}  # tap name -> NHWC SplitTensor of the tap's input (what its forward convolution consumed)
         self._fwd_words = None
         try:
             return super().forward(x, need_vjp)
@@ -158,6 +159,10 @@ class SplitSweep(SeedBatchedSweep):
         if prep is None:
             prep = self._prep[node.target] = cv.PreparedConv(m)
         xs = self._split_input(inp, pad_to=prep.padded_in if prep.padded_in != m.in_channels else None)
+        if node.target in self.tap_names and prep.padded_in == m.in_channels:
+            # consumers of the tap's input that run our convolution on it again (the Kron predictive's eigenbasis
+            # rotation) take the split copy instead of measuring and splitting the activation a second time
+            self.tap_splits[node.target] = xs
         w = self._fwd_word(inp.device)
         out = cv.conv_forward(prep, xs, amax_out=w)
         if m.bias is not None:
