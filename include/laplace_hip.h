@@ -400,6 +400,11 @@ size_t lk_quadform_shared_workspace_bytes(int64_t B, int64_t C, int64_t Do, int6
 int lk_kron_quadform_shared_f32(const float* u, const float* v, const float* l1, const float* l2, const float* delta,
                                 int64_t B, int64_t C, int64_t Do, int64_t Dk, int64_t L, float* fvar, void* ws,
                                 size_t ws_bytes, void* stream);
+/* lk_kron_quadform_shared_f32 for u stored seed-major, [C][B][Do][L]: what a seed-batched reverse sweep (and the rotation
+ * convolution over its cotangent) leaves in memory — no transposed copy. */
+int lk_kron_quadform_shared_seedmajor_f32(const float* u, const float* v, const float* l1, const float* l2, const float* delta,
+                                          int64_t B, int64_t C, int64_t Do, int64_t Dk, int64_t L, float* fvar, void* ws,
+                                          size_t ws_bytes, void* stream);
 /* lk_kron_quadform_shared_f32 with the products in the two-piece fp16 split (three v_mfma_f32_32x32x16_f16 per product
  * block instead of six bf16 ones): u_bound / v_bound are device words >= max|u|, max|v| from which the kernel derives
  * the power-of-two scales of its in-flight split (loose bounds only cost fixed-point range). */

@@ -99,6 +99,7 @@ SIGNATURES = {
     "lk_diag_quadform_linear_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "lk_quadform_shared_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "lk_kron_quadform_shared_f16x2": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
+    "lk_kron_quadform_shared_seedmajor_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "lk_kron_quadform_shared_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "lk_diag_quadform_shared_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "lk_diag_ggn_shared_workspace_bytes": (_sz, [_i64, _i64, _i64]),
@@ -965,15 +966,26 @@ class HipKernels:
     #: by the in-flight splitting, not by the matrix pipe
     use_quad16 = os.environ.get("LK_QUAD16", "0") != "0"
 
-    def kron_quadform_shared(self, u, v, l1, l2, delta, fvar, u_bound=None, v_bound=None):
-        """``u [B, C, Do, L]``, ``v [B, Dk, L]`` (eigenbasis projections); ``fvar [B, C, C] +=``.  With device words
-        ``u_bound >= max|u|``, ``v_bound >= max|v|`` the products run in the two-piece fp16 split (three MFMAs per
-        block, lk_kron_quadform_shared_f16x2) instead of the three-piece bf16 one (six)."""
+    def kron_quadform_shared(self, u, v, l1, l2, delta, fvar, u_bound=None, v_bound=None, seed_major=False):
+        """``u [B, C, Do, L]`` (``seed_major``: ``[C, B, Do, L]``), ``v [B, Dk, L]`` (eigenbasis projections);
+        ``fvar [B, C, C] +=``.  With device words ``u_bound >= max|u|``, ``v_bound >= max|v|`` the products run in the
+        two-piece fp16 split (three MFMAs per block, lk_kron_quadform_shared_f16x2) instead of the three-piece bf16 one."""
         for t, nm in ((u, "u"), (v, "v"), (l1, "l1"), (l2, "l2"), (delta, "delta"), (fvar, "fvar")):
             _check(t, nm)
-        B, C, Do, L = u.shape
+        if seed_major:
+            C, B, Do, L = u.shape
+        else:
+            B, C, Do, L = u.shape
         Dk = v.shape[1]
         ws = self._workspace(self.lib.lk_quadform_shared_workspace_bytes(B, C, Do, Dk), u.device)
+        if seed_major:
+            self._rc(
+                self._timed("quadconv", 2.0 * B * C * L * Do * Dk, u.device, lambda: self.lib.lk_kron_quadform_shared_seedmajor_f32(
+                    _ptr(u), _ptr(v), _ptr(l1), _ptr(l2), _ptr(delta), B, C, Do, Dk, L, _ptr(fvar), _ptr(ws), ws.numel(),
+                    self._stream(u.device))),
+                "lk_kron_quadform_shared_seedmajor_f32",
+            )
+            return fvar
         if u_bound is not None and v_bound is not None and self.use_quad16:
             _check(u_bound, "u_bound"), _check(v_bound, "v_bound")
             self._rc(

@@ -58,7 +58,18 @@ def shared_operands(tap, g, B, C, Q1=None, Q2=None, bounds=None):
         K = get_kernels()
         Do = m.out_channels
         Dk = m.weight[0].numel()
-        if isinstance(g, SplitTensor):      # NHWC split cotangent [C*B, H, W, Do] straight from the sweep: one pass
+        rotated = False
+        if (isinstance(g, SplitTensor) and Q1 is not None and bounds is not None and not tap.has_bias and _OWN_ROTATION
+                and Do % 32 == 0 and (g.shape[1] * g.shape[2]) % 4 == 0 and C <= K.quadform_shared_max_outputs
+                and hasattr(K, "conv_nhwc_f16x2")):
+            # rotation into the G factor's eigenbasis as a 1x1 convolution over the split cotangent, position-contiguous
+            # output: u stays SEED-major [C, B, Do, L] (the quadratic-form kernel takes it as it is)
+            L = g.shape[1] * g.shape[2]
+            u = cv.rotate_channels(g, Q1, Q1).reshape(C, B, Do, L)
+            gsum = None
+            bounds["u_seed_major"] = True
+            rotated = True
+        elif isinstance(g, SplitTensor):    # NHWC split cotangent [C*B, H, W, Do] straight from the sweep: one pass
             u = K.unsplit_transpose(g, C, B)                           # [B, C, Do, L]
             L = u.shape[-1]
             gsum = u.sum(-1).permute(1, 0, 2) if tap.has_bias else None  # [C, B, Do]: only a bias block reads it
@@ -78,7 +89,7 @@ def shared_operands(tap, g, B, C, Q1=None, Q2=None, bounds=None):
             # unfolded patches (x) Q2 = one convolution whose filters are the eigenvectors (rows of the A factor
             # follow F.unfold's (c_in, kh, kw) order = the weight layout); its position-contiguous output IS [B, Dk, L]
             filt = Q2.T.reshape(Dk, *m.weight.shape[1:])
-            if (_OWN_ROTATION and hasattr(K, "conv_nhwc_f16x2") and a.is_cuda and cv._geometry_ok(m) and m.in_channels % 32 == 0 and Dk % 8 == 0
+            if (_OWN_ROTATION and hasattr(K, "conv_nhwc_f16x2") and cv._geometry_ok(m) and m.in_channels % 32 == 0 and Dk % 8 == 0
                     and L % 4 == 0):
                 # our implicit-GEMM convolution (fp32-level products on the fp16 matrix cores), eigenvector filters
                 # kept as split planes per decomposition
@@ -88,7 +99,7 @@ def shared_operands(tap, g, B, C, Q1=None, Q2=None, bounds=None):
                     bounds["v"] = vb  # measured by the convolution's epilogue
             else:
                 v = F.conv2d(a, filt, None, m.stride, m.padding, m.dilation).reshape(B, Dk, L)
-        if Q1 is not None:
+        if Q1 is not None and not rotated:
             u = torch.matmul(Q1.T, u)
     else:                                                              # Linear over [B, ..., Di]
         Do = m.out_features

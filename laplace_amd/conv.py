@@ -183,3 +183,21 @@ def conv_forward_filters(m: nn.Conv2d, a: torch.Tensor, filt: torch.Tensor, key_
     K.conv_nhwc_f16x2(xs, planes, sexp, Ho, Wo, s, out.view(N, Ho, Wo, Dk), 1, 0, 0, taps, amax_out=amax_out,
                       config=(K.conv_config | 2 | 16))
     return out
+
+
+def rotate_channels(g: SplitTensor, Q: torch.Tensor, key_tensor: torch.Tensor) -> torch.Tensor:
+    """``out[n, :, p] = Q^T g[n, p, :]`` for an NHWC split tensor ``g [N, H, W, C]`` and a square ``Q [C, C]`` — the Kron
+    predictive's rotation of the output cotangents into a G factor's eigenbasis (matrix.py:406-456) — as a 1x1
+    convolution on the implicit-GEMM kernel with POSITION-contiguous output ``[N, C, H*W]`` fp32: what the quadratic-form
+    kernel reads, without the un-split / transpose copy and the library GEMM.  Filter planes cached on ``key_tensor``."""
+    K = get_kernels()
+    N, H, W, C = g.shape
+    key = (key_tensor._version, "rot", C)
+    hit = getattr(key_tensor, "_lk_rot_planes", None)
+    if hit is None or hit[0] != key:
+        hit = (key, K.conv_prep_weights(Q.T.reshape(C, C, 1, 1).contiguous(), False, None))
+        key_tensor._lk_rot_planes = hit
+    planes, sexp = hit[1]
+    out = torch.empty(N, C, H * W, dtype=torch.float32, device=g.planes.device)
+    K.conv_nhwc_f16x2(g, planes, sexp, H, W, 1, out.view(N, H, W, C), 1, 0, 0, [(0, 0, 0)], config=(K.conv_config | 2 | 16))
+    return out

@@ -23,9 +23,10 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct QcOperands {  // one tile's operands: sample base pointers, first row, this lane's column
-  const float* un;   // u[n]: [C][Do][L]
+  const float* un;   // u[n]: [C][Do][L] with the outputs `cs` elements apart (Do * L when u is sample-major)
   const float* vn;   // v[n]: [Dk][L]
   int o0, icol;
+  unsigned cs;
 };
 
 // LDS arena of one workgroup, reinterpreted by the two tile products below
@@ -56,7 +57,7 @@ __device__ __forceinline__ void qc_tile_gemm(const QcOperands& t, int C, int Do,
       const int e = tid + 256 * j, o = e & 31, ll = (e >> 5) & (QC_KC - 1), c = e >> 9;
       const bool ok = c < C && l0 + ll < L && t.o0 + o < Do;
       // 32-bit offsets from the sample's (uniform) base pointer: the host checks C*L*Do and L*Dk < 2^29
-      ra[j] = ok ? t.un[(unsigned)((c * Do + t.o0 + o) * L + l0 + ll)] : 0.f;
+      ra[j] = ok ? t.un[(unsigned)(c * t.cs + (t.o0 + o) * L + l0 + ll)] : 0.f;
     }
 #pragma unroll
     for (int kk = 0; kk < QC_KC / 2; ++kk) {
@@ -131,7 +132,7 @@ __device__ __forceinline__ void qc_fetch_b6(QcStage<CT>& st, int j_lo, int j_hi,
 #pragma unroll
   for (int j = j_lo; j < j_hi; ++j) {
     const bool ok = t.o0 + o < Do && c0 + 2 * j < C && l0 + k4 < L;
-    const unsigned off = ok ? (unsigned)(((c0 + 2 * j) * Do + t.o0 + o) * L + l0 + k4) : 0u;
+    const unsigned off = ok ? (unsigned)((c0 + 2 * j) * t.cs + (t.o0 + o) * L + l0 + k4) : 0u;
     st.ra[j] = *reinterpret_cast<const f32x4*>(t.un + off);
   }
 #pragma unroll
@@ -335,7 +336,8 @@ __global__ __launch_bounds__(256) void quadform_conv_kernel(const float* __restr
                                                             const float* __restrict__ delta, int C, int Do, int Dk, int L,
                                                             int split, float* __restrict__ partial,
                                                             const float* __restrict__ u_bound,
-                                                            const float* __restrict__ v_bound) {
+                                                            const float* __restrict__ v_bound, int64_t u_sample_stride,
+                                                            unsigned u_class_stride) {
   constexpr bool B6 = ARITH != 0;
   float sc_u = 1.f, sc_v = 1.f, un_u = 1.f, un_v = 1.f;
   if constexpr (ARITH == 2) {
@@ -348,7 +350,7 @@ __global__ __launch_bounds__(256) void quadform_conv_kernel(const float* __restr
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
   const int n = blockIdx.x / split, sp = blockIdx.x % split;
   const int nOt = (Do + 31) / 32, nIg = (Dk + 127) / 128, ntiles = nOt * nIg;
-  const float* __restrict__ un = u + (size_t)n * C * Do * L;
+  const float* __restrict__ un = u + (size_t)n * u_sample_stride;
   const float* __restrict__ vn = v + (size_t)n * Dk * L;
   const float dlt = MODE == 0 ? delta[0] : 0.f;
 
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(256) void quadform_conv_kernel(const float* __restr
 #pragma unroll
   for (int p = 0; p < NP; ++p) pair[p] = 0.f;
 
-  auto operands = [&](int t) { return QcOperands{un, vn, (t % nOt) * 32, (t / nOt) * 128 + wave * 32 + lo}; };
+  auto operands = [&](int t) { return QcOperands{un, vn, (t % nOt) * 32, (t / nOt) * 128 + wave * 32 + lo, u_class_stride}; };
   QcStage<CT> st;
   if (B6 && sp < ntiles) qc_fetch_b6<CT>(st, 0, (CT + 1) / 2, 0, 2, operands(sp), 0, C, Do, Dk, L);
   for (int t = sp; t < ntiles; t += split) {
@@ -451,7 +453,7 @@ __global__ __launch_bounds__(256) void diag_ggn_shared_kernel(const float* __res
   float hacc[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) hacc[r] = 0.f;
-  auto operands = [&](int n) { return QcOperands{u + (size_t)n * C * Do * L, v + (size_t)n * Dk * L, o0, icol}; };
+  auto operands = [&](int n) { return QcOperands{u + (size_t)n * C * Do * L, v + (size_t)n * Dk * L, o0, icol, (unsigned)(Do * L)}; };
   QcStage<CT> st;
   if (B6 && sp < B) qc_fetch_b6<CT>(st, 0, (CT + 1) / 2, 0, 2, operands(sp), 0, C, Do, Dk, L);
   for (int n = sp; n < B; n += nsplit) {
@@ -519,7 +521,10 @@ template <int MODE>
 static int launch_quadform_conv(const float* u, const float* v, const float* w0, const float* w1, const float* delta,
                                 int64_t B, int64_t C, int64_t Do, int64_t Dk, int64_t L, float* fvar, void* ws,
                                 size_t ws_bytes, hipStream_t stream, const char* what, const float* u_bound = nullptr,
-                                const float* v_bound = nullptr) {
+                                const float* v_bound = nullptr, bool seed_major = false) {
+  // u is [B][C][Do][L] (sample-major) or, seed_major, [C][B][Do][L] (how a seed-batched sweep leaves it)
+  const int64_t uss = seed_major ? Do * L : C * Do * L;
+  const unsigned ucs = (unsigned)(seed_major ? B * Do * L : Do * L);
   const int ct = qc_class_tile(C);
   if (ct == 0) {
     set_error("%s: more than 10 outputs are not supported by the fused kernel", what);
@@ -539,13 +544,13 @@ static int launch_quadform_conv(const float* u, const float* v, const float* w0,
   case CT:                                                                                                          \
     if (h3)                                                                                                         \
       hipLaunchKernelGGL((quadform_conv_kernel<CT, 0, 2>), grid, dim3(256), 0, stream, u, v, w0, w1, delta,         \
-                         (int)C, (int)Do, (int)Dk, (int)L, split, partial, u_bound, v_bound);                       \
+                         (int)C, (int)Do, (int)Dk, (int)L, split, partial, u_bound, v_bound, uss, ucs);                       \
     else if (v4)                                                                                                    \
       hipLaunchKernelGGL((quadform_conv_kernel<CT, MODE, 1>), grid, dim3(256), 0, stream, u, v, w0, w1, delta,      \
-                         (int)C, (int)Do, (int)Dk, (int)L, split, partial, nullptr, nullptr);                       \
+                         (int)C, (int)Do, (int)Dk, (int)L, split, partial, nullptr, nullptr, uss, ucs);             \
     else                                                                                                            \
       hipLaunchKernelGGL((quadform_conv_kernel<CT, MODE, 0>), grid, dim3(256), 0, stream, u, v, w0, w1, delta,      \
-                         (int)C, (int)Do, (int)Dk, (int)L, split, partial, nullptr, nullptr);                       \
+                         (int)C, (int)Do, (int)Dk, (int)L, split, partial, nullptr, nullptr, uss, ucs);             \
     break;
   switch (ct) {
     LK_QC_CASE(1)
@@ -588,6 +593,19 @@ extern "C" int lk_kron_quadform_shared_f16x2(const float* u, const float* v, con
              "lk_kron_quadform_shared_f16x2: sizes out of range");
   return launch_quadform_conv<0>(u, v, l1, l2, delta, B, C, Do, Dk, L, fvar, ws, ws_bytes, (hipStream_t)stream,
                                  "lk_kron_quadform_shared_f16x2", u_bound, v_bound);
+}
+
+// lk_kron_quadform_shared_f32 for u stored SEED-major, [C][B][Do][L] — what one seed-batched reverse sweep (and the
+// position-contiguous output of the rotation convolution over it) leaves in memory: no transposed copy is needed.
+extern "C" int lk_kron_quadform_shared_seedmajor_f32(const float* u, const float* v, const float* l1, const float* l2,
+                                                     const float* delta, int64_t B, int64_t C, int64_t Do, int64_t Dk,
+                                                     int64_t L, float* fvar, void* ws, size_t ws_bytes, void* stream) {
+  LK_REQUIRE(u && v && l1 && l2 && delta && fvar && B >= 0 && C >= 1 && Do >= 1 && Dk >= 1 && L >= 1,
+             "lk_kron_quadform_shared_seedmajor_f32: bad arguments");
+  LK_REQUIRE(B * 64 < (1ll << 31) && C * B * L * Do < (1ll << 31) && L * Dk < (1ll << 29),
+             "lk_kron_quadform_shared_seedmajor_f32: sizes out of range");
+  return launch_quadform_conv<0>(u, v, l1, l2, delta, B, C, Do, Dk, L, fvar, ws, ws_bytes, (hipStream_t)stream,
+                                 "lk_kron_quadform_shared_seedmajor_f32", nullptr, nullptr, true);
 }
 
 extern "C" int lk_diag_quadform_shared_f32(const float* u, const float* v, const float* var_w, int64_t B, int64_t C,

@@ -97,6 +97,12 @@ class EmulatedKernels:
             xt = xin[:, hh.clamp(0, Hi - 1)][:, :, ww.clamp(0, Wi - 1)]
             xt = xt * (vh[:, None] & vw[None, :])[None, :, :, None]
             res += torch.einsum("nijc,oc->nijo", xt, w[wt])
+        if config is not None and (config & 16):  # position-contiguous output: `out` is an NHWC-shaped view of [N, Co, Hc*Wc]
+            assert not accumulate and out_step == 1 and oh0 == 0 and ow0 == 0 and out.is_contiguous()
+            out.view(N, w.shape[1], Hc, Wc).copy_(res.permute(0, 3, 1, 2))
+            if amax_out is not None:
+                amax_out.copy_(torch.maximum(amax_out, res.abs().max().reshape(1)))
+            return out
         view = out[:, oh0::out_step, ow0::out_step][:, :Hc, :Wc]
         if accumulate:
             view += res
@@ -418,7 +424,9 @@ class EmulatedKernels:
 
     quadform_shared_max_outputs = 10
 
-    def kron_quadform_shared(self, u, v, l1, l2, delta, fvar, u_bound=None, v_bound=None):
+    def kron_quadform_shared(self, u, v, l1, l2, delta, fvar, u_bound=None, v_bound=None, seed_major=False):
+        if seed_major:
+            u = u.permute(1, 0, 2, 3)
         assert u.shape[1] <= self.quadform_shared_max_outputs, "the HIP kernel holds at most 10 outputs"
         if u_bound is not None and v_bound is not None:  # the fp16x2 form relies on these being bounds
             assert float(u.abs().max()) <= float(u_bound[0]) * (1 + 1e-6) + 1e-30, "u_bound does not bound u"

@@ -128,3 +128,44 @@ def test_unsupported_graphs_fall_back_to_the_parent_sweep():
     _, want = _autograd_tap_grads(model, taps, x, seeds)
     for n in taps:
         assert torch.allclose(got[n], want[n], atol=1e-5)
+
+
+def test_kron_predictive_through_the_nhwc_rotations():
+    """Full-network KFAC posterior of the tiny ResNet: the GLM predictive with both eigenbasis rotations on our
+    convolution kernel (inputs: the forward's split activations; cotangents: a 1x1 convolution whose position-contiguous
+    output stays seed-major for the quadratic-form kernel) == the same with library rotations and the transposed copy."""
+    import laplace_amd.backend as be
+    from laplace_amd.laplace import HipLaplace
+
+    model = _model(torch.relu)
+    torch.manual_seed(1)
+    X, y = torch.randn(12, 3, 8, 8), torch.randint(5, (12,))
+    la = HipLaplace(model, "classification", "all", "kron", prior_precision=0.7)
+
+    class L(list):
+        dataset = list(range(12))
+
+    la.fit(L([(X[:6], y[:6]), (X[6:], y[6:])]))
+    K = get_kernels()
+    seen = {"seed_major": 0, "other": 0}
+    orig = K.kron_quadform_shared
+
+    def counting(*a, seed_major=False, **k):
+        seen["seed_major" if seed_major else "other"] += 1
+        return orig(*a, seed_major=seed_major, **k)
+
+    K.kron_quadform_shared = counting
+    try:
+        f1, v1 = la._glm_predictive_distribution(X[:5])
+        n_fast = dict(seen)
+        prev = be._OWN_ROTATION
+        be._OWN_ROTATION = False
+        try:
+            f2, v2 = la._glm_predictive_distribution(X[:5])
+        finally:
+            be._OWN_ROTATION = prev
+    finally:
+        del K.kron_quadform_shared
+    assert n_fast["seed_major"] >= 6, n_fast  # every 32- / 64-channel convolution of the three blocks
+    assert torch.allclose(f1, f2, atol=1e-6)
+    assert (v1 - v2).abs().max() / v2.abs().max() < 2e-5

@@ -1,0 +1,6 @@
+cd $GRAFT_REPO_ROOT
+timeout 600 python -m pytest tests/test_gpu_kernels.py -x -q -k "quadform" 2>&1 | tail -2
+timeout 900 python -m pytest tests/test_gpu_baseline_parity.py -x -q -k "c4" 2>&1 | tail -2
+timeout 900 python -m pytest tests/test_gpu_fullsize.py -x -q -k "c4" 2>&1 | tail -2
+for i in 1 2; do timeout 300 python tools/kron_predictive_c4.py 2>&1 | tail -1 | cut -c1-300; done
+LK_ROT_CONV=0 timeout 300 python tools/kron_predictive_c4.py 2>&1 | tail -1 | cut -c1-300
