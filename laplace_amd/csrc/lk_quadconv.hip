@@ -348,7 +348,13 @@ __global__ __launch_bounds__(256) void quadform_conv_kernel(const float* __restr
   __shared__ __attribute__((aligned(16))) char lds[QcLds<CT>::BYTES];
   __shared__ float sR[4][NP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
-  const int n = blockIdx.x / split, sp = blockIdx.x % split;
+  // XCD-aware: consecutive block ids run on different XCDs (id % 8); the workgroups of one sample re-read the same
+  // u[n], v[n] tile after tile, so they are all given to ONE XCD (its L2 then holds the sample's operands)
+  int n = blockIdx.x / split, sp = blockIdx.x % split;
+  if (gridDim.x % (8 * split) == 0) {
+    const int xcd = blockIdx.x % 8, j = blockIdx.x / 8;
+    n = xcd + 8 * (j / split), sp = j % split;
+  }
   const int nOt = (Do + 31) / 32, nIg = (Dk + 127) / 128, ntiles = nOt * nIg;
   const float* __restrict__ un = u + (size_t)n * u_sample_stride;
   const float* __restrict__ vn = v + (size_t)n * Dk * L;
@@ -413,7 +419,7 @@ __global__ __launch_bounds__(256) void quadform_conv_kernel(const float* __restr
     if (lane == 0) sR[wave][p] = s;
   }
   __syncthreads();
-  if (tid < NP) partial[(size_t)blockIdx.x * NP + tid] = (sR[0][tid] + sR[1][tid]) + (sR[2][tid] + sR[3][tid]);
+  if (tid < NP) partial[((size_t)n * split + sp) * NP + tid] = (sR[0][tid] + sR[1][tid]) + (sR[2][tid] + sR[3][tid]);
 }
 
 // fvar[n][c][k] (and [k][c]) += sum over the workgroups of sample n, in fixed order
