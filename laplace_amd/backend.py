@@ -483,7 +483,14 @@ class _HipCurvatureMixin:
                     "KFAC supports nn.Linear / nn.Conv2d parameters only (as the reference, docs/index.md:364-366); "
                     "freeze the others (requires_grad=False)") from e
             raise
+        if self.lazy_kron:
+            # the minibatch stays in the accumulator's raw form inside the returned Kron: `H += ` merges raw forms, the
+            # symmetrise / permute into the public layout runs once, when somebody reads `kfacs`
+            return acc.loss[0].clone(), HipKron(None, pending=acc)
         return acc.finalize()
+
+    #: ``False`` (env LK_LAZY_KRON=0): ``kron`` returns its minibatch already in the reference's layout
+    lazy_kron = os.environ.get("LK_LAZY_KRON", "1") != "0"
 
     def _diag_impl(self, x, y, seeds_fn, alpha):
         K = get_kernels()
@@ -796,6 +803,46 @@ class KronAccumulator:
             cur = (torch.zeros(need, dtype=torch.uint8, device=g.device), Do, L, alpha)
             self._gslabs[idx] = cur
         return cur[0]
+
+    # ---- raw-form algebra (HipKron keeps the minibatches of the reference's literal loop in this form) --------------------
+    def _raw_tensors(self):
+        return [t for F in self.factors for t in F] + [self.loss]
+
+    def _raw_compatible(self, other) -> bool:
+        return (self.factors is not None and other.factors is not None and not self._pix and not other._pix
+                and not self._pix_pending and not other._pix_pending and not self._gslabs and not other._gslabs
+                and self.N == other.N and self.kfac_approx == other.kfac_approx and self.backend is other.backend
+                and self._taps_meta == other._taps_meta and len(self.factors) == len(other.factors)
+                and all(a.shape == b.shape for a, b in zip(self._raw_tensors(), other._raw_tensors()))
+                and set(self._gscale) == set(other._gscale)
+                and all(self._gscale[k] is other._gscale[k] or torch.equal(self._gscale[k], other._gscale[k])
+                        for k in self._gscale))
+
+    def clone(self) -> "KronAccumulator":
+        """an independent copy of the accumulated state (factors in the accumulator's raw form)"""
+        self._join_side()
+        new = KronAccumulator(self.backend, self.N, self.kfac_approx, self.overlap)
+        new.use_pixgram, new._persist_slabs = self.use_pixgram, self._persist_slabs
+        if self.factors is not None:
+            if self._pix or self._pix_pending or self._gslabs:
+                raise RuntimeError("clone() of an accumulator with pixel-pair / slab state is not supported")
+            new.factors = [[t.clone() for t in F] for F in self.factors]
+            new.loss = self.loss.clone()
+            new._taps_meta = list(self._taps_meta)
+            new._gscale = dict(self._gscale)
+            new._tap_index = dict(self._tap_index)
+            new._pix, new._pix_pending, new._gslabs = {}, {}, {}
+            new._side = self._side
+        return new
+
+    def merge_(self, other: "KronAccumulator") -> bool:
+        """``self += other`` on the raw forms (one multi-tensor add); False if the two do not have the same structure"""
+        if not self._raw_compatible(other):
+            return False
+        self._join_side()
+        other._join_side()
+        torch._foreach_add_(self._raw_tensors(), other._raw_tensors())
+        return True
 
     def _join_side(self):
         """the calling stream waits for everything the factor kernels have been asked to do so far"""

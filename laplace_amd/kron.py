@@ -55,8 +55,47 @@ def _side_streams(dev, n: int):
 class HipKron(_KronBase):
     """Kronecker-factored curvature: ``kfacs[i]`` is ``[G, A]`` (weight) or ``[B]`` (bias)."""
 
-    def __init__(self, kfacs):
-        self.kfacs = kfacs
+    def __init__(self, kfacs, pending=None):
+        #: ``pending``: a :class:`laplace_amd.backend.KronAccumulator` holding minibatches in the accumulator's raw form
+        #: (upper triangles, native column order, deferred scales).  ``backend.kron`` hands its minibatch over like this,
+        #: ``+=`` merges raw forms with one multi-tensor add, and the symmetrise / permute into the public layout
+        #: happens ONCE, the first time ``kfacs`` is read (decompose, state_dict, any of the Kron algebra) — so the
+        #: reference's literal loop ``self.H += backend.kron(X, y, N)`` (baselaplace.py:969-985) does per minibatch what
+        #: the fused accumulator does, plus one add.
+        self._kfacs = kfacs
+        self._pending = pending
+
+    @property
+    def kfacs(self):
+        if self._pending is not None:
+            self._materialize()
+        return self._kfacs
+
+    @kfacs.setter
+    def kfacs(self, value):
+        self._kfacs = value
+        self._pending = None
+
+    def _materialize(self):
+        acc, self._pending = self._pending, None
+        fresh = acc.finalize()[1]._kfacs
+        if self._kfacs is None:
+            self._kfacs = fresh
+        else:
+            for Fi, Fj in zip(self._kfacs, fresh):
+                for Hi, Hj in zip(Fi, Fj):
+                    Hi.add_(Hj)
+
+    def _absorb(self, other: "HipKron") -> bool:
+        """fold ``other``'s raw minibatches into this object's without touching ``other``; False if ``other`` has none"""
+        acc = other._pending
+        if acc is None:
+            return False
+        if self._pending is None:
+            self._pending = acc.clone()
+        elif not self._pending.merge_(acc):  # different structure (cannot happen for one model): go through the layout
+            return False
+        return True
 
     @classmethod
     def init_from_model(cls, model: nn.Module | Iterable[nn.Parameter], device, dtype) -> "HipKron":
@@ -76,15 +115,44 @@ class HipKron(_KronBase):
 
     # -- accumulation (matrix.py:79-118) ---------------------------------------------------------
     def __add__(self, other):
-        if not isinstance(other, _KronBase) or not hasattr(other, "kfacs"):
+        if not isinstance(other, _KronBase) or not (isinstance(other, HipKron) or hasattr(other, "kfacs")):
             raise ValueError("Can only add Kron to Kron.")
+        if self._pending is not None or getattr(other, "_pending", None) is not None:
+            # keep raw minibatches raw: raw parts are merged (copies: neither operand changes), public-layout parts summed
+            out, ok = HipKron(None), True
+            for part in (self, other):
+                pend, plain = (part._pending, part._kfacs) if isinstance(part, HipKron) else (None, part.kfacs)
+                if pend is not None:
+                    if out._pending is None:
+                        out._pending = pend.clone()
+                    elif not out._pending.merge_(pend):
+                        ok = False
+                        break
+                if plain is not None:
+                    if out._kfacs is None:
+                        out._kfacs = [[Hi.clone() for Hi in F] for F in plain]
+                    else:
+                        for Fi, Fj in zip(out._kfacs, plain):
+                            for Hi, Hj in zip(Fi, Fj):
+                                Hi.add_(Hj)
+            if ok:
+                return out
         return HipKron([[Hi.add(Hj) for Hi, Hj in zip(Fi, Fj)] for Fi, Fj in zip(self.kfacs, other.kfacs)])
 
     __radd__ = __add__
 
     def __iadd__(self, other):
-        if not isinstance(other, _KronBase) or not hasattr(other, "kfacs"):
+        if not isinstance(other, _KronBase) or not (isinstance(other, HipKron) or hasattr(other, "kfacs")):
             raise ValueError("Can only add Kron to Kron.")
+        if isinstance(other, HipKron) and other._pending is not None and self._absorb(other):
+            if other._kfacs is not None:  # (a lazily summed Kron that also carries a public-layout part)
+                if self._kfacs is None:
+                    self._kfacs = [[Hi.clone() for Hi in F] for F in other._kfacs]
+                else:
+                    for Fi, Fj in zip(self._kfacs, other._kfacs):
+                        for Hi, Hj in zip(Fi, Fj):
+                            Hi.add_(Hj)
+            return self
         for Fi, Fj in zip(self.kfacs, other.kfacs):
             for Hi, Hj in zip(Fi, Fj):
                 Hi.add_(Hj)

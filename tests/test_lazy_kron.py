@@ -1,0 +1,67 @@
+"""``backend.kron`` hands its minibatch over in the accumulator's raw form (laplace_amd/kron.py: HipKron._pending): the
+algebra of the reference's literal fit loop — ``H = Kron.init_from_model(..)``, ``H += backend.kron(X, y, N)[1]`` per
+minibatch (laplace/baselaplace.py:969-985) — must give what the eager, public-layout objects give, and must not change
+its operands.  CPU emulation of the kernels (the host logic is what is under test)."""
+import pytest
+import torch
+
+from laplace_amd import _lib
+from tests.conftest import golden_model, load_golden
+from tests.emulated_kernels import EmulatedKernels
+
+
+@pytest.fixture(autouse=True)
+def _emulated():
+    prev = _lib.set_kernels_for_testing(EmulatedKernels())
+    yield
+    _lib.set_kernels_for_testing(prev)
+
+
+def _flat(K):
+    return [t.clone() for F in K.kfacs for t in F]
+
+
+def _close(a, b, tol=1e-6):
+    return all((x - y).abs().max() <= tol * (y.abs().max() + 1e-30) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("name", ["conv", "bnres", "mlp"])
+def test_lazy_minibatch_krons_equal_the_eager_ones(name):
+    from laplace_amd import HipGGN, HipKron
+
+    g = load_golden(name, "classification")
+    model, X, y = golden_model(name, g, dtype=torch.float32)
+    N = X.shape[0]
+    eager = HipGGN(model, "classification")
+    eager.lazy_kron = False
+    lazy = HipGGN(model, "classification")
+    assert lazy.lazy_kron
+    parts = [slice(0, 4), slice(4, 7), slice(7, 10)]
+    want = [_flat(eager.kron(X[s], y[s], N)[1]) for s in parts]
+    total = [sum(w[i] for w in want) for i in range(len(want[0]))]
+
+    ks = [lazy.kron(X[s], y[s], N) for s in parts]
+    assert all(k._pending is not None for _, k in ks), "kron() should hand over the raw form"
+    for (loss, _), s in zip(ks, parts):
+        assert torch.allclose(loss, eager.kron(X[s], y[s], N)[0], rtol=1e-6)
+    # out-of-place sum: operands untouched, result right
+    s01 = ks[0][1] + ks[1][1]
+    assert ks[0][1]._pending is not None and ks[1][1]._pending is not None
+    assert _close(_flat(s01), [a + b for a, b in zip(want[0], want[1])])
+    assert _close(_flat(ks[0][1]), want[0]) and _close(_flat(ks[1][1]), want[1])
+    # the literal loop, starting from zeros in the public layout
+    params = [p for p in model.parameters() if p.requires_grad]
+    H = HipKron.init_from_model(params, X.device, torch.float32)
+    for s in parts:
+        H += lazy.kron(X[s], y[s], N)[1]
+    assert H._pending is not None, "nothing should have been brought into the public layout yet"
+    assert _close(_flat(H), total)
+    assert H._pending is None
+    # mixing: a materialised Kron plus a raw one, both orders; scalar multiplication reads the public layout
+    k_raw = lazy.kron(X[parts[2]], y[parts[2]], N)[1]
+    assert _close(_flat(s01 + k_raw), total) and _close(_flat(k_raw + s01), total)
+    doubled = k_raw * 2.0
+    for F2, F1 in zip(doubled.kfacs, k_raw.kfacs):
+        for t2, t1 in zip(F2, F1):
+            assert torch.allclose(t2, 2.0 ** (1 / len(F1)) * t1)
+    assert len(k_raw) == len(k_raw.kfacs)
