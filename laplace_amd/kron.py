@@ -76,6 +76,12 @@ class HipKron(_KronBase):
         self._kfacs = value
         self._pending = None
 
+    def __getstate__(self):  # pickling / deepcopy see the public layout only (the raw form holds streams and the backend)
+        return {"kfacs": self.kfacs}
+
+    def __setstate__(self, state):
+        self._kfacs, self._pending = state["kfacs"], None
+
     def _materialize(self):
         acc, self._pending = self._pending, None
         fresh = acc.finalize()[1]._kfacs

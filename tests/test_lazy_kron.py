@@ -65,3 +65,19 @@ def test_lazy_minibatch_krons_equal_the_eager_ones(name):
         for t2, t1 in zip(F2, F1):
             assert torch.allclose(t2, 2.0 ** (1 / len(F1)) * t1)
     assert len(k_raw) == len(k_raw.kfacs)
+
+
+def test_lazy_kron_survives_deepcopy_and_pickle():
+    import copy
+    import pickle
+
+    from laplace_amd import HipGGN
+
+    g = load_golden("conv", "classification")
+    model, X, y = golden_model("conv", g, dtype=torch.float32)
+    k = HipGGN(model, "classification").kron(X[:5], y[:5], X.shape[0])[1]
+    assert k._pending is not None
+    c = copy.deepcopy(k)
+    p = pickle.loads(pickle.dumps(k))
+    for other in (c, p):
+        assert other._pending is None and _close(_flat(other), _flat(k), 0.0)
