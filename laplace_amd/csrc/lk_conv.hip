@@ -206,6 +206,12 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
     bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
   }
   const int tile_n = bid / nb_m, tile_m = bid % nb_m;
+  if ((ablate & 16) && blockIdx.x >= 256 && blockIdx.x < 512) {
+    // (experiment) the two workgroups of a CU run equal tiles in lockstep and reach their epilogues together; delaying
+    // the second resident workgroup of every CU by part of a tile time staggers them for the whole launch
+    __builtin_amdgcn_s_sleep(127);
+    __builtin_amdgcn_s_sleep(127);
+  }
   const int M = g.N * g.Hc * g.Wc;
   const int KC = g.Ci / BK;
 
@@ -969,7 +975,7 @@ static int conv_dispatch(const void* in_h, const void* in_l, const int* in_sexp,
   LK_REQUIRE(!g.out_nchw || (g.dense && (Ho * Wo) % 4 == 0 && !accumulate),
              "lk_conv_nhwc_f16x2: position-contiguous output needs a dense grid with Ho*Wo % 4 == 0 and no accumulate");
   hipStream_t st = (hipStream_t)stream;
-  g_ablate = ((config >> 8) & 7) | ((config & 524288) ? 8 : 0);  // bit 19: chunk-major K order
+  g_ablate = ((config >> 8) & 7) | ((config & 524288) ? 8 : 0) | ((config & 1048576) ? 16 : 0);  // bit 19: chunk-major K order
   // "patch" form (A operand resident in LDS across the taps) where the output grid is the input grid
   bool patch = !fz && !(config & 2) && !(config & 16) && in_mul == 1 && Hc == Hi && Wc == Wi && 256 + 2 * Wi + 2 <= 336 && N * Hi * Wi >= 256;
   if ((config & 262144) && Co > 64) patch = false;  // development switch: the patch form for the 64-channel layers only
