@@ -3,6 +3,7 @@
 //   variant 1: + the 8 ds_read_b128 fragment reads of one k16 step per 12 MFMAs (two register sets, counted waits)
 //   variant 2: + one s_barrier per 24 MFMAs (the stage hand-over)
 //   variant 3: + 10 LDS-DMA loads (global_load_lds, 16 B per lane) per 24 MFMAs from a small L2-resident buffer
+//   variants 4 / 5 / 6: the same loads in the convolution's address pattern (64-byte pieces of rows 128 / 256 / 64 B apart)
 // Launch shape = the conv kernel's: 256-thread workgroups, `wgs_per_cu` x 256 of them.  Prints fp16 TFLOP/s and the
 // fraction of 2.5 PFLOP/s.   Build: hipcc --offload-arch=gfx950 -O3 mfma_peak_probe.hip -o mfma_peak_probe
 #include <hip/hip_runtime.h>
@@ -61,10 +62,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       __builtin_amdgcn_s_waitcnt(0x0f70);
       __builtin_amdgcn_s_barrier();
     }
-    if (V >= 3) {
+    if (V == 3) {
 #pragma unroll
       for (int i = 0; i < 10; ++i) {
         const _Float16* sp = src + ((size_t)((blockIdx.x * 7 + it * 13 + i) & 1023) * 256 + threadIdx.x) * 8;
+        __builtin_amdgcn_global_load_lds((gbl_void*)sp, (lds_void*)(smem + (it & 1) * 40960 + (i * 256 + wave * 64) * 16), 16, 0, 0);
+      }
+    }
+    if (V >= 4) {
+      // the convolution's pattern: four lanes read one 64-byte piece of a row, rows ROWB bytes apart (V = 4: 128 B =
+      // half of every cache line is used; 5: 256 B; 6: 64 B = contiguous), 64 rows per instruction, from a 1 MB window
+      constexpr int ROWB = V == 4 ? 128 : (V == 5 ? 256 : 64);
+#pragma unroll
+      for (int i = 0; i < 10; ++i) {
+        const size_t row = ((size_t)(blockIdx.x * 37 + it * 11 + i) * 64 + (threadIdx.x >> 2)) & (size_t)(1048576 / ROWB - 1);
+        const char* sp = (const char*)src + row * ROWB + (threadIdx.x & 3) * 16;
         __builtin_amdgcn_global_load_lds((gbl_void*)sp, (lds_void*)(smem + (it & 1) * 40960 + (i * 256 + wave * 64) * 16), 16, 0, 0);
       }
     }
@@ -114,6 +126,9 @@ int main(int argc, char** argv) {
     run<1>(src, out, 2, iters);
     run<2>(src, out, 2, iters);
     run<3>(src, out, 2, iters);
+    run<4>(src, out, 2, iters);
+    run<5>(src, out, 2, iters);
+    run<6>(src, out, 2, iters);
     run<0>(src, out, 1, iters);
     run<2>(src, out, 1, iters);
     run<3>(src, out, 1, iters);
