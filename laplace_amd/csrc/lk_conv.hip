@@ -508,8 +508,40 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
     const float sc_out = exp2i(so);
     // the wave's 64 x 64 (32 x 32, ...) block goes through LDS: MFMA layout (lane = channel, registers = pixels) ->
     // lane = 8 consecutive channels of one pixel, i.e. 16-byte loads of the addend / mask and 16-byte stores of each plane
-    constexpr int ROWS_W = TM * 32, COLS_W = TN * 32, PITCH = COLS_W + 4, C8 = COLS_W / 8;
+    constexpr int ROWS_W = TM * 32, COLS_W = TN * 32, PITCH = COLS_W + 4, C8 = COLS_W / 8, NIT = ROWS_W * C8 / 64;
     static_assert(CFG::EPI_LDS == CFG::WM * CFG::WN * ROWS_W * PITCH * 4 && CFG::EPI_LDS <= 80 * 1024, "staging image: two workgroups per CU");
+    // The addend planes and the mask bytes of ALL of this lane's chunks are requested first: their latency (an HBM miss
+    // each) then runs under the hand-over barrier and the staging of the accumulators instead of once per chunk.
+    const int HWc = g.Hc * g.Wc;
+    int64_t e_[NIT];
+    bool ok_[NIT];
+    f16x8 h2_[NIT], l2_[NIT];
+    uint2 mk_[NIT];
+    const bool pre_mask = fz.mask && !fz.mask_float;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = it * 64 + lane;
+      const int row = idx / C8, c8 = idx - row * C8;
+      const int m = tile_m * BM + wm * ROWS_W + row;
+      const int col0 = tile_n * BN + wn * COLS_W + c8 * 8;
+      ok_[it] = m < M && col0 < g.Co;
+      int64_t opix = m;  // dense grid: the output pixel index is the GEMM row, up to the position-major order
+      if (g.pmajor) {
+        const int rem = fdiv(m, g.div_n);
+        opix = (int64_t)(m - rem * g.N) * HWc + rem;
+      }
+      e_[it] = ok_[it] ? opix * g.Co + col0 : 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) h2_[it][j] = (_Float16)0.f, l2_[it][j] = (_Float16)0.f;
+      mk_[it] = make_uint2(0x01010101u, 0x01010101u);
+      if (ablate & 32) continue;  // (development switch, config bit 21: load per chunk, where the values are consumed)
+      if (fz.add_h && ok_[it]) {
+        h2_[it] = *reinterpret_cast<const f16x8*>(fz.add_h + e_[it]);
+        l2_[it] = *reinterpret_cast<const f16x8*>(fz.add_l + e_[it]);
+      }
+      if (pre_mask && ok_[it])
+        mk_[it] = *reinterpret_cast<const uint2*>((const unsigned char*)fz.mask + (opix % fz.mask_rows) * g.Co + col0);
+    }
     __syncthreads();  // every wave is done with the K loop's stage buffers
     float* img = reinterpret_cast<float*>(smem) + wave * (ROWS_W * PITCH);
     const float inv = inv_a * inv_w;
@@ -521,40 +553,36 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
         for (int r = 0; r < 16; ++r)
           img[(a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * PITCH + b * 32 + lr] = acc[a][b][r] * inv;
     // (LDS operations of one wave execute in order: no barrier between its own writes and reads)
-    const int HWc = g.Hc * g.Wc;
-#pragma unroll 2
-    for (int it = 0; it < ROWS_W * C8 / 64; ++it) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      if (!ok_[it]) continue;
       const int idx = it * 64 + lane;
       const int row = idx / C8, c8 = idx - row * C8;
-      const int m = tile_m * BM + wm * ROWS_W + row;
       const int col0 = tile_n * BN + wn * COLS_W + c8 * 8;
-      if (m >= M || col0 >= g.Co) continue;
       const f32x4 p0 = *reinterpret_cast<const f32x4*>(img + row * PITCH + c8 * 8);
       const f32x4 p1 = *reinterpret_cast<const f32x4*>(img + row * PITCH + c8 * 8 + 4);
       float v[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
-      int64_t opix = m;  // dense grid: the output pixel index is the GEMM row, up to the position-major order
-      if (g.pmajor) {
-        const int rem = fdiv(m, g.div_n);
-        opix = (int64_t)(m - rem * g.N) * HWc + rem;
+      const int64_t e = e_[it];
+      if (ablate & 32) {
+        if (fz.add_h) h2_[it] = *reinterpret_cast<const f16x8*>(fz.add_h + e), l2_[it] = *reinterpret_cast<const f16x8*>(fz.add_l + e);
+        if (pre_mask) mk_[it] = *reinterpret_cast<const uint2*>((const unsigned char*)fz.mask + ((e / g.Co) % fz.mask_rows) * g.Co + col0);
       }
-      const int64_t e = opix * g.Co + col0;
       if (fz.add_h) {
-        const f16x8 h2 = *reinterpret_cast<const f16x8*>(fz.add_h + e), l2 = *reinterpret_cast<const f16x8*>(fz.add_l + e);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += ((float)h2[j] + (float)l2[j]) * inv2;
+        for (int j = 0; j < 8; ++j) v[j] += ((float)h2_[it][j] + (float)l2_[it][j]) * inv2;
       }
       float mult[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) mult[j] = sc_out;
       if (fz.mask) {
-        const int64_t em = (opix % fz.mask_rows) * g.Co + col0;
         if (fz.mask_float) {
+          const int64_t em = ((e / g.Co) % fz.mask_rows) * g.Co + col0;
           const f32x4 a = *reinterpret_cast<const f32x4*>((const float*)fz.mask + em);
           const f32x4 b = *reinterpret_cast<const f32x4*>((const float*)fz.mask + em + 4);
 #pragma unroll
           for (int j = 0; j < 4; ++j) mult[j] *= a[j], mult[4 + j] *= b[j];
         } else {
-          const uint2 u = *reinterpret_cast<const uint2*>((const unsigned char*)fz.mask + em);
+          const uint2 u = mk_[it];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             if (!((u.x >> (8 * j)) & 0xffu)) mult[j] = 0.f;
@@ -975,7 +1003,7 @@ static int conv_dispatch(const void* in_h, const void* in_l, const int* in_sexp,
   LK_REQUIRE(!g.out_nchw || (g.dense && (Ho * Wo) % 4 == 0 && !accumulate),
              "lk_conv_nhwc_f16x2: position-contiguous output needs a dense grid with Ho*Wo % 4 == 0 and no accumulate");
   hipStream_t st = (hipStream_t)stream;
-  g_ablate = ((config >> 8) & 7) | ((config & 524288) ? 8 : 0) | ((config & 1048576) ? 16 : 0);  // bit 19: chunk-major K order
+  g_ablate = ((config >> 8) & 7) | ((config & 524288) ? 8 : 0) | ((config & 1048576) ? 16 : 0) | ((config & 2097152) ? 32 : 0);  // bit 19: chunk-major K order
   // "patch" form (A operand resident in LDS across the taps) where the output grid is the input grid
   bool patch = !fz && !(config & 2) && !(config & 16) && in_mul == 1 && Hc == Hi && Wc == Wi && 256 + 2 * Wi + 2 <= 336 && N * Hi * Wi >= 256;
   if ((config & 262144) && Co > 64) patch = false;  // development switch: the patch form for the 64-channel layers only
