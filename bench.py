@@ -143,7 +143,7 @@ def pmc_traffic(kernel_prefix: str):
     command (FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied: tools/pmc_traffic.py).
     Counters cannot be collected from inside the process, so the figure is read from profiles/; None if absent."""
     table, used = None, None
-    for name in ("r02_pmc_traffic_bench_c4_v4", "r02_pmc_traffic_bench_c4", "r01_pmc_traffic_bench_c4"):
+    for name in ("r02_pmc_traffic_bench_c4_v5", "r02_pmc_traffic_bench_c4_v4", "r02_pmc_traffic_bench_c4", "r01_pmc_traffic_bench_c4"):
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name + ".json")
         try:
             with open(path) as fh:
