@@ -676,10 +676,10 @@ class HipKernels:
                                  tiles.shape[0], self._stream(x.device))), "lk_conv3x3_pixpair_accumulate_f32")
         return blocks
 
-    #: ``True`` (env LK_PIXPAIR16=1): the pixel-pair products run on the split-fp16 kernel.  Off by default: measured
-    #: equal to the exact-fp32 MFMA kernel (1.40 vs 1.39 ms per c4 step) — the product is bound by the L2 -> LDS traffic of
-    #: its panels (every pixel's panel is loaded 26 times), not by the matrix pipe
-    use_pixpair16 = os.environ.get("LK_PIXPAIR16", "0") != "0"
+    #: ``False`` (env LK_PIXPAIR16=0): the pixel-pair products stay on the exact-fp32 MFMA kernel.  The split-fp16 kernel
+    #: requests the block it read-modify-writes at the START of its (short) tile: 0.87 vs 1.39 ms per c4 step — the
+    #: dependent 16 KB read at the end of every 8-stage tile, not traffic or the matrix pipe, was what bound the product
+    use_pixpair16 = os.environ.get("LK_PIXPAIR16", "1") != "0"
 
     def pixpair_accumulate_split(self, xs, alpha, blocks, plan):
         """:meth:`pixpair_accumulate_nhwc` on a SplitTensor ``xs [B, H, W, Cin]`` (three fp16 MFMAs per product block)."""

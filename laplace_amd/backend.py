@@ -567,7 +567,7 @@ class KronAccumulator:
         self._persist_slabs = os.environ.get("LK_PERSIST_SLABS", "1") != "0"
         #: minibatches stacked per pixel-pair launch: the kernel is bound by the read-modify-write of its blocks, which
         #: happens once per LAUNCH, so stacking the NHWC inputs of consecutive minibatches divides that traffic
-        self.pix_group = max(1, int(os.environ.get("LK_PIX_GROUP", "4")))
+        self.pix_group = max(1, int(os.environ.get("LK_PIX_GROUP", "8")))
         self._side = None
         self._side_done = None  # event at the end of the previous minibatch's side-stream work (lagged join)
         #: ``False`` (env LK_LAG_JOIN=0): the main stream waits for the factor kernels at the end of every minibatch

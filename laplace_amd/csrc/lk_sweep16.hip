@@ -324,6 +324,32 @@ __global__ __launch_bounds__(256) void gram16_kernel(const _Float16* __restrict_
     return out;
   };
 
+  // TNP: the block this workgroup adds into is requested NOW, so that the read of the read-modify-write runs under the K
+  // loop instead of after it (the tiles are short — 8 to 16 stages — and a dependent 16 KB read at their end was a third
+  // of a tile's time)
+  constexpr int NOLD = TNP ? (KW == 4 ? TW * TW * 4 : TW * TW * 16) : 1;
+  float old[NOLD];
+  if constexpr (TNP) {
+    const int lr_ = lane & 31, lh_ = lane >> 5;
+    if (KW == 4) {
+#pragma unroll
+      for (int i = 0; i < NOLD; ++i) {
+        const int e = tid + 256 * i, t = e >> 10, a = t / TW, b = t % TW, row = (e >> 5) & 31, col = e & 31;
+        old[i] = tp.blocks[out_off + (int64_t)(a * 32 + row) * tp.ldc + b * 32 + col];
+      }
+    } else {
+#pragma unroll
+      for (int a = 0; a < TW; ++a)
+#pragma unroll
+        for (int b = 0; b < TW; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh_;
+            const int col = wc * 64 + b * 32 + lr_;
+            old[(a * TW + b) * 16 + r] = tp.blocks[out_off + (int64_t)row * tp.ldc + col];
+          }
+    }
+  }
   if (nstage > 0) stage(0, 0);
   for (int s = 0; s < nstage; ++s) {
     const int buf = s & 1;
@@ -385,12 +411,14 @@ __global__ __launch_bounds__(256) void gram16_kernel(const _Float16* __restrict_
       const float inv = exp2i16(-tp.sexp[0]);
       tscale = tp.alpha * inv * inv;
     }
-    for (int e = tid; e < TW * TW * 1024; e += 256) {
+#pragma unroll
+    for (int i = 0; i < TW * TW * 4; ++i) {
+      const int e = tid + 256 * i;
       const int t = e >> 10, a = t / TW, b = t % TW;
       if (!TNP && a > b) continue;
       const float v = ((red[e] + red[TW * TW * 1024 + e]) + red[2 * TW * TW * 1024 + e]) + red[3 * TW * TW * 1024 + e];
       const int row = (e >> 5) & 31, col = e & 31;
-      if constexpr (TNP) tp.blocks[out_off + (int64_t)(a * 32 + row) * tp.ldc + b * 32 + col] += tscale * v;
+      if constexpr (TNP) tp.blocks[out_off + (int64_t)(a * 32 + row) * tp.ldc + b * 32 + col] = old[i] + tscale * v;
       else blk[(a * 32 + row) * NB + b * 32 + col] = v;
     }
     return;
@@ -410,7 +438,7 @@ __global__ __launch_bounds__(256) void gram16_kernel(const _Float16* __restrict_
       for (int r = 0; r < 16; ++r) {
         const int row = wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int col = wc * 64 + b * 32 + lr;
-        if constexpr (TNP) tp.blocks[out_off + (int64_t)row * tp.ldc + col] += tscale * acc[a][b][r];
+        if constexpr (TNP) tp.blocks[out_off + (int64_t)row * tp.ldc + col] = old[(a * TW + b) * 16 + r] + tscale * acc[a][b][r];
         else blk[row * NB + col] = acc[a][b][r];
       }
     }
