@@ -260,6 +260,27 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
   }
   const int64_t w_tap = (int64_t)g.Co * g.Ci;
 
+  // The scale words (and, for the fused epilogue, the bound they combine to) are read HERE, at the top: left where they
+  // are used — behind the K loop — they were a chain of dependent global loads at the end of every tile.
+  const int sexp_a = a_sexp[0], sexp_w = w_sexp[0];
+  const float inv_a = exp2i(-sexp_a < -126 ? -126 : -sexp_a), inv_w = exp2i(-sexp_w < -126 ? -126 : -sexp_w);
+  int so = 0;
+  float sc_out = 1.f, inv2 = 0.f;
+  if constexpr (FUSE) {
+    // scale of the result from the guaranteed bound (every thread computes the same few flops; one writes the word)
+    float bound = fz.in_amax ? __uint_as_float(fz.in_amax[0]) : exp2i(15 - sexp_a < -126 ? -126 : (15 - sexp_a > 127 ? 127 : 15 - sexp_a));
+    bound *= fz.w_l1[0];
+    if (fz.add_h) {
+      const int s2 = fz.add_sexp[0];
+      bound += exp2i(15 - s2 < -126 ? -126 : (15 - s2 > 127 ? 127 : 15 - s2));
+      inv2 = exp2i(-s2 < -126 ? -126 : -s2);
+    }
+    if (fz.mask && fz.mask_float && fz.mult_amax) bound *= __uint_as_float(fz.mult_amax[0]);
+    if (fz.scale) bound *= __uint_as_float(fz.scale_amax[0]);
+    so = scale_exp_for(bound);
+    sc_out = exp2i(so);
+  }
+
   // Taps that reach no row of this tile are dropped from the K loop (position-major tiles of small maps: a corner pixel
   // of a 4 x 4 map sees 4 of the 9 taps).  The list is uniform over the workgroup: OR of every thread's validity bits.
   unsigned long long tap_list = 0;  // 4 bits per listed tap
@@ -489,23 +510,9 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
   }  // (pipeline form)
 
   // ---- epilogue: un-scale, store NHWC (a half-wave writes 32 consecutive channels = 128 B), max|out|
-  const float inv_a = exp2i(-a_sexp[0] < -126 ? -126 : -a_sexp[0]), inv_w = exp2i(-w_sexp[0] < -126 ? -126 : -w_sexp[0]);
   unsigned vmax = 0;
   if constexpr (FUSE) {
-    // scale of the result from the guaranteed bound (every thread computes the same few flops; one writes the word)
-    float bound = fz.in_amax ? __uint_as_float(fz.in_amax[0]) : exp2i(15 - a_sexp[0] < -126 ? -126 : (15 - a_sexp[0] > 127 ? 127 : 15 - a_sexp[0]));
-    bound *= fz.w_l1[0];
-    float inv2 = 0.f;
-    if (fz.add_h) {
-      const int s2 = fz.add_sexp[0];
-      bound += exp2i(15 - s2 < -126 ? -126 : (15 - s2 > 127 ? 127 : 15 - s2));
-      inv2 = exp2i(-s2 < -126 ? -126 : -s2);
-    }
-    if (fz.mask && fz.mask_float && fz.mult_amax) bound *= __uint_as_float(fz.mult_amax[0]);
-    if (fz.scale) bound *= __uint_as_float(fz.scale_amax[0]);
-    const int so = scale_exp_for(bound);
     if (blockIdx.x == 0 && tid == 0) fz.out_sexp[0] = so;
-    const float sc_out = exp2i(so);
     // the wave's 64 x 64 (32 x 32, ...) block goes through LDS: MFMA layout (lane = channel, registers = pixels) ->
     // lane = 8 consecutive channels of one pixel, i.e. 16-byte loads of the addend / mask and 16-byte stores of each plane
     constexpr int ROWS_W = TM * 32, COLS_W = TN * 32, PITCH = COLS_W + 4, C8 = COLS_W / 8, NIT = ROWS_W * C8 / 64;
