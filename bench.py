@@ -138,12 +138,12 @@ def predictive_leg(dev):
             "fit_samples_per_s": fit_rate, "predictive_samples_per_s": 10 * 512 / (time.time() - t0)}
 
 
-def pmc_traffic(kernel_prefix: str):
+def pmc_traffic(kernel_prefix: str, kernel_suffix: str = ""):
     """HBM bytes per launch of the dominant kernel family from the committed rocprofv3 PMC passes over this very
     command (FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied: tools/pmc_traffic.py).
     Counters cannot be collected from inside the process, so the figure is read from profiles/; None if absent."""
     table, used = None, None
-    for name in ("r02_pmc_traffic_bench_c4_v5", "r02_pmc_traffic_bench_c4_v4", "r02_pmc_traffic_bench_c4", "r01_pmc_traffic_bench_c4"):
+    for name in ("r02_pmc_traffic_bench_c4_v6", "r02_pmc_traffic_bench_c4_v5", "r02_pmc_traffic_bench_c4_v4", "r02_pmc_traffic_bench_c4", "r01_pmc_traffic_bench_c4"):
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name + ".json")
         try:
             with open(path) as fh:
@@ -153,7 +153,7 @@ def pmc_traffic(kernel_prefix: str):
             continue
     if table is None:
         return None, None
-    rows = [v for k, v in table.items() if k.startswith(kernel_prefix)]
+    rows = [v for k, v in table.items() if k.startswith(kernel_prefix) and k.endswith(kernel_suffix)]
     launches = sum(r["launches"] for r in rows)
     if not launches:
         return None, None
@@ -272,7 +272,7 @@ def main():
                        "seed-batched reverse sweep (batch 9 x 128) and the forward; " + F16X2, "mfma16",
                        "lk::conv_f16x2_kernel"),
             "gram16": ("lk::gram16_kernel (+ fixed-order reduce): G factors as Grams of the NHWC split cotangents through "
-                       "transposing LDS reads; symmetric-half flop K*n*(n+1); " + F16X2, "mfma16", "lk::gram16_kernel"),
+                       "transposing LDS reads; symmetric-half flop K*n*(n+1); " + F16X2, "mfma16", "lk::gram16_kernel", ",0>"),
             "vjp16": ("lk::vjp_nhwc_split_kernel: element-wise VJP (mask x folded BatchNorm scale x residual add) of all "
                       "seeds, emitting split tensors", "hbm", "lk::vjp_nhwc_split_kernel"),
             "bnact16": ("lk::bn_act_fwd_nhwc_kernel: forward BatchNorm-eval + add + ReLU, emitting fp32, mask, split planes",
@@ -283,14 +283,16 @@ def main():
                         "(block read-modify-write)", "hbm", "void lk::gram_kernel<4,"),
             "pixpair16": ("lk::gram16_kernel<.., TNP>: banded pixel-pair accumulation of the 3x3-conv A factors from the split "
                           "images (block read-modify-write once per four stacked minibatches; three fp16 MFMAs per fp32 "
-                          "product block); priced on its algorithmic bytes, 2 x blocks + input", "hbm", "lk::gram16_kernel"),
+                          "product block); priced on its algorithmic bytes, 2 x blocks + input", "hbm", "lk::gram16_kernel", ",1>"),
             "gram_conv": ("lk::gram_kernel<MODE_CONV> (+ slab reduce): implicit-im2col A-factor accumulation, "
                           "exact-fp32 MFMA", "mfma", "void lk::gram_kernel<2,"),
             "shiftcorr": ("lk_conv3x3_shiftcorr_f32: shift-correlation A factors", "mfma", "void lk::gram_kernel<3,"),
             "gram_tn": ("lk::gram_kernel<MODE_TN>: Linear-layer factors", "mfma", "void lk::gram_kernel<0,"),
         }
         fam_out, dominant = {}, None
-        for key, (what, bound, prefix) in fams.items():
+        for key, spec in fams.items():
+            what, bound, prefix = spec[:3]
+            suffix = spec[3] if len(spec) > 3 else ""
             ms, work, n = agg(key)
             if n == 0 or ms <= 0:
                 continue
@@ -300,7 +302,7 @@ def main():
                 achieved, peak, unit, bound = work / (ms * 1e-3) / 1e12, PEAK_F16X2_TFLOPS, "TFLOP/s", "mfma"
             else:
                 achieved, peak, unit = work / (ms * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
-            traffic, traffic_src = pmc_traffic(prefix)
+            traffic, traffic_src = pmc_traffic(prefix, suffix)
             fam_out[key] = {"kernel": what, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
                             "frac": achieved / peak, "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                             "traffic_source": traffic_src, "launches": n, "avg_launch_ms": ms / n,
