@@ -40,11 +40,13 @@ PEAK_BF16X3_TFLOPS = PEAK_F16_MFMA_TFLOPS / 6.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-predictive", action="store_true")
     ap.add_argument("--no-eigh", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip fit_50k and the c1 / c2 / c5 legs")
+    ap.add_argument("--no-check", action="store_true", help="skip the serial re-run the timed factors are compared with")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bound of the CPU-baseline leg")
     ap.add_argument("--no-overlap", action="store_true", help="A-factor kernels on the main stream (A/B switch)")
     ap.add_argument("--no-sweep", action="store_true", help="one autograd reverse pass per seed instead of the seed-batched sweep")
@@ -60,12 +62,24 @@ def make_batches(steps, dev, seed):
     return xs
 
 
-def fit_steps(backend, batches, n_steps, world, overlap=True):
+def fit_steps(backend, batches, n_steps, world, overlap=True, serial=False):
     """K minibatches through the fused accumulator, the fit's single all-reduce, and the one-off
-    symmetrise/permute into the reference's Kron layout — i.e. everything `fit` does before decompose."""
+    symmetrise/permute into the reference's Kron layout — i.e. everything `fit` does before decompose.
+    ``serial``: every scheduling feature off (one pixel-pair launch per minibatch, no lagged join, no side stream) —
+    the independent re-run the timed factors are checked against."""
     from laplace_amd.laplace import allreduce_curvature
 
-    acc = backend.kron_accumulator(N_DATASET, overlap=overlap)
+    if serial:
+        saved = {k: os.environ.get(k) for k in ("LK_PIX_GROUP", "LK_LAG_JOIN")}
+        os.environ.update(LK_PIX_GROUP="1", LK_LAG_JOIN="0")
+        try:
+            acc = backend.kron_accumulator(N_DATASET, overlap=False)
+        finally:
+            for k, v in saved.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        assert acc.pix_group == 1 and not acc.lag_join and not acc.overlap
+    else:
+        acc = backend.kron_accumulator(N_DATASET, overlap=overlap)
     for i in range(n_steps):
         X, y = batches[i % len(batches)]
         acc.add_batch(X, y)
@@ -138,27 +152,190 @@ def predictive_leg(dev):
             "fit_samples_per_s": fit_rate, "predictive_samples_per_s": 10 * 512 / (time.time() - t0)}
 
 
+def cpu_predictive_baseline(dec, prior: float, seconds: float):
+    """The reference's GLM predictive as written — per-sample Jacobians ``Js [B, 10, P]`` (curvature.py:88-129), every
+    Kronecker block rotated into the eigenbasis, weighted and contracted (utils/matrix.py:406-461 via
+    baselaplace.py:1834-1835) — by the oracle's restatement on this host's cores, fp32, on the c4 posterior just
+    decomposed (eigenpairs copied to the host): a reported baseline only."""
+    from laplace_amd.nets import ResNet18
+    from oracle import curvature_oracle as co
+
+    torch.manual_seed(711)
+    model = ResNet18(CLASSES).eval()
+    Qs = [[Q.float().cpu() for Q in blk] for blk in dec.eigenvectors]
+    ls = [[l.float().cpu() for l in blk] for blk in dec.eigenvalues]
+    g = torch.Generator().manual_seed(1)
+    bs = 2
+    X = torch.randn(bs, 3, 32, 32, generator=g)
+    done, t0 = 0, time.time()
+    while done < bs or time.time() - t0 < seconds:
+        Js, _ = co.jacobians(model, X)
+        fvar = co.krondecomposed_inv_square_form_blocks(Qs, ls, prior, Js)
+        done += bs
+    dt = time.time() - t0
+    return {"value": done / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "finite": bool(torch.isfinite(fvar).all()),
+            "sample": f"{done} synthetic images (batch {bs}) through oracle.jacobians + "
+                      f"oracle.krondecomposed_inv_square_form_blocks, ResNet-18 KFAC posterior (P = 11.2 M), fp32, {dt:.1f} s"}
+
+
+def fit_50k_leg(backend, dev):
+    """The end-to-end figure BASELINE.json's c4 names: a 50 000-sample fit = 390 minibatches of 128 + one of 80, then
+    finalise (pixel-pair assembly, symmetrise, permute) and the eigendecomposition of all 43 factors (one GPU; on N
+    GPUs the driver's per-N runs carry the all-reduce).  Inputs resident in HBM (four distinct minibatches cycled)."""
+    g = torch.Generator().manual_seed(7)
+    bs = [(torch.randn(BATCH, 3, 32, 32, generator=g).to(dev), torch.randint(CLASSES, (BATCH,), generator=g).to(dev))
+          for _ in range(4)]
+    n_full, rest = divmod(N_DATASET, BATCH)
+    last = (bs[1][0][:rest].contiguous(), bs[1][1][:rest].contiguous()) if rest else None
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    acc = backend.kron_accumulator(N_DATASET)
+    for i in range(n_full):
+        acc.add_batch(*bs[i % 4])
+    if last is not None:
+        acc.add_batch(*last)
+    loss, H = acc.finalize()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    dec = H.decompose()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    ok = all(int(i[0].item()) == 0 for i in dec._eig_info)
+    return {"samples": N_DATASET, "minibatches": n_full + (1 if rest else 0), "wall_s": t2 - t0, "accumulate_s": t1 - t0,
+            "decompose_s": t2 - t1, "samples_per_s": N_DATASET / (t2 - t0), "eigh_converged": bool(ok),
+            "loss_finite": bool(torch.isfinite(loss).all())}
+
+
+def small_config_legs(dev):
+    """The other BASELINE.json configs as extras of the same line (whole `fit` incl. decomposition, median of 3):
+    c1 MLP 1-50-1 regression (diag, N = 1000, batch 100), c2 LeNet-5 KFAC (N = 10 000, batch 256) + its Kron GLM
+    predictive, c5 BERT-base last-layer KFAC + 100 marginal-likelihood steps (random init, sequence 128, batch 32)."""
+    from laplace_amd.laplace import HipLaplace
+    from laplace_amd.nets import lenet5, mlp_1_50_1
+
+    out = {}
+
+    def run(model, X, y, lik, hs, bs, reps=3, **kw):
+        class L(list):
+            dataset = X
+
+        loader = L([(X[i:i + bs], y[i:i + bs]) for i in range(0, len(X), bs)])
+        ts, la = [], None
+        for _ in range(reps + 1):
+            la = HipLaplace(model, lik, "all", hs, **kw)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            la.fit(loader)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        t = sorted(ts[1:])[len(ts[1:]) // 2]
+        return la, {"fit_ms": t * 1e3, "samples_per_s": len(X) / t}
+
+    torch.manual_seed(711)
+    m = mlp_1_50_1().to(dev)
+    X = (8 * torch.rand(1000, 1)).to(dev)
+    y = (torch.sin(X) + 0.3 * torch.randn_like(X)).to(dev)
+    out["c1_mlp_diag"] = run(m, X, y, "regression", "diag", 100)[1]
+    out["c1_mlp_kron"] = run(m, X, y, "regression", "kron", 100)[1]
+    torch.manual_seed(711)
+    m = lenet5().to(dev)
+    X = torch.randn(10000, 3, 32, 32, device=dev)
+    y = torch.randint(0, 10, (10000,), device=dev)
+    la, out["c2_lenet_kron"] = run(m, X, y, "classification", "kron", 256)
+    for _ in range(2):
+        la._glm_predictive_distribution(X[:256])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(0, 2048, 256):
+        la._glm_predictive_distribution(X[i:i + 256])
+    torch.cuda.synchronize()
+    out["c2_lenet_kron"]["predictive_samples_per_s"] = 2048 / (time.perf_counter() - t0)
+    del la, X, y
+    try:
+        out["c5_bert_base_ll_kron"] = _c5_leg(dev)
+    except Exception as e:  # transformers missing / a model change: the headline number must not depend on this leg
+        out["c5_bert_base_ll_kron"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    return out
+
+
+def _c5_leg(dev):
+    from torch import nn
+    from transformers import BertConfig, BertForSequenceClassification
+
+    from laplace_amd.laplace import HipLaplace
+
+    class BertHead(nn.Module):  # the wrapper of the reference's HuggingFace example: dict batch in, logits out
+        def __init__(self, cfg):
+            super().__init__()
+            self.hf = BertForSequenceClassification(cfg)
+
+        def forward(self, data):
+            return self.hf(input_ids=data["input_ids"], attention_mask=data["attention_mask"]).logits
+
+    torch.manual_seed(711)
+    cfg = BertConfig(num_labels=2)
+    T, bs, n = 128, 32, 1024
+    model = BertHead(cfg).to(dev).eval()
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(cfg.vocab_size, (n, T), generator=g)
+    mask = torch.ones(n, T, dtype=torch.long)
+    lens = torch.randint(T // 2, T + 1, (n,), generator=g)
+    mask[torch.arange(T)[None, :] >= lens[:, None]] = 0
+    yy = torch.randint(2, (n,), generator=g)
+
+    class Loader(list):
+        dataset = range(n)
+
+    train = Loader([{"input_ids": ids[i:i + bs].to(dev), "attention_mask": mask[i:i + bs].to(dev), "labels": yy[i:i + bs].to(dev)}
+                    for i in range(0, n, bs)])
+    la = HipLaplace(model, "classification", "last_layer", "kron", last_layer_name="hf.classifier")
+    la.fit(train)  # warm-up (library GEMM selection for the encoder)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    la.fit(train)
+    torch.cuda.synchronize()
+    t_fit = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    la.optimize_prior_precision(pred_type="glm", method="marglik", n_steps=100, lr=0.1, prior_structure="layerwise")
+    torch.cuda.synchronize()
+    t_ml = time.perf_counter() - t0
+    return {"fit_samples_per_s": n / t_fit, "marglik_100_steps_ms": t_ml * 1e3,
+            "note": "dominated by the encoder forward (stock PyTorch-ROCm: not part of the path)"}
+
+
 def pmc_traffic(kernel_prefix: str, kernel_suffix: str = ""):
-    """HBM bytes per launch of the dominant kernel family from the committed rocprofv3 PMC passes over this very
-    command (FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied: tools/pmc_traffic.py).
-    Counters cannot be collected from inside the process, so the figure is read from profiles/; None if absent."""
-    table, used = None, None
-    for name in ("r02_pmc_traffic_bench_c4_v6", "r02_pmc_traffic_bench_c4_v5", "r02_pmc_traffic_bench_c4_v4", "r02_pmc_traffic_bench_c4", "r01_pmc_traffic_bench_c4"):
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name + ".json")
+    """HBM bytes per launch of a kernel family from the rocprofv3 PMC passes over this very command (FETCH_SIZE /
+    WRITE_SIZE in separate passes, gfx950 correction applied: tools/pmc_traffic.py).  Counters cannot be collected from
+    inside the process, so the figure is read from profiles/ — but ONLY from a table stamped with the hash of the
+    kernel sources it was collected on (`_meta.csrc_sha16`) equal to the sources of this run; anything else is stale
+    and reported as null with the reason."""
+    import glob
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from pmc_traffic import csrc_sha16
+
+    want = csrc_sha16(ROOT)
+    newest = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_bench_c4*.json")), reverse=True):
         try:
             with open(path) as fh:
-                table, used = json.load(fh), name
-            break
+                table = json.load(fh)
         except (OSError, ValueError):
             continue
-    if table is None:
-        return None, None
-    rows = [v for k, v in table.items() if k.startswith(kernel_prefix) and k.endswith(kernel_suffix)]
-    launches = sum(r["launches"] for r in rows)
-    if not launches:
-        return None, None
-    total = sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows)
-    return total / launches, f"profiles/{used}.{{json,md}} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2x read correction)"
+        meta = table.get("_meta") or {}
+        newest = newest or os.path.basename(path)
+        if meta.get("csrc_sha16") != want:
+            continue
+        rows = [v for k, v in table.items() if k != "_meta" and k.startswith(kernel_prefix) and k.endswith(kernel_suffix)]
+        launches = sum(r["launches"] for r in rows)
+        if not launches:
+            return None, f"profiles/{os.path.basename(path)}: no launch of this family in the PMC pass"
+        total = sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows)
+        return total / launches, (f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2x read "
+                                  f"correction; kernel sources {want}, git {meta.get('git_head')})")
+    return None, (f"stale: no PMC table under profiles/ was collected on these kernel sources ({want}); newest is "
+                  f"{newest} — rerun tools/gpu_evidence_r03.sh")
 
 
 # LK_BENCH_SELFTEST=1: control-flow check of this script without a GPU (tests/test_bench_contract.py): CPU tensors,
@@ -228,6 +405,27 @@ def main():
     loss, H = fit_steps(backend, batches, args.steps, world, overlap)
     barrier()
     dt = time.perf_counter() - t0
+
+    # ---- check (rank 0): the factors of the TIMED run against the same K minibatches re-run with every scheduling
+    # feature off (no side stream, no lagged join, one pixel-pair launch per minibatch, per-launch reductions) — an
+    # ordering bug in the overlapped schedule would produce a fast wrong number.  Each factor block relative to its
+    # own largest element; the fp64 / reference-level parity of the same configuration is tests/test_gpu_timed_config.py
+    check = None
+    if rank == 0 and world == 1 and not args.no_check:
+        loss_s, H_s = fit_steps(backend, batches, args.steps, 1, serial=True)
+        worst, worst_at = 0.0, None
+        for bi, (F_, S_) in enumerate(zip(H.kfacs, H_s.kfacs)):
+            for fi, (a_, s_) in enumerate(zip(F_, S_)):
+                r = float((a_.double() - s_.double()).abs().max() / (s_.double().abs().max() + 1e-300))
+                if r >= worst:
+                    worst, worst_at = r, f"block {bi} factor {fi} (n={a_.shape[0]})"
+        lerr = float((loss.double() - loss_s.double()).abs() / (loss_s.double().abs() + 1e-300))
+        finite = bool(all(torch.isfinite(t).all() for F_ in H.kfacs for t in F_))
+        check = {"what": "timed run's factors vs the same minibatches re-run serially (LK_PIX_GROUP=1, LK_LAG_JOIN=0, "
+                         "no side stream); max over the 43 factors of max|a-b| / max|b| per factor",
+                 "max_block_rel_err": worst, "at": worst_at, "loss_rel_err": lerr, "finite": finite,
+                 "ok": bool(finite and worst < 1e-5 and lerr < 1e-6), "tol": 1e-5}
+        del H_s
 
     # ---- roofline leg (rank 0): the same steps once more with every Gram launch bracketed by HIP events on
     # its launch stream, A-factor kernels NOT overlapped with the reverse passes so that the per-launch
@@ -312,17 +510,9 @@ def main():
         roof = dict(fam_out[dominant]) if dominant else {"bound": "mfma", "achieved": 0.0, "peak": PEAK_F32_MFMA_TFLOPS,
                                                           "unit": "TFLOP/s", "frac": 0.0, "traffic": None}
         roof["family"] = dominant
-        if dominant in ("conv16", "gram16"):
-            # what the nominal peak means on this chip (committed probes, same box type): the matrix pipe alone, fed from
-            # registers with this kernel's instruction mix, sustains 0.63-0.78 of 2.5 PFLOP/s; the vendor library's plain
-            # fp16 GEMM reaches 0.43 on 8192^3 and 0.11-0.39 on the GEMM shapes these convolutions reduce to
-            roof["peak_calibration"] = {
-                "sustained_mfma_frac_of_nominal": [0.63, 0.78],
-                "hipblaslt_fp16_gemm_frac_of_nominal": {"8192^3": 0.43, "conv_shapes_c4": [0.11, 0.19, 0.31, 0.39]},
-                "source": "profiles/r02_mfma_peak_probe.txt, profiles/r02_gemm_calib_hipblaslt_fp16.json "
-                          "(tools/probes/mfma_peak_probe.hip, tools/gemm_calib.py)"}
-        roof["flop_convention"] = ("convolution: 2 * pixels * Cout * Cin * taps per launch (fp32 multiply-adds of the "
-                                   "algorithm); Gram families: symmetric half K*n*(n+1)")
+        roof["flop_convention"] = ("convolution: 2 * Cout * Cin * (output pixel, tap) pairs that fall INSIDE the image "
+                                   "(zero-padding taps are not counted: the figure does not move with the padding); "
+                                   "Gram families: symmetric half K*n*(n+1)")
         own_ms = sum(v["ms_per_step"] for v in fam_out.values())
         breakdown = None
         if serial_ms is not None:
@@ -343,7 +533,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32 (fp16x2-split products, fp32 accumulate)",
             "data": "synthetic",
             "config": {"workload": "c4: ResNet-18 (CIFAR stem, BN frozen) full-network KFAC exact GGN fit, "
                                    "per-GPU minibatch 128, synthetic N(0,1) 3x32x32, 10 classes, N=50000",
@@ -351,6 +541,7 @@ def main():
             "roofline": roof,  # the family with the largest share of the WHOLE step (measured without stream overlap)
             "roofline_families": fam_out,
             "step_breakdown": breakdown,
+            "check": check,
         }
     # ---- untimed extras on rank 0 (separate line items per BASELINE.md) --------------------------------------
     if rank == 0 and world == 1 and not SELFTEST:
@@ -419,9 +610,14 @@ def main():
                     "workload": "c4 posterior: ResNet-18 full-network KFAC, GLM predictive variance [B,10,10], batch 128",
                     "samples_per_s": pred_rate, "ms_per_call": pred_ms, "finite": bool(torch.isfinite(f_var).all()),
                     "roofline": dict(pfam[dom], family=dom) if dom else None, "roofline_families": pfam}
+                if not args.no_cpu_baseline:
+                    result["predictive_kron_c4"]["cpu_baseline"] = cpu_predictive_baseline(dec, 1.0, args.cpu_seconds)
             del dec
         if not args.no_predictive and not SELFTEST:
             result["predictive"] = predictive_leg(dev)
+        if not args.no_extras and not SELFTEST:
+            result["fit_50k"] = fit_50k_leg(backend, dev)
+            result["other_configs"] = small_config_legs(dev)
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(0.0 if SELFTEST else args.cpu_seconds)
     if world > 1 and not args.no_eigh:

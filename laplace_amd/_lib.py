@@ -392,6 +392,18 @@ class HipKernels:
             z = self._zeros[dev.index] = torch.zeros(64, dtype=torch.uint8, device=dev)
         return z
 
+    @staticmethod
+    def conv_valid_pairs(Hc, Wc, in_mul, Hi, Wi, taps) -> int:
+        """(output pixel, tap) pairs of one image whose input pixel ``(i * in_mul + dh, j * in_mul + dw)`` lies INSIDE the
+        ``Hi x Wi`` map: the multiply-adds the convolution has to do (zero-padding taps are no work, and the kernels
+        skip them where a tile holds none) — the flop figure behind the roofline numbers."""
+        def inside(n_out, n_in, d):
+            lo = 0 if d >= 0 else (-d + in_mul - 1) // in_mul          # first i with i * in_mul + d >= 0
+            hi = min(n_out - 1, (n_in - 1 - d) // in_mul) if n_in - 1 - d >= 0 else -1
+            return max(hi - lo + 1, 0)
+
+        return sum(inside(Hc, Hi, t[0]) * inside(Wc, Wi, t[1]) for t in taps)
+
     def conv_nhwc_f16x2(self, x, wplanes, wsexp, Hc, Wc, in_mul, out, out_step, oh0, ow0, taps, accumulate=False,
                         amax_out=None, config=None):
         """one launch of lk_conv_nhwc_f16x2; ``x``: SplitTensor [N, Hi, Wi, Ci]; ``wplanes`` [2, T, Co, Ci];
@@ -404,7 +416,8 @@ class HipKernels:
         cfg = self.conv_config if config is None else config
         z = self._zero16(out.device)
         # algorithmic work: the fp32 multiply-adds of the convolution (each is three fp16 MFMA multiply-adds on the chip)
-        self._rc(self._timed("conv16", 2.0 * N * Hc * Wc * Co * Ci * len(taps), out.device, lambda: self.lib.lk_conv_nhwc_f16x2(
+        work = 2.0 * N * Co * Ci * self.conv_valid_pairs(Hc, Wc, in_mul, Hi, Wi, taps) if self.profile is not None else 0.0
+        self._rc(self._timed("conv16", work, out.device, lambda: self.lib.lk_conv_nhwc_f16x2(
             _ptr(x.planes[0]), _ptr(x.planes[1]), _ptr(x.sexp), N, Hi, Wi, Ci, _ptr(wplanes[0]), _ptr(wplanes[1]),
             _ptr(wsexp), Co, Hc, Wc, in_mul, out.shape[1], out.shape[2], out_step, oh0, ow0, len(taps), flat, _ptr(z),
             _ptr(out), 1 if accumulate else 0, _ptr(amax_out), int(cfg), self._stream(out.device))), "lk_conv_nhwc_f16x2")
@@ -437,7 +450,8 @@ class HipKernels:
         flat = (ctypes.c_int * (3 * len(taps)))(*[int(v) for t in taps for v in t])
         cfg = self.conv_config if config is None else config
         z = self._zero16(dev)
-        self._rc(self._timed("conv16", 2.0 * N * Ho * Wo * Co * Ci * len(taps), dev, lambda: self.lib.lk_conv_nhwc_f16x2_vjp(
+        work = 2.0 * N * Co * Ci * self.conv_valid_pairs(Ho, Wo, 1, Hi, Wi, taps) if self.profile is not None else 0.0
+        self._rc(self._timed("conv16", work, dev, lambda: self.lib.lk_conv_nhwc_f16x2_vjp(
             _ptr(x.planes[0]), _ptr(x.planes[1]), _ptr(x.sexp), _ptr(x.amax), N, Hi, Wi, Ci, _ptr(wplanes[0]), _ptr(wplanes[1]),
             _ptr(wsexp), _ptr(w_l1), Co, Ho, Wo, len(taps), flat, _ptr(z),
             None if add is None else _ptr(add.planes[0]), None if add is None else _ptr(add.planes[1]),

@@ -144,8 +144,9 @@ class _HipCurvatureMixin:
         if f.dtype != torch.float32:
             raise TypeError(f"HIP curvature backend computes in float32; model output is {f.dtype}")
 
-    def _forward(self, x):
-        """Returns (f [B,C] detached, tape, grad_fn) where grad_fn(seeds[S,B,C]) -> per-tap [S,B,...]."""
+    def _forward(self, x, keep_tap_splits: bool = False):
+        """Returns (f [B,C] detached, tape, grad_fn) where grad_fn(seeds[S,B,C]) -> per-tap [S,B,...].
+        ``keep_tap_splits``: the NHWC sweep also keeps the split copies of the tapped inputs (``tap.a_split``)."""
         tape = self._tape()
         if self.last_layer:
             # f = last_layer(phi): the gradient w.r.t. the head's output IS the seed -> no reverse pass
@@ -162,7 +163,7 @@ class _HipCurvatureMixin:
             B = phi.shape[0]
             f = f.detach().reshape(B, -1).contiguous()
             return f, tape, lambda seeds, stack=True: [seeds.contiguous()]
-        swept = self._forward_swept(x, tape)
+        swept = self._forward_swept(x, tape, keep_tap_splits)
         if swept is not None:
             return swept
         f = tape.forward(x)
@@ -218,7 +219,7 @@ class _HipCurvatureMixin:
         fs.release()
         return f, phi
 
-    def _forward_swept(self, x, tape):
+    def _forward_swept(self, x, tape, keep_tap_splits: bool = False):
         """Seed-batched reverse sweep (laplace_amd/sweep.py) when the model is fx-traceable and built from
         modules with a closed-form VJP; ``None`` -> caller uses the autograd tape."""
         if not self.use_sweep or not torch.is_tensor(x) or not tape.taps:
@@ -236,7 +237,7 @@ class _HipCurvatureMixin:
         if sweep is False:
             return None
         try:
-            f = sweep.forward(x)
+            f = sweep.forward(x, keep_tap_splits=True) if keep_tap_splits and isinstance(sweep, SplitSweep) else sweep.forward(x)
         except SweepUnsupported as e:  # e.g. the model is in training mode for this call
             tape.sweep_reason = str(e)
             return None
@@ -274,6 +275,7 @@ class _HipCurvatureMixin:
             return [torch.cat([p[i] for p in parts]) for i in range(len(tape.taps))]
 
         grad_fn.streams_taps = True  # accepts on_tap: gradients are delivered layer by layer
+        grad_fn.accepts_keep_split = True  # can hand conv-tap gradients back as NHWC SplitTensors
         grad_fn.grad_scale = lambda: sweep.grad_scale  # name -> per-channel scale owed by the caller (deferred BN)
 
         return f.detach().reshape(f.shape[0], -1).contiguous(), tape, grad_fn
@@ -879,9 +881,12 @@ class KronAccumulator:
         self._gscale = {}
 
     def tensors(self) -> list[torch.Tensor]:
-        """Everything a data-parallel fit has to all-reduce (upper triangles are what counts)."""
+        """Everything a data-parallel fit has to all-reduce (upper triangles are what counts).  The deferred BatchNorm
+        scales are applied HERE, before the exchange: ``diag(s) G diag(s)`` is linear in G, so scaled factors add
+        exactly, and a rank with an empty shard — which never learned a scale and contributes zeros — needs none."""
         self._flush_pixgrams()  # the assembled factors are what is exchanged, not the larger pixel-pair Grams
         self._flush_g_slabs()
+        self._apply_grad_scales()
         return [t for F in self.factors for t in F] + [self.loss]
 
     def finalize(self):

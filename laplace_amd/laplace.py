@@ -61,6 +61,15 @@ class ShardedLoader:
         from torch.utils.data import DataLoader
 
         if isinstance(ld, DataLoader) and ld.batch_sampler is not None:
+            from torch.utils.data import RandomSampler
+
+            smp = getattr(ld.batch_sampler, "sampler", None) or ld.sampler
+            if isinstance(smp, RandomSampler) and smp.generator is None and self.world_size > 1:
+                # every rank would draw ITS OWN permutation from its default RNG: the strided shards would overlap and
+                # miss samples, and the all-reduced curvature would be silently wrong
+                raise ValueError("ShardedLoader: the wrapped DataLoader shuffles without a `generator`; the ranks "
+                                 "cannot cut the same permutation. Use shuffle=False (the order of the data does not "
+                                 "matter to a curvature fit) or pass a torch.Generator seeded identically on all ranks.")
             return DataLoader(ld.dataset, batch_sampler=_StridedBatches(ld.batch_sampler, self.rank, self.world_size),
                               num_workers=ld.num_workers, collate_fn=ld.collate_fn, pin_memory=ld.pin_memory,
                               timeout=ld.timeout, worker_init_fn=ld.worker_init_fn,
@@ -144,6 +153,20 @@ def allreduce_curvature(tensors: list[torch.Tensor], group=None, mirror: bool = 
         else:
             t.copy_(flat[off:off + n].view_as(t))
         off += n
+
+
+def _share_n_outputs(la, group=None) -> None:
+    """A rank whose shard was empty never ran the model: it learns the output width (``n_outputs`` /
+    ``model.output_size``, which the reference's ``fit`` sets from its first minibatch, baselaplace.py:955-963) from
+    the ranks that did.  One tiny MAX all-reduce, issued by every rank right after the curvature exchange."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    dev = la._device if dist.get_backend(group) == "nccl" else "cpu"
+    n = torch.tensor([int(la.n_outputs or 0)], dtype=torch.int64, device=dev)
+    dist.all_reduce(n, op=dist.ReduceOp.MAX, group=group)
+    if la.n_outputs is None and int(n.item()) > 0:
+        la.n_outputs = int(n.item())
+        setattr(la.model, "output_size", la.n_outputs)
 
 
 class _HipLaplace:
@@ -646,6 +669,7 @@ class HipKronLaplace(_HipLaplace):
             if distributed:
                 acc.ensure_allocated(self._device)  # a rank whose shard is empty contributes zeros
                 allreduce_curvature(acc.tensors(), group=process_group, mirror=False)  # finalize() mirrors
+                _share_n_outputs(self, process_group)
             self.loss, self.H = acc.finalize()
             self.n_data = N
             self._posterior_cache = None
@@ -863,6 +887,7 @@ def fit_kron(la, train_loader, process_group=None, distributed: bool | None = No
     if distributed:
         acc.ensure_allocated(la._device)  # a rank whose shard is empty contributes zeros
         allreduce_curvature(acc.tensors(), group=process_group, mirror=False)  # finalize() mirrors
+        _share_n_outputs(la, process_group)
     la.loss, la.H_facs = acc.finalize()
     la.n_data = N
     la.H = la.H_facs.decompose(damping=la.damping, distributed=bool(distributed), process_group=process_group)

@@ -37,10 +37,51 @@ def _identity_seeds(f: torch.Tensor) -> torch.Tensor:
 
 def _grads(grad_fn, seeds):
     """output gradients of all taps; the NHWC sweep hands conv taps over as split tensors (no layout conversion)"""
-    try:
+    if getattr(grad_fn, "accepts_keep_split", False):
         return grad_fn(seeds, keep_split=True)
-    except TypeError:  # autograd-tape grad_fn
-        return grad_fn(seeds)
+    return grad_fn(seeds)  # autograd-tape / last-layer grad_fn
+
+
+#: largest spread (in powers of two) of the per-sample input magnitudes that one sweep takes: the split-fp16 tensors of
+#: the sweep carry ONE scale per tensor (csrc/lk_conv.hip), whose fixed-point floor is 2^-39 of the tensor's largest
+#: element — a sample 2^-16 below the largest one still keeps 2^-23 of ITS OWN maximum, and the quadratic growth of the
+#: variance with the activations is covered twice over.  Wider minibatches are swept in magnitude groups.
+RANGE_GUARD_LOG2 = 16
+
+
+def _range_groups(x, max_log2: int = RANGE_GUARD_LOG2):
+    """``None`` (one sweep) or index tensors of sub-batches whose per-sample input magnitudes stay within
+    ``2^max_log2`` of each other.  The predictive is per sample (``f_var[n]`` must be right relative to ITS OWN size,
+    tests/test_baselaplace.py:334-410 of the reference compare element-wise), unlike the factors of a fit, which are
+    sums over the minibatch.  Costs one [B]-float read-back per call."""
+    if not torch.is_tensor(x) or not x.is_floating_point() or x.dim() < 2 or x.shape[0] < 2:
+        return None
+    amax = x.detach().abs().reshape(x.shape[0], -1).amax(1).float()
+    e = torch.floor(torch.log2(amax.clamp_min(1e-38))).cpu()
+    if float(e.max() - e.min()) <= max_log2:
+        return None
+    order = torch.argsort(e)
+    groups, start = [], 0
+    for i in range(1, len(order) + 1):
+        if i == len(order) or float(e[order[i]] - e[order[start]]) > max_log2:
+            groups.append(order[start:i].sort().values.to(x.device))
+            start = i
+    return groups
+
+
+def _by_range_groups(fn, backend, x, *args):
+    """run a per-sample predictive over magnitude groups of the minibatch and put the rows back in order"""
+    groups = _range_groups(x) if getattr(backend, "range_guard", True) else None
+    if groups is None:
+        return None
+    f = fvar = None
+    for idx in groups:
+        f_g, v_g = fn(backend, x.index_select(0, idx).contiguous(), *args, _grouped=True)
+        if f is None:
+            f = f_g.new_empty(x.shape[0], *f_g.shape[1:])
+            fvar = v_g.new_empty(x.shape[0], *v_g.shape[1:])
+        f[idx], fvar[idx] = f_g, v_g
+    return f, fvar
 
 
 def _as_nchw(g, B, C):
@@ -100,11 +141,15 @@ def _shared_quadform(K, call, u, v, fvar, weight_sharing_only: bool):
     return True
 
 
-def glm_variance_kron(backend, x, post):
+def glm_variance_kron(backend, x, post, _grouped: bool = False):
     """``(f_mu, f_var)`` under a :class:`HipKronDecomposed` posterior precision ``post``
     (= ``H * H_factor + prior_precision``), i.e. KronLaplace.functional_variance."""
+    if not _grouped:
+        out = _by_range_groups(glm_variance_kron, backend, x, post)
+        if out is not None:
+            return out
     K = get_kernels()
-    f, tape, grad_fn = backend._forward(x)
+    f, tape, grad_fn = backend._forward(x, keep_tap_splits=True)  # the eigenbasis rotations re-use the split inputs
     if tape.uncovered or post.damping:
         raise NotImplementedError("fused Kron predictive needs Linear/Conv2d-only models and damping=False")
     B, C = f.shape
@@ -163,8 +208,12 @@ def glm_variance_kron(backend, x, post):
     return f, fvar
 
 
-def glm_variance_diag(backend, x, post_var: torch.Tensor):
+def glm_variance_diag(backend, x, post_var: torch.Tensor, _grouped: bool = False):
     """``(f_mu, f_var)`` under a diagonal posterior with variances ``post_var[P]``."""
+    if not _grouped:
+        out = _by_range_groups(glm_variance_diag, backend, x, post_var)
+        if out is not None:
+            return out
     K = get_kernels()
     f, tape, grad_fn = backend._forward(x)
     if tape.uncovered:

@@ -112,14 +112,80 @@ class SplitSweep(SeedBatchedSweep):
                     return f"{getattr(node.target, '__name__', node.target)} has no NHWC rule"
             elif node.op == "call_method" and node.target in ("mean", "size"):
                 return f"method {node.target} has no NHWC rule"
-        return None if n_conv else "no convolution in the graph"
+        if not n_conv:
+            return "no convolution in the graph"
+        return self._region_check()
+
+    # The reverse sweep must not fail half-way (`on_tap` has already added G factors by then): every structural
+    # condition `backward` would raise on is checked here, on the graph alone, so that such a model runs through the
+    # parent class's NCHW sweep from the start.
+    def _is_reshape(self, node) -> bool:
+        if node.op == "call_module":
+            return isinstance(self.modules[node.target], nn.Flatten)
+        if node.op == "call_function":
+            return node.target is torch.flatten
+        return node.op == "call_method" and node.target in ("view", "reshape", "flatten")
+
+    def _is_global_pool(self, node) -> bool:
+        if node.op == "call_module":
+            return isinstance(self.modules[node.target], nn.AdaptiveAvgPool2d)
+        return node.op == "call_function" and node.target is F.adaptive_avg_pool2d
+
+    def _is_feature_op(self, node) -> bool:
+        """produces / consumes NHWC feature maps"""
+        if node.op == "call_module" and isinstance(self.modules[node.target], (nn.Conv2d, nn.BatchNorm2d)):
+            return True
+        return self._is_global_pool(node)
+
+    def _passes_through(self, node) -> bool:
+        """shape-preserving nodes: the cotangent keeps the representation it arrives in"""
+        if node.op == "call_module":
+            return isinstance(self.modules[node.target], (nn.ReLU, nn.Tanh, nn.Sigmoid, nn.Identity, nn.Dropout)
+                              + self._GENERIC_ACT_MODULES)
+        if node.op == "call_function":
+            return (node.target in self._ELEMENTWISE_FN or node.target in self._GENERIC_ACT_FN
+                    or node.target in (operator.add, torch.add, operator.iadd))
+        return node.op == "call_method" and node.target in ("relu", "tanh", "sigmoid", "contiguous")
+
+    def _walk(self, start, downstream: bool):
+        """nodes reachable from ``start`` through shape-preserving nodes (users if ``downstream`` else inputs)"""
+        seen, todo, out = set(), [start], []
+        while todo:
+            n = todo.pop()
+            nxt = list(n.users) if downstream else [a for a in n.all_input_nodes]
+            for m in nxt:
+                if m in seen:
+                    continue
+                seen.add(m)
+                out.append(m)
+                if self._passes_through(m):
+                    todo.append(m)
+        return out
+
+    def _region_check(self):
+        for node in self.gm.graph.nodes:
+            if self._is_reshape(node) and any(self._is_feature_op(u) for u in self._walk(node, True)):
+                return f"{node.name}: view / reshape / flatten whose result is used as a feature map"
+            if self._is_global_pool(node):
+                users = list(node.users)
+                if len(users) != 1 or not self._is_reshape(users[0]):
+                    return f"{node.name}: pooled tensor with a consumer other than one flatten"
+            if node.op == "call_module" and isinstance(self.modules[node.target], nn.Linear):
+                if any(self._is_feature_op(a) and not self._is_global_pool(a) or a.op == "placeholder"
+                       for a in self._walk(node, False)):
+                    return f"{node.target}: Linear layer applied to a feature map"
+        return None
 
     # ---- forward: own convolution + fused BatchNorm/add/activation kernels on NHWC -----------------------------------
     #: ``False`` (env LK_NHWC_FORWARD=0): the forward stays on the library's NCHW convolutions
     nhwc_forward = __import__("os").environ.get("LK_NHWC_FORWARD", "1") != "0"
 
     @torch.no_grad()
-    def forward(self, x, need_vjp: bool = True):
+    def forward(self, x, need_vjp: bool = True, keep_tap_splits: bool = False):
+        """``keep_tap_splits``: keep the NHWC split copy of every tapped convolution's input (``tap_splits``) until
+        ``release()`` — only the Kron predictive's eigenbasis rotation reads it; a fit would hold a second
+        activation-sized copy through the whole reverse sweep for nothing."""
+        self._keep_tap_splits = keep_tap_splits
         self._aux = {}  # data_ptr of a feature map produced here -> {"amax": word} / {"split": SplitTensor, "bound": word}
         self.tap_splits = {}  # tap name -> NHWC SplitTensor of the tap's input (what its forward convolution consumed)
         self._fwd_words = None
@@ -159,7 +225,7 @@ class SplitSweep(SeedBatchedSweep):
         if prep is None:
             prep = self._prep[node.target] = cv.PreparedConv(m)
         xs = self._split_input(inp, pad_to=prep.padded_in if prep.padded_in != m.in_channels else None)
-        if node.target in self.tap_names and prep.padded_in == m.in_channels:
+        if self._keep_tap_splits and node.target in self.tap_names and prep.padded_in == m.in_channels:
             # consumers of the tap's input that run our convolution on it again (the Kron predictive's eigenbasis
             # rotation) take the split copy instead of measuring and splitting the activation a second time
             self.tap_splits[node.target] = xs

@@ -1,4 +1,5 @@
-"""Import the UNMODIFIED reference package from /root/reference (this container only).
+"""Import the UNMODIFIED reference package from /root/reference (this container), or from the archive of it that
+`stage_reference()` packed into the git-ignored oracle/_ref/ (GPU box).
 
 TEST INFRASTRUCTURE - not product code.  Only `oracle/make_golden.py` and the
 `not gpu` oracle-pinning tests use this, and only where `/root/reference` exists.
@@ -17,10 +18,52 @@ import sys
 import types
 
 REFERENCE_ROOT = "/root/reference"
+#: ``oracle/_ref/`` is git-ignored (never in history) but travels with a `gpurun` snapshot: `stage_reference()` packs the
+#: reference's `laplace/` package there so that the ONE test of the reference's own classes on the real kernels
+#: (tests/test_gpu_dropin_reference.py) can execute on the GPU box, where /root/reference does not exist.  The archive
+#: is made from the sources where they lie; nothing of it is ever committed.
+STAGED_ARCHIVE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "laplace_reference.tgz")
+_unpacked = None
+
+
+def stage_reference() -> str | None:
+    """(this container only) pack /root/reference/laplace into oracle/_ref/; returns the archive path or None"""
+    import tarfile
+
+    src = os.path.join(REFERENCE_ROOT, "laplace")
+    if not os.path.isdir(src):
+        return None
+    os.makedirs(os.path.dirname(STAGED_ARCHIVE), exist_ok=True)
+    newest = max(os.path.getmtime(os.path.join(d, f)) for d, _, fs in os.walk(src) for f in fs if f.endswith(".py"))
+    if os.path.exists(STAGED_ARCHIVE) and os.path.getmtime(STAGED_ARCHIVE) >= newest:
+        return STAGED_ARCHIVE
+    with tarfile.open(STAGED_ARCHIVE, "w:gz") as tar:
+        tar.add(src, arcname="laplace", filter=lambda ti: None if "__pycache__" in ti.name else ti)
+    return STAGED_ARCHIVE
+
+
+def reference_root() -> str | None:
+    """directory that holds the reference's `laplace` package: /root/reference, or the staged archive unpacked into a
+    temporary directory (GPU box)"""
+    global _unpacked
+    if os.path.isdir(os.path.join(REFERENCE_ROOT, "laplace")):
+        return REFERENCE_ROOT
+    if _unpacked is not None:
+        return _unpacked
+    if os.path.exists(STAGED_ARCHIVE):
+        import tarfile
+        import tempfile
+
+        dst = tempfile.mkdtemp(prefix="lk_reference_")
+        with tarfile.open(STAGED_ARCHIVE, "r:gz") as tar:
+            tar.extractall(dst)
+        _unpacked = dst
+        return dst
+    return None
 
 
 def reference_available() -> bool:
-    return os.path.isdir(os.path.join(REFERENCE_ROOT, "laplace"))
+    return reference_root() is not None
 
 
 def _shell(name: str, **attrs) -> types.ModuleType:
@@ -85,11 +128,12 @@ def _install_stubs() -> None:
 
 def import_reference():
     """Return the reference `laplace` package (raises if /root/reference is absent)."""
-    if not reference_available():
-        raise ImportError(f"{REFERENCE_ROOT} not present on this machine")
+    root = reference_root()
+    if root is None:
+        raise ImportError(f"{REFERENCE_ROOT} not present on this machine (and no staged archive under oracle/_ref/)")
     _install_stubs()
-    if REFERENCE_ROOT not in sys.path:
-        sys.path.insert(0, REFERENCE_ROOT)
+    if root not in sys.path:
+        sys.path.insert(0, root)
     import laplace  # noqa: WPS433
 
     return laplace

@@ -20,7 +20,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, hs, out_path, bs=2):
+def _worker(rank, world, port, hs, out_path, bs=2, fixture="resnetish"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -30,13 +30,14 @@ def _worker(rank, world, port, hs, out_path, bs=2):
         from tests.emulated_kernels import EmulatedKernels
 
         _lib.set_kernels_for_testing(EmulatedKernels())
-        g = load_golden("resnetish", "classification")
-        model, X, y = golden_model("resnetish", g, dtype=torch.float32)
+        g = load_golden(fixture, "classification")
+        model, X, y = golden_model(fixture, g, dtype=torch.float32)
         loader = ShardedLoader(DataLoader(TensorDataset(X, y), batch_size=bs), rank, world)
         la = HipLaplace(model, "classification", "all", hs, prior_precision=0.7)
         la.fit(loader)
         if hs == "kron":  # every rank keeps the FULL decomposition although it solved only its share
-            torch.save({"l": la.H.eigenvalues, "Q": la.H.eigenvectors}, f"{out_path}.eig{rank}")
+            torch.save({"l": la.H.eigenvalues, "Q": la.H.eigenvectors, "n_outputs": la.n_outputs,
+                        "output_size": getattr(la.model, "output_size", None)}, f"{out_path}.eig{rank}")
         if rank == 0:
             payload = {"loss": la.loss, "n_data": la.n_data}
             if hs == "kron":
@@ -49,23 +50,27 @@ def _worker(rank, world, port, hs, out_path, bs=2):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("hs,world,bs", [("kron", 2, 2), ("diag", 2, 2), ("full", 2, 2),
-                                         ("kron", 3, 3),   # ragged last batch (3 + 3 + 3 + 1), uneven shards (2, 1, 1)
-                                         ("kron", 3, 5),   # two batches for three ranks: rank 2 has an EMPTY shard
-                                         ("full", 3, 3)])
-def test_sharded_fit_equals_single_process(tmp_path, hs, world, bs):
+@pytest.mark.parametrize("hs,world,bs,fixture", [
+    ("kron", 2, 2, "resnetish"), ("diag", 2, 2, "resnetish"), ("full", 2, 2, "resnetish"),
+    ("kron", 3, 3, "resnetish"),   # ragged last batch (3 + 3 + 3 + 1), uneven shards (2, 1, 1)
+    ("kron", 3, 5, "resnetish"),   # two batches for three ranks: rank 2 has an EMPTY shard
+    # conv -> eval-BatchNorm taps: the G factors carry a DEFERRED BatchNorm scale that an empty rank never learns; it
+    # must be applied before the exchange (the sharded eigendecomposition then runs on that rank's copy of the sums)
+    ("kron", 3, 5, "bnres"), ("kron", 4, 4, "bnres"),
+    ("full", 3, 3, "resnetish")])
+def test_sharded_fit_equals_single_process(tmp_path, hs, world, bs, fixture):
     from laplace_amd import _lib
     from laplace_amd.laplace import HipLaplace
     from tests.emulated_kernels import EmulatedKernels
 
     out = str(tmp_path / "rank0.pt")
-    mp.spawn(_worker, args=(world, _free_port(), hs, out, bs), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), hs, out, bs, fixture), nprocs=world, join=True)
     got = torch.load(out, weights_only=False)
 
     prev = _lib.set_kernels_for_testing(EmulatedKernels())
     try:
-        g = load_golden("resnetish", "classification")
-        model, X, y = golden_model("resnetish", g, dtype=torch.float32)
+        g = load_golden(fixture, "classification")
+        model, X, y = golden_model(fixture, g, dtype=torch.float32)
         la = HipLaplace(model, "classification", "all", hs, prior_precision=0.7)
         la.fit(DataLoader(TensorDataset(X, y), batch_size=bs), distributed=False)
         ref_marglik = la.log_marginal_likelihood() if hs == "kron" else None
@@ -82,6 +87,7 @@ def test_sharded_fit_equals_single_process(tmp_path, hs, world, bs):
         # decomposition of every factor
         e0 = torch.load(out + ".eig0", weights_only=False)
         e1 = torch.load(out + f".eig{world - 1}", weights_only=False)
+        assert e1["n_outputs"] == e0["n_outputs"] == la.n_outputs and e1["output_size"] == la.n_outputs
         for F_, ls0, ls1, Qs0, Qs1 in zip(la.H_facs.kfacs, e0["l"], e1["l"], e0["Q"], e1["Q"]):
             for Hi, l0, l1, Q0, Q1 in zip(F_, ls0, ls1, Qs0, Qs1):
                 assert torch.equal(l0, l1) and torch.equal(Q0, Q1)
@@ -154,3 +160,18 @@ def test_unsharded_loader_under_an_initialised_process_group_stays_local(tmp_pat
     for F_, G_ in zip(got["H"], la.H_facs.kfacs):
         for a, b in zip(F_, G_):
             torch.testing.assert_close(a, b)
+
+
+def test_sharded_loader_refuses_a_shuffle_that_the_ranks_cannot_reproduce():
+    from laplace_amd.laplace import ShardedLoader
+
+    ds = TensorDataset(torch.arange(12.0).reshape(12, 1), torch.zeros(12))
+    with pytest.raises(ValueError, match="generator"):
+        iter(ShardedLoader(DataLoader(ds, batch_size=2, shuffle=True), 0, 2))
+    # a shared generator is fine: both ranks cut the same permutation, and together they see every sample once
+    seen = []
+    for rank in range(2):
+        ld = DataLoader(ds, batch_size=2, shuffle=True, generator=torch.Generator().manual_seed(5))
+        seen += [float(v) for X, _ in ShardedLoader(ld, rank, 2) for v in X.reshape(-1)]
+    assert sorted(seen) == [float(i) for i in range(12)]
+    assert len(list(ShardedLoader(DataLoader(ds, batch_size=2), 0, 1))) == 6

@@ -1,7 +1,8 @@
 """The UNMODIFIED reference's classes and the real HIP kernels in one process: ``laplace.Laplace(model, ...,
 backend=HipGGN)`` on the MI355X, against the golden outputs of the reference's own backends.  Needs a GPU AND the
-reference checkout, so it is skipped on the driver's GPU box (no /root/reference there) and on the CPU-only build
-container; `tests/test_dropin_reference.py` covers the same seam on the kernel emulation, `tests/test_gpu_backend.py`
+reference's package: on the GPU box (no /root/reference) it is unpacked from the archive that `build()` stages under
+the git-ignored oracle/_ref/ (oracle/ref_import.py: stage_reference — made from the sources where they lie, never
+committed).  `tests/test_dropin_reference.py` covers the same seam on the kernel emulation, `tests/test_gpu_backend.py`
 the same kernels behind the mirrored classes."""
 import importlib
 
@@ -12,7 +13,7 @@ from torch.utils.data import DataLoader, TensorDataset
 from oracle.ref_import import reference_available
 from tests.conftest import golden_kfacs, golden_model, load_golden
 
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not reference_available(), reason="/root/reference not present")]
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not reference_available(), reason="neither /root/reference nor oracle/_ref/laplace_reference.tgz")]
 DEV = "cuda"
 
 

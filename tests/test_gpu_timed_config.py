@@ -1,0 +1,201 @@
+"""Parity of the configuration bench.py TIMES (-m gpu): >= 10 minibatches of 128 through ``KronAccumulator`` with its
+DEFAULT settings — pixel-pair groups of 8 drained with buffer reuse (full group + ragged remainder), factor kernels
+lagging one minibatch on the side stream, persistent accumulators, batch-128 tile selection — against
+
+* fp64 Gram matrices of the SAME minibatches' activations / output gradients, taken from a stock-autograd tape of the
+  model (library convolutions, one reverse pass per seed: nothing of the fused path), i.e. what
+  laplace/curvature/curvlinops.py:77-108 + ``self.H += H_batch`` (laplace/baselaplace.py:984-985) accumulate;
+* the same minibatches through the accumulator with every scheduling feature off (``LK_PIX_GROUP=1``,
+  ``LK_LAG_JOIN=0``, no side stream).
+
+Tolerance: 1e-4, each factor block relative to ITS OWN largest element (tests/test_curv_backends_curvlinops.py:207-305
+of the reference compare element-wise at rtol 1e-4 / 1e-5; a block-wise bar is the strictest norm-wise form that the
+K4 scalar split of utils/matrix.py:100-118 permits)."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+# LK_TEST_DEVICE=cpu: self-check of this file's host logic on the kernel emulation (GPU-less box), tiny minibatches
+DEV = os.environ.get("LK_TEST_DEVICE", "cuda")
+N = 50_000
+BATCH = 128 if DEV != "cpu" else 2
+
+
+@pytest.fixture(autouse=True, scope="module")
+def _kernels():
+    if DEV != "cpu":
+        yield
+        return
+    from laplace_amd import _lib
+    from tests.emulated_kernels import EmulatedKernels
+
+    prev = _lib.set_kernels_for_testing(EmulatedKernels())
+    yield
+    _lib.set_kernels_for_testing(prev)
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return (a - b).abs().max().item() / (b.abs().max().item() + 1e-300)
+
+
+def _batch(i):
+    g = torch.Generator().manual_seed(1000 + i)
+    return torch.randn(BATCH, 3, 32, 32, generator=g).to(DEV), torch.randint(10, (BATCH,), generator=g).to(DEV)
+
+
+@pytest.fixture(scope="module", params=["relu", "tanh"])
+def resnet(request):
+    """ReLU is what bench.py times.  Two separately executed forward passes of a ReLU network flip the few
+    pre-activations that sit within fp32 rounding of zero, which moves individual gradients by
+    O(1) and the factors — sums over 1408 x 10 x L outer products — by ~1e-5; tanh has no such effect and pins the
+    kernels themselves."""
+    from laplace_amd.nets import ResNet18
+
+    torch.manual_seed(711)
+    return ResNet18(10, act=torch.relu if request.param == "relu" else torch.tanh).to(DEV).eval()
+
+
+class _TapeGrams:
+    """per tap [G, A] in fp64 (A in F.unfold order, 1/(N L)) + the summed loss: stock autograd, fp64 products"""
+
+    def __init__(self, model, backend):
+        from laplace_amd.capture import Tape
+
+        self.tape = Tape(model, backend.params)
+        self.refs = [[None, None] for _ in self.tape.taps]
+        self.has_bias = [t.has_bias for t in self.tape.taps]
+        self.loss = torch.zeros((), dtype=torch.float64, device=DEV)
+
+    def add(self, X, y):
+        from laplace_amd._lib import get_kernels
+
+        K, tape = get_kernels(), self.tape
+        f = tape.forward(X)
+        self.loss += F.cross_entropy(f.detach().double(), y, reduction="sum")
+        S = K.softmax_hess_sqrt(f.detach().contiguous(), y, None)  # symmetric root, C seeds: G is root-invariant
+        grads = tape.output_grads(f, S, stack=False)
+        for i, (tap, g) in enumerate(zip(tape.taps, grads)):
+            a = tap.a.double()
+            if tap.kind == "conv2d":
+                m = tap.module
+                cols = F.unfold(a, m.kernel_size, dilation=m.dilation, padding=m.padding, stride=m.stride)
+                L = cols.shape[-1]
+                A = torch.einsum("bil,bjl->ij", cols, cols) / (N * L)
+                g2 = torch.stack(g).double().reshape(-1, m.out_channels, L)
+                G = torch.einsum("bil,bjl->ij", g2, g2)
+                del cols, g2
+            else:
+                A = a.T @ a / N
+                g2 = g.double().reshape(-1, tap.module.out_features)
+                G = g2.T @ g2
+            r = self.refs[i]
+            r[0] = G if r[0] is None else r[0] + G
+            r[1] = A if r[1] is None else r[1] + A
+        del grads, f
+        tape.release()
+
+
+def test_eleven_minibatches_of_128_with_default_scheduling(resnet, monkeypatch):
+    from laplace_amd import HipGGN
+
+    n_batches = 11  # one full pixel-pair group of 8 (buffer reused) + a ragged remainder of 3
+    batches = [_batch(i) for i in range(n_batches)]
+    b = HipGGN(resnet, "classification")
+
+    # (1) the timed configuration: defaults, side stream, lagged join.  Interleaved with unrelated main-stream work
+    # (the tape's library kernels of the NEXT comparison) so that a missing stream dependency has something to race
+    # and with (3), the fp64 Grams of the same minibatches from a stock-autograd tape
+    acc = b.kron_accumulator(N)
+    assert acc.pix_group == 8 and acc.lag_join and acc.overlap, "defaults changed: update bench.py's `check` too"
+    ref = _TapeGrams(resnet, b)
+    for X, y in batches:
+        acc.add_batch(X, y)
+        ref.add(X, y)
+    loss, H = acc.finalize()
+
+    # (2) every scheduling feature off
+    monkeypatch.setenv("LK_PIX_GROUP", "1")
+    monkeypatch.setenv("LK_LAG_JOIN", "0")
+    ser = b.kron_accumulator(N, overlap=False)
+    assert ser.pix_group == 1 and not ser.lag_join and not ser.overlap
+    for X, y in batches:
+        ser.add_batch(X, y)
+    loss_s, H_s = ser.finalize()
+    assert rel(loss, loss_s) < 1e-6
+    worst = 0.0
+    for blk, (F_, S_) in enumerate(zip(H.kfacs, H_s.kfacs)):
+        for j, (a_, s_) in enumerate(zip(F_, S_)):
+            r = rel(a_, s_)
+            worst = max(worst, r)
+            assert r < 1e-5, f"default vs serial scheduling: block {blk} factor {j} (n={a_.shape[0]}) rel {r:.2e}"
+
+    # (3)
+    refs, has_bias, loss_ref = ref.refs, ref.has_bias, ref.loss
+    if DEV == "cpu" and resnet.act is torch.relu:
+        return  # 22 samples: a single ReLU flip between the two executions is 1e-3 of a factor; meaningful at 1408 only
+    assert rel(loss, loss_ref) < 1e-5
+    blk, worst_ref = 0, 0.0
+    for (G_ref, A_ref), hb in zip(refs, has_bias):
+        G, A = H.kfacs[blk]
+        for name, got, want in (("G", G, G_ref), ("A", A, A_ref)):
+            r = rel(got, want)
+            worst_ref = max(worst_ref, r)
+            assert r < 1e-4, f"tap {blk} {name} (n={got.shape[0]}): rel to the block's own max {r:.2e}"
+        blk += 1
+        if hb:
+            assert rel(H.kfacs[blk][0], G_ref) < 1e-4
+            blk += 1
+    assert blk == len(H.kfacs) == 22
+    print(f"timed configuration, {n_batches} x {BATCH}: default vs serial {worst:.2e}, vs fp64 tape Grams {worst_ref:.2e}")
+
+
+def test_two_consecutive_fits_reuse_the_side_stream_and_buffers(resnet):
+    """bench.py runs warm-up fit, timed fit, instrumented fit on ONE backend object: the second fit must not see
+    anything of the first (pixel-pair accumulators, pending groups, deferred BatchNorm scales, lagged events)."""
+    from laplace_amd import HipGGN
+
+    b = HipGGN(resnet, "classification")
+    batches = [_batch(20 + i) for i in range(3)]
+
+    def fit(bs):
+        acc = b.kron_accumulator(N)
+        for X, y in bs:
+            acc.add_batch(X, y)
+        return acc.finalize()
+
+    fit([_batch(40 + i) for i in range(9)])  # a different fit first; its last group is ragged (9 = 8 + 1)
+    loss1, H1 = fit(batches)
+    loss2, H2 = fit(batches)
+    assert torch.equal(loss1, loss2)
+    for F1, F2 in zip(H1.kfacs, H2.kfacs):
+        for a_, b_ in zip(F1, F2):
+            assert rel(a_, b_) < 1e-6  # (split-K partials are reduced in a fixed order: equal up to the launch geometry)
+
+
+def test_a_ragged_last_minibatch_as_in_a_50k_fit(resnet, monkeypatch):
+    """N = 50 000 = 390 x 128 + 80 (bench.py's fit_50k): the 80-sample minibatch ends the stacked pixel-pair group early
+    and runs other tile shapes; default scheduling against the serial one."""
+    from laplace_amd import HipGGN
+
+    b = HipGGN(resnet, "classification")
+    full = [_batch(60 + i) for i in range(3)]
+    rest = 80 if BATCH == 128 else 1
+    batches = full + [(full[0][0][:rest].contiguous(), full[0][1][:rest].contiguous())]
+    acc = b.kron_accumulator(N)
+    for X, y in batches:
+        acc.add_batch(X, y)
+    loss, H = acc.finalize()
+    monkeypatch.setenv("LK_PIX_GROUP", "1")
+    monkeypatch.setenv("LK_LAG_JOIN", "0")
+    ser = b.kron_accumulator(N, overlap=False)
+    for X, y in batches:
+        ser.add_batch(X, y)
+    loss_s, H_s = ser.finalize()
+    assert rel(loss, loss_s) < 1e-6
+    for F_, S_ in zip(H.kfacs, H_s.kfacs):
+        for a_, s_ in zip(F_, S_):
+            assert rel(a_, s_) < 1e-5

@@ -1,7 +1,8 @@
 """``backend.kron`` hands its minibatch over in the accumulator's raw form (laplace_amd/kron.py: HipKron._pending): the
 algebra of the reference's literal fit loop — ``H = Kron.init_from_model(..)``, ``H += backend.kron(X, y, N)[1]`` per
 minibatch (laplace/baselaplace.py:969-985) — must give what the eager, public-layout objects give, and must not change
-its operands.  CPU emulation of the kernels (the host logic is what is under test)."""
+its operands.  Every test runs twice: on the CPU emulation of the kernels (host logic, `not gpu` tier) and — marked
+``gpu`` — on the real library, where the raw forms are device buffers merged with a multi-tensor add."""
 import pytest
 import torch
 
@@ -9,11 +10,17 @@ from laplace_amd import _lib
 from tests.conftest import golden_model, load_golden
 from tests.emulated_kernels import EmulatedKernels
 
+DEVICES = [pytest.param("cpu", id="emulated"), pytest.param("cuda", id="hip", marks=pytest.mark.gpu)]
 
-@pytest.fixture(autouse=True)
-def _emulated():
+
+@pytest.fixture(params=DEVICES)
+def dev(request):
+    if request.param == "cuda":
+        assert isinstance(_lib.get_kernels(), _lib.HipKernels), "the real library, not the emulation"
+        yield "cuda"
+        return
     prev = _lib.set_kernels_for_testing(EmulatedKernels())
-    yield
+    yield "cpu"
     _lib.set_kernels_for_testing(prev)
 
 
@@ -26,11 +33,11 @@ def _close(a, b, tol=1e-6):
 
 
 @pytest.mark.parametrize("name", ["conv", "bnres", "mlp"])
-def test_lazy_minibatch_krons_equal_the_eager_ones(name):
+def test_lazy_minibatch_krons_equal_the_eager_ones(name, dev):
     from laplace_amd import HipGGN, HipKron
 
     g = load_golden(name, "classification")
-    model, X, y = golden_model(name, g, dtype=torch.float32)
+    model, X, y = golden_model(name, g, dtype=torch.float32, device=dev)
     N = X.shape[0]
     eager = HipGGN(model, "classification")
     eager.lazy_kron = False
@@ -67,14 +74,14 @@ def test_lazy_minibatch_krons_equal_the_eager_ones(name):
     assert len(k_raw) == len(k_raw.kfacs)
 
 
-def test_lazy_kron_survives_deepcopy_and_pickle():
+def test_lazy_kron_survives_deepcopy_and_pickle(dev):
     import copy
     import pickle
 
     from laplace_amd import HipGGN
 
     g = load_golden("conv", "classification")
-    model, X, y = golden_model("conv", g, dtype=torch.float32)
+    model, X, y = golden_model("conv", g, dtype=torch.float32, device=dev)
     k = HipGGN(model, "classification").kron(X[:5], y[:5], X.shape[0])[1]
     assert k._pending is not None
     c = copy.deepcopy(k)

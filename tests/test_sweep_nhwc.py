@@ -169,3 +169,58 @@ def test_kron_predictive_through_the_nhwc_rotations():
     assert n_fast["seed_major"] >= 6, n_fast  # every 32- / 64-channel convolution of the three blocks
     assert torch.allclose(f1, f2, atol=1e-6)
     assert (v1 - v2).abs().max() / v2.abs().max() < 2e-5
+
+
+class _ReshapeBetweenConvs(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.c1, self.c2 = nn.Conv2d(32, 32, 3, 1, 1, bias=False), nn.Conv2d(32, 32, 3, 1, 1, bias=False)
+        self.pool, self.fc = nn.AdaptiveAvgPool2d(1), nn.Linear(32, 3)
+
+    def forward(self, x):
+        h = torch.relu(self.c1(x))
+        h = h.reshape(-1, 32, 4, 4).contiguous()
+        return self.fc(torch.flatten(self.pool(torch.relu(self.c2(h))), 1))
+
+
+class _PoolWithTwoConsumers(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.c1, self.pool = nn.Conv2d(32, 32, 3, 1, 1, bias=False), nn.AdaptiveAvgPool2d(1)
+        self.fc1, self.fc2 = nn.Linear(32, 3), nn.Linear(32, 3)
+
+    def forward(self, x):
+        p = self.pool(torch.relu(self.c1(x)))
+        return self.fc1(torch.flatten(p, 1)) + self.fc2(torch.flatten(p, 1))
+
+
+class _LinearOnFeatureMap(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.c1, self.lin, self.pool, self.fc = nn.Conv2d(32, 32, 3, 1, 1, bias=False), nn.Linear(4, 4), nn.AdaptiveAvgPool2d(1), nn.Linear(32, 3)
+
+    def forward(self, x):
+        h = self.lin(torch.relu(self.c1(x)))  # Linear along the last (W) axis of the map
+        return self.fc(torch.flatten(self.pool(h), 1))
+
+
+@pytest.mark.parametrize("cls", [_ReshapeBetweenConvs, _PoolWithTwoConsumers, _LinearOnFeatureMap])
+def test_graphs_the_nhwc_walk_has_no_rule_for_are_rejected_before_any_gradient_is_handed_over(cls):
+    """`backward` of the NHWC path would raise half-way on these (after `on_tap` has already added G factors); the
+    static check sends them through the parent class's NCHW sweep instead, with the same results as autograd."""
+    torch.manual_seed(0)
+    model = cls().eval()
+    taps = {n: m for n, m in model.named_modules() if isinstance(m, (nn.Conv2d, nn.Linear))}
+    sweep = SplitSweep(model, taps, kernels=get_kernels)
+    assert not sweep.split_ok and sweep.split_reason
+    x = torch.randn(3, 32, 4, 4)
+    f = sweep.forward(x)
+    seeds = torch.eye(3)[:, None, :].expand(3, 3, 3).contiguous()
+    seen = []
+    grads = sweep.backward(seeds, on_tap=lambda n, g: seen.append(n))
+    assert sorted(seen) == sorted(taps)
+    f_ref, want = _autograd_tap_grads(model, taps, x, seeds)
+    assert torch.allclose(f, f_ref, atol=1e-5)
+    got = sweep.backward(seeds)
+    for n in taps:
+        assert torch.allclose(got[n].reshape(want[n].shape), want[n], atol=1e-5), n

@@ -2,11 +2,27 @@
 over the bench workload.  gfx950 correction per MI355X_MICROARCH.md (HBM section): FETCH_SIZE reports half of
 the bytes of wide coalesced streaming reads -> read bytes = 2 x FETCH_SIZE(KB) x 1024; WRITE_SIZE(KB) x 1024.
 usage: pmc_traffic.py fetch.db write.db out.json out.md"""
+import hashlib
 import json
+import os
 import re
 import sqlite3
+import subprocess
 import sys
 from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def csrc_sha16(root=ROOT):
+    """hash of the kernel sources the counters were collected on (bench.py refuses a table made from other sources)"""
+    h = hashlib.sha256()
+    d = os.path.join(root, "laplace_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def short(name):
@@ -44,6 +60,12 @@ def main(fetch_db, write_db, out_json, out_md):
                   "hbm_write_bytes": wr, "hbm_bytes_per_launch": rd + wr}
         lines.append(f"| `{k}` | {len(f[k])} | {sum(dur[k]) / len(dur[k]) / 1e3:.1f} | {fk:.4g} | {wk:.4g} | {rd / 1e6:.2f} | "
                      f"{wr / 1e6:.2f} | {(rd + wr) / 1e6:.2f} |")
+    try:
+        head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
+    except OSError:
+        head = ""
+    res["_meta"] = {"csrc_sha16": csrc_sha16(), "git_head": head or None,
+                    "note": "git_head is empty on the GPU box (the snapshot has no .git): csrc_sha16 is the stamp"}
     json.dump(res, open(out_json, "w"), indent=1)
     open(out_md, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
