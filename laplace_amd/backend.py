@@ -117,6 +117,34 @@ def shared_operands(tap, g, B, C, Q1=None, Q2=None, bounds=None):
     return u.contiguous(), v.contiguous(), gsum
 
 
+#: largest spread (in powers of two) of the per-sample input magnitudes that one sweep takes: the split-fp16 tensors of
+#: the sweep carry ONE scale per tensor (csrc/lk_conv.hip), whose fixed-point floor is 2^-39 of the tensor's largest
+#: element — a sample 2^-16 below the largest one still keeps 2^-23 of ITS OWN maximum, and the quadratic growth of the
+#: variance with the activations is covered twice over.  Wider minibatches are swept in magnitude groups.
+RANGE_GUARD_LOG2 = 16
+
+
+def range_groups(x, max_log2: int = RANGE_GUARD_LOG2):
+    """``None`` (one sweep) or index tensors of sub-batches whose per-sample input magnitudes stay within
+    ``2^max_log2`` of each other.  The predictive is per sample (``f_var[n]`` must be right relative to ITS OWN size,
+    tests/test_baselaplace.py:334-410 of the reference compare element-wise), unlike the factors of a fit, which are
+    sums over the minibatch.  Costs one [B]-float read-back per call."""
+    if not torch.is_tensor(x) or not x.is_floating_point() or x.dim() < 2 or x.shape[0] < 2:
+        return None
+    amax = x.detach().abs().reshape(x.shape[0], -1).amax(1).float()
+    e = torch.floor(torch.log2(amax.clamp_min(1e-38))).cpu()
+    if float(e.max() - e.min()) <= max_log2:
+        return None
+    order = torch.argsort(e)
+    groups, start = [], 0
+    for i in range(1, len(order) + 1):
+        if i == len(order) or float(e[order[i]] - e[order[start]]) > max_log2:
+            groups.append(order[start:i].sort().values.to(x.device))
+            start = i
+    return groups
+
+
+
 class CachedFeatures:
     """Head input ``phi [B, D]`` and output ``f [B, C]`` of one batch; accepted wherever a last-layer backend takes ``x``."""
 
@@ -131,6 +159,13 @@ class CachedFeatures:
 
 class _HipCurvatureMixin:
     """Shared machinery of :class:`HipGGN` and :class:`HipEF`."""
+
+    #: What happens when the samples of ONE minibatch differ by more than ``2**RANGE_GUARD_LOG2`` in input magnitude
+    #: (the split-fp16 tensors of the sweep carry one scale per tensor, see :func:`range_groups`):
+    #: ``"check"`` (default) — per-sample results (predictive, Jacobians) sweep such a minibatch in magnitude groups; a fit
+    #: records the spread on the device (no sync per step) and RAISES at the end if a minibatch was outside the range;
+    #: ``"group"`` — fits also sweep in magnitude groups (exact, costs one read-back per minibatch); ``"off"`` — no check.
+    range_guard = "check"
 
     # ---- forward / taps -------------------------------------------------------------------------
     def _tape(self) -> Tape:
@@ -250,7 +285,7 @@ class _HipCurvatureMixin:
             t.a = sweep.taps[t.name]["a"]
             t.a_split = getattr(sweep, "tap_splits", {}).get(t.name)  # NHWC SplitTensor of the same activation, if any
 
-        def grad_fn(seeds, stack=True, on_tap=None, defer_bn_scale=False, keep_split=False):
+        def grad_fn(seeds, stack=True, on_tap=None, defer_bn_scale=False, keep_split=False, fuse_gram=False):
             """All seeds in one sweep while ``S*B`` stays below ``sweep_max_rows`` images; many-output models
             (C = 1000 -> 999 seeds) go through in seed chunks of that size.  With ``on_tap`` every chunk's gradients
             are handed over layer by layer (additive consumers such as the KFAC accumulator) and nothing is returned."""
@@ -262,6 +297,8 @@ class _HipCurvatureMixin:
             if S <= chunk:
                 if keep_split and isinstance(sweep, SplitSweep):  # NHWC SplitTensors for consumers that take them
                     grads = sweep.backward(seeds, on_tap=on_tap, defer_bn_scale=defer_bn_scale, keep_split=True)
+                elif fuse_gram and isinstance(sweep, SplitSweep):
+                    grads = sweep.backward(seeds, on_tap=on_tap, defer_bn_scale=defer_bn_scale, fuse_gram=True)
                 else:
                     grads = sweep.backward(seeds, on_tap=on_tap, defer_bn_scale=defer_bn_scale)
                 return [grads[t.name] for t in tape.taps]
@@ -392,6 +429,11 @@ class _HipCurvatureMixin:
         m = tap.module
         if isinstance(g, SplitTensor):  # NHWC split cotangent [S*B, H, W, Do] of the split-fp16 sweep
             Do = g.shape[-1]
+            if kfac_approx == "expand" and g.gram_parts is not None:
+                K.gram_partials_reduce(g, alpha_g, G)  # the producing launch accumulated the Gram already
+                if not fused:
+                    K.symmetrize(G)
+                return G
             if kfac_approx == "expand" and (Do == 64 or Do % 128 == 0):
                 K.gram_tn_f16x2(g, alpha_g, G)  # upper 32x32 tiles; mirrored by the caller (symmetrize)
                 if not fused:
@@ -577,6 +619,7 @@ class KronAccumulator:
         self.factors = None  # per tap: [G, A]
         self.loss = None
         self._taps_meta = None
+        self._range_tab, self._range_n, self._range_full = None, 0, []  # see _note_range
 
     def _alloc(self, tape, dev):
         self.factors, self._taps_meta = [], []
@@ -713,6 +756,50 @@ class KronAccumulator:
 
     def add_batch(self, x, y):
         b = self.backend
+        mode = getattr(b, "range_guard", "check")
+        if mode not in (False, "off") and torch.is_tensor(x) and x.is_floating_point() and x.dim() >= 2 and x.shape[0] > 1:
+            if mode == "group":
+                groups = range_groups(x)  # (one read-back; the sum over samples is additive, so sub-minibatches are exact)
+                if groups is not None:
+                    for idx in groups:
+                        self._add_batch(x.index_select(0, idx).contiguous(), y.index_select(0, idx).contiguous())
+                    return
+            elif x.dtype == torch.float32 and x.is_contiguous():
+                self._note_range(x)
+        self._add_batch(x, y)
+
+    def _note_range(self, x):
+        """record max / min-nonzero of the per-sample input magnitudes of this minibatch in a device table (one tiny
+        launch, no synchronisation); :meth:`_check_range` reads the table once, when the fit ends"""
+        cap = 1024
+        if self._range_tab is None or self._range_n == cap:
+            if self._range_tab is not None:
+                self._range_full.append(self._range_tab)
+            tab = torch.empty(cap, 2, dtype=torch.int32, device=x.device)
+            tab[:, 0] = 0
+            tab[:, 1] = 0x7F800000
+            self._range_tab, self._range_n = tab, 0
+        get_kernels().range_words(x, self._range_tab[self._range_n])
+        self._range_n += 1
+
+    def _check_range(self):
+        tabs = list(self._range_full) + ([self._range_tab[:self._range_n]] if self._range_tab is not None else [])
+        self._range_tab, self._range_n, self._range_full = None, 0, []
+        if not tabs:
+            return
+        w = torch.cat(tabs).cpu().view(torch.float32)
+        bad = (w[:, 0] > 0) & (w[:, 0] > w[:, 1] * float(2 ** RANGE_GUARD_LOG2))
+        if bool(bad.any()):
+            i = int(bad.nonzero()[0])
+            raise RuntimeError(
+                f"minibatch {i} of this fit mixes samples whose input magnitudes differ by "
+                f"{float(w[i, 0] / w[i, 1]):.1e} (max|x_n| from {float(w[i, 1]):.1e} to {float(w[i, 0]):.1e}): beyond the "
+                f"2^{RANGE_GUARD_LOG2} the split-fp16 sweep resolves per sample with one scale per tensor. Set "
+                "`backend.range_guard = 'group'` (such minibatches are then swept in magnitude groups; exact), normalise "
+                "the inputs, or `'off'` to accept reduced accuracy of the small-magnitude samples.")
+
+    def _add_batch(self, x, y):
+        b = self.backend
         f, tape, grad_fn = b._forward(x)
         if tape.uncovered:
             raise NotImplementedError("KFAC supports nn.Linear / nn.Conv2d parameters only")
@@ -760,8 +847,10 @@ class KronAccumulator:
                 (g.planes if isinstance(g, SplitTensor) else g).record_stream(side)  # allocated on main, read on side
                 if isinstance(g, SplitTensor) and torch.is_tensor(g.sexp):
                     g.sexp.record_stream(side)
+                if isinstance(g, SplitTensor) and g.gram_parts is not None:
+                    g.gram_parts.record_stream(side)
 
-            grad_fn(seeds, stack=False, on_tap=on_tap, defer_bn_scale=defer)
+            grad_fn(seeds, stack=False, on_tap=on_tap, defer_bn_scale=defer, fuse_gram=self.kfac_approx == "expand")
         else:
             grads = grad_fn(seeds, stack=False)
             for tap, g, F in zip(tape.taps, grads, self.factors):
@@ -844,6 +933,9 @@ class KronAccumulator:
         self._join_side()
         other._join_side()
         torch._foreach_add_(self._raw_tensors(), other._raw_tensors())
+        # (the merged minibatches' magnitude records come along: checked when the sum is finalised)
+        if other._range_tab is not None:
+            self._range_full += list(other._range_full) + [other._range_tab[:other._range_n]]
         return True
 
     def _join_side(self):
@@ -884,6 +976,7 @@ class KronAccumulator:
         """Everything a data-parallel fit has to all-reduce (upper triangles are what counts).  The deferred BatchNorm
         scales are applied HERE, before the exchange: ``diag(s) G diag(s)`` is linear in G, so scaled factors add
         exactly, and a rank with an empty shard — which never learned a scale and contributes zeros — needs none."""
+        self._check_range()
         self._flush_pixgrams()  # the assembled factors are what is exchanged, not the larger pixel-pair Grams
         self._flush_g_slabs()
         self._apply_grad_scales()
@@ -893,6 +986,7 @@ class KronAccumulator:
         """-> (loss, HipKron) in the reference's layout (laplace/curvature/curvlinops.py:55-75)."""
         K = get_kernels()
         rt = math.sqrt(float(self.backend.factor))
+        self._check_range()
         self._flush_pixgrams()
         self._flush_g_slabs()
         self._apply_grad_scales()
@@ -1003,7 +1097,16 @@ class HipGGN(_HipCurvatureMixin, GGNInterface):
             eye = torch.eye(C, dtype=f.dtype, device=f.device)
             return eye[:, None, :].expand(C, B, C).contiguous()
 
-        Js, f = self._rows(x, seeds_fn)
+        groups = range_groups(x) if self.range_guard not in (False, "off") else None
+        if groups is None:
+            Js, f = self._rows(x, seeds_fn)
+        else:  # per-sample results: a minibatch of very different magnitudes is swept in magnitude groups (range_groups)
+            Js = f = None
+            for idx in groups:
+                J_g, f_g = self._rows(x.index_select(0, idx).contiguous(), seeds_fn)
+                if Js is None:
+                    Js, f = J_g.new_empty(x.shape[0], *J_g.shape[1:]), f_g.new_empty(x.shape[0], *f_g.shape[1:])
+                Js[idx], f[idx] = J_g, f_g
         if self.subnetwork_indices is not None:
             Js = Js[:, :, self.subnetwork_indices]
         return Js, f

@@ -31,9 +31,13 @@
 // device word (what the next producer needs to choose ITS scale).
 #include "lk_common.h"
 
+#include <type_traits>
+
 namespace lk {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // ---- power-of-two scaling -------------------------------------------------------------------------------------------
@@ -69,6 +73,25 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
   if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+// ---- spread of the per-sample magnitudes of a minibatch: words[0] = max over samples of max|x_n|, words[1] = min over
+//      the samples that are not identically zero (bit patterns; atomicMax / atomicMin are order-independent).  The split
+//      tensors of a sweep carry ONE scale per tensor: a minibatch whose samples differ by more than ~2^16 in magnitude is
+//      outside what that scheme resolves per sample, and the host checks these words for it (once per fit, no sync per step).
+__global__ __launch_bounds__(256) void range_words_kernel(const float* __restrict__ x, int64_t per, unsigned* __restrict__ words) {
+  const float* xs = x + (int64_t)blockIdx.x * per;
+  unsigned m = 0;
+  for (int64_t i = threadIdx.x; i < per; i += 256) m = max(m, __float_as_uint(xs[i]) & 0x7fffffffu);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
+  __shared__ unsigned red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = max(max(red[0], red[1]), max(red[2], red[3]));
+    if (m) atomicMax(words, m), atomicMin(words + 1, m);
+  }
 }
 
 // ---- fp32 [rows][C] (NHWC) -> two fp16 planes, scale from the device-side bound `amax[0]` (* bound_mul) --------------
@@ -186,15 +209,32 @@ struct ConvVjp {
   int* out_sexp;
 };
 
-template <typename CFG, bool FUSE>
+// GRAM (fused epilogue, Co == BN == 64, one wave = 64 pixels x all 64 channels): the launch ALSO accumulates the Gram of
+// what it emits — o^T o over every output pixel, i.e. the G factor of the layer whose output cotangent this launch
+// produces (laplace/curvature/curvlinops.py:57-62: the hook that sums g g^T over (sample, position)) — instead of
+// leaving it to a separate pass that re-reads the whole cotangent from HBM (lk_gram_tn_f16x2: 302 MB per 64-channel
+// ResNet-18 layer and minibatch).  Each wave stages the fp16 planes of its 64 x 64 block in its own part of the epilogue
+// image (the layout lk_sweep16.hip's gram16_kernel reads through ds_read_b64_tr_b16) and runs the three upper 32 x 32
+// tiles of the 64 x 64 product on them; the sums stay in registers while the workgroup walks through `tiles_per_wg`
+// consecutive pixel tiles (the grid is ONE round of workgroups), and leave as one 64 x 64 partial per workgroup
+// (gram_ws[workgroup][64][64], upper tiles), summed in a fixed order by gram16_reduce_kernel.
+template <typename CFG, bool FUSE, bool GRAM = false>
 __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WPE, CFG::WPE))) void conv_f16x2_kernel(const ConvGeom g, const _Float16* __restrict__ Ah,
                                                          const _Float16* __restrict__ Al, const _Float16* __restrict__ Wh,
                                                          const _Float16* __restrict__ Wl, const int* __restrict__ a_sexp,
                                                          const int* __restrict__ w_sexp, const _Float16* __restrict__ zero16,
                                                          float* __restrict__ out, int accumulate,
-                                                         unsigned* __restrict__ amax_out, int nb_m, int ablate,
-                                                         const ConvVjp fz) {
+                                                         unsigned* __restrict__ amax_out, int nb_m, int ablate_arg,
+                                                         const ConvVjp fz, int tiles_per_wg, int n_tiles,
+                                                         float* __restrict__ gram_ws) {
   constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK, Q = CFG::Q, TM = CFG::TM, TN = CFG::TN, NT = CFG::NT;
+  static_assert(!GRAM || (FUSE && CFG::WN == 1 && TN == 2 && TM == 2 && CFG::WM == 4), "GRAM: one wave = 64 rows x 64 channels");
+#ifdef LK_CONV_DEV  // development switches (skip stores / MFMAs / staging, K order, ...): compiled out of the shipped kernel
+  const int ablate = ablate_arg;
+#else
+  constexpr int ablate = 0;
+  (void)ablate_arg;
+#endif
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // XCD-aware tile order: consecutive block ids run on different XCDs (id % 8); give every XCD a contiguous range of
@@ -205,15 +245,29 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
     const int q = nblk / 8, r = nblk % 8, x = bid % 8, j = bid / 8;
     bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
   }
-  const int tile_n = bid / nb_m, tile_m = bid % nb_m;
+#ifdef LK_CONV_DEV
   if ((ablate & 16) && blockIdx.x >= 256 && blockIdx.x < 512) {
     // (experiment) the two workgroups of a CU run equal tiles in lockstep and reach their epilogues together; delaying
     // the second resident workgroup of every CU by part of a tile time staggers them for the whole launch
     __builtin_amdgcn_s_sleep(127);
     __builtin_amdgcn_s_sleep(127);
   }
+#endif
   const int M = g.N * g.Hc * g.Wc;
   const int KC = g.Ci / BK;
+  // GRAM: running sums of the three upper 32 x 32 tiles (0,0), (0,1), (1,1) of this wave's o^T o
+  f32x16 gram_acc[GRAM ? 3 : 1];
+  if constexpr (GRAM) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gram_acc[t][r] = 0.f;
+  }
+  const int t_count = GRAM ? tiles_per_wg : 1;
+  for (int ti = 0; ti < t_count; ++ti) {
+  const int tile = GRAM ? bid * tiles_per_wg + ti : bid;
+  if (GRAM && tile >= n_tiles) break;  // (uniform over the workgroup)
+  const int tile_n = tile / nb_m, tile_m = tile % nb_m;
 
   // ---- per-thread staging context: which rows / slots this thread feeds, fixed for the whole K loop
   // A: A_LD instructions; instruction i covers slots [i*256, i*256+256) of the concatenated [plane h | plane l] image
@@ -525,8 +579,10 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
     f16x8 h2_[NIT], l2_[NIT];
     uint2 mk_[NIT];
     const bool pre_mask = fz.mask && !fz.mask_float;
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
+    // GRAM keeps 48 more registers alive (the running Gram tiles): only the first half of the chunks is requested ahead
+    // of the barrier, the second half once the accumulators have been staged (their registers are free by then)
+    constexpr int NPRE = GRAM ? NIT / 2 : NIT;
+    auto prefetch = [&](int it) {
       const int idx = it * 64 + lane;
       const int row = idx / C8, c8 = idx - row * C8;
       const int m = tile_m * BM + wm * ROWS_W + row;
@@ -541,16 +597,26 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
 #pragma unroll
       for (int j = 0; j < 8; ++j) h2_[it][j] = (_Float16)0.f, l2_[it][j] = (_Float16)0.f;
       mk_[it] = make_uint2(0x01010101u, 0x01010101u);
-      if (ablate & 32) continue;  // (development switch, config bit 21: load per chunk, where the values are consumed)
+      if (ablate & 32) return;  // (development switch, config bit 21: load per chunk, where the values are consumed)
       if (fz.add_h && ok_[it]) {
         h2_[it] = *reinterpret_cast<const f16x8*>(fz.add_h + e_[it]);
         l2_[it] = *reinterpret_cast<const f16x8*>(fz.add_l + e_[it]);
       }
       if (pre_mask && ok_[it])
         mk_[it] = *reinterpret_cast<const uint2*>((const unsigned char*)fz.mask + (opix % fz.mask_rows) * g.Co + col0);
-    }
+    };
+#pragma unroll
+    for (int it = 0; it < NPRE; ++it) prefetch(it);
     __syncthreads();  // every wave is done with the K loop's stage buffers
     float* img = reinterpret_cast<float*>(smem) + wave * (ROWS_W * PITCH);
+    // GRAM: the wave's fp16 planes overlay its own image, row by row: [row][h: 64 channels | l: 64 channels], 256 bytes
+    // per row — less than the 272 bytes of an image row, so row r of the planes ends before image row r does and the
+    // planes are written IN PLACE while the image rows are consumed in increasing order (LDS operations of one wave
+    // execute in order, and a row is written from values read from it).  The 32-byte segments (16 channels) of a plane
+    // row are XOR-swizzled by row & 3, so that the four rows a transposing read gathers lie in different banks.
+    char* gram_pl = reinterpret_cast<char*>(img);
+    constexpr int GP = 4 * COLS_W;  // bytes per row of the plane image
+    static_assert(!GRAM || (COLS_W == 64 && ROWS_W == 64 && GP <= PITCH * 4), "plane rows must not run ahead of the image rows");
     const float inv = inv_a * inv_w;
 #pragma unroll
     for (int a = 0; a < TM; ++a)
@@ -559,12 +625,25 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           img[(a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * PITCH + b * 32 + lr] = acc[a][b][r] * inv;
+#pragma unroll
+    for (int it = NPRE; it < NIT; ++it) prefetch(it);
     // (LDS operations of one wave execute in order: no barrier between its own writes and reads)
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      if (!ok_[it]) continue;
       const int idx = it * 64 + lane;
       const int row = idx / C8, c8 = idx - row * C8;
+      // byte offset of (row, channels c8 * 8 ..) inside the h part of the plane image (GRAM); l: + 2 * COLS_W
+      const int poff = row * GP + (((c8 >> 1) ^ (row & 3)) << 5) + (c8 & 1) * 16;
+      if (!ok_[it]) {
+        if constexpr (GRAM) {  // rows beyond the tensor contribute zeros to the Gram
+          f16x8 z;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) z[j] = (_Float16)0.f;
+          *reinterpret_cast<f16x8*>(gram_pl + poff) = z;
+          *reinterpret_cast<f16x8*>(gram_pl + poff + 2 * COLS_W) = z;
+        }
+        continue;
+      }
       const int col0 = tile_n * BN + wn * COLS_W + c8 * 8;
       const f32x4 p0 = *reinterpret_cast<const f32x4*>(img + row * PITCH + c8 * 8);
       const f32x4 p1 = *reinterpret_cast<const f32x4*>(img + row * PITCH + c8 * 8 + 4);
@@ -614,6 +693,10 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
       }
       *reinterpret_cast<f16x8*>(fz.out_h + e) = h;
       *reinterpret_cast<f16x8*>(fz.out_l + e) = l;
+      if constexpr (GRAM) {
+        *reinterpret_cast<f16x8*>(gram_pl + poff) = h;
+        *reinterpret_cast<f16x8*>(gram_pl + poff + 2 * COLS_W) = l;
+      }
     }
     if (amax_out) {
 #pragma unroll
@@ -622,7 +705,45 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
       const int back = -so < -126 ? -126 : -so;
       if (lane == 0 && vmax) atomicMax(amax_out, __float_as_uint(__uint_as_float(vmax) * exp2i(back)));
     }
-    return;
+    if constexpr (GRAM) {
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's plane writes are in LDS (its reads follow in order)
+      // o^T o of this wave's 64 pixels: k = pixels is the strided direction of both operands -> transposing reads
+      const int grp = lane >> 4, r16 = lane & 15;
+      const int f_row = (grp >> 1) * 8 + (r16 >> 2);
+      const int f_col = (grp & 1) * 16 + (r16 & 3) * 4;
+      auto tr_frag = [&](const char* plane, int k16, int col0) -> f16x8 {
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int row = k16 * 16 + f_row + j * 4;
+          const int col = col0 + f_col;
+          const int off = row * GP + (((col >> 4) ^ (row & 3)) << 5) + (col & 15) * 2;
+          const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(plane + off));
+          const f16x4 f = __builtin_bit_cast(f16x4, v);
+          o[4 * j] = f[0], o[4 * j + 1] = f[1], o[4 * j + 2] = f[2], o[4 * j + 3] = f[3];
+        }
+        return o;
+      };
+#pragma unroll
+      for (int k16 = 0; k16 < ROWS_W / 16; ++k16) {
+        f16x8 xh[2], xl[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) xh[a] = tr_frag(gram_pl, k16, a * 32), xl[a] = tr_frag(gram_pl + 2 * COLS_W, k16, a * 32);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const int a = t == 2 ? 1 : 0, b = t == 0 ? 0 : 1;
+          f32x16 c = gram_acc[t];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[a], xh[b], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[a], xl[b], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[a], xh[b], c, 0, 0, 0);
+          gram_acc[t] = c;
+        }
+      }
+      __syncthreads();  // the next tile's staging overwrites every wave's image
+      continue;
+    } else {
+      return;
+    }
   }
   if (g.out_nchw) {
     // position-contiguous output [n][co][pixel] (what the predictive's quadratic-form kernel reads): a lane owns one
@@ -681,6 +802,27 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) vmax = max(vmax, (unsigned)__shfl_xor((int)vmax, off, 64));
     if (lane == 0 && vmax) atomicMax(amax_out, vmax);
+  }
+  }  // (tile loop: one pass unless GRAM)
+  if constexpr (GRAM) {
+    // the four waves hold sums over different pixels of the SAME three tiles: added in wave order through LDS, one
+    // 64 x 64 partial (upper tiles) per workgroup
+    const int lr_ = lane & 31, lh_ = lane >> 5;
+    float* red = reinterpret_cast<float*>(smem);  // [wave][tile][32 x 32]
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[(wave * 3 + t) * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * lh_) * 32 + lr_] = gram_acc[t][r];
+    __syncthreads();
+    float* blk = gram_ws + (int64_t)blockIdx.x * (64 * 64);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      const int e = tid + 256 * i, t = e >> 10, q = e & 1023;
+      const float v = ((red[e] + red[3 * 1024 + e]) + red[6 * 1024 + e]) + red[9 * 1024 + e];
+      const int a = t == 2 ? 1 : 0, b = t == 0 ? 0 : 1;
+      blk[(a * 32 + (q >> 5)) * 64 + b * 32 + (q & 31)] = v;
+    }
   }
 }
 
@@ -909,6 +1051,13 @@ extern "C" int lk_absmax_f32(const float* x, int64_t n, const float* cscale, int
   return check_launch("absmax_kernel");
 }
 
+extern "C" int lk_range_words_f32(const float* x, int64_t B, int64_t per, unsigned* words, void* stream) {
+  LK_REQUIRE(x && words && B >= 0 && per >= 0 && B < (1ll << 31), "lk_range_words_f32: bad arguments");
+  if (B == 0 || per == 0) return LK_OK;
+  hipLaunchKernelGGL(range_words_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, x, per, words);
+  return check_launch("range_words_kernel");
+}
+
 extern "C" int lk_split_f16x2(const float* x, int64_t n, const float* amax, float bound_mul, void* planes_h,
                               void* planes_l, int* sexp, void* stream) {
   LK_REQUIRE(x && amax && planes_h && planes_l && sexp && n >= 0 && n % 8 == 0, "lk_split_f16x2: bad arguments (n % 8 == 0)");
@@ -936,13 +1085,43 @@ extern "C" int lk_conv_prep_weights_f16x2(const float* W, int64_t Co, int64_t Ci
 
 static int g_ablate = 0;  // development switch (config bits 8..10 of lk_conv_nhwc_f16x2): skip stores / MFMAs / staging
 
+// GRAM launches (see the kernel): 64 output channels on the 256 x 64 tile; the grid is one round of workgroups, each
+// walking through `tiles_per_wg` consecutive pixel tiles
+typedef ConvCfg<256, 64, 32, 4, 1> GramConvCfg;
+static void gram_conv_plan(int64_t M, int* tiles_per_wg, int* n_wg) {
+  const int64_t nb_m = (M + GramConvCfg::BM - 1) / GramConvCfg::BM;
+  int64_t per = (nb_m + 511) / 512;
+  if (per < 1) per = 1;
+  *tiles_per_wg = (int)per;
+  *n_wg = (int)((nb_m + per - 1) / per);
+}
+
 template <typename CFG>
 static int launch_conv(const ConvGeom& g, const void* Ah, const void* Al, const void* Wh, const void* Wl, const int* a_sexp,
                        const int* w_sexp, const void* zero16, float* out, int accumulate, unsigned* amax_out,
-                       hipStream_t stream, const ConvVjp* fz = nullptr) {
+                       hipStream_t stream, const ConvVjp* fz = nullptr, float* gram_ws = nullptr) {
   const int64_t M = (int64_t)g.N * g.Hc * g.Wc;
   const int nb_m = (int)((M + CFG::BM - 1) / CFG::BM), nb_n = (g.Co + CFG::BN - 1) / CFG::BN;
   const size_t lds = (size_t)CFG::NBUF * CFG::STAGE;
+  if (fz && gram_ws) {
+    if constexpr (std::is_same<CFG, GramConvCfg>::value) {
+      const size_t lds_f = lds > (size_t)CFG::EPI_LDS ? lds : (size_t)CFG::EPI_LDS;
+      static bool attr_set_g = false;
+      if (!attr_set_g) {
+        (void)hipFuncSetAttribute((const void*)conv_f16x2_kernel<CFG, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);
+        attr_set_g = true;
+      }
+      int per, n_wg;
+      gram_conv_plan(M, &per, &n_wg);
+      hipLaunchKernelGGL((conv_f16x2_kernel<CFG, true, true>), dim3((unsigned)n_wg), dim3(CFG::NT), lds_f, stream, g,
+                         (const _Float16*)Ah, (const _Float16*)Al, (const _Float16*)Wh, (const _Float16*)Wl, a_sexp, w_sexp,
+                         (const _Float16*)zero16, out, accumulate, amax_out, nb_m, g_ablate, *fz, per, nb_m * nb_n, gram_ws);
+      return check_launch("conv_f16x2_kernel(vjp + gram)");
+    } else {
+      set_error("lk_conv_nhwc_f16x2_vjp_gram: the fused Gram needs the 256 x 64 tile (Co == 64)");
+      return LK_EINVAL;
+    }
+  }
   if (fz) {
     if constexpr (CFG::FUSABLE) {
       const size_t lds_f = lds > (size_t)CFG::EPI_LDS ? lds : (size_t)CFG::EPI_LDS;
@@ -953,7 +1132,7 @@ static int launch_conv(const ConvGeom& g, const void* Ah, const void* Al, const 
       }
       hipLaunchKernelGGL((conv_f16x2_kernel<CFG, true>), dim3((unsigned)(nb_m * nb_n)), dim3(CFG::NT), lds_f, stream, g,
                          (const _Float16*)Ah, (const _Float16*)Al, (const _Float16*)Wh, (const _Float16*)Wl, a_sexp, w_sexp,
-                         (const _Float16*)zero16, out, accumulate, amax_out, nb_m, g_ablate, *fz);
+                         (const _Float16*)zero16, out, accumulate, amax_out, nb_m, g_ablate, *fz, 1, nb_m * nb_n, (float*)nullptr);
       return check_launch("conv_f16x2_kernel(vjp)");
     } else {
       set_error("lk_conv_nhwc_f16x2_vjp: this K-pipeline variant has no fused epilogue");
@@ -967,7 +1146,7 @@ static int launch_conv(const ConvGeom& g, const void* Ah, const void* Al, const 
   }
   hipLaunchKernelGGL((conv_f16x2_kernel<CFG, false>), dim3((unsigned)(nb_m * nb_n)), dim3(CFG::NT), lds, stream, g, (const _Float16*)Ah,
                      (const _Float16*)Al, (const _Float16*)Wh, (const _Float16*)Wl, a_sexp, w_sexp, (const _Float16*)zero16,
-                     out, accumulate, amax_out, nb_m, g_ablate, ConvVjp{});
+                     out, accumulate, amax_out, nb_m, g_ablate, ConvVjp{}, 1, nb_m * nb_n, (float*)nullptr);
   return check_launch("conv_f16x2_kernel");
 }
 template <typename CFG>
@@ -992,7 +1171,8 @@ static int conv_dispatch(const void* in_h, const void* in_l, const int* in_sexp,
                          int64_t Ci, const void* w_h, const void* w_l, const int* w_sexp, int64_t Co,
                          int64_t Hc, int64_t Wc, int64_t in_mul, int64_t Ho, int64_t Wo, int64_t out_step,
                          int64_t oh0, int64_t ow0, int64_t T, const int* taps, const void* zero16, float* out,
-                         int accumulate, unsigned* amax_out, int config, void* stream, const ConvVjp* fz) {
+                         int accumulate, unsigned* amax_out, int config, void* stream, const ConvVjp* fz,
+                         float* gram_ws = nullptr) {
   LK_REQUIRE(in_h && in_l && in_sexp && w_h && w_l && w_sexp && zero16 && (out || fz) && taps, "lk_conv_nhwc_f16x2: null pointer");
   LK_REQUIRE(T >= 1 && T <= 9 && Ci >= 32 && Ci % 32 == 0 && Co >= 1 && N >= 1, "lk_conv_nhwc_f16x2: Ci % 32 == 0, 1..9 taps");
   LK_REQUIRE(N * Hc * Wc < (1ll << 31) && N * Hi * Wi * Ci < (1ll << 40), "lk_conv_nhwc_f16x2: tensor too large");
@@ -1010,6 +1190,11 @@ static int conv_dispatch(const void* in_h, const void* in_l, const int* in_sexp,
   LK_REQUIRE(!g.out_nchw || (g.dense && (Ho * Wo) % 4 == 0 && !accumulate),
              "lk_conv_nhwc_f16x2: position-contiguous output needs a dense grid with Ho*Wo % 4 == 0 and no accumulate");
   hipStream_t st = (hipStream_t)stream;
+  if (fz && gram_ws) {
+    LK_REQUIRE(lk_conv_vjp_gram_parts(N, Ho, Wo, Co, config) > 0, "lk_conv_nhwc_f16x2_vjp_gram: shape not eligible (lk_conv_vjp_gram_parts)");
+    g_ablate = 0;
+    return launch_conv<GramConvCfg>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz, gram_ws);
+  }
   g_ablate = ((config >> 8) & 7) | ((config & 524288) ? 8 : 0) | ((config & 1048576) ? 16 : 0) | ((config & 2097152) ? 32 : 0);  // bit 19: chunk-major K order
   // "patch" form (A operand resident in LDS across the taps) where the output grid is the input grid
   bool patch = !fz && !(config & 2) && !(config & 16) && in_mul == 1 && Hc == Hi && Wc == Wi && 256 + 2 * Wi + 2 <= 336 && N * Hi * Wi >= 256;
@@ -1085,6 +1270,21 @@ static int conv_dispatch(const void* in_h, const void* in_l, const int* in_sexp,
               : launch_conv<ConvCfg<128, 128, 32, 2, 2>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz);
 }
 
+// Workgroups (= 64 x 64 partials) of a fused launch that also accumulates the Gram of its result; 0 = not eligible: the
+// result must have exactly 64 channels, the map more than 64 pixels (position-major tiles mix pixels of many images into a
+// wave in another order; they are small layers anyway), no explicit tile / pipeline variant may be selected, and there
+// must be at least one round of 256 x 64 tiles.
+extern "C" int64_t lk_conv_vjp_gram_parts(int64_t N, int64_t Ho, int64_t Wo, int64_t Co, int config) {
+  if (Co != 64 || N < 1 || Ho < 1 || Wo < 1) return 0;
+  if (Ho * Wo <= (64 << (2 * ((config >> 16) & 3))) && N >= 64 && !(config & 32768)) return 0;  // position-major rows
+  if (((config >> 12) & 7) || (config & (1 | 4 | 8 | 16 | 32 | 64 | 2048))) return 0;
+  const int64_t M = N * Ho * Wo;
+  if ((M + 255) / 256 < 512) return 0;
+  int per, n_wg;
+  gram_conv_plan(M, &per, &n_wg);
+  return n_wg;
+}
+
 extern "C" int lk_conv_nhwc_f16x2(const void* in_h, const void* in_l, const int* in_sexp, int64_t N, int64_t Hi, int64_t Wi,
                                   int64_t Ci, const void* w_h, const void* w_l, const int* w_sexp, int64_t Co,
                                   int64_t Hc, int64_t Wc, int64_t in_mul, int64_t Ho, int64_t Wo, int64_t out_step,
@@ -1096,13 +1296,13 @@ extern "C" int lk_conv_nhwc_f16x2(const void* in_h, const void* in_l, const int*
 
 // The same launch with the fused VJP epilogue (see ConvVjp): dense output grid (the output tensor IS the class grid), no
 // accumulate, Co % 8 == 0.  Emits the split tensor out_h / out_l / out_sexp and max|result| (out_amax, zeroed by the caller).
-extern "C" int lk_conv_nhwc_f16x2_vjp(const void* in_h, const void* in_l, const int* in_sexp, const void* in_amax, int64_t N,
-                                      int64_t Hi, int64_t Wi, int64_t Ci, const void* w_h, const void* w_l, const int* w_sexp,
-                                      const float* w_l1, int64_t Co, int64_t Ho, int64_t Wo, int64_t T, const int* taps,
-                                      const void* zero16, const void* add_h, const void* add_l, const int* add_sexp,
-                                      const void* mask, int mask_is_float, const void* mult_amax, int64_t mask_rows,
-                                      const float* scale, const void* scale_amax, void* out_h, void* out_l, int* out_sexp,
-                                      void* out_amax, int config, void* stream) {
+static int conv_vjp_impl(const void* in_h, const void* in_l, const int* in_sexp, const void* in_amax, int64_t N,
+                         int64_t Hi, int64_t Wi, int64_t Ci, const void* w_h, const void* w_l, const int* w_sexp,
+                         const float* w_l1, int64_t Co, int64_t Ho, int64_t Wo, int64_t T, const int* taps,
+                         const void* zero16, const void* add_h, const void* add_l, const int* add_sexp,
+                         const void* mask, int mask_is_float, const void* mult_amax, int64_t mask_rows,
+                         const float* scale, const void* scale_amax, void* out_h, void* out_l, int* out_sexp,
+                         void* out_amax, int config, void* stream, float* gram_ws) {
   LK_REQUIRE(w_l1 && out_h && out_l && out_sexp && out_amax, "lk_conv_nhwc_f16x2_vjp: null pointer");
   LK_REQUIRE(Co % 8 == 0, "lk_conv_nhwc_f16x2_vjp: Co % 8 == 0");
   LK_REQUIRE(!add_h || (add_l && add_sexp), "lk_conv_nhwc_f16x2_vjp: incomplete addend");
@@ -1115,5 +1315,36 @@ extern "C" int lk_conv_nhwc_f16x2_vjp(const void* in_h, const void* in_l, const 
   fz.scale = scale, fz.scale_amax = (const unsigned*)scale_amax;
   fz.out_h = (_Float16*)out_h, fz.out_l = (_Float16*)out_l, fz.out_sexp = out_sexp;
   return conv_dispatch(in_h, in_l, in_sexp, N, Hi, Wi, Ci, w_h, w_l, w_sexp, Co, Ho, Wo, 1, Ho, Wo, 1, 0, 0, T, taps, zero16,
-                       nullptr, 0, (unsigned*)out_amax, config & ~(1 | 4 | 8 | 16 | 32 | 64 | 2048), stream, &fz);
+                       nullptr, 0, (unsigned*)out_amax, config & ~(1 | 4 | 8 | 16 | 32 | 64 | 2048), stream, &fz, gram_ws);
+}
+
+extern "C" int lk_conv_nhwc_f16x2_vjp(const void* in_h, const void* in_l, const int* in_sexp, const void* in_amax, int64_t N,
+                                      int64_t Hi, int64_t Wi, int64_t Ci, const void* w_h, const void* w_l, const int* w_sexp,
+                                      const float* w_l1, int64_t Co, int64_t Ho, int64_t Wo, int64_t T, const int* taps,
+                                      const void* zero16, const void* add_h, const void* add_l, const int* add_sexp,
+                                      const void* mask, int mask_is_float, const void* mult_amax, int64_t mask_rows,
+                                      const float* scale, const void* scale_amax, void* out_h, void* out_l, int* out_sexp,
+                                      void* out_amax, int config, void* stream) {
+  return conv_vjp_impl(in_h, in_l, in_sexp, in_amax, N, Hi, Wi, Ci, w_h, w_l, w_sexp, w_l1, Co, Ho, Wo, T, taps, zero16, add_h,
+                       add_l, add_sexp, mask, mask_is_float, mult_amax, mask_rows, scale, scale_amax, out_h, out_l, out_sexp,
+                       out_amax, config, stream, nullptr);
+}
+
+// lk_conv_nhwc_f16x2_vjp that ALSO leaves the Gram of its result, o^T o over all output pixels, as
+// lk_conv_vjp_gram_parts(N, Ho, Wo, Co, config) partial 64 x 64 blocks (upper 32 x 32 tiles, in units of 2^(-2 out_sexp))
+// in gram_ws; lk_gram_partials_reduce_f16x2 adds their sum to a G factor.
+extern "C" int lk_conv_nhwc_f16x2_vjp_gram(const void* in_h, const void* in_l, const int* in_sexp, const void* in_amax, int64_t N,
+                                           int64_t Hi, int64_t Wi, int64_t Ci, const void* w_h, const void* w_l,
+                                           const int* w_sexp, const float* w_l1, int64_t Co, int64_t Ho, int64_t Wo, int64_t T,
+                                           const int* taps, const void* zero16, const void* add_h, const void* add_l,
+                                           const int* add_sexp, const void* mask, int mask_is_float, const void* mult_amax,
+                                           int64_t mask_rows, const float* scale, const void* scale_amax, void* out_h,
+                                           void* out_l, int* out_sexp, void* out_amax, float* gram_ws, int64_t gram_ws_floats,
+                                           int config, void* stream) {
+  LK_REQUIRE(gram_ws, "lk_conv_nhwc_f16x2_vjp_gram: null workspace");
+  const int64_t parts = lk_conv_vjp_gram_parts(N, Ho, Wo, Co, config & ~(1 | 4 | 8 | 16 | 32 | 64 | 2048));
+  LK_REQUIRE(parts > 0 && gram_ws_floats >= parts * 64 * 64, "lk_conv_nhwc_f16x2_vjp_gram: shape not eligible or workspace too small");
+  return conv_vjp_impl(in_h, in_l, in_sexp, in_amax, N, Hi, Wi, Ci, w_h, w_l, w_sexp, w_l1, Co, Ho, Wo, T, taps, zero16, add_h,
+                       add_l, add_sexp, mask, mask_is_float, mult_amax, mask_rows, scale, scale_amax, out_h, out_l, out_sexp,
+                       out_amax, config, stream, gram_ws);
 }

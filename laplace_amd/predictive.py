@@ -26,6 +26,7 @@ from __future__ import annotations
 import torch
 
 from laplace_amd._lib import get_kernels
+from laplace_amd.backend import range_groups as _range_groups
 from laplace_amd.backend import shared_operands as _shared_operands
 
 
@@ -42,36 +43,9 @@ def _grads(grad_fn, seeds):
     return grad_fn(seeds)  # autograd-tape / last-layer grad_fn
 
 
-#: largest spread (in powers of two) of the per-sample input magnitudes that one sweep takes: the split-fp16 tensors of
-#: the sweep carry ONE scale per tensor (csrc/lk_conv.hip), whose fixed-point floor is 2^-39 of the tensor's largest
-#: element — a sample 2^-16 below the largest one still keeps 2^-23 of ITS OWN maximum, and the quadratic growth of the
-#: variance with the activations is covered twice over.  Wider minibatches are swept in magnitude groups.
-RANGE_GUARD_LOG2 = 16
-
-
-def _range_groups(x, max_log2: int = RANGE_GUARD_LOG2):
-    """``None`` (one sweep) or index tensors of sub-batches whose per-sample input magnitudes stay within
-    ``2^max_log2`` of each other.  The predictive is per sample (``f_var[n]`` must be right relative to ITS OWN size,
-    tests/test_baselaplace.py:334-410 of the reference compare element-wise), unlike the factors of a fit, which are
-    sums over the minibatch.  Costs one [B]-float read-back per call."""
-    if not torch.is_tensor(x) or not x.is_floating_point() or x.dim() < 2 or x.shape[0] < 2:
-        return None
-    amax = x.detach().abs().reshape(x.shape[0], -1).amax(1).float()
-    e = torch.floor(torch.log2(amax.clamp_min(1e-38))).cpu()
-    if float(e.max() - e.min()) <= max_log2:
-        return None
-    order = torch.argsort(e)
-    groups, start = [], 0
-    for i in range(1, len(order) + 1):
-        if i == len(order) or float(e[order[i]] - e[order[start]]) > max_log2:
-            groups.append(order[start:i].sort().values.to(x.device))
-            start = i
-    return groups
-
-
 def _by_range_groups(fn, backend, x, *args):
     """run a per-sample predictive over magnitude groups of the minibatch and put the rows back in order"""
-    groups = _range_groups(x) if getattr(backend, "range_guard", True) else None
+    groups = _range_groups(x) if getattr(backend, "range_guard", "check") not in (False, "off") else None
     if groups is None:
         return None
     f = fvar = None

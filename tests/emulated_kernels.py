@@ -70,6 +70,15 @@ class EmulatedKernels:
             return out
         return v
 
+    def range_words(self, x, words):
+        a = x.detach().abs().reshape(x.shape[0], -1).amax(1).float()
+        a = a[a > 0]
+        if a.numel():
+            cur = words.view(torch.float32)
+            cur[0] = torch.maximum(cur[0], a.max())
+            cur[1] = torch.minimum(cur[1], a.min())
+        return words
+
     def split_f16x2(self, x, amax=None, bound_mul=1.0):
         if amax is None:
             amax = self.absmax(x)
@@ -112,8 +121,13 @@ class EmulatedKernels:
             amax_out.copy_(torch.maximum(amax_out, view.abs().max().reshape(1)))
         return out
 
+    fuse_gram = True
+    #: the device kernel accumulates the Gram of its result only on launches of at least one round of 256 x 64 tiles
+    #: (lk_conv_vjp_gram_parts); the emulation does it for every 64-channel result so that tiny CPU cases walk the path
+    gram_min_rows = 0
+
     def conv_nhwc_f16x2_vjp(self, x, wplanes, wsexp, w_l1, Ho, Wo, taps, add=None, mult=None, mult_amax=None, scale=None,
-                            scale_amax=None, config=None):
+                            scale_amax=None, config=None, want_gram=False):
         """lk_conv_nhwc_f16x2_vjp: the convolution, then (conv + add) * mult * scale split with the scale of the
         guaranteed bound max|in| * l1(W) (+ ...); the measured max|.| rides along as ``amax``"""
         N = x.shape[0]
@@ -138,6 +152,19 @@ class EmulatedKernels:
         assert float(v.abs().max()) <= bound * (1 + 1e-6) + 1e-30, "the guaranteed bound of the fused epilogue does not hold"
         out = self._split(v, self._sexp_for(bound))
         out.amax = out.float().abs().max().reshape(1).float()
+        if want_gram and self.fuse_gram and Co == 64 and N * Ho * Wo >= self.gram_min_rows:
+            # lk_conv_nhwc_f16x2_vjp_gram: partial blocks of X^T X (upper 32 x 32 tiles) in units of 2^(-2 sexp), here two
+            X = (out.planes[0].float() + out.planes[1].float()).reshape(-1, Co)
+            half = (X.shape[0] + 1) // 2
+            idx = torch.arange(Co) // 32
+            upper = (idx[:, None] <= idx[None, :]).float()
+            out.gram_parts = torch.stack([(P.T @ P) * upper for P in (X[:half], X[half:])])
+        return out
+
+    def gram_partials_reduce(self, x, alpha, out):
+        idx = torch.arange(out.shape[0]) // 32
+        upper = idx[:, None] <= idx[None, :]
+        out += alpha * x.gram_parts.sum(0) * upper * 2.0 ** (-2 * int(x.sexp[0]))
         return out
 
     def vjp_nhwc_split(self, g, g_amax, g2, mult, mult_amax, scale, scale_amax, S, out_shape):

@@ -265,3 +265,47 @@ def test_position_major_rows_on_small_maps(shape, config):
     if fused is not None:
         want = (want_b.permute(0, 2, 3, 1) + addend.float().double().cpu()).reshape(S, B, H, H, cin) * mask.double().cpu()
         assert rel(fused.float(), want.reshape(N, H, H, cin)) < 1e-5
+
+
+@pytest.mark.parametrize("variant", ["mask+add", "plain"])
+@pytest.mark.parametrize("n_img", [144, 131])  # 131: the last pixel tile is ragged and the last workgroup walks fewer tiles
+def test_fused_launch_accumulates_the_gram_of_its_result(variant, n_img, monkeypatch):
+    """lk_conv_nhwc_f16x2_vjp_gram on the 64-channel 32 x 32 layer of c4: the split result equals the plain fused launch bit
+    for bit, and the partial blocks reduce to the fp64 Gram of that result — the G factor of the layer whose output
+    cotangent the launch produces (curvlinops.py:57-62) without a second pass over the cotangent."""
+    from laplace_amd import conv as cv
+    from laplace_amd._lib import get_kernels
+
+    K = get_kernels()
+    monkeypatch.setattr(K, "fuse_gram", True)  # (off by default: it pays on one stream, not in the overlapped step)
+    cin, cout, k, s, p, H = 64, 64, 3, 1, 1, 32
+    m = _conv(cin, cout, k, s, p)
+    S, B = 1, n_img
+    N = S * B
+    torch.manual_seed(17)
+    g = torch.randn(N, cout, H, H, device=DEV) * 2e-3
+    gs = K.split_f16x2(g.permute(0, 2, 3, 1).contiguous())
+    kw = {}
+    if variant == "mask+add":
+        kw["add"] = K.split_f16x2(torch.randn(N, H, H, cin, device=DEV) * 0.01)
+        kw["mult"] = (torch.rand(B, H, H, cin, device=DEV) > 0.4).to(torch.uint8)
+    prep = cv.PreparedConv(m)
+    assert int(K.lib.lk_conv_vjp_gram_parts(N, H, H, cin, K.conv_config)) > 0
+    plain = cv.conv_backward_data_vjp(prep, gs, (H, H), **kw)
+    fused = cv.conv_backward_data_vjp(prep, gs, (H, H), want_gram=True, **kw)
+    assert plain.gram_parts is None and fused.gram_parts is not None and fused.gram_parts.shape[1:] == (64, 64)
+    assert torch.equal(plain.planes, fused.planes) and torch.equal(plain.sexp, fused.sexp) and torch.equal(plain.amax, fused.amax)
+    G = torch.zeros(64, 64, device=DEV)
+    K.gram_partials_reduce(fused, 0.5, G)
+    K.symmetrize(G)
+    X = fused.float().double().reshape(-1, 64)
+    want = 0.5 * (X.T @ X)
+    assert rel(G, want) < 1e-5, rel(G, want)
+    # and against the stand-alone Gram kernel it replaces
+    G2 = torch.zeros(64, 64, device=DEV)
+    K.gram_tn_f16x2(plain, 0.5, G2)
+    K.symmetrize(G2)
+    assert rel(G, G2) < 1e-5
+    # shapes the fused Gram does not cover are refused by the query, and the wrapper then launches the plain kernel
+    small = cv.conv_backward_data_vjp(prep, K.split_f16x2(g[:8].permute(0, 2, 3, 1).contiguous()), (H, H), want_gram=True)
+    assert small.gram_parts is None

@@ -8,7 +8,7 @@ torch.manual_seed(711)
 model = ResNet18(10).cuda().eval()
 b = HipGGN(model, "classification")
 X = torch.randn(128, 3, 32, 32, device="cuda"); y = torch.randint(10, (128,), device="cuda")
-acc = b.kron_accumulator(50000)
+acc = b.kron_accumulator(50000, overlap=os.environ.get("LK_NO_OVERLAP") != "1")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 for _ in range(4): acc.add_batch(X, y)
 torch.cuda.synchronize()
