@@ -17,7 +17,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "liblaplace_hip.so")
+# (LK_LIB: another build of the same library, e.g. csrc/liblaplace_hip_dev.so with the kernels' development switches)
+LIB_PATH = os.environ.get("LK_LIB") or os.path.join(_HERE, "csrc", "liblaplace_hip.so")
 
 LK_GRAM_UPPER_ONLY = 1
 LK_GRAM_SLABS_PERSIST = 2

@@ -203,6 +203,7 @@ struct ConvVjp {
   int mask_float;
   const unsigned* mult_amax; // max|M| for fp32 multipliers (NULL: 1)
   int64_t mask_rows;
+  FastDiv div_mask;          // GEMM row m (< 2^31) -> m / mask_rows without a 64-bit division in the epilogue
   const float* scale;        // [Co] or NULL
   const unsigned* scale_amax;
   _Float16 *out_h, *out_l;
@@ -400,6 +401,50 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+  // ---- fused (VJP) epilogue, part 1: per-lane chunk context and the requests for the addend planes / mask bytes of ALL of
+  // this lane's chunks (issued right behind the K loop: their latency runs under the hand-over barrier and the staging of
+  // the accumulators.  Issuing them two K stages EARLIER was measured: 9.60 vs 9.33 ms per step — the vmcnt(0) of the last
+  // hand-over then waits for HBM-latency loads in front of the last MFMAs.)
+  constexpr int ROWS_W = TM * 32, COLS_W = TN * 32, PITCH = COLS_W + 4, C8 = COLS_W / 8, NIT = FUSE ? ROWS_W * C8 / 64 : 1;
+  const int HWc = g.Hc * g.Wc;
+  int64_t e_[NIT];
+  int pix_[NIT];  // output pixel index of the chunk's row (< 2^31)
+  bool ok_[NIT];
+  f16x8 h2_[NIT], l2_[NIT];
+  uint2 mk_[NIT];
+  const bool pre_mask = fz.mask && !fz.mask_float;
+  // row of the multiplier for output pixel p (the multiplier is shared by the seeds): p mod mask_rows in 32-bit
+  // arithmetic (a 64-bit % here was a ~100-instruction software division per chunk: 8 per tile and lane)
+  const int mrows = (int)fz.mask_rows;
+  auto mask_row = [&](int p) { return p - fdiv(p, fz.div_mask) * mrows; };
+  // GRAM keeps 48 more registers alive (the running Gram tiles): only the first half of the chunks is requested ahead
+  // of the barrier, the second half once the accumulators have been staged (their registers are free by then)
+  constexpr int NPRE = GRAM ? NIT / 2 : NIT;
+  auto prefetch = [&](int it) {
+    const int idx = it * 64 + lane;
+    const int row = idx / C8, c8 = idx - row * C8;
+    const int m = tile_m * BM + wm * ROWS_W + row;
+    const int col0 = tile_n * BN + wn * COLS_W + c8 * 8;
+    ok_[it] = m < M && col0 < g.Co;
+    int64_t opix = m;  // dense grid: the output pixel index is the GEMM row, up to the position-major order
+    if (g.pmajor) {
+      const int rem = fdiv(m, g.div_n);
+      opix = (int64_t)(m - rem * g.N) * HWc + rem;
+    }
+    e_[it] = ok_[it] ? opix * g.Co + col0 : 0;
+    pix_[it] = ok_[it] ? (int)opix : 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h2_[it][j] = (_Float16)0.f, l2_[it][j] = (_Float16)0.f;
+    mk_[it] = make_uint2(0x01010101u, 0x01010101u);
+    if (ablate & 32) return;  // (development switch, config bit 21: load per chunk, where the values are consumed)
+    if (fz.add_h && ok_[it]) {
+      h2_[it] = *reinterpret_cast<const f16x8*>(fz.add_h + e_[it]);
+      l2_[it] = *reinterpret_cast<const f16x8*>(fz.add_l + e_[it]);
+    }
+    if (pre_mask && ok_[it])
+      mk_[it] = *reinterpret_cast<const uint2*>((const unsigned char*)fz.mask + (int64_t)mask_row((int)opix) * g.Co + col0);
+  };
+
   if constexpr (CFG::MIDBAR) {
     // Two workgroups of a CU run the same code from the same start: they reach their LDS-read phase together, so the
     // partner wave on a SIMD cannot cover a fragment read with its MFMAs, and each wave has to hide its own LDS latency.
@@ -569,42 +614,9 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
     if (blockIdx.x == 0 && tid == 0) fz.out_sexp[0] = so;
     // the wave's 64 x 64 (32 x 32, ...) block goes through LDS: MFMA layout (lane = channel, registers = pixels) ->
     // lane = 8 consecutive channels of one pixel, i.e. 16-byte loads of the addend / mask and 16-byte stores of each plane
-    constexpr int ROWS_W = TM * 32, COLS_W = TN * 32, PITCH = COLS_W + 4, C8 = COLS_W / 8, NIT = ROWS_W * C8 / 64;
     static_assert(CFG::EPI_LDS == CFG::WM * CFG::WN * ROWS_W * PITCH * 4 && CFG::EPI_LDS <= 80 * 1024, "staging image: two workgroups per CU");
     // The addend planes and the mask bytes of ALL of this lane's chunks are requested first: their latency (an HBM miss
     // each) then runs under the hand-over barrier and the staging of the accumulators instead of once per chunk.
-    const int HWc = g.Hc * g.Wc;
-    int64_t e_[NIT];
-    bool ok_[NIT];
-    f16x8 h2_[NIT], l2_[NIT];
-    uint2 mk_[NIT];
-    const bool pre_mask = fz.mask && !fz.mask_float;
-    // GRAM keeps 48 more registers alive (the running Gram tiles): only the first half of the chunks is requested ahead
-    // of the barrier, the second half once the accumulators have been staged (their registers are free by then)
-    constexpr int NPRE = GRAM ? NIT / 2 : NIT;
-    auto prefetch = [&](int it) {
-      const int idx = it * 64 + lane;
-      const int row = idx / C8, c8 = idx - row * C8;
-      const int m = tile_m * BM + wm * ROWS_W + row;
-      const int col0 = tile_n * BN + wn * COLS_W + c8 * 8;
-      ok_[it] = m < M && col0 < g.Co;
-      int64_t opix = m;  // dense grid: the output pixel index is the GEMM row, up to the position-major order
-      if (g.pmajor) {
-        const int rem = fdiv(m, g.div_n);
-        opix = (int64_t)(m - rem * g.N) * HWc + rem;
-      }
-      e_[it] = ok_[it] ? opix * g.Co + col0 : 0;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) h2_[it][j] = (_Float16)0.f, l2_[it][j] = (_Float16)0.f;
-      mk_[it] = make_uint2(0x01010101u, 0x01010101u);
-      if (ablate & 32) return;  // (development switch, config bit 21: load per chunk, where the values are consumed)
-      if (fz.add_h && ok_[it]) {
-        h2_[it] = *reinterpret_cast<const f16x8*>(fz.add_h + e_[it]);
-        l2_[it] = *reinterpret_cast<const f16x8*>(fz.add_l + e_[it]);
-      }
-      if (pre_mask && ok_[it])
-        mk_[it] = *reinterpret_cast<const uint2*>((const unsigned char*)fz.mask + (opix % fz.mask_rows) * g.Co + col0);
-    };
 #pragma unroll
     for (int it = 0; it < NPRE; ++it) prefetch(it);
     __syncthreads();  // every wave is done with the K loop's stage buffers
@@ -651,7 +663,7 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
       const int64_t e = e_[it];
       if (ablate & 32) {
         if (fz.add_h) h2_[it] = *reinterpret_cast<const f16x8*>(fz.add_h + e), l2_[it] = *reinterpret_cast<const f16x8*>(fz.add_l + e);
-        if (pre_mask) mk_[it] = *reinterpret_cast<const uint2*>((const unsigned char*)fz.mask + ((e / g.Co) % fz.mask_rows) * g.Co + col0);
+        if (pre_mask) mk_[it] = *reinterpret_cast<const uint2*>((const unsigned char*)fz.mask + (int64_t)mask_row(pix_[it]) * g.Co + col0);
       }
       if (fz.add_h) {
 #pragma unroll
@@ -662,7 +674,7 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
       for (int j = 0; j < 8; ++j) mult[j] = sc_out;
       if (fz.mask) {
         if (fz.mask_float) {
-          const int64_t em = ((e / g.Co) % fz.mask_rows) * g.Co + col0;
+          const int64_t em = (int64_t)mask_row(pix_[it]) * g.Co + col0;
           const f32x4 a = *reinterpret_cast<const f32x4*>((const float*)fz.mask + em);
           const f32x4 b = *reinterpret_cast<const f32x4*>((const float*)fz.mask + em + 4);
 #pragma unroll
@@ -1031,6 +1043,402 @@ __global__ __launch_bounds__(512) void conv_patch_f16x2_kernel(const ConvGeom g,
   }
 }
 
+
+// ---- "window" form: stride-1 / same-grid convolutions with the input window of a pixel tile RESIDENT in LDS --------------
+// The generic kernel stages the A operand once per tap: nine times the input of a 3 x 3 convolution through L2 -> LDS, and
+// with 64 workgroups per XCD walking through 5 MB of windows its 4 MB L2 does not hold them between the taps (measured:
+// 3.4 x the operand bytes from the fabric; the load path alone takes as long as the MFMAs alone and the two overlap only
+// partly).  Where the output grid IS the input grid, tap (dh, dw) of GEMM row m is raster pixel m + dh * Wi + dw, so a tile
+// of BM consecutive raster pixels needs the contiguous pixel range [m0 - Wi - 1, m0 + BM + Wi + 1) for ALL taps:
+//   * that window is brought into LDS once per 16-channel chunk (one k16 step), DOUBLE-buffered — chunk c + 1 lands while
+//     the nine taps of chunk c are computed — and every tap reads it at shifted rows; out-of-image taps read a zero block
+//     through a per-lane select;
+//   * the weights go through a two-slot ring of THREE taps each (3 x BN x 16 k x h/l), so there is one hand-over barrier
+//     per three taps (18 / 36 MFMAs per wave) instead of one per tap and 32-channel chunk;
+//   * L2 -> LDS bytes per tile and chunk: window (BM + 96) x 64 B + weights 9 x BN x 64 B, against 9 x (BM + BN) x 64 B of the
+//     generic form: 3.2 x fewer for 256 x 64, and the input itself is read from the fabric once (plus the halo).
+// (The older "patch" kernel below keeps a 32-channel window single-buffered and hands over per tap; it has no fused epilogue.)
+template <int BM_, int BN_, int WM_, int WN_, int WPE_>
+struct WinCfg {
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, WPE = WPE_;
+  static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  static constexpr int NW = WM * WN, NT = 64 * NW;
+  static constexpr int CK = 16;                           // channels per window chunk = one k16 step
+  static constexpr int PP = BM + 96;                      // window pixels: BM + 2 Wi + 2 <= PP  (Wi <= 47); a multiple of 32
+  static constexpr int W_PLANE = PP * CK * 2;             // bytes
+  static constexpr int WIN = 2 * W_PLANE;                 // h + l
+  static constexpr int B_TAP = BN * CK * 2;               // one tap, one plane
+  static constexpr int B_STEP = 6 * B_TAP;                // three taps, h + l
+  static constexpr int ZERO_OFF = (PP - 1) * CK * 2;      // the LAST window pixel of a plane is kept zero (need < PP): what
+                                                          // out-of-image taps read, in the h plane and (+ W_PLANE) the l plane
+  static constexpr int WINZ = WIN;                        // stride of the two window buffers
+  static constexpr int LDS = 2 * WINZ + 2 * B_STEP;
+  static constexpr int W_INSTR = 4 * PP / 64;             // LDS-DMA wave-instructions per window (2 planes x PP x 2 slots)
+  static constexpr int B_INSTR = 12 * BN / 64;            // ... per weight step
+  static constexpr int W_IT = (W_INSTR + NW - 1) / NW, B_IT = (B_INSTR + NW - 1) / NW;
+  static constexpr int EPI_LDS = NW * (TM * 32) * (TN * 32 + 4) * 4;  // staging image of the fused epilogue
+  static_assert((4 * PP) % 64 == 0 && (12 * BN) % 64 == 0, "whole wave-instructions");
+  static_assert(TM >= 1 && TN >= 1 && TM * TN <= 4, "MFMA tiles per wave");
+};
+
+__device__ __forceinline__ int swz2(int row) { return (row >> 3) & 1; }  // two 16-byte slots per row (see swz<2>)
+
+// The fused (VJP) epilogue of conv_f16x2_kernel for a wave that holds rows [row0, row0 + TM*32) x columns [col0, col0 + TN*32)
+// of a DENSE output grid (output pixel = GEMM row): (acc * inv + add) * M * scale -> split planes, max|.| -> amax_out.
+template <int TM, int TN>
+__device__ __forceinline__ void fused_vjp_epilogue(f32x16 (&acc)[TM][TN], char* smem, int wave, int lane, int row0, int col0,
+                                                   int M, const ConvGeom& g, const ConvVjp& fz, float inv, float inv2,
+                                                   float sc_out, int so, unsigned* amax_out) {
+  constexpr int ROWS_W = TM * 32, COLS_W = TN * 32, PITCH = COLS_W + 4, C8 = COLS_W / 8, NIT = ROWS_W * C8 / 64;
+  const int lr = lane & 31, lh = lane >> 5;
+  int64_t e_[NIT];
+  bool ok_[NIT];
+  f16x8 h2_[NIT], l2_[NIT];
+  uint2 mk_[NIT];
+  const bool pre_mask = fz.mask && !fz.mask_float;
+  const int mrows = (int)fz.mask_rows;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int idx = it * 64 + lane;
+    const int row = idx / C8, c8 = idx - row * C8;
+    const int m = row0 + row;
+    const int c0 = col0 + c8 * 8;
+    ok_[it] = m < M && c0 < g.Co;
+    e_[it] = ok_[it] ? (int64_t)m * g.Co + c0 : 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h2_[it][j] = (_Float16)0.f, l2_[it][j] = (_Float16)0.f;
+    mk_[it] = make_uint2(0x01010101u, 0x01010101u);
+    if (fz.add_h && ok_[it]) {
+      h2_[it] = *reinterpret_cast<const f16x8*>(fz.add_h + e_[it]);
+      l2_[it] = *reinterpret_cast<const f16x8*>(fz.add_l + e_[it]);
+    }
+    if (pre_mask && ok_[it])
+      mk_[it] = *reinterpret_cast<const uint2*>((const unsigned char*)fz.mask + (int64_t)(m - fdiv(m, fz.div_mask) * mrows) * g.Co + c0);
+  }
+  __syncthreads();  // every wave is done with the K loop's LDS buffers
+  float* img = reinterpret_cast<float*>(smem) + wave * (ROWS_W * PITCH);
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        img[(a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * PITCH + b * 32 + lr] = acc[a][b][r] * inv;
+  // (LDS operations of one wave execute in order: no barrier between its own writes and reads)
+  unsigned vmax = 0;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    if (!ok_[it]) continue;
+    const int idx = it * 64 + lane;
+    const int row = idx / C8, c8 = idx - row * C8;
+    const int c0 = col0 + c8 * 8;
+    const f32x4 p0 = *reinterpret_cast<const f32x4*>(img + row * PITCH + c8 * 8);
+    const f32x4 p1 = *reinterpret_cast<const f32x4*>(img + row * PITCH + c8 * 8 + 4);
+    float v[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+    const int64_t e = e_[it];
+    if (fz.add_h) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += ((float)h2_[it][j] + (float)l2_[it][j]) * inv2;
+    }
+    float mult[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mult[j] = sc_out;
+    if (fz.mask) {
+      if (fz.mask_float) {
+        const int mm = row0 + row;
+        const int64_t em = (int64_t)(mm - fdiv(mm, fz.div_mask) * mrows) * g.Co + c0;
+        const f32x4 a = *reinterpret_cast<const f32x4*>((const float*)fz.mask + em);
+        const f32x4 b = *reinterpret_cast<const f32x4*>((const float*)fz.mask + em + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mult[j] *= a[j], mult[4 + j] *= b[j];
+      } else {
+        const uint2 u = mk_[it];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (!((u.x >> (8 * j)) & 0xffu)) mult[j] = 0.f;
+          if (!((u.y >> (8 * j)) & 0xffu)) mult[4 + j] = 0.f;
+        }
+      }
+    }
+    if (fz.scale) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(fz.scale + c0), b = *reinterpret_cast<const f32x4*>(fz.scale + c0 + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mult[j] *= a[j], mult[4 + j] *= b[j];
+    }
+    f16x8 h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float xs = v[j] * mult[j];
+      asm volatile("" : "+v"(xs));  // h and the residual from the SAME fp32 value (see split2)
+      const _Float16 hh = (_Float16)xs;
+      h[j] = hh;
+      l[j] = (_Float16)(xs - (float)hh);
+      vmax = max(vmax, __float_as_uint(xs) & 0x7fffffffu);
+    }
+    *reinterpret_cast<f16x8*>(fz.out_h + e) = h;
+    *reinterpret_cast<f16x8*>(fz.out_l + e) = l;
+  }
+  if (amax_out) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) vmax = max(vmax, (unsigned)__shfl_xor((int)vmax, off, 64));
+    const int back = -so < -126 ? -126 : -so;
+    if (lane == 0 && vmax) atomicMax(amax_out, __float_as_uint(__uint_as_float(vmax) * exp2i(back)));
+  }
+}
+
+template <typename CFG, bool FUSE>
+__global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WPE, CFG::WPE)))
+void conv_win_f16x2_kernel(const ConvGeom g, const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al,
+                           const _Float16* __restrict__ Wh, const _Float16* __restrict__ Wl, const int* __restrict__ a_sexp,
+                           const int* __restrict__ w_sexp, const _Float16* __restrict__ zero16, float* __restrict__ out,
+                           int accumulate, unsigned* __restrict__ amax_out, int nb_m, const ConvVjp fz, int ablate_arg) {
+  constexpr int BM = CFG::BM, BN = CFG::BN, TM = CFG::TM, TN = CFG::TN, NW = CFG::NW, PP = CFG::PP;
+#ifdef LK_CONV_DEV  // development switches: 1 skip the epilogue, 2 the MFMAs, 4 the in-loop staging, 32 the barrier
+  const int ablate = ablate_arg;
+#else
+  constexpr int ablate = 0;
+  (void)ablate_arg;
+#endif
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  // The instruction stream of the K loop is what bounds this kernel (the generic kernel issues ~3 vector and ~4 scalar
+  // instructions per MFMA for its addresses): everything per-lane is computed ONCE per tile — fragment addresses of all
+  // nine taps, staging pointers that only advance by a constant per chunk — and everything per-wave is scalar (the wave
+  // index is read with readfirstlane, so LDS-DMA destinations, instruction ranges and tap constants live in SGPRs).
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nblk = gridDim.x;
+  int bid = blockIdx.x;
+  {  // XCD-aware tile order (as conv_f16x2_kernel): every XCD gets a contiguous range of (n-tile major, m-tile minor) tiles
+    const int q = nblk / 8, r = nblk % 8, x = bid % 8, j = bid / 8;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+  }
+  const int tile_n = bid / nb_m, tile_m = bid % nb_m;
+  const int M = g.N * g.Hi * g.Wi;
+  const int KC = g.Ci / 16;
+  const int m0 = tile_m * BM;
+
+  // the last window pixel of every plane of both buffers stays zero: staging either skips it or fills it from zero16
+  if (tid < 32) {
+    const int q = tid >> 3, w8 = tid & 7;  // (buffer, plane) x 8 words
+    reinterpret_cast<unsigned*>(smem + (q >> 1) * CFG::WINZ + (q & 1) * CFG::W_PLANE + CFG::ZERO_OFF)[w8] = 0u;
+  }
+
+  // ---- window staging: wave-instruction i = it * NW + wave covers slots [64 i, 64 i + 64) of [plane][pixel][2];
+  //      per lane a pointer that advances by 16 channels per chunk (0 for rows outside the tensor: they read zero16)
+  const int need_px = BM + 2 * g.Wi + 2;  // window pixels this geometry reads; instructions wholly beyond them are skipped
+  const _Float16* w_ptr[CFG::W_IT];
+  int w_step[CFG::W_IT];
+#pragma unroll
+  for (int it = 0; it < CFG::W_IT; ++it) {
+    const int i = it * NW + wave;
+    const int sidx = i * 64 + lane;
+    const int rem = sidx % (2 * PP);
+    const int px = rem >> 1, pq = rem & 1;
+    const int64_t raster = (int64_t)m0 - (g.Wi + 1) + px;
+    const bool ok = raster >= 0 && raster < M && px < need_px;  // (pixels behind the window, the zero pixel among them: zero16)
+    const _Float16* plane = (i * 64 >= 2 * PP) ? Al : Ah;  // (whole instructions lie inside one plane: 2 PP % 64 == 0)
+    w_ptr[it] = ok ? plane + raster * g.Ci + ((pq ^ swz2(px)) << 3) : zero16;
+    w_step[it] = ok ? 16 : 0;
+  }
+  static_assert((2 * PP) % 64 == 0, "a window plane is a whole number of wave-instructions");
+  auto stage_win = [&](int buf) {  // the next chunk (the pointers advance)
+    const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + buf * CFG::WINZ;
+#pragma unroll
+    for (int it = 0; it < CFG::W_IT; ++it) {
+      const int i = it * NW + wave;  // (scalar)
+      if (i < CFG::W_INSTR && (((i * 64) % (2 * PP)) >> 1) < need_px)
+        __builtin_amdgcn_global_load_lds((gbl_void*)w_ptr[it], (lds_void*)(uintptr_t)(base + i * 1024), 16, 0, 0);
+      w_ptr[it] += w_step[it];
+    }
+  };
+  // ---- weight staging: slots [tap j of the step][plane][n][2]; an instruction lies inside one (tap, plane)
+  static_assert(BN % 32 == 0, "a weight instruction covers 32 output channels of one tap and plane");
+  const _Float16* b_ptr[CFG::B_IT];
+  int b_step[CFG::B_IT];
+#pragma unroll
+  for (int it = 0; it < CFG::B_IT; ++it) {
+    const int i = it * NW + wave;
+    const int sidx = i * 64 + lane;
+    const int pq = sidx & 1, n = (sidx >> 1) % BN, jp = (i * 32) / BN;  // jp: scalar
+    const int col = tile_n * BN + n;
+    const bool ok = col < g.Co;
+    b_ptr[it] = ok ? ((jp & 1) ? Wl : Wh) + (int64_t)col * g.Ci + ((pq ^ swz2(n)) << 3) : zero16;
+    b_step[it] = ok ? 1 : 0;
+  }
+  const int64_t w_tap = (int64_t)g.Co * g.Ci;
+  // tap constants as scalars: weight slice offsets (elements) and window shifts (pixels) of the nine taps
+  int64_t t_woff[9];
+  int t_shift[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    t_woff[t] = (int64_t)g.wt[t] * w_tap;
+    t_shift[t] = (g.dh[t] + 1) * g.Wi + g.dw[t] + 1;
+  }
+  auto stage_b = [&](int kc, int r, int slot) {  // r: compile-time after unrolling
+    const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + 2 * CFG::WINZ + slot * CFG::B_STEP;
+#pragma unroll
+    for (int it = 0; it < CFG::B_IT; ++it) {
+      const int i = it * NW + wave;  // (scalar)
+      if (i < CFG::B_INSTR) {
+        const int j = ((i * 32) / BN) >> 1;  // tap of the step (scalar)
+        const int64_t e = (j == 0 ? t_woff[r * 3] : j == 1 ? t_woff[r * 3 + 1] : t_woff[r * 3 + 2]) + kc * 16;
+        __builtin_amdgcn_global_load_lds((gbl_void*)(b_ptr[it] + e * b_step[it]), (lds_void*)(uintptr_t)(base + i * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  // ---- fragment addresses, once per tile: byte offsets inside a window buffer for every (tile a, tap t) — the zero
+  //      block where the tap falls outside the image — and inside a weight slot for every n-tile b
+  const int wm = wave / CFG::WN, wn = wave % CFG::WN;
+  const int lr = lane & 31, lh = lane >> 5;
+  int a_addr[TM][9];
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+    const int m = m0 + (wm * TM + a) * 32 + lr;
+    int h = 0, w = 0;
+    const bool in = m < M;
+    if (in) {
+      const int rem = m - fdiv(m, g.div_hw) * (g.Hi * g.Wi);
+      h = fdiv(rem, g.div_w), w = rem - h * g.Wi;
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int hh = h + g.dh[t], ww = w + g.dw[t];
+      const bool ok = in && hh >= 0 && hh < g.Hi && ww >= 0 && ww < g.Wi;
+      const int px = (wm * TM + a) * 32 + lr + t_shift[t];
+      a_addr[a][t] = ok ? (px * 2 + (lh ^ swz2(px))) * 16 : CFG::ZERO_OFF;
+    }
+  }
+  int b_addr[TN];
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    const int n = (wn * TN + b) * 32 + lr;
+    b_addr[b] = n * 32 + (lh ^ swz2(n)) * 16;
+  }
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int sexp_a = a_sexp[0], sexp_w = w_sexp[0];
+  const float inv_a = exp2i(-sexp_a < -126 ? -126 : -sexp_a), inv_w = exp2i(-sexp_w < -126 ? -126 : -sexp_w);
+  int so = 0;
+  float sc_out = 1.f, inv2 = 0.f;
+  if constexpr (FUSE) {  // scale of the result from the guaranteed bound (see conv_f16x2_kernel)
+    float bound = fz.in_amax ? __uint_as_float(fz.in_amax[0]) : exp2i(15 - sexp_a < -126 ? -126 : (15 - sexp_a > 127 ? 127 : 15 - sexp_a));
+    bound *= fz.w_l1[0];
+    if (fz.add_h) {
+      const int s2 = fz.add_sexp[0];
+      bound += exp2i(15 - s2 < -126 ? -126 : (15 - s2 > 127 ? 127 : 15 - s2));
+      inv2 = exp2i(-s2 < -126 ? -126 : -s2);
+    }
+    if (fz.mask && fz.mask_float && fz.mult_amax) bound *= __uint_as_float(fz.mult_amax[0]);
+    if (fz.scale) bound *= __uint_as_float(fz.scale_amax[0]);
+    so = scale_exp_for(bound);
+    sc_out = exp2i(so);
+    if (blockIdx.x == 0 && tid == 0) fz.out_sexp[0] = so;
+  }
+
+  // prologue: the first window and the first three taps
+  stage_win(0);
+  stage_b(0, 0, 0);
+  for (int kc = 0; kc < KC; ++kc) {
+    const char* pw = smem + (kc & 1) * CFG::WINZ;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int slot = (kc + r) & 1;  // = (3 kc + r) & 1
+      __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's parts of this step (and of the window of chunk kc) have landed
+      if (!(ablate & 32)) __syncthreads();  // ... everybody's; and nobody reads the buffers that are loaded next any more
+      if (!(ablate & 4)) {
+        if (r < 2) stage_b(kc, r + 1, slot ^ 1);
+        else if (kc + 1 < KC) stage_b(kc + 1, 0, slot ^ 1);
+        if (r == 0 && kc + 1 < KC) stage_win((kc + 1) & 1);
+      }
+      const char* pb = smem + 2 * CFG::WINZ + slot * CFG::B_STEP;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int t = r * 3 + j;  // compile-time
+        f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+          ah[a] = *reinterpret_cast<const f16x8*>(pw + a_addr[a][t]);
+          al[a] = *reinterpret_cast<const f16x8*>(pw + a_addr[a][t] + CFG::W_PLANE);
+        }
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          bh[b] = *reinterpret_cast<const f16x8*>(pb + b_addr[b] + (j * 2) * CFG::B_TAP);
+          bl[b] = *reinterpret_cast<const f16x8*>(pb + b_addr[b] + (j * 2 + 1) * CFG::B_TAP);
+        }
+#ifdef LK_CONV_DEV
+        if (ablate & 2) {
+#pragma unroll
+          for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) acc[a][b][0] += (float)ah[a][0] + (float)al[a][1] + (float)bh[b][2] + (float)bl[b][3];
+          continue;
+        }
+#endif
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b) {
+            f32x16 c = acc[a][b];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], c, 0, 0, 0);  // small terms first
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], c, 0, 0, 0);
+            acc[a][b] = c;
+          }
+      }
+    }
+  }
+  if (ablate & 1) {
+    if (acc[0][0][0] == 12345.678f) out[0] = 1.f;  // (keeps the loop alive)
+    return;
+  }
+
+  if constexpr (FUSE) {
+    fused_vjp_epilogue<TM, TN>(acc, smem, wave, lane, m0 + wm * (TM * 32), tile_n * BN + wn * (TN * 32), M, g, fz, inv_a * inv_w,
+                               inv2, sc_out, so, amax_out);
+    return;
+  }
+  // ---- plain epilogue: un-scale, store NHWC (the output grid may be a strided class of the output tensor), max|out|
+  unsigned vmax = 0;
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int m = m0 + row;
+      if (m >= M) continue;
+      int64_t opix = m;
+      if (!g.dense) {
+        const int n = fdiv(m, g.div_hw), rem = m - n * (g.Hi * g.Wi);
+        const int ci_ = fdiv(rem, g.div_w);
+        opix = ((int64_t)n * g.Ho + ci_ * g.os + g.oh0) * g.Wo + (rem - ci_ * g.Wi) * g.os + g.ow0;
+      }
+      float* orow = out + opix * g.Co;
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const int col = tile_n * BN + (wn * TN + b) * 32 + lr;
+        if (col < g.Co) {
+          float v = acc[a][b][r] * inv_a * inv_w;
+          if (accumulate) v += orow[col];
+          orow[col] = v;
+          vmax = max(vmax, __float_as_uint(v) & 0x7fffffffu);
+        }
+      }
+    }
+  }
+  if (amax_out) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) vmax = max(vmax, (unsigned)__shfl_xor((int)vmax, off, 64));
+    if (lane == 0 && vmax) atomicMax(amax_out, vmax);
+  }
+}
+
 }  // namespace lk
 
 using namespace lk;
@@ -1166,6 +1574,35 @@ static int launch_patch(const ConvGeom& g, const void* Ah, const void* Al, const
   return check_launch("conv_patch_f16x2_kernel");
 }
 
+template <typename CFG>
+static int launch_win(const ConvGeom& g, const void* Ah, const void* Al, const void* Wh, const void* Wl, const int* a_sexp,
+                      const int* w_sexp, const void* zero16, float* out, int accumulate, unsigned* amax_out,
+                      hipStream_t stream, const ConvVjp* fz) {
+  const int64_t M = (int64_t)g.N * g.Hi * g.Wi;
+  const int nb_m = (int)((M + CFG::BM - 1) / CFG::BM), nb_n = (g.Co + CFG::BN - 1) / CFG::BN;
+  if (fz) {
+    const int lds_f = CFG::LDS > CFG::EPI_LDS ? CFG::LDS : CFG::EPI_LDS;
+    static bool attr_set_f = false;
+    if (!attr_set_f) {
+      (void)hipFuncSetAttribute((const void*)conv_win_f16x2_kernel<CFG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_f);
+      attr_set_f = true;
+    }
+    hipLaunchKernelGGL((conv_win_f16x2_kernel<CFG, true>), dim3((unsigned)(nb_m * nb_n)), dim3(CFG::NT), lds_f, stream, g,
+                       (const _Float16*)Ah, (const _Float16*)Al, (const _Float16*)Wh, (const _Float16*)Wl, a_sexp, w_sexp,
+                       (const _Float16*)zero16, out, accumulate, amax_out, nb_m, *fz, g_ablate);
+    return check_launch("conv_win_f16x2_kernel(vjp)");
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv_win_f16x2_kernel<CFG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_win_f16x2_kernel<CFG, false>), dim3((unsigned)(nb_m * nb_n)), dim3(CFG::NT), CFG::LDS, stream, g,
+                     (const _Float16*)Ah, (const _Float16*)Al, (const _Float16*)Wh, (const _Float16*)Wl, a_sexp, w_sexp,
+                     (const _Float16*)zero16, out, accumulate, amax_out, nb_m, ConvVjp{}, g_ablate);
+  return check_launch("conv_win_f16x2_kernel");
+}
+
 // One launch of the implicit GEMM.  `taps`: T x {dh, dw, weight slice}.
 static int conv_dispatch(const void* in_h, const void* in_l, const int* in_sexp, int64_t N, int64_t Hi, int64_t Wi,
                          int64_t Ci, const void* w_h, const void* w_l, const int* w_sexp, int64_t Co,
@@ -1196,6 +1633,26 @@ static int conv_dispatch(const void* in_h, const void* in_l, const int* in_sexp,
     return launch_conv<GramConvCfg>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz, gram_ws);
   }
   g_ablate = ((config >> 8) & 7) | ((config & 524288) ? 8 : 0) | ((config & 1048576) ? 16 : 0) | ((config & 2097152) ? 32 : 0);  // bit 19: chunk-major K order
+  // "window" form (config bit 22): nine taps inside [-1, 1]^2 on the input grid, maps of more than 64 pixels (small maps
+  // run position-major with tap skipping), enough tiles to fill the chip; bit 23: the 512-pixel tile for 64 output channels
+  if ((config & 4194304) && T == 9 && in_mul == 1 && Hc == Hi && Wc == Wi && 2 * Wi + 2 <= 94 && Ci % 16 == 0 && !(config & 16) &&
+      !g.pmajor && (Co == 64 || Co % 128 == 0)) {
+    bool ok = true;
+    for (int t = 0; t < 9; ++t) ok = ok && g.dh[t] >= -1 && g.dh[t] <= 1 && g.dw[t] >= -1 && g.dw[t] <= 1;
+    const int64_t M = N * Hi * Wi;
+    if (ok && (config & 16777216)) {  // four-wave workgroups, two per CU: one workgroup's epilogue under the other's K loop
+      if (Co == 64 && M >= 256 * 512)
+        return launch_win<WinCfg<256, 64, 4, 1, 2>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz);
+      if (Co % 128 == 0 && M * (Co / 128) >= 128 * 512)
+        return launch_win<WinCfg<128, 128, 2, 2, 2>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz);
+    }
+    if (ok && Co == 64 && (config & 8388608) && M >= 512 * 256)
+      return launch_win<WinCfg<512, 64, 8, 1, 2>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz);
+    if (ok && Co == 64 && M >= 256 * 512)
+      return launch_win<WinCfg<256, 64, 4, 2, 4>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz);
+    if (ok && Co % 128 == 0 && M * (Co / 128) >= 256 * 256)
+      return launch_win<WinCfg<256, 128, 4, 2, 2>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz);
+  }
   // "patch" form (A operand resident in LDS across the taps) where the output grid is the input grid
   bool patch = !fz && !(config & 2) && !(config & 16) && in_mul == 1 && Hc == Hi && Wc == Wi && 256 + 2 * Wi + 2 <= 336 && N * Hi * Wi >= 256;
   if ((config & 262144) && Co > 64) patch = false;  // development switch: the patch form for the 64-channel layers only
@@ -1312,6 +1769,8 @@ static int conv_vjp_impl(const void* in_h, const void* in_l, const int* in_sexp,
   fz.in_amax = (const unsigned*)in_amax, fz.w_l1 = w_l1;
   fz.add_h = (const _Float16*)add_h, fz.add_l = (const _Float16*)add_l, fz.add_sexp = add_sexp;
   fz.mask = mask, fz.mask_float = mask_is_float, fz.mult_amax = (const unsigned*)mult_amax, fz.mask_rows = mask ? mask_rows : 1;
+  LK_REQUIRE(fz.mask_rows >= 1 && fz.mask_rows < (1ll << 31), "lk_conv_nhwc_f16x2_vjp: mask_rows out of range");
+  fz.div_mask = make_fastdiv((int)fz.mask_rows);
   fz.scale = scale, fz.scale_amax = (const unsigned*)scale_amax;
   fz.out_h = (_Float16*)out_h, fz.out_l = (_Float16*)out_l, fz.out_sexp = out_sexp;
   return conv_dispatch(in_h, in_l, in_sexp, N, Hi, Wi, Ci, w_h, w_l, w_sexp, Co, Ho, Wo, 1, Ho, Wo, 1, 0, 0, T, taps, zero16,

@@ -309,3 +309,59 @@ def test_fused_launch_accumulates_the_gram_of_its_result(variant, n_img, monkeyp
     # shapes the fused Gram does not cover are refused by the query, and the wrapper then launches the plain kernel
     small = cv.conv_backward_data_vjp(prep, K.split_f16x2(g[:8].permute(0, 2, 3, 1).contiguous()), (H, H), want_gram=True)
     assert small.gram_parts is None
+
+
+WIN = 4194304  # config bit 22: the window form (input window of a pixel tile resident in LDS); bit 23: its 512-pixel tile
+WINDOW_CASES = [(64, 64, 32, 131, WIN), (64, 64, 32, 131, WIN | 8388608), (128, 128, 16, 290, WIN), (64, 128, 32, 72, WIN),
+                (128, 256, 16, 160, WIN), (64, 64, 32, 131, WIN | 16777216), (128, 128, 16, 290, WIN | 16777216),
+                (64, 128, 32, 72, WIN | 16777216), (128, 64, 40, 88, WIN | 16777216)]
+
+
+@pytest.mark.parametrize("cin,cout,H,n_img,cfg", WINDOW_CASES, ids=[f"{c[0]}-{c[1]}-{c[2]}x{c[2]}-n{c[3]}-{c[4] >> 22}" for c in WINDOW_CASES])
+def test_window_form_backward_forward_and_fused_epilogue(cin, cout, H, n_img, cfg):
+    """conv_win_f16x2_kernel (3 x 3 / stride 1 on maps of more than 64 pixels) against fp64: backward-data, forward, the
+    accumulate mode, the fused VJP epilogue — with an image count that leaves the last pixel tile ragged — and bit for
+    bit against the generic kernel's fused result (same products, same order of the k16 steps within a tap differs:
+    compared at 1e-6 instead)."""
+    from laplace_amd import conv as cv
+    from laplace_amd._lib import get_kernels
+
+    K = get_kernels()
+    m = _conv(cin, cout, 3, 1, 1)
+    N = n_img
+    torch.manual_seed(23)
+    g = torch.randn(N, cout, H, H, device=DEV) * 1e-2
+    x = torch.randn(N, cin, H, H, device=DEV)
+    want_b = torch.nn.grad.conv2d_input((N, cin, H, H), m.weight.double().cpu(), g.double().cpu(), stride=1, padding=1)
+    want_f = F.conv2d(x.double().cpu(), m.weight.double().cpu(), None, 1, 1)
+    gs = K.split_f16x2(g.permute(0, 2, 3, 1).contiguous())
+    xs = K.split_f16x2(x.permute(0, 2, 3, 1).contiguous())
+    prep = cv.PreparedConv(m)
+    prev = K.conv_config
+    try:
+        K.conv_config = 2 | cfg
+        amax = torch.zeros(1, dtype=torch.float32, device=DEV)
+        dx = cv.conv_backward_data(prep, gs, (H, H), amax_out=amax)
+        y = cv.conv_forward(prep, xs)
+        base = torch.randn_like(dx) * dx.abs().max()  # (comparable magnitudes: `acc - base` must not cancel below the bar)
+        acc = base.clone()
+        cv.conv_backward_data(prep, gs, (H, H), out=acc, accumulate=True)
+        S = 2 if N % 2 == 0 else 1
+        B = N // S
+        mask = (torch.rand(B, H, H, cin, device=DEV) > 0.4).to(torch.uint8)
+        addend = K.split_f16x2(torch.randn(N, H, H, cin, device=DEV) * 0.05)
+        sc = (torch.rand(cin, device=DEV) * 1.5 + 0.25).contiguous()
+        fused = cv.conv_backward_data_vjp(prep, gs, (H, H), add=addend, mult=mask, scale=sc, scale_amax=K.absmax(sc))
+        K.conv_config = 2
+        fused_ref = cv.conv_backward_data_vjp(prep, gs, (H, H), add=addend, mult=mask, scale=sc, scale_amax=K.absmax(sc))
+    finally:
+        K.conv_config = prev
+    assert rel(dx.permute(0, 3, 1, 2), want_b) < 1e-5
+    assert abs(amax.item() - dx.abs().max().item()) <= 1e-6 * amax.item()
+    assert rel(y.permute(0, 3, 1, 2), want_f) < 1e-5
+    assert rel(acc - base, dx) < 1e-5
+    want_v = (want_b.permute(0, 2, 3, 1) + addend.float().double().cpu())
+    want_v = (want_v.reshape(S, B, H, H, cin) * mask.double().cpu()).reshape(N, H, H, cin) * sc.double().cpu()
+    assert rel(fused.float(), want_v) < 1e-5
+    assert torch.equal(fused.sexp, fused_ref.sexp) and rel(fused.float(), fused_ref.float()) < 1e-6
+    assert abs(fused.amax.item() - fused.float().abs().max().item()) <= 1e-5 * fused.amax.item()

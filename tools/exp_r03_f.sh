@@ -1,0 +1,8 @@
+mkdir -p gpurun_out; export TMPDIR=/tmp
+O=gpurun_out/exp_r03_f.log; : > $O
+timeout 600 python -m pytest tests/test_gpu_conv.py -m gpu -q -x -k "window" > gpurun_out/exp_r03_f_tests.log 2>&1
+echo "tests rc=$?" >> $O; tail -25 gpurun_out/exp_r03_f_tests.log | cut -c1-250 >> $O
+for cfg in "LK_CONV_CONFIG=2" "LK_CONV_CONFIG=4194306" "LK_CONV_CONFIG=12582914"; do
+  for rep in 1 2; do echo "$cfg: $(env $cfg timeout 300 python tools/steps_only.py 48 2>&1 | tail -1)" >> $O; done
+done
+cat $O

@@ -1,0 +1,7 @@
+mkdir -p gpurun_out; export TMPDIR=/tmp
+O=gpurun_out/exp_r03_m.log; : > $O
+for rep in 1 2 3; do
+for cfg in "LK_CONV_CONFIG=2" "LK_CONV_CONFIG=12582914" "LK_CONV_CONFIG=20971522"; do
+  echo "$cfg: $(env $cfg timeout 300 python tools/steps_only.py 48 2>&1 | tail -1)" >> $O
+done; done
+cat $O
