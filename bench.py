@@ -84,7 +84,8 @@ def fit_steps(backend, batches, n_steps, world, overlap=True, serial=False):
         X, y = batches[i % len(batches)]
         acc.add_batch(X, y)
     if world > 1:
-        allreduce_curvature(acc.tensors(), mirror=False)  # packed upper triangles; finalize() mirrors
+        info = allreduce_curvature(acc.tensors(), mirror=False)  # packed upper triangles; finalize() mirrors
+        fit_steps.last_exchange = info
     loss, H = acc.finalize()
     return loss, H
 
@@ -620,6 +621,27 @@ def main():
             result["other_configs"] = small_config_legs(dev)
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(0.0 if SELFTEST else args.cpu_seconds)
+    if world > 1:
+        # the fit's ONE collective: message size against what the model's factor shapes say it must be (a wrong pack /
+        # a missed factor shows here, not as a silently wrong posterior), and its stand-alone time on the same buffer size
+        from laplace_amd.laplace import expected_exchange_bytes
+
+        info = getattr(fit_steps, "last_exchange", None) or {}
+        want = expected_exchange_bytes(model)
+        buf = torch.zeros(max(want // 4, 1), dtype=torch.float32, device=dev)
+        dist.all_reduce(buf)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            dist.all_reduce(buf)
+        barrier()
+        t_ar = (time.perf_counter() - t0) / 5
+        if rank == 0:
+            result["allreduce"] = {"bytes": info.get("bytes"), "expected_bytes": want, "ok": info.get("bytes") == want,
+                                   "ms": t_ar * 1e3, "bus_GBps": 2 * (world - 1) / world * want / t_ar / 1e9,
+                                   "note": "one all-reduce per fit (packed upper triangles of the 43 factors + loss)"}
+            assert info.get("bytes") == want, f"curvature exchange moved {info.get('bytes')} bytes, expected {want}"
+        del buf
     if world > 1 and not args.no_eigh:
         # the factors are identical on every rank after the all-reduce: shard the eigensolves over the GPUs
         barrier()

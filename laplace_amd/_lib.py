@@ -452,7 +452,7 @@ class HipKernels:
     fuse_gram = os.environ.get("LK_FUSE_GRAM", "0") == "1"
 
     def conv_nhwc_f16x2_vjp(self, x, wplanes, wsexp, w_l1, Ho, Wo, taps, add=None, mult=None, mult_amax=None, scale=None,
-                            scale_amax=None, config=None, want_gram=False):
+                            scale_amax=None, config=None, want_gram=False, amax_word=None):
         """one dense launch of the convolution with the element-wise VJP fused into its epilogue (lk_conv_nhwc_f16x2_vjp):
         ``(conv(x) + add) * mult * scale[channel]`` -> SplitTensor [N, Ho, Wo, Co] carrying its measured ``amax``.
         ``mult``: [B, Ho, Wo, Co] uint8 / bool mask or fp32 multiplier (``mult_amax``: its bound, fp32 only), shared by
@@ -463,7 +463,7 @@ class HipKernels:
         assert wplanes.shape[3] == Ci
         planes = torch.empty((2, N, Ho, Wo, Co), dtype=torch.float16, device=dev)
         sexp = torch.empty(1, dtype=torch.int32, device=dev)
-        amax = torch.zeros(1, dtype=torch.float32, device=dev)
+        amax = amax_word if amax_word is not None else torch.zeros(1, dtype=torch.float32, device=dev)
         m_is_float, mask_rows = 0, 0
         if mult is not None:
             if mult.dtype == torch.bool:

@@ -14,11 +14,13 @@ Boundary (laplace/baselaplace.py:179-194): the class is instantiated lazily as
 substrings ``backpack`` / ``asdl`` / ``asdfghjkl`` that baselaplace.py:142-149,943-952,1313-1325
 sniff for.
 
-What runs where: the model forward and the convolution backward-data kernels are stock PyTorch-ROCm / MIOpen,
-driven by the seed-batched reverse sweep of :mod:`laplace_amd.sweep` (all seeds in one pass; models it cannot
-trace fall back to the autograd tape of :mod:`laplace_amd.capture`); everything named in BASELINE.json's
-north_star — likelihood-Hessian root + loss, the element-wise VJPs of the sweep, A/G factor accumulation,
-diagonal / dense GGN, per-sample Jacobian assembly — is a HIP entry point of ``include/laplace_hip.h`` (through
+What runs where: for convolutional networks the whole minibatch step runs on our own kernels — the forward (implicit-GEMM
+convolution on split-fp16 operands, fused BatchNorm / add / activation) and the seed-batched reverse sweep on NHWC split
+tensors (:mod:`laplace_amd.sweep_nhwc`: backward-data with the element-wise VJP in its epilogue, all seeds in one pass);
+graphs that path has no rule for take the NCHW sweep of :mod:`laplace_amd.sweep` (library convolutions, our element-wise
+kernels), models ``torch.fx`` cannot trace the autograd tape of :mod:`laplace_amd.capture`.  Everything named in
+BASELINE.json's north_star — likelihood-Hessian root + loss, the VJPs of the sweep, A/G factor accumulation, diagonal /
+dense GGN, per-sample Jacobian assembly — is a HIP entry point of ``include/laplace_hip.h`` (through
 :mod:`laplace_amd._lib`).  Only fp32 models on a ROCm device are accepted; there is no CPU path.
 """
 from __future__ import annotations

@@ -127,7 +127,7 @@ def fused_backward_ok(m: nn.Conv2d) -> bool:
 
 
 def conv_backward_data_vjp(prep: PreparedConv, g: SplitTensor, in_hw, cscale=None, add=None, mult=None, mult_amax=None,
-                           scale=None, scale_amax=None, want_gram=False) -> SplitTensor:
+                           scale=None, scale_amax=None, want_gram=False, amax_word=None) -> SplitTensor:
     """``(dX + add) * mult * scale[channel]`` as a SplitTensor (with its measured ``amax``): :func:`conv_backward_data`
     followed by the sweep's element-wise VJP, in one launch (stride-1 convs, see :func:`fused_backward_ok`)."""
     K = get_kernels()
@@ -137,6 +137,8 @@ def conv_backward_data_vjp(prep: PreparedConv, g: SplitTensor, in_hw, cscale=Non
     (Hc, Wc, oh0, ow0, taps), = backward_plan(m, Hin, Win)
     assert (Hc, Wc, oh0, ow0) == (Hin, Win, 0, 0)
     kw = {"want_gram": True} if want_gram else {}  # (``want_gram``: see HipKernels.conv_nhwc_f16x2_vjp)
+    if amax_word is not None:
+        kw["amax_word"] = amax_word  # a zeroed device word for the measured max|result| (saves a fill launch)
     return K.conv_nhwc_f16x2_vjp(g, planes, sexp, prep.backward_l1(cscale), Hin, Win, taps, add=add, mult=mult,
                                  mult_amax=mult_amax, scale=scale, scale_amax=scale_amax, **kw)
 

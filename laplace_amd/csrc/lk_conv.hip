@@ -872,8 +872,14 @@ __global__ __launch_bounds__(512) void conv_patch_f16x2_kernel(const ConvGeom g,
                                                                const int* __restrict__ a_sexp, const int* __restrict__ w_sexp,
                                                                const _Float16* __restrict__ zero16, float* __restrict__ out,
                                                                int accumulate, unsigned* __restrict__ amax_out, int nb_m,
-                                                               int ablate) {
+                                                               int ablate_arg) {
   constexpr int BM = CFG::BM, BN = CFG::BN, TM = CFG::TM, TN = CFG::TN;
+#ifdef LK_CONV_DEV
+  const int ablate = ablate_arg;
+#else
+  constexpr int ablate = 0;
+  (void)ablate_arg;
+#endif
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nblk = gridDim.x;

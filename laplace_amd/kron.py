@@ -285,72 +285,79 @@ class HipKron(_KronBase):
         out._conv = {"checked": False, "source": self, "slots": [(bi, fi) for _, bi, fi in all_dense]}
         return out
 
-    # -- generic algebra (plumbing; torch ops) ------------------------------------------------------
+    # -- generic algebra: the differentiable torch route behind the HIP kernels (same results as utils/matrix.py:152-279) -----
+    # Everything below is phrased over BLOCK VIEWS of the flattened parameter axis: block b of the Kronecker matrix acts on
+    # the columns [off, off + size) of W, seen as a [rows, d_1, ..., d_k] tensor whose axis i is contracted with factor i
+    # (a vector stands for a diagonal factor).
+    def _block_views(self):
+        """(column offset, column count, factors) of every block along the flattened parameter axis"""
+        off = 0
+        for Fs in self.kfacs:
+            size = 1
+            for F_ in Fs:
+                size *= len(F_)
+            yield off, size, Fs
+            off += size
+
+    @staticmethod
+    def _contract_axis(X: torch.Tensor, F_: torch.Tensor, axis: int) -> torch.Tensor:
+        """``Y[..., i, ...] = sum_j F[i, j] X[..., j, ...]`` along ``axis`` (a 1-D ``F`` is a diagonal: a scaling)"""
+        if F_.ndim == 1:
+            shape = [1] * X.ndim
+            shape[axis] = -1
+            return X * F_.reshape(shape)
+        return torch.movedim(torch.tensordot(X, F_, dims=([axis], [1])), -1, axis)
+
     def _bmm(self, W: torch.Tensor) -> torch.Tensor:
         assert W.ndim == 3
-        B, K_, P = W.shape
-        W = W.reshape(B * K_, P)
-        cur, SW = 0, []
-        for Fs in self.kfacs:
-            if len(Fs) == 1:
-                Q = Fs[0]
-                p = len(Q)
-                Wp = W[:, cur:cur + p]
-                SW.append(Wp @ Q.T if Q.ndim > 1 else Wp * Q.view(1, -1))
-                cur += p
-            else:
-                Q, H = Fs
-                p_in, p_out = len(Q), len(H)
-                Wp = W[:, cur:cur + p_in * p_out].reshape(B * K_, p_in, p_out)
-                QW = Q @ Wp if Q.ndim > 1 else Q.view(-1, 1) * Wp
-                QWH = QW @ H.T if H.ndim > 1 else QW * H.view(1, -1)
-                SW.append(QWH.reshape(B * K_, p_in * p_out))
-                cur += p_in * p_out
-        return torch.cat(SW, dim=1).reshape(B, K_, P)
+        rows = W.reshape(-1, W.shape[-1])
+        out = torch.empty_like(rows)
+        for off, size, Fs in self._block_views():
+            X = rows[:, off:off + size].reshape(rows.shape[0], *[len(F_) for F_ in Fs])
+            for i, F_ in enumerate(Fs):
+                X = self._contract_axis(X, F_, i + 1)
+            out[:, off:off + size] = X.reshape(rows.shape[0], size)
+        return out.reshape(W.shape)
 
     def bmm(self, W: torch.Tensor, exponent: float = 1) -> torch.Tensor:
         if exponent != 1:
             raise ValueError("Only supported after decomposition.")
-        if W.ndim == 1:
-            return self._bmm(W.unsqueeze(0).unsqueeze(0)).squeeze()
-        if W.ndim == 2:
-            return self._bmm(W.unsqueeze(1)).squeeze()
-        if W.ndim == 3:
-            return self._bmm(W)
-        raise ValueError("Invalid shape for W")
+        if W.ndim not in (1, 2, 3):
+            raise ValueError("Invalid shape for W")
+        lead = {1: (1, 1), 2: (W.shape[0], 1), 3: tuple(W.shape[:2])}[W.ndim]
+        res = self._bmm(W.reshape(*lead, W.shape[-1]))
+        return res if W.ndim == 3 else res.squeeze()
+
+    @staticmethod
+    def _factor_logdet(F_: torch.Tensor) -> torch.Tensor:
+        return F_.logdet() if F_.ndim > 1 else F_.log().sum()
 
     def logdet(self) -> torch.Tensor:
+        # log det (F_1 (x) ... (x) F_k) = sum_i (size / d_i) log det F_i
         total = 0
-        for F in self.kfacs:
-            if len(F) == 1:
-                total = total + (F[0].logdet() if F[0].ndim > 1 else F[0].log().sum())
-            else:
-                Hi, Hj = F
-                p_in, p_out = len(Hi), len(Hj)
-                total = total + p_out * (Hi.logdet() if Hi.ndim > 1 else Hi.log().sum())
-                total = total + p_in * (Hj.logdet() if Hj.ndim > 1 else Hj.log().sum())
+        for _, size, Fs in self._block_views():
+            for F_ in Fs:
+                total = total + (size // len(F_)) * self._factor_logdet(F_)
         return total
 
     def diag(self) -> torch.Tensor:
-        out = []
-        for F in self.kfacs:
-            d0 = F[0].diagonal() if F[0].ndim > 1 else F[0]
-            if len(F) == 1:
-                out.append(d0)
-            else:
-                d1 = F[1].diagonal() if F[1].ndim > 1 else F[1]
-                out.append(torch.outer(d0, d1).flatten())
-        return torch.cat(out)
+        parts = []
+        for _, _, Fs in self._block_views():
+            d = None
+            for F_ in Fs:
+                fd = F_.diagonal() if F_.ndim > 1 else F_
+                d = fd if d is None else (d.unsqueeze(-1) * fd).reshape(-1)
+            parts.append(d)
+        return torch.cat(parts)
 
     def to_matrix(self) -> torch.Tensor:
         blocks = []
-        for F in self.kfacs:
-            F0 = F[0] if F[0].ndim > 1 else F[0].diag()
-            if len(F) == 1:
-                blocks.append(F0)
-            else:
-                F1 = F[1] if F[1].ndim > 1 else F[1].diag()
-                blocks.append(_kron2(F0, F1))
+        for _, _, Fs in self._block_views():
+            M = None
+            for F_ in Fs:
+                F2 = F_ if F_.ndim > 1 else F_.diag()
+                M = F2 if M is None else _kron2(M, F2)
+            blocks.append(M)
         return torch.block_diag(*blocks)
 
 
@@ -579,53 +586,53 @@ class HipKronDecomposed(_KronDecomposedBase):
                     K.kron_sandwich(Wc, cur, P, B * K_, Qs[0].contiguous(), Qs[1].contiguous(), lam, out)
                     cur += len(ls[0]) * len(ls[1])
             return out.reshape(B, K_, P)
-        W = W.reshape(B * K_, P)
-        cur, SW = 0, []
+        # differentiable torch route (eigenvalues / prior with requires_grad, CPU tensors): in the eigenbasis of block b
+        # the operator is diagonal, so  S W_b = Q ((Q^T W_b) . lam) Q^T  with Q = Q_1 (x) Q_2 applied factor by factor
+        rows = W.reshape(B * K_, P)
+        out = torch.empty_like(rows)
+        off = 0
         for ls, Qs, delta in zip(self.eigenvalues, self.eigenvectors, self.deltas):
-            lam = self._block_pow(ls, delta, exponent)
-            if len(ls) == 1:
-                Q, p = Qs[0], len(ls[0])
-                Wp = W[:, cur:cur + p]
-                SW.append(((Wp @ Q) * lam.reshape(1, -1)) @ Q.T)
-                cur += p
-            else:
-                Q1, Q2 = Qs
-                p_in, p_out = len(ls[0]), len(ls[1])
-                Wp = W[:, cur:cur + p_in * p_out].reshape(B * K_, p_in, p_out)
-                Wp = (Q1.T @ Wp @ Q2) * lam.unsqueeze(0)
-                Wp = Q1 @ Wp @ Q2.T
-                SW.append(Wp.reshape(B * K_, p_in * p_out))
-                cur += p_in * p_out
-        return torch.cat(SW, dim=1).reshape(B, K_, P)
+            dims = [len(l) for l in ls]
+            size = 1
+            for d in dims:
+                size *= d
+            lam = self._block_pow(ls, delta, exponent).reshape(1, *dims)
+            X = rows[:, off:off + size].reshape(rows.shape[0], *dims)
+            for i, Q in enumerate(Qs):                       # into the eigenbasis: contract axis i with Q^T
+                X = torch.movedim(torch.tensordot(X, Q, dims=([i + 1], [0])), -1, i + 1)
+            X = X * lam
+            for i, Q in enumerate(Qs):                       # and back: contract axis i with Q
+                X = torch.movedim(torch.tensordot(X, Q, dims=([i + 1], [1])), -1, i + 1)
+            out[:, off:off + size] = X.reshape(rows.shape[0], size)
+            off += size
+        return out.reshape(B, K_, P)
 
     def inv_square_form(self, W: torch.Tensor) -> torch.Tensor:
         SW = self._bmm(W, exponent=-1)
         return torch.bmm(W, SW.transpose(1, 2))
 
     def bmm(self, W: torch.Tensor, exponent: float = -1) -> torch.Tensor:
-        if W.ndim == 1:
-            return self._bmm(W.unsqueeze(0).unsqueeze(0), exponent).squeeze()
-        if W.ndim == 2:
-            return self._bmm(W.unsqueeze(1), exponent).squeeze()
-        if W.ndim == 3:
-            return self._bmm(W, exponent)
-        raise ValueError("Invalid shape for W")
+        if W.ndim not in (1, 2, 3):
+            raise ValueError("Invalid shape for W")
+        lead = {1: (1, 1), 2: (W.shape[0], 1), 3: tuple(W.shape[:2])}[W.ndim]
+        res = self._bmm(W.reshape(*lead, W.shape[-1]), exponent)
+        return res if W.ndim == 3 else res.squeeze()
 
     def diag(self, exponent: float = 1) -> torch.Tensor:
-        out = []
+        # diag(Q diag(lam) Q^T)_p = sum_e Q[p, e]^2 lam[e]; for Q = Q_1 (x) Q_2 the squares factorise as well
+        parts = []
         for Qs, ls, delta in zip(self.eigenvectors, self.eigenvalues, self.deltas):
             lam = self._block_pow(ls, delta, exponent)
             if len(ls) == 1:
-                out.append(((Qs[0] ** 2) * lam.reshape(1, -1)).sum(1))
+                parts.append(torch.einsum("pe,e->p", Qs[0].square(), lam.reshape(-1)))
             else:
-                Q1, Q2 = Qs
-                out.append(((Q1**2) @ lam @ (Q2**2).T).flatten())
-        return torch.cat(out)
+                parts.append(torch.einsum("ae,ef,bf->ab", Qs[0].square(), lam, Qs[1].square()).reshape(-1))
+        return torch.cat(parts)
 
     def to_matrix(self, exponent: float = 1) -> torch.Tensor:
         blocks = []
         for Qs, ls, delta in zip(self.eigenvectors, self.eigenvalues, self.deltas):
-            lam = self._block_pow(ls, delta, exponent)
+            lam = self._block_pow(ls, delta, exponent).reshape(-1)
             Q = Qs[0] if len(ls) == 1 else _kron2(Qs[0], Qs[1])
-            blocks.append((Q * lam.reshape(1, -1)) @ Q.T)
+            blocks.append(torch.einsum("pe,e,qe->pq", Q, lam, Q))
         return torch.block_diag(*blocks)

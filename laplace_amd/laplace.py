@@ -121,14 +121,16 @@ def resolve_distributed(train_loader, distributed, group=None) -> bool:
     return False
 
 
-def allreduce_curvature(tensors: list[torch.Tensor], group=None, mirror: bool = True) -> None:
+def allreduce_curvature(tensors: list[torch.Tensor], group=None, mirror: bool = True) -> dict | None:
     """Sum the accumulated curvature over ranks with ONE collective (RCCL over xGMI when the backend is "nccl"; gloo in
     the CPU tests).  Square fp32 matrices are symmetric factors: only their packed upper triangles travel (half the
     bytes; ``lk_pack_upper_f32`` writes them straight into the exchange buffer, the all-reduce runs on that buffer in
     place, ``lk_unpack_upper_f32`` writes the sums back) — no concatenated copy of the squares.  ``mirror``: restore the
-    lower triangles afterwards (callers that symmetrise later anyway pass ``False``)."""
+    lower triangles afterwards (callers that symmetrise later anyway pass ``False``).  Returns what was exchanged
+    (``{"bytes": .., "tensors": .., "packed": ..}``; ``None`` without a process group) so that a launch script can assert
+    the message size it expects (ResNet-18: 188 MB of packed upper triangles)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return
+        return None
     from laplace_amd._lib import get_kernels
 
     K = get_kernels()
@@ -153,6 +155,23 @@ def allreduce_curvature(tensors: list[torch.Tensor], group=None, mirror: bool = 
         else:
             t.copy_(flat[off:off + n].view_as(t))
         off += n
+    return {"bytes": int(flat.numel() * flat.element_size()), "tensors": len(tensors), "packed": int(sum(sym))}
+
+
+def expected_exchange_bytes(model_or_shapes) -> int:
+    """bytes of ONE data-parallel curvature exchange of a KFAC fit: packed upper triangles of every factor (G, A per
+    Linear / Conv2d weight) + the loss word, fp32 — what :func:`allreduce_curvature` must report (asserted by
+    ``bench.py --gpus N`` and tools/launch_multi_gpu.sh).  ``model_or_shapes``: a module or a list of factor sizes."""
+    if isinstance(model_or_shapes, nn.Module):
+        sizes = []
+        for m in model_or_shapes.modules():
+            if isinstance(m, nn.Linear) and m.weight.requires_grad:
+                sizes += [m.out_features, m.in_features]
+            elif isinstance(m, nn.Conv2d) and m.weight.requires_grad:
+                sizes += [m.out_channels, m.in_channels * m.kernel_size[0] * m.kernel_size[1]]
+    else:
+        sizes = list(model_or_shapes)
+    return 4 * (sum(n * (n + 1) // 2 if n > 1 else 1 for n in sizes) + 1)
 
 
 def _share_n_outputs(la, group=None) -> None:

@@ -302,7 +302,8 @@ class SplitSweep(SeedBatchedSweep):
                 # (in a KFAC sweep every cotangent that comes out of a fused launch is the output gradient of a tapped
                 # convolution, possibly up to a deferred BatchNorm scale: let the launch accumulate its Gram on the way)
                 return lazy[0].fused(add=rest[0] if rest else None, mult=mult, mult_amax=mult_amax, scale=scale,
-                                     scale_amax=scale_amax, want_gram=self._want_gram)
+                                     scale_amax=scale_amax, want_gram=self._want_gram,
+                                     amax_word=self._new_word() if self._new_word is not None else None)
             parts = _materialize(parts)
         f32 = [p for p in parts if isinstance(p, _F32)]
         spl = [p for p in parts if isinstance(p, SplitTensor)]
@@ -329,6 +330,7 @@ class SplitSweep(SeedBatchedSweep):
 
     # ---- reverse sweep ------------------------------------------------------------------------------------------------
     _want_gram = False
+    _new_word = None  # zeroed device words of the running sweep (one fill per 64 of them)
 
     @torch.no_grad()
     def backward(self, seeds, on_tap=None, defer_bn_scale: bool = False, keep_split: bool = False, fuse_gram: bool = False):
@@ -360,6 +362,8 @@ class SplitSweep(SeedBatchedSweep):
             w = words[word_i[0]:word_i[0] + 1]
             word_i[0] += 1
             return w
+
+        self._new_word = new_word
 
         def push(n, part):
             if not isinstance(n, fx.Node) or n.op == "placeholder":
@@ -510,6 +514,7 @@ class SplitSweep(SeedBatchedSweep):
                         push(node.args[0], p)
                 else:
                     raise SweepUnsupported(f"no NHWC rule for method {t}")
+        self._new_word = None
         if remaining:
             raise SweepUnsupported(f"no cotangent reached {sorted(remaining)}")
         if on_tap is None and not keep_split:

@@ -127,7 +127,7 @@ class EmulatedKernels:
     gram_min_rows = 0
 
     def conv_nhwc_f16x2_vjp(self, x, wplanes, wsexp, w_l1, Ho, Wo, taps, add=None, mult=None, mult_amax=None, scale=None,
-                            scale_amax=None, config=None, want_gram=False):
+                            scale_amax=None, config=None, want_gram=False, amax_word=None):
         """lk_conv_nhwc_f16x2_vjp: the convolution, then (conv + add) * mult * scale split with the scale of the
         guaranteed bound max|in| * l1(W) (+ ...); the measured max|.| rides along as ``amax``"""
         N = x.shape[0]

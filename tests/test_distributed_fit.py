@@ -175,3 +175,21 @@ def test_sharded_loader_refuses_a_shuffle_that_the_ranks_cannot_reproduce():
         seen += [float(v) for X, _ in ShardedLoader(ld, rank, 2) for v in X.reshape(-1)]
     assert sorted(seen) == [float(i) for i in range(12)]
     assert len(list(ShardedLoader(DataLoader(ds, batch_size=2), 0, 1))) == 6
+
+
+def test_expected_exchange_bytes_of_resnet18():
+    """what bench.py asserts on a multi-GPU run: the fit's one all-reduce moves the packed upper triangles of the 42 dense
+    factors + the loss word — 188 MB for ResNet-18 (376 MB as squares)"""
+    from laplace_amd.laplace import expected_exchange_bytes
+    from laplace_amd.nets import ResNet18
+
+    m = ResNet18(10)
+    want = expected_exchange_bytes(m)
+    sizes = []
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Conv2d):
+            sizes += [mod.out_channels, mod.in_channels * 9 if mod.kernel_size[0] == 3 else mod.in_channels]
+        elif isinstance(mod, torch.nn.Linear):
+            sizes += [mod.out_features, mod.in_features]
+    assert len(sizes) == 42 and want == 4 * (sum(n * (n + 1) // 2 for n in sizes) + 1)
+    assert 187e6 < want < 189e6
