@@ -155,6 +155,7 @@ struct ConvGeom {
                             // so the taps that fall outside the image there are skipped as whole K stages
   int dense;                // the output grid is the output tensor (os = 1, Hc = Ho, Wc = Wo): output pixel = m
   int out_nchw;             // write out[n][co][pixel] (dense grids with Ho*Wo % 4 == 0 only): float4 along the pixels
+  int chunk_major;          // K order: channel chunks major, taps minor (the nine taps of one 32-channel chunk back to back)
 };
 
 template <int BM_, int BN_, int BK_, int WM_, int WN_, int NBUF_ = 2, int WPE_ = 2, bool MIDBAR_ = false>
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
     // so that only a quarter-to-sixteenth-depth window has to survive in L2 between them — was measured: better on the
     // stride-2 classes, worse on the 64- and 512-channel layers, 10.66 vs 10.50 ms per step; config bit 19 selects it.)
     int tj, kc;
-    if (ablate & 8) kc = s / ntap, tj = s - kc * ntap;
+    if (g.chunk_major) kc = s / ntap, tj = s - kc * ntap;
     else tj = s / KC, kc = s - tj * KC;
     const int t = (int)((tap_list >> (4 * tj)) & 15ull);
     char* base = smem + buf * CFG::STAGE;
@@ -1630,6 +1631,10 @@ static int conv_dispatch(const void* in_h, const void* in_l, const int* in_sexp,
   g.pmajor = (Hc * Wc <= (64 << (2 * ((config >> 16) & 3))) && N >= 64 && !(config & 16) && !(config & 32768)) ? 1 : 0;
   g.dense = out_step == 1 && oh0 == 0 && ow0 == 0 && Hc == Ho && Wc == Wo;
   g.out_nchw = (config & 16) ? 1 : 0;
+  // K order: bit 19 = chunk-major everywhere; bit 25 = chunk-major where the input has 128 or 256 channels (a tile's
+  // window then has to survive 36 / 72 stages between a tap and the next in tap-major order: measured 3.2 x the operand
+  // bytes from the fabric on those launches, none on the 64-channel ones)
+  g.chunk_major = ((config & 524288) || ((config & 33554432) && (Ci == 128 || Ci == 256))) ? 1 : 0;
   LK_REQUIRE(!g.out_nchw || (g.dense && (Ho * Wo) % 4 == 0 && !accumulate),
              "lk_conv_nhwc_f16x2: position-contiguous output needs a dense grid with Ho*Wo % 4 == 0 and no accumulate");
   hipStream_t st = (hipStream_t)stream;
@@ -1638,7 +1643,7 @@ static int conv_dispatch(const void* in_h, const void* in_l, const int* in_sexp,
     g_ablate = 0;
     return launch_conv<GramConvCfg>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz, gram_ws);
   }
-  g_ablate = ((config >> 8) & 7) | ((config & 524288) ? 8 : 0) | ((config & 1048576) ? 16 : 0) | ((config & 2097152) ? 32 : 0);  // bit 19: chunk-major K order
+  g_ablate = ((config >> 8) & 7) | ((config & 1048576) ? 16 : 0) | ((config & 2097152) ? 32 : 0);  // (development build only)
   // "window" form (config bit 22): nine taps inside [-1, 1]^2 on the input grid, maps of more than 64 pixels (small maps
   // run position-major with tap skipping), enough tiles to fill the chip; bit 23: the 512-pixel tile for 64 output channels
   if ((config & 4194304) && T == 9 && in_mul == 1 && Hc == Hi && Wc == Wi && 2 * Wi + 2 <= 94 && Ci % 16 == 0 && !(config & 16) &&

@@ -102,6 +102,7 @@ CASES = {
     "LK_CONV_CONFIG window, 512-pixel tile": dict(kernel_attrs={"conv_config": 2 | WIN | WIN_Z}),
     "LK_CONV_CONFIG window, four waves": dict(kernel_attrs={"conv_config": 2 | WIN | WIN_4}),
     "LK_CONV_CONFIG chunk-major K order": dict(kernel_attrs={"conv_config": 2 | (1 << 19)}),
+    "LK_CONV_CONFIG chunk-major K order on 128 / 256 channels": dict(kernel_attrs={"conv_config": 2 | (1 << 25)}),
     "LK_CONV_CONFIG plain row order": dict(kernel_attrs={"conv_config": 2 | 32768}),
 }
 
