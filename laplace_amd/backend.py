@@ -99,9 +99,10 @@ def shared_operands(tap, g, B, C, Q1=None, Q2=None, bounds=None):
                 v = cv.conv_forward_filters(m, a, filt, Q2, amax_out=vb, xs=getattr(tap, "a_split", None)).reshape(B, Dk, L)
                 if vb is not None:
                     bounds["v"] = vb  # measured by the convolution's epilogue
-            elif Dk <= 128:
-                # a thin layer (the RGB stem: Dk = 27): unfold + ONE small batched GEMM.  The library convolution runs this
-                # shape as im2col + GEMM PER IMAGE (256 launches of ~6 us for a minibatch of 128: 1.5 ms of a 30 ms call)
+            elif Dk <= 32:
+                # a very thin layer (the 3 x 3 RGB stem: Dk = 27): unfold + ONE small batched GEMM.  The library convolution
+                # runs this shape as im2col + GEMM PER IMAGE (256 launches of ~6 us for a minibatch of 128: 1.5 ms of a
+                # 30 ms call); wider thin layers (LeNet's 5 x 5 stem, Dk = 75) are faster through the library (measured)
                 v = torch.matmul(Q2.T, F.unfold(a, m.kernel_size, m.dilation, m.padding, m.stride))
             else:
                 v = F.conv2d(a, filt, None, m.stride, m.padding, m.dilation).reshape(B, Dk, L)
