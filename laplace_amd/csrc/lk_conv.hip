@@ -1365,26 +1365,37 @@ void conv_win_f16x2_kernel(const ConvGeom g, const _Float16* __restrict__ Ah, co
         if (r == 0 && kc + 1 < KC) stage_win((kc + 1) & 1);
       }
       const char* pb = smem + 2 * CFG::WINZ + slot * CFG::B_STEP;
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const int t = r * 3 + j;  // compile-time
-        f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+      // the fragments of tap j + 1 are requested BEFORE the MFMAs of tap j are issued (two register sets): the LDS
+      // latency of a tap's eight reads (~350 cycles with eight waves reading) otherwise parks the wave in front of every
+      // tap, and the two waves of a SIMD — in lockstep behind the hand-over barrier — wait at the same time
+      f16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+      auto load_frags = [&](int j, int set) {
+        const int t = r * 3 + j;  // compile-time after unrolling
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
-          ah[a] = *reinterpret_cast<const f16x8*>(pw + a_addr[a][t]);
-          al[a] = *reinterpret_cast<const f16x8*>(pw + a_addr[a][t] + CFG::W_PLANE);
+          ah[set][a] = *reinterpret_cast<const f16x8*>(pw + a_addr[a][t]);
+          al[set][a] = *reinterpret_cast<const f16x8*>(pw + a_addr[a][t] + CFG::W_PLANE);
         }
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
-          bh[b] = *reinterpret_cast<const f16x8*>(pb + b_addr[b] + (j * 2) * CFG::B_TAP);
-          bl[b] = *reinterpret_cast<const f16x8*>(pb + b_addr[b] + (j * 2 + 1) * CFG::B_TAP);
+          bh[set][b] = *reinterpret_cast<const f16x8*>(pb + b_addr[b] + (j * 2) * CFG::B_TAP);
+          bl[set][b] = *reinterpret_cast<const f16x8*>(pb + b_addr[b] + (j * 2 + 1) * CFG::B_TAP);
         }
+      };
+      load_frags(0, 0);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int set = j & 1;
+        if (j + 1 < 3) load_frags(j + 1, set ^ 1);
+        // (left to itself hipcc sinks these reads back behind the MFMAs into ONE register set and waits lgkmcnt(0) twice
+        // per tap; pinned, it keeps both sets and waits for the older eight reads only)
+        __builtin_amdgcn_sched_barrier(0);
 #ifdef LK_CONV_DEV
         if (ablate & 2) {
 #pragma unroll
           for (int a = 0; a < TM; ++a)
 #pragma unroll
-            for (int b = 0; b < TN; ++b) acc[a][b][0] += (float)ah[a][0] + (float)al[a][1] + (float)bh[b][2] + (float)bl[b][3];
+            for (int b = 0; b < TN; ++b) acc[a][b][0] += (float)ah[set][a][0] + (float)al[set][a][1] + (float)bh[set][b][2] + (float)bl[set][b][3];
           continue;
         }
 #endif
@@ -1393,11 +1404,12 @@ void conv_win_f16x2_kernel(const ConvGeom g, const _Float16* __restrict__ Ah, co
 #pragma unroll
           for (int b = 0; b < TN; ++b) {
             f32x16 c = acc[a][b];
-            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], c, 0, 0, 0);  // small terms first
-            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[set][a], bh[set][b], c, 0, 0, 0);  // small terms first
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[set][a], bl[set][b], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[set][a], bh[set][b], c, 0, 0, 0);
             acc[a][b] = c;
           }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }

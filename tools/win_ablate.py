@@ -10,9 +10,11 @@ from laplace_amd._lib import get_kernels
 K = get_kernels()
 dev = "cuda"
 WIN, Z, W4 = 1 << 22, 1 << 23, 1 << 24
-AB = {"full": 0, "no-epilogue": 256, "no-mfma": 512, "no-staging": 1024, 
-      "no-barrier": 1 << 21, "no-mfma+no-staging": 512 | 1024, 
-      "no-staging+no-barrier": 1024 | (1 << 21)}
+AB = {"full": 0, "no-epilogue": 256, "no-mfma": 512, "no-staging": 1024,
+      "no-barrier": 1 << 21, "no-mfma+no-staging": 512 | 1024,
+      "no-staging+no-barrier": 1024 | (1 << 21), "no-reads(+mfma)": 1 << 26, "no-reads+no-staging": 1024 | (1 << 26),
+      "no-reads+no-staging+no-epilogue": 256 | 1024 | (1 << 26), "no-staging+no-epilogue": 256 | 1024,
+      "no-mfma+no-staging+no-epilogue": 256 | 512 | 1024}
 
 
 def timeit(fn, n=10):
@@ -40,7 +42,7 @@ for C, H in ((64, 32), (128, 16)):
     for kname, kcfg in (("generic", 2), ("window 4 waves", 2 | WIN | W4), ("window 8 waves", 2 | WIN | (Z if C == 64 else 0))):
         row = []
         for aname, abit in AB.items():
-            if kname == "generic" and aname in ("no-barrier", "no-staging+no-barrier"):
+            if kname == "generic" and (aname in ("no-barrier", "no-staging+no-barrier") or "reads" in aname):
                 continue
             K.conv_config = kcfg | abit
             t = timeit(lambda: cv.conv_backward_data_vjp(prep, g, (H, H), add=add, mult=mask))
