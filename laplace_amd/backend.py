@@ -524,7 +524,11 @@ class _HipCurvatureMixin:
         if kfac_approx not in ("expand", "reduce"):
             raise ValueError(f"kfac_approx must be 'expand' or 'reduce', got {kfac_approx!r}")
         acc = KronAccumulator(self, N, kfac_approx, overlap=True)
-        acc.use_pixgram = False
+        # a lazily handed-over minibatch leaves the banded pixel-pair products of its 3x3 A factors to the running sum that
+        # absorbs it (KronAccumulator.defer_pix); an eager one computes every factor here, the per-minibatch way
+        acc.defer_pix = bool(self.lazy_kron and self.lazy_pixpair and acc.use_pixgram and kfac_approx == "expand")
+        if not acc.defer_pix:
+            acc.use_pixgram = False
         acc._persist_slabs = False
         try:
             acc.add_batch(x, y)
@@ -542,6 +546,8 @@ class _HipCurvatureMixin:
 
     #: ``False`` (env LK_LAZY_KRON=0): ``kron`` returns its minibatch already in the reference's layout
     lazy_kron = os.environ.get("LK_LAZY_KRON", "1") != "0"
+    #: ``False`` (env LK_LAZY_PIXPAIR=0): a lazily handed-over minibatch computes its 3x3 A factors itself
+    lazy_pixpair = os.environ.get("LK_LAZY_PIXPAIR", "1") != "0"
 
     def _diag_impl(self, x, y, seeds_fn, alpha):
         K = get_kernels()
@@ -627,6 +633,12 @@ class KronAccumulator:
         self.loss = None
         self._taps_meta = None
         self._range_tab, self._range_n, self._range_full = None, 0, []  # see _note_range
+        #: ``True`` (set by ``backend.kron`` for the minibatches of the reference's literal loop): the banded pixel-pair
+        #: products of the 3x3 A factors are NOT computed here — the minibatch keeps its NHWC inputs (`_pix_inputs`) and
+        #: the running sum that absorbs it (`merge_`) stacks them and runs the grouped kernel into ITS accumulators, as
+        #: the fused accumulator does.  A minibatch nobody absorbs computes them the per-minibatch way when it is read.
+        self.defer_pix = False
+        self._pix_inputs = {}  # tap index -> list of (geometry, alpha, NHWC fp32 tensor [B, H, W, C], module)
 
     def _alloc(self, tape, dev):
         self.factors, self._taps_meta = [], []
@@ -683,6 +695,14 @@ class KronAccumulator:
 
     def _accumulate_A(self, idx, tap, F, rt):
         K = get_kernels()
+        if self.defer_pix:
+            geo = self._pix_geometry(tap)
+            if geo is not None and geo[0] == "pair" and tap.a.dtype == torch.float32:
+                t = K.nchw_to_nhwc(keep_layout(tap.a))  # (a copy: the sweep releases the activation)
+                self._pix_inputs.setdefault(idx, []).append((geo, rt / (self.N * geo[1] * geo[2]), t, tap.module))
+                return
+            self.backend._factor_A(tap, self.N, rt, self.kfac_approx, F[1], fused=True)
+            return
         acc = self._pix.get(idx)
         if acc is None:
             self.backend._factor_A(tap, self.N, rt, self.kfac_approx, F[1], fused=True)
@@ -695,19 +715,63 @@ class KronAccumulator:
         elif self.pix_group <= 1:
             K.pixpair_accumulate(a, alpha, buf, geo[4])
         else:
-            # NHWC copy of this minibatch into its slot of the group buffer; launch when the group is full
-            B = a.shape[0]
-            pend = self._pix_pending.get(idx)
-            if pend is not None and (pend["B"] != B or pend["alpha"] != alpha):
-                self._drain_pixpair(idx)  # ragged last batch / changed scale: flush what is stacked
-                pend = None
-            if pend is None:
-                stack = torch.empty(self.pix_group * B, geo[1], geo[2], geo[3], dtype=torch.float32, device=a.device)
-                pend = self._pix_pending[idx] = {"B": B, "alpha": alpha, "stack": stack, "n": 0}
-            K.nchw_to_nhwc(a, out=pend["stack"][pend["n"] * B:(pend["n"] + 1) * B])
-            pend["n"] += 1
-            if pend["n"] == self.pix_group:
-                self._drain_pixpair(idx, keep=True)
+            self._push_pix_input(idx, geo, alpha, a, nhwc=False)
+
+    def _push_pix_input(self, idx, geo, alpha, a, nhwc: bool):
+        """NHWC copy of one minibatch into its slot of the group buffer; launch when the group is full.  ``a``: the
+        activation (logical NCHW) or, ``nhwc=True``, an NHWC fp32 tensor a deferred minibatch kept"""
+        K = get_kernels()
+        B = a.shape[0]
+        pend = self._pix_pending.get(idx)
+        if pend is not None and (pend["B"] != B or pend["alpha"] != alpha):
+            self._drain_pixpair(idx)  # ragged last batch / changed scale: flush what is stacked
+            pend = None
+        if pend is None:
+            stack = torch.empty(self.pix_group * B, geo[1], geo[2], geo[3], dtype=torch.float32, device=a.device)
+            pend = self._pix_pending[idx] = {"B": B, "alpha": alpha, "stack": stack, "n": 0}
+        slot = pend["stack"][pend["n"] * B:(pend["n"] + 1) * B]
+        if nhwc:
+            slot.copy_(a)
+        else:
+            K.nchw_to_nhwc(a, out=slot)
+        pend["n"] += 1
+        if pend["n"] == self.pix_group:
+            self._drain_pixpair(idx, keep=True)
+
+    def _adopt_pix_inputs(self, other):
+        """(merge_, calling stream) take over the NHWC inputs a deferred minibatch kept: once ``pix_group`` of them have
+        come together for a tap, this accumulator allocates that tap's pixel-pair blocks and from then on stacks /
+        launches like the fused accumulator; until then they stay deferred here as well.  Returns what
+        :meth:`_push_adopted` has to stack (possibly on the side stream)"""
+        todo = []
+        for idx, items in other._pix_inputs.items():
+            if idx not in self._pix:
+                mine = self._pix_inputs.setdefault(idx, [])
+                mine.extend(items)
+                if len(mine) < max(self.pix_group, 2):
+                    continue
+                geo = mine[0][0]
+                self._pix[idx] = (geo, torch.zeros(geo[4][0] * geo[3] * geo[3], dtype=torch.float32, device=mine[0][2].device))
+                items = self._pix_inputs.pop(idx)
+            todo.append((idx, items))
+        return todo
+
+    def _push_adopted(self, todo):
+        for idx, items in todo:
+            for geo, alpha, t, _ in items:
+                self._push_pix_input(idx, geo, alpha, t, nhwc=True)
+
+    def _resolve_pix_inputs(self):
+        """(finalize) deferred inputs that never met a running sum: the per-minibatch A-factor kernel on each"""
+        if not self._pix_inputs:
+            return
+        K = get_kernels()
+        self._join_side()
+        for idx, items in self._pix_inputs.items():
+            for _, alpha, t, m in items:  # (alpha = sqrt(factor) / (N L), L = H W for these convs)
+                K.gram_conv(t.permute(0, 3, 1, 2), m.kernel_size, m.stride, m.padding, m.dilation, alpha, self.factors[idx][1],
+                            upper_only=True, native=True)
+        self._pix_inputs = {}
 
     def _drain_pixpair(self, idx, keep=False):
         """launch the pixel-pair product over the minibatches stacked so far"""
@@ -813,7 +877,8 @@ class KronAccumulator:
         if self.factors is None:
             self._alloc(tape, f.device)
         rt = math.sqrt(float(b.factor))
-        self._ensure_pixgrams(tape)
+        if not self.defer_pix:
+            self._ensure_pixgrams(tape)
         # The A factors need only the forward activations: enqueue them on a side stream so that they
         # overlap the C reverse passes (whose late, small-spatial conv kernels do not fill the chip).
         side = None
@@ -907,8 +972,9 @@ class KronAccumulator:
         return [t for F in self.factors for t in F] + [self.loss]
 
     def _raw_compatible(self, other) -> bool:
-        return (self.factors is not None and other.factors is not None and not self._pix and not other._pix
-                and not self._pix_pending and not other._pix_pending and not self._gslabs and not other._gslabs
+        return (self.factors is not None and other.factors is not None and not other._pix
+                and not other._pix_pending and not self._gslabs and not other._gslabs
+                and (not (self._pix or self._pix_pending) or all(g[0] == "pair" for g, _ in self._pix.values()))
                 and self.N == other.N and self.kfac_approx == other.kfac_approx and self.backend is other.backend
                 and self._taps_meta == other._taps_meta and len(self.factors) == len(other.factors)
                 and all(a.shape == b.shape for a, b in zip(self._raw_tensors(), other._raw_tensors()))
@@ -921,25 +987,58 @@ class KronAccumulator:
         self._join_side()
         new = KronAccumulator(self.backend, self.N, self.kfac_approx, self.overlap)
         new.use_pixgram, new._persist_slabs = self.use_pixgram, self._persist_slabs
+        new.defer_pix, new.pix_group = self.defer_pix, self.pix_group
+        new._pix_inputs = {k: list(v) for k, v in self._pix_inputs.items()}  # (the tensors themselves are never written)
         if self.factors is not None:
-            if self._pix or self._pix_pending or self._gslabs:
-                raise RuntimeError("clone() of an accumulator with pixel-pair / slab state is not supported")
+            if self._gslabs or any(g[0] != "pair" for g, _ in self._pix.values()):
+                raise RuntimeError("clone() of an accumulator with dense pixel-pair / slab state is not supported")
+            for idx in list(self._pix_pending):
+                self._drain_pixpair(idx)  # (a partly filled group: launch it, so the blocks below are the whole state)
             new.factors = [[t.clone() for t in F] for F in self.factors]
             new.loss = self.loss.clone()
             new._taps_meta = list(self._taps_meta)
             new._gscale = dict(self._gscale)
             new._tap_index = dict(self._tap_index)
-            new._pix, new._pix_pending, new._gslabs = {}, {}, {}
+            new._pix = {idx: (geo, buf.clone()) for idx, (geo, buf) in self._pix.items()}
+            new._pix_pending, new._gslabs = {}, {}
+            new._range_full = list(self._range_full) + ([self._range_tab[:self._range_n]] if self._range_tab is not None else [])
             new._side = self._side
         return new
 
     def merge_(self, other: "KronAccumulator") -> bool:
-        """``self += other`` on the raw forms (one multi-tensor add); False if the two do not have the same structure"""
+        """``self += other`` on the raw forms (one multi-tensor add); False if the two do not have the same structure.
+
+        With a side stream the add is enqueued THERE, behind ``other``'s factor kernels (same stream, in order): the
+        calling stream does not wait for them and goes on with the next minibatch, at most one merge ahead — the schedule
+        the fused accumulator has with ``lag_join``.  Readers (`finalize`, `tensors`, `clone`) join the side stream."""
         if not self._raw_compatible(other):
             return False
-        self._join_side()
-        other._join_side()
-        torch._foreach_add_(self._raw_tensors(), other._raw_tensors())
+        skip = set(other._pix_inputs)  # A factors `other` left to this sum: identically zero there, nothing to add
+        mine = [t for i, F in enumerate(self.factors) for j, t in enumerate(F) if not (j == 1 and i in skip)] + [self.loss]
+        theirs = [t for i, F in enumerate(other.factors) for j, t in enumerate(F) if not (j == 1 and i in skip)] + [other.loss]
+        side = self._side or other._side
+        if side is None or not self.lag_join or not self.loss.is_cuda:
+            self._join_side()
+            other._join_side()
+            torch._foreach_add_(mine, theirs)
+            self._push_adopted(self._adopt_pix_inputs(other))
+        else:
+            self._side = side
+            main = torch.cuda.current_stream(self.loss.device)
+            if self._side_done is not None:
+                main.wait_event(self._side_done)  # (bounded lag: the merge before this one has finished)
+            todo = self._adopt_pix_inputs(other)  # (allocates pixel-pair blocks on the calling stream: read there at the end)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                torch._foreach_add_(mine, theirs)
+                self._push_adopted(todo)
+            for t in theirs:  # allocated on the calling stream, read on the side stream: keep them until it is done
+                t.record_stream(side)
+            for items in other._pix_inputs.values():
+                for _, _, t, _ in items:
+                    t.record_stream(side)
+            self._side_done = torch.cuda.Event()
+            self._side_done.record(side)
         # (the merged minibatches' magnitude records come along: checked when the sum is finalised)
         if other._range_tab is not None:
             self._range_full += list(other._range_full) + [other._range_tab[:other._range_n]]
@@ -984,6 +1083,7 @@ class KronAccumulator:
         scales are applied HERE, before the exchange: ``diag(s) G diag(s)`` is linear in G, so scaled factors add
         exactly, and a rank with an empty shard — which never learned a scale and contributes zeros — needs none."""
         self._check_range()
+        self._resolve_pix_inputs()
         self._flush_pixgrams()  # the assembled factors are what is exchanged, not the larger pixel-pair Grams
         self._flush_g_slabs()
         self._apply_grad_scales()
@@ -994,6 +1094,7 @@ class KronAccumulator:
         K = get_kernels()
         rt = math.sqrt(float(self.backend.factor))
         self._check_range()
+        self._resolve_pix_inputs()
         self._flush_pixgrams()
         self._flush_g_slabs()
         self._apply_grad_scales()

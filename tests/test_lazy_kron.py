@@ -88,3 +88,51 @@ def test_lazy_kron_survives_deepcopy_and_pickle(dev):
     p = pickle.loads(pickle.dumps(k))
     for other in (c, p):
         assert other._pending is None and _close(_flat(other), _flat(k), 0.0)
+
+
+@pytest.mark.parametrize("group", [1, 3, 8])
+def test_literal_loop_leaves_the_pixel_pair_products_to_the_running_sum(dev, group, monkeypatch):
+    """3x3 convs whose A factor has a banded pixel-pair form: a lazily handed-over minibatch keeps its NHWC input
+    (KronAccumulator.defer_pix), the running sum stacks ``LK_PIX_GROUP`` of them per launch as the fused accumulator
+    does.  Same factors as the eager per-minibatch kernels, whatever is read when, and no operand is changed."""
+    from laplace_amd import HipGGN, HipKron
+
+    monkeypatch.setenv("LK_PIX_GROUP", str(group))
+    C = 64 if dev == "cuda" else 8
+    torch.manual_seed(3)
+    model = torch.nn.Sequential(
+        torch.nn.Conv2d(3, C, 3, padding=1), torch.nn.Tanh(), torch.nn.Conv2d(C, C, 3, padding=1, bias=False), torch.nn.Tanh(),
+        torch.nn.Conv2d(C, C, 3, padding=1), torch.nn.Tanh(), torch.nn.AdaptiveAvgPool2d(1), torch.nn.Flatten(),
+        torch.nn.Linear(C, 4)).to(dev).eval()
+    X, y = torch.randn(20, 3, 6, 6, device=dev), torch.randint(0, 4, (20,), device=dev)
+    N = X.shape[0]
+    parts = [slice(i, min(i + 3, N)) for i in range(0, N, 3)]  # 7 minibatches, the last one ragged
+    eager = HipGGN(model, "classification")
+    eager.lazy_kron = False
+    want = [_flat(eager.kron(X[s], y[s], N)[1]) for s in parts]
+    total = [sum(w[i] for w in want) for i in range(len(want[0]))]
+    lazy = HipGGN(model, "classification")
+    first = lazy.kron(X[parts[0]], y[parts[0]], N)[1]
+    assert first._pending.defer_pix and first._pending._pix_inputs, "the wide 3x3 convs should have been deferred"
+
+    params = [p for p in model.parameters() if p.requires_grad]
+    H = HipKron.init_from_model(params, X.device, torch.float32)
+    H += first
+    for i, s in enumerate(parts[1:], 1):
+        H += lazy.kron(X[s], y[s], N)[1]
+        if i == 4:  # out of place on a running sum that holds pixel-pair blocks: a copy, the sum goes on
+            part = H + HipKron.init_from_model(params, X.device, torch.float32)
+            assert _close(_flat(part), [sum(w[j] for w in want[:5]) for j in range(len(total))], 1e-5)
+            assert H._pending is not None
+    assert bool(H._pending._pix) == (group <= len(parts)), "blocks are allocated once a whole group has come together"
+    assert _close(_flat(H), total, 1e-5)
+    assert _close(_flat(first), want[0], 1e-5), "an absorbed minibatch still stands for itself"
+    # the fused accumulator of the same fit
+    acc = lazy.kron_accumulator(N)
+    for s in parts:
+        acc.add_batch(X[s], y[s])
+    assert _close(_flat(acc.finalize()[1]), total, 1e-5)
+    # switch off: every minibatch computes its own A factors
+    lazy.lazy_pixpair = False
+    k = lazy.kron(X[parts[1]], y[parts[1]], N)[1]
+    assert not k._pending._pix_inputs and _close(_flat(k), want[1], 1e-5)
