@@ -917,8 +917,9 @@ class HipKernels:
     def syevj_batched(self, mats, clamp=True, max_sweeps=0, streams=None):
         """Eigendecompose a list of symmetric matrices (largest first is best) -> list of (w, Q, info).
 
-        ``streams``: torch side streams the solves are spread over (matrix i on ``streams[i % len]``); the caller
-        orders them against its own stream (``wait_stream`` before / after).  ``None`` = the current stream."""
+        ``streams``: torch side streams for the solve — the rounds of all matrices run on ``streams[0]``, finished
+        matrices are refined on ``streams[1]`` beside them (more than two are accepted and only made to wait); the
+        caller orders them against its own stream (``wait_stream`` before / after).  ``None`` = the current stream."""
         if not mats:
             return []
         dev = mats[0].device
@@ -952,11 +953,11 @@ class HipKernels:
             arr(ctypes.c_size_t, [w_.numel() for w_ in keep]), 1 if clamp else 0, int(max_sweeps),
             arr(ctypes.c_void_p, [st.cuda_stream for st in used]), nstreams)
         self._rc(rc, "lk_syevj_batched_f32")
-        for i, (A, o, ws) in enumerate(zip(mats, outs, keep)):
-            st = used[i % nstreams]
+        for st in used[:2]:
             if st != cur:  # allocated on `cur`, used on `st`
-                for t in (A, ws) + o:
-                    t.record_stream(st)
+                for A, o, ws in zip(mats, outs, keep):
+                    for t in (A, ws) + o:
+                        t.record_stream(st)
         return outs
 
     # ---- logdet -------------------------------------------------------------------------------

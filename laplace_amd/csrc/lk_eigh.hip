@@ -17,6 +17,13 @@
 //   quotients v_i^T A v_i against the ORIGINAL matrix (three MFMA GEMMs), then rank-sorted ascending,
 //   clamped, and V's columns gathered.
 // Zero padding is exact: padded rows/columns never rotate (their off-diagonals are exactly 0).
+//
+// Many matrices (one decomposition = 43 factors for ResNet-18): every launch of the three kernels serves a ROUND --
+// the current round-robin step of every matrix that is still iterating, each at its own position of its own sweep
+// (`EigRound`: per slot the matrix' descriptor, its step and the first workgroup of its share of the grid).  One
+// stream, one pivot + one update launch per round for all of them: measured on the c4 factors, six streams with one
+// matrix each had on average 1.3-1.8 kernels in flight (profiles/r03_eig_timeline.md) -- the solves were serialised
+// by the queue, not overlapped by it.
 #include <chrono>
 #include <cstdlib>
 #include <thread>
@@ -25,6 +32,16 @@
 #include "lk_common.h"
 
 namespace lk {
+
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// x = h + l (+ <= 2^-22 |x|, 2^-25 absolute), both fp16.  The value is made opaque first: h and the residual must come
+// from the SAME fp32 value (hipcc otherwise fuses the residual into fp16(x - h') with h' rounded from an exact product)
+__device__ __forceinline__ void eig_split2(float x, _Float16& h, _Float16& l) {
+  asm volatile("" : "+v"(x));
+  h = (_Float16)x;
+  l = (_Float16)(x - (float)h);
+}
 
 constexpr int EB = 32;       // index block
 constexpr int EP = 64;       // pivot size (two blocks)
@@ -35,7 +52,34 @@ struct EigCtrl {             // lives in the workspace
   int rotations;             // rotations performed in the current sweep
   int converged;             // set when a sweep performed none
   int sweeps;                // completed sweeps
+  float bound;               // max_i sum_j |a_ij| >= lambda_max: fixes the power-of-two scale of the split-fp16 tile products
 };
+
+struct EigDesc {             // one matrix: where its buffers are (lives in its workspace, written once per solve)
+  float* Aw;
+  float* V;
+  float* Rws;
+  float* Dws;
+  int* rotated;
+  EigCtrl* ctrl;
+  int np, nb;
+};
+
+constexpr int kEigBatch = 64;  // matrices served by one launch
+struct EigRound {              // kernel argument, by value
+  int njobs;
+  int step[kEigBatch];         // round-robin step of slot j in ITS sweep
+  int first[kEigBatch + 1];    // first workgroup of slot j (prefix sums over the slots)
+  const EigDesc* desc[kEigBatch];
+};
+
+__device__ __forceinline__ int eig_slot(const EigRound& rd, int block) {  // block-uniform
+  int j = 0;
+  while (j + 1 < rd.njobs && block >= rd.first[j + 1]) ++j;
+  return j;
+}
+
+__global__ void eig_desc_kernel(EigDesc d, EigDesc* out) { *out = d; }
 
 // round-robin pairing of nb blocks (nb even): step s in [0, nb-1), pivot p in [0, nb/2)
 __device__ __forceinline__ void pivot_blocks(int s, int p, int nb, int& I, int& J) {
@@ -89,6 +133,16 @@ __global__ __launch_bounds__(256) void eig_matvec_kernel(const float* __restrict
   s = wave_sum(s);
   if (lane == 0) y[row] = s;
 }
+// ctrl->bound = max_i sum_j |a_ij|  (one wave per row, fixed summation order; the max is order-independent)
+__global__ __launch_bounds__(256) void eig_rowabs_kernel(const float* __restrict__ A, int np, EigCtrl* ctrl) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= np) return;
+  float s = 0.f;
+  for (int c = lane; c < np; c += 64) s += fabsf(A[(int64_t)row * np + c]);
+  s = wave_sum(s);
+  if (lane == 0 && s > 0.f && s < 3.0e38f) atomicMax(reinterpret_cast<int*>(&ctrl->bound), __float_as_int(s));
+}
 // x <- y / ||y||, ctrl->scale <- max(ctrl->scale, ||y||)   (one workgroup)
 __global__ __launch_bounds__(256) void eig_normalize_kernel(const float* __restrict__ y, int np, float* __restrict__ x,
                                                             EigCtrl* ctrl, int init) {
@@ -110,11 +164,18 @@ __global__ __launch_bounds__(256) void eig_normalize_kernel(const float* __restr
 // indices): (a) 32 lanes compute the rotations; (b) ONE fused phase applies J^T S J on disjoint 2x2
 // blocks (block (k1,k2) = rows of pair k1 x columns of pair k2 sees exactly the row rotation k1 and
 // the column rotation k2) and the column rotation on R.  Two barriers per step.
-__global__ __launch_bounds__(256) void eig_pivot_kernel(float* __restrict__ Aw, int np, int nb, int step,
-                                                        float* __restrict__ Rws, float* __restrict__ Dws,
-                                                        int* __restrict__ rotated, EigCtrl* ctrl, float tol_rel,
-                                                        float tol_abs, float tol_conv, int max_inner, int cross_only) {
+__global__ __launch_bounds__(256) void eig_pivot_kernel(EigRound rd, float tol_rel, float tol_abs, float tol_conv,
+                                                        int max_inner, int cross_only) {
+  const int slot = eig_slot(rd, blockIdx.x);
+  const EigDesc ds = *rd.desc[slot];
+  EigCtrl* ctrl = ds.ctrl;
   if (ctrl->converged) return;
+  float* __restrict__ Aw = ds.Aw;
+  float* __restrict__ Rws = ds.Rws;
+  float* __restrict__ Dws = ds.Dws;
+  int* __restrict__ rotated = ds.rotated;
+  const int np = ds.np, nb = ds.nb, step = rd.step[slot];
+  const int pv = blockIdx.x - rd.first[slot];  // this workgroup's pivot of the matrix
   __shared__ float S[EP][ELD];
   __shared__ float R[EP][ELD];
   __shared__ float cs[32][2];
@@ -125,7 +186,7 @@ __global__ __launch_bounds__(256) void eig_pivot_kernel(float* __restrict__ Aw, 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int I, J;
-  pivot_blocks(step, blockIdx.x, nb, I, J);
+  pivot_blocks(step, pv, nb, I, J);
   int total_rot = 0;
   const float floor_abs = tol_abs * ctrl->scale;   // below this an off-diagonal is rounding noise: never rotate
   const float floor_conv = tol_conv * ctrl->scale; // rotations of elements below this do not count as "unconverged"
@@ -157,7 +218,7 @@ __global__ __launch_bounds__(256) void eig_pivot_kernel(float* __restrict__ Aw, 
       }
     }
     if (!__syncthreads_or(any)) {
-      if (tid == 0) rotated[blockIdx.x] = 0;
+      if (tid == 0) rotated[pv] = 0;
       return;
     }
   }
@@ -277,74 +338,149 @@ __global__ __launch_bounds__(256) void eig_pivot_kernel(float* __restrict__ Aw, 
 
   // outputs: R_P (row-major 64x64), the solved pivot, and whether anything rotated at all (R_P == I otherwise,
   // which lets the tile updates of untouched pivot pairs be skipped in the late, mostly-converged sweeps)
-  if (tid == 0) rotated[blockIdx.x] = total_rot > 0 ? 1 : 0;
+  if (tid == 0) rotated[pv] = total_rot > 0 ? 1 : 0;
   if (total_rot == 0) return;
-  float* Rout = Rws + (int64_t)blockIdx.x * EP * EP;
-  for (int idx = tid; idx < EP * EP; idx += 256) Rout[idx] = R[idx >> 6][idx & 63];
-  float* Sout = Dws + (int64_t)blockIdx.x * EP * EP;  // the (nearly) diagonalised pivot itself
+  // R_P for the tile updates: the two fp16 planes of R^T * 2^14 (h, l; [j][k] = R[k][j], k contiguous -- what a lane of
+  // the 16-bit MFMA reads), split once here instead of by each of the ~2 n / 64 workgroups that use it
+  _Float16* Rout = reinterpret_cast<_Float16*>(Rws + (int64_t)pv * EP * EP);
+  for (int idx = tid; idx < EP * EP / 4; idx += 256) {
+    const int j = idx >> 4, k0 = (idx & 15) * 4;
+    f16x4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      _Float16 hh, ll;
+      eig_split2(R[k0 + e][j] * 16384.f, hh, ll);
+      h[e] = hh, l[e] = ll;
+    }
+    *reinterpret_cast<f16x4*>(Rout + j * EP + k0) = h;
+    *reinterpret_cast<f16x4*>(Rout + EP * EP + j * EP + k0) = l;
+  }
+  float* Sout = Dws + (int64_t)pv * EP * EP;  // the (nearly) diagonalised pivot itself
   for (int idx = tid; idx < EP * EP; idx += 256) Sout[idx] = S[idx >> 6][idx & 63];
   if (tid == 0 && sweep_big > 0) atomicAdd(&ctrl->rotations, sweep_big);
 }
 
-// ---- 2. tile update  A_PQ <- R_P^T A_PQ R_Q ----------------------------------------------------------
-// out = X * Y (64x64x64) for this wave's 32x32 quadrant; X read by column-of-row (pitch ELD), Y by row
-__device__ __forceinline__ f32x16 quad_mm_AB(const float (*X)[ELD], const float (*Y)[ELD], int wm, int wn, int lo,
-                                             int hi) {
+// ---- 2. tile update  A_PQ <- R_P^T A_PQ R_Q   and   3. eigenvector update  V[:, Q] <- V[:, Q] R_Q ----------------------
+// The exact-fp32 MFMA (64 cycles per 32x32x2) made these products the bound of the whole solver: the n = 4608 update ran at
+// 136 TFLOP/s, 87 % of that pipe's peak.  They now run on the fp16 matrix cores at fp32 level, as the convolutions do
+// (lk_conv.hip): every operand is scaled by a power of two and split into two fp16 planes, x 2^s = h + l (+ <= 2^-22 |x 2^s|),
+// a product is three v_mfma_f32_32x32x16_f16 (h h', h l', l h'; fp32 accumulation) -- 96 instead of 512 matrix-pipe cycles
+// per 32x32x16 block.  Scales: rotations and eigenvectors (|x| <= 1) by 2^14; the matrix by 2^sa with
+// bound * 2^sa in [2^13, 2^14), bound = max row sum >= lambda_max >= every entry of A, A R and R^T A R (sub-blocks of an
+// orthogonal similarity), so nothing can overflow and an entry far below lambda_max keeps an ABSOLUTE accuracy of
+// 2^-38 bound -- orders below the fp32 noise of the method.  The pivot tiles themselves (all large entries: the diagonal)
+// are written back from the fp32 LDS solve and never pass through a split product.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int EHP = EP + 8;                    // plane pitch in halfs (144 B): 16-byte fragment reads spread over the banks
+constexpr int EPLANE = EP * EHP;               // one fp16 plane of a 64 x 64 operand
+struct EigTileLds {
+  union {
+    struct {
+      _Float16 a[2][EPLANE];                   // A-operand planes (h, l): [row i][k]
+      _Float16 b[2][EPLANE];                   // B-operand planes (h, l): [column j][k]
+    } op;
+    float out[EP][ELD];                        // result staging for coalesced stores (after the last product)
+  };
+};
+
+// acc += A B for this wave's 32 x 32 quadrant, K = 64: A-operand rows wm*32 + lr, B-operand columns wn*32 + lr
+__device__ __forceinline__ f32x16 quad_mm16(const EigTileLds& L, int wm, int wn, int lr, int lh) {
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll 8
-  for (int kk = 0; kk < EP / 2; ++kk) {
-    const int k = 2 * kk + hi;
-    const float a = X[wm * 32 + lo][k];  // A[i][k]
-    const float b = Y[k][wn * 32 + lo];  // B[k][j]
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+  const _Float16* pa = &L.op.a[0][(wm * 32 + lr) * EHP + lh * 8];
+  const _Float16* pb = &L.op.b[0][(wn * 32 + lr) * EHP + lh * 8];
+#pragma unroll
+  for (int k16 = 0; k16 < EP / 16; ++k16) {
+    const f16x8 ah = *reinterpret_cast<const f16x8*>(pa + k16 * 16);
+    const f16x8 al = *reinterpret_cast<const f16x8*>(pa + EPLANE + k16 * 16);
+    const f16x8 bh = *reinterpret_cast<const f16x8*>(pb + k16 * 16);
+    const f16x8 bl = *reinterpret_cast<const f16x8*>(pb + EPLANE + k16 * 16);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);  // small terms first
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
   }
   return acc;
 }
-// out = X^T * Y
-__device__ __forceinline__ f32x16 quad_mm_AtB(const float (*X)[ELD], const float (*Y)[ELD], int wm, int wn, int lo,
-                                              int hi) {
-  f32x16 acc;
+
+// the planes of R^T (written by the pivot kernel) -> an operand slot; identity when the pivot did not rotate
+__device__ __forceinline__ void eig_stage_rot(_Float16 (*dst)[EPLANE], const float* __restrict__ Rws, int pv, bool rotated,
+                                              int tid) {
+  if (rotated) {
+    const _Float16* src = reinterpret_cast<const _Float16*>(Rws + (int64_t)pv * EP * EP);
+    for (int idx = tid; idx < 2 * EP * EP / 8; idx += 256) {
+      const int pl = idx >> 9, j = (idx >> 3) & 63, k0 = (idx & 7) * 8;
+      *reinterpret_cast<f16x8*>(&dst[pl][j * EHP + k0]) = *reinterpret_cast<const f16x8*>(src + pl * EP * EP + j * EP + k0);
+    }
+  } else {
+    for (int idx = tid; idx < 2 * EP * EP / 8; idx += 256) {
+      const int pl = idx >> 9, j = (idx >> 3) & 63, k0 = (idx & 7) * 8;
+      f16x8 v;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll 8
-  for (int kk = 0; kk < EP / 2; ++kk) {
-    const int k = 2 * kk + hi;
-    const float a = X[k][wm * 32 + lo];  // X^T[i][k] = X[k][i]
-    const float b = Y[k][wn * 32 + lo];
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      for (int e = 0; e < 8; ++e) v[e] = (pl == 0 && k0 + e == j) ? (_Float16)16384.f : (_Float16)0.f;
+      *reinterpret_cast<f16x8*>(&dst[pl][j * EHP + k0]) = v;
+    }
   }
-  return acc;
-}
-__device__ __forceinline__ void quad_store(float (*Z)[ELD], const f32x16& acc, int wm, int wn, int lo, int hi) {
-#pragma unroll
-  for (int r = 0; r < 16; ++r) Z[wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi][wn * 32 + lo] = acc[r];
 }
 
-// One launch per round: workgroups [0, ntiles) rotate the tiles of A, the remaining npv * (np/64) rotate V
-// (section 3 below) -- the two updates are independent of each other, so they share the launch and the chip.
-__device__ void eig_vupdate_block(float (*X)[ELD], float (*Y)[ELD], float* __restrict__ V, int np, int nb, int step,
-                                  const float* __restrict__ Rws, const int* __restrict__ rotated, int Q, int rb);
+// a 64 x 64 fp32 block (rows gr(r), columns gc(c) of a row-major matrix of pitch np) * sc -> the A-operand planes
+template <typename RowFn, typename ColFn>
+__device__ __forceinline__ void eig_stage_block(EigTileLds& L, const float* __restrict__ M, int np, RowFn gr, ColFn gc, float sc,
+                                                int tid) {
+  for (int idx = tid; idx < EP * EP / 4; idx += 256) {
+    const int r = idx >> 4, c0 = (idx & 15) * 4;  // (four consecutive columns never straddle a 32-wide index block)
+    const float4 v = *reinterpret_cast<const float4*>(M + (int64_t)gr(r) * np + gc(c0));
+    f16x4 h, l;
+    _Float16 hh, ll;
+    eig_split2(v.x * sc, hh, ll), h[0] = hh, l[0] = ll;
+    eig_split2(v.y * sc, hh, ll), h[1] = hh, l[1] = ll;
+    eig_split2(v.z * sc, hh, ll), h[2] = hh, l[2] = ll;
+    eig_split2(v.w * sc, hh, ll), h[3] = hh, l[3] = ll;
+    *reinterpret_cast<f16x4*>(&L.op.a[0][r * EHP + c0]) = h;
+    *reinterpret_cast<f16x4*>(&L.op.a[1][r * EHP + c0]) = l;
+  }
+}
 
-__global__ __launch_bounds__(256) void eig_update_kernel(float* __restrict__ Aw, float* __restrict__ V, int np, int nb,
-                                                         int step, const float* __restrict__ Rws,
-                                                         const float* __restrict__ Dws,
-                                                         const int* __restrict__ rotated, const EigCtrl* ctrl,
-                                                         int ntiles) {
-  if (ctrl->converged) return;
-  __shared__ float X[EP][ELD];
-  __shared__ float Y[EP][ELD];
+// One launch per round: of a matrix' share of the grid, workgroups [0, ntiles) rotate the tiles of A, the remaining
+// npv * (np/64) rotate V -- the two updates are independent of each other, so they share the launch and the chip.
+__global__ __launch_bounds__(256) void eig_update_kernel(EigRound rd) {
+  const int slot = eig_slot(rd, blockIdx.x);
+  const EigDesc ds = *rd.desc[slot];
+  if (ds.ctrl->converged) return;
+  float* __restrict__ Aw = ds.Aw;
+  float* __restrict__ V = ds.V;
+  const float* __restrict__ Rws = ds.Rws;
+  const float* __restrict__ Dws = ds.Dws;
+  const int* __restrict__ rotated = ds.rotated;
+  const int np = ds.np, nb = ds.nb, step = rd.step[slot];
+  const int blk = blockIdx.x - rd.first[slot];  // this workgroup's index within the matrix' share
+  __shared__ EigTileLds L;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lo = lane & 31, hi = lane >> 5, wm = wave >> 1, wn = wave & 1;
-  // linear index over pivot pairs P <= Q
+  const int lr = lane & 31, lh = lane >> 5, wm = wave >> 1, wn = wave & 1;
   const int npv = nb / 2;
-  if ((int)blockIdx.x >= ntiles) {
-    const int v = blockIdx.x - ntiles;
-    eig_vupdate_block(X, Y, V, np, nb, step, Rws, rotated, v % npv, v / npv);
+  const int ntiles = npv * (npv + 1) / 2;
+  if (blk >= ntiles) {  // ---- V[rb-th 64 rows, columns of pivot Q] <- (that block) R_Q
+    const int v = blk - ntiles, Q = v % npv, rb = v / npv;
+    if (!rotated[Q]) return;
+    int IQ, JQ;
+    pivot_blocks(step, Q, nb, IQ, JQ);
+    eig_stage_block(L, V, np, [&](int r) { return rb * EP + r; }, [&](int c) { return pivot_index(c, IQ, JQ); }, 16384.f, tid);
+    eig_stage_rot(L.op.b, Rws, Q, true, tid);
+    __syncthreads();
+    const f32x16 t = quad_mm16(L, wm, wn, lr, lh);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) L.out[wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh][wn * 32 + lr] = t[r] * (1.f / 268435456.f);
+    __syncthreads();
+    for (int idx = tid; idx < EP * EP; idx += 256) {
+      const int r = idx >> 6, c = idx & 63;
+      V[(int64_t)(rb * EP + r) * np + pivot_index(c, IQ, JQ)] = L.out[r][c];
+    }
     return;
   }
-  int P = 0, rem = blockIdx.x, rowlen = npv;
+  // linear index over pivot pairs P <= Q
+  int P = 0, rem = blk, rowlen = npv;
   while (rem >= rowlen) {
     rem -= rowlen;
     ++P;
@@ -364,58 +500,50 @@ __global__ __launch_bounds__(256) void eig_update_kernel(float* __restrict__ Aw,
     }
     return;
   }
-  const float* RP = Rws + (int64_t)P * EP * EP;
-  const float* RQ = Rws + (int64_t)Q * EP * EP;
-  const bool rotP = rotated[P] != 0, rotQ = rotated[Q] != 0;
-  for (int idx = tid; idx < EP * EP; idx += 256) {
-    const int r = idx >> 6, c = idx & 63;
-    X[r][c] = Aw[(int64_t)pivot_index(r, IP, JP) * np + pivot_index(c, IQ, JQ)];
-    Y[r][c] = rotQ ? RQ[idx] : (r == c ? 1.f : 0.f);
+  // 2^sa: bound * 2^sa in [2^13, 2^14)
+  int be = (int)((__float_as_uint(ds.ctrl->bound) >> 23) & 0xffu);
+  if (be == 0) be = 1;
+  int sa = 13 - (be - 127);
+  sa = sa > 100 ? 100 : (sa < -100 ? -100 : sa);
+  const float sc_a = __uint_as_float((unsigned)(127 + sa) << 23), inv_a = __uint_as_float((unsigned)(127 - sa) << 23);
+  eig_stage_block(L, Aw, np, [&](int r) { return pivot_index(r, IP, JP); }, [&](int c) { return pivot_index(c, IQ, JQ); }, sc_a, tid);
+  eig_stage_rot(L.op.b, Rws, Q, rotated[Q] != 0, tid);
+  __syncthreads();
+  const f32x16 t = quad_mm16(L, wm, wn, lr, lh);  // T 2^(sa+14) = (A_PQ 2^sa) (R_Q 2^14)
+  __syncthreads();
+  // T^T 2^sa -> the B-operand planes ([column j of T][k = row of T]: this lane holds four consecutive rows per group);
+  // R_P^T -> the A-operand planes
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    f16x4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      _Float16 hh, ll;
+      eig_split2(t[4 * g + e] * (1.f / 16384.f), hh, ll);
+      h[e] = hh, l[e] = ll;
+    }
+    const int off = (wn * 32 + lr) * EHP + wm * 32 + 8 * g + 4 * lh;
+    *reinterpret_cast<f16x4*>(&L.op.b[0][off]) = h;
+    *reinterpret_cast<f16x4*>(&L.op.b[1][off]) = l;
   }
+  eig_stage_rot(L.op.a, Rws, P, rotated[P] != 0, tid);
   __syncthreads();
-  f32x16 t = quad_mm_AB(X, Y, wm, wn, lo, hi);  // T = A_PQ R_Q
+  const f32x16 m = quad_mm16(L, wm, wn, lr, lh);  // M 2^(sa+14) = (R_P^T 2^14) (T 2^sa)
   __syncthreads();
-  quad_store(X, t, wm, wn, lo, hi);  // X <- T
-  for (int idx = tid; idx < EP * EP; idx += 256)
-    Y[idx >> 6][idx & 63] = rotP ? RP[idx] : ((idx >> 6) == (idx & 63) ? 1.f : 0.f);
-  __syncthreads();
-  f32x16 m = quad_mm_AtB(Y, X, wm, wn, lo, hi);  // M = R_P^T T
-  __syncthreads();
-  quad_store(X, m, wm, wn, lo, hi);  // X <- M
+  const float un = inv_a * (1.f / 16384.f);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) L.out[wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh][wn * 32 + lr] = m[r] * un;
   __syncthreads();
   for (int idx = tid; idx < EP * EP; idx += 256) {
     const int r = idx >> 6, c = idx & 63;
-    Aw[(int64_t)pivot_index(r, IP, JP) * np + pivot_index(c, IQ, JQ)] = X[r][c];
-    Aw[(int64_t)pivot_index(r, IQ, JQ) * np + pivot_index(c, IP, JP)] = X[c][r];  // mirrored tile
-  }
-}
-
-// ---- 3. eigenvector update  V[:, Q] <- V[:, Q] R_Q -----------------------------------------------------
-__device__ void eig_vupdate_block(float (*X)[ELD], float (*Y)[ELD], float* __restrict__ V, int np, int nb, int step,
-                                  const float* __restrict__ Rws, const int* __restrict__ rotated, int Q, int rb) {
-  if (!rotated[Q]) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lo = lane & 31, hi = lane >> 5, wm = wave >> 1, wn = wave & 1;
-  int IQ, JQ;
-  pivot_blocks(step, Q, nb, IQ, JQ);
-  const float* RQ = Rws + (int64_t)Q * EP * EP;
-  for (int idx = tid; idx < EP * EP; idx += 256) {
-    const int r = idx >> 6, c = idx & 63;
-    X[r][c] = V[(int64_t)(rb * EP + r) * np + pivot_index(c, IQ, JQ)];
-    Y[r][c] = RQ[idx];
-  }
-  __syncthreads();
-  f32x16 t = quad_mm_AB(X, Y, wm, wn, lo, hi);
-  __syncthreads();
-  quad_store(X, t, wm, wn, lo, hi);
-  __syncthreads();
-  for (int idx = tid; idx < EP * EP; idx += 256) {
-    const int r = idx >> 6, c = idx & 63;
-    V[(int64_t)(rb * EP + r) * np + pivot_index(c, IQ, JQ)] = X[r][c];
+    Aw[(int64_t)pivot_index(r, IP, JP) * np + pivot_index(c, IQ, JQ)] = L.out[r][c];
+    Aw[(int64_t)pivot_index(r, IQ, JQ) * np + pivot_index(c, IP, JP)] = L.out[c][r];  // mirrored tile
   }
 }
 
-__global__ void eig_sweep_end_kernel(EigCtrl* ctrl) {
+__global__ void eig_sweep_end_kernel(EigRound rd) {  // one thread per matrix whose sweep ends with this round
+  if ((int)threadIdx.x >= rd.njobs) return;
+  EigCtrl* ctrl = rd.desc[threadIdx.x]->ctrl;
   if (ctrl->converged) return;
   if (ctrl->rotations == 0) ctrl->converged = 1;
   ctrl->rotations = 0;
@@ -532,7 +660,7 @@ __global__ __launch_bounds__(256) void eig_coldot_kernel(const float* __restrict
 
 struct EigPlan {
   int np, nb, npv;
-  size_t off_A, off_V, off_A0, off_T, off_R, off_D, off_perm, off_diag, off_rot, off_ctrl, total;
+  size_t off_A, off_V, off_A0, off_T, off_R, off_D, off_perm, off_diag, off_rot, off_ctrl, off_desc, total;
 };
 
 static EigPlan eig_plan(int64_t n) {
@@ -552,6 +680,7 @@ static EigPlan eig_plan(int64_t n) {
   p.off_diag = off; off += align_up((size_t)p.np * 4, 256);
   p.off_rot = off; off += align_up((size_t)p.npv * 4, 256);
   p.off_ctrl = off; off += 256;
+  p.off_desc = off; off += 256;
   p.total = off;
   return p;
 }
@@ -576,6 +705,7 @@ struct EigJob {  // one matrix in flight: buffers carved out of its workspace + 
   float *Aw, *V, *A0, *T, *Rws, *Dws, *dvec;
   int *perm, *rotated;
   EigCtrl* ctrl;
+  EigDesc* desc;
   int clamp;
 };
 
@@ -625,6 +755,7 @@ static int eig_job_setup(EigJob& j, const float* A, int64_t n, float* w, float* 
   j.dvec = reinterpret_cast<float*>(base + j.p.off_diag);
   j.rotated = reinterpret_cast<int*>(base + j.p.off_rot);
   j.ctrl = reinterpret_cast<EigCtrl*>(base + j.p.off_ctrl);
+  j.desc = reinterpret_cast<EigDesc*>(base + j.p.off_desc);
   return LK_OK;
 }
 
@@ -634,10 +765,14 @@ static int eig_enqueue_init(const EigJob& j, hipStream_t stream) {
     set_error("lk_syevj_f32: hipMemsetAsync failed");
     return LK_ELAUNCH;
   }
+  EigDesc d;
+  d.Aw = j.Aw, d.V = j.V, d.Rws = j.Rws, d.Dws = j.Dws, d.rotated = j.rotated, d.ctrl = j.ctrl, d.np = p.np, d.nb = p.nb;
+  hipLaunchKernelGGL(eig_desc_kernel, dim3(1), dim3(1), 0, stream, d, j.desc);
   int64_t blocks = ((int64_t)p.np * p.np + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(eig_init_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, j.A, (int)j.n, p.np, j.Aw, j.A0, j.V,
                      j.ctrl);
+  hipLaunchKernelGGL(eig_rowabs_kernel, dim3((p.np + 3) / 4), dim3(256), 0, stream, j.A0, p.np, j.ctrl);
   // lambda_max estimate -> ctrl->scale (x, y live in the not-yet-used T buffer)
   float* xv = j.T;
   float* yv = j.T + p.np;
@@ -649,19 +784,34 @@ static int eig_enqueue_init(const EigJob& j, hipStream_t stream) {
   return LK_OK;
 }
 
-static void eig_enqueue_sweep(const EigJob& j, hipStream_t stream) {
-  const EigPlan& p = j.p;
-  const int steps = p.nb - 1;
-  const int ntiles = p.npv * (p.npv + 1) / 2;
-  const int nvblk = p.npv * (p.np / EP);
-  const int inner = eig_max_inner();
-  for (int s = 0; s < steps; ++s) {
-    hipLaunchKernelGGL(eig_pivot_kernel, dim3(p.npv), dim3(256), 0, stream, j.Aw, p.np, p.nb, s, j.Rws, j.Dws, j.rotated,
-                       j.ctrl, kTolRel, kTolAbs, kTolConv, inner, eig_cross_only());
-    hipLaunchKernelGGL(eig_update_kernel, dim3(ntiles + nvblk), dim3(256), 0, stream, j.Aw, j.V, p.np, p.nb, s, j.Rws,
-                       j.Dws, j.rotated, j.ctrl, ntiles);
+// One round: the pivot solves and the tile / eigenvector updates of the given matrices, each at its own step; then the
+// end-of-sweep bookkeeping of those whose sweep this round completes.
+struct EigSlot {
+  const EigJob* job;
+  int step;
+};
+static void eig_enqueue_round(const EigSlot* slots, int nslots, hipStream_t stream) {
+  EigRound pv, up, end;
+  pv.njobs = up.njobs = nslots;
+  end.njobs = 0;
+  pv.first[0] = up.first[0] = 0;
+  for (int i = 0; i < nslots; ++i) {
+    const EigPlan& p = slots[i].job->p;
+    pv.step[i] = up.step[i] = slots[i].step;
+    pv.desc[i] = up.desc[i] = slots[i].job->desc;
+    pv.first[i + 1] = pv.first[i] + p.npv;
+    up.first[i + 1] = up.first[i] + p.npv * (p.npv + 1) / 2 + p.npv * (p.np / EP);
+    if (slots[i].step == p.nb - 2) end.desc[end.njobs++] = slots[i].job->desc;
   }
-  hipLaunchKernelGGL(eig_sweep_end_kernel, dim3(1), dim3(1), 0, stream, j.ctrl);
+  hipLaunchKernelGGL(eig_pivot_kernel, dim3((unsigned)pv.first[nslots]), dim3(256), 0, stream, pv, kTolRel, kTolAbs, kTolConv,
+                     eig_max_inner(), eig_cross_only());
+  hipLaunchKernelGGL(eig_update_kernel, dim3((unsigned)up.first[nslots]), dim3(256), 0, stream, up);
+  if (end.njobs > 0) hipLaunchKernelGGL(eig_sweep_end_kernel, dim3(1), dim3(kEigBatch), 0, stream, end);
+}
+
+static void eig_enqueue_sweep(const EigJob& j, hipStream_t stream) {
+  EigSlot sl{&j, 0};
+  for (sl.step = 0; sl.step < j.p.nb - 1; ++sl.step) eig_enqueue_round(&sl, 1, stream);
 }
 
 // refinement: one Newton-Schulz step re-orthonormalises V (thousands of fp32 rotations leave
@@ -699,13 +849,15 @@ extern "C" int lk_syevj_f32(const float* A, int64_t n, float* w, float* Q, int c
 }
 
 // ---- many matrices: host-side scheduler -------------------------------------------------------------------------
-// A KFAC posterior needs one decomposition per factor (42 for ResNet-18, n = 10 ... 4608).  Enqueuing them one after
-// the other serialises the whole job on the host: a single solve is ~10^4 dependent launches, the device queue
-// back-pressures the enqueuing thread, and the other streams starve.  The scheduler below keeps every stream
-// exactly `kLookahead` sweeps ahead of the device: per stream it enqueues one sweep of the current matrix, an
-// asynchronous read-back of its `converged` flag into pinned memory and an event, then moves on to the next
-// stream; flags are polled without blocking, a converged matrix is finalised immediately (no empty sweeps) and the
-// stream's next matrix starts.  The host only sleeps on an event when every stream is already `kLookahead` ahead.
+// A KFAC posterior needs one decomposition per factor (43 for ResNet-18, n = 10 ... 4608).  All of them iterate in
+// ROUNDS on streams[0]: one pivot launch and one update launch serve the current step of every matrix that is still
+// running (up to kEigBatch at a time, the rest waits for a free slot), so the chip always sees the tiles of all of
+// them at once instead of one matrix' latency chain per queue.  After a round that completes a matrix' sweep its
+// `converged` flag is read back asynchronously into pinned memory; a matrix is never more than `kLookahead` sweeps
+// ahead of its last harvested flag (its workgroups return at once after convergence, so running ahead costs launches
+// only), a converged matrix is finalised at once on streams[1] (Newton-Schulz / Rayleigh GEMMs beside the rounds of
+// the others) and its slot is handed to the next waiting matrix.  On return every given stream has been made to
+// wait for all of it; the host has only ever slept when every running matrix was `kLookahead` sweeps ahead.
 extern "C" int lk_syevj_batched_f32(int64_t count, const float* const* A, const int64_t* n, float* const* w,
                                     float* const* Q, int32_t* const* info, void* const* ws, const size_t* ws_bytes,
                                     int clamp, int max_sweeps, void* const* streams, int64_t nstreams) {
@@ -715,99 +867,166 @@ extern "C" int lk_syevj_batched_f32(int64_t count, const float* const* A, const 
   if (max_sweeps <= 0) max_sweeps = 24;
   constexpr int kLookahead = 2;
   constexpr int kSlots = kLookahead + 1;
-  struct Lane {                 // one stream and the matrices queued on it (round-robin assignment, input order)
-    hipStream_t stream;
-    std::vector<int> jobs;
-    size_t cur = 0;             // index into jobs
-    bool started = false;
-    int enq = 0;                // sweeps enqueued for the current matrix
-    int pending_head = 0, pending = 0;  // ring of outstanding flag read-backs (<= kLookahead)
-    hipEvent_t ev[kSlots];
-  };
   std::vector<EigJob> jobs((size_t)count);
+  std::vector<int> waiting;  // input order (the caller passes the largest first)
   for (int64_t i = 0; i < count; ++i) {
     LK_REQUIRE(n[i] >= 0 && n[i] <= 32768 && (n[i] == 0 || (A[i] && w[i] && Q[i])), "lk_syevj_batched_f32: bad matrix");
     if (n[i] == 0) continue;
     if (int rc = eig_job_setup(jobs[(size_t)i], A[i], n[i], w[i], Q[i], clamp, info[i], ws[i], ws_bytes[i])) return rc;
+    waiting.push_back((int)i);
   }
-  const int64_t nl = nstreams < count ? nstreams : count;
-  std::vector<Lane> lanes((size_t)nl);
+  hipStream_t main = (hipStream_t)streams[0];
+  hipStream_t fin = (hipStream_t)streams[nstreams > 1 ? 1 : 0];
   int* hflags = nullptr;
-  if (hipHostMalloc(reinterpret_cast<void**>(&hflags), sizeof(int) * kSlots * (size_t)nl, hipHostMallocDefault) != hipSuccess) {
+  if (hipHostMalloc(reinterpret_cast<void**>(&hflags), sizeof(int) * kSlots * (size_t)count, hipHostMallocDefault) != hipSuccess) {
     set_error("lk_syevj_batched_f32: hipHostMalloc failed");
     return LK_ELAUNCH;
   }
+  struct Run {        // a matrix that is iterating
+    int job;
+    int step = 0;     // its next round-robin step
+    int enq = 0;      // sweeps enqueued completely
+    int pending = 0;  // flag read-backs not yet harvested
+    int head = 0;     // ring position of the oldest of them
+    bool converged = false;
+  };
+  struct Readback {   // the flags read back behind one round
+    hipEvent_t ev;
+    std::vector<std::pair<int, int>> items;  // (job, slot of its ring)
+  };
+  std::vector<Run> active;
+  std::vector<Readback> inflight;  // in stream order
+  std::vector<hipEvent_t> spare, handed;
+  size_t next_waiting = 0;
   int rc = LK_OK;
-  for (int64_t l = 0; l < nl; ++l) {
-    lanes[(size_t)l].stream = (hipStream_t)streams[l];
-    for (int k = 0; k < kSlots; ++k)
-      if (hipEventCreateWithFlags(&lanes[(size_t)l].ev[k], hipEventDisableTiming) != hipSuccess) rc = LK_ELAUNCH;
-  }
-  for (int64_t i = 0; i < count; ++i)
-    if (n[i] > 0) lanes[(size_t)(i % nl)].jobs.push_back((int)i);
-
-  size_t active = 0;
-  for (auto& L : lanes) active += L.cur < L.jobs.size();
-  while (active > 0 && rc == LK_OK) {
-    bool progressed = false;
-    for (size_t li = 0; li < lanes.size() && rc == LK_OK; ++li) {
-      Lane& L = lanes[li];
-      if (L.cur >= L.jobs.size()) continue;
-      const EigJob& j = jobs[(size_t)L.jobs[L.cur]];
-      if (!L.started) {
-        rc = eig_enqueue_init(j, L.stream);
-        L.started = true, L.enq = 0, L.pending = 0, L.pending_head = 0;
-        progressed = true;
-        if (rc != LK_OK) break;
+  auto new_event = [&](hipEvent_t* ev) {
+    if (!spare.empty()) {
+      *ev = spare.back();
+      spare.pop_back();
+      return true;
+    }
+    return hipEventCreateWithFlags(ev, hipEventDisableTiming) == hipSuccess;
+  };
+  auto fill_slots = [&]() {
+    while (rc == LK_OK && active.size() < (size_t)kEigBatch && next_waiting < waiting.size()) {
+      Run r;
+      r.job = waiting[next_waiting++];
+      rc = eig_enqueue_init(jobs[(size_t)r.job], main);
+      active.push_back(r);
+    }
+  };
+  fill_slots();
+  EigSlot slots[kEigBatch];
+  int slot_run[kEigBatch];
+  while (!active.empty() && rc == LK_OK) {
+    // harvest finished read-backs (in stream order)
+    size_t done = 0;
+    for (; done < inflight.size(); ++done) {
+      const hipError_t q = hipEventQuery(inflight[done].ev);
+      if (q == hipErrorNotReady) break;
+      if (q != hipSuccess) {
+        set_error("lk_syevj_batched_f32: %s", hipGetErrorString(q));
+        rc = LK_ELAUNCH;
+        break;
       }
-      // harvest finished read-backs (in order)
-      bool converged = false;
-      while (L.pending > 0) {
-        const int slot = L.pending_head % kSlots;
-        const hipError_t q = hipEventQuery(L.ev[slot]);
-        if (q == hipErrorNotReady) break;
-        if (q != hipSuccess) {
-          set_error("lk_syevj_batched_f32: %s", hipGetErrorString(q));
-          rc = LK_ELAUNCH;
-          break;
-        }
-        converged = converged || hflags[li * kSlots + slot] != 0;
-        ++L.pending_head, --L.pending;
-        progressed = true;
-      }
-      if (rc != LK_OK) break;
-      if (converged || L.enq >= max_sweeps) {
-        eig_enqueue_finalize(j, L.stream);
-        ++L.cur, L.started = false;
-        if (L.cur >= L.jobs.size()) --active;
-        progressed = true;
+      for (const auto& it : inflight[done].items)
+        for (Run& r : active)
+          if (r.job == it.first) {
+            r.converged = r.converged || hflags[(size_t)it.first * kSlots + it.second] != 0;
+            ++r.head, --r.pending;
+          }
+      spare.push_back(inflight[done].ev);
+    }
+    if (rc != LK_OK) break;
+    inflight.erase(inflight.begin(), inflight.begin() + (long)done);
+    // retire: converged, or out of sweeps (the gather kernel reports the device-side flag in `info`)
+    bool retired = false;
+    for (size_t i = 0; i < active.size();) {
+      const Run& r = active[i];
+      if (!(r.converged || r.enq >= max_sweeps)) {
+        ++i;
         continue;
       }
-      if (L.pending < kLookahead) {
-        eig_enqueue_sweep(j, L.stream);
-        const int slot = (L.pending_head + L.pending) % kSlots;
-        if (hipMemcpyAsync(&hflags[li * kSlots + slot], &j.ctrl->converged, sizeof(int), hipMemcpyDeviceToHost, L.stream) !=
-                hipSuccess ||
-            hipEventRecord(L.ev[slot], L.stream) != hipSuccess) {
-          set_error("lk_syevj_batched_f32: flag read-back failed");
+      const EigJob& j = jobs[(size_t)r.job];
+      if (fin != main) {
+        hipEvent_t ev;
+        if (!new_event(&ev) || hipEventRecord(ev, main) != hipSuccess || hipStreamWaitEvent(fin, ev, 0) != hipSuccess) {
+          set_error("lk_syevj_batched_f32: event hand-over to the finalising stream failed");
           rc = LK_ELAUNCH;
           break;
         }
-        ++L.enq, ++L.pending;
-        progressed = true;
+        handed.push_back(ev);  // (another stream waits on it: not re-recorded, destroyed at the end)
       }
+      eig_enqueue_finalize(j, fin);
+      active.erase(active.begin() + (long)i);
+      retired = true;
     }
-    // every lane is kLookahead sweeps ahead of the device: nap instead of spinning (a blocking wait on ONE lane's
-    // event would starve the lanes whose small matrices finish sooner)
-    if (!progressed && rc == LK_OK) std::this_thread::sleep_for(std::chrono::microseconds(20));
+    if (rc != LK_OK) break;
+    if (retired) fill_slots();
+    // the next round: every running matrix that is not yet kLookahead sweeps ahead of its flags
+    int ns = 0;
+    for (size_t i = 0; i < active.size(); ++i)
+      if (active[i].pending < kLookahead && active[i].enq < max_sweeps) {
+        slots[ns].job = &jobs[(size_t)active[i].job];
+        slots[ns].step = active[i].step;
+        slot_run[ns++] = (int)i;
+      }
+    if (ns == 0) {
+      if (!retired) std::this_thread::sleep_for(std::chrono::microseconds(20));
+      continue;
+    }
+    eig_enqueue_round(slots, ns, main);
+    Readback rb;
+    for (int k = 0; k < ns; ++k) {
+      Run& r = active[(size_t)slot_run[k]];
+      const EigJob& j = jobs[(size_t)r.job];
+      if (r.step < j.p.nb - 2) {
+        ++r.step;
+        continue;
+      }
+      r.step = 0, ++r.enq;  // the round completed this matrix' sweep: read its flag back
+      const int slot = (r.head + r.pending) % kSlots;
+      if (hipMemcpyAsync(&hflags[(size_t)r.job * kSlots + slot], &j.ctrl->converged, sizeof(int), hipMemcpyDeviceToHost, main) !=
+          hipSuccess) {
+        set_error("lk_syevj_batched_f32: flag read-back failed");
+        rc = LK_ELAUNCH;
+        break;
+      }
+      ++r.pending;
+      rb.items.emplace_back(r.job, slot);
+    }
+    if (rc == LK_OK && !rb.items.empty()) {
+      if (!new_event(&rb.ev) || hipEventRecord(rb.ev, main) != hipSuccess) {
+        set_error("lk_syevj_batched_f32: event record failed");
+        rc = LK_ELAUNCH;
+        break;
+      }
+      inflight.push_back(std::move(rb));
+    }
   }
   // speculative read-backs still in flight write into hflags: drain them before the pinned buffer goes away
-  for (auto& L : lanes) {
-    for (int k = 0; k < kSlots; ++k) {
-      (void)hipEventSynchronize(L.ev[k]);
-      (void)hipEventDestroy(L.ev[k]);
-    }
+  for (auto& rb : inflight) {
+    (void)hipEventSynchronize(rb.ev);
+    spare.push_back(rb.ev);
   }
+  // every given stream waits for the rounds and for the finalisations
+  if (rc == LK_OK) {
+    hipEvent_t e_main = nullptr, e_fin = nullptr;
+    if (new_event(&e_main) && new_event(&e_fin) && hipEventRecord(e_main, main) == hipSuccess &&
+        hipEventRecord(e_fin, fin) == hipSuccess) {
+      for (int64_t l = 0; l < nstreams; ++l) {
+        (void)hipStreamWaitEvent((hipStream_t)streams[l], e_main, 0);
+        (void)hipStreamWaitEvent((hipStream_t)streams[l], e_fin, 0);
+      }
+    } else {
+      set_error("lk_syevj_batched_f32: final event failed");
+      rc = LK_ELAUNCH;
+    }
+    if (e_main) spare.push_back(e_main);
+    if (e_fin) spare.push_back(e_fin);
+  }
+  for (hipEvent_t ev : spare) (void)hipEventDestroy(ev);
+  for (hipEvent_t ev : handed) (void)hipEventDestroy(ev);
   (void)hipHostFree(hflags);
   if (rc != LK_OK) return rc;
   return check_launch("lk_syevj_batched_f32");
