@@ -917,9 +917,11 @@ class HipKernels:
     def syevj_batched(self, mats, clamp=True, max_sweeps=0, streams=None):
         """Eigendecompose a list of symmetric matrices (largest first is best) -> list of (w, Q, info).
 
-        ``streams``: torch side streams for the solve — the rounds of all matrices run on ``streams[0]``, finished
-        matrices are refined on ``streams[1]`` beside them (more than two are accepted and only made to wait); the
-        caller orders them against its own stream (``wait_stream`` before / after).  ``None`` = the current stream."""
+        ``streams``: torch side streams for the solve — with three or more, the matrices iterate in two lanes of rounds
+        (``streams[0]``, ``streams[1]``: the pivot solves of one beside the tile updates of the other) and finished
+        matrices are refined on ``streams[2]``; with two, one lane + the refinements; further streams are only made to
+        wait.  The caller orders them against its own stream (``wait_stream`` before / after).  ``None`` = the current
+        stream."""
         if not mats:
             return []
         dev = mats[0].device
@@ -953,7 +955,7 @@ class HipKernels:
             arr(ctypes.c_size_t, [w_.numel() for w_ in keep]), 1 if clamp else 0, int(max_sweeps),
             arr(ctypes.c_void_p, [st.cuda_stream for st in used]), nstreams)
         self._rc(rc, "lk_syevj_batched_f32")
-        for st in used[:2]:
+        for st in used[:3]:
             if st != cur:  # allocated on `cur`, used on `st`
                 for A, o, ws in zip(mats, outs, keep):
                     for t in (A, ws) + o:

@@ -404,23 +404,33 @@ __device__ __forceinline__ f32x16 quad_mm16(const EigTileLds& L, int wm, int wn,
   return acc;
 }
 
-// the planes of R^T (written by the pivot kernel) -> an operand slot; identity when the pivot did not rotate
-__device__ __forceinline__ void eig_stage_rot(_Float16 (*dst)[EPLANE], const float* __restrict__ Rws, int pv, bool rotated,
-                                              int tid) {
-  if (rotated) {
-    const _Float16* src = reinterpret_cast<const _Float16*>(Rws + (int64_t)pv * EP * EP);
-    for (int idx = tid; idx < 2 * EP * EP / 8; idx += 256) {
-      const int pl = idx >> 9, j = (idx >> 3) & 63, k0 = (idx & 7) * 8;
-      *reinterpret_cast<f16x8*>(&dst[pl][j * EHP + k0]) = *reinterpret_cast<const f16x8*>(src + pl * EP * EP + j * EP + k0);
-    }
-  } else {
-    for (int idx = tid; idx < 2 * EP * EP / 8; idx += 256) {
-      const int pl = idx >> 9, j = (idx >> 3) & 63, k0 = (idx & 7) * 8;
-      f16x8 v;
+// the planes of R^T (written by the pivot kernel) -> an operand slot; identity when the pivot did not rotate.  In two
+// halves, so that the global loads of BOTH rotations of a tile are in flight before its first product starts.
+struct EigRotRegs {
+  f16x8 v[4];
+};
+__device__ __forceinline__ EigRotRegs eig_load_rot(const float* __restrict__ Rws, int pv, bool rotated, int tid) {
+  EigRotRegs g;
+  const _Float16* src = reinterpret_cast<const _Float16*>(Rws + (int64_t)pv * EP * EP);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (pl == 0 && k0 + e == j) ? (_Float16)16384.f : (_Float16)0.f;
-      *reinterpret_cast<f16x8*>(&dst[pl][j * EHP + k0]) = v;
+  for (int e = 0; e < 4; ++e) {
+    const int idx = tid + 256 * e;
+    const int pl = idx >> 9, j = (idx >> 3) & 63, k0 = (idx & 7) * 8;
+    if (rotated) {
+      g.v[e] = *reinterpret_cast<const f16x8*>(src + pl * EP * EP + j * EP + k0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) g.v[e][i] = (pl == 0 && k0 + i == j) ? (_Float16)16384.f : (_Float16)0.f;
     }
+  }
+  return g;
+}
+__device__ __forceinline__ void eig_store_rot(_Float16 (*dst)[EPLANE], const EigRotRegs& g, int tid) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int idx = tid + 256 * e;
+    const int pl = idx >> 9, j = (idx >> 3) & 63, k0 = (idx & 7) * 8;
+    *reinterpret_cast<f16x8*>(&dst[pl][j * EHP + k0]) = g.v[e];
   }
 }
 
@@ -428,9 +438,18 @@ __device__ __forceinline__ void eig_stage_rot(_Float16 (*dst)[EPLANE], const flo
 template <typename RowFn, typename ColFn>
 __device__ __forceinline__ void eig_stage_block(EigTileLds& L, const float* __restrict__ M, int np, RowFn gr, ColFn gc, float sc,
                                                 int tid) {
-  for (int idx = tid; idx < EP * EP / 4; idx += 256) {
+  float4 vv[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int idx = tid + 256 * e;
     const int r = idx >> 4, c0 = (idx & 15) * 4;  // (four consecutive columns never straddle a 32-wide index block)
-    const float4 v = *reinterpret_cast<const float4*>(M + (int64_t)gr(r) * np + gc(c0));
+    vv[e] = *reinterpret_cast<const float4*>(M + (int64_t)gr(r) * np + gc(c0));
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int idx = tid + 256 * e;
+    const int r = idx >> 4, c0 = (idx & 15) * 4;
+    const float4 v = vv[e];
     f16x4 h, l;
     _Float16 hh, ll;
     eig_split2(v.x * sc, hh, ll), h[0] = hh, l[0] = ll;
@@ -465,17 +484,21 @@ __global__ __launch_bounds__(256) void eig_update_kernel(EigRound rd) {
     if (!rotated[Q]) return;
     int IQ, JQ;
     pivot_blocks(step, Q, nb, IQ, JQ);
+    const EigRotRegs rq = eig_load_rot(Rws, Q, true, tid);
     eig_stage_block(L, V, np, [&](int r) { return rb * EP + r; }, [&](int c) { return pivot_index(c, IQ, JQ); }, 16384.f, tid);
-    eig_stage_rot(L.op.b, Rws, Q, true, tid);
+    eig_store_rot(L.op.b, rq, tid);
     __syncthreads();
     const f32x16 t = quad_mm16(L, wm, wn, lr, lh);
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 16; ++r) L.out[wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh][wn * 32 + lr] = t[r] * (1.f / 268435456.f);
     __syncthreads();
-    for (int idx = tid; idx < EP * EP; idx += 256) {
-      const int r = idx >> 6, c = idx & 63;
-      V[(int64_t)(rb * EP + r) * np + pivot_index(c, IQ, JQ)] = L.out[r][c];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = tid + 256 * e;
+      const int r = idx >> 4, c0 = (idx & 15) * 4;
+      const float4 o = make_float4(L.out[r][c0], L.out[r][c0 + 1], L.out[r][c0 + 2], L.out[r][c0 + 3]);
+      *reinterpret_cast<float4*>(V + (int64_t)(rb * EP + r) * np + pivot_index(c0, IQ, JQ)) = o;
     }
     return;
   }
@@ -506,8 +529,10 @@ __global__ __launch_bounds__(256) void eig_update_kernel(EigRound rd) {
   int sa = 13 - (be - 127);
   sa = sa > 100 ? 100 : (sa < -100 ? -100 : sa);
   const float sc_a = __uint_as_float((unsigned)(127 + sa) << 23), inv_a = __uint_as_float((unsigned)(127 - sa) << 23);
+  const EigRotRegs rq = eig_load_rot(Rws, Q, rotated[Q] != 0, tid);
+  const EigRotRegs rp = eig_load_rot(Rws, P, rotated[P] != 0, tid);
   eig_stage_block(L, Aw, np, [&](int r) { return pivot_index(r, IP, JP); }, [&](int c) { return pivot_index(c, IQ, JQ); }, sc_a, tid);
-  eig_stage_rot(L.op.b, Rws, Q, rotated[Q] != 0, tid);
+  eig_store_rot(L.op.b, rq, tid);
   __syncthreads();
   const f32x16 t = quad_mm16(L, wm, wn, lr, lh);  // T 2^(sa+14) = (A_PQ 2^sa) (R_Q 2^14)
   __syncthreads();
@@ -526,7 +551,7 @@ __global__ __launch_bounds__(256) void eig_update_kernel(EigRound rd) {
     *reinterpret_cast<f16x4*>(&L.op.b[0][off]) = h;
     *reinterpret_cast<f16x4*>(&L.op.b[1][off]) = l;
   }
-  eig_stage_rot(L.op.a, Rws, P, rotated[P] != 0, tid);
+  eig_store_rot(L.op.a, rp, tid);
   __syncthreads();
   const f32x16 m = quad_mm16(L, wm, wn, lr, lh);  // M 2^(sa+14) = (R_P^T 2^14) (T 2^sa)
   __syncthreads();
@@ -534,10 +559,14 @@ __global__ __launch_bounds__(256) void eig_update_kernel(EigRound rd) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) L.out[wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh][wn * 32 + lr] = m[r] * un;
   __syncthreads();
-  for (int idx = tid; idx < EP * EP; idx += 256) {
-    const int r = idx >> 6, c = idx & 63;
-    Aw[(int64_t)pivot_index(r, IP, JP) * np + pivot_index(c, IQ, JQ)] = L.out[r][c];
-    Aw[(int64_t)pivot_index(r, IQ, JQ) * np + pivot_index(c, IP, JP)] = L.out[c][r];  // mirrored tile
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int idx = tid + 256 * e;
+    const int r = idx >> 4, c0 = (idx & 15) * 4;
+    const float4 o = make_float4(L.out[r][c0], L.out[r][c0 + 1], L.out[r][c0 + 2], L.out[r][c0 + 3]);
+    const float4 t4 = make_float4(L.out[c0][r], L.out[c0 + 1][r], L.out[c0 + 2][r], L.out[c0 + 3][r]);
+    *reinterpret_cast<float4*>(Aw + (int64_t)pivot_index(r, IP, JP) * np + pivot_index(c0, IQ, JQ)) = o;
+    *reinterpret_cast<float4*>(Aw + (int64_t)pivot_index(r, IQ, JQ) * np + pivot_index(c0, IP, JP)) = t4;  // mirrored tile
   }
 }
 
@@ -875,8 +904,11 @@ extern "C" int lk_syevj_batched_f32(int64_t count, const float* const* A, const 
     if (int rc = eig_job_setup(jobs[(size_t)i], A[i], n[i], w[i], Q[i], clamp, info[i], ws[i], ws_bytes[i])) return rc;
     waiting.push_back((int)i);
   }
-  hipStream_t main = (hipStream_t)streams[0];
-  hipStream_t fin = (hipStream_t)streams[nstreams > 1 ? 1 : 0];
+  // lanes: the matrices are dealt (largest first, to the lane with the smaller sum of n^3) to up to two streams, each
+  // iterating its share in rounds of its own -- the pivot solves of one lane (few workgroups, LDS latency) then run
+  // beside the tile updates of the other (HBM-bound); the stream after the lanes takes the finalisations
+  const int nlanes = nstreams >= 3 ? 2 : 1;
+  hipStream_t fin = (hipStream_t)streams[nstreams > nlanes ? nlanes : nstreams - 1];
   int* hflags = nullptr;
   if (hipHostMalloc(reinterpret_cast<void**>(&hflags), sizeof(int) * kSlots * (size_t)count, hipHostMallocDefault) != hipSuccess) {
     set_error("lk_syevj_batched_f32: hipHostMalloc failed");
@@ -894,10 +926,24 @@ extern "C" int lk_syevj_batched_f32(int64_t count, const float* const* A, const 
     hipEvent_t ev;
     std::vector<std::pair<int, int>> items;  // (job, slot of its ring)
   };
-  std::vector<Run> active;
-  std::vector<Readback> inflight;  // in stream order
+  struct Lane {
+    hipStream_t stream;
+    std::vector<int> waiting;
+    size_t next_waiting = 0;
+    std::vector<Run> active;
+    std::vector<Readback> inflight;  // in stream order
+    double load = 0.0;
+  };
+  std::vector<Lane> lanes((size_t)nlanes);
+  for (int l = 0; l < nlanes; ++l) lanes[(size_t)l].stream = (hipStream_t)streams[l];
+  for (int ji : waiting) {
+    Lane* best = &lanes[0];
+    for (Lane& L : lanes)
+      if (L.load < best->load) best = &L;
+    best->waiting.push_back(ji);
+    best->load += (double)n[ji] * (double)n[ji] * (double)n[ji];
+  }
   std::vector<hipEvent_t> spare, handed;
-  size_t next_waiting = 0;
   int rc = LK_OK;
   auto new_event = [&](hipEvent_t* ev) {
     if (!spare.empty()) {
@@ -907,42 +953,44 @@ extern "C" int lk_syevj_batched_f32(int64_t count, const float* const* A, const 
     }
     return hipEventCreateWithFlags(ev, hipEventDisableTiming) == hipSuccess;
   };
-  auto fill_slots = [&]() {
-    while (rc == LK_OK && active.size() < (size_t)kEigBatch && next_waiting < waiting.size()) {
+  auto fill_slots = [&](Lane& L) {
+    while (rc == LK_OK && L.active.size() < (size_t)kEigBatch && L.next_waiting < L.waiting.size()) {
       Run r;
-      r.job = waiting[next_waiting++];
-      rc = eig_enqueue_init(jobs[(size_t)r.job], main);
-      active.push_back(r);
+      r.job = L.waiting[L.next_waiting++];
+      rc = eig_enqueue_init(jobs[(size_t)r.job], L.stream);
+      L.active.push_back(r);
     }
   };
-  fill_slots();
   EigSlot slots[kEigBatch];
   int slot_run[kEigBatch];
-  while (!active.empty() && rc == LK_OK) {
+  // one pass over a lane: harvest flags, retire finished matrices, enqueue the next round; false = nothing to do now
+  auto advance = [&](Lane& L) -> bool {
+    hipStream_t main = L.stream;
+    bool progressed = false;
     // harvest finished read-backs (in stream order)
     size_t done = 0;
-    for (; done < inflight.size(); ++done) {
-      const hipError_t q = hipEventQuery(inflight[done].ev);
+    for (; done < L.inflight.size(); ++done) {
+      const hipError_t q = hipEventQuery(L.inflight[done].ev);
       if (q == hipErrorNotReady) break;
       if (q != hipSuccess) {
         set_error("lk_syevj_batched_f32: %s", hipGetErrorString(q));
         rc = LK_ELAUNCH;
-        break;
+        return true;
       }
-      for (const auto& it : inflight[done].items)
-        for (Run& r : active)
+      for (const auto& it : L.inflight[done].items)
+        for (Run& r : L.active)
           if (r.job == it.first) {
             r.converged = r.converged || hflags[(size_t)it.first * kSlots + it.second] != 0;
             ++r.head, --r.pending;
           }
-      spare.push_back(inflight[done].ev);
+      spare.push_back(L.inflight[done].ev);
+      progressed = true;
     }
-    if (rc != LK_OK) break;
-    inflight.erase(inflight.begin(), inflight.begin() + (long)done);
+    L.inflight.erase(L.inflight.begin(), L.inflight.begin() + (long)done);
     // retire: converged, or out of sweeps (the gather kernel reports the device-side flag in `info`)
     bool retired = false;
-    for (size_t i = 0; i < active.size();) {
-      const Run& r = active[i];
+    for (size_t i = 0; i < L.active.size();) {
+      const Run& r = L.active[i];
       if (!(r.converged || r.enq >= max_sweeps)) {
         ++i;
         continue;
@@ -953,32 +1001,32 @@ extern "C" int lk_syevj_batched_f32(int64_t count, const float* const* A, const 
         if (!new_event(&ev) || hipEventRecord(ev, main) != hipSuccess || hipStreamWaitEvent(fin, ev, 0) != hipSuccess) {
           set_error("lk_syevj_batched_f32: event hand-over to the finalising stream failed");
           rc = LK_ELAUNCH;
-          break;
+          return true;
         }
         handed.push_back(ev);  // (another stream waits on it: not re-recorded, destroyed at the end)
       }
       eig_enqueue_finalize(j, fin);
-      active.erase(active.begin() + (long)i);
+      L.active.erase(L.active.begin() + (long)i);
       retired = true;
     }
-    if (rc != LK_OK) break;
-    if (retired) fill_slots();
+    if (retired) {
+      fill_slots(L);
+      progressed = true;
+      if (rc != LK_OK) return true;
+    }
     // the next round: every running matrix that is not yet kLookahead sweeps ahead of its flags
     int ns = 0;
-    for (size_t i = 0; i < active.size(); ++i)
-      if (active[i].pending < kLookahead && active[i].enq < max_sweeps) {
-        slots[ns].job = &jobs[(size_t)active[i].job];
-        slots[ns].step = active[i].step;
+    for (size_t i = 0; i < L.active.size(); ++i)
+      if (L.active[i].pending < kLookahead && L.active[i].enq < max_sweeps) {
+        slots[ns].job = &jobs[(size_t)L.active[i].job];
+        slots[ns].step = L.active[i].step;
         slot_run[ns++] = (int)i;
       }
-    if (ns == 0) {
-      if (!retired) std::this_thread::sleep_for(std::chrono::microseconds(20));
-      continue;
-    }
+    if (ns == 0) return progressed;
     eig_enqueue_round(slots, ns, main);
     Readback rb;
     for (int k = 0; k < ns; ++k) {
-      Run& r = active[(size_t)slot_run[k]];
+      Run& r = L.active[(size_t)slot_run[k]];
       const EigJob& j = jobs[(size_t)r.job];
       if (r.step < j.p.nb - 2) {
         ++r.step;
@@ -990,40 +1038,55 @@ extern "C" int lk_syevj_batched_f32(int64_t count, const float* const* A, const 
           hipSuccess) {
         set_error("lk_syevj_batched_f32: flag read-back failed");
         rc = LK_ELAUNCH;
-        break;
+        return true;
       }
       ++r.pending;
       rb.items.emplace_back(r.job, slot);
     }
-    if (rc == LK_OK && !rb.items.empty()) {
+    if (!rb.items.empty()) {
       if (!new_event(&rb.ev) || hipEventRecord(rb.ev, main) != hipSuccess) {
         set_error("lk_syevj_batched_f32: event record failed");
         rc = LK_ELAUNCH;
-        break;
+        return true;
       }
-      inflight.push_back(std::move(rb));
+      L.inflight.push_back(std::move(rb));
     }
+    return true;
+  };
+  for (Lane& L : lanes) fill_slots(L);
+  for (;;) {
+    bool any_active = false, progressed = false;
+    for (Lane& L : lanes) {
+      if (L.active.empty() || rc != LK_OK) continue;
+      any_active = true;
+      progressed = advance(L) || progressed;
+    }
+    if (!any_active || rc != LK_OK) break;
+    // every running matrix is kLookahead sweeps ahead of the device: nap instead of spinning
+    if (!progressed) std::this_thread::sleep_for(std::chrono::microseconds(20));
   }
   // speculative read-backs still in flight write into hflags: drain them before the pinned buffer goes away
-  for (auto& rb : inflight) {
-    (void)hipEventSynchronize(rb.ev);
-    spare.push_back(rb.ev);
-  }
+  for (Lane& L : lanes)
+    for (auto& rb : L.inflight) {
+      (void)hipEventSynchronize(rb.ev);
+      spare.push_back(rb.ev);
+    }
   // every given stream waits for the rounds and for the finalisations
   if (rc == LK_OK) {
-    hipEvent_t e_main = nullptr, e_fin = nullptr;
-    if (new_event(&e_main) && new_event(&e_fin) && hipEventRecord(e_main, main) == hipSuccess &&
-        hipEventRecord(e_fin, fin) == hipSuccess) {
-      for (int64_t l = 0; l < nstreams; ++l) {
-        (void)hipStreamWaitEvent((hipStream_t)streams[l], e_main, 0);
-        (void)hipStreamWaitEvent((hipStream_t)streams[l], e_fin, 0);
+    std::vector<hipStream_t> producers;
+    for (Lane& L : lanes) producers.push_back(L.stream);
+    producers.push_back(fin);
+    for (hipStream_t ps : producers) {
+      hipEvent_t ev = nullptr;
+      if (!new_event(&ev) || hipEventRecord(ev, ps) != hipSuccess) {
+        set_error("lk_syevj_batched_f32: final event failed");
+        rc = LK_ELAUNCH;
+        break;
       }
-    } else {
-      set_error("lk_syevj_batched_f32: final event failed");
-      rc = LK_ELAUNCH;
+      for (int64_t l = 0; l < nstreams; ++l)
+        if ((hipStream_t)streams[l] != ps) (void)hipStreamWaitEvent((hipStream_t)streams[l], ev, 0);
+      handed.push_back(ev);
     }
-    if (e_main) spare.push_back(e_main);
-    if (e_fin) spare.push_back(e_fin);
   }
   for (hipEvent_t ev : spare) (void)hipEventDestroy(ev);
   for (hipEvent_t ev : handed) (void)hipEventDestroy(ev);

@@ -187,14 +187,15 @@ class HipKron(_KronBase):
             load[r] += float(sizes[i]) ** 3
         return owner
 
-    def decompose(self, damping: bool = False, n_streams: int = 2, process_group=None,
+    def decompose(self, damping: bool = False, n_streams: int = 3, process_group=None,
                   distributed: bool = False) -> "HipKronDecomposed":
         """Eigendecompose every dense factor with the HIP block-Jacobi solver.
 
         The solver of one matrix is a long chain of small launches (latency-bound pivot solves), so all factors
         iterate together: every launch serves the current round of every matrix still running (largest first;
-        ``lk_syevj_batched_f32``), on one side stream, with the final refinement of finished matrices on a second
-        (``n_streams`` = 1 or 2); the calling stream waits for both before returning.
+        ``lk_syevj_batched_f32``), in two lanes on two side streams (the pivot solves of one lane beside the tile
+        updates of the other), with the final refinement of finished matrices on a third (``n_streams`` = 3; 2 = one
+        lane, 1 = everything on one stream); the calling stream waits for all of them before returning.
 
         ``distributed=True`` (every rank of ``process_group`` holds the SAME factors, i.e. after the fit's
         all-reduce): the factors are sharded over the ranks (:meth:`shard_factors`), each rank solves its

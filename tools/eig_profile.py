@@ -32,9 +32,9 @@ if len(sys.argv) < 2 or sys.argv[1] != "decompose":
         ms = 1e3 * (time.perf_counter() - t0)
         rec = float(((Q * w) @ Q.T - M).abs().max() / M.abs().max())
         print(f"n {n:5d}: {ms:7.1f} ms  sweeps {int(info[1]):2d}  info {int(info[0])}  rec {rec:.1e}", flush=True)
-for _ in range(3):
+for ns in (3, 2, 3, 2, 3):
     t0 = time.perf_counter()
-    D = H.decompose()
+    D = H.decompose(n_streams=ns)
     D.check_converged()
     torch.cuda.synchronize()
-    print(f"decompose: {1e3 * (time.perf_counter() - t0):.1f} ms", flush=True)
+    print(f"decompose (n_streams {ns}): {1e3 * (time.perf_counter() - t0):.1f} ms", flush=True)

@@ -15,8 +15,9 @@ def main(db, out=None):
     rows = sorted(cur.execute(f"select name, start, end, {qcol}, {scol}, {gcol} from kernels"), key=lambda r: r[1])
     lines = ["columns: " + ", ".join(cols)]
     gathers = [r for r in rows if "eig_gather" in r[0]]
-    per = len(gathers) // 3
-    t0 = max(r[2] for r in gathers[:2 * per])
+    ndec = 5  # eig_profile.py runs five decompositions (n_streams 3, 2, 3, 2, 3): the window is the last one
+    per = len(gathers) // ndec
+    t0 = max(r[2] for r in gathers[:(ndec - 1) * per])
     t1 = max(r[2] for r in gathers)
     rows = [r for r in rows if r[1] >= t0 and r[2] <= t1 and "eig" in r[0]]
     t0 = rows[0][1]
