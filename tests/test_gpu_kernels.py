@@ -404,6 +404,34 @@ def test_syevj_batched(K, nstreams):
     assert torch.equal(w1, outs[0][0]) and torch.equal(Q1, outs[0][1])
 
 
+@pytest.mark.parametrize("nstreams", [2, 3])
+def test_syevj_batched_more_matrices_than_slots(K, nstreams):
+    """A round serves at most 64 matrices per lane: with 150 of them the rest waits for freed slots (a converged matrix
+    hands its slot on).  Every matrix must come out as from the single solve, bit for bit."""
+    sizes = [3 + (37 * i) % 140 for i in range(150)]
+    mats64 = []
+    for i, n in enumerate(sizes):
+        X = rnd(2 * n + 3, n, seed=1000 + i)
+        mats64.append(X.T @ X / X.shape[0])
+    order = sorted(range(150), key=lambda i: -sizes[i])  # (largest first, as decompose passes them)
+    mats = [mats64[i].float().to(DEV).contiguous() for i in order]
+    streams = [torch.cuda.Stream() for _ in range(nstreams)] if DEV != "cpu" else None
+    outs = K.syevj_batched(mats, clamp=True, streams=streams)
+    if streams:
+        for st in streams:
+            torch.cuda.current_stream().wait_stream(st)
+    _sync()
+    for k, i in enumerate(order):
+        w, Q, info = outs[k]
+        assert int(info[0].item()) == 0
+        wref = torch.linalg.eigvalsh(mats64[i]).clamp(min=0)
+        assert (w.double().cpu() - wref).abs().max().item() / wref.max().item() < 2e-5, f"matrix {i} (n = {sizes[i]})"
+    for k in (0, 63, 64, 65, 127, 128, 149):
+        w1, Q1, _ = K.syevj(mats[k])
+        _sync()
+        assert torch.equal(w1, outs[k][0]) and torch.equal(Q1, outs[k][1]), f"position {k}"
+
+
 # ---- logdet / predictive -----------------------------------------------------------------------------------
 @pytest.mark.parametrize("n1,n2", [(1, 0), (20, 0), (2, 20), (64, 576), (10, 513), (130, 77)])
 def test_kron_logdet(K, n1, n2):
