@@ -475,6 +475,46 @@ __global__ __launch_bounds__(256) void gram16_reduce_kernel(const float* __restr
   }
 }
 
+// The same reduction for the split-K slabs of lk_gram_tn_f16x2 (a few dozen partials of 16 / 64 KB each): a workgroup owns
+// 256 consecutive floats of one block; wave g sums the partials p = g, g + 4, ... as float4s (1 KB contiguous per wave and
+// partial, where the kernel above reads 128 bytes), then the four sums are added in wave order.  Fixed order, no atomics.
+template <int NB>
+__global__ __launch_bounds__(256) void gram16_reduce4_kernel(const float* __restrict__ ws, int nparts, int npairs, int nbc,
+                                                             int C, const int* __restrict__ sexp, float alpha,
+                                                             float* __restrict__ Gm) {
+  __shared__ float4 red[4][64];
+  const int pair = blockIdx.y;
+  int bi = 0, bj = 0;
+  {
+    int p = pair;
+    while (p >= nbc - bi) p -= nbc - bi, ++bi;
+    bj = bi + p;
+  }
+  const int q = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int e = blockIdx.x * 256 + 4 * q;  // first of this thread's four elements of the NB x NB block (one row: NB % 4 == 0)
+  const int row = e / NB, col = e % NB;
+  const bool live = !(bi == bj && (row >> 5) > (col >> 5));  // (tiles below the diagonal of a diagonal block are never computed)
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* src = ws + (int64_t)pair * (NB * NB) + e;
+  for (int p = g; live && p < nparts; p += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)p * npairs * (NB * NB));
+    s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+  }
+  red[g][q] = s;
+  __syncthreads();
+  if (g == 0 && live) {
+    float4 t = red[0][q];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) t.x += red[k][q].x, t.y += red[k][q].y, t.z += red[k][q].z, t.w += red[k][q].w;
+    const float inv = exp2i16(-sexp[0]);
+    const float f = alpha * inv * inv;
+    float4* dst = reinterpret_cast<float4*>(Gm + (int64_t)(bi * NB + row) * C + bj * NB + col);
+    float4 o = *dst;
+    o.x += f * t.x, o.y += f * t.y, o.z += f * t.z, o.w += f * t.w;
+    *dst = o;
+  }
+}
+
 }  // namespace lk
 
 using namespace lk;
@@ -584,14 +624,14 @@ extern "C" int lk_gram_tn_f16x2(const void* x_h, const void* x_l, const int* sex
   }
   int rc = check_launch("gram16_kernel");
   if (rc != LK_OK) return rc;
-  dim3 rgrid((unsigned)(p.nb * p.nb / 32), (unsigned)p.npairs);
+  dim3 rgrid((unsigned)(p.nb * p.nb / 256), (unsigned)p.npairs);
   if (C == 64)
-    hipLaunchKernelGGL(gram16_reduce_kernel<64>, rgrid, dim3(256), 0, st, (const float*)ws, (int)p.nparts, p.npairs, p.nbc,
+    hipLaunchKernelGGL(gram16_reduce4_kernel<64>, rgrid, dim3(256), 0, st, (const float*)ws, (int)p.nparts, p.npairs, p.nbc,
                        (int)C, sexp, alpha, Gm);
   else
-    hipLaunchKernelGGL(gram16_reduce_kernel<128>, rgrid, dim3(256), 0, st, (const float*)ws, (int)p.nparts, p.npairs, p.nbc,
+    hipLaunchKernelGGL(gram16_reduce4_kernel<128>, rgrid, dim3(256), 0, st, (const float*)ws, (int)p.nparts, p.npairs, p.nbc,
                        (int)C, sexp, alpha, Gm);
-  return check_launch("gram16_reduce_kernel");
+  return check_launch("gram16_reduce4_kernel");
 }
 
 // G[64][64] (upper 32x32 tiles) += alpha * 2^(-2 sexp) * sum of `nparts` partial blocks [nparts][64][64] left by a fused

@@ -365,3 +365,20 @@ def test_window_form_backward_forward_and_fused_epilogue(cin, cout, H, n_img, cf
     assert rel(fused.float(), want_v) < 1e-5
     assert torch.equal(fused.sexp, fused_ref.sexp) and rel(fused.float(), fused_ref.float()) < 1e-6
     assert abs(fused.amax.item() - fused.float().abs().max().item()) <= 1e-5 * fused.amax.item()
+
+
+@pytest.mark.parametrize("n,where", [(4096, 0), (4096, 4095), (4100, 2049), (4099, 4098), (1 << 22, 1234567), (3 * (1 << 20) + 8, 17)])
+def test_absmax_vector_and_scalar_forms(n, where):
+    """lk_absmax_f32 streams float4s when it can (16-byte aligned, n % 4 == 0, n >= 4096) and falls back to the scalar
+    form otherwise: the planted extreme must be found wherever it sits, negative or not, and through an unaligned view."""
+    from laplace_amd import _lib
+
+    K = _lib.get_kernels()
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n + 1, generator=g).to(DEV)
+    for sign in (1.0, -1.0):
+        y = x.clone()
+        y[where] = sign * 77.5
+        assert float(K.absmax(y[:n])[0]) == 77.5  # (a leading slice of a 1-D tensor is contiguous and keeps the alignment)
+        tail = y[1:]  # data pointer 4 bytes past a 16-byte boundary: the scalar form
+        assert float(K.absmax(tail)[0]) == float(tail.abs().max())
