@@ -530,6 +530,7 @@ class _HipCurvatureMixin:
         if not acc.defer_pix:
             acc.use_pixgram = False
         acc._persist_slabs = False
+        acc.lanes = 1  # (one minibatch: nothing to run beside it)
         try:
             acc.add_batch(x, y)
         except NotImplementedError as e:
@@ -639,6 +640,12 @@ class KronAccumulator:
         #: the fused accumulator does.  A minibatch nobody absorbs computes them the per-minibatch way when it is read.
         self.defer_pix = False
         self._pix_inputs = {}  # tap index -> list of (geometry, alpha, NHWC fp32 tensor [B, H, W, C], module)
+        #: minibatches in flight on the device (env LK_LANES): with 2, consecutive minibatches go alternately to two
+        #: sub-accumulators, each with its own stream (and side stream) and its own factor buffers, summed when the fit
+        #: is read — the forward pass of one minibatch (small grids at batch 128) then runs beside the reverse sweep of
+        #: the one before it.  The sum over minibatches is linear: same factors up to the order of fp32 additions.
+        self.lanes = max(1, int(os.environ.get("LK_LANES", "2")))
+        self._lane_accs, self._lane_next, self._lane_id, self._lane_stream = None, 0, 0, None
 
     def _alloc(self, tape, dev):
         self.factors, self._taps_meta = [], []
@@ -663,6 +670,7 @@ class KronAccumulator:
     def ensure_allocated(self, device):
         """Zero factors for a rank that saw no minibatch (empty shard of a data-parallel fit): shapes come from the
         modules alone, so the rank can still take part in the all-reduce."""
+        self._fold_lanes()
         if self.factors is None:
             self._alloc(self.backend._tape(), device)
 
@@ -825,8 +833,69 @@ class KronAccumulator:
             else:
                 K.pixgram_assemble(buf, geo[1], geo[2], geo[3], 1.0, self.factors[idx][1])
 
+    def _lane_add_batch(self, x, y):
+        dev = x.device
+        cur = torch.cuda.current_stream(dev)
+        if self._lane_accs is None:
+            cache = self.backend.__dict__.setdefault("_lane_streams", {})
+            streams = cache.setdefault((dev, self.lanes), [torch.cuda.Stream(dev) for _ in range(self.lanes)])
+            self._lane_accs = []
+            for k in range(self.lanes):
+                sub = KronAccumulator(self.backend, self.N, self.kfac_approx, self.overlap)
+                sub.lanes, sub._lane_id, sub._lane_stream = 1, k, streams[k]
+                sub.use_pixgram, sub.pix_group, sub.lag_join = self.use_pixgram, self.pix_group, self.lag_join
+                sub._defer_bn, sub._persist_slabs = self._defer_bn, self._persist_slabs
+                self._lane_accs.append(sub)
+        k = self._lane_next
+        self._lane_next = (k + 1) % self.lanes
+        sub = self._lane_accs[k]
+        st = sub._lane_stream
+        st.wait_stream(cur)
+        if sub.factors is None and k > 0:
+            # first minibatch of this lane: whatever lane 0's first minibatch built lazily and everybody shares from then
+            # on (split weight planes, BatchNorm scale words, pixel-pair tables) must exist before it is read here
+            first = self._lane_accs[0]
+            st.wait_stream(first._lane_stream)
+            if first._side is not None:
+                st.wait_stream(first._side)
+        with torch.cuda.stream(st):
+            sub.add_batch(x, y)
+        for t in (x, y):
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(st)
+
+    def _fold_lanes(self):
+        """bring the lanes' partial sums together on the calling stream (before anything reads the accumulated state)"""
+        subs, self._lane_accs = self._lane_accs, None
+        if not subs:
+            return
+        dev = subs[0]._lane_stream.device
+        cur = torch.cuda.current_stream(dev)
+        for sub in subs:
+            cur.wait_stream(sub._lane_stream)
+        for sub in subs:
+            if sub.factors is None:
+                continue
+            sub._join_side()
+            sub._flush_pixgrams()
+            sub._flush_g_slabs()
+            if self.factors is None:
+                self.factors, self.loss, self._taps_meta = sub.factors, sub.loss, sub._taps_meta
+                self._pix, self._pix_pending, self._gslabs = {}, {}, {}
+                self._gscale, self._tap_index = dict(sub._gscale), dict(sub._tap_index)
+            else:
+                if set(self._gscale) != set(sub._gscale):
+                    raise RuntimeError("the lanes of a fit disagree about the deferred BatchNorm scales")
+                torch._foreach_add_(self._raw_tensors(), sub._raw_tensors())
+            if sub._range_tab is not None:
+                self._range_full += list(sub._range_full) + [sub._range_tab[:sub._range_n]]
+            for t in sub._raw_tensors():  # allocated on the lane's stream, read (and from now on owned) here
+                t.record_stream(cur)
+
     def add_batch(self, x, y):
         b = self.backend
+        if self.lanes > 1 and self.overlap and not self.defer_pix and torch.is_tensor(x) and x.is_cuda:
+            return self._lane_add_batch(x, y)
         mode = getattr(b, "range_guard", "check")
         if mode not in (False, "off") and torch.is_tensor(x) and x.is_floating_point() and x.dim() >= 2 and x.shape[0] > 1:
             if mode == "group":
@@ -885,9 +954,10 @@ class KronAccumulator:
         if self.overlap and f.is_cuda:
             if self._side is None:  # one side stream per backend object, shared by all its accumulators
                 cache = b.__dict__.setdefault("_side_streams", {})
-                if f.device not in cache:
-                    cache[f.device] = torch.cuda.Stream(f.device)
-                self._side = cache[f.device]
+                key = f.device if self._lane_id == 0 else (f.device, self._lane_id)
+                if key not in cache:
+                    cache[key] = torch.cuda.Stream(f.device)
+                self._side = cache[key]
             side = self._side
             main = torch.cuda.current_stream(f.device)
             side.wait_stream(main)
@@ -984,6 +1054,7 @@ class KronAccumulator:
 
     def clone(self) -> "KronAccumulator":
         """an independent copy of the accumulated state (factors in the accumulator's raw form)"""
+        self._fold_lanes()
         self._join_side()
         new = KronAccumulator(self.backend, self.N, self.kfac_approx, self.overlap)
         new.use_pixgram, new._persist_slabs = self.use_pixgram, self._persist_slabs
@@ -1011,6 +1082,8 @@ class KronAccumulator:
         With a side stream the add is enqueued THERE, behind ``other``'s factor kernels (same stream, in order): the
         calling stream does not wait for them and goes on with the next minibatch, at most one merge ahead — the schedule
         the fused accumulator has with ``lag_join``.  Readers (`finalize`, `tensors`, `clone`) join the side stream."""
+        self._fold_lanes()
+        other._fold_lanes()
         if not self._raw_compatible(other):
             return False
         skip = set(other._pix_inputs)  # A factors `other` left to this sum: identically zero there, nothing to add
@@ -1082,6 +1155,7 @@ class KronAccumulator:
         """Everything a data-parallel fit has to all-reduce (upper triangles are what counts).  The deferred BatchNorm
         scales are applied HERE, before the exchange: ``diag(s) G diag(s)`` is linear in G, so scaled factors add
         exactly, and a rank with an empty shard — which never learned a scale and contributes zeros — needs none."""
+        self._fold_lanes()
         self._check_range()
         self._resolve_pix_inputs()
         self._flush_pixgrams()  # the assembled factors are what is exchanged, not the larger pixel-pair Grams
@@ -1093,6 +1167,7 @@ class KronAccumulator:
         """-> (loss, HipKron) in the reference's layout (laplace/curvature/curvlinops.py:55-75)."""
         K = get_kernels()
         rt = math.sqrt(float(self.backend.factor))
+        self._fold_lanes()
         self._check_range()
         self._resolve_pix_inputs()
         self._flush_pixgrams()

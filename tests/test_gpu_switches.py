@@ -90,6 +90,8 @@ CASES = {
     "LK_PIX_GROUP=2": dict(acc_attrs={"pix_group": 2}),
     "LK_LAG_JOIN=0": dict(acc_attrs={"lag_join": False}),
     "overlap=False": dict(acc_attrs={"overlap": False}),
+    "LK_LANES=1": dict(acc_attrs={"lanes": 1}),
+    "LK_LANES=3": dict(acc_attrs={"lanes": 3}),
     "LK_FUSE_VJP=0": dict(sweep_attrs={"fuse_vjp": False}),
     "LK_NHWC_FORWARD=0": dict(sweep_attrs={"nhwc_forward": False}),
     "LK_PIXPAIR16=0": dict(kernel_attrs={"use_pixpair16": False}),
