@@ -199,3 +199,33 @@ def test_a_ragged_last_minibatch_as_in_a_50k_fit(resnet, monkeypatch):
     for F_, S_ in zip(H.kfacs, H_s.kfacs):
         for a_, s_ in zip(F_, S_):
             assert rel(a_, s_) < 1e-5
+
+
+@pytest.mark.skipif(DEV == "cpu", reason="streams: device only")
+def test_a_caller_that_refills_one_device_buffer_per_minibatch():
+    """With two minibatches in flight the forward of a minibatch runs on a lane stream while the caller's stream goes on:
+    a loader that copies every minibatch into the SAME device tensors must still be safe (the caller's stream waits until
+    the lane has consumed its inputs).  Same factors as with a fresh tensor per minibatch."""
+    from laplace_amd import HipGGN
+    from laplace_amd.nets import ResNet18
+
+    torch.manual_seed(711)
+    model = ResNet18(10, act=torch.tanh).to(DEV).eval()
+    g = torch.Generator().manual_seed(21)
+    host = [(torch.randn(128, 3, 32, 32, generator=g).pin_memory(), torch.randint(10, (128,), generator=g).pin_memory()) for _ in range(6)]
+    b = HipGGN(model, "classification")
+    acc = b.kron_accumulator(50_000)
+    assert acc.lanes >= 2
+    Xd, yd = torch.empty(128, 3, 32, 32, device=DEV), torch.empty(128, dtype=torch.long, device=DEV)
+    for X, y in host:
+        Xd.copy_(X, non_blocking=True)
+        yd.copy_(y, non_blocking=True)
+        acc.add_batch(Xd, yd)
+    _, H = acc.finalize()
+    ref = b.kron_accumulator(50_000)
+    for X, y in host:
+        ref.add_batch(X.to(DEV), y.to(DEV))
+    _, Hr = ref.finalize()
+    for F_, G_ in zip(H.kfacs, Hr.kfacs):
+        for a, w in zip(F_, G_):
+            assert (a - w).abs().max().item() <= 1e-5 * w.abs().max().item()
