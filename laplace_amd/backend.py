@@ -646,6 +646,7 @@ class KronAccumulator:
         #: the one before it.  The sum over minibatches is linear: same factors up to the order of fp32 additions.
         self.lanes = max(1, int(os.environ.get("LK_LANES", "2")))
         self._lane_accs, self._lane_next, self._lane_id, self._lane_stream = None, 0, 0, None
+        self._lanes_anywhere = False  # (tests: the lanes' host logic on the CPU emulation of the kernels, without streams)
 
     def _alloc(self, tape, dev):
         self.factors, self._taps_meta = [], []
@@ -835,10 +836,13 @@ class KronAccumulator:
 
     def _lane_add_batch(self, x, y):
         dev = x.device
-        cur = torch.cuda.current_stream(dev)
+        on_device = x.is_cuda
+        cur = torch.cuda.current_stream(dev) if on_device else None
         if self._lane_accs is None:
-            cache = self.backend.__dict__.setdefault("_lane_streams", {})
-            streams = cache.setdefault((dev, self.lanes), [torch.cuda.Stream(dev) for _ in range(self.lanes)])
+            streams = [None] * self.lanes
+            if on_device:
+                cache = self.backend.__dict__.setdefault("_lane_streams", {})
+                streams = cache.setdefault((dev, self.lanes), [torch.cuda.Stream(dev) for _ in range(self.lanes)])
             self._lane_accs = []
             for k in range(self.lanes):
                 sub = KronAccumulator(self.backend, self.N, self.kfac_approx, self.overlap)
@@ -849,6 +853,9 @@ class KronAccumulator:
         k = self._lane_next
         self._lane_next = (k + 1) % self.lanes
         sub = self._lane_accs[k]
+        if not on_device:
+            sub.add_batch(x, y)
+            return
         st = sub._lane_stream
         # The lane works on PRIVATE copies of the minibatch, taken on the calling stream: the caller's stream does not wait for
         # the lane, so a caller who refills the same device buffers for the next minibatch would otherwise overwrite them
@@ -875,10 +882,11 @@ class KronAccumulator:
         subs, self._lane_accs = self._lane_accs, None
         if not subs:
             return
-        dev = subs[0]._lane_stream.device
-        cur = torch.cuda.current_stream(dev)
+        on_device = subs[0]._lane_stream is not None
+        cur = torch.cuda.current_stream(subs[0]._lane_stream.device) if on_device else None
         for sub in subs:
-            cur.wait_stream(sub._lane_stream)
+            if on_device:
+                cur.wait_stream(sub._lane_stream)
         for sub in subs:
             if sub.factors is None:
                 continue
@@ -895,12 +903,13 @@ class KronAccumulator:
                 torch._foreach_add_(self._raw_tensors(), sub._raw_tensors())
             if sub._range_tab is not None:
                 self._range_full += list(sub._range_full) + [sub._range_tab[:sub._range_n]]
-            for t in sub._raw_tensors():  # allocated on the lane's stream, read (and from now on owned) here
-                t.record_stream(cur)
+            if on_device:
+                for t in sub._raw_tensors():  # allocated on the lane's stream, read (and from now on owned) here
+                    t.record_stream(cur)
 
     def add_batch(self, x, y):
         b = self.backend
-        if self.lanes > 1 and self.overlap and not self.defer_pix and torch.is_tensor(x) and x.is_cuda:
+        if self.lanes > 1 and self.overlap and not self.defer_pix and torch.is_tensor(x) and (x.is_cuda or self._lanes_anywhere):
             return self._lane_add_batch(x, y)
         mode = getattr(b, "range_guard", "check")
         if mode not in (False, "off") and torch.is_tensor(x) and x.is_floating_point() and x.dim() >= 2 and x.shape[0] > 1:

@@ -369,3 +369,53 @@ def test_general_avgpool_geometries_go_through_the_sweep(pool):
         grads = torch.autograd.grad(f2, [outs[n] for n in taps], grad_outputs=seeds[s], retain_graph=True)
         for n, g in zip(taps, grads):
             assert torch.allclose(got[n][s], g, atol=1e-12), n
+
+
+@pytest.mark.parametrize("lanes", [2, 3])
+def test_lanes_of_a_fit_sum_to_the_single_chain(lanes):
+    """KronAccumulator.lanes: consecutive minibatches go alternately to sub-accumulators (on the device: own streams) that are
+    folded when the fit is read.  Host logic on the kernel emulation: same loss / factors as one chain, for a ragged last
+    minibatch, deferred BatchNorm scales, pixel-pair accumulators in every lane, `tensors()` (the all-reduce's view) and
+    an accumulator that never saw a minibatch."""
+    from laplace_amd import HipGGN, _lib
+    from tests.emulated_kernels import EmulatedKernels
+
+    prev = _lib.set_kernels_for_testing(EmulatedKernels())
+    try:
+        torch.manual_seed(5)
+        model = nn.Sequential(
+            nn.Conv2d(3, 8, 3, padding=1, bias=False), nn.BatchNorm2d(8), nn.ReLU(), nn.Conv2d(8, 8, 3, padding=1), nn.Tanh(),
+            nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(8, 3)).eval()
+        with torch.no_grad():
+            model[1].weight.uniform_(0.5, 1.5), model[1].running_var.uniform_(0.5, 2.0)
+        for p_ in model[1].parameters():
+            p_.requires_grad_(False)
+        g = torch.Generator().manual_seed(9)
+        batches = [(torch.randn(b, 3, 6, 6, generator=g), torch.randint(3, (b,), generator=g)) for b in (4, 4, 4, 4, 3)]
+        b = HipGGN(model, "classification")
+
+        def fit(n_lanes, read):
+            acc = b.kron_accumulator(19)
+            acc.lanes, acc._lanes_anywhere, acc.pix_group = n_lanes, True, 2
+            for X, y in batches:
+                acc.add_batch(X, y)
+            if n_lanes > 1:
+                assert acc._lane_accs is not None and all(s.factors is not None for s in acc._lane_accs)
+            if read == "tensors":
+                ts = [t.clone() for t in acc.tensors()]
+                assert acc._lane_accs is None
+            loss, H = acc.finalize()
+            return loss, [t for F in H.kfacs for t in F]
+
+        loss1, want = fit(1, "finalize")
+        for read in ("finalize", "tensors"):
+            loss, got = fit(lanes, read)
+            assert torch.allclose(loss, loss1, rtol=1e-6)
+            for a, w in zip(got, want):
+                assert (a - w).abs().max() <= 1e-6 * w.abs().max() + 1e-12
+        empty = b.kron_accumulator(19)
+        empty.lanes, empty._lanes_anywhere = lanes, True
+        empty.ensure_allocated(torch.device("cpu"))
+        assert all(float(t.abs().max()) == 0.0 for t in empty.tensors())
+    finally:
+        _lib.set_kernels_for_testing(prev)
