@@ -615,6 +615,12 @@ class KronAccumulator:
     (kh, kw, ci) order; ``finalize`` mirrors / permutes ONCE and hands back an ordinary
     :class:`HipKron` (same values as the sum of per-batch ``kron()`` results; covered by
     tests/test_laplace_e2e.py and tests/test_gpu_backend.py).
+
+    Scheduling on the device (all of it invisible in the results beyond fp32 addition order): the A- and G-factor
+    kernels of a minibatch run on a side stream under its reverse sweep and may run on into the next minibatch
+    (``lag_join``); the banded pixel-pair products of 3x3 A factors are stacked over ``pix_group`` minibatches per launch;
+    consecutive minibatches alternate between ``lanes`` sub-accumulators with streams of their own, folded when the fit is
+    read.  ``overlap=False`` switches all of it off (the serial schedule the tests compare against).
     """
 
     def __init__(self, backend, N: int, kfac_approx: str = "expand", overlap: bool = True):
