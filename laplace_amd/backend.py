@@ -829,17 +829,46 @@ class KronAccumulator:
                 buf = torch.zeros(npix, npix, dtype=torch.float32, device=tap.a.device)
             self._pix[idx] = (geo, buf)
 
+    #: streams the per-tap work of `_flush_pixgrams` is dealt to (env LK_FLUSH_STREAMS; 1 = the calling stream only)
+    flush_streams = max(1, int(os.environ.get("LK_FLUSH_STREAMS", "3")))
+
     def _flush_pixgrams(self, only=None):
-        """fold the pixel-pair accumulators into the (native-order) A factors; idempotent"""
+        """fold the pixel-pair accumulators into the (native-order) A factors; idempotent.  The taps are independent of
+        each other and their kernels (the last partly filled group's products, the 81-block assembly) are small next to
+        the chip: with several of them to do they are dealt, largest first, to a few streams that the calling stream
+        joins at the end — this is once-per-fit work, but a 20-minibatch fit (the driver's bench) spends 5 % of its time
+        in it."""
         K = get_kernels()
         self._join_side()
-        for idx in ([only] if only is not None else list(self._pix)):
+        todo = [only] if only is not None else sorted(self._pix, key=lambda i: -self._pix[i][1].numel())
+
+        def one(idx):
             self._drain_pixpair(idx)
             geo, buf = self._pix.pop(idx)
             if geo[0] == "pair":
                 K.pixpair_assemble(buf, geo[4], geo[1], geo[2], geo[3], 1.0, self.factors[idx][1])
             else:
                 K.pixgram_assemble(buf, geo[1], geo[2], geo[3], 1.0, self.factors[idx][1])
+            return buf
+
+        dev = self.loss.device if self.loss is not None else None
+        if len(todo) < 3 or self.flush_streams < 2 or dev is None or dev.type != "cuda" or not self.overlap:
+            for idx in todo:
+                one(idx)
+            return
+        cache = self.backend.__dict__.setdefault("_flush_streams", {})
+        streams = cache.setdefault((dev, self.flush_streams), [torch.cuda.Stream(dev) for _ in range(self.flush_streams)])
+        cur = torch.cuda.current_stream(dev)
+        for st in streams:
+            st.wait_stream(cur)
+        for j, idx in enumerate(todo):
+            st = streams[j % len(streams)]
+            with torch.cuda.stream(st):
+                buf = one(idx)
+            buf.record_stream(st)  # (dropped here, still read by the assembly on `st`)
+            self.factors[idx][1].record_stream(st)
+        for st in streams:
+            cur.wait_stream(st)
 
     def _lane_add_batch(self, x, y):
         dev = x.device
