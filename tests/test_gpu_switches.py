@@ -92,6 +92,8 @@ CASES = {
     "overlap=False": dict(acc_attrs={"overlap": False}),
     "LK_LANES=1": dict(acc_attrs={"lanes": 1}),
     "LK_LANES=3": dict(acc_attrs={"lanes": 3}),
+    "LK_FLUSH_STREAMS=1": dict(acc_attrs={"flush_streams": 1}),
+    "LK_FLUSH_STREAMS=5": dict(acc_attrs={"flush_streams": 5}),
     "LK_FUSE_VJP=0": dict(sweep_attrs={"fuse_vjp": False}),
     "LK_NHWC_FORWARD=0": dict(sweep_attrs={"nhwc_forward": False}),
     "LK_PIXPAIR16=0": dict(kernel_attrs={"use_pixpair16": False}),
