@@ -128,6 +128,10 @@ int lk_conv3x3_pixpair_accumulate_f32(const float* x, int64_t B, int64_t H, int6
                                       float* blocks, const int32_t* tiles_dev, int64_t n_tiles, void* stream);
 int lk_conv3x3_pixpair_assemble_f32(const float* blocks, const int32_t* slots_dev, int64_t H, int64_t W, int64_t Cin,
                                     float alpha, float* A, void* stream);
+/* _assemble of blocks + blocks2 (blocks2 optional): the accumulators of the two lanes of a fit with two minibatches in
+ * flight are summed on the fly, element by element, in the same order as a separate addition would. */
+int lk_conv3x3_pixpair_assemble2_f32(const float* blocks, const float* blocks2, const int32_t* slots_dev, int64_t H, int64_t W,
+                                     int64_t Cin, float alpha, float* A, void* stream);
 /* _accumulate on a split tensor (csrc/lk_sweep16.hip): x as two fp16 planes with one power-of-two scale (lk_split_f16x2 of
  * the NHWC images), three fp16 MFMAs per fp32 product block instead of the exact-fp32 MFMA; same tables, same blocks. */
 int lk_conv3x3_pixpair_accumulate_f16x2(const void* x_h, const void* x_l, const int* sexp, int64_t B, int64_t H, int64_t W,
@@ -153,6 +157,16 @@ int lk_symmetrize_f32(float* C, int64_t n, void* stream);
 /* dst[(ci*KK+d), (cj*KK+e)] (+)= src[(d*Cin+ci), (e*Cin+cj)]  — native (kh,kw,ci) -> unfold (ci,kh,kw)
  * order.  accumulate != 0 adds into dst. */
 int lk_permute_sym_f32(const float* src, int64_t Cin, int64_t KK, float* dst, int accumulate, void* stream);
+
+/* The once-per-fit layout pass of `count` factors in ONE launch (what CurvlinopsInterface.kron does per minibatch with
+ * torch ops on the library's factors, laplace/curvature/curvlinops.py:55-75; here once, on the accumulated sums).
+ * Host arrays of length count.  Factor i is n[i] x n[i], upper triangle valid:
+ *   kk[i] <= 1: mirrored (in place if dst[i] == NULL), with C[r][c] *= scale[i][r] * scale[i][c] first when scale[i] is
+ *               given (the deferred BatchNorm scale of a G factor: diag(s) G diag(s));
+ *   kk[i]  > 1: dst[i] = the full matrix in F.unfold's (ci, kh, kw) order from src[i] in the kernels' (kh, kw, ci) order
+ *               (n = cin * kk, dst != src, no scale) -- lk_symmetrize_f32 + lk_permute_sym_f32 in one pass. */
+int lk_finalize_factors_f32(int64_t count, const float* const* src, float* const* dst, const float* const* scale,
+                            const int64_t* n, const int64_t* cin, const int64_t* kk, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Convolution of the seed-batched reverse sweep (csrc/lk_conv.hip): implicit GEMM on NHWC tensors, fp32-level

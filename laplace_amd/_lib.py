@@ -57,6 +57,7 @@ SIGNATURES = {
     "lk_conv3x3_pixpair_accumulate_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _f32, _vp, _vp, _i64, _vp]),
     "lk_conv3x3_pixpair_accumulate_f16x2": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp, _vp, _i64, _vp, _vp]),
     "lk_conv3x3_pixpair_assemble_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _f32, _vp, _vp]),
+    "lk_conv3x3_pixpair_assemble2_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _f32, _vp, _vp]),
     "lk_nchw_to_nhwc_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "lk_absmax_f32": (_int, [_vp, _i64, _vp, _i64, _i64, _vp, _vp]),
     "lk_range_words_f32": (_int, [_vp, _i64, _i64, _vp, _vp]),
@@ -84,6 +85,7 @@ SIGNATURES = {
     "lk_unpack_upper_f32": (_int, [_vp, _i64, _vp, _vp]),
     "lk_symmetrize_f32": (_int, [_vp, _i64, _vp]),
     "lk_permute_sym_f32": (_int, [_vp, _i64, _i64, _vp, _int, _vp]),
+    "lk_finalize_factors_f32": (_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "lk_diag_ggn_linear_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp, _vp, _vp]),
     "lk_jac_linear_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp]),
     "lk_jac_conv_f32": (
@@ -767,11 +769,16 @@ class HipKernels:
                  "lk_conv3x3_pixpair_accumulate_f16x2")
         return blocks
 
-    def pixpair_assemble(self, blocks, plan, H, W, Cin, alpha, A_native):
+    def pixpair_assemble(self, blocks, plan, H, W, Cin, alpha, A_native, blocks2=None):
+        """``A_native += alpha * assemble(blocks [+ blocks2])``: ``blocks2`` is a second accumulator set of the same geometry
+        (the other lane of a fit), summed on the fly"""
         _check(blocks, "blocks"), _check(A_native, "A")
-        self._rc(self.lib.lk_conv3x3_pixpair_assemble_f32(_ptr(blocks), ctypes.c_void_p(plan[2].data_ptr()), int(H), int(W),
-                                                          int(Cin), float(alpha), _ptr(A_native),
-                                                          self._stream(blocks.device)), "lk_conv3x3_pixpair_assemble_f32")
+        if blocks2 is not None:
+            _check(blocks2, "blocks2")
+            assert blocks2.numel() == blocks.numel()
+        self._rc(self.lib.lk_conv3x3_pixpair_assemble2_f32(_ptr(blocks), _ptr(blocks2), ctypes.c_void_p(plan[2].data_ptr()),
+                                                           int(H), int(W), int(Cin), float(alpha), _ptr(A_native),
+                                                           self._stream(blocks.device)), "lk_conv3x3_pixpair_assemble2_f32")
         return A_native
 
     def permute_native_to_unfold(self, src, Cin, KK, dst, accumulate=False):
@@ -779,6 +786,37 @@ class HipKernels:
         self._rc(self.lib.lk_permute_sym_f32(_ptr(src), Cin, KK, _ptr(dst), 1 if accumulate else 0, self._stream(src.device)),
                  "lk_permute_sym_f32")
         return dst
+
+    def finalize_factors(self, items):
+        """The once-per-fit layout pass of many factors in one launch.  ``items``: ``(src, dst, scale, cin, kk)`` per
+        factor — ``kk <= 1``: mirror the upper triangle (in place when ``dst`` is None), after ``diag(scale) C diag(scale)``
+        when ``scale`` is given; ``kk > 1``: ``dst`` = the full matrix in unfold order from the native-order upper triangle
+        of ``src`` (what :meth:`symmetrize` + :meth:`permute_native_to_unfold` do with two launches per factor)."""
+        items = [it for it in items if it[0].numel()]
+        if not items:
+            return
+        n = len(items)
+        dev = items[0][0].device
+        src = (ctypes.c_void_p * n)()
+        dst = (ctypes.c_void_p * n)()
+        scl = (ctypes.c_void_p * n)()
+        ns = (ctypes.c_int64 * n)()
+        cins = (ctypes.c_int64 * n)()
+        kks = (ctypes.c_int64 * n)()
+        for i, (s_, d_, sc_, cin, kk) in enumerate(items):
+            _check(s_, "src")
+            assert s_.dim() == 2 and s_.shape[0] == s_.shape[1] and s_.device == dev
+            src[i] = s_.data_ptr()
+            if d_ is not None:
+                _check(d_, "dst")
+                assert d_.shape == s_.shape
+                dst[i] = d_.data_ptr()
+            if sc_ is not None:
+                _check(sc_, "scale")
+                assert sc_.numel() == s_.shape[0]
+                scl[i] = sc_.data_ptr()
+            ns[i], cins[i], kks[i] = s_.shape[0], int(cin), int(kk)
+        self._rc(self.lib.lk_finalize_factors_f32(n, src, dst, scl, ns, cins, kks, self._stream(dev)), "lk_finalize_factors_f32")
 
     def symmetrize(self, C):
         _check(C, "C")

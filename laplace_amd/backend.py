@@ -138,8 +138,12 @@ def range_groups(x, max_log2: int = RANGE_GUARD_LOG2):
     sums over the minibatch.  Costs one [B]-float read-back per call."""
     if not torch.is_tensor(x) or not x.is_floating_point() or x.dim() < 2 or x.shape[0] < 2:
         return None
-    amax = x.detach().abs().reshape(x.shape[0], -1).amax(1).float()
-    e = torch.floor(torch.log2(amax.clamp_min(1e-38))).cpu()
+    amax = x.detach().abs().reshape(x.shape[0], -1).amax(1).float().cpu()
+    nz = amax > 0
+    if not bool(nz.any()):
+        return None
+    e = torch.floor(torch.log2(amax.clamp_min(1e-38)))
+    e = torch.where(nz, e, e[nz].max())  # an all-zero sample is exact under any scale: it joins the largest group
     if float(e.max() - e.min()) <= max_log2:
         return None
     order = torch.argsort(e)
@@ -181,6 +185,15 @@ class _HipCurvatureMixin:
             tape = Tape(self._model, self.params)
             self._tape_cache = tape
         return tape
+
+    def _split_sweep_state(self):
+        """Does the split-fp16 NHWC sweep (one power-of-two scale per tensor) serve this model's minibatches?  ``True`` /
+        ``False`` once a forward pass has built the sweep, ``None`` before that."""
+        tape = getattr(self, "_tape_cache", None)
+        sweep = getattr(tape, "sweep", None) if tape is not None else None
+        if sweep is None:
+            return None
+        return bool(isinstance(sweep, SplitSweep) and sweep.split_reason is None)
 
     def _check_dtype(self, f: torch.Tensor):
         if f.dtype != torch.float32:
@@ -605,6 +618,13 @@ class _HipCurvatureMixin:
         return K.gram_tn(Z2, alpha, H)
 
 
+class CurvatureExchange(list):
+    """What `KronAccumulator.tensors` hands to `allreduce_curvature`: the tensors of the exchange, plus the accumulator
+    whose range verdict (`_range_msg`) must be agreed on by all ranks before anybody raises."""
+
+    owner = None
+
+
 class KronAccumulator:
     """Running KFAC factors of one ``fit`` kept in the kernels' own form.
 
@@ -653,10 +673,17 @@ class KronAccumulator:
         self.lanes = max(1, int(os.environ.get("LK_LANES", "2")))
         self._lane_accs, self._lane_next, self._lane_id, self._lane_stream = None, 0, 0, None
         self._lane_sig = None
+        self._range_msg = None  # verdict of `_range_verdict` a data-parallel fit carries through its all-reduce
+        self._a_done = None  # event on the side stream behind the A-side work of the latest minibatch
         self._lanes_anywhere = False  # (tests: the lanes' host logic on the CPU emulation of the kernels, without streams)
 
     def _alloc(self, tape, dev):
+        """Zeroed factors of every tap, carved out of TWO flat buffers (one fill each instead of one per factor — a fit
+        starts with ~90 fewer launches per lane): the factors that keep their storage when the fit is read (G, Linear A,
+        1x1-conv A) and the conv A factors in the kernels' native column order, whose storage is dropped by `finalize`
+        (it writes the permuted copies)."""
         self.factors, self._taps_meta = [], []
+        shapes = []
         for tap in tape.taps:
             m = tap.module
             if tap.kind == "linear":
@@ -665,10 +692,25 @@ class KronAccumulator:
             else:
                 do, di = m.out_channels, m.in_channels * m.kernel_size[0] * m.kernel_size[1]
                 native = (m.in_channels, m.kernel_size[0] * m.kernel_size[1])
-            self.factors.append([torch.zeros(do, do, dtype=torch.float32, device=dev),
-                                 torch.zeros(di, di, dtype=torch.float32, device=dev)])
+            shapes.append((do, di, native is not None and native[1] > 1))
             self._taps_meta.append((tap.has_bias, native))
-        self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        pad = lambda n: (n + 63) // 64 * 64  # (256-byte aligned factors)
+        kept = sum(pad(do * do) + (0 if nat else pad(di * di)) for do, di, nat in shapes) + 64
+        natv = sum(pad(di * di) for do, di, nat in shapes if nat)
+        flat_k = torch.zeros(kept, dtype=torch.float32, device=dev)
+        flat_n = torch.zeros(natv, dtype=torch.float32, device=dev) if natv else None
+        ok, on = 0, 0
+        for do, di, nat in shapes:
+            G = flat_k[ok:ok + do * do].view(do, do)
+            ok += pad(do * do)
+            if nat:
+                A = flat_n[on:on + di * di].view(di, di)
+                on += pad(di * di)
+            else:
+                A = flat_k[ok:ok + di * di].view(di, di)
+                ok += pad(di * di)
+            self.factors.append([G, A])
+        self.loss = flat_k[ok:ok + 1]
         self._pix = {}  # tap index -> (geometry, buffer): pixel-pair accumulators of 3x3 convs
         self._pix_pending = {}  # tap index -> minibatches stacked for the next pixel-pair launch
         self._gscale = {}  # tap index -> deferred BatchNorm scale owed to the G accumulator
@@ -812,7 +854,9 @@ class KronAccumulator:
             del self._pix_pending[idx]
 
     def _ensure_pixgrams(self, tape):
-        """allocate the pixel-pair accumulators on the CALLING stream (they are consumed there at the end of the fit)"""
+        """allocate the pixel-pair accumulators on the CALLING stream (they are consumed there at the end of the fit); the
+        first minibatch of a fit carves all of them out of one zeroed buffer (one fill instead of one per layer)"""
+        todo = []
         for idx, tap in enumerate(tape.taps):
             if idx in self._pix:
                 old = self._pix[idx][0]
@@ -823,11 +867,19 @@ class KronAccumulator:
             if geo is None:
                 continue
             if geo[0] == "pair":
-                buf = torch.zeros(geo[4][0] * geo[3] * geo[3], dtype=torch.float32, device=tap.a.device)
+                todo.append((idx, geo, (geo[4][0] * geo[3] * geo[3],), tap.a.device))
             else:
                 npix = geo[1] * geo[2] * geo[3]
-                buf = torch.zeros(npix, npix, dtype=torch.float32, device=tap.a.device)
-            self._pix[idx] = (geo, buf)
+                todo.append((idx, geo, (npix, npix), tap.a.device))
+        if not todo:
+            return
+        pad = lambda n: (n + 63) // 64 * 64
+        numel = [math.prod(shape) for _, _, shape, _ in todo]
+        flat = torch.zeros(sum(pad(n) for n in numel), dtype=torch.float32, device=todo[0][3])
+        off = 0
+        for (idx, geo, shape, _), n in zip(todo, numel):
+            self._pix[idx] = (geo, flat[off:off + n].view(shape))
+            off += pad(n)
 
     #: streams the per-tap work of `_flush_pixgrams` is dealt to (env LK_FLUSH_STREAMS; 1 = the calling stream only)
     flush_streams = max(1, int(os.environ.get("LK_FLUSH_STREAMS", "3")))
@@ -924,43 +976,108 @@ class KronAccumulator:
         ts = list(m.parameters()) + list(m.buffers())
         return (tuple((t.data_ptr(), t._version) for t in ts), tuple(x.shape[1:]), x.dtype, x.device)
 
+    #: ``False`` (env LK_EARLY_FLUSH=0): the A-side work of reading a fit waits for the lanes' reverse sweeps
+    early_flush = os.environ.get("LK_EARLY_FLUSH", "1") != "0"
+
     def _fold_lanes(self):
-        """bring the lanes' partial sums together on the calling stream (before anything reads the accumulated state)"""
+        """bring the lanes' partial sums together on the calling stream (before anything reads the accumulated state).
+
+        What reading a fit costs besides its minibatches matters for short fits (the driver's bench is 20 minibatches: round
+        3 spent 10 ms here, half a minibatch per step).  The A side — the last, partly filled pixel-pair groups and the
+        81-block assembly of every 3x3 layer — depends only on the FORWARD passes, so it is dealt to the flush streams
+        behind the event at the end of each lane's latest A-side work and runs UNDER the reverse sweeps that are still in
+        flight; the lanes' blocks are summed inside the assembly (`blocks2`) instead of by a pass of their own.  Only the G
+        side (one multi-tensor add) waits for the sweeps."""
         subs, self._lane_accs = self._lane_accs, None
         if not subs:
             return
         if self._lane_sig is not None and any(sub.factors is not None for sub in subs):
             self.backend.__dict__["_lanes_warm"] = self._lane_sig  # (the calling stream waits for the lanes just below)
+        K = get_kernels()
         on_device = subs[0]._lane_stream is not None
-        cur = torch.cuda.current_stream(subs[0]._lane_stream.device) if on_device else None
-        for sub in subs:
-            if on_device:
-                cur.wait_stream(sub._lane_stream)
+        dev = subs[0]._lane_stream.device if on_device else None
+        cur = torch.cuda.current_stream(dev) if on_device else None
         live = [sub for sub in subs if sub.factors is not None]
-        for sub in live:
-            sub._join_side()
+        early = (on_device and self.overlap and self.early_flush and bool(live) and all(sub._a_done is not None for sub in live)
+                 and any(sub._pix for sub in live))
+        fstreams = None
+        if early:
+            cache = self.backend.__dict__.setdefault("_flush_streams", {})
+            nfs = max(self.flush_streams, 1)
+            fstreams = cache.setdefault((dev, nfs), [torch.cuda.Stream(dev) for _ in range(nfs)])
+            for st in fstreams:
+                st.wait_stream(cur)
+                for sub in live:
+                    st.wait_event(sub._a_done)
+        else:
+            for sub in subs:
+                if on_device:
+                    cur.wait_stream(sub._lane_stream)
+            for sub in live:
+                sub._join_side()
         # Pixel-pair state first: the lanes' blocks (and what is still stacked for their next launch) are brought together
         # in the first lane, so that the 81-block assembly — the expensive part of reading a fit — runs ONCE, not per lane
         # (a 20-minibatch fit spent 18 ms here with two lanes against 8.5 ms with one).
-        for sub in live[1:]:
+        merged = set()  # taps whose A factor is assembled into the first lane's (the other lanes' stay zero)
+        if live:
             base = live[0]
-            for idx, (geo, buf) in list(sub._pix.items()):
-                mine = base._pix.get(idx)
-                if mine is None or mine[0][:4] != geo[:4] or (geo[0] == "pair" and mine[0][4] is not geo[4]):
-                    continue  # (different geometry: this lane assembles its own)
-                pend = sub._pix_pending.pop(idx, None)
-                if pend is not None and pend["n"]:
-                    bp = base._pix_pending.get(idx)
-                    B = pend["B"]
-                    if (bp is not None and bp["B"] == B and bp["alpha"] == pend["alpha"]
-                            and bp["n"] + pend["n"] <= bp["stack"].shape[0] // B):
-                        bp["stack"][bp["n"] * B:(bp["n"] + pend["n"]) * B].copy_(pend["stack"][:pend["n"] * B])
-                        bp["n"] += pend["n"]
-                    else:
-                        sub._pix_pending[idx] = pend
-                        sub._drain_pixpair(idx)
-                mine[1].add_(buf)
-                del sub._pix[idx]
+
+            def one(idx, st):
+                geo, buf = base._pix[idx]
+                others = []
+                for sub in live[1:]:
+                    o = sub._pix.get(idx)
+                    if o is None or o[0][:4] != geo[:4] or (geo[0] == "pair" and o[0][4] is not geo[4]):
+                        continue  # (different geometry: this lane assembles its own)
+                    pend = sub._pix_pending.pop(idx, None)
+                    if pend is not None and pend["n"]:
+                        bp = base._pix_pending.get(idx)
+                        B = pend["B"]
+                        if (bp is not None and bp["B"] == B and bp["alpha"] == pend["alpha"]
+                                and bp["n"] + pend["n"] <= bp["stack"].shape[0] // B):
+                            bp["stack"][bp["n"] * B:(bp["n"] + pend["n"]) * B].copy_(pend["stack"][:pend["n"] * B])
+                            bp["n"] += pend["n"]
+                            if st is not None:
+                                pend["stack"].record_stream(st)
+                        else:
+                            sub._pix_pending[idx] = pend
+                            sub._drain_pixpair(idx)
+                    others.append(o[1])
+                    del sub._pix[idx]
+                if not others:
+                    return False
+                base._drain_pixpair(idx)
+                del base._pix[idx]
+                A = base.factors[idx][1]
+                for o in others[1:]:
+                    buf.add_(o)
+                if geo[0] == "pair":
+                    K.pixpair_assemble(buf, geo[4], geo[1], geo[2], geo[3], 1.0, A, blocks2=others[0])
+                else:
+                    buf.add_(others[0])
+                    K.pixgram_assemble(buf, geo[1], geo[2], geo[3], 1.0, A)
+                if st is not None:
+                    for t in [buf, A] + others:  # allocated on a lane's stream, read here
+                        t.record_stream(st)
+                return True
+
+            todo = sorted(base._pix, key=lambda i: -base._pix[i][1].numel())
+            for j, idx in enumerate(todo):
+                if fstreams is not None:
+                    st = fstreams[j % len(fstreams)]
+                    with torch.cuda.stream(st):
+                        if one(idx, st):
+                            merged.add(idx)
+                elif one(idx, None):
+                    merged.add(idx)
+        if early:
+            for sub in subs:
+                cur.wait_stream(sub._lane_stream)
+            for sub in live:
+                sub._join_side()
+            for st in fstreams:
+                cur.wait_stream(st)
+        first = True
         for sub in subs:
             if sub.factors is None:
                 continue
@@ -973,9 +1090,13 @@ class KronAccumulator:
             else:
                 if set(self._gscale) != set(sub._gscale):
                     raise RuntimeError("the lanes of a fit disagree about the deferred BatchNorm scales")
-                torch._foreach_add_(self._raw_tensors(), sub._raw_tensors())
-            if sub._range_tab is not None:
-                self._range_full += list(sub._range_full) + [sub._range_tab[:sub._range_n]]
+                skip = merged if not first else set()  # (those A factors were never written in the other lanes: zeros)
+                mine = [t for i, F in enumerate(self.factors) for j, t in enumerate(F) if not (j == 1 and i in skip)] + [self.loss]
+                theirs = [t for i, F in enumerate(sub.factors) for j, t in enumerate(F) if not (j == 1 and i in skip)] + [sub.loss]
+                torch._foreach_add_(mine, theirs)
+            first = False
+            if sub._range_tab is not None or sub._range_full:
+                self._range_full += list(sub._range_full) + ([sub._range_tab[:sub._range_n]] if sub._range_tab is not None else [])
             if on_device:
                 for t in sub._raw_tensors():  # allocated on the lane's stream, read (and from now on owned) here
                     t.record_stream(cur)
@@ -985,15 +1106,17 @@ class KronAccumulator:
         if self.lanes > 1 and self.overlap and not self.defer_pix and torch.is_tensor(x) and (x.is_cuda or self._lanes_anywhere):
             return self._lane_add_batch(x, y)
         mode = getattr(b, "range_guard", "check")
-        if mode not in (False, "off") and torch.is_tensor(x) and x.is_floating_point() and x.dim() >= 2 and x.shape[0] > 1:
-            if mode == "group":
-                groups = range_groups(x)  # (one read-back; the sum over samples is additive, so sub-minibatches are exact)
-                if groups is not None:
-                    for idx in groups:
-                        self._add_batch(x.index_select(0, idx).contiguous(), y.index_select(0, idx).contiguous())
-                    return
-            elif x.dtype == torch.float32 and x.is_contiguous():
-                self._note_range(x)
+        # The guard concerns the split-fp16 NHWC sweep only (one scale per tensor): a model that runs through the NCHW sweep
+        # or the autograd tape computes per element in fp32 like the reference and takes any data (a 1-D regression set
+        # with one sample near zero used to raise here).  Before the first forward of a model the path is not known yet:
+        # `_add_batch` records the range once it is (mode "check"); mode "group" then groups to be safe.
+        if (mode == "group" and b._split_sweep_state() is not False and torch.is_tensor(x) and x.is_floating_point()
+                and x.dim() >= 2 and x.shape[0] > 1):
+            groups = range_groups(x)  # (one read-back; the sum over samples is additive, so sub-minibatches are exact)
+            if groups is not None:
+                for idx in groups:
+                    self._add_batch(x.index_select(0, idx).contiguous(), y.index_select(0, idx).contiguous())
+                return
         self._add_batch(x, y)
 
     def _note_range(self, x):
@@ -1010,25 +1133,35 @@ class KronAccumulator:
         get_kernels().range_words(x, self._range_tab[self._range_n])
         self._range_n += 1
 
-    def _check_range(self):
+    def _range_verdict(self):
+        """read (and clear) the recorded per-minibatch magnitude spreads: ``None`` or what is wrong with them"""
         tabs = list(self._range_full) + ([self._range_tab[:self._range_n]] if self._range_tab is not None else [])
         self._range_tab, self._range_n, self._range_full = None, 0, []
         if not tabs:
-            return
+            return None
         w = torch.cat(tabs).cpu().view(torch.float32)
         bad = (w[:, 0] > 0) & (w[:, 0] > w[:, 1] * float(2 ** RANGE_GUARD_LOG2))
-        if bool(bad.any()):
-            i = int(bad.nonzero()[0])
-            raise RuntimeError(
-                f"minibatch {i} of this fit mixes samples whose input magnitudes differ by "
+        if not bool(bad.any()):
+            return None
+        i = int(bad.nonzero()[0])
+        return (f"minibatch {i} of this fit mixes samples whose input magnitudes differ by "
                 f"{float(w[i, 0] / w[i, 1]):.1e} (max|x_n| from {float(w[i, 1]):.1e} to {float(w[i, 0]):.1e}): beyond the "
                 f"2^{RANGE_GUARD_LOG2} the split-fp16 sweep resolves per sample with one scale per tensor. Set "
                 "`backend.range_guard = 'group'` (such minibatches are then swept in magnitude groups; exact), normalise "
                 "the inputs, or `'off'` to accept reduced accuracy of the small-magnitude samples.")
 
+    def _check_range(self):
+        msg = self._range_verdict() or self._range_msg
+        self._range_msg = None
+        if msg:
+            raise RuntimeError(msg)
+
     def _add_batch(self, x, y):
         b = self.backend
         f, tape, grad_fn = b._forward(x)
+        if (getattr(b, "range_guard", "check") == "check" and b._split_sweep_state() is True and torch.is_tensor(x)
+                and x.dtype == torch.float32 and x.dim() >= 2 and x.shape[0] > 1 and x.is_contiguous()):
+            self._note_range(x)  # (only minibatches the split-fp16 sweep serves)
         if tape.uncovered:
             raise NotImplementedError("KFAC supports nn.Linear / nn.Conv2d parameters only")
         if self.factors is None:
@@ -1052,6 +1185,10 @@ class KronAccumulator:
             with torch.cuda.stream(side):
                 for i, (tap, F) in enumerate(zip(tape.taps, self.factors)):
                     self._accumulate_A(i, tap, F, rt)
+            # everything the A factors of this fit need from this minibatch has been enqueued: whoever reads the fit
+            # (`_fold_lanes`) starts the A-side flush behind THIS event, under the reverse sweep that is still to come
+            self._a_done = torch.cuda.Event()
+            self._a_done.record(side)
         else:
             for i, (tap, F) in enumerate(zip(tape.taps, self.factors)):
                 self._accumulate_A(i, tap, F, rt)
@@ -1201,8 +1338,9 @@ class KronAccumulator:
             self._side_done = torch.cuda.Event()
             self._side_done.record(side)
         # (the merged minibatches' magnitude records come along: checked when the sum is finalised)
+        self._range_full += list(other._range_full)
         if other._range_tab is not None:
-            self._range_full += list(other._range_full) + [other._range_tab[:other._range_n]]
+            self._range_full.append(other._range_tab[:other._range_n])
         return True
 
     def _join_side(self):
@@ -1244,12 +1382,17 @@ class KronAccumulator:
         scales are applied HERE, before the exchange: ``diag(s) G diag(s)`` is linear in G, so scaled factors add
         exactly, and a rank with an empty shard — which never learned a scale and contributes zeros — needs none."""
         self._fold_lanes()
-        self._check_range()
+        # The range verdict of THIS rank's shard must not be raised here: the other ranks would enter the all-reduce and
+        # hang until the collective times out.  It travels with the exchange (one flag word, `allreduce_curvature`) and
+        # every rank raises after the collective; without a process group `allreduce_curvature` / `finalize` raise it.
+        self._range_msg = self._range_verdict() or self._range_msg
         self._resolve_pix_inputs()
         self._flush_pixgrams()  # the assembled factors are what is exchanged, not the larger pixel-pair Grams
         self._flush_g_slabs()
         self._apply_grad_scales()
-        return [t for F in self.factors for t in F] + [self.loss]
+        out = CurvatureExchange([t for F in self.factors for t in F] + [self.loss])
+        out.owner = self
+        return out
 
     def finalize(self):
         """-> (loss, HipKron) in the reference's layout (laplace/curvature/curvlinops.py:55-75)."""
@@ -1260,13 +1403,27 @@ class KronAccumulator:
         self._resolve_pix_inputs()
         self._flush_pixgrams()
         self._flush_g_slabs()
-        self._apply_grad_scales()
-        kfacs = []
-        for (G, A), (has_bias, native) in zip(self.factors, self._taps_meta):
-            K.symmetrize(G)
-            K.symmetrize(A)
+        self._join_side()
+        # ONE launch for the layout pass of every factor: mirror the upper triangles, bring the conv A factors from the
+        # kernels' (kh, kw, ci) column order into F.unfold's, apply the deferred BatchNorm scales diag(s) G diag(s)
+        # (round 3: two or three small launches per factor, 1.7 ms of launch gaps at the end of every fit)
+        items, done = [], []
+        for idx, ((G, A), (has_bias, native)) in enumerate(zip(self.factors, self._taps_meta)):
+            s_ = self._gscale.get(idx)
+            if s_ is not None:
+                s_ = s_.detach().to(torch.float32).reshape(-1).contiguous()
+            items.append((G, None, s_, 0, 1))
             if native is not None and native[1] > 1:
-                A = K.permute_native_to_unfold(A, native[0], native[1], torch.empty_like(A))
+                A_out = torch.empty_like(A)
+                items.append((A, A_out, None, native[0], native[1]))
+                A = A_out
+            else:
+                items.append((A, None, None, 0, 1))
+            done.append((G, A, has_bias))
+        K.finalize_factors(items)
+        self._gscale = {}
+        kfacs = []
+        for G, A, has_bias in done:
             if G.numel() == 1 and A.numel() == 1 and not has_bias:
                 kfacs.append([G * A])
             else:
@@ -1368,7 +1525,7 @@ class HipGGN(_HipCurvatureMixin, GGNInterface):
             eye = torch.eye(C, dtype=f.dtype, device=f.device)
             return eye[:, None, :].expand(C, B, C).contiguous()
 
-        groups = range_groups(x) if self.range_guard not in (False, "off") else None
+        groups = range_groups(x) if self.range_guard not in (False, "off") and self._split_sweep_state() is not False else None
         if groups is None:
             Js, f = self._rows(x, seeds_fn)
         else:  # per-sample results: a minibatch of very different magnitudes is swept in magnitude groups (range_groups)

@@ -965,13 +965,22 @@ static const signed char kHalfDx[13] = {0, 1, 2, -2, -1, 0, 1, 2, -2, -1, 0, 1, 
 
 // One thread per (shift h, ci, cj): every block element is read exactly once; up to nine (d, e) patch-offset pairs
 // share the shift D = e - d and differ only in which pixels q = p + d they may use (p itself must be in the map).
-__global__ __launch_bounds__(256) void pixpair_assemble_kernel(const float* __restrict__ blocks,
-                                                               const int* __restrict__ slots, int H, int W, int Cin,
-                                                               float alpha, float* __restrict__ A) {
+// `blocks2` (optional): a second set of accumulators of the same geometry (the other lane of a fit with two minibatches
+// in flight) — the element-wise sum of the two is what is assembled, so the lanes' blocks never need a pass of their own.
+// The loop over the map's pixels is a chain of dependent additions per thread; eight block elements are requested ahead
+// of it (the slot table and every condition are uniform over the 64-thread workgroup: Cin % 64 == 0), and the grid is
+// one wave per 64 (ci, cj) pairs so that a 64-channel layer (53 k threads) still reaches every CU.  Round 3's form — 256
+// threads, one load in flight per thread — took 0.9-1.2 ms on the 32 x 32 maps of ResNet-18, latency-bound at 0.2 TB/s.
+__global__ __launch_bounds__(64) void pixpair_assemble_kernel(const float* __restrict__ blocks,
+                                                              const float* __restrict__ blocks2,
+                                                              const int* __restrict__ slots, int H, int W, int Cin,
+                                                              float alpha, float* __restrict__ A) {
   const int n = 9 * Cin;
   const int64_t bsz = (int64_t)Cin * Cin;
   const int64_t total = 13 * bsz;
-  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+  const int HW = H * W;
+  constexpr int U = 8;
+  for (int64_t idx = (int64_t)blockIdx.x * 64 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 64) {
     const int h = (int)(idx / bsz);
     const int64_t inner = idx - (int64_t)h * bsz;
     const int ci = (int)(inner / Cin), cj = (int)(inner - (int64_t)ci * Cin);
@@ -985,11 +994,26 @@ __global__ __launch_bounds__(256) void pixpair_assemble_kernel(const float* __re
     for (int a = 0; a < 3; ++a)
 #pragma unroll
       for (int b = 0; b < 3; ++b) acc[a][b] = 0.f;
-    for (int qy = 0; qy < H; ++qy)
-      for (int qx = 0; qx < W; ++qx) {
-        const int slot = slots[(qy * W + qx) * 13 + h];
-        if (slot < 0) continue;
-        const float v = blocks[(int64_t)slot * bsz + inner];
+    int qy0 = 0, qx0 = 0;  // pixel q0 (tracked incrementally: no division in the loop)
+    for (int q0 = 0; q0 < HW; q0 += U) {
+      float v[U];
+      bool have[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int q = q0 + u;
+        const int slot = q < HW ? slots[q * 13 + h] : -1;
+        have[u] = slot >= 0;
+        v[u] = 0.f;
+        if (have[u]) {
+          v[u] = blocks[(int64_t)slot * bsz + inner];
+          if (blocks2) v[u] += blocks2[(int64_t)slot * bsz + inner];
+        }
+      }
+      int qy = qy0, qx = qx0;
+#pragma unroll
+      for (int u = 0; u < U; ++u, ++qx) {
+        if (qx == W) qx = 0, ++qy;
+        if (!have[u]) continue;
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -997,9 +1021,12 @@ __global__ __launch_bounds__(256) void pixpair_assemble_kernel(const float* __re
             const int dy = a - 1, dx = b - 1;  // p = q - d has to be a pixel of the map
             if (dy >= dy_lo && dy <= dy_hi && dx >= dx_lo && dx <= dx_hi && qy - dy >= 0 && qy - dy < H && qx - dx >= 0 &&
                 qx - dx < W)
-              acc[a][b] += v;
+              acc[a][b] += v[u];
           }
       }
+      if (qx == W) qx = 0, ++qy;
+      qy0 = qy, qx0 = qx;
+    }
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -1081,6 +1108,78 @@ __global__ __launch_bounds__(256) void permute_sym_kernel(const float* __restric
     const int cj = c / KK, e = c - cj * KK;
     const float v = src[(int64_t)(d * Cin + ci) * n + (e * Cin + cj)];
     dst[idx] = accumulate ? dst[idx] + v : v;
+  }
+}
+
+// ---- the once-per-fit layout pass of ALL factors in one launch ----------------------------------------------------------
+// What `KronAccumulator.finalize` did with ~110 small launches (symmetrise every factor, permute every conv A factor from
+// the kernels' (kh, kw, ci) column order to F.unfold's (ci, kh, kw), apply the deferred BatchNorm scales to the G factors):
+// 1.7 ms of a 20-minibatch fit, all of it launch gaps.  Per factor (descriptor):
+//   kk <= 1:  in place,  C[r][c] = C[c][r] = s[r] s[c] C[r][c]  for r <= c        (s optional)
+//   kk  > 1:  dst[(ci,d)][(cj,e)] = src_upper[(d,ci)][(e,cj)]                     (src: upper triangle valid; dst != src)
+struct FinDesc {
+  const float* src;
+  float* dst;
+  const float* scale;
+  int n, cin, kk, blk0;  // blk0: first workgroup of this factor
+};
+constexpr int FIN_MAX = 48;
+struct FinBatch {
+  int count, nblk;
+  FinDesc d[FIN_MAX];
+};
+constexpr int FIN_PERM_ELEMS = 4096;  // elements of dst per workgroup (kk > 1)
+
+__global__ __launch_bounds__(256) void finalize_factors_kernel(const FinBatch fb) {
+  __shared__ float tile[64][65];
+  int k = 0;
+  for (int i = 1; i < fb.count; ++i)
+    if ((int)blockIdx.x >= fb.d[i].blk0) k = i;  // (uniform; blk0 ascending)
+  const FinDesc& D = fb.d[k];
+  const int local = (int)blockIdx.x - D.blk0;
+  const int n = D.n;
+  if (D.kk <= 1) {
+    // tile pair (bi <= bj), pairs ordered by bj, then bi: local = bj (bj + 1) / 2 + bi
+    int bj = (int)((sqrtf(8.f * (float)local + 1.f) - 1.f) * 0.5f);
+    while ((bj + 1) * (bj + 2) / 2 <= local) ++bj;
+    while (bj * (bj + 1) / 2 > local) --bj;
+    const int bi = local - bj * (bj + 1) / 2;
+    float* Cm = D.dst ? D.dst : const_cast<float*>(D.src);
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+      const int r = bi * 64 + i, c = bj * 64 + tx;
+      float v = (r < n && c < n) ? D.src[(int64_t)r * n + c] : 0.f;
+      if (D.scale && r < n && c < n) v *= D.scale[r] * D.scale[c];
+      tile[i][tx] = v;
+    }
+    __syncthreads();
+    if (D.scale || D.dst) {  // the upper part itself changes (or moves)
+      for (int i = ty; i < 64; i += 4) {
+        const int r = bi * 64 + i, c = bj * 64 + tx;
+        if (r < n && c < n && r <= c) Cm[(int64_t)r * n + c] = tile[i][tx];
+      }
+    }
+    for (int i = ty; i < 64; i += 4) {
+      const int r = bj * 64 + i, c = bi * 64 + tx;  // destination (lower) element, source = tile[tx][i]
+      if (r < n && c < n && r > c) Cm[(int64_t)r * n + c] = tile[tx][i];
+    }
+    return;
+  }
+  const int Cin = D.cin, KK = D.kk;
+  const int64_t total = (int64_t)n * n;
+  const int64_t e0 = (int64_t)local * FIN_PERM_ELEMS;
+  for (int j = threadIdx.x; j < FIN_PERM_ELEMS; j += 256) {
+    const int64_t idx = e0 + j;
+    if (idx >= total) break;
+    const int r = (int)(idx / n), c = (int)(idx - (int64_t)r * n);
+    const int ci = r / KK, d = r - ci * KK;
+    const int cj = c / KK, e = c - cj * KK;
+    int rs = d * Cin + ci, cs = e * Cin + cj;
+    if (rs > cs) {
+      const int t = rs;
+      rs = cs, cs = t;
+    }
+    D.dst[idx] = D.src[(int64_t)rs * n + cs];
   }
 }
 
@@ -1209,6 +1308,39 @@ extern "C" int lk_permute_sym_f32(const float* src, int64_t Cin, int64_t KK, flo
   return check_launch("permute_sym_kernel");
 }
 
+extern "C" int lk_finalize_factors_f32(int64_t count, const float* const* src, float* const* dst, const float* const* scale,
+                                       const int64_t* n, const int64_t* cin, const int64_t* kk, void* stream) {
+  LK_REQUIRE(count >= 0 && (count == 0 || (src && dst && scale && n && cin && kk)), "lk_finalize_factors_f32: bad arguments");
+  int64_t i = 0;
+  while (i < count) {
+    FinBatch fb;
+    fb.count = 0, fb.nblk = 0;
+    for (; i < count && fb.count < FIN_MAX; ++i) {
+      LK_REQUIRE(src[i] && n[i] >= 0 && n[i] < (1ll << 24), "lk_finalize_factors_f32: bad factor");
+      if (n[i] == 0) continue;
+      FinDesc& D = fb.d[fb.count];
+      D.src = src[i], D.dst = dst[i], D.scale = scale[i];
+      D.n = (int)n[i], D.cin = (int)cin[i], D.kk = (int)kk[i], D.blk0 = fb.nblk;
+      int64_t blocks;
+      if (kk[i] > 1) {
+        LK_REQUIRE(dst[i] && dst[i] != src[i] && cin[i] * kk[i] == n[i] && !scale[i],
+                   "lk_finalize_factors_f32: a permuted factor needs dst != src, n = cin * kk and no scale");
+        blocks = (n[i] * n[i] + FIN_PERM_ELEMS - 1) / FIN_PERM_ELEMS;
+      } else {
+        const int64_t nb = (n[i] + 63) / 64;
+        blocks = nb * (nb + 1) / 2;
+      }
+      if ((int64_t)fb.nblk + blocks >= (1ll << 30)) break;  // (next launch)
+      fb.nblk += (int)blocks;
+      ++fb.count;
+    }
+    if (fb.count == 0) continue;
+    hipLaunchKernelGGL(finalize_factors_kernel, dim3((unsigned)fb.nblk), dim3(256), 0, (hipStream_t)stream, fb);
+    if (int rc = check_launch("finalize_factors_kernel")) return rc;
+  }
+  return LK_OK;
+}
+
 extern "C" int lk_conv3x3_pixpair_plan(int64_t H, int64_t W, int64_t Cin, int64_t* tile, int64_t* n_tiles,
                                        int64_t* n_blocks) {
   LK_REQUIRE(H >= 1 && W >= 1 && Cin >= 64 && Cin % 64 == 0 && tile && n_tiles && n_blocks,
@@ -1291,16 +1423,22 @@ extern "C" int lk_conv3x3_pixpair_accumulate_f32(const float* x, int64_t B, int6
   return check_launch("gram_kernel<TNP>");
 }
 
-extern "C" int lk_conv3x3_pixpair_assemble_f32(const float* blocks, const int32_t* slots_dev, int64_t H, int64_t W,
-                                               int64_t Cin, float alpha, float* A, void* stream) {
-  LK_REQUIRE(blocks && slots_dev && A && H >= 1 && W >= 1 && Cin >= 1 && 9 * Cin < (1ll << 24),
+// blocks2 (optional): a second accumulator set of the same geometry; what is assembled is blocks + blocks2
+extern "C" int lk_conv3x3_pixpair_assemble2_f32(const float* blocks, const float* blocks2, const int32_t* slots_dev, int64_t H,
+                                                int64_t W, int64_t Cin, float alpha, float* A, void* stream) {
+  LK_REQUIRE(blocks && slots_dev && A && H >= 1 && W >= 1 && Cin >= 1 && 9 * Cin < (1ll << 24) && H * W < (1ll << 24),
              "lk_conv3x3_pixpair_assemble_f32: bad arguments");
   const int64_t total = 13 * Cin * Cin;
-  int64_t nblk = (total + 255) / 256;
-  if (nblk > 16384) nblk = 16384;
-  hipLaunchKernelGGL(pixpair_assemble_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, blocks, slots_dev,
-                     (int)H, (int)W, (int)Cin, alpha, A);
+  int64_t nblk = (total + 63) / 64;
+  if (nblk > 65536) nblk = 65536;
+  hipLaunchKernelGGL(pixpair_assemble_kernel, dim3((unsigned)nblk), dim3(64), 0, (hipStream_t)stream, blocks, blocks2,
+                     slots_dev, (int)H, (int)W, (int)Cin, alpha, A);
   return check_launch("pixpair_assemble_kernel");
+}
+
+extern "C" int lk_conv3x3_pixpair_assemble_f32(const float* blocks, const int32_t* slots_dev, int64_t H, int64_t W,
+                                               int64_t Cin, float alpha, float* A, void* stream) {
+  return lk_conv3x3_pixpair_assemble2_f32(blocks, nullptr, slots_dev, H, W, Cin, alpha, A, stream);
 }
 
 extern "C" int lk_conv3x3_pixgram_assemble_f32(const float* Cp, int64_t H, int64_t W, int64_t Cin, float alpha, float* A,

@@ -45,7 +45,8 @@ def _grads(grad_fn, seeds):
 
 def _by_range_groups(fn, backend, x, *args):
     """run a per-sample predictive over magnitude groups of the minibatch and put the rows back in order"""
-    groups = _range_groups(x) if getattr(backend, "range_guard", "check") not in (False, "off") else None
+    state = backend._split_sweep_state() if hasattr(backend, "_split_sweep_state") else None
+    groups = _range_groups(x) if getattr(backend, "range_guard", "check") not in (False, "off") and state is not False else None
     if groups is None:
         return None
     f = fvar = None

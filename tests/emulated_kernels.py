@@ -274,6 +274,19 @@ class EmulatedKernels:
         C.copy_(torch.triu(C) + torch.triu(C, 1).T)
         return C
 
+    def finalize_factors(self, items):
+        for src, dst, scale, cin, kk in items:
+            if not src.numel():
+                continue
+            full = torch.triu(src) + torch.triu(src, 1).T
+            if kk > 1:
+                assert dst is not None and scale is None
+                self.permute_native_to_unfold(full, cin, kk, dst)
+            else:
+                if scale is not None:
+                    full = full * (scale.reshape(-1, 1) * scale.reshape(1, -1))
+                (src if dst is None else dst).copy_(full)
+
     def nchw_to_nhwc(self, x, out=None):
         if out is None:
             return x.permute(0, 2, 3, 1).contiguous()
@@ -407,7 +420,9 @@ class EmulatedKernels:
     def pixpair_accumulate_split(self, xs, alpha, blocks, plan):
         return self.pixpair_accumulate_nhwc(xs.float(), alpha, blocks, plan)
 
-    def pixpair_assemble(self, blocks, plan, H, W, Cin, alpha, A_native):
+    def pixpair_assemble(self, blocks, plan, H, W, Cin, alpha, A_native, blocks2=None):
+        if blocks2 is not None:
+            blocks = blocks + blocks2
         blk = blocks.view(plan[0], Cin, Cin)
         for d in range(9):
             dy, dx = d // 3 - 1, d % 3 - 1

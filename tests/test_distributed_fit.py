@@ -179,7 +179,7 @@ def test_sharded_loader_refuses_a_shuffle_that_the_ranks_cannot_reproduce():
 
 def test_expected_exchange_bytes_of_resnet18():
     """what bench.py asserts on a multi-GPU run: the fit's one all-reduce moves the packed upper triangles of the 42 dense
-    factors + the loss word — 188 MB for ResNet-18 (376 MB as squares)"""
+    factors + the loss word + the range-verdict flag — 188 MB for ResNet-18 (376 MB as squares)"""
     from laplace_amd.laplace import expected_exchange_bytes
     from laplace_amd.nets import ResNet18
 
@@ -191,5 +191,47 @@ def test_expected_exchange_bytes_of_resnet18():
             sizes += [mod.out_channels, mod.in_channels * 9 if mod.kernel_size[0] == 3 else mod.in_channels]
         elif isinstance(mod, torch.nn.Linear):
             sizes += [mod.out_features, mod.in_features]
-    assert len(sizes) == 42 and want == 4 * (sum(n * (n + 1) // 2 for n in sizes) + 1)
+    assert len(sizes) == 42 and want == 4 * (sum(n * (n + 1) // 2 for n in sizes) + 2)
     assert 187e6 < want < 189e6
+
+
+def _range_worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from laplace_amd import HipGGN, _lib
+        from laplace_amd.laplace import allreduce_curvature
+        from tests.emulated_kernels import EmulatedKernels
+
+        _lib.set_kernels_for_testing(EmulatedKernels())
+        from tests.test_sweep_nhwc import _model
+
+        model = _model(torch.relu)  # (a model the split-fp16 sweep serves: the guard concerns that path only)
+        torch.manual_seed(11)
+        X, y = torch.randn(6, 3, 8, 8), torch.randint(5, (6,))
+        if rank == 1:  # only THIS rank's shard holds a minibatch outside the range
+            X = X.clone()
+            X[0] *= 1e-4
+            X[1] *= 1e4
+        acc = HipGGN(model, "classification").kron_accumulator(20)
+        acc.add_batch(X, y)
+        try:
+            allreduce_curvature(acc.tensors(), mirror=False)  # must not raise BEFORE the collective on rank 1 alone
+            verdict = "no error"
+        except RuntimeError as e:
+            verdict = str(e)
+        dist.barrier()  # (a rank that raised early would have left the others hanging in the all-reduce)
+        torch.save(verdict, f"{out_path}.{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_range_verdict_of_one_rank_is_raised_on_every_rank_after_the_collective(tmp_path):
+    """ADVICE (round 3): the range check was rank-local and ran right BEFORE the all-reduce — a rank whose shard held a
+    wide-range minibatch raised while the others entered the collective and hung until its timeout."""
+    out = str(tmp_path / "verdict")
+    mp.spawn(_range_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    v0, v1 = torch.load(out + ".0", weights_only=False), torch.load(out + ".1", weights_only=False)
+    assert "range_guard" in v0 and "other rank" in v0     # rank 0's own data was fine: it learns about it from the flag
+    assert "range_guard" in v1 and "minibatch 0" in v1

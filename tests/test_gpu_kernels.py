@@ -723,6 +723,59 @@ def test_conv3x3_banded_pixel_pair_form_on_split_tensors(K, B, Cin, H, W):
     assert_close(got, want, 1e-5, what="banded pixel-pair form, split tensors")
 
 
+@pytest.mark.parametrize("B,Cin,H,W", [(3, 64, 4, 4), (2, 64, 5, 7), (2, 128, 3, 3), (2, 64, 32, 32), (3, 64, 1, 1)])
+def test_conv3x3_banded_pixel_pair_form_two_accumulator_sets(K, B, Cin, H, W):
+    """lk_conv3x3_pixpair_assemble2_f32: the blocks of the two lanes of a fit are summed inside the assembly (maps whose
+    pixel count is not a multiple of the kernel's eight-deep request window included) == patch Gram of both minibatches,
+    and == adding the sets first."""
+    if DEV == "cpu":
+        Cin = 8
+    x1, x2 = rnd(B, Cin, H, W, seed=B + Cin + H), rnd(B, Cin, H, W, seed=B + Cin + H + 1)
+    n = 9 * Cin
+    want = torch.zeros(n, n, dtype=torch.float64)
+    for x in (x1, x2):
+        EMU.gram_conv(x, 3, 1, 1, 1, 0.5, want)
+    plan = K.pixpair_plan(H, W, Cin, torch.device(DEV))
+    sets = []
+    for x in (x1, x2):
+        blocks = torch.zeros(plan[0] * Cin * Cin, device=DEV)
+        K.pixpair_accumulate(x.float().to(DEV), 0.5, blocks, plan)
+        sets.append(blocks)
+    nat = K.pixpair_assemble(sets[0], plan, H, W, Cin, 1.0, torch.zeros(n, n, device=DEV), blocks2=sets[1])
+    got = K.permute_native_to_unfold(nat, Cin, 9, torch.zeros(n, n, device=DEV))
+    assert_close(got, want, what="banded pixel-pair form, two accumulator sets")
+    nat1 = K.pixpair_assemble(sets[0] + sets[1], plan, H, W, Cin, 1.0, torch.zeros(n, n, device=DEV))
+    assert torch.equal(nat, nat1)  # the same additions in the same order
+
+
+def test_finalize_factors_is_symmetrize_scale_and_permute_in_one_launch(K):
+    """lk_finalize_factors_f32 against the per-factor kernels it replaces (lk_symmetrize_f32, lk_permute_sym_f32, the
+    deferred BatchNorm scale diag(s) G diag(s)); only the upper triangles of the inputs are valid."""
+    g = torch.Generator().manual_seed(5)
+    specs = [(1, 0, 1, False), (10, 0, 1, True), (64, 0, 1, False), (65, 0, 1, True), (130, 0, 1, False), (27, 3, 9, False),
+             (576, 64, 9, False), (200, 0, 1, True), (128, 128, 1, False), (1152, 128, 9, False), (0, 0, 1, False)]
+    specs = specs * 6  # more factors than one launch's descriptor table holds
+    items, want = [], []
+    for n, cin, kk, scaled in specs:
+        M = torch.randn(n, n, generator=g)
+        up = torch.triu(M) + torch.tril(torch.full((n, n), float("nan")), -1)  # the lower triangle must never be read
+        full = torch.triu(M) + torch.triu(M, 1).T
+        s_ = torch.rand(n, generator=g) + 0.5 if scaled else None
+        src = up.to(DEV)
+        if kk > 1:
+            dst = torch.full((n, n), float("nan"), device=DEV)
+            items.append((src, dst, None, cin, kk))
+            want.append((dst, EMU.permute_native_to_unfold(full, cin, kk, torch.empty(n, n))))
+        else:
+            items.append((src, None, s_.to(DEV) if scaled else None, 0, 1))
+            want.append((src, full * (s_.reshape(-1, 1) * s_.reshape(1, -1)) if scaled else full))
+    K.finalize_factors(items)
+    for (got, ref), (n, cin, kk, scaled) in zip(want, specs):
+        assert got.shape == ref.shape
+        if n:
+            assert torch.equal(got.cpu(), ref) if not scaled else torch.allclose(got.cpu(), ref, rtol=1e-6, atol=0), (n, cin, kk, scaled)
+
+
 @pytest.mark.parametrize("shape", [(4, 16, 8, 8), (3, 7, 5, 3), (5, 6), (2, 64, 32, 32), (3, 5, 9)])
 @pytest.mark.parametrize("relu", [True, False])
 @pytest.mark.parametrize("with_addend", [False, True])

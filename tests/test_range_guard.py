@@ -19,8 +19,12 @@ def _emulated():
 
 
 def _setup():
-    g = load_golden("bnres", "classification")
-    return golden_model("bnres", g, dtype=torch.float32)
+    """a model the split-fp16 NHWC sweep serves (the guard concerns that path only: one scale per tensor)"""
+    from tests.test_sweep_nhwc import _model
+
+    model = _model(torch.relu)
+    torch.manual_seed(11)
+    return model, torch.randn(10, 3, 8, 8), torch.randint(5, (10,))
 
 
 def test_range_groups_partition_by_magnitude():
@@ -50,6 +54,7 @@ def test_a_fit_refuses_a_minibatch_outside_the_range_and_group_mode_is_exact():
     assert b.range_guard == "check"
     acc = b.kron_accumulator(10)
     acc.add_batch(X, y)            # fine
+    assert b._split_sweep_state() is True
     acc.add_batch(Xw, y)           # spread 1e8 > 2^16: recorded on the device, no synchronisation here
     with pytest.raises(RuntimeError, match="range_guard"):
         acc.finalize()
@@ -60,8 +65,11 @@ def test_a_fit_refuses_a_minibatch_outside_the_range_and_group_mode_is_exact():
     loss, H = acc.finalize()
     b.range_guard = "off"
     ref = b.kron_accumulator(10)
-    small, mid, big = torch.tensor([0]), torch.arange(2, 10), torch.tensor([1])
-    for idx in (small, mid, big):
+    from laplace_amd.backend import range_groups
+
+    groups = range_groups(Xw)
+    assert groups is not None and len(groups) >= 2
+    for idx in groups:
         ref.add_batch(Xw[idx].contiguous(), y[idx])
     loss_r, H_r = ref.finalize()
     assert torch.allclose(loss, loss_r, rtol=1e-6)
@@ -84,3 +92,24 @@ def test_per_sample_results_are_swept_in_magnitude_groups():
     assert torch.allclose(f, f0, rtol=1e-5, atol=1e-6) and Js.shape == Js0.shape
     for n in range(X.shape[0]):
         assert torch.allclose(Js[n], Js0[n], rtol=1e-4, atol=1e-6 * float(Js0[n].abs().max()))
+
+
+def test_the_guard_leaves_models_outside_the_split_sweep_alone():
+    """ADVICE (round 3): a 1-D regression set with one sample near zero raised at the end of the fit although no split-fp16
+    tensor was involved (an MLP runs through the fp32 kernels, per element like the reference)."""
+    from laplace_amd import HipGGN
+
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(1, 50), torch.nn.Tanh(), torch.nn.Linear(50, 1))
+    X = torch.rand(64, 1) * 8
+    X[3] = 5e-5
+    y = torch.randn(64, 1)
+    b = HipGGN(model, "regression")
+    acc = b.kron_accumulator(64)
+    acc.add_batch(X, y)
+    loss, H = acc.finalize()                       # no RuntimeError
+    assert b._split_sweep_state() is False
+    loss2, H2 = b.kron(X, y, 64)                   # the literal loop's entry point
+    _ = H2.kfacs
+    from laplace_amd.backend import range_groups
+    assert range_groups(torch.tensor([[0.0], [1.0], [2.0]])) is None   # an all-zero sample forces no extra group
