@@ -1399,7 +1399,6 @@ class KronAccumulator:
         K = get_kernels()
         rt = math.sqrt(float(self.backend.factor))
         self._fold_lanes()
-        self._check_range()
         self._resolve_pix_inputs()
         self._flush_pixgrams()
         self._flush_g_slabs()
@@ -1422,6 +1421,9 @@ class KronAccumulator:
             done.append((G, A, has_bias))
         K.finalize_factors(items)
         self._gscale = {}
+        # (the range verdict is a device-to-host read: taken once everything of the fit has been enqueued, so that the
+        # device does not idle behind the host's round trip)
+        self._check_range()
         kfacs = []
         for G, A, has_bias in done:
             if G.numel() == 1 and A.numel() == 1 and not has_bias:

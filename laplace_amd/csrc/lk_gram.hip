@@ -963,26 +963,35 @@ __global__ __launch_bounds__(256) void pixgram_assemble_kernel(const float* __re
 static const signed char kHalfDy[13] = {0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2};
 static const signed char kHalfDx[13] = {0, 1, 2, -2, -1, 0, 1, 2, -2, -1, 0, 1, 2};
 
-// One thread per (shift h, ci, cj): every block element is read exactly once; up to nine (d, e) patch-offset pairs
-// share the shift D = e - d and differ only in which pixels q = p + d they may use (p itself must be in the map).
-// `blocks2` (optional): a second set of accumulators of the same geometry (the other lane of a fit with two minibatches
-// in flight) — the element-wise sum of the two is what is assembled, so the lanes' blocks never need a pass of their own.
-// The loop over the map's pixels is a chain of dependent additions per thread; eight block elements are requested ahead
-// of it (the slot table and every condition are uniform over the 64-thread workgroup: Cin % 64 == 0), and the grid is
-// one wave per 64 (ci, cj) pairs so that a 64-channel layer (53 k threads) still reaches every CU.  Round 3's form — 256
-// threads, one load in flight per thread — took 0.9-1.2 ms on the 32 x 32 maps of ResNet-18, latency-bound at 0.2 TB/s.
-__global__ __launch_bounds__(64) void pixpair_assemble_kernel(const float* __restrict__ blocks,
-                                                              const float* __restrict__ blocks2,
-                                                              const int* __restrict__ slots, int H, int W, int Cin,
-                                                              float alpha, float* __restrict__ A) {
+// One thread per (shift h, ci, cj) and pixel range: every block element is read exactly once; up to nine (d, e)
+// patch-offset pairs share the shift D = e - d and differ only in which pixels q = p + d they may use (p itself must be in
+// the map).  `blocks2` (optional): a second set of accumulators of the same geometry (the other lane of a fit with two
+// minibatches in flight) — the element-wise sum of the two is what is assembled, so the lanes' blocks never need a pass of
+// their own.
+// Parallelism: a 64-channel layer has only 13 * 64 * 64 = 53 k (h, ci, cj) triples and 1024 pixels to sum over each —
+// round 3's form (one thread per triple, one load in flight) ran at 0.2 TB/s, 0.9-1.2 ms per 32 x 32 layer.  Now the P
+// waves of a workgroup share 64 triples and split the map's pixels into P contiguous ranges (fixed-order sum of the P
+// partials through LDS: deterministic), and every thread requests eight block elements ahead of its chain of additions;
+// the slot table and all conditions are uniform over a wave when Cin % 64 == 0.
+__global__ __launch_bounds__(512) void pixpair_assemble_kernel(const float* __restrict__ blocks,
+                                                               const float* __restrict__ blocks2,
+                                                               const int* __restrict__ slots, int H, int W, int Cin,
+                                                               float alpha, float* __restrict__ A) {
+  __shared__ float red[8 * 9 * 64];
   const int n = 9 * Cin;
   const int64_t bsz = (int64_t)Cin * Cin;
   const int64_t total = 13 * bsz;
   const int HW = H * W;
+  const int lane = threadIdx.x & 63, part = threadIdx.x >> 6, P = blockDim.x >> 6;
+  // this wave's pixels [q_lo, q_hi)
+  const int per = (HW + P - 1) / P;
+  const int q_lo = part * per < HW ? part * per : HW, q_hi = q_lo + per < HW ? q_lo + per : HW;
   constexpr int U = 8;
-  for (int64_t idx = (int64_t)blockIdx.x * 64 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 64) {
-    const int h = (int)(idx / bsz);
-    const int64_t inner = idx - (int64_t)h * bsz;
+  for (int64_t base = (int64_t)blockIdx.x * 64; base < total; base += (int64_t)gridDim.x * 64) {  // (uniform over the workgroup)
+    const int64_t idx = base + lane;
+    const bool live = idx < total;
+    const int h = (int)((live ? idx : base) / bsz);
+    const int64_t inner = (live ? idx : base) - (int64_t)h * bsz;
     const int ci = (int)(inner / Cin), cj = (int)(inner - (int64_t)ci * Cin);
     const int Dy = h < 3 ? 0 : (h < 8 ? 1 : 2);
     const int Dx = h < 3 ? h : (h < 8 ? h - 5 : h - 10);
@@ -994,14 +1003,14 @@ __global__ __launch_bounds__(64) void pixpair_assemble_kernel(const float* __res
     for (int a = 0; a < 3; ++a)
 #pragma unroll
       for (int b = 0; b < 3; ++b) acc[a][b] = 0.f;
-    int qy0 = 0, qx0 = 0;  // pixel q0 (tracked incrementally: no division in the loop)
-    for (int q0 = 0; q0 < HW; q0 += U) {
+    int qy0 = q_lo / W, qx0 = q_lo - qy0 * W;  // pixel q0 (tracked incrementally: no division in the loop)
+    for (int q0 = q_lo; q0 < q_hi; q0 += U) {
       float v[U];
       bool have[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int q = q0 + u;
-        const int slot = q < HW ? slots[q * 13 + h] : -1;
+        const int slot = q < q_hi ? slots[q * 13 + h] : -1;
         have[u] = slot >= 0;
         v[u] = 0.f;
         if (have[u]) {
@@ -1027,6 +1036,21 @@ __global__ __launch_bounds__(64) void pixpair_assemble_kernel(const float* __res
       if (qx == W) qx = 0, ++qy;
       qy0 = qy, qx0 = qx;
     }
+    if (P > 1) {  // partials of the P pixel ranges, summed in range order by the first wave
+#pragma unroll
+      for (int k = 0; k < 9; ++k) red[(part * 9 + k) * 64 + lane] = acc[k / 3][k % 3];
+      __syncthreads();
+      if (part == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          float t = red[k * 64 + lane];
+          for (int p_ = 1; p_ < P; ++p_) t += red[(p_ * 9 + k) * 64 + lane];
+          acc[k / 3][k % 3] = t;
+        }
+      }
+      __syncthreads();
+    }
+    if (part != 0 || !live) continue;
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -1431,7 +1455,11 @@ extern "C" int lk_conv3x3_pixpair_assemble2_f32(const float* blocks, const float
   const int64_t total = 13 * Cin * Cin;
   int64_t nblk = (total + 63) / 64;
   if (nblk > 65536) nblk = 65536;
-  hipLaunchKernelGGL(pixpair_assemble_kernel, dim3((unsigned)nblk), dim3(64), 0, (hipStream_t)stream, blocks, blocks2,
+  // waves per workgroup = pixel ranges: enough threads for the chip on the few-channel / large-map layers, at least 32
+  // pixels per range
+  int P = 1;
+  while (P < 8 && nblk * 64 * P < (1 << 19) && H * W >= 64 * P) P *= 2;
+  hipLaunchKernelGGL(pixpair_assemble_kernel, dim3((unsigned)nblk), dim3(64 * P), 0, (hipStream_t)stream, blocks, blocks2,
                      slots_dev, (int)H, (int)W, (int)Cin, alpha, A);
   return check_launch("pixpair_assemble_kernel");
 }

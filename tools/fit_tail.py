@@ -17,6 +17,8 @@ for rep in range(3):
     acc = b.kron_accumulator(50000)
     for i in range(K):
         acc.add_batch(*data[i % 4])
+    if os.environ.get("LK_SYNC_BEFORE_FINALIZE"):
+        torch.cuda.synchronize()
     t1 = time.perf_counter()
     loss, H = acc.finalize()
     torch.cuda.synchronize()
