@@ -1477,6 +1477,367 @@ void conv_win_f16x2_kernel(const ConvGeom g, const _Float16* __restrict__ Ah, co
   }
 }
 
+
+// ---- persistent window form ------------------------------------------------------------------------------------------
+// Round 3's measurements (profiles/r03_win_ablate.txt) say what bounds a fused 64-channel launch: not the matrix
+// pipe (104 us at the nominal rate, ~165 at the clock the chip sustains) and not its traffic (172 us of HBM time), but
+//   (1) the fused epilogue — HBM time, 120 us — that nothing overlaps,
+//   (2) ~20 us per workgroup generation: prologue, the first loads' latency in the open, barriers draining at the end,
+//   (3) every load of a step waited for with vmcnt(0): the window of the NEXT chunk (an HBM miss) held up every hand-over.
+// This kernel is the window form (input window of a pixel tile resident in LDS, conv_win_f16x2_kernel) restructured
+// against exactly those: TWO four-wave workgroups per CU stay for the whole launch and walk through pixel tiles tile,
+// tile + G, ...; the stream of K steps runs across tile boundaries (the next tile's first window and weights are requested
+// during the current tile's last chunk and land under its epilogue); the window is waited for only where it is read; and
+// the second workgroup of a CU starts half a tile late, so that one workgroup's epilogue (memory) runs beside the other's
+// K loop (matrix pipe) for the whole launch.  (A one-workgroup form with the epilogue interleaved into the next tile's K
+// steps was built first: two accumulator sets do not fit 256 registers, and hipcc spilled the second one.)
+// Output channels = 64 (the 64-channel layers: the HBM-bound ones); nine taps in raster order (the host sorts them), weight
+// slice of tap t = wt0 + t * wtstep; multipliers: none or a byte mask.
+template <int BM_, int WPE_ = 2>
+struct WinPCfg {
+  static constexpr int BM = BM_, BN = 64, NW = BM / 64, NT = 64 * NW, WPE = WPE_;
+  static constexpr int CK = 16;                          // channels per window chunk = one k16 step
+  static constexpr int PP = BM + 96;                     // window pixels: BM + 2 Wi + 2 <= PP (Wi <= 47)
+  static constexpr int W_PLANE = PP * CK * 2, WIN = 2 * W_PLANE;
+  static constexpr int B_TAP = BN * CK * 2, B_STEP = 6 * B_TAP;  // three taps, h + l
+  static constexpr int W_INSTR = 4 * PP / 64, W_IT = (W_INSTR + NW - 1) / NW;  // LDS-DMA wave-instructions per window / per wave
+  static constexpr int B_INSTR = 12, B_IT = (B_INSTR + NW - 1) / NW;           // ... per weight step
+  static constexpr int EPI_OFF = 2 * WIN + 2 * B_STEP;
+  static constexpr int EPI_PITCH = 68, EPI_WAVE = 8 * EPI_PITCH * 4;  // per-wave image of one 8-row slice
+  static constexpr int ZERO_OFF = EPI_OFF + NW * EPI_WAVE;            // 32 zero bytes: what out-of-image taps read
+  static constexpr int LDS = ZERO_OFF + 32;
+  static constexpr int NSLICE = 8;                       // 64 rows per wave = 8 slices of 8 rows
+  static_assert((2 * PP) % 64 == 0, "a window plane is a whole number of wave-instructions");
+  static_assert(2 * LDS <= 160 * 1024, "two workgroups per CU");
+};
+
+struct WinPArgs {  // (a slim argument block: everything here stays in scalar registers for the whole launch)
+  int M, Hi, Wi, Ci, HW, n_tiles, wt0, wtstep, stagger;
+  FastDiv div_hw, div_w, div_mask;
+  const _Float16 *Ah, *Al, *Wh, *Wl;
+  const int *a_sexp, *w_sexp, *add_sexp;
+  const unsigned *in_amax, *scale_amax;
+  const float *w_l1, *scale;
+  const _Float16 *add_h, *add_l;
+  const unsigned char* mask;
+  int mask_rows;
+  _Float16 *out_h, *out_l;
+  int* out_sexp;
+  unsigned* amax_out;
+};
+
+template <typename CFG>
+__global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WPE, CFG::WPE)))
+void conv_winp_f16x2_kernel(const WinPArgs p) {
+  constexpr int BM = CFG::BM, NW = CFG::NW, PP = CFG::PP, TM = 2, TN = 2, PITCH = CFG::EPI_PITCH, NS = CFG::NSLICE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, lh = lane >> 5;
+  const int M = p.M, KC = p.Ci / 16, Wi = p.Wi;
+  const int G = gridDim.x;
+  int tile = blockIdx.x;
+  if (tile >= p.n_tiles) return;  // (uniform)
+
+  // a zero block behind everything the LDS-DMA writes: what out-of-image taps read (every lane of every staging
+  // instruction then reads mapped memory and lands somewhere harmless: no pointer selects, no partial instructions);
+  // the folded BatchNorm scale of the epilogue behind it
+  if (tid < 8) reinterpret_cast<unsigned*>(smem + CFG::ZERO_OFF)[tid] = 0u;
+  __syncthreads();  // (the hand-over barriers of the K loop are raw s_barriers: they do not order this LDS write)
+
+  // ---- scales (see conv_f16x2_kernel): the result's scale from the guaranteed bound
+  const int sexp_a = p.a_sexp[0], sexp_w = p.w_sexp[0];
+  const float inv = exp2i(-sexp_a < -126 ? -126 : -sexp_a) * exp2i(-sexp_w < -126 ? -126 : -sexp_w);
+  float inv2 = 0.f;
+  float bound = p.in_amax ? __uint_as_float(p.in_amax[0]) : exp2i(15 - sexp_a < -126 ? -126 : (15 - sexp_a > 127 ? 127 : 15 - sexp_a));
+  bound *= p.w_l1[0];
+  if (p.add_h) {
+    const int s2 = p.add_sexp[0];
+    bound += exp2i(15 - s2 < -126 ? -126 : (15 - s2 > 127 ? 127 : 15 - s2));
+    inv2 = exp2i(-s2 < -126 ? -126 : -s2);
+  }
+  if (p.scale) bound *= __uint_as_float(p.scale_amax[0]);
+  const int so = scale_exp_for(bound);
+  const float sc_out = exp2i(so);
+  if (blockIdx.x == 0 && tid == 0) p.out_sexp[0] = so;
+
+  // ---- window staging: wave-instruction i = it * NW + wave covers slots [64 i, 64 i + 64) of [plane][pixel][2].
+  //      Addresses are (scalar base) + (32-bit lane offset): the lane offsets are the only registers the staging keeps.
+  //      (W_INSTR need not divide by the waves: a wave whose last instruction does not exist repeats its first one —
+  //      same bytes to the same place — so that every wave issues W_IT instructions and the counted waits hold)
+  unsigned w_off[CFG::W_IT];  // byte offset of this lane's source slot inside a plane, for the tile that is being staged
+  auto w_instr = [&](int it) {
+    const int i = it * NW + wave;
+    return i < CFG::W_INSTR ? i : wave;
+  };
+  auto setup_window = [&](int m0) {
+#pragma unroll
+    for (int it = 0; it < CFG::W_IT; ++it) {
+      const int i = w_instr(it);
+      const int rem = (i * 64) % (2 * PP) + lane;  // (whole instructions lie inside one plane: 2 PP % 64 == 0)
+      const int px = rem >> 1, pq = rem & 1;
+      int raster = m0 - (Wi + 1) + px;
+      // rows outside the tensor (and the window's padding) are only reached by taps that read the zero block instead: any
+      // mapped address will do for them
+      raster = raster < 0 ? 0 : (raster > M - 1 ? M - 1 : raster);
+      w_off[it] = (unsigned)(raster * p.Ci + ((pq ^ swz2(px)) << 3)) * 2u;
+    }
+  };
+  auto stage_win = [&](int kc, int buf) {
+    const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + buf * CFG::WIN;
+#pragma unroll
+    for (int it = 0; it < CFG::W_IT; ++it) {
+      const int i = w_instr(it);  // (scalar)
+      const char* sb = reinterpret_cast<const char*>((i * 64 >= 2 * PP) ? p.Al : p.Ah) + kc * 32;  // (scalar)
+      __builtin_amdgcn_global_load_lds((gbl_void*)(sb + w_off[it]), (lds_void*)(uintptr_t)(base + i * 1024), 16, 0, 0);
+    }
+  };
+  // ---- weight staging: slots [tap j of the step][plane][n][2]; instruction i covers 32 output channels of one (tap, plane)
+  const int w_tap_bytes = 64 * p.Ci * 2;  // (one 64 x Ci weight slice of a plane)
+  unsigned b_off[CFG::B_IT];
+#pragma unroll
+  for (int j = 0; j < CFG::B_IT; ++j) {
+    const int i = (wave * CFG::B_IT + j) % CFG::B_INSTR;
+    const int sidx = i * 64 + lane;
+    const int pq = sidx & 1, n = (sidx >> 1) & 63;
+    b_off[j] = (unsigned)(n * p.Ci + ((pq ^ swz2(n)) << 3)) * 2u;
+  }
+  auto stage_b = [&](int kc, int r, int slot) {  // r: compile-time after unrolling
+    const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + 2 * CFG::WIN + slot * CFG::B_STEP;
+#pragma unroll
+    for (int j = 0; j < CFG::B_IT; ++j) {
+      const int i = (wave * CFG::B_IT + j) % CFG::B_INSTR;  // (scalar)
+      const int jp = i >> 1;                                 // (tap of the step, plane)
+      const int t = r * 3 + (jp >> 1);
+      const char* sb = reinterpret_cast<const char*>((jp & 1) ? p.Wl : p.Wh) + (int64_t)(p.wt0 + t * p.wtstep) * w_tap_bytes + kc * 32;
+      __builtin_amdgcn_global_load_lds((gbl_void*)(sb + b_off[j]), (lds_void*)(uintptr_t)(base + i * 1024), 16, 0, 0);
+    }
+  };
+
+  // ---- fragment addresses: a validity bit per (row tile, tap); the bits depend on the pixel (h, w) of a row only —
+  //      constant over this workgroup's tiles when its tile stride is a whole number of images and no tile is ragged
+  unsigned a_valid[TM];  // bit t: tap t of this lane's row (row tile a) lies inside the image
+  const int a_px0 = wave * (TM * 32) + lr;  // window pixel of row tile 0 at shift 0 (row tile a: + 32 a)
+  auto setup_frag = [&](int m0) {
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      const int m = m0 + (wave * TM + a) * 32 + lr;
+      int h = 0, w = 0;
+      const bool in = m < M;
+      if (in) {
+        const int rem = m - fdiv(m, p.div_hw) * p.HW;
+        h = fdiv(rem, p.div_w), w = rem - h * Wi;
+      }
+      unsigned v = 0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
+        if (in && hh >= 0 && hh < p.Hi && ww >= 0 && ww < Wi) v |= 1u << t;
+      }
+      a_valid[a] = v;
+    }
+  };
+  const bool frag_const = ((int64_t)G * BM) % p.HW == 0 && (int64_t)p.n_tiles * BM <= M;
+  int b_addr[TN];
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    const int n = b * 32 + lr;
+    b_addr[b] = n * 32 + (lh ^ swz2(n)) * 16;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // one step = three taps behind one hand-over barrier
+  int m0 = tile * BM;
+  int next_m0 = -1;
+  auto step = [&](int kc, bool last_tile, auto r_c) {
+    constexpr int r = decltype(r_c)::value;
+    const int slot = (kc + r) & 1;  // = (3 kc + r) & 1
+    // this wave's parts of this step have landed — at r == 1 the window requested one step ago (behind the weights, in
+    // issue order) may stay in flight: it is not read before the next chunk (no window was requested in the last chunk of
+    // the last tile: counting on it there let the weights of its second step slip through the wait)
+    // (inline asm with a memory clobber: the s_barrier builtin is no memory operation to the optimiser, which may move the
+    //  fragment reads of this step above it — it did, intermittently wrong results on the device)
+    if (r == 1 && (kc + 1 < KC || !last_tile)) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(CFG::W_IT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // ... everybody's; and nobody reads the buffers that are loaded next any more
+    __builtin_amdgcn_sched_barrier(0);
+    const bool more = kc + 1 < KC;
+    if (r < 2) stage_b(kc, r + 1, slot ^ 1);
+    else if (more) stage_b(kc + 1, 0, slot ^ 1);
+    else if (!last_tile) stage_b(0, 0, slot ^ 1);
+    if (r == 0) {
+      if (more) stage_win(kc + 1, (kc + 1) & 1);
+      else if (!last_tile) {
+        setup_window(next_m0);
+        stage_win(0, (kc + 1) & 1);
+      }
+    }
+    // (opaque to the optimiser: the fragment addresses and tap-validity selects below are invariant over the K loop, and
+    //  hipcc otherwise hoists all 2 x 18 of them — and their 18 lane masks — out of it and spills them)
+    int wbase = (kc & 1) * CFG::WIN;
+    asm volatile("" : "+s"(wbase));
+    unsigned av[TM];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      av[a] = a_valid[a];
+      asm volatile("" : "+v"(av[a]));
+    }
+    const char* pb = smem + 2 * CFG::WIN + slot * CFG::B_STEP;
+    // fragments of tap j + 1 are requested before the MFMAs of tap j are issued (two register sets): while this workgroup's
+    // partner on the CU is in its epilogue nobody else covers the LDS round trip
+    f16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+    auto load_frags = [&](int j, int set) {
+      const int t = r * 3 + j;  // compile-time after unrolling
+      const int shift = (t / 3) * Wi + t % 3;  // window pixel shift of tap t (raster order)
+#pragma unroll
+      for (int a = 0; a < TM; ++a) {
+        const int px = a_px0 + 32 * a + shift;
+        const int ad = wbase + (px * 2 + (lh ^ ((px >> 3) & 1))) * 16;
+        const bool ok = (av[a] >> t) & 1u;
+        ah[set][a] = *reinterpret_cast<const f16x8*>(smem + (ok ? ad : (int)CFG::ZERO_OFF));
+        al[set][a] = *reinterpret_cast<const f16x8*>(smem + (ok ? ad + CFG::W_PLANE : (int)CFG::ZERO_OFF));
+      }
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        bh[set][b] = *reinterpret_cast<const f16x8*>(pb + b_addr[b] + (j * 2) * CFG::B_TAP);
+        bl[set][b] = *reinterpret_cast<const f16x8*>(pb + b_addr[b] + (j * 2 + 1) * CFG::B_TAP);
+      }
+    };
+    load_frags(0, 0);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int set = j & 1;
+      if (j + 1 < 3) load_frags(j + 1, set ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          f32x16 c = acc[a][b];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[set][a], bh[set][b], c, 0, 0, 0);  // small terms first
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[set][a], bl[set][b], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[set][a], bh[set][b], c, 0, 0, 0);
+          acc[a][b] = c;
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // ---- fused epilogue of one tile: eight 8-row slices per wave, lane = (row lane >> 3 of the slice, channels (lane & 7) * 8 ..)
+  const int e_row = lane >> 3, e_c0 = (lane & 7) * 8;
+  float* img = reinterpret_cast<float*>(smem + CFG::EPI_OFF) + wave * (8 * PITCH);
+  unsigned vmax = 0;
+  auto epilogue = [&](int m0_t) {
+    // every slice's addend planes and mask bytes are requested first (the fragment registers are free by now): their
+    // latency — an HBM miss each — is paid once per tile
+    f16x8 e_h2[NS], e_l2[NS];
+    uint2 e_mk[NS];
+    const int mrow0 = m0_t + wave * 64 + e_row;
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl) {
+      const int m = mrow0 + sl * 8;
+      const bool ok = m < M;
+      const int64_t e = ok ? (int64_t)m * 64 + e_c0 : 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e_h2[sl][j] = (_Float16)0.f, e_l2[sl][j] = (_Float16)0.f;
+      e_mk[sl] = make_uint2(0x01010101u, 0x01010101u);
+      if (p.add_h && ok) {
+        e_h2[sl] = *reinterpret_cast<const f16x8*>(p.add_h + e);
+        e_l2[sl] = *reinterpret_cast<const f16x8*>(p.add_l + e);
+      }
+      if (p.mask && ok) {
+        const int mr = m - fdiv(m, p.div_mask) * p.mask_rows;
+        e_mk[sl] = *reinterpret_cast<const uint2*>(p.mask + (int64_t)mr * 64 + e_c0);
+      }
+    }
+    float mult[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mult[j] = sc_out;
+    if (p.scale) {
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(p.scale + e_c0), s1 = *reinterpret_cast<const f32x4*>(p.scale + e_c0 + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mult[j] *= s0[j], mult[4 + j] *= s1[j];
+    }
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl) {
+      const int a = sl >> 2, q = sl & 3;
+      // MFMA layout (lane = channel, registers = pixels) -> image [8 rows][64 channels] -> lane = 8 channels of one pixel
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) img[(i + 4 * lh) * PITCH + b * 32 + lr] = acc[a][b][4 * q + i] * inv;
+      // (LDS operations of one wave execute in order: no barrier between its own writes and reads)
+      const f32x4 p0 = *reinterpret_cast<const f32x4*>(img + e_row * PITCH + e_c0);
+      const f32x4 p1 = *reinterpret_cast<const f32x4*>(img + e_row * PITCH + e_c0 + 4);
+      const int m = mrow0 + sl * 8;
+      if (m >= M) continue;
+      float v[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+      if (p.add_h) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += ((float)e_h2[sl][j] + (float)e_l2[sl][j]) * inv2;
+      }
+      f16x8 h, l;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool keep = ((j < 4 ? e_mk[sl].x >> (8 * j) : e_mk[sl].y >> (8 * (j - 4))) & 0xffu) != 0;
+        float xs = keep ? v[j] * mult[j] : 0.f;
+        asm volatile("" : "+v"(xs));  // h and the residual from the SAME fp32 value (see split2)
+        const _Float16 hh = (_Float16)xs;
+        h[j] = hh;
+        l[j] = (_Float16)(xs - (float)hh);
+        vmax = max(vmax, __float_as_uint(xs) & 0x7fffffffu);
+      }
+      const int64_t e = (int64_t)m * 64 + e_c0;
+      *reinterpret_cast<f16x8*>(p.out_h + e) = h;
+      *reinterpret_cast<f16x8*>(p.out_l + e) = l;
+    }
+  };
+
+  // prologue: the first tile's first window and first three taps
+  setup_window(m0);
+  setup_frag(m0);
+  stage_win(0, 0);
+  stage_b(0, 0, 0);
+  // the second workgroup of a CU starts half a tile late (the host passes the delay in units of 64 s_sleep cycles): from
+  // then on one workgroup's epilogue runs beside the other's K loop
+  if (blockIdx.x >= (unsigned)(G / 2))
+    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(64);
+  // (the chunk parity of the LDS buffers restarts with every tile: KC is even — checked by the host — so that the window
+  //  buffer (kc & 1) and the weight slot ((kc + r) & 1) of a tile's first step are those the previous tile's last step fed)
+  while (true) {
+    const bool last_tile = tile + G >= p.n_tiles;
+    next_m0 = (tile + G) * BM;
+    for (int kc = 0; kc < KC; ++kc) {
+      step(kc, last_tile, std::integral_constant<int, 0>{});
+      step(kc, last_tile, std::integral_constant<int, 1>{});
+      step(kc, last_tile, std::integral_constant<int, 2>{});
+    }
+    epilogue(m0);
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    if (last_tile) break;
+    tile += G;
+    m0 = next_m0;
+    if (!frag_const) setup_frag(m0);
+  }
+  if (p.amax_out) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) vmax = max(vmax, (unsigned)__shfl_xor((int)vmax, off, 64));
+    const int back = -so < -126 ? -126 : -so;
+    if (lane == 0 && vmax) atomicMax(p.amax_out, __float_as_uint(__uint_as_float(vmax) * exp2i(back)));
+  }
+}
+
 }  // namespace lk
 
 using namespace lk;
@@ -1648,6 +2009,63 @@ static int launch_win(const ConvGeom& g, const void* Ah, const void* Al, const v
   return check_launch("conv_win_f16x2_kernel");
 }
 
+static int cu_count() {
+  static int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+      v = 256;
+    return v;
+  }();
+  return n;
+}
+
+// persistent window form (fused VJP epilogue only): one workgroup per CU walks through the pixel tiles.  The taps are put
+// into raster order here (the sum over taps is commutative); their weight slices must then form an arithmetic sequence
+// (forward: 0, 1, ..; backward-data: 8, 7, ..) — returns false (caller takes another kernel) otherwise.
+template <typename CFG>
+static bool launch_winp(const ConvGeom& g, const void* Ah, const void* Al, const void* Wh, const void* Wl, const int* a_sexp,
+                        const int* w_sexp, unsigned* amax_out, hipStream_t stream, const ConvVjp* fz, int* rc) {
+  int wt[9];
+  for (int t = 0; t < 9; ++t) wt[t] = -1;
+  for (int t = 0; t < 9; ++t) {
+    if (g.dh[t] < -1 || g.dh[t] > 1 || g.dw[t] < -1 || g.dw[t] > 1) return false;
+    const int c = (g.dh[t] + 1) * 3 + g.dw[t] + 1;
+    if (wt[c] >= 0) return false;
+    wt[c] = g.wt[t];
+  }
+  const int step = wt[1] - wt[0];
+  for (int t = 0; t < 9; ++t)
+    if (wt[t] != wt[0] + t * step) return false;
+  WinPArgs p;
+  const int64_t M = (int64_t)g.N * g.Hi * g.Wi;
+  p.M = (int)M, p.Hi = g.Hi, p.Wi = g.Wi, p.Ci = g.Ci, p.HW = g.Hi * g.Wi;
+  p.n_tiles = (int)((M + CFG::BM - 1) / CFG::BM);
+  p.wt0 = wt[0], p.wtstep = step;
+  p.div_hw = g.div_hw, p.div_w = g.div_w, p.div_mask = fz->div_mask;
+  p.Ah = (const _Float16*)Ah, p.Al = (const _Float16*)Al, p.Wh = (const _Float16*)Wh, p.Wl = (const _Float16*)Wl;
+  p.a_sexp = a_sexp, p.w_sexp = w_sexp, p.add_sexp = fz->add_sexp;
+  p.in_amax = fz->in_amax, p.scale_amax = fz->scale_amax;
+  p.w_l1 = fz->w_l1, p.scale = fz->scale;
+  p.add_h = fz->add_h, p.add_l = fz->add_l;
+  p.mask = (const unsigned char*)fz->mask, p.mask_rows = (int)fz->mask_rows;
+  static const int stagger = [] {
+    const char* e = getenv("LK_WINP_STAGGER");  // (tuning knob: start delay of a CU's second workgroup, x 64 s_sleep cycles)
+    return e ? atoi(e) : 3;
+  }();
+  p.stagger = stagger * (g.Ci / 64);
+  p.out_h = fz->out_h, p.out_l = fz->out_l, p.out_sexp = fz->out_sexp;
+  p.amax_out = amax_out;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv_winp_f16x2_kernel<CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS);
+    attr_set = true;
+  }
+  const int grid = p.n_tiles < 2 * cu_count() ? p.n_tiles : 2 * cu_count();  // two workgroups per CU
+  hipLaunchKernelGGL((conv_winp_f16x2_kernel<CFG>), dim3((unsigned)grid), dim3(CFG::NT), CFG::LDS, stream, p);
+  *rc = check_launch("conv_winp_f16x2_kernel");
+  return true;
+}
+
 // One launch of the implicit GEMM.  `taps`: T x {dh, dw, weight slice}.
 static int conv_dispatch(const void* in_h, const void* in_l, const int* in_sexp, int64_t N, int64_t Hi, int64_t Wi,
                          int64_t Ci, const void* w_h, const void* w_l, const int* w_sexp, int64_t Co,
@@ -1682,6 +2100,12 @@ static int conv_dispatch(const void* in_h, const void* in_l, const int* in_sexp,
     return launch_conv<GramConvCfg>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz, gram_ws);
   }
   g_ablate = ((config >> 8) & 7) | ((config & 1048576) ? 16 : 0) | ((config & 2097152) ? 32 : 0);  // (development build only)
+  // persistent window form (config bit 27; fused launches with 64 output channels): see conv_winp_f16x2_kernel
+  if ((config & 134217728) && fz && !gram_ws && T == 9 && in_mul == 1 && Hc == Hi && Wc == Wi && Wi <= 47 && Ci % 32 == 0 && Co == 64 &&
+      g.dense && !g.pmajor && N * Hi * Wi * Ci < (1ll << 30) && N * Hi * Wi >= 512 && !(fz->mask && fz->mask_float)) {
+    int rc = LK_OK;
+    if (launch_winp<WinPCfg<256>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, amax_out, st, fz, &rc)) return rc;
+  }
   // "window" form (config bit 22): nine taps inside [-1, 1]^2 on the input grid, maps of more than 64 pixels (small maps
   // run position-major with tap skipping), enough tiles to fill the chip; bit 23: the 512-pixel tile for 64 output channels
   if ((config & 4194304) && T == 9 && in_mul == 1 && Hc == Hi && Wc == Wi && 2 * Wi + 2 <= 94 && Ci % 16 == 0 && !(config & 16) &&
