@@ -221,6 +221,19 @@ int lk_conv_nhwc_f16x2_vjp(const void* in_h, const void* in_l, const int* in_sex
                            const void* add_h, const void* add_l, const int* add_sexp, const void* mask, int mask_is_float,
                            const void* mult_amax, int64_t mask_rows, const float* scale, const void* scale_amax, void* out_h,
                            void* out_l, int* out_sexp, void* out_amax, int config, void* stream);
+/* lk_conv_nhwc_f16x2_vjp with the weights ALSO handed over chunk-major (wc_h / wc_l: [tap][Ci / 16][Co][16] fp16 per plane,
+ * same scale w_sexp): 3 x 3 / stride-1 launches with 64 output channels on maps of more than 64 pixels
+ * (lk_conv_winp_eligible) then run the PERSISTENT window form — two workgroups per CU walk through the pixel tiles, the
+ * input window of a tile resident in LDS, the next tile's operands requested under the epilogue; the chunk-major order
+ * makes every weight staging instruction one contiguous kilobyte.  Other shapes ignore the extra planes. */
+int lk_conv_winp_eligible(int64_t N, int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t T, int mask_is_float);
+int lk_conv_nhwc_f16x2_vjp_wc(const void* in_h, const void* in_l, const int* in_sexp, const void* in_amax, int64_t N, int64_t Hi,
+                              int64_t Wi, int64_t Ci, const void* w_h, const void* w_l, const int* w_sexp, const float* w_l1,
+                              const void* wc_h, const void* wc_l, int64_t Co, int64_t Ho, int64_t Wo, int64_t T, const int* taps,
+                              const void* zero16, const void* add_h, const void* add_l, const int* add_sexp, const void* mask,
+                              int mask_is_float, const void* mult_amax, int64_t mask_rows, const float* scale,
+                              const void* scale_amax, void* out_h, void* out_l, int* out_sexp, void* out_amax, int config,
+                              void* stream);
 
 /* lk_conv_nhwc_f16x2_vjp that ALSO accumulates the Gram of what it emits, o^T o over all N*Ho*Wo output pixels — the G
  * factor of the layer whose output cotangent the launch produces (the per-pass hooks of

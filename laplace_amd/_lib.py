@@ -68,6 +68,10 @@ SIGNATURES = {
     "lk_conv_nhwc_f16x2_vjp": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64,
                                       _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _i64, _vp, _vp, _vp, _vp, _vp,
                                       _vp, _int, _vp]),
+    "lk_conv_winp_eligible": (_int, [_i64, _i64, _i64, _i64, _i64, _i64, _int]),
+    "lk_conv_nhwc_f16x2_vjp_wc": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64,
+                                         _i64, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _int,
+                                         _vp]),
     "lk_conv_vjp_gram_parts": (_i64, [_i64, _i64, _i64, _i64, _int]),
     "lk_conv_nhwc_f16x2_vjp_gram": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64,
                                            _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _i64, _vp, _vp, _vp, _vp, _vp,
@@ -453,8 +457,17 @@ class HipKernels:
     #: default for that reason; the kernels and their parity tests stay.
     fuse_gram = os.environ.get("LK_FUSE_GRAM", "0") == "1"
 
+    #: ``False`` (env LK_WINP=0): fused 64-channel launches stay on the generic kernel (see :meth:`conv_winp_eligible`)
+    use_winp = os.environ.get("LK_WINP", "1") != "0"
+
+    def conv_winp_eligible(self, N, Hi, Wi, Ci, Co, T, mask_is_float=False) -> bool:
+        """does a fused 3 x 3 / stride-1 launch of this shape run the persistent window form (lk_conv_nhwc_f16x2_vjp_wc)?  The
+        caller then hands over chunk-major weights (``wplanes_chunked``)"""
+        return bool(self.use_winp and self.lib.lk_conv_winp_eligible(int(N), int(Hi), int(Wi), int(Ci), int(Co), int(T),
+                                                                     1 if mask_is_float else 0))
+
     def conv_nhwc_f16x2_vjp(self, x, wplanes, wsexp, w_l1, Ho, Wo, taps, add=None, mult=None, mult_amax=None, scale=None,
-                            scale_amax=None, config=None, want_gram=False, amax_word=None):
+                            scale_amax=None, config=None, want_gram=False, amax_word=None, wplanes_chunked=None):
         """one dense launch of the convolution with the element-wise VJP fused into its epilogue (lk_conv_nhwc_f16x2_vjp):
         ``(conv(x) + add) * mult * scale[channel]`` -> SplitTensor [N, Ho, Wo, Co] carrying its measured ``amax``.
         ``mult``: [B, Ho, Wo, Co] uint8 / bool mask or fp32 multiplier (``mult_amax``: its bound, fp32 only), shared by
@@ -497,6 +510,17 @@ class HipKernels:
             out = SplitTensor(planes, sexp, amax)
             out.gram_parts = gws
             return out
+        if wplanes_chunked is not None:
+            # [2, T, Ci / 16, Co, 16]: the persistent window form where the library finds the launch eligible
+            assert wplanes_chunked.shape == (2, wplanes.shape[1], Ci // 16, Co, 16) and wplanes_chunked.is_contiguous()
+            self._rc(self._timed("conv16", work, dev, lambda: self.lib.lk_conv_nhwc_f16x2_vjp_wc(
+                _ptr(x.planes[0]), _ptr(x.planes[1]), _ptr(x.sexp), _ptr(x.amax), N, Hi, Wi, Ci, _ptr(wplanes[0]),
+                _ptr(wplanes[1]), _ptr(wsexp), _ptr(w_l1), _ptr(wplanes_chunked[0]), _ptr(wplanes_chunked[1]), Co, Ho, Wo,
+                len(taps), flat, _ptr(z), None if add is None else _ptr(add.planes[0]),
+                None if add is None else _ptr(add.planes[1]), None if add is None else _ptr(add.sexp), _ptr(mult), m_is_float,
+                _ptr(mult_amax), mask_rows, _ptr(scale), _ptr(scale_amax), _ptr(planes[0]), _ptr(planes[1]), _ptr(sexp),
+                _ptr(amax), int(cfg), self._stream(dev))), "lk_conv_nhwc_f16x2_vjp_wc")
+            return SplitTensor(planes, sexp, amax)
         self._rc(self._timed("conv16", work, dev, lambda: self.lib.lk_conv_nhwc_f16x2_vjp(
             _ptr(x.planes[0]), _ptr(x.planes[1]), _ptr(x.sexp), _ptr(x.amax), N, Hi, Wi, Ci, _ptr(wplanes[0]), _ptr(wplanes[1]),
             _ptr(wsexp), _ptr(w_l1), Co, Ho, Wo, len(taps), flat, _ptr(z),

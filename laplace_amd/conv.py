@@ -36,6 +36,7 @@ class PreparedConv:
     def __init__(self, m: nn.Conv2d):
         self.m = m
         self._bwd = None  # (key, planes, sexp)
+        self._bwdc = None  # (key, chunk-major copy of the backward planes)
         self._fwd = None
 
     def _key(self, cscale):
@@ -59,6 +60,16 @@ class PreparedConv:
     def backward_l1(self, cscale=None):
         self.backward_planes(cscale)
         return self._bwd[3]
+
+    def backward_planes_chunked(self, cscale=None):
+        """the backward planes ``[2, T, N, K]`` once more in chunk-major order ``[2, T, K / 16, N, 16]`` (what the
+        persistent window form of the fused launch stages: every 16-channel chunk of a tap is one contiguous block)"""
+        planes, _ = self.backward_planes(cscale)
+        key = self._bwd[0]
+        if self._bwdc is None or self._bwdc[0] != key:
+            two, T, N, Kd = planes.shape
+            self._bwdc = (key, planes.view(two, T, N, Kd // 16, 16).permute(0, 1, 3, 2, 4).contiguous())
+        return self._bwdc[1]
 
     @property
     def padded_in(self) -> int:
@@ -139,6 +150,10 @@ def conv_backward_data_vjp(prep: PreparedConv, g: SplitTensor, in_hw, cscale=Non
     kw = {"want_gram": True} if want_gram else {}  # (``want_gram``: see HipKernels.conv_nhwc_f16x2_vjp)
     if amax_word is not None:
         kw["amax_word"] = amax_word  # a zeroed device word for the measured max|result| (saves a fill launch)
+    N = g.planes.shape[1]
+    if not (want_gram and getattr(K, "fuse_gram", False)) and planes.shape[3] % 16 == 0 and K.conv_winp_eligible(
+            N, Hin, Win, planes.shape[3], planes.shape[2], len(taps), mult is not None and mult.dtype == torch.float32):
+        kw["wplanes_chunked"] = prep.backward_planes_chunked(cscale)
     return K.conv_nhwc_f16x2_vjp(g, planes, sexp, prep.backward_l1(cscale), Hin, Win, taps, add=add, mult=mult,
                                  mult_amax=mult_amax, scale=scale, scale_amax=scale_amax, **kw)
 

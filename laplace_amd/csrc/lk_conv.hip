@@ -228,6 +228,7 @@ struct ConvVjp {
   const unsigned* scale_amax;
   _Float16 *out_h, *out_l;
   int* out_sexp;
+  const _Float16 *wc_h, *wc_l;  // the same weights chunk-major, [tap][Ci / 16][Co][16] per plane (persistent window form), or NULL
 };
 
 // GRAM (fused epilogue, Co == BN == 64, one wave = 64 pixels x all 64 channels): the launch ALSO accumulates the Gram of
@@ -1512,7 +1513,7 @@ struct WinPCfg {
 };
 
 struct WinPArgs {  // (a slim argument block: everything here stays in scalar registers for the whole launch)
-  int M, Hi, Wi, Ci, HW, n_tiles, wt0, wtstep, stagger;
+  int M, Hi, Wi, Ci, Co, HW, n_tiles, nb_m, wt0, wtstep, stagger, ablate;
   FastDiv div_hw, div_w, div_mask;
   const _Float16 *Ah, *Al, *Wh, *Wl;
   const int *a_sexp, *w_sexp, *add_sexp;
@@ -1526,6 +1527,11 @@ struct WinPArgs {  // (a slim argument block: everything here stays in scalar re
   unsigned* amax_out;
 };
 
+#ifdef LK_CONV_DEV
+// (development build) per workgroup and tile: s_memtime at the start of the K loop, at its end, at the end of the epilogue
+__device__ unsigned long long g_winp_trace[1024 * 16 * 3];
+#endif
+
 template <typename CFG>
 __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WPE, CFG::WPE)))
 void conv_winp_f16x2_kernel(const WinPArgs p) {
@@ -1538,6 +1544,11 @@ void conv_winp_f16x2_kernel(const WinPArgs p) {
   const int G = gridDim.x;
   int tile = blockIdx.x;
   if (tile >= p.n_tiles) return;  // (uniform)
+#ifdef LK_WINP_ABLATE  // development switches, compile-time (a run-time switch perturbs this kernel's schedule beyond
+  constexpr int ablate = LK_WINP_ABLATE;  // comparison): 1 skip the epilogue, 2 the MFMAs, 4 the in-loop staging
+#else
+  constexpr int ablate = 0;
+#endif
 
   // a zero block behind everything the LDS-DMA writes: what out-of-image taps read (every lane of every staging
   // instruction then reads mapped memory and lands somewhere harmless: no pointer selects, no partial instructions);
@@ -1592,24 +1603,29 @@ void conv_winp_f16x2_kernel(const WinPArgs p) {
       __builtin_amdgcn_global_load_lds((gbl_void*)(sb + w_off[it]), (lds_void*)(uintptr_t)(base + i * 1024), 16, 0, 0);
     }
   };
-  // ---- weight staging: slots [tap j of the step][plane][n][2]; instruction i covers 32 output channels of one (tap, plane)
-  const int w_tap_bytes = 64 * p.Ci * 2;  // (one 64 x Ci weight slice of a plane)
+  // ---- weight staging: slots [tap j of the step][plane][n][2]; instruction i covers 32 output channels of one (tap, plane).
+  //      The weights come CHUNK-major, [plane][tap][Ci / 16][64][16]: the 32 rows of an instruction are one contiguous
+  //      kilobyte = 8 cache lines.  From the GEMM-natural [tap][64][Ci] layout the same instruction touches 32 lines for 32
+  //      bytes each, and the requests — not the bytes — are what the CU's vector memory path runs out of: staging cost
+  //      136 of 400 us with every lane of every instruction asking for a quarter of its line.
+  const int w_tap_bytes = p.Co * p.Ci * 2;  // (one Co x Ci weight slice of a plane)
   unsigned b_off[CFG::B_IT];
 #pragma unroll
   for (int j = 0; j < CFG::B_IT; ++j) {
     const int i = (wave * CFG::B_IT + j) % CFG::B_INSTR;
     const int sidx = i * 64 + lane;
     const int pq = sidx & 1, n = (sidx >> 1) & 63;
-    b_off[j] = (unsigned)(n * p.Ci + ((pq ^ swz2(n)) << 3)) * 2u;
+    b_off[j] = (unsigned)(n * 16 + ((pq ^ swz2(n)) << 3)) * 2u;
   }
-  auto stage_b = [&](int kc, int r, int slot) {  // r: compile-time after unrolling
+  auto stage_b = [&](int kc, int r, int slot, int bn0) {  // r: compile-time after unrolling; bn0: first output channel of the tile
     const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + 2 * CFG::WIN + slot * CFG::B_STEP;
 #pragma unroll
     for (int j = 0; j < CFG::B_IT; ++j) {
       const int i = (wave * CFG::B_IT + j) % CFG::B_INSTR;  // (scalar)
       const int jp = i >> 1;                                 // (tap of the step, plane)
       const int t = r * 3 + (jp >> 1);
-      const char* sb = reinterpret_cast<const char*>((jp & 1) ? p.Wl : p.Wh) + (int64_t)(p.wt0 + t * p.wtstep) * w_tap_bytes + kc * 32;
+      const char* sb = reinterpret_cast<const char*>((jp & 1) ? p.Wl : p.Wh) + (int64_t)(p.wt0 + t * p.wtstep) * w_tap_bytes +
+                       (kc * p.Co + bn0) * 32;
       __builtin_amdgcn_global_load_lds((gbl_void*)(sb + b_off[j]), (lds_void*)(uintptr_t)(base + i * 1024), 16, 0, 0);
     }
   };
@@ -1637,7 +1653,8 @@ void conv_winp_f16x2_kernel(const WinPArgs p) {
       a_valid[a] = v;
     }
   };
-  const bool frag_const = ((int64_t)G * BM) % p.HW == 0 && (int64_t)p.n_tiles * BM <= M;
+  const int nb_n = p.Co / 64;
+  const bool frag_const = G % nb_n == 0 && ((int64_t)(G / nb_n) * BM) % p.HW == 0 && (int64_t)p.nb_m * BM <= M;
   int b_addr[TN];
 #pragma unroll
   for (int b = 0; b < TN; ++b) {
@@ -1653,9 +1670,12 @@ void conv_winp_f16x2_kernel(const WinPArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  // one step = three taps behind one hand-over barrier
-  int m0 = tile * BM;
-  int next_m0 = -1;
+  // one step = three taps behind one hand-over barrier.  A tile = (pixel tile, 64 output channels); the n-tiles of one
+  // pixel tile are consecutive tile indices, i.e. run at the same time on neighbouring workgroups: the second one finds the
+  // window's lines in L2.
+  int m0 = (tile / nb_n) * BM, n0 = (tile % nb_n) * 64;
+  int next_m0 = -1, next_n0 = 0;
+  bool fresh = false;  // the next step follows an epilogue, which has drained this wave's loads itself (see there)
   auto step = [&](int kc, bool last_tile, auto r_c) {
     constexpr int r = decltype(r_c)::value;
     const int slot = (kc + r) & 1;  // = (3 kc + r) & 1
@@ -1664,14 +1684,17 @@ void conv_winp_f16x2_kernel(const WinPArgs p) {
     // the last tile: counting on it there let the weights of its second step slip through the wait)
     // (inline asm with a memory clobber: the s_barrier builtin is no memory operation to the optimiser, which may move the
     //  fragment reads of this step above it — it did, intermittently wrong results on the device)
-    if (r == 1 && (kc + 1 < KC || !last_tile)) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(CFG::W_IT) : "memory");
+    if ((r == 0 && fresh) || (ablate & 8)) asm volatile("s_barrier" ::: "memory");  // (8: loads requested, never waited for: WRONG results, timing only)
+    else if (r == 1 && (kc + 1 < KC || !last_tile)) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(CFG::W_IT) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // ... everybody's; and nobody reads the buffers that are loaded next any more
+    if (r == 0) fresh = false;
     __builtin_amdgcn_sched_barrier(0);
     const bool more = kc + 1 < KC;
-    if (r < 2) stage_b(kc, r + 1, slot ^ 1);
-    else if (more) stage_b(kc + 1, 0, slot ^ 1);
-    else if (!last_tile) stage_b(0, 0, slot ^ 1);
-    if (r == 0) {
+    if (ablate & 4) {
+    } else if (r < 2) stage_b(kc, r + 1, slot ^ 1, n0);
+    else if (more) stage_b(kc + 1, 0, slot ^ 1, n0);
+    else if (!last_tile) stage_b(0, 0, slot ^ 1, next_n0);
+    if (r == 0 && !(ablate & 4)) {
       if (more) stage_win(kc + 1, (kc + 1) & 1);
       else if (!last_tile) {
         setup_window(next_m0);
@@ -1715,6 +1738,15 @@ void conv_winp_f16x2_kernel(const WinPArgs p) {
       const int set = j & 1;
       if (j + 1 < 3) load_frags(j + 1, set ^ 1);
       __builtin_amdgcn_sched_barrier(0);
+#ifdef LK_WINP_ABLATE
+      if (ablate & 2) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b) acc[a][b][0] += (float)ah[set][a][0] + (float)al[set][a][1] + (float)bh[set][b][2] + (float)bl[set][b][3];
+        continue;
+      }
+#endif
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -1733,34 +1765,44 @@ void conv_winp_f16x2_kernel(const WinPArgs p) {
   const int e_row = lane >> 3, e_c0 = (lane & 7) * 8;
   float* img = reinterpret_cast<float*>(smem + CFG::EPI_OFF) + wave * (8 * PITCH);
   unsigned vmax = 0;
-  auto epilogue = [&](int m0_t) {
-    // every slice's addend planes and mask bytes are requested first (the fragment registers are free by now): their
-    // latency — an HBM miss each — is paid once per tile
-    f16x8 e_h2[NS], e_l2[NS];
-    uint2 e_mk[NS];
+  // Requests: every slice's addend planes and mask bytes are in flight before the first one is used — the first half
+  // already under the tile's last K chunk (the registers exist: the K loop needs ~170), the second half when the fragment
+  // registers are free — so that their latency, an HBM miss each, is not paid in the open.
+  constexpr int NH = 0;
+  f16x8 e_h2[NS], e_l2[NS];
+  uint2 e_mk[NS];
+  auto epi_request = [&](int m0_t, int n0_t, int s0, int s1) {
     const int mrow0 = m0_t + wave * 64 + e_row;
 #pragma unroll
     for (int sl = 0; sl < NS; ++sl) {
+      if (sl < s0 || sl >= s1) continue;
       const int m = mrow0 + sl * 8;
       const bool ok = m < M;
-      const int64_t e = ok ? (int64_t)m * 64 + e_c0 : 0;
+      const int64_t e = ok ? (int64_t)m * p.Co + n0_t + e_c0 : 0;
 #pragma unroll
       for (int j = 0; j < 8; ++j) e_h2[sl][j] = (_Float16)0.f, e_l2[sl][j] = (_Float16)0.f;
       e_mk[sl] = make_uint2(0x01010101u, 0x01010101u);
+      // (streaming accesses: read once / written once.  The L2 is needed for the window's lines, which the four channel
+      //  chunks of a tile come back to one after the other — measured: 2.3 x the operand bytes from the fabric when the
+      //  epilogue's 640 MB wash through the same cache with the default policy)
       if (p.add_h && ok) {
-        e_h2[sl] = *reinterpret_cast<const f16x8*>(p.add_h + e);
-        e_l2[sl] = *reinterpret_cast<const f16x8*>(p.add_l + e);
+        e_h2[sl] = __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(p.add_h + e));
+        e_l2[sl] = __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(p.add_l + e));
       }
       if (p.mask && ok) {
         const int mr = m - fdiv(m, p.div_mask) * p.mask_rows;
-        e_mk[sl] = *reinterpret_cast<const uint2*>(p.mask + (int64_t)mr * 64 + e_c0);
+        e_mk[sl] = *reinterpret_cast<const uint2*>(p.mask + (int64_t)mr * p.Co + n0_t + e_c0);
       }
     }
+  };
+  auto epilogue = [&](int m0_t, int n0_t) {
+    epi_request(m0_t, n0_t, NH, NS);
+    const int mrow0 = m0_t + wave * 64 + e_row;
     float mult[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) mult[j] = sc_out;
     if (p.scale) {
-      const f32x4 s0 = *reinterpret_cast<const f32x4*>(p.scale + e_c0), s1 = *reinterpret_cast<const f32x4*>(p.scale + e_c0 + 4);
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(p.scale + n0_t + e_c0), s1 = *reinterpret_cast<const f32x4*>(p.scale + n0_t + e_c0 + 4);
 #pragma unroll
       for (int j = 0; j < 4; ++j) mult[j] *= s0[j], mult[4 + j] *= s1[j];
     }
@@ -1793,32 +1835,53 @@ void conv_winp_f16x2_kernel(const WinPArgs p) {
         l[j] = (_Float16)(xs - (float)hh);
         vmax = max(vmax, __float_as_uint(xs) & 0x7fffffffu);
       }
-      const int64_t e = (int64_t)m * 64 + e_c0;
-      *reinterpret_cast<f16x8*>(p.out_h + e) = h;
-      *reinterpret_cast<f16x8*>(p.out_l + e) = l;
+      // Before this wave's FIRST store: everything it has requested so far has landed (the operands above are in
+      // registers, and the next tile's first weights were requested a whole epilogue ago) — said explicitly, because
+      // the next tile's first step then does not wait on vmcnt at all: the stores below would be in that count, and a
+      // store's acknowledgement (an HBM round trip per tile, in the open) is nothing the K loop has to wait for.
+      if (sl == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int64_t e = (int64_t)m * p.Co + n0_t + e_c0;
+      __builtin_nontemporal_store(h, reinterpret_cast<f16x8*>(p.out_h + e));
+      __builtin_nontemporal_store(l, reinterpret_cast<f16x8*>(p.out_l + e));
     }
+    fresh = true;
   };
 
   // prologue: the first tile's first window and first three taps
   setup_window(m0);
   setup_frag(m0);
   stage_win(0, 0);
-  stage_b(0, 0, 0);
+  stage_b(0, 0, 0, n0);
   // the second workgroup of a CU starts half a tile late (the host passes the delay in units of 64 s_sleep cycles): from
   // then on one workgroup's epilogue runs beside the other's K loop
   if (blockIdx.x >= (unsigned)(G / 2))
     for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(64);
   // (the chunk parity of the LDS buffers restarts with every tile: KC is even — checked by the host — so that the window
   //  buffer (kc & 1) and the weight slot ((kc + r) & 1) of a tile's first step are those the previous tile's last step fed)
+#ifdef LK_CONV_DEV
+  int trace_it = 0;
+#define LK_WINP_STAMP(k) \
+  if (tid == 0 && blockIdx.x < 1024 && trace_it < 16) g_winp_trace[(blockIdx.x * 16 + trace_it) * 3 + (k)] = __builtin_amdgcn_s_memtime();
+#else
+#define LK_WINP_STAMP(k)
+#endif
   while (true) {
     const bool last_tile = tile + G >= p.n_tiles;
-    next_m0 = (tile + G) * BM;
+    next_m0 = ((tile + G) / nb_n) * BM, next_n0 = ((tile + G) % nb_n) * 64;
+    LK_WINP_STAMP(0)
     for (int kc = 0; kc < KC; ++kc) {
+      if (kc == KC - 1) epi_request(m0, n0, 0, NH);
       step(kc, last_tile, std::integral_constant<int, 0>{});
       step(kc, last_tile, std::integral_constant<int, 1>{});
       step(kc, last_tile, std::integral_constant<int, 2>{});
     }
-    epilogue(m0);
+    LK_WINP_STAMP(1)
+    if (!(ablate & 1)) epilogue(m0, n0);
+    else if (acc[0][0][0] == 12345.678f) p.out_h[0] = (_Float16)1.f;
+    LK_WINP_STAMP(2)
+#ifdef LK_CONV_DEV
+    ++trace_it;
+#endif
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -1827,7 +1890,7 @@ void conv_winp_f16x2_kernel(const WinPArgs p) {
         for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     if (last_tile) break;
     tile += G;
-    m0 = next_m0;
+    m0 = next_m0, n0 = next_n0;
     if (!frag_const) setup_frag(m0);
   }
   if (p.amax_out) {
@@ -1841,6 +1904,12 @@ void conv_winp_f16x2_kernel(const WinPArgs p) {
 }  // namespace lk
 
 using namespace lk;
+
+#ifdef LK_CONV_DEV
+extern "C" int lk_winp_trace_read(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_winp_trace), sizeof(unsigned long long) * 1024 * 16 * 3) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int lk_absmax_f32(const float* x, int64_t n, const float* cscale, int64_t inner, int64_t C, unsigned* out,
                              void* stream) {
@@ -1896,6 +1965,8 @@ extern "C" int lk_conv_prep_weights_f16x2(const float* W, int64_t Co, int64_t Ci
                      (int)Ci, (int)taps, transpose, cscale, amax_ws, (_Float16*)planes, sexp);
   return check_launch("conv_prep_weights_kernel");
 }
+
+extern "C" int lk_conv_winp_eligible(int64_t N, int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t T, int mask_is_float);
 
 static int g_ablate = 0;  // development switch (config bits 8..10 of lk_conv_nhwc_f16x2): skip stores / MFMAs / staging
 
@@ -2023,7 +2094,7 @@ static int cu_count() {
 // into raster order here (the sum over taps is commutative); their weight slices must then form an arithmetic sequence
 // (forward: 0, 1, ..; backward-data: 8, 7, ..) — returns false (caller takes another kernel) otherwise.
 template <typename CFG>
-static bool launch_winp(const ConvGeom& g, const void* Ah, const void* Al, const void* Wh, const void* Wl, const int* a_sexp,
+static bool launch_winp(const ConvGeom& g, const void* Ah, const void* Al, const void* Wh /* chunk-major */, const void* Wl, const int* a_sexp,
                         const int* w_sexp, unsigned* amax_out, hipStream_t stream, const ConvVjp* fz, int* rc) {
   int wt[9];
   for (int t = 0; t < 9; ++t) wt[t] = -1;
@@ -2038,8 +2109,9 @@ static bool launch_winp(const ConvGeom& g, const void* Ah, const void* Al, const
     if (wt[t] != wt[0] + t * step) return false;
   WinPArgs p;
   const int64_t M = (int64_t)g.N * g.Hi * g.Wi;
-  p.M = (int)M, p.Hi = g.Hi, p.Wi = g.Wi, p.Ci = g.Ci, p.HW = g.Hi * g.Wi;
-  p.n_tiles = (int)((M + CFG::BM - 1) / CFG::BM);
+  p.M = (int)M, p.Hi = g.Hi, p.Wi = g.Wi, p.Ci = g.Ci, p.Co = g.Co, p.HW = g.Hi * g.Wi;
+  p.nb_m = (int)((M + CFG::BM - 1) / CFG::BM);
+  p.n_tiles = p.nb_m * (g.Co / 64);
   p.wt0 = wt[0], p.wtstep = step;
   p.div_hw = g.div_hw, p.div_w = g.div_w, p.div_mask = fz->div_mask;
   p.Ah = (const _Float16*)Ah, p.Al = (const _Float16*)Al, p.Wh = (const _Float16*)Wh, p.Wl = (const _Float16*)Wl;
@@ -2053,6 +2125,11 @@ static bool launch_winp(const ConvGeom& g, const void* Ah, const void* Al, const
     return e ? atoi(e) : 3;
   }();
   p.stagger = stagger * (g.Ci / 64);
+  static const int ablate = [] {
+    const char* e = getenv("LK_WINP_ABLATE");  // (development build only)
+    return e ? atoi(e) : 0;
+  }();
+  p.ablate = ablate;
   p.out_h = fz->out_h, p.out_l = fz->out_l, p.out_sexp = fz->out_sexp;
   p.amax_out = amax_out;
   static bool attr_set = false;
@@ -2100,11 +2177,12 @@ static int conv_dispatch(const void* in_h, const void* in_l, const int* in_sexp,
     return launch_conv<GramConvCfg>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz, gram_ws);
   }
   g_ablate = ((config >> 8) & 7) | ((config & 1048576) ? 16 : 0) | ((config & 2097152) ? 32 : 0);  // (development build only)
-  // persistent window form (config bit 27; fused launches with 64 output channels): see conv_winp_f16x2_kernel
-  if ((config & 134217728) && fz && !gram_ws && T == 9 && in_mul == 1 && Hc == Hi && Wc == Wi && Wi <= 47 && Ci % 32 == 0 && Co == 64 &&
-      g.dense && !g.pmajor && N * Hi * Wi * Ci < (1ll << 30) && N * Hi * Wi >= 512 && !(fz->mask && fz->mask_float)) {
+  // persistent window form (fused launches with 64 output channels whose caller also handed over chunk-major weights;
+  // config bit 27 switches it off): see conv_winp_f16x2_kernel
+  if (fz && fz->wc_h && !(config & 134217728) && !gram_ws && lk_conv_winp_eligible(N, Hi, Wi, Ci, Co, T, fz->mask && fz->mask_float) &&
+      in_mul == 1 && Hc == Hi && Wc == Wi && g.dense) {
     int rc = LK_OK;
-    if (launch_winp<WinPCfg<256>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, amax_out, st, fz, &rc)) return rc;
+    if (launch_winp<WinPCfg<256>>(g, in_h, in_l, fz->wc_h, fz->wc_l, in_sexp, w_sexp, amax_out, st, fz, &rc)) return rc;
   }
   // "window" form (config bit 22): nine taps inside [-1, 1]^2 on the input grid, maps of more than 64 pixels (small maps
   // run position-major with tap skipping), enough tiles to fill the chip; bit 23: the 512-pixel tile for 64 output channels
@@ -2200,6 +2278,15 @@ static int conv_dispatch(const void* in_h, const void* in_l, const int* in_sexp,
               : launch_conv<ConvCfg<128, 128, 32, 2, 2>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz);
 }
 
+// Does a fused 3 x 3 / stride-1 launch of this shape qualify for the persistent window form (conv_winp_f16x2_kernel)?  The
+// caller then prepares chunk-major weights for it (lk_conv_nhwc_f16x2_vjp_wc).
+extern "C" int lk_conv_winp_eligible(int64_t N, int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t T, int mask_is_float) {
+  return T == 9 && Wi <= 47 && Hi * Wi >= 16 && Ci % 32 == 0 && Ci >= 32 && Co >= 64 && Co % 64 == 0 && N * Hi * Wi * Ci < (1ll << 30) &&
+                 N * Hi * Wi * Co < (1ll << 31) && N * Hi * Wi >= 512 && !mask_is_float
+             ? 1
+             : 0;
+}
+
 // Workgroups (= 64 x 64 partials) of a fused launch that also accumulates the Gram of its result; 0 = not eligible: the
 // result must have exactly 64 channels, the map more than 64 pixels (position-major tiles mix pixels of many images into a
 // wave in another order; they are small layers anyway), no explicit tile / pipeline variant may be selected, and there
@@ -2232,8 +2319,10 @@ static int conv_vjp_impl(const void* in_h, const void* in_l, const int* in_sexp,
                          const void* zero16, const void* add_h, const void* add_l, const int* add_sexp,
                          const void* mask, int mask_is_float, const void* mult_amax, int64_t mask_rows,
                          const float* scale, const void* scale_amax, void* out_h, void* out_l, int* out_sexp,
-                         void* out_amax, int config, void* stream, float* gram_ws) {
+                         void* out_amax, int config, void* stream, float* gram_ws, const void* wc_h = nullptr,
+                         const void* wc_l = nullptr) {
   LK_REQUIRE(w_l1 && out_h && out_l && out_sexp && out_amax, "lk_conv_nhwc_f16x2_vjp: null pointer");
+  LK_REQUIRE(!wc_h == !wc_l, "lk_conv_nhwc_f16x2_vjp_wc: incomplete chunk-major weights");
   LK_REQUIRE(Co % 8 == 0, "lk_conv_nhwc_f16x2_vjp: Co % 8 == 0");
   LK_REQUIRE(!add_h || (add_l && add_sexp), "lk_conv_nhwc_f16x2_vjp: incomplete addend");
   LK_REQUIRE(!mask || mask_rows > 0, "lk_conv_nhwc_f16x2_vjp: mask_rows");
@@ -2246,6 +2335,7 @@ static int conv_vjp_impl(const void* in_h, const void* in_l, const int* in_sexp,
   fz.div_mask = make_fastdiv((int)fz.mask_rows);
   fz.scale = scale, fz.scale_amax = (const unsigned*)scale_amax;
   fz.out_h = (_Float16*)out_h, fz.out_l = (_Float16*)out_l, fz.out_sexp = out_sexp;
+  fz.wc_h = (const _Float16*)wc_h, fz.wc_l = (const _Float16*)wc_l;
   return conv_dispatch(in_h, in_l, in_sexp, N, Hi, Wi, Ci, w_h, w_l, w_sexp, Co, Ho, Wo, 1, Ho, Wo, 1, 0, 0, T, taps, zero16,
                        nullptr, 0, (unsigned*)out_amax, config & ~(1 | 4 | 8 | 16 | 32 | 64 | 2048), stream, &fz, gram_ws);
 }
@@ -2260,6 +2350,21 @@ extern "C" int lk_conv_nhwc_f16x2_vjp(const void* in_h, const void* in_l, const 
   return conv_vjp_impl(in_h, in_l, in_sexp, in_amax, N, Hi, Wi, Ci, w_h, w_l, w_sexp, w_l1, Co, Ho, Wo, T, taps, zero16, add_h,
                        add_l, add_sexp, mask, mask_is_float, mult_amax, mask_rows, scale, scale_amax, out_h, out_l, out_sexp,
                        out_amax, config, stream, nullptr);
+}
+
+// lk_conv_nhwc_f16x2_vjp with the weights ALSO in chunk-major order (wc_h / wc_l: [tap][Ci / 16][Co][16] fp16 per plane, same
+// scale as w_h / w_l): shapes for which lk_conv_winp_eligible says so run the persistent window form, everything else
+// ignores the extra planes.
+extern "C" int lk_conv_nhwc_f16x2_vjp_wc(const void* in_h, const void* in_l, const int* in_sexp, const void* in_amax, int64_t N,
+                                         int64_t Hi, int64_t Wi, int64_t Ci, const void* w_h, const void* w_l, const int* w_sexp,
+                                         const float* w_l1, const void* wc_h, const void* wc_l, int64_t Co, int64_t Ho, int64_t Wo,
+                                         int64_t T, const int* taps, const void* zero16, const void* add_h, const void* add_l,
+                                         const int* add_sexp, const void* mask, int mask_is_float, const void* mult_amax,
+                                         int64_t mask_rows, const float* scale, const void* scale_amax, void* out_h, void* out_l,
+                                         int* out_sexp, void* out_amax, int config, void* stream) {
+  return conv_vjp_impl(in_h, in_l, in_sexp, in_amax, N, Hi, Wi, Ci, w_h, w_l, w_sexp, w_l1, Co, Ho, Wo, T, taps, zero16, add_h,
+                       add_l, add_sexp, mask, mask_is_float, mult_amax, mask_rows, scale, scale_amax, out_h, out_l, out_sexp,
+                       out_amax, config, stream, nullptr, wc_h, wc_l);
 }
 
 // lk_conv_nhwc_f16x2_vjp that ALSO leaves the Gram of its result, o^T o over all output pixels, as

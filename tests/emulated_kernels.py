@@ -126,8 +126,16 @@ class EmulatedKernels:
     #: (lk_conv_vjp_gram_parts); the emulation does it for every 64-channel result so that tiny CPU cases walk the path
     gram_min_rows = 0
 
+    def conv_winp_eligible(self, N, Hi, Wi, Ci, Co, T, mask_is_float=False) -> bool:
+        # (mirrors lk_conv_winp_eligible, so that the host logic around the chunk-major weights is exercised on the CPU)
+        return bool(T == 9 and Wi <= 47 and Hi * Wi >= 64 and Ci % 32 == 0 and Ci >= 32 and Co >= 64 and Co % 64 == 0 and N * Hi * Wi >= 512
+                    and not mask_is_float)
+
     def conv_nhwc_f16x2_vjp(self, x, wplanes, wsexp, w_l1, Ho, Wo, taps, add=None, mult=None, mult_amax=None, scale=None,
-                            scale_amax=None, config=None, want_gram=False, amax_word=None):
+                            scale_amax=None, config=None, want_gram=False, amax_word=None, wplanes_chunked=None):
+        if wplanes_chunked is not None:  # the same weights, chunk-major: must agree with the GEMM-natural planes
+            two, T, N_, Kd = wplanes.shape
+            assert torch.equal(wplanes_chunked, wplanes.view(two, T, N_, Kd // 16, 16).permute(0, 1, 3, 2, 4))
         """lk_conv_nhwc_f16x2_vjp: the convolution, then (conv + add) * mult * scale split with the scale of the
         guaranteed bound max|in| * l1(W) (+ ...); the measured max|.| rides along as ``amax``"""
         N = x.shape[0]

@@ -278,6 +278,7 @@ def test_fused_launch_accumulates_the_gram_of_its_result(variant, n_img, monkeyp
 
     K = get_kernels()
     monkeypatch.setattr(K, "fuse_gram", True)  # (off by default: it pays on one stream, not in the overlapped step)
+    monkeypatch.setattr(K, "use_winp", False)  # (bit for bit against the SAME kernel without the Gram, not the persistent form)
     cin, cout, k, s, p, H = 64, 64, 3, 1, 1, 32
     m = _conv(cin, cout, k, s, p)
     S, B = 1, n_img
@@ -365,6 +366,57 @@ def test_window_form_backward_forward_and_fused_epilogue(cin, cout, H, n_img, cf
     assert rel(fused.float(), want_v) < 1e-5
     assert torch.equal(fused.sexp, fused_ref.sexp) and rel(fused.float(), fused_ref.float()) < 1e-6
     assert abs(fused.amax.item() - fused.float().abs().max().item()) <= 1e-5 * fused.amax.item()
+
+
+WINP_CASES = [(64, 64, 32, 131), (64, 64, 20, 131), (128, 64, 16, 290), (128, 128, 16, 37), (256, 256, 8, 300), (64, 128, 12, 75),
+              (512, 512, 4, 200), (64, 64, 32, 1152), (64, 96, 9, 64)]
+
+
+@pytest.mark.parametrize("cin,cout,H,n_img", WINP_CASES, ids=[f"{c[0]}-{c[1]}-{c[2]}x{c[2]}-n{c[3]}" for c in WINP_CASES])
+def test_persistent_window_form_of_the_fused_launch(cin, cout, H, n_img):
+    """conv_winp_f16x2_kernel (lk_conv_nhwc_f16x2_vjp_wc: chunk-major weights, two persistent workgroups per CU, the next
+    tile's operands requested under the epilogue) against fp64 and against the generic kernel: ragged last tiles, tile
+    strides that are no whole number of images, several 64-channel column tiles, several tiles per workgroup (the 1152-image
+    case is the c4 launch), with and without addend / mask / channel scale."""
+    from laplace_amd import conv as cv
+    from laplace_amd._lib import get_kernels
+
+    K = get_kernels()
+    m = _conv(cin, cout, 3, 1, 1)
+    N = n_img
+    torch.manual_seed(29)
+    g = torch.randn(N, cout, H, H, device=DEV) * 1e-2
+    gs = K.split_f16x2(g.permute(0, 2, 3, 1).contiguous())
+    prep = cv.PreparedConv(m)
+    assert K.conv_winp_eligible(N, H, H, cout, cin, 9)
+    S = 3 if N % 3 == 0 else 1
+    B = N // S
+    mask = (torch.rand(B, H, H, cin, device=DEV) > 0.4).to(torch.uint8)
+    addend = K.split_f16x2(torch.randn(N, H, H, cin, device=DEV) * 0.05)
+    sc = (torch.rand(cin, device=DEV) * 1.5 + 0.25).contiguous()
+    want_b = None
+    if N * H * H * cin <= 40e6:  # (the fp64 reference on the host: small cases only)
+        want_b = torch.nn.grad.conv2d_input((N, cin, H, H), m.weight.double().cpu(), g.double().cpu(), stride=1, padding=1)
+    prev = K.conv_config
+    try:
+        for kw in ({}, {"add": addend}, {"mult": mask}, {"add": addend, "mult": mask, "scale": sc, "scale_amax": K.absmax(sc)}):
+            K.conv_config = 2
+            fused = cv.conv_backward_data_vjp(prep, gs, (H, H), **kw)
+            K.conv_config = 2 | (1 << 27)  # (bit 27: the persistent form off)
+            ref = cv.conv_backward_data_vjp(prep, gs, (H, H), **kw)
+            assert torch.equal(fused.sexp, ref.sexp) and rel(fused.float(), ref.float()) < 4e-6, sorted(kw)  # (other order of the K steps)
+            assert abs(fused.amax.item() - fused.float().abs().max().item()) <= 1e-5 * fused.amax.item()
+            if want_b is not None:
+                want = want_b.permute(0, 2, 3, 1)
+                if "add" in kw:
+                    want = want + addend.float().double().cpu()
+                if "mult" in kw:
+                    want = (want.reshape(S, B, H, H, cin) * mask.double().cpu()).reshape(N, H, H, cin)
+                if "scale" in kw:
+                    want = want * sc.double().cpu()
+                assert rel(fused.float(), want) < 1e-5, sorted(kw)
+    finally:
+        K.conv_config = prev
 
 
 @pytest.mark.parametrize("n,where", [(4096, 0), (4096, 4095), (4100, 2049), (4099, 4098), (1 << 22, 1234567), (3 * (1 << 20) + 8, 17)])

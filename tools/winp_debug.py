@@ -20,7 +20,7 @@ kw = {"add": add} if mode == "add" else {"mult": mask} if mode == "mask" else {"
 print("mode", mode)
 ref = cv.conv_backward_data_vjp(prep, g, (H, H), **kw).float()
 for rep in range(2):
-    K.conv_config = 2 | WP
+    K.conv_config = 2
     out = cv.conv_backward_data_vjp(prep, g, (H, H), **kw).float()
     torch.cuda.synchronize()
     err = (out - ref).abs().reshape(-1, 64)          # [M, 64]
