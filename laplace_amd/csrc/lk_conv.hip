@@ -1542,7 +1542,15 @@ void conv_winp_f16x2_kernel(const WinPArgs p) {
   const int lr = lane & 31, lh = lane >> 5;
   const int M = p.M, KC = p.Ci / 16, Wi = p.Wi;
   const int G = gridDim.x;
+  // XCD-aware tile order for 64 output channels: consecutive block ids run on different XCDs (id % 8); every XCD gets a
+  // contiguous range of the pixel tiles in flight together, so that neighbours (shared halo rows) meet in ONE L2 (334 ->
+  // 321 us on the c4 launch).  With several 64-channel column tiles per pixel tile the same order puts all the readers of
+  // one window into one L2 at the same moment and LOSES (256 channels: 264 -> 314 us, 512: 289 -> 385): they stay spread.
   int tile = blockIdx.x;
+  if (p.Co == 64) {
+    const int q = G / 8, r = G % 8, x = tile % 8, j = tile / 8;
+    tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+  }
   if (tile >= p.n_tiles) return;  // (uniform)
 #ifdef LK_WINP_ABLATE  // development switches, compile-time (a run-time switch perturbs this kernel's schedule beyond
   constexpr int ablate = LK_WINP_ABLATE;  // comparison): 1 skip the epilogue, 2 the MFMAs, 4 the in-loop staging

@@ -217,7 +217,10 @@ class HipKron(_KronBase):
         results = {}
         infos = []
         if dense:
-            mats = [self.kfacs[bi][fi].contiguous() for _, bi, fi in dense]
+            # (the solver is fp32: factors in another floating dtype — an fp64 model, see backend._twin — are solved in fp32
+            #  and their eigenpairs handed back in their own dtype)
+            f_dtype = self.kfacs[dense[0][1]][dense[0][2]].dtype
+            mats = [self.kfacs[bi][fi].to(torch.float32).contiguous() for _, bi, fi in dense]
             streams = None
             if mats[0].is_cuda and n_streams > 1 and len(mats) > 1:
                 dev = mats[0].device
@@ -226,7 +229,7 @@ class HipKron(_KronBase):
             # one call for all factors: the native scheduler interleaves the solves over the streams
             solved = K.syevj_batched(mats, clamp=True, streams=streams)
             for (_, bi, fi), (l, Q, info) in zip(dense, solved):
-                results[(bi, fi)] = (l, Q)
+                results[(bi, fi)] = (l.to(f_dtype), Q.to(f_dtype))
                 infos.append(info)
             if streams is not None:
                 for st in streams:
@@ -542,7 +545,15 @@ class HipKronDecomposed(_KronDecomposedBase):
             return _KronLogdetBlocks.apply(self.deltas, self)
         total = 0
         for ls, delta in zip(self.eigenvalues, self.deltas):
-            if len(ls) == 1:
+            if any(l.dtype != torch.float32 for l in ls):  # (fp64 / fp16 posteriors: the formula itself, matrix.py:381-404)
+                if len(ls) == 1:
+                    total = total + torch.log(ls[0] + delta).sum()
+                elif self.damping:
+                    sd = torch.sqrt(delta)
+                    total = total + torch.log(torch.outer(ls[0] + sd, ls[1] + sd)).sum()
+                else:
+                    total = total + torch.log(torch.outer(ls[0], ls[1]) + delta).sum()
+            elif len(ls) == 1:
                 total = total + _KronLogdet.apply(ls[0], None, delta)
             elif len(ls) == 2:
                 l1, l2 = ls

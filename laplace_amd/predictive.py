@@ -125,8 +125,8 @@ def glm_variance_kron(backend, x, post, _grouped: bool = False):
             return out
     K = get_kernels()
     f, tape, grad_fn = backend._forward(x, keep_tap_splits=True)  # the eigenbasis rotations re-use the split inputs
-    if tape.uncovered or post.damping:
-        raise NotImplementedError("fused Kron predictive needs Linear/Conv2d-only models and damping=False")
+    if tape.uncovered:
+        raise NotImplementedError("fused Kron predictive needs Linear/Conv2d-only models")
     B, C = f.shape
     grads = _grads(grad_fn, _identity_seeds(f))
     fvar = torch.zeros(B, C, C, dtype=torch.float32, device=f.device)
@@ -137,6 +137,12 @@ def glm_variance_kron(backend, x, post, _grouped: bool = False):
             tape.release()
             raise NotImplementedError("merged single-factor weight block: use the Jacobian route")
         (Q1, Q2), (l1, l2), delta = post.eigenvectors[blk], post.eigenvalues[blk], post.deltas[blk]
+        if post.damping:
+            # laplace/utils/matrix.py:397-399, 441-444: the damped block is (Q1 (l1 + sqrt d) Q1^T) x (Q2 (l2 + sqrt d) Q2^T) —
+            # eigenvalues outer(l1 + sqrt d, l2 + sqrt d) instead of outer(l1, l2) + d: the same kernels with shifted
+            # eigenvalues and no additive term
+            sq = torch.sqrt(delta.detach().to(l1.dtype))
+            l1, l2, delta = l1 + sq, l2 + sq, torch.zeros_like(delta)
         blk += 1
         Qb = lb = delta_b = None
         if tap.has_bias:

@@ -131,3 +131,42 @@ def test_sampling_smoke_on_emulation(emulated):
 @pytest.mark.gpu
 def test_sampling_smoke_gpu():
     _sampling_smoke("cuda")
+
+
+def test_parameters_outside_linear_and_conv_take_the_generic_route():
+    """`jacobians` / `diag` / `full` of a model with parameters the kernels have no rule for (LayerNorm, an unfrozen
+    BatchNorm affine): the reference's functorch route (laplace/curvature/curvature.py:88-129, 375-433) serves them — no
+    NotImplementedError — and only `kron` refuses, as the reference does (docs/index.md:364-366)."""
+    import pytest
+    from torch.func import functional_call, jacrev, vmap
+
+    from laplace_amd import HipGGN, _lib
+    from tests.emulated_kernels import EmulatedKernels
+
+    prev = _lib.set_kernels_for_testing(EmulatedKernels())
+    try:
+        torch.manual_seed(0)
+        for m in (torch.nn.Sequential(torch.nn.Linear(4, 6), torch.nn.LayerNorm(6), torch.nn.Tanh(), torch.nn.Linear(6, 3)),
+                  torch.nn.Sequential(torch.nn.Conv2d(2, 4, 3, padding=1), torch.nn.BatchNorm2d(4), torch.nn.ReLU(),
+                                      torch.nn.AdaptiveAvgPool2d(1), torch.nn.Flatten(), torch.nn.Linear(4, 3)).eval()):
+            conv = isinstance(m[0], torch.nn.Conv2d)
+            X = torch.randn(5, 2, 6, 6) if conv else torch.randn(5, 4)
+            y = torch.randint(3, (5,))
+            b = HipGGN(m, "classification")
+            assert b._tape().uncovered
+            Js, f = b.jacobians(X)
+            params = {k: v for k, v in m.named_parameters()}
+            buffers = {k: v for k, v in m.named_buffers()}
+            J = vmap(lambda x: jacrev(lambda p: functional_call(m, (p, buffers), (x[None],))[0])(params))(X)
+            want = torch.cat([J[k].reshape(5, 3, -1) for k in params], -1)
+            assert torch.allclose(Js, want, atol=1e-6)
+            _, d = b.diag(X, y)
+            _, H = b.full(X, y)
+            assert torch.allclose(torch.diagonal(H), d, rtol=1e-5, atol=1e-7)
+            p = torch.softmax(f, -1)
+            Hw = torch.einsum("ncp,nck,nkq->pq", want, torch.diag_embed(p) - p[:, :, None] * p[:, None, :], want)
+            assert torch.allclose(H, Hw, rtol=1e-4, atol=1e-6)
+            with pytest.raises(NotImplementedError, match="KFAC supports"):
+                b.kron(X, y, 5)
+    finally:
+        _lib.set_kernels_for_testing(prev)
