@@ -1527,8 +1527,9 @@ struct WinPArgs {  // (a slim argument block: everything here stays in scalar re
   unsigned* amax_out;
 };
 
-#ifdef LK_CONV_DEV
-// (development build) per workgroup and tile: s_memtime at the start of the K loop, at its end, at the end of the epilogue
+#ifdef LK_WINP_TRACE
+// (development build, -DLK_WINP_TRACE) per workgroup and tile: s_memtime at the start of the K loop, at its end, at the end
+// of the epilogue; slot 15 of a workgroup: its hardware id (XCC / SE / CU)
 __device__ unsigned long long g_winp_trace[1024 * 16 * 3];
 #endif
 
@@ -1697,18 +1698,6 @@ void conv_winp_f16x2_kernel(const WinPArgs p) {
     else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // ... everybody's; and nobody reads the buffers that are loaded next any more
     if (r == 0) fresh = false;
     __builtin_amdgcn_sched_barrier(0);
-    const bool more = kc + 1 < KC;
-    if (ablate & 4) {
-    } else if (r < 2) stage_b(kc, r + 1, slot ^ 1, n0);
-    else if (more) stage_b(kc + 1, 0, slot ^ 1, n0);
-    else if (!last_tile) stage_b(0, 0, slot ^ 1, next_n0);
-    if (r == 0 && !(ablate & 4)) {
-      if (more) stage_win(kc + 1, (kc + 1) & 1);
-      else if (!last_tile) {
-        setup_window(next_m0);
-        stage_win(0, (kc + 1) & 1);
-      }
-    }
     // (opaque to the optimiser: the fragment addresses and tap-validity selects below are invariant over the K loop, and
     //  hipcc otherwise hoists all 2 x 18 of them — and their 18 lane masks — out of it and spills them)
     int wbase = (kc & 1) * CFG::WIN;
@@ -1719,10 +1708,15 @@ void conv_winp_f16x2_kernel(const WinPArgs p) {
       av[a] = a_valid[a];
       asm volatile("" : "+v"(av[a]));
     }
-    const char* pb = smem + 2 * CFG::WIN + slot * CFG::B_STEP;
-    // fragments of tap j + 1 are requested before the MFMAs of tap j are issued (two register sets): while this workgroup's
-    // partner on the CU is in its epilogue nobody else covers the LDS round trip
+    // Fragments of tap j + 1 are requested before the MFMAs of tap j are issued (two register sets): while this workgroup's
+    // partner on the CU is in its epilogue nobody else covers the LDS round trip.  The reads are issued as asm and waited
+    // for by COUNT: hipcc books the LDS-DMA instructions between them as possible LDS traffic and would wait lgkmcnt(0) —
+    // for both sets — in front of the first MFMA (it did: the first sixteen reads of every step were paid in the open).
+    // wait_set ties the set's registers to the wait, so that no use of them can be placed above it.
     f16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+    static_assert(TM == 2 && TN == 2, "wait_set names eight registers");
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    auto lds_read = [&](f16x8& dst, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr)); };
     auto load_frags = [&](int j, int set) {
       const int t = r * 3 + j;  // compile-time after unrolling
       const int shift = (t / 3) * Wi + t % 3;  // window pixel shift of tap t (raster order)
@@ -1731,20 +1725,50 @@ void conv_winp_f16x2_kernel(const WinPArgs p) {
         const int px = a_px0 + 32 * a + shift;
         const int ad = wbase + (px * 2 + (lh ^ ((px >> 3) & 1))) * 16;
         const bool ok = (av[a] >> t) & 1u;
-        ah[set][a] = *reinterpret_cast<const f16x8*>(smem + (ok ? ad : (int)CFG::ZERO_OFF));
-        al[set][a] = *reinterpret_cast<const f16x8*>(smem + (ok ? ad + CFG::W_PLANE : (int)CFG::ZERO_OFF));
+        lds_read(ah[set][a], lds0 + (unsigned)(ok ? ad : (int)CFG::ZERO_OFF));
+        lds_read(al[set][a], lds0 + (unsigned)(ok ? ad + CFG::W_PLANE : (int)CFG::ZERO_OFF));
       }
+      const unsigned pbo = lds0 + 2 * CFG::WIN + slot * CFG::B_STEP;
 #pragma unroll
       for (int b = 0; b < TN; ++b) {
-        bh[set][b] = *reinterpret_cast<const f16x8*>(pb + b_addr[b] + (j * 2) * CFG::B_TAP);
-        bl[set][b] = *reinterpret_cast<const f16x8*>(pb + b_addr[b] + (j * 2 + 1) * CFG::B_TAP);
+        lds_read(bh[set][b], pbo + b_addr[b] + (j * 2) * CFG::B_TAP);
+        lds_read(bl[set][b], pbo + b_addr[b] + (j * 2 + 1) * CFG::B_TAP);
       }
     };
+    auto wait_set = [&](int set, bool younger) {  // the set has arrived (`younger`: the eight reads issued after it may still fly)
+      if (younger)
+        asm volatile("s_waitcnt lgkmcnt(8)"
+                     : "+v"(ah[set][0]), "+v"(ah[set][1]), "+v"(al[set][0]), "+v"(al[set][1]), "+v"(bh[set][0]),
+                       "+v"(bh[set][1]), "+v"(bl[set][0]), "+v"(bl[set][1]));
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(ah[set][0]), "+v"(ah[set][1]), "+v"(al[set][0]), "+v"(al[set][1]), "+v"(bh[set][0]),
+                       "+v"(bh[set][1]), "+v"(bl[set][0]), "+v"(bl[set][1]));
+    };
     load_frags(0, 0);
+    // the next step's operands are requested BEHIND this step's first fragment reads: the LDS round trip of those reads
+    // (in the open behind every hand-over barrier) then runs under the issue of the staging instructions instead of after it
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const bool more = kc + 1 < KC;
+      if (ablate & 4) {
+      } else if (r < 2) stage_b(kc, r + 1, slot ^ 1, n0);
+      else if (more) stage_b(kc + 1, 0, slot ^ 1, n0);
+      else if (!last_tile) stage_b(0, 0, slot ^ 1, next_n0);
+      if (r == 0 && !(ablate & 4)) {
+        if (more) stage_win(kc + 1, (kc + 1) & 1);
+        else if (!last_tile) {
+          setup_window(next_m0);
+          stage_win(0, (kc + 1) & 1);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const int set = j & 1;
       if (j + 1 < 3) load_frags(j + 1, set ^ 1);
+      wait_set(set, j + 1 < 3);
       __builtin_amdgcn_sched_barrier(0);
 #ifdef LK_WINP_ABLATE
       if (ablate & 2) {
@@ -1866,10 +1890,14 @@ void conv_winp_f16x2_kernel(const WinPArgs p) {
     for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(64);
   // (the chunk parity of the LDS buffers restarts with every tile: KC is even — checked by the host — so that the window
   //  buffer (kc & 1) and the weight slot ((kc + r) & 1) of a tile's first step are those the previous tile's last step fed)
-#ifdef LK_CONV_DEV
+#ifdef LK_WINP_TRACE
   int trace_it = 0;
+  if (tid == 0 && blockIdx.x < 1024) {
+    g_winp_trace[(blockIdx.x * 16 + 15) * 3] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
+    g_winp_trace[(blockIdx.x * 16 + 15) * 3 + 1] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
+  }
 #define LK_WINP_STAMP(k) \
-  if (tid == 0 && blockIdx.x < 1024 && trace_it < 16) g_winp_trace[(blockIdx.x * 16 + trace_it) * 3 + (k)] = __builtin_amdgcn_s_memtime();
+  if (tid == 0 && blockIdx.x < 1024 && trace_it < 15) g_winp_trace[(blockIdx.x * 16 + trace_it) * 3 + (k)] = __builtin_amdgcn_s_memtime();
 #else
 #define LK_WINP_STAMP(k)
 #endif
@@ -1887,7 +1915,7 @@ void conv_winp_f16x2_kernel(const WinPArgs p) {
     if (!(ablate & 1)) epilogue(m0, n0);
     else if (acc[0][0][0] == 12345.678f) p.out_h[0] = (_Float16)1.f;
     LK_WINP_STAMP(2)
-#ifdef LK_CONV_DEV
+#ifdef LK_WINP_TRACE
     ++trace_it;
 #endif
 #pragma unroll
@@ -1913,7 +1941,7 @@ void conv_winp_f16x2_kernel(const WinPArgs p) {
 
 using namespace lk;
 
-#ifdef LK_CONV_DEV
+#ifdef LK_WINP_TRACE
 extern "C" int lk_winp_trace_read(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_winp_trace), sizeof(unsigned long long) * 1024 * 16 * 3) == hipSuccess ? 0 : -1;
 }
@@ -2145,7 +2173,11 @@ static bool launch_winp(const ConvGeom& g, const void* Ah, const void* Al, const
     (void)hipFuncSetAttribute((const void*)conv_winp_f16x2_kernel<CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS);
     attr_set = true;
   }
-  const int grid = p.n_tiles < 2 * cu_count() ? p.n_tiles : 2 * cu_count();  // two workgroups per CU
+  static const int wg_per_cu = [] {
+    const char* e = getenv("LK_WINP_WGS");  // (tuning knob: persistent workgroups per CU, 1 or 2)
+    return e && atoi(e) == 1 ? 1 : 2;
+  }();
+  const int grid = p.n_tiles < wg_per_cu * cu_count() ? p.n_tiles : wg_per_cu * cu_count();  // two workgroups per CU
   hipLaunchKernelGGL((conv_winp_f16x2_kernel<CFG>), dim3((unsigned)grid), dim3(CFG::NT), CFG::LDS, stream, p);
   *rc = check_launch("conv_winp_f16x2_kernel");
   return true;
