@@ -235,24 +235,6 @@ int lk_conv_nhwc_f16x2_vjp_wc(const void* in_h, const void* in_l, const int* in_
                               const void* scale_amax, void* out_h, void* out_l, int* out_sexp, void* out_amax, int config,
                               void* stream);
 
-/* lk_conv_nhwc_f16x2_vjp that ALSO accumulates the Gram of what it emits, o^T o over all N*Ho*Wo output pixels — the G
- * factor of the layer whose output cotangent the launch produces (the per-pass hooks of
- * laplace/curvature/curvlinops.py:57-62 sum g g^T over (sample, position)) — so that the separate pass
- * lk_gram_tn_f16x2 over the cotangent (a full re-read from HBM) disappears.  The result must have exactly 64 channels
- * (one wave of the 256 x 64 tile holds all channels of its pixels); lk_conv_vjp_gram_parts returns the number of partial
- * 64 x 64 blocks the launch writes to gram_ws (>= parts * 4096 floats; upper 32 x 32 tiles only, in units of
- * 2^(-2 out_sexp)), 0 when the shape / config is not eligible.  lk_gram_partials_reduce_f16x2 adds
- * alpha * 2^(-2 sexp) * (sum of the partials, in a fixed order) to the upper tiles of G [C][C] (C = 64). */
-int64_t lk_conv_vjp_gram_parts(int64_t N, int64_t Ho, int64_t Wo, int64_t Co, int config);
-int lk_conv_nhwc_f16x2_vjp_gram(const void* in_h, const void* in_l, const int* in_sexp, const void* in_amax, int64_t N,
-                                int64_t Hi, int64_t Wi, int64_t Ci, const void* w_h, const void* w_l, const int* w_sexp,
-                                const float* w_l1, int64_t Co, int64_t Ho, int64_t Wo, int64_t T, const int* taps,
-                                const void* zero16, const void* add_h, const void* add_l, const int* add_sexp,
-                                const void* mask, int mask_is_float, const void* mult_amax, int64_t mask_rows,
-                                const float* scale, const void* scale_amax, void* out_h, void* out_l, int* out_sexp,
-                                void* out_amax, float* gram_ws, int64_t gram_ws_floats, int config, void* stream);
-int lk_gram_partials_reduce_f16x2(const float* parts, int64_t nparts, int64_t C, const int* sexp, float alpha, float* G,
-                                  void* stream);
 
 /* Element-wise VJP of the NHWC sweep with a split result (csrc/lk_sweep16.hip):
  *     out[s][e] = (g[s][e] + g2[s][e]) * M[e] * scale[e % C]      e < per = B*H*W*C,  s < S

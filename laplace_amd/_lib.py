@@ -72,11 +72,6 @@ SIGNATURES = {
     "lk_conv_nhwc_f16x2_vjp_wc": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64,
                                          _i64, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _int,
                                          _vp]),
-    "lk_conv_vjp_gram_parts": (_i64, [_i64, _i64, _i64, _i64, _int]),
-    "lk_conv_nhwc_f16x2_vjp_gram": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64,
-                                           _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _i64, _vp, _vp, _vp, _vp, _vp,
-                                           _vp, _vp, _i64, _int, _vp]),
-    "lk_gram_partials_reduce_f16x2": (_int, [_vp, _i64, _i64, _vp, _f32, _vp, _vp]),
     "lk_vjp_nhwc_split_f16x2": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "lk_bn_act_fwd_nhwc_f16x2": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "lk_unsplit_transpose_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
@@ -131,15 +126,12 @@ class LaplaceHipError(RuntimeError):
 class SplitTensor:
     """Two fp16 planes ``planes[0] + planes[1] ~= x * 2**sexp`` of a tensor (include/laplace_hip.h, lk_split_f16x2)."""
 
-    __slots__ = ("planes", "sexp", "amax", "gram_parts")
+    __slots__ = ("planes", "sexp", "amax")
 
     def __init__(self, planes: torch.Tensor, sexp: torch.Tensor, amax: torch.Tensor | None = None):
         #: ``amax``: device word with the MEASURED max|x| when the producer provides one (fused convolution epilogue);
         #: consumers that need a bound otherwise use 2**(15 - sexp)
         self.planes, self.sexp, self.amax = planes, sexp, amax
-        #: partial blocks ``[parts, C, C]`` of ``X^T X`` over all rows (units of 2**(-2 sexp)) when the producing launch
-        #: accumulated them on the way (lk_conv_nhwc_f16x2_vjp_gram): a G factor then needs only their reduction
-        self.gram_parts = None
 
     @property
     def shape(self):
@@ -448,15 +440,6 @@ class HipKernels:
             _ptr(out), 1 if accumulate else 0, _ptr(amax_out), int(cfg), self._stream(out.device))), "lk_conv_nhwc_f16x2")
         return out
 
-    #: ``True`` (env LK_FUSE_GRAM=1): a fused convolution launch whose result is a 64-channel output cotangent also
-    #: accumulates the Gram of that result (lk_conv_nhwc_f16x2_vjp_gram), and the G factor only reduces the partials.
-    #: Measured on the 64-channel 32 x 32 layer of c4 (profiles/r03_gram_fuse_bench.md): the launch grows from 461 to 482 us
-    #: and replaces 60 + 18 us of stand-alone Gram + reduce — a gain of 47 us per layer when everything runs on one
-    #: stream (10.25 -> 10.18 ms per step), a LOSS inside the overlapped step (9.33 -> 9.43 ms), where the stand-alone
-    #: Gram runs on the side stream under the next convolution and the extra 21 us land on the critical path.  Off by
-    #: default for that reason; the kernels and their parity tests stay.
-    fuse_gram = os.environ.get("LK_FUSE_GRAM", "0") == "1"
-
     #: ``False`` (env LK_WINP=0): fused 64-channel launches stay on the generic kernel (see :meth:`conv_winp_eligible`)
     use_winp = os.environ.get("LK_WINP", "1") != "0"
 
@@ -467,7 +450,7 @@ class HipKernels:
                                                                      1 if mask_is_float else 0))
 
     def conv_nhwc_f16x2_vjp(self, x, wplanes, wsexp, w_l1, Ho, Wo, taps, add=None, mult=None, mult_amax=None, scale=None,
-                            scale_amax=None, config=None, want_gram=False, amax_word=None, wplanes_chunked=None):
+                            scale_amax=None, config=None, amax_word=None, wplanes_chunked=None):
         """one dense launch of the convolution with the element-wise VJP fused into its epilogue (lk_conv_nhwc_f16x2_vjp):
         ``(conv(x) + add) * mult * scale[channel]`` -> SplitTensor [N, Ho, Wo, Co] carrying its measured ``amax``.
         ``mult``: [B, Ho, Wo, Co] uint8 / bool mask or fp32 multiplier (``mult_amax``: its bound, fp32 only), shared by
@@ -494,22 +477,6 @@ class HipKernels:
         cfg = self.conv_config if config is None else config
         z = self._zero16(dev)
         work = 2.0 * N * Co * Ci * self.conv_valid_pairs(Ho, Wo, 1, Hi, Wi, taps) if self.profile is not None else 0.0
-        # ``want_gram``: the consumer of the result is a G factor — where the launch can (64 channels, at least one round
-        # of tiles) it accumulates the Gram of its result on the way and hands the partial blocks over with the tensor
-        parts = int(self.lib.lk_conv_vjp_gram_parts(N, Ho, Wo, Co, int(cfg) & ~(1 | 4 | 8 | 16 | 32 | 64 | 2048))) \
-            if (want_gram and self.fuse_gram) else 0
-        if parts > 0:
-            gws = torch.empty(parts, Co, Co, dtype=torch.float32, device=dev)
-            self._rc(self._timed("conv16", work, dev, lambda: self.lib.lk_conv_nhwc_f16x2_vjp_gram(
-                _ptr(x.planes[0]), _ptr(x.planes[1]), _ptr(x.sexp), _ptr(x.amax), N, Hi, Wi, Ci, _ptr(wplanes[0]),
-                _ptr(wplanes[1]), _ptr(wsexp), _ptr(w_l1), Co, Ho, Wo, len(taps), flat, _ptr(z),
-                None if add is None else _ptr(add.planes[0]), None if add is None else _ptr(add.planes[1]),
-                None if add is None else _ptr(add.sexp), _ptr(mult), m_is_float, _ptr(mult_amax), mask_rows, _ptr(scale),
-                _ptr(scale_amax), _ptr(planes[0]), _ptr(planes[1]), _ptr(sexp), _ptr(amax), _ptr(gws), gws.numel(), int(cfg),
-                self._stream(dev))), "lk_conv_nhwc_f16x2_vjp_gram")
-            out = SplitTensor(planes, sexp, amax)
-            out.gram_parts = gws
-            return out
         if wplanes_chunked is not None:
             # [2, T, Ci / 16, Co, 16]: the persistent window form where the library finds the launch eligible
             assert wplanes_chunked.shape == (2, wplanes.shape[1], Ci // 16, Co, 16) and wplanes_chunked.is_contiguous()
@@ -529,19 +496,6 @@ class HipKernels:
             _ptr(scale_amax), _ptr(planes[0]), _ptr(planes[1]), _ptr(sexp), _ptr(amax), int(cfg), self._stream(dev))),
             "lk_conv_nhwc_f16x2_vjp")
         return SplitTensor(planes, sexp, amax)
-
-    def gram_partials_reduce(self, x: "SplitTensor", alpha, out):
-        """``out[upper tiles] += alpha * X^T X`` from the partial blocks a fused convolution launch left with ``x``"""
-        _check(out, "out")
-        parts = x.gram_parts
-        C = parts.shape[-1]
-        assert tuple(out.shape) == (C, C)
-        # bytes: the partials once + the factor's read-modify-write
-        self._rc(self._timed("gram16_parts", 4.0 * (parts.numel() + 2 * C * C), out.device,
-                             lambda: self.lib.lk_gram_partials_reduce_f16x2(_ptr(parts), parts.shape[0], C, _ptr(x.sexp),
-                                                                            float(alpha), _ptr(out), self._stream(out.device))),
-                 "lk_gram_partials_reduce_f16x2")
-        return out
 
     def vjp_nhwc_split(self, g, g_amax, g2, mult, mult_amax, scale, scale_amax, S, out_shape):
         """``(g + g2) * mult * scale[channel]`` for all ``S`` seeds -> SplitTensor of ``out_shape`` ([S*B, H, W, C]).

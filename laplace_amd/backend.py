@@ -362,7 +362,7 @@ class _HipCurvatureMixin:
             t.a = sweep.taps[t.name]["a"]
             t.a_split = getattr(sweep, "tap_splits", {}).get(t.name)  # NHWC SplitTensor of the same activation, if any
 
-        def grad_fn(seeds, stack=True, on_tap=None, defer_bn_scale=False, keep_split=False, fuse_gram=False):
+        def grad_fn(seeds, stack=True, on_tap=None, defer_bn_scale=False, keep_split=False):
             """All seeds in one sweep while ``S*B`` stays below ``sweep_max_rows`` images; many-output models
             (C = 1000 -> 999 seeds) go through in seed chunks of that size.  With ``on_tap`` every chunk's gradients
             are handed over layer by layer (additive consumers such as the KFAC accumulator) and nothing is returned."""
@@ -374,8 +374,6 @@ class _HipCurvatureMixin:
             if S <= chunk:
                 if keep_split and isinstance(sweep, SplitSweep):  # NHWC SplitTensors for consumers that take them
                     grads = sweep.backward(seeds, on_tap=on_tap, defer_bn_scale=defer_bn_scale, keep_split=True)
-                elif fuse_gram and isinstance(sweep, SplitSweep):
-                    grads = sweep.backward(seeds, on_tap=on_tap, defer_bn_scale=defer_bn_scale, fuse_gram=True)
                 else:
                     grads = sweep.backward(seeds, on_tap=on_tap, defer_bn_scale=defer_bn_scale)
                 return [grads[t.name] for t in tape.taps]
@@ -506,11 +504,6 @@ class _HipCurvatureMixin:
         m = tap.module
         if isinstance(g, SplitTensor):  # NHWC split cotangent [S*B, H, W, Do] of the split-fp16 sweep
             Do = g.shape[-1]
-            if kfac_approx == "expand" and g.gram_parts is not None:
-                K.gram_partials_reduce(g, alpha_g, G)  # the producing launch accumulated the Gram already
-                if not fused:
-                    K.symmetrize(G)
-                return G
             if kfac_approx == "expand" and (Do == 64 or Do % 128 == 0):
                 K.gram_tn_f16x2(g, alpha_g, G)  # upper 32x32 tiles; mirrored by the caller (symmetrize)
                 if not fused:
@@ -1271,10 +1264,8 @@ class KronAccumulator:
                 (g.planes if isinstance(g, SplitTensor) else g).record_stream(side)  # allocated on main, read on side
                 if isinstance(g, SplitTensor) and torch.is_tensor(g.sexp):
                     g.sexp.record_stream(side)
-                if isinstance(g, SplitTensor) and g.gram_parts is not None:
-                    g.gram_parts.record_stream(side)
 
-            grad_fn(seeds, stack=False, on_tap=on_tap, defer_bn_scale=defer, fuse_gram=self.kfac_approx == "expand")
+            grad_fn(seeds, stack=False, on_tap=on_tap, defer_bn_scale=defer)
         else:
             grads = grad_fn(seeds, stack=False)
             for tap, g, F in zip(tape.taps, grads, self.factors):

@@ -138,7 +138,7 @@ def fused_backward_ok(m: nn.Conv2d) -> bool:
 
 
 def conv_backward_data_vjp(prep: PreparedConv, g: SplitTensor, in_hw, cscale=None, add=None, mult=None, mult_amax=None,
-                           scale=None, scale_amax=None, want_gram=False, amax_word=None) -> SplitTensor:
+                           scale=None, scale_amax=None, amax_word=None) -> SplitTensor:
     """``(dX + add) * mult * scale[channel]`` as a SplitTensor (with its measured ``amax``): :func:`conv_backward_data`
     followed by the sweep's element-wise VJP, in one launch (stride-1 convs, see :func:`fused_backward_ok`)."""
     K = get_kernels()
@@ -147,11 +147,11 @@ def conv_backward_data_vjp(prep: PreparedConv, g: SplitTensor, in_hw, cscale=Non
     planes, sexp = prep.backward_planes(cscale)
     (Hc, Wc, oh0, ow0, taps), = backward_plan(m, Hin, Win)
     assert (Hc, Wc, oh0, ow0) == (Hin, Win, 0, 0)
-    kw = {"want_gram": True} if want_gram else {}  # (``want_gram``: see HipKernels.conv_nhwc_f16x2_vjp)
+    kw = {}
     if amax_word is not None:
         kw["amax_word"] = amax_word  # a zeroed device word for the measured max|result| (saves a fill launch)
     N = g.planes.shape[1]
-    if not (want_gram and getattr(K, "fuse_gram", False)) and planes.shape[3] % 16 == 0 and K.conv_winp_eligible(
+    if planes.shape[3] % 16 == 0 and K.conv_winp_eligible(
             N, Hin, Win, planes.shape[3], planes.shape[2], len(taps), mult is not None and mult.dtype == torch.float32):
         kw["wplanes_chunked"] = prep.backward_planes_chunked(cscale)
     return K.conv_nhwc_f16x2_vjp(g, planes, sexp, prep.backward_l1(cscale), Hin, Win, taps, add=add, mult=mult,

@@ -174,14 +174,12 @@ struct ConvGeom {
                             // so the taps that fall outside the image there are skipped as whole K stages
   int dense;                // the output grid is the output tensor (os = 1, Hc = Ho, Wc = Wo): output pixel = m
   int out_nchw;             // write out[n][co][pixel] (dense grids with Ho*Wo % 4 == 0 only): float4 along the pixels
-  int chunk_major;          // K order: channel chunks major, taps minor (the nine taps of one 32-channel chunk back to back)
 };
 
-template <int BM_, int BN_, int BK_, int WM_, int WN_, int NBUF_ = 2, int WPE_ = 2, bool MIDBAR_ = false>
+template <int BM_, int BN_, int BK_, int WM_, int WN_, int NBUF_ = 2, int WPE_ = 2>
 struct ConvCfg {
-  static constexpr bool MIDBAR = MIDBAR_;                 // hand over to the next stage in the MIDDLE of a stage's MFMAs
   static constexpr int EPI_LDS = WM_ * WN_ * (BM_ / WM_) * (BN_ / WN_ + 4) * 4;  // staging image of the fused (VJP) epilogue
-  static constexpr bool FUSABLE = NBUF_ == 2 && BK_ == 32 && !MIDBAR_ && WM_ * WN_ == 4;  // shapes the VJP epilogue is built for
+  static constexpr bool FUSABLE = NBUF_ == 2 && BK_ == 32 && WM_ * WN_ == 4;  // shapes the VJP epilogue is built for
   static constexpr int WPE = WPE_;                        // waves per SIMD the register allocation is sized for
   static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_;
   static constexpr int NBUF = NBUF_;                      // LDS stages: NBUF - 1 stages of loads are in flight
@@ -231,32 +229,14 @@ struct ConvVjp {
   const _Float16 *wc_h, *wc_l;  // the same weights chunk-major, [tap][Ci / 16][Co][16] per plane (persistent window form), or NULL
 };
 
-// GRAM (fused epilogue, Co == BN == 64, one wave = 64 pixels x all 64 channels): the launch ALSO accumulates the Gram of
-// what it emits — o^T o over every output pixel, i.e. the G factor of the layer whose output cotangent this launch
-// produces (laplace/curvature/curvlinops.py:57-62: the hook that sums g g^T over (sample, position)) — instead of
-// leaving it to a separate pass that re-reads the whole cotangent from HBM (lk_gram_tn_f16x2: 302 MB per 64-channel
-// ResNet-18 layer and minibatch).  Each wave stages the fp16 planes of its 64 x 64 block in its own part of the epilogue
-// image (the layout lk_sweep16.hip's gram16_kernel reads through ds_read_b64_tr_b16) and runs the three upper 32 x 32
-// tiles of the 64 x 64 product on them; the sums stay in registers while the workgroup walks through `tiles_per_wg`
-// consecutive pixel tiles (the grid is ONE round of workgroups), and leave as one 64 x 64 partial per workgroup
-// (gram_ws[workgroup][64][64], upper tiles), summed in a fixed order by gram16_reduce_kernel.
-template <typename CFG, bool FUSE, bool GRAM = false>
+template <typename CFG, bool FUSE>
 __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WPE, CFG::WPE))) void conv_f16x2_kernel(const ConvGeom g, const _Float16* __restrict__ Ah,
                                                          const _Float16* __restrict__ Al, const _Float16* __restrict__ Wh,
                                                          const _Float16* __restrict__ Wl, const int* __restrict__ a_sexp,
                                                          const int* __restrict__ w_sexp, const _Float16* __restrict__ zero16,
                                                          float* __restrict__ out, int accumulate,
-                                                         unsigned* __restrict__ amax_out, int nb_m, int ablate_arg,
-                                                         const ConvVjp fz, int tiles_per_wg, int n_tiles,
-                                                         float* __restrict__ gram_ws) {
+                                                         unsigned* __restrict__ amax_out, int nb_m, const ConvVjp fz) {
   constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK, Q = CFG::Q, TM = CFG::TM, TN = CFG::TN, NT = CFG::NT;
-  static_assert(!GRAM || (FUSE && CFG::WN == 1 && TN == 2 && TM == 2 && CFG::WM == 4), "GRAM: one wave = 64 rows x 64 channels");
-#ifdef LK_CONV_DEV  // development switches (skip stores / MFMAs / staging, K order, ...): compiled out of the shipped kernel
-  const int ablate = ablate_arg;
-#else
-  constexpr int ablate = 0;
-  (void)ablate_arg;
-#endif
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // XCD-aware tile order: consecutive block ids run on different XCDs (id % 8); give every XCD a contiguous range of
@@ -267,28 +247,9 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
     const int q = nblk / 8, r = nblk % 8, x = bid % 8, j = bid / 8;
     bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
   }
-#ifdef LK_CONV_DEV
-  if ((ablate & 16) && blockIdx.x >= 256 && blockIdx.x < 512) {
-    // (experiment) the two workgroups of a CU run equal tiles in lockstep and reach their epilogues together; delaying
-    // the second resident workgroup of every CU by part of a tile time staggers them for the whole launch
-    __builtin_amdgcn_s_sleep(127);
-    __builtin_amdgcn_s_sleep(127);
-  }
-#endif
   const int M = g.N * g.Hc * g.Wc;
   const int KC = g.Ci / BK;
-  // GRAM: running sums of the three upper 32 x 32 tiles (0,0), (0,1), (1,1) of this wave's o^T o
-  f32x16 gram_acc[GRAM ? 3 : 1];
-  if constexpr (GRAM) {
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) gram_acc[t][r] = 0.f;
-  }
-  const int t_count = GRAM ? tiles_per_wg : 1;
-  for (int ti = 0; ti < t_count; ++ti) {
-  const int tile = GRAM ? bid * tiles_per_wg + ti : bid;
-  if (GRAM && tile >= n_tiles) break;  // (uniform over the workgroup)
+  const int tile = bid;
   const int tile_n = tile / nb_m, tile_m = tile % nb_m;
 
   // ---- per-thread staging context: which rows / slots this thread feeds, fixed for the whole K loop
@@ -385,9 +346,7 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
     // K order: taps major, channel chunks minor.  (The other order — the nine taps of one 32-channel chunk back to back,
     // so that only a quarter-to-sixteenth-depth window has to survive in L2 between them — was measured: better on the
     // stride-2 classes, worse on the 64- and 512-channel layers, 10.66 vs 10.50 ms per step; config bit 19 selects it.)
-    int tj, kc;
-    if (g.chunk_major) kc = s / ntap, tj = s - kc * ntap;
-    else tj = s / KC, kc = s - tj * KC;
+    const int tj = s / KC, kc = s - tj * KC;
     const int t = (int)((tap_list >> (4 * tj)) & 15ull);
     char* base = smem + buf * CFG::STAGE;
     const int64_t tap_off = ((int64_t)g.dh[t] * g.Wi + g.dw[t]) * g.Ci + kc * BK;
@@ -438,9 +397,6 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
   // arithmetic (a 64-bit % here was a ~100-instruction software division per chunk: 8 per tile and lane)
   const int mrows = (int)fz.mask_rows;
   auto mask_row = [&](int p) { return p - fdiv(p, fz.div_mask) * mrows; };
-  // GRAM keeps 48 more registers alive (the running Gram tiles): only the first half of the chunks is requested ahead
-  // of the barrier, the second half once the accumulators have been staged (their registers are free by then)
-  constexpr int NPRE = GRAM ? NIT / 2 : NIT;
   auto prefetch = [&](int it) {
     const int idx = it * 64 + lane;
     const int row = idx / C8, c8 = idx - row * C8;
@@ -457,7 +413,6 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
 #pragma unroll
     for (int j = 0; j < 8; ++j) h2_[it][j] = (_Float16)0.f, l2_[it][j] = (_Float16)0.f;
     mk_[it] = make_uint2(0x01010101u, 0x01010101u);
-    if (ablate & 32) return;  // (development switch, config bit 21: load per chunk, where the values are consumed)
     if (fz.add_h && ok_[it]) {
       h2_[it] = *reinterpret_cast<const f16x8*>(fz.add_h + e_[it]);
       l2_[it] = *reinterpret_cast<const f16x8*>(fz.add_l + e_[it]);
@@ -466,109 +421,7 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
       mk_[it] = *reinterpret_cast<const uint2*>((const unsigned char*)fz.mask + (int64_t)mask_row((int)opix) * g.Co + col0);
   };
 
-  if constexpr (CFG::MIDBAR) {
-    // Two workgroups of a CU run the same code from the same start: they reach their LDS-read phase together, so the
-    // partner wave on a SIMD cannot cover a fragment read with its MFMAs, and each wave has to hide its own LDS latency.
-    // Fragments therefore run one k16 step ahead in a second register set, ACROSS stages: the barrier that hands over
-    // to the next stage sits in the middle of a stage — before the MFMAs of its last k16 step, whose operands are
-    // already in registers — followed by the next stage's loads and the first fragment reads of the next stage, all of
-    // which the 12 MFMAs behind them cover.
-    static_assert(CFG::NBUF == 2 && (BK / 16) % 2 == 0, "two LDS stages, an even number of k16 steps");
-    constexpr int K16 = BK / 16, LDS_PER = CFG::A_LD + CFG::B_LD;
-    constexpr int WAIT_ONE_BEHIND = 0x0f70 | (LDS_PER & 15) | ((LDS_PER >> 4) << 14);
-    f16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
-    // The fragment reads are issued as asm: hipcc books an LDS-DMA load as a "flat" access that may return out of
-    // order with LDS reads and then waits lgkmcnt(0) at every dependency behind it — which serialises exactly the
-    // read/MFMA overlap this loop is for.  With asm reads the counter is ours: wait_set() waits until at most
-    // `younger` reads issued after the wanted set are outstanding, and ties the set's registers to the wait so that
-    // no use of them can be placed above it.
-    static_assert(TM == 2 && TN == 2, "wait_set names eight registers");
-    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    unsigned fa[TM], fb[TN];   // byte address of (row, slot 0 ^ swizzle) — the k16 / half / plane parts are XORed or added
-    int fswz_a[TM], fswz_b[TN];
-#pragma unroll
-    for (int a = 0; a < TM; ++a) {
-      const int row = (wm * TM + a) * 32 + lr;
-      fa[a] = lds0 + row * Q * 16, fswz_a[a] = swz<Q>(row);
-    }
-#pragma unroll
-    for (int b = 0; b < TN; ++b) {
-      const int row = (wn * TN + b) * 32 + lr;
-      fb[b] = lds0 + 2 * CFG::A_PLANE + row * Q * 16, fswz_b[b] = swz<Q>(row);
-    }
-    auto lds_read = [&](f16x8& dst, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr)); };
-    auto load_frags = [&](int buf, int k16, int set) {
-#pragma unroll
-      for (int a = 0; a < TM; ++a) {
-        const unsigned ad = fa[a] + buf * CFG::STAGE + (((k16 * 2 + lh) ^ fswz_a[a]) * 16);
-        lds_read(ah[set][a], ad);
-        lds_read(al[set][a], ad + CFG::A_PLANE);
-      }
-#pragma unroll
-      for (int b = 0; b < TN; ++b) {
-        const unsigned ad = fb[b] + buf * CFG::STAGE + (((k16 * 2 + lh) ^ fswz_b[b]) * 16);
-        lds_read(bh[set][b], ad);
-        lds_read(bl[set][b], ad + CFG::B_PLANE);
-      }
-    };
-    constexpr int READS_PER_SET = 2 * TM + 2 * TN;
-    auto wait_set = [&](int set, bool younger) {
-      if (younger)
-        asm volatile("s_waitcnt lgkmcnt(%8)"
-                     : "+v"(ah[set][0]), "+v"(ah[set][1]), "+v"(al[set][0]), "+v"(al[set][1]), "+v"(bh[set][0]),
-                       "+v"(bh[set][1]), "+v"(bl[set][0]), "+v"(bl[set][1])
-                     : "n"(READS_PER_SET));
-      else
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(ah[set][0]), "+v"(ah[set][1]), "+v"(al[set][0]), "+v"(al[set][1]), "+v"(bh[set][0]),
-                       "+v"(bh[set][1]), "+v"(bl[set][0]), "+v"(bl[set][1]));
-    };
-    auto mfmas = [&](int set) {
-#pragma unroll
-      for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b) {
-          f32x16 c = acc[a][b];
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[set][a], bh[set][b], c, 0, 0, 0);  // small terms first
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[set][a], bl[set][b], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[set][a], bh[set][b], c, 0, 0, 0);
-          acc[a][b] = c;
-        }
-    };
-    static_assert(K16 == 2, "the loop below is written for two k16 steps per stage");
-    // The loop boundary sits AT the hand-over barrier (no LDS read is pending there), so that inside the body the
-    // compiler's own lgkmcnt bookkeeping can wait for the older fragment set only.
-    stage(0, 0);
-    if (nstage > 1) {
-      stage(1, 1);
-      __builtin_amdgcn_s_waitcnt(WAIT_ONE_BEHIND);  // stage 0 has landed, stage 1 may still be in flight
-    } else {
-      __builtin_amdgcn_s_waitcnt(0x0f70);
-    }
-    __builtin_amdgcn_s_barrier();
-    load_frags(0, 0, 0);
-    load_frags(0, 1, 1);
-    wait_set(0, true);
-    __builtin_amdgcn_sched_barrier(0);
-    mfmas(0);                                        // k16 step 0 of stage 0
-    for (int s = 0; s + 1 < nstage; ++s) {
-      wait_set(1, false);                            // lgkmcnt(0): every fragment of stage s is in registers
-      __builtin_amdgcn_s_waitcnt(0x0f70);            // vmcnt(0): this wave's part of stage s+1 has landed
-      __builtin_amdgcn_s_barrier();                  // ... everybody's; and nobody reads buffer s & 1 any more
-      const int nb = (s + 1) & 1;
-      if (s + 2 < nstage && !(ablate & 4)) stage(s + 2, s & 1);
-      load_frags(nb, 0, 0);                          // stage s+1, step 0 -> set 0
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(1);                                      // stage s, step 1 (covers the reads above and the loads)
-      __builtin_amdgcn_sched_barrier(0);
-      load_frags(nb, 1, 1);                          // stage s+1, step 1 -> set 1 (its old contents have been issued)
-      wait_set(0, true);                             // set 0 has arrived; set 1 stays in flight behind the MFMAs below
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(0);                                      // stage s+1, step 0
-    }
-    wait_set(1, false);
-    mfmas(1);                                        // step 1 of the last stage
-  } else {
+  {
   // Software pipeline over NBUF LDS stages: the loads of stages s+1 .. s+NBUF-1 are in flight while stage s is
   // computed (an L2 hit takes ~1.6k cycles here, two to three stage times).  vmcnt counts this wave's LDS-DMA
   // instructions in issue order, every stage issues exactly LD_PER_STAGE of them, so "stage s has landed" is
@@ -587,10 +440,9 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
     else
       __builtin_amdgcn_s_waitcnt(0x0f70);  // tail: fewer stages in flight
     __builtin_amdgcn_s_barrier();
-    if (s + NBUF - 1 < nstage && !(ablate & 4)) stage(s + NBUF - 1, buf == 0 ? NBUF - 1 : buf - 1);
+    if (s + NBUF - 1 < nstage) stage(s + NBUF - 1, buf == 0 ? NBUF - 1 : buf - 1);
     const int cur = buf;
     buf = buf + 1 == NBUF ? 0 : buf + 1;
-    if (ablate & 2) continue;
     const char* base = smem + cur * CFG::STAGE;
     // fragments of step k16 + 1 are requested before the MFMAs of step k16 are issued (two register sets)
     f16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
@@ -639,17 +491,9 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
     // The addend planes and the mask bytes of ALL of this lane's chunks are requested first: their latency (an HBM miss
     // each) then runs under the hand-over barrier and the staging of the accumulators instead of once per chunk.
 #pragma unroll
-    for (int it = 0; it < NPRE; ++it) prefetch(it);
+    for (int it = 0; it < NIT; ++it) prefetch(it);
     __syncthreads();  // every wave is done with the K loop's stage buffers
     float* img = reinterpret_cast<float*>(smem) + wave * (ROWS_W * PITCH);
-    // GRAM: the wave's fp16 planes overlay its own image, row by row: [row][h: 64 channels | l: 64 channels], 256 bytes
-    // per row — less than the 272 bytes of an image row, so row r of the planes ends before image row r does and the
-    // planes are written IN PLACE while the image rows are consumed in increasing order (LDS operations of one wave
-    // execute in order, and a row is written from values read from it).  The 32-byte segments (16 channels) of a plane
-    // row are XOR-swizzled by row & 3, so that the four rows a transposing read gathers lie in different banks.
-    char* gram_pl = reinterpret_cast<char*>(img);
-    constexpr int GP = 4 * COLS_W;  // bytes per row of the plane image
-    static_assert(!GRAM || (COLS_W == 64 && ROWS_W == 64 && GP <= PITCH * 4), "plane rows must not run ahead of the image rows");
     const float inv = inv_a * inv_w;
 #pragma unroll
     for (int a = 0; a < TM; ++a)
@@ -658,34 +502,17 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           img[(a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * PITCH + b * 32 + lr] = acc[a][b][r] * inv;
-#pragma unroll
-    for (int it = NPRE; it < NIT; ++it) prefetch(it);
     // (LDS operations of one wave execute in order: no barrier between its own writes and reads)
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int idx = it * 64 + lane;
       const int row = idx / C8, c8 = idx - row * C8;
-      // byte offset of (row, channels c8 * 8 ..) inside the h part of the plane image (GRAM); l: + 2 * COLS_W
-      const int poff = row * GP + (((c8 >> 1) ^ (row & 3)) << 5) + (c8 & 1) * 16;
-      if (!ok_[it]) {
-        if constexpr (GRAM) {  // rows beyond the tensor contribute zeros to the Gram
-          f16x8 z;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) z[j] = (_Float16)0.f;
-          *reinterpret_cast<f16x8*>(gram_pl + poff) = z;
-          *reinterpret_cast<f16x8*>(gram_pl + poff + 2 * COLS_W) = z;
-        }
-        continue;
-      }
+      if (!ok_[it]) continue;
       const int col0 = tile_n * BN + wn * COLS_W + c8 * 8;
       const f32x4 p0 = *reinterpret_cast<const f32x4*>(img + row * PITCH + c8 * 8);
       const f32x4 p1 = *reinterpret_cast<const f32x4*>(img + row * PITCH + c8 * 8 + 4);
       float v[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
       const int64_t e = e_[it];
-      if (ablate & 32) {
-        if (fz.add_h) h2_[it] = *reinterpret_cast<const f16x8*>(fz.add_h + e), l2_[it] = *reinterpret_cast<const f16x8*>(fz.add_l + e);
-        if (pre_mask) mk_[it] = *reinterpret_cast<const uint2*>((const unsigned char*)fz.mask + (int64_t)mask_row(pix_[it]) * g.Co + col0);
-      }
       if (fz.add_h) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += ((float)h2_[it][j] + (float)l2_[it][j]) * inv2;
@@ -726,10 +553,6 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
       }
       *reinterpret_cast<f16x8*>(fz.out_h + e) = h;
       *reinterpret_cast<f16x8*>(fz.out_l + e) = l;
-      if constexpr (GRAM) {
-        *reinterpret_cast<f16x8*>(gram_pl + poff) = h;
-        *reinterpret_cast<f16x8*>(gram_pl + poff + 2 * COLS_W) = l;
-      }
     }
     if (amax_out) {
 #pragma unroll
@@ -738,45 +561,7 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
       const int back = -so < -126 ? -126 : -so;
       if (lane == 0 && vmax) atomicMax(amax_out, __float_as_uint(__uint_as_float(vmax) * exp2i(back)));
     }
-    if constexpr (GRAM) {
-      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's plane writes are in LDS (its reads follow in order)
-      // o^T o of this wave's 64 pixels: k = pixels is the strided direction of both operands -> transposing reads
-      const int grp = lane >> 4, r16 = lane & 15;
-      const int f_row = (grp >> 1) * 8 + (r16 >> 2);
-      const int f_col = (grp & 1) * 16 + (r16 & 3) * 4;
-      auto tr_frag = [&](const char* plane, int k16, int col0) -> f16x8 {
-        f16x8 o;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int row = k16 * 16 + f_row + j * 4;
-          const int col = col0 + f_col;
-          const int off = row * GP + (((col >> 4) ^ (row & 3)) << 5) + (col & 15) * 2;
-          const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(plane + off));
-          const f16x4 f = __builtin_bit_cast(f16x4, v);
-          o[4 * j] = f[0], o[4 * j + 1] = f[1], o[4 * j + 2] = f[2], o[4 * j + 3] = f[3];
-        }
-        return o;
-      };
-#pragma unroll
-      for (int k16 = 0; k16 < ROWS_W / 16; ++k16) {
-        f16x8 xh[2], xl[2];
-#pragma unroll
-        for (int a = 0; a < 2; ++a) xh[a] = tr_frag(gram_pl, k16, a * 32), xl[a] = tr_frag(gram_pl + 2 * COLS_W, k16, a * 32);
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-          const int a = t == 2 ? 1 : 0, b = t == 0 ? 0 : 1;
-          f32x16 c = gram_acc[t];
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[a], xh[b], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[a], xl[b], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[a], xh[b], c, 0, 0, 0);
-          gram_acc[t] = c;
-        }
-      }
-      __syncthreads();  // the next tile's staging overwrites every wave's image
-      continue;
-    } else {
-      return;
-    }
+    return;
   }
   if (g.out_nchw) {
     // position-contiguous output [n][co][pixel] (what the predictive's quadratic-form kernel reads): a lane owns one
@@ -825,646 +610,6 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
         if (col < g.Co) {
           float v = acc[a][b][r] * inv_a * inv_w;
           if (accumulate) v += orow[col];
-          if (!(ablate & 1)) orow[col] = v;
-          vmax = max(vmax, __float_as_uint(v) & 0x7fffffffu);
-        }
-      }
-    }
-  }
-  if (amax_out) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) vmax = max(vmax, (unsigned)__shfl_xor((int)vmax, off, 64));
-    if (lane == 0 && vmax) atomicMax(amax_out, vmax);
-  }
-  }  // (tile loop: one pass unless GRAM)
-  if constexpr (GRAM) {
-    // the four waves hold sums over different pixels of the SAME three tiles: added in wave order through LDS, one
-    // 64 x 64 partial (upper tiles) per workgroup
-    const int lr_ = lane & 31, lh_ = lane >> 5;
-    float* red = reinterpret_cast<float*>(smem);  // [wave][tile][32 x 32]
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) red[(wave * 3 + t) * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * lh_) * 32 + lr_] = gram_acc[t][r];
-    __syncthreads();
-    float* blk = gram_ws + (int64_t)blockIdx.x * (64 * 64);
-#pragma unroll
-    for (int i = 0; i < 12; ++i) {
-      const int e = tid + 256 * i, t = e >> 10, q = e & 1023;
-      const float v = ((red[e] + red[3 * 1024 + e]) + red[6 * 1024 + e]) + red[9 * 1024 + e];
-      const int a = t == 2 ? 1 : 0, b = t == 0 ? 0 : 1;
-      blk[(a * 32 + (q >> 5)) * 64 + b * 32 + (q & 31)] = v;
-    }
-  }
-}
-
-
-// ---- the same GEMM with the A operand RESIDENT in LDS across the taps ("patch" form) ----------------------------------
-// The generic kernel re-stages the A tile for every tap: 9 x the input from L2 / Infinity Cache, and with 2 x 32 CUs per
-// XCD streaming 64 KB tiles the 4 MB L2 does not hold them — measured, it runs at the L2-miss rate (~12 B/clk/CU), the
-// matrix pipe 23-40 % busy.  When the output grid IS the input grid (stride-1 forward / backward-data, and the residue
-// classes of a stride-2 backward-data), tap (dh, dw) of GEMM row m is raster pixel m + dh*Wi + dw: a tile of 256
-// consecutive raster pixels needs the contiguous range [m0 - Wi - 1, m0 + 256 + Wi + 1) for ALL taps.  That patch is
-// brought into LDS once per 32-channel chunk and the taps read it at shifted rows; only the weight tile is re-staged per
-// tap (double-buffered).  Out-of-image taps read a zero block.  8 waves, 256 x BN output tile, 76 KB of LDS: TWO
-// workgroups per CU, so that one computes while the other sits in the (single-buffered) patch reload between chunks.
-template <int BN_, int WM_, int WN_>
-struct PatchCfg {
-  static constexpr int BM = 256, BN = BN_, CK = 32, WM = WM_, WN = WN_;
-  static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  static constexpr int PP = 336;                      // patch pixels incl. padding: BM + 2 Wi + 2 <= PP
-  static constexpr int PATCH_PLANE = PP * CK * 2;     // bytes
-  static constexpr int PATCH = 2 * PATCH_PLANE;       // h + l
-  static constexpr int B_PLANE = BN * CK * 2;
-  static constexpr int BSTAGE = 2 * B_PLANE;
-  static constexpr int ZERO_OFF = PATCH + 2 * BSTAGE;
-  static constexpr int LDS = ZERO_OFF + 64;
-  static constexpr int P_SLOTS = PP * 4;              // 16-byte slots per plane
-  static constexpr int P_LD = (P_SLOTS + 511) / 512;  // LDS-DMA instructions per thread and plane (the last one partial)
-  static_assert(WM * WN == 8 && P_SLOTS % 64 == 0, "eight waves, whole waves inside the patch");
-};
-
-template <typename CFG>
-__global__ __launch_bounds__(512) void conv_patch_f16x2_kernel(const ConvGeom g, const _Float16* __restrict__ Ah,
-                                                               const _Float16* __restrict__ Al,
-                                                               const _Float16* __restrict__ Wh,
-                                                               const _Float16* __restrict__ Wl,
-                                                               const int* __restrict__ a_sexp, const int* __restrict__ w_sexp,
-                                                               const _Float16* __restrict__ zero16, float* __restrict__ out,
-                                                               int accumulate, unsigned* __restrict__ amax_out, int nb_m,
-                                                               int ablate_arg) {
-  constexpr int BM = CFG::BM, BN = CFG::BN, TM = CFG::TM, TN = CFG::TN;
-#ifdef LK_CONV_DEV
-  const int ablate = ablate_arg;
-#else
-  constexpr int ablate = 0;
-  (void)ablate_arg;
-#endif
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nblk = gridDim.x;
-  int bid = blockIdx.x;
-  {
-    const int q = nblk / 8, r = nblk % 8, x = bid % 8, j = bid / 8;
-    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
-  }
-  const int tile_n = bid / nb_m, tile_m = bid % nb_m;
-  const int M = g.N * g.Hi * g.Wi;
-  const int KC = g.Ci / 32;
-  const int T = g.T;
-  const int nstage = KC * T;
-  const int m0 = tile_m * BM;
-
-  if (tid < 16) reinterpret_cast<unsigned*>(smem + CFG::ZERO_OFF)[tid] = 0u;
-
-  // ---- patch staging context (per plane: P_LD instructions; instruction j covers slots [j*512, j*512+512))
-  int64_t p_off[CFG::P_LD];
-  bool p_ok[CFG::P_LD];
-#pragma unroll
-  for (int j = 0; j < CFG::P_LD; ++j) {
-    const int slot = j * 512 + tid;
-    const int px = slot >> 2, pq = slot & 3;
-    const int64_t raster = (int64_t)m0 - (g.Wi + 1) + px;
-    p_ok[j] = raster >= 0 && raster < M;
-    p_off[j] = raster * g.Ci + ((pq ^ ((px >> 2) & 3)) << 3);
-  }
-  auto patch_piece = [&](int kc, int i) {  // piece i of 2 * P_LD: plane i / P_LD, instruction i % P_LD
-    const int plane = i / CFG::P_LD, j = i % CFG::P_LD;
-    const _Float16* src = plane ? Al : Ah;
-    const _Float16* sp = p_ok[j] ? src + p_off[j] + kc * 32 : zero16;
-    if (j * 512 + wave * 64 >= CFG::P_SLOTS) return;  // (wave-uniform: the last instruction covers part of the waves)
-    char* d = smem + plane * CFG::PATCH_PLANE + (j * 512 + wave * 64) * 16;
-    __builtin_amdgcn_global_load_lds((gbl_void*)sp, (lds_void*)d, 16, 0, 0);
-  };
-  // ---- weight staging context: one instruction covers 128 rows of one plane
-  const int b_row = tid >> 2, b_pq = tid & 3;
-  const int64_t w_tap = (int64_t)g.Co * g.Ci;
-  auto stage_b = [&](int s) {
-    const int kc = s / T, t = s - kc * T;
-    char* base = smem + CFG::PATCH + (s & 1) * CFG::BSTAGE;
-#pragma unroll
-    for (int jj = 0; jj < (BN + 127) / 128; ++jj) {
-      const int row = jj * 128 + b_row;
-      if (BN < 128 && wave * 16 >= BN) break;  // (BN = 64: the upper four waves have no weight rows)
-      const int n = tile_n * BN + row;
-      const int64_t e = (int64_t)g.wt[t] * w_tap + (int64_t)n * g.Ci + kc * 32 + ((b_pq ^ ((row >> 2) & 3)) << 3);
-      const bool ok = n < g.Co;
-      char* d = base + (jj * 512 + wave * 64) * 16;
-      __builtin_amdgcn_global_load_lds((gbl_void*)(ok ? Wh + e : zero16), (lds_void*)d, 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gbl_void*)(ok ? Wl + e : zero16), (lds_void*)(d + CFG::B_PLANE), 16, 0, 0);
-    }
-  };
-
-  // ---- fragment geometry
-  const int wm = wave / CFG::WN, wn = wave % CFG::WN;
-  const int lr = lane & 31, lh = lane >> 5;
-  unsigned vmask[TM];  // bit t: tap t of this lane's row (tile a) lies inside the image
-#pragma unroll
-  for (int a = 0; a < TM; ++a) {
-    const int m = m0 + (wm * TM + a) * 32 + lr;
-    unsigned v = 0;
-    if (m < M) {
-      const int rem = m - fdiv(m, g.div_hw) * (g.Hi * g.Wi);
-      const int h = fdiv(rem, g.div_w), w = rem - h * g.Wi;
-      for (int t = 0; t < T; ++t) {
-        const int hh = h + g.dh[t], ww = w + g.dw[t];
-        if (hh >= 0 && hh < g.Hi && ww >= 0 && ww < g.Wi) v |= 1u << t;
-      }
-    }
-    vmask[a] = v;
-  }
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int a = 0; a < TM; ++a)
-#pragma unroll
-    for (int b = 0; b < TN; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-  // prologue: the whole first patch and the first weight tile
-#pragma unroll
-  for (int i = 0; i < 2 * CFG::P_LD; ++i) patch_piece(0, i);
-  stage_b(0);
-
-  for (int s = 0; s < nstage; ++s) {
-    const int kc = s / T, t = s - kc * T;
-    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
-    __syncthreads();
-    if (t == 0 && kc > 0 && !(ablate & 4)) {
-      // chunk change: everybody has left the old patch (barrier above); reload it, wait, and only then go on.  The
-      // other workgroup of the CU computes meanwhile.
-#pragma unroll
-      for (int i = 0; i < 2 * CFG::P_LD; ++i) patch_piece(kc, i);
-      __builtin_amdgcn_s_waitcnt(0x0f70);
-      __syncthreads();
-    }
-    if (s + 1 < nstage && !(ablate & 4)) stage_b(s + 1);
-    if (ablate & 2) continue;
-    const char* pa = smem;
-    const char* pb = smem + CFG::PATCH + (s & 1) * CFG::BSTAGE;
-    const int shift = (g.dh[t] + 1) * g.Wi + g.dw[t] + 1;
-#pragma unroll
-    for (int k16 = 0; k16 < 2; ++k16) {
-      f16x8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-      for (int a = 0; a < TM; ++a) {
-        const int px = (wm * TM + a) * 32 + lr + shift;
-        const int off = ((vmask[a] >> t) & 1u) ? (px * 4 + ((k16 * 2 + lh) ^ ((px >> 2) & 3))) * 16 : -1;
-        ah[a] = *reinterpret_cast<const f16x8*>(off >= 0 ? pa + off : smem + CFG::ZERO_OFF);
-        al[a] = *reinterpret_cast<const f16x8*>(off >= 0 ? pa + CFG::PATCH_PLANE + off : smem + CFG::ZERO_OFF);
-      }
-#pragma unroll
-      for (int b = 0; b < TN; ++b) {
-        const int row = (wn * TN + b) * 32 + lr;
-        const int off = (row * 4 + ((k16 * 2 + lh) ^ ((row >> 2) & 3))) * 16;
-        bh[b] = *reinterpret_cast<const f16x8*>(pb + off);
-        bl[b] = *reinterpret_cast<const f16x8*>(pb + CFG::B_PLANE + off);
-      }
-#pragma unroll
-      for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b) {
-          f32x16 c = acc[a][b];
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], c, 0, 0, 0);
-          acc[a][b] = c;
-        }
-    }
-  }
-
-  // ---- epilogue (as the generic kernel; dense output grids need no index arithmetic)
-  const float inv_a = exp2i(-a_sexp[0] < -126 ? -126 : -a_sexp[0]), inv_w = exp2i(-w_sexp[0] < -126 ? -126 : -w_sexp[0]);
-  unsigned vmax = 0;
-#pragma unroll
-  for (int a = 0; a < TM; ++a) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const int m = m0 + row;
-      if (m >= M) continue;
-      int64_t opix = m;
-      if (!g.dense) {
-        const int n = fdiv(m, g.div_hw), rem = m - n * (g.Hi * g.Wi);
-        const int ci_ = fdiv(rem, g.div_w);
-        opix = ((int64_t)n * g.Ho + ci_ * g.os + g.oh0) * g.Wo + (rem - ci_ * g.Wi) * g.os + g.ow0;
-      }
-      float* orow = out + opix * g.Co;
-#pragma unroll
-      for (int b = 0; b < TN; ++b) {
-        const int col = tile_n * BN + (wn * TN + b) * 32 + lr;
-        if (col < g.Co) {
-          float v = acc[a][b][r] * inv_a * inv_w;
-          if (accumulate) v += orow[col];
-          if (!(ablate & 1)) orow[col] = v;
-          vmax = max(vmax, __float_as_uint(v) & 0x7fffffffu);
-        }
-      }
-    }
-  }
-  if (amax_out) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) vmax = max(vmax, (unsigned)__shfl_xor((int)vmax, off, 64));
-    if (lane == 0 && vmax) atomicMax(amax_out, vmax);
-  }
-}
-
-
-// ---- "window" form: stride-1 / same-grid convolutions with the input window of a pixel tile RESIDENT in LDS --------------
-// The generic kernel stages the A operand once per tap: nine times the input of a 3 x 3 convolution through L2 -> LDS, and
-// with 64 workgroups per XCD walking through 5 MB of windows its 4 MB L2 does not hold them between the taps (measured:
-// 3.4 x the operand bytes from the fabric; the load path alone takes as long as the MFMAs alone and the two overlap only
-// partly).  Where the output grid IS the input grid, tap (dh, dw) of GEMM row m is raster pixel m + dh * Wi + dw, so a tile
-// of BM consecutive raster pixels needs the contiguous pixel range [m0 - Wi - 1, m0 + BM + Wi + 1) for ALL taps:
-//   * that window is brought into LDS once per 16-channel chunk (one k16 step), DOUBLE-buffered — chunk c + 1 lands while
-//     the nine taps of chunk c are computed — and every tap reads it at shifted rows; out-of-image taps read a zero block
-//     through a per-lane select;
-//   * the weights go through a two-slot ring of THREE taps each (3 x BN x 16 k x h/l), so there is one hand-over barrier
-//     per three taps (18 / 36 MFMAs per wave) instead of one per tap and 32-channel chunk;
-//   * L2 -> LDS bytes per tile and chunk: window (BM + 96) x 64 B + weights 9 x BN x 64 B, against 9 x (BM + BN) x 64 B of the
-//     generic form: 3.2 x fewer for 256 x 64, and the input itself is read from the fabric once (plus the halo).
-// (The older "patch" kernel below keeps a 32-channel window single-buffered and hands over per tap; it has no fused epilogue.)
-template <int BM_, int BN_, int WM_, int WN_, int WPE_>
-struct WinCfg {
-  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, WPE = WPE_;
-  static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  static constexpr int NW = WM * WN, NT = 64 * NW;
-  static constexpr int CK = 16;                           // channels per window chunk = one k16 step
-  static constexpr int PP = BM + 96;                      // window pixels: BM + 2 Wi + 2 <= PP  (Wi <= 47); a multiple of 32
-  static constexpr int W_PLANE = PP * CK * 2;             // bytes
-  static constexpr int WIN = 2 * W_PLANE;                 // h + l
-  static constexpr int B_TAP = BN * CK * 2;               // one tap, one plane
-  static constexpr int B_STEP = 6 * B_TAP;                // three taps, h + l
-  static constexpr int ZERO_OFF = (PP - 1) * CK * 2;      // the LAST window pixel of a plane is kept zero (need < PP): what
-                                                          // out-of-image taps read, in the h plane and (+ W_PLANE) the l plane
-  static constexpr int WINZ = WIN;                        // stride of the two window buffers
-  static constexpr int LDS = 2 * WINZ + 2 * B_STEP;
-  static constexpr int W_INSTR = 4 * PP / 64;             // LDS-DMA wave-instructions per window (2 planes x PP x 2 slots)
-  static constexpr int B_INSTR = 12 * BN / 64;            // ... per weight step
-  static constexpr int W_IT = (W_INSTR + NW - 1) / NW, B_IT = (B_INSTR + NW - 1) / NW;
-  static constexpr int EPI_LDS = NW * (TM * 32) * (TN * 32 + 4) * 4;  // staging image of the fused epilogue
-  static_assert((4 * PP) % 64 == 0 && (12 * BN) % 64 == 0, "whole wave-instructions");
-  static_assert(TM >= 1 && TN >= 1 && TM * TN <= 4, "MFMA tiles per wave");
-};
-
-__device__ __forceinline__ int swz2(int row) { return (row >> 3) & 1; }  // two 16-byte slots per row (see swz<2>)
-
-// The fused (VJP) epilogue of conv_f16x2_kernel for a wave that holds rows [row0, row0 + TM*32) x columns [col0, col0 + TN*32)
-// of a DENSE output grid (output pixel = GEMM row): (acc * inv + add) * M * scale -> split planes, max|.| -> amax_out.
-template <int TM, int TN>
-__device__ __forceinline__ void fused_vjp_epilogue(f32x16 (&acc)[TM][TN], char* smem, int wave, int lane, int row0, int col0,
-                                                   int M, const ConvGeom& g, const ConvVjp& fz, float inv, float inv2,
-                                                   float sc_out, int so, unsigned* amax_out) {
-  constexpr int ROWS_W = TM * 32, COLS_W = TN * 32, PITCH = COLS_W + 4, C8 = COLS_W / 8, NIT = ROWS_W * C8 / 64;
-  const int lr = lane & 31, lh = lane >> 5;
-  int64_t e_[NIT];
-  bool ok_[NIT];
-  f16x8 h2_[NIT], l2_[NIT];
-  uint2 mk_[NIT];
-  const bool pre_mask = fz.mask && !fz.mask_float;
-  const int mrows = (int)fz.mask_rows;
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int idx = it * 64 + lane;
-    const int row = idx / C8, c8 = idx - row * C8;
-    const int m = row0 + row;
-    const int c0 = col0 + c8 * 8;
-    ok_[it] = m < M && c0 < g.Co;
-    e_[it] = ok_[it] ? (int64_t)m * g.Co + c0 : 0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) h2_[it][j] = (_Float16)0.f, l2_[it][j] = (_Float16)0.f;
-    mk_[it] = make_uint2(0x01010101u, 0x01010101u);
-    if (fz.add_h && ok_[it]) {
-      h2_[it] = *reinterpret_cast<const f16x8*>(fz.add_h + e_[it]);
-      l2_[it] = *reinterpret_cast<const f16x8*>(fz.add_l + e_[it]);
-    }
-    if (pre_mask && ok_[it])
-      mk_[it] = *reinterpret_cast<const uint2*>((const unsigned char*)fz.mask + (int64_t)(m - fdiv(m, fz.div_mask) * mrows) * g.Co + c0);
-  }
-  __syncthreads();  // every wave is done with the K loop's LDS buffers
-  float* img = reinterpret_cast<float*>(smem) + wave * (ROWS_W * PITCH);
-#pragma unroll
-  for (int a = 0; a < TM; ++a)
-#pragma unroll
-    for (int b = 0; b < TN; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        img[(a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * PITCH + b * 32 + lr] = acc[a][b][r] * inv;
-  // (LDS operations of one wave execute in order: no barrier between its own writes and reads)
-  unsigned vmax = 0;
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    if (!ok_[it]) continue;
-    const int idx = it * 64 + lane;
-    const int row = idx / C8, c8 = idx - row * C8;
-    const int c0 = col0 + c8 * 8;
-    const f32x4 p0 = *reinterpret_cast<const f32x4*>(img + row * PITCH + c8 * 8);
-    const f32x4 p1 = *reinterpret_cast<const f32x4*>(img + row * PITCH + c8 * 8 + 4);
-    float v[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
-    const int64_t e = e_[it];
-    if (fz.add_h) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] += ((float)h2_[it][j] + (float)l2_[it][j]) * inv2;
-    }
-    float mult[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) mult[j] = sc_out;
-    if (fz.mask) {
-      if (fz.mask_float) {
-        const int mm = row0 + row;
-        const int64_t em = (int64_t)(mm - fdiv(mm, fz.div_mask) * mrows) * g.Co + c0;
-        const f32x4 a = *reinterpret_cast<const f32x4*>((const float*)fz.mask + em);
-        const f32x4 b = *reinterpret_cast<const f32x4*>((const float*)fz.mask + em + 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) mult[j] *= a[j], mult[4 + j] *= b[j];
-      } else {
-        const uint2 u = mk_[it];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (!((u.x >> (8 * j)) & 0xffu)) mult[j] = 0.f;
-          if (!((u.y >> (8 * j)) & 0xffu)) mult[4 + j] = 0.f;
-        }
-      }
-    }
-    if (fz.scale) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(fz.scale + c0), b = *reinterpret_cast<const f32x4*>(fz.scale + c0 + 4);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) mult[j] *= a[j], mult[4 + j] *= b[j];
-    }
-    f16x8 h, l;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float xs = v[j] * mult[j];
-      asm volatile("" : "+v"(xs));  // h and the residual from the SAME fp32 value (see split2)
-      const _Float16 hh = (_Float16)xs;
-      h[j] = hh;
-      l[j] = (_Float16)(xs - (float)hh);
-      vmax = max(vmax, __float_as_uint(xs) & 0x7fffffffu);
-    }
-    *reinterpret_cast<f16x8*>(fz.out_h + e) = h;
-    *reinterpret_cast<f16x8*>(fz.out_l + e) = l;
-  }
-  if (amax_out) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) vmax = max(vmax, (unsigned)__shfl_xor((int)vmax, off, 64));
-    const int back = -so < -126 ? -126 : -so;
-    if (lane == 0 && vmax) atomicMax(amax_out, __float_as_uint(__uint_as_float(vmax) * exp2i(back)));
-  }
-}
-
-template <typename CFG, bool FUSE>
-__global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WPE, CFG::WPE)))
-void conv_win_f16x2_kernel(const ConvGeom g, const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al,
-                           const _Float16* __restrict__ Wh, const _Float16* __restrict__ Wl, const int* __restrict__ a_sexp,
-                           const int* __restrict__ w_sexp, const _Float16* __restrict__ zero16, float* __restrict__ out,
-                           int accumulate, unsigned* __restrict__ amax_out, int nb_m, const ConvVjp fz, int ablate_arg) {
-  constexpr int BM = CFG::BM, BN = CFG::BN, TM = CFG::TM, TN = CFG::TN, NW = CFG::NW, PP = CFG::PP;
-#ifdef LK_CONV_DEV  // development switches: 1 skip the epilogue, 2 the MFMAs, 4 the in-loop staging, 32 the barrier
-  const int ablate = ablate_arg;
-#else
-  constexpr int ablate = 0;
-  (void)ablate_arg;
-#endif
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  // The instruction stream of the K loop is what bounds this kernel (the generic kernel issues ~3 vector and ~4 scalar
-  // instructions per MFMA for its addresses): everything per-lane is computed ONCE per tile — fragment addresses of all
-  // nine taps, staging pointers that only advance by a constant per chunk — and everything per-wave is scalar (the wave
-  // index is read with readfirstlane, so LDS-DMA destinations, instruction ranges and tap constants live in SGPRs).
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nblk = gridDim.x;
-  int bid = blockIdx.x;
-  {  // XCD-aware tile order (as conv_f16x2_kernel): every XCD gets a contiguous range of (n-tile major, m-tile minor) tiles
-    const int q = nblk / 8, r = nblk % 8, x = bid % 8, j = bid / 8;
-    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
-  }
-  const int tile_n = bid / nb_m, tile_m = bid % nb_m;
-  const int M = g.N * g.Hi * g.Wi;
-  const int KC = g.Ci / 16;
-  const int m0 = tile_m * BM;
-
-  // the last window pixel of every plane of both buffers stays zero: staging either skips it or fills it from zero16
-  if (tid < 32) {
-    const int q = tid >> 3, w8 = tid & 7;  // (buffer, plane) x 8 words
-    reinterpret_cast<unsigned*>(smem + (q >> 1) * CFG::WINZ + (q & 1) * CFG::W_PLANE + CFG::ZERO_OFF)[w8] = 0u;
-  }
-
-  // ---- window staging: wave-instruction i = it * NW + wave covers slots [64 i, 64 i + 64) of [plane][pixel][2];
-  //      per lane a pointer that advances by 16 channels per chunk (0 for rows outside the tensor: they read zero16)
-  const int need_px = BM + 2 * g.Wi + 2;  // window pixels this geometry reads; instructions wholly beyond them are skipped
-  const _Float16* w_ptr[CFG::W_IT];
-  int w_step[CFG::W_IT];
-#pragma unroll
-  for (int it = 0; it < CFG::W_IT; ++it) {
-    const int i = it * NW + wave;
-    const int sidx = i * 64 + lane;
-    const int rem = sidx % (2 * PP);
-    const int px = rem >> 1, pq = rem & 1;
-    const int64_t raster = (int64_t)m0 - (g.Wi + 1) + px;
-    const bool ok = raster >= 0 && raster < M && px < need_px;  // (pixels behind the window, the zero pixel among them: zero16)
-    const _Float16* plane = (i * 64 >= 2 * PP) ? Al : Ah;  // (whole instructions lie inside one plane: 2 PP % 64 == 0)
-    w_ptr[it] = ok ? plane + raster * g.Ci + ((pq ^ swz2(px)) << 3) : zero16;
-    w_step[it] = ok ? 16 : 0;
-  }
-  static_assert((2 * PP) % 64 == 0, "a window plane is a whole number of wave-instructions");
-  auto stage_win = [&](int buf) {  // the next chunk (the pointers advance)
-    const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + buf * CFG::WINZ;
-#pragma unroll
-    for (int it = 0; it < CFG::W_IT; ++it) {
-      const int i = it * NW + wave;  // (scalar)
-      if (i < CFG::W_INSTR && (((i * 64) % (2 * PP)) >> 1) < need_px)
-        __builtin_amdgcn_global_load_lds((gbl_void*)w_ptr[it], (lds_void*)(uintptr_t)(base + i * 1024), 16, 0, 0);
-      w_ptr[it] += w_step[it];
-    }
-  };
-  // ---- weight staging: slots [tap j of the step][plane][n][2]; an instruction lies inside one (tap, plane)
-  static_assert(BN % 32 == 0, "a weight instruction covers 32 output channels of one tap and plane");
-  const _Float16* b_ptr[CFG::B_IT];
-  int b_step[CFG::B_IT];
-#pragma unroll
-  for (int it = 0; it < CFG::B_IT; ++it) {
-    const int i = it * NW + wave;
-    const int sidx = i * 64 + lane;
-    const int pq = sidx & 1, n = (sidx >> 1) % BN, jp = (i * 32) / BN;  // jp: scalar
-    const int col = tile_n * BN + n;
-    const bool ok = col < g.Co;
-    b_ptr[it] = ok ? ((jp & 1) ? Wl : Wh) + (int64_t)col * g.Ci + ((pq ^ swz2(n)) << 3) : zero16;
-    b_step[it] = ok ? 1 : 0;
-  }
-  const int64_t w_tap = (int64_t)g.Co * g.Ci;
-  // tap constants as scalars: weight slice offsets (elements) and window shifts (pixels) of the nine taps
-  int64_t t_woff[9];
-  int t_shift[9];
-#pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    t_woff[t] = (int64_t)g.wt[t] * w_tap;
-    t_shift[t] = (g.dh[t] + 1) * g.Wi + g.dw[t] + 1;
-  }
-  auto stage_b = [&](int kc, int r, int slot) {  // r: compile-time after unrolling
-    const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + 2 * CFG::WINZ + slot * CFG::B_STEP;
-#pragma unroll
-    for (int it = 0; it < CFG::B_IT; ++it) {
-      const int i = it * NW + wave;  // (scalar)
-      if (i < CFG::B_INSTR) {
-        const int j = ((i * 32) / BN) >> 1;  // tap of the step (scalar)
-        const int64_t e = (j == 0 ? t_woff[r * 3] : j == 1 ? t_woff[r * 3 + 1] : t_woff[r * 3 + 2]) + kc * 16;
-        __builtin_amdgcn_global_load_lds((gbl_void*)(b_ptr[it] + e * b_step[it]), (lds_void*)(uintptr_t)(base + i * 1024), 16, 0, 0);
-      }
-    }
-  };
-
-  // ---- fragment addresses, once per tile: byte offsets inside a window buffer for every (tile a, tap t) — the zero
-  //      block where the tap falls outside the image — and inside a weight slot for every n-tile b
-  const int wm = wave / CFG::WN, wn = wave % CFG::WN;
-  const int lr = lane & 31, lh = lane >> 5;
-  int a_addr[TM][9];
-#pragma unroll
-  for (int a = 0; a < TM; ++a) {
-    const int m = m0 + (wm * TM + a) * 32 + lr;
-    int h = 0, w = 0;
-    const bool in = m < M;
-    if (in) {
-      const int rem = m - fdiv(m, g.div_hw) * (g.Hi * g.Wi);
-      h = fdiv(rem, g.div_w), w = rem - h * g.Wi;
-    }
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int hh = h + g.dh[t], ww = w + g.dw[t];
-      const bool ok = in && hh >= 0 && hh < g.Hi && ww >= 0 && ww < g.Wi;
-      const int px = (wm * TM + a) * 32 + lr + t_shift[t];
-      a_addr[a][t] = ok ? (px * 2 + (lh ^ swz2(px))) * 16 : CFG::ZERO_OFF;
-    }
-  }
-  int b_addr[TN];
-#pragma unroll
-  for (int b = 0; b < TN; ++b) {
-    const int n = (wn * TN + b) * 32 + lr;
-    b_addr[b] = n * 32 + (lh ^ swz2(n)) * 16;
-  }
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int a = 0; a < TM; ++a)
-#pragma unroll
-    for (int b = 0; b < TN; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-  const int sexp_a = a_sexp[0], sexp_w = w_sexp[0];
-  const float inv_a = exp2i(-sexp_a < -126 ? -126 : -sexp_a), inv_w = exp2i(-sexp_w < -126 ? -126 : -sexp_w);
-  int so = 0;
-  float sc_out = 1.f, inv2 = 0.f;
-  if constexpr (FUSE) {  // scale of the result from the guaranteed bound (see conv_f16x2_kernel)
-    float bound = fz.in_amax ? __uint_as_float(fz.in_amax[0]) : exp2i(15 - sexp_a < -126 ? -126 : (15 - sexp_a > 127 ? 127 : 15 - sexp_a));
-    bound *= fz.w_l1[0];
-    if (fz.add_h) {
-      const int s2 = fz.add_sexp[0];
-      bound += exp2i(15 - s2 < -126 ? -126 : (15 - s2 > 127 ? 127 : 15 - s2));
-      inv2 = exp2i(-s2 < -126 ? -126 : -s2);
-    }
-    if (fz.mask && fz.mask_float && fz.mult_amax) bound *= __uint_as_float(fz.mult_amax[0]);
-    if (fz.scale) bound *= __uint_as_float(fz.scale_amax[0]);
-    so = scale_exp_for(bound);
-    sc_out = exp2i(so);
-    if (blockIdx.x == 0 && tid == 0) fz.out_sexp[0] = so;
-  }
-
-  // prologue: the first window and the first three taps
-  stage_win(0);
-  stage_b(0, 0, 0);
-  for (int kc = 0; kc < KC; ++kc) {
-    const char* pw = smem + (kc & 1) * CFG::WINZ;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const int slot = (kc + r) & 1;  // = (3 kc + r) & 1
-      __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's parts of this step (and of the window of chunk kc) have landed
-      if (!(ablate & 32)) __syncthreads();  // ... everybody's; and nobody reads the buffers that are loaded next any more
-      if (!(ablate & 4)) {
-        if (r < 2) stage_b(kc, r + 1, slot ^ 1);
-        else if (kc + 1 < KC) stage_b(kc + 1, 0, slot ^ 1);
-        if (r == 0 && kc + 1 < KC) stage_win((kc + 1) & 1);
-      }
-      const char* pb = smem + 2 * CFG::WINZ + slot * CFG::B_STEP;
-      // the fragments of tap j + 1 are requested BEFORE the MFMAs of tap j are issued (two register sets): the LDS
-      // latency of a tap's eight reads (~350 cycles with eight waves reading) otherwise parks the wave in front of every
-      // tap, and the two waves of a SIMD — in lockstep behind the hand-over barrier — wait at the same time
-      f16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
-      auto load_frags = [&](int j, int set) {
-        const int t = r * 3 + j;  // compile-time after unrolling
-#pragma unroll
-        for (int a = 0; a < TM; ++a) {
-          ah[set][a] = *reinterpret_cast<const f16x8*>(pw + a_addr[a][t]);
-          al[set][a] = *reinterpret_cast<const f16x8*>(pw + a_addr[a][t] + CFG::W_PLANE);
-        }
-#pragma unroll
-        for (int b = 0; b < TN; ++b) {
-          bh[set][b] = *reinterpret_cast<const f16x8*>(pb + b_addr[b] + (j * 2) * CFG::B_TAP);
-          bl[set][b] = *reinterpret_cast<const f16x8*>(pb + b_addr[b] + (j * 2 + 1) * CFG::B_TAP);
-        }
-      };
-      load_frags(0, 0);
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const int set = j & 1;
-        if (j + 1 < 3) load_frags(j + 1, set ^ 1);
-        // (left to itself hipcc sinks these reads back behind the MFMAs into ONE register set and waits lgkmcnt(0) twice
-        // per tap; pinned, it keeps both sets and waits for the older eight reads only)
-        __builtin_amdgcn_sched_barrier(0);
-#ifdef LK_CONV_DEV
-        if (ablate & 2) {
-#pragma unroll
-          for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int b = 0; b < TN; ++b) acc[a][b][0] += (float)ah[set][a][0] + (float)al[set][a][1] + (float)bh[set][b][2] + (float)bl[set][b][3];
-          continue;
-        }
-#endif
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-          for (int b = 0; b < TN; ++b) {
-            f32x16 c = acc[a][b];
-            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[set][a], bh[set][b], c, 0, 0, 0);  // small terms first
-            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[set][a], bl[set][b], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[set][a], bh[set][b], c, 0, 0, 0);
-            acc[a][b] = c;
-          }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-  }
-  if (ablate & 1) {
-    if (acc[0][0][0] == 12345.678f) out[0] = 1.f;  // (keeps the loop alive)
-    return;
-  }
-
-  if constexpr (FUSE) {
-    fused_vjp_epilogue<TM, TN>(acc, smem, wave, lane, m0 + wm * (TM * 32), tile_n * BN + wn * (TN * 32), M, g, fz, inv_a * inv_w,
-                               inv2, sc_out, so, amax_out);
-    return;
-  }
-  // ---- plain epilogue: un-scale, store NHWC (the output grid may be a strided class of the output tensor), max|out|
-  unsigned vmax = 0;
-#pragma unroll
-  for (int a = 0; a < TM; ++a) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const int m = m0 + row;
-      if (m >= M) continue;
-      int64_t opix = m;
-      if (!g.dense) {
-        const int n = fdiv(m, g.div_hw), rem = m - n * (g.Hi * g.Wi);
-        const int ci_ = fdiv(rem, g.div_w);
-        opix = ((int64_t)n * g.Ho + ci_ * g.os + g.oh0) * g.Wo + (rem - ci_ * g.Wi) * g.os + g.ow0;
-      }
-      float* orow = out + opix * g.Co;
-#pragma unroll
-      for (int b = 0; b < TN; ++b) {
-        const int col = tile_n * BN + (wn * TN + b) * 32 + lr;
-        if (col < g.Co) {
-          float v = acc[a][b][r] * inv_a * inv_w;
-          if (accumulate) v += orow[col];
           orow[col] = v;
           vmax = max(vmax, __float_as_uint(v) & 0x7fffffffu);
         }
@@ -1478,6 +623,8 @@ void conv_win_f16x2_kernel(const ConvGeom g, const _Float16* __restrict__ Ah, co
   }
 }
 
+
+__device__ __forceinline__ int swz2(int row) { return (row >> 3) & 1; }  // two 16-byte slots per row (see swz<2>)
 
 // ---- persistent window form ------------------------------------------------------------------------------------------
 // Round 3's measurements (profiles/r03_win_ablate.txt) say what bounds a fused 64-channel launch: not the matrix
@@ -2004,45 +1151,13 @@ extern "C" int lk_conv_prep_weights_f16x2(const float* W, int64_t Co, int64_t Ci
 
 extern "C" int lk_conv_winp_eligible(int64_t N, int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t T, int mask_is_float);
 
-static int g_ablate = 0;  // development switch (config bits 8..10 of lk_conv_nhwc_f16x2): skip stores / MFMAs / staging
-
-// GRAM launches (see the kernel): 64 output channels on the 256 x 64 tile; the grid is one round of workgroups, each
-// walking through `tiles_per_wg` consecutive pixel tiles
-typedef ConvCfg<256, 64, 32, 4, 1> GramConvCfg;
-static void gram_conv_plan(int64_t M, int* tiles_per_wg, int* n_wg) {
-  const int64_t nb_m = (M + GramConvCfg::BM - 1) / GramConvCfg::BM;
-  int64_t per = (nb_m + 511) / 512;
-  if (per < 1) per = 1;
-  *tiles_per_wg = (int)per;
-  *n_wg = (int)((nb_m + per - 1) / per);
-}
-
 template <typename CFG>
 static int launch_conv(const ConvGeom& g, const void* Ah, const void* Al, const void* Wh, const void* Wl, const int* a_sexp,
                        const int* w_sexp, const void* zero16, float* out, int accumulate, unsigned* amax_out,
-                       hipStream_t stream, const ConvVjp* fz = nullptr, float* gram_ws = nullptr) {
+                       hipStream_t stream, const ConvVjp* fz = nullptr) {
   const int64_t M = (int64_t)g.N * g.Hc * g.Wc;
   const int nb_m = (int)((M + CFG::BM - 1) / CFG::BM), nb_n = (g.Co + CFG::BN - 1) / CFG::BN;
   const size_t lds = (size_t)CFG::NBUF * CFG::STAGE;
-  if (fz && gram_ws) {
-    if constexpr (std::is_same<CFG, GramConvCfg>::value) {
-      const size_t lds_f = lds > (size_t)CFG::EPI_LDS ? lds : (size_t)CFG::EPI_LDS;
-      static bool attr_set_g = false;
-      if (!attr_set_g) {
-        (void)hipFuncSetAttribute((const void*)conv_f16x2_kernel<CFG, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);
-        attr_set_g = true;
-      }
-      int per, n_wg;
-      gram_conv_plan(M, &per, &n_wg);
-      hipLaunchKernelGGL((conv_f16x2_kernel<CFG, true, true>), dim3((unsigned)n_wg), dim3(CFG::NT), lds_f, stream, g,
-                         (const _Float16*)Ah, (const _Float16*)Al, (const _Float16*)Wh, (const _Float16*)Wl, a_sexp, w_sexp,
-                         (const _Float16*)zero16, out, accumulate, amax_out, nb_m, g_ablate, *fz, per, nb_m * nb_n, gram_ws);
-      return check_launch("conv_f16x2_kernel(vjp + gram)");
-    } else {
-      set_error("lk_conv_nhwc_f16x2_vjp_gram: the fused Gram needs the 256 x 64 tile (Co == 64)");
-      return LK_EINVAL;
-    }
-  }
   if (fz) {
     if constexpr (CFG::FUSABLE) {
       const size_t lds_f = lds > (size_t)CFG::EPI_LDS ? lds : (size_t)CFG::EPI_LDS;
@@ -2053,10 +1168,10 @@ static int launch_conv(const ConvGeom& g, const void* Ah, const void* Al, const 
       }
       hipLaunchKernelGGL((conv_f16x2_kernel<CFG, true>), dim3((unsigned)(nb_m * nb_n)), dim3(CFG::NT), lds_f, stream, g,
                          (const _Float16*)Ah, (const _Float16*)Al, (const _Float16*)Wh, (const _Float16*)Wl, a_sexp, w_sexp,
-                         (const _Float16*)zero16, out, accumulate, amax_out, nb_m, g_ablate, *fz, 1, nb_m * nb_n, (float*)nullptr);
+                         (const _Float16*)zero16, out, accumulate, amax_out, nb_m, *fz);
       return check_launch("conv_f16x2_kernel(vjp)");
     } else {
-      set_error("lk_conv_nhwc_f16x2_vjp: this K-pipeline variant has no fused epilogue");
+      set_error("lk_conv_nhwc_f16x2_vjp: this tile shape has no fused epilogue");
       return LK_EINVAL;
     }
   }
@@ -2067,53 +1182,8 @@ static int launch_conv(const ConvGeom& g, const void* Ah, const void* Al, const 
   }
   hipLaunchKernelGGL((conv_f16x2_kernel<CFG, false>), dim3((unsigned)(nb_m * nb_n)), dim3(CFG::NT), lds, stream, g, (const _Float16*)Ah,
                      (const _Float16*)Al, (const _Float16*)Wh, (const _Float16*)Wl, a_sexp, w_sexp, (const _Float16*)zero16,
-                     out, accumulate, amax_out, nb_m, g_ablate, ConvVjp{}, 1, nb_m * nb_n, (float*)nullptr);
+                     out, accumulate, amax_out, nb_m, ConvVjp{});
   return check_launch("conv_f16x2_kernel");
-}
-template <typename CFG>
-static int launch_patch(const ConvGeom& g, const void* Ah, const void* Al, const void* Wh, const void* Wl, const int* a_sexp,
-                        const int* w_sexp, const void* zero16, float* out, int accumulate, unsigned* amax_out,
-                        hipStream_t stream) {
-  const int64_t M = (int64_t)g.N * g.Hi * g.Wi;
-  const int nb_m = (int)((M + CFG::BM - 1) / CFG::BM), nb_n = (g.Co + CFG::BN - 1) / CFG::BN;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_patch_f16x2_kernel<CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(conv_patch_f16x2_kernel<CFG>, dim3((unsigned)(nb_m * nb_n)), dim3(512), CFG::LDS, stream, g,
-                     (const _Float16*)Ah, (const _Float16*)Al, (const _Float16*)Wh, (const _Float16*)Wl, a_sexp, w_sexp,
-                     (const _Float16*)zero16, out, accumulate, amax_out, nb_m, g_ablate);
-  return check_launch("conv_patch_f16x2_kernel");
-}
-
-template <typename CFG>
-static int launch_win(const ConvGeom& g, const void* Ah, const void* Al, const void* Wh, const void* Wl, const int* a_sexp,
-                      const int* w_sexp, const void* zero16, float* out, int accumulate, unsigned* amax_out,
-                      hipStream_t stream, const ConvVjp* fz) {
-  const int64_t M = (int64_t)g.N * g.Hi * g.Wi;
-  const int nb_m = (int)((M + CFG::BM - 1) / CFG::BM), nb_n = (g.Co + CFG::BN - 1) / CFG::BN;
-  if (fz) {
-    const int lds_f = CFG::LDS > CFG::EPI_LDS ? CFG::LDS : CFG::EPI_LDS;
-    static bool attr_set_f = false;
-    if (!attr_set_f) {
-      (void)hipFuncSetAttribute((const void*)conv_win_f16x2_kernel<CFG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_f);
-      attr_set_f = true;
-    }
-    hipLaunchKernelGGL((conv_win_f16x2_kernel<CFG, true>), dim3((unsigned)(nb_m * nb_n)), dim3(CFG::NT), lds_f, stream, g,
-                       (const _Float16*)Ah, (const _Float16*)Al, (const _Float16*)Wh, (const _Float16*)Wl, a_sexp, w_sexp,
-                       (const _Float16*)zero16, out, accumulate, amax_out, nb_m, *fz, g_ablate);
-    return check_launch("conv_win_f16x2_kernel(vjp)");
-  }
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_win_f16x2_kernel<CFG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((conv_win_f16x2_kernel<CFG, false>), dim3((unsigned)(nb_m * nb_n)), dim3(CFG::NT), CFG::LDS, stream, g,
-                     (const _Float16*)Ah, (const _Float16*)Al, (const _Float16*)Wh, (const _Float16*)Wl, a_sexp, w_sexp,
-                     (const _Float16*)zero16, out, accumulate, amax_out, nb_m, ConvVjp{}, g_ablate);
-  return check_launch("conv_win_f16x2_kernel");
 }
 
 static int cu_count() {
@@ -2188,8 +1258,7 @@ static int conv_dispatch(const void* in_h, const void* in_l, const int* in_sexp,
                          int64_t Ci, const void* w_h, const void* w_l, const int* w_sexp, int64_t Co,
                          int64_t Hc, int64_t Wc, int64_t in_mul, int64_t Ho, int64_t Wo, int64_t out_step,
                          int64_t oh0, int64_t ow0, int64_t T, const int* taps, const void* zero16, float* out,
-                         int accumulate, unsigned* amax_out, int config, void* stream, const ConvVjp* fz,
-                         float* gram_ws = nullptr) {
+                         int accumulate, unsigned* amax_out, int config, void* stream, const ConvVjp* fz) {
   LK_REQUIRE(in_h && in_l && in_sexp && w_h && w_l && w_sexp && zero16 && (out || fz) && taps, "lk_conv_nhwc_f16x2: null pointer");
   LK_REQUIRE(T >= 1 && T <= 9 && Ci >= 32 && Ci % 32 == 0 && Co >= 1 && N >= 1, "lk_conv_nhwc_f16x2: Ci % 32 == 0, 1..9 taps");
   LK_REQUIRE(N * Hc * Wc < (1ll << 31) && N * Hi * Wi * Ci < (1ll << 40), "lk_conv_nhwc_f16x2: tensor too large");
@@ -2204,68 +1273,26 @@ static int conv_dispatch(const void* in_h, const void* in_l, const int* in_sexp,
   g.pmajor = (Hc * Wc <= (64 << (2 * ((config >> 16) & 3))) && N >= 64 && !(config & 16) && !(config & 32768)) ? 1 : 0;
   g.dense = out_step == 1 && oh0 == 0 && ow0 == 0 && Hc == Ho && Wc == Wo;
   g.out_nchw = (config & 16) ? 1 : 0;
-  // K order: bit 19 = chunk-major everywhere; bit 25 = chunk-major where the input has 128 or 256 channels (a tile's
-  // window then has to survive 36 / 72 stages between a tap and the next in tap-major order: measured 3.2 x the operand
-  // bytes from the fabric on those launches, none on the 64-channel ones)
-  g.chunk_major = ((config & 524288) || ((config & 33554432) && (Ci == 128 || Ci == 256))) ? 1 : 0;
   LK_REQUIRE(!g.out_nchw || (g.dense && (Ho * Wo) % 4 == 0 && !accumulate),
              "lk_conv_nhwc_f16x2: position-contiguous output needs a dense grid with Ho*Wo % 4 == 0 and no accumulate");
   hipStream_t st = (hipStream_t)stream;
-  if (fz && gram_ws) {
-    LK_REQUIRE(lk_conv_vjp_gram_parts(N, Ho, Wo, Co, config) > 0, "lk_conv_nhwc_f16x2_vjp_gram: shape not eligible (lk_conv_vjp_gram_parts)");
-    g_ablate = 0;
-    return launch_conv<GramConvCfg>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz, gram_ws);
-  }
-  g_ablate = ((config >> 8) & 7) | ((config & 1048576) ? 16 : 0) | ((config & 2097152) ? 32 : 0);  // (development build only)
   // persistent window form (fused launches with 64 output channels whose caller also handed over chunk-major weights;
   // config bit 27 switches it off): see conv_winp_f16x2_kernel
-  if (fz && fz->wc_h && !(config & 134217728) && !gram_ws && lk_conv_winp_eligible(N, Hi, Wi, Ci, Co, T, fz->mask && fz->mask_float) &&
+  if (fz && fz->wc_h && !(config & 134217728) && lk_conv_winp_eligible(N, Hi, Wi, Ci, Co, T, fz->mask && fz->mask_float) &&
       in_mul == 1 && Hc == Hi && Wc == Wi && g.dense) {
     int rc = LK_OK;
     if (launch_winp<WinPCfg<256>>(g, in_h, in_l, fz->wc_h, fz->wc_l, in_sexp, w_sexp, amax_out, st, fz, &rc)) return rc;
   }
-  // "window" form (config bit 22): nine taps inside [-1, 1]^2 on the input grid, maps of more than 64 pixels (small maps
-  // run position-major with tap skipping), enough tiles to fill the chip; bit 23: the 512-pixel tile for 64 output channels
-  if ((config & 4194304) && T == 9 && in_mul == 1 && Hc == Hi && Wc == Wi && 2 * Wi + 2 <= 94 && Ci % 16 == 0 && !(config & 16) &&
-      !g.pmajor && (Co == 64 || Co % 128 == 0)) {
-    bool ok = true;
-    for (int t = 0; t < 9; ++t) ok = ok && g.dh[t] >= -1 && g.dh[t] <= 1 && g.dw[t] >= -1 && g.dw[t] <= 1;
-    const int64_t M = N * Hi * Wi;
-    if (ok && (config & 16777216)) {  // four-wave workgroups, two per CU: one workgroup's epilogue under the other's K loop
-      if (Co == 64 && M >= 256 * 512)
-        return launch_win<WinCfg<256, 64, 4, 1, 2>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz);
-      if (Co % 128 == 0 && M * (Co / 128) >= 128 * 512)
-        return launch_win<WinCfg<128, 128, 2, 2, 2>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz);
-    }
-    if (ok && Co == 64 && (config & 8388608) && M >= 512 * 256)
-      return launch_win<WinCfg<512, 64, 8, 1, 2>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz);
-    if (ok && Co == 64 && M >= 256 * 512)
-      return launch_win<WinCfg<256, 64, 4, 2, 4>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz);
-    if (ok && Co % 128 == 0 && M * (Co / 128) >= 256 * 256)
-      return launch_win<WinCfg<256, 128, 4, 2, 2>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz);
-  }
-  // "patch" form (A operand resident in LDS across the taps) where the output grid is the input grid
-  bool patch = !fz && !(config & 2) && !(config & 16) && in_mul == 1 && Hc == Hi && Wc == Wi && 256 + 2 * Wi + 2 <= 336 && N * Hi * Wi >= 256;
-  if ((config & 262144) && Co > 64) patch = false;  // development switch: the patch form for the 64-channel layers only
-  for (int t = 0; t < T && patch; ++t) patch = g.dh[t] >= -1 && g.dh[t] <= 1 && g.dw[t] >= -1 && g.dw[t] <= 1;
-  if (patch) {
-    g.pmajor = 0;  // the patch form walks raster pixels
-    if (Co <= 64)
-      return launch_patch<PatchCfg<64, 4, 2>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st);
-    return launch_patch<PatchCfg<128, 4, 2>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st);
-  }
-  const bool bk64 = (Ci % 64 == 0) && (config & 1);
 #define LK_CONV_GO(...) return launch_conv<ConvCfg<__VA_ARGS__>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz)
-  switch ((config >> 12) & 7) {  // explicit tile shape (bits 12..14); 0: chosen below
+  switch ((config >> 12) & 7) {  // explicit tile shape (bits 12..14; the tests walk through them); 0: chosen below
     case 1: LK_CONV_GO(64, 64, 32, 2, 2, 2, 4);
     case 2: LK_CONV_GO(128, 64, 32, 2, 2, 2, 3);
     case 3: LK_CONV_GO(64, 128, 32, 2, 2, 2, 3);
     case 4: LK_CONV_GO(128, 128, 32, 2, 2);
     case 5: LK_CONV_GO(256, 64, 32, 4, 1);
-    case 6: break;  // the big tile by output width only (the choice before the occupancy rule)
     default: break;
   }
-  if (((config >> 12) & 7) == 0 && !(config & (1 | 4 | 8 | 32 | 2048))) {
+  {
     // Tile shape by occupancy (measured on the c4 layer shapes, profiles/r02_conv_tile_sweep.json): the big tile
     // (2 workgroups per CU = 512 slots) when it fills the chip and its last round is not mostly idle; otherwise the
     // half tile (3 per CU) if that gives >= 512 tiles; otherwise 64 x 64 (the forward of the deep, small-map layers at
@@ -2284,38 +1311,10 @@ static int conv_dispatch(const void* in_h, const void* in_l, const int* in_sexp,
       }
       LK_CONV_GO(64, 64, 32, 2, 2, 2, 4);
     }
+    if (narrow) LK_CONV_GO(256, 64, 32, 4, 1);
+    LK_CONV_GO(128, 128, 32, 2, 2);
   }
-  if (config & 8) {  // 8 waves, one workgroup per CU: 256 x 128 (256 x 64) tile, three LDS stages (two in flight)
-    if (Co <= 64)
-      return launch_conv<ConvCfg<256, 64, 32, 4, 2, 3>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz);
-    return launch_conv<ConvCfg<256, 128, 32, 4, 2, 3>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz);
-  }
-  if (config & 2048) {  // hand-over barrier in the middle of a stage, fragments one k16 step ahead across stages
-    if (Co <= 64)
-      return launch_conv<ConvCfg<256, 64, 32, 4, 1, 2, 2, true>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz);
-    return launch_conv<ConvCfg<128, 128, 32, 2, 2, 2, 2, true>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz);
-  }
-  if (config & 32) {  // 16-deep chunks, two or three LDS stages, registers sized for three waves per SIMD: 3+ workgroups per CU
-    if (config & 64) {
-      if (Co <= 64)
-        return launch_conv<ConvCfg<256, 64, 16, 4, 1, 3, 3>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz);
-      return launch_conv<ConvCfg<128, 128, 16, 2, 2, 3, 3>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz);
-    }
-    if (Co <= 64)
-      return launch_conv<ConvCfg<256, 64, 16, 4, 1, 2, 3>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz);
-    return launch_conv<ConvCfg<128, 128, 16, 2, 2, 2, 3>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz);
-  }
-  if (config & 4) {  // 16-deep chunks, four LDS stages (three stages of loads in flight)
-    if (Co <= 64)
-      return launch_conv<ConvCfg<256, 64, 16, 4, 1, 4>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz);
-    return launch_conv<ConvCfg<128, 128, 16, 2, 2, 4>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz);
-  }
-  if (Co <= 64) {
-    return bk64 ? launch_conv<ConvCfg<256, 64, 64, 4, 1>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz)
-                : launch_conv<ConvCfg<256, 64, 32, 4, 1>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz);
-  }
-  return bk64 ? launch_conv<ConvCfg<128, 128, 64, 2, 2>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz)
-              : launch_conv<ConvCfg<128, 128, 32, 2, 2>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz);
+#undef LK_CONV_GO
 }
 
 // Does a fused 3 x 3 / stride-1 launch of this shape qualify for the persistent window form (conv_winp_f16x2_kernel)?  The
@@ -2325,21 +1324,6 @@ extern "C" int lk_conv_winp_eligible(int64_t N, int64_t Hi, int64_t Wi, int64_t 
                  N * Hi * Wi * Co < (1ll << 31) && N * Hi * Wi >= 512 && !mask_is_float
              ? 1
              : 0;
-}
-
-// Workgroups (= 64 x 64 partials) of a fused launch that also accumulates the Gram of its result; 0 = not eligible: the
-// result must have exactly 64 channels, the map more than 64 pixels (position-major tiles mix pixels of many images into a
-// wave in another order; they are small layers anyway), no explicit tile / pipeline variant may be selected, and there
-// must be at least one round of 256 x 64 tiles.
-extern "C" int64_t lk_conv_vjp_gram_parts(int64_t N, int64_t Ho, int64_t Wo, int64_t Co, int config) {
-  if (Co != 64 || N < 1 || Ho < 1 || Wo < 1) return 0;
-  if (Ho * Wo <= (64 << (2 * ((config >> 16) & 3))) && N >= 64 && !(config & 32768)) return 0;  // position-major rows
-  if (((config >> 12) & 7) || (config & (1 | 4 | 8 | 16 | 32 | 64 | 2048))) return 0;
-  const int64_t M = N * Ho * Wo;
-  if ((M + 255) / 256 < 512) return 0;
-  int per, n_wg;
-  gram_conv_plan(M, &per, &n_wg);
-  return n_wg;
 }
 
 extern "C" int lk_conv_nhwc_f16x2(const void* in_h, const void* in_l, const int* in_sexp, int64_t N, int64_t Hi, int64_t Wi,
@@ -2359,8 +1343,7 @@ static int conv_vjp_impl(const void* in_h, const void* in_l, const int* in_sexp,
                          const void* zero16, const void* add_h, const void* add_l, const int* add_sexp,
                          const void* mask, int mask_is_float, const void* mult_amax, int64_t mask_rows,
                          const float* scale, const void* scale_amax, void* out_h, void* out_l, int* out_sexp,
-                         void* out_amax, int config, void* stream, float* gram_ws, const void* wc_h = nullptr,
-                         const void* wc_l = nullptr) {
+                         void* out_amax, int config, void* stream, const void* wc_h = nullptr, const void* wc_l = nullptr) {
   LK_REQUIRE(w_l1 && out_h && out_l && out_sexp && out_amax, "lk_conv_nhwc_f16x2_vjp: null pointer");
   LK_REQUIRE(!wc_h == !wc_l, "lk_conv_nhwc_f16x2_vjp_wc: incomplete chunk-major weights");
   LK_REQUIRE(Co % 8 == 0, "lk_conv_nhwc_f16x2_vjp: Co % 8 == 0");
@@ -2377,7 +1360,7 @@ static int conv_vjp_impl(const void* in_h, const void* in_l, const int* in_sexp,
   fz.out_h = (_Float16*)out_h, fz.out_l = (_Float16*)out_l, fz.out_sexp = out_sexp;
   fz.wc_h = (const _Float16*)wc_h, fz.wc_l = (const _Float16*)wc_l;
   return conv_dispatch(in_h, in_l, in_sexp, N, Hi, Wi, Ci, w_h, w_l, w_sexp, Co, Ho, Wo, 1, Ho, Wo, 1, 0, 0, T, taps, zero16,
-                       nullptr, 0, (unsigned*)out_amax, config & ~(1 | 4 | 8 | 16 | 32 | 64 | 2048), stream, &fz, gram_ws);
+                       nullptr, 0, (unsigned*)out_amax, config & ~16, stream, &fz);
 }
 
 extern "C" int lk_conv_nhwc_f16x2_vjp(const void* in_h, const void* in_l, const int* in_sexp, const void* in_amax, int64_t N,
@@ -2389,7 +1372,7 @@ extern "C" int lk_conv_nhwc_f16x2_vjp(const void* in_h, const void* in_l, const 
                                       void* out_amax, int config, void* stream) {
   return conv_vjp_impl(in_h, in_l, in_sexp, in_amax, N, Hi, Wi, Ci, w_h, w_l, w_sexp, w_l1, Co, Ho, Wo, T, taps, zero16, add_h,
                        add_l, add_sexp, mask, mask_is_float, mult_amax, mask_rows, scale, scale_amax, out_h, out_l, out_sexp,
-                       out_amax, config, stream, nullptr);
+                       out_amax, config, stream);
 }
 
 // lk_conv_nhwc_f16x2_vjp with the weights ALSO in chunk-major order (wc_h / wc_l: [tap][Ci / 16][Co][16] fp16 per plane, same
@@ -2404,24 +1387,5 @@ extern "C" int lk_conv_nhwc_f16x2_vjp_wc(const void* in_h, const void* in_l, con
                                          int* out_sexp, void* out_amax, int config, void* stream) {
   return conv_vjp_impl(in_h, in_l, in_sexp, in_amax, N, Hi, Wi, Ci, w_h, w_l, w_sexp, w_l1, Co, Ho, Wo, T, taps, zero16, add_h,
                        add_l, add_sexp, mask, mask_is_float, mult_amax, mask_rows, scale, scale_amax, out_h, out_l, out_sexp,
-                       out_amax, config, stream, nullptr, wc_h, wc_l);
-}
-
-// lk_conv_nhwc_f16x2_vjp that ALSO leaves the Gram of its result, o^T o over all output pixels, as
-// lk_conv_vjp_gram_parts(N, Ho, Wo, Co, config) partial 64 x 64 blocks (upper 32 x 32 tiles, in units of 2^(-2 out_sexp))
-// in gram_ws; lk_gram_partials_reduce_f16x2 adds their sum to a G factor.
-extern "C" int lk_conv_nhwc_f16x2_vjp_gram(const void* in_h, const void* in_l, const int* in_sexp, const void* in_amax, int64_t N,
-                                           int64_t Hi, int64_t Wi, int64_t Ci, const void* w_h, const void* w_l,
-                                           const int* w_sexp, const float* w_l1, int64_t Co, int64_t Ho, int64_t Wo, int64_t T,
-                                           const int* taps, const void* zero16, const void* add_h, const void* add_l,
-                                           const int* add_sexp, const void* mask, int mask_is_float, const void* mult_amax,
-                                           int64_t mask_rows, const float* scale, const void* scale_amax, void* out_h,
-                                           void* out_l, int* out_sexp, void* out_amax, float* gram_ws, int64_t gram_ws_floats,
-                                           int config, void* stream) {
-  LK_REQUIRE(gram_ws, "lk_conv_nhwc_f16x2_vjp_gram: null workspace");
-  const int64_t parts = lk_conv_vjp_gram_parts(N, Ho, Wo, Co, config & ~(1 | 4 | 8 | 16 | 32 | 64 | 2048));
-  LK_REQUIRE(parts > 0 && gram_ws_floats >= parts * 64 * 64, "lk_conv_nhwc_f16x2_vjp_gram: shape not eligible or workspace too small");
-  return conv_vjp_impl(in_h, in_l, in_sexp, in_amax, N, Hi, Wi, Ci, w_h, w_l, w_sexp, w_l1, Co, Ho, Wo, T, taps, zero16, add_h,
-                       add_l, add_sexp, mask, mask_is_float, mult_amax, mask_rows, scale, scale_amax, out_h, out_l, out_sexp,
-                       out_amax, config, stream, gram_ws);
+                       out_amax, config, stream, wc_h, wc_l);
 }

@@ -634,17 +634,6 @@ extern "C" int lk_gram_tn_f16x2(const void* x_h, const void* x_l, const int* sex
   return check_launch("gram16_reduce4_kernel");
 }
 
-// G[64][64] (upper 32x32 tiles) += alpha * 2^(-2 sexp) * sum of `nparts` partial blocks [nparts][64][64] left by a fused
-// convolution launch (lk_conv_nhwc_f16x2_vjp_gram), in a fixed order.
-extern "C" int lk_gram_partials_reduce_f16x2(const float* parts, int64_t nparts, int64_t C, const int* sexp, float alpha,
-                                             float* Gm, void* stream) {
-  LK_REQUIRE(parts && sexp && Gm && nparts >= 1 && nparts < (1ll << 31), "lk_gram_partials_reduce_f16x2: bad arguments");
-  LK_REQUIRE(C == 64, "lk_gram_partials_reduce_f16x2: C must be 64");
-  hipLaunchKernelGGL(gram16_reduce_kernel<64>, dim3(64 * 64 / 32, 1), dim3(256), 0, (hipStream_t)stream, parts, (int)nparts, 1,
-                     1, (int)C, sexp, alpha, Gm);
-  return check_launch("gram16_reduce_kernel(partials)");
-}
-
 // Pixel-pair blocks of a 3x3 convolution's A factor from a split tensor (see Gram16Tnp): x [B][H][W][Cin] as planes with
 // one scale, tables of lk_conv3x3_pixpair_tables (tile edge 64 for Cin % 128 != 0, else 128).
 extern "C" int lk_conv3x3_pixpair_accumulate_f16x2(const void* x_h, const void* x_l, const int* sexp, int64_t B, int64_t H,

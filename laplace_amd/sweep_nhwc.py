@@ -299,10 +299,8 @@ class SplitSweep(SeedBatchedSweep):
         if lazy:
             rest = [p for p in parts if not isinstance(p, _LazyConv)]
             if len(lazy) == 1 and lazy[0]._done is None and len(rest) <= 1 and all(isinstance(p, SplitTensor) for p in rest):
-                # (in a KFAC sweep every cotangent that comes out of a fused launch is the output gradient of a tapped
-                # convolution, possibly up to a deferred BatchNorm scale: let the launch accumulate its Gram on the way)
                 return lazy[0].fused(add=rest[0] if rest else None, mult=mult, mult_amax=mult_amax, scale=scale,
-                                     scale_amax=scale_amax, want_gram=self._want_gram,
+                                     scale_amax=scale_amax,
                                      amax_word=self._new_word() if self._new_word is not None else None)
             parts = _materialize(parts)
         f32 = [p for p in parts if isinstance(p, _F32)]
@@ -329,18 +327,14 @@ class SplitSweep(SeedBatchedSweep):
                                 scale_amax, S, tuple(shape))
 
     # ---- reverse sweep ------------------------------------------------------------------------------------------------
-    _want_gram = False
     _new_word = None  # zeroed device words of the running sweep (one fill per 64 of them)
 
     @torch.no_grad()
-    def backward(self, seeds, on_tap=None, defer_bn_scale: bool = False, keep_split: bool = False, fuse_gram: bool = False):
+    def backward(self, seeds, on_tap=None, defer_bn_scale: bool = False, keep_split: bool = False):
         """``keep_split``: hand conv-tap gradients back as NHWC SplitTensors (consumers with their own kernels for
-        them) instead of converting to ``[S, B, C, H, W]`` fp32.  ``fuse_gram``: the consumer builds G factors
-        (``expand``): fused convolution launches leave the Gram partials of their result with it
-        (``SplitTensor.gram_parts``) where they can."""
+        them) instead of converting to ``[S, B, C, H, W]`` fp32."""
         if not self.split_ok:
             return super().backward(seeds, on_tap=on_tap, defer_bn_scale=defer_bn_scale)
-        self._want_gram = bool(fuse_gram)
         K = self.kernels()
         self.grad_scale = {}
         self._mult_cache = {}

@@ -1,5 +1,5 @@
 """Import the UNMODIFIED reference package from /root/reference (this container), or from the archive of it that
-`stage_reference()` packed into the git-ignored oracle/_ref/ (GPU box).
+`stage_reference()` (run by the test session in this container, tests/conftest.py) packed into the git-ignored oracle/_ref/ (GPU box).
 
 TEST INFRASTRUCTURE - not product code.  Only `oracle/make_golden.py` and the
 `not gpu` oracle-pinning tests use this, and only where `/root/reference` exists.
@@ -56,7 +56,7 @@ def reference_root() -> str | None:
 
         dst = tempfile.mkdtemp(prefix="lk_reference_")
         with tarfile.open(STAGED_ARCHIVE, "r:gz") as tar:
-            tar.extractall(dst)
+            tar.extractall(dst, filter="data")
         _unpacked = dst
         return dst
     return None

@@ -121,18 +121,13 @@ class EmulatedKernels:
             amax_out.copy_(torch.maximum(amax_out, view.abs().max().reshape(1)))
         return out
 
-    fuse_gram = True
-    #: the device kernel accumulates the Gram of its result only on launches of at least one round of 256 x 64 tiles
-    #: (lk_conv_vjp_gram_parts); the emulation does it for every 64-channel result so that tiny CPU cases walk the path
-    gram_min_rows = 0
-
     def conv_winp_eligible(self, N, Hi, Wi, Ci, Co, T, mask_is_float=False) -> bool:
         # (mirrors lk_conv_winp_eligible, so that the host logic around the chunk-major weights is exercised on the CPU)
         return bool(T == 9 and Wi <= 47 and Hi * Wi >= 64 and Ci % 32 == 0 and Ci >= 32 and Co >= 64 and Co % 64 == 0 and N * Hi * Wi >= 512
                     and not mask_is_float)
 
     def conv_nhwc_f16x2_vjp(self, x, wplanes, wsexp, w_l1, Ho, Wo, taps, add=None, mult=None, mult_amax=None, scale=None,
-                            scale_amax=None, config=None, want_gram=False, amax_word=None, wplanes_chunked=None):
+                            scale_amax=None, config=None, amax_word=None, wplanes_chunked=None):
         if wplanes_chunked is not None:  # the same weights, chunk-major: must agree with the GEMM-natural planes
             two, T, N_, Kd = wplanes.shape
             assert torch.equal(wplanes_chunked, wplanes.view(two, T, N_, Kd // 16, 16).permute(0, 1, 3, 2, 4))
@@ -160,19 +155,6 @@ class EmulatedKernels:
         assert float(v.abs().max()) <= bound * (1 + 1e-6) + 1e-30, "the guaranteed bound of the fused epilogue does not hold"
         out = self._split(v, self._sexp_for(bound))
         out.amax = out.float().abs().max().reshape(1).float()
-        if want_gram and self.fuse_gram and Co == 64 and N * Ho * Wo >= self.gram_min_rows:
-            # lk_conv_nhwc_f16x2_vjp_gram: partial blocks of X^T X (upper 32 x 32 tiles) in units of 2^(-2 sexp), here two
-            X = (out.planes[0].float() + out.planes[1].float()).reshape(-1, Co)
-            half = (X.shape[0] + 1) // 2
-            idx = torch.arange(Co) // 32
-            upper = (idx[:, None] <= idx[None, :]).float()
-            out.gram_parts = torch.stack([(P.T @ P) * upper for P in (X[:half], X[half:])])
-        return out
-
-    def gram_partials_reduce(self, x, alpha, out):
-        idx = torch.arange(out.shape[0]) // 32
-        upper = idx[:, None] <= idx[None, :]
-        out += alpha * x.gram_parts.sum(0) * upper * 2.0 ** (-2 * int(x.sexp[0]))
         return out
 
     def vjp_nhwc_split(self, g, g_amax, g2, mult, mult_amax, scale, scale_amax, S, out_shape):

@@ -8,7 +8,6 @@ import torch
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 N = 50_000
-WIN, WIN_Z, WIN_4 = 1 << 22, 1 << 23, 1 << 24
 
 
 def rel(a, b):
@@ -98,15 +97,8 @@ CASES = {
     "LK_NHWC_FORWARD=0": dict(sweep_attrs={"nhwc_forward": False}),
     "LK_PIXPAIR16=0": dict(kernel_attrs={"use_pixpair16": False}),
     "LK_SHIFTCORR=0": dict(kernel_attrs={"use_shiftcorr": False}, acc_attrs={"use_pixgram": False}),
-    "LK_FUSE_GRAM=1": dict(kernel_attrs={"fuse_gram": True}),
     "LK_QUAD16=1": dict(kernel_attrs={"use_quad16": True}),
-    "LK_CONV_CONFIG=0 (patch form)": dict(kernel_attrs={"conv_config": 0}),
-    "LK_CONV_CONFIG=3 (64-deep chunks)": dict(kernel_attrs={"conv_config": 3}),
-    "LK_CONV_CONFIG window": dict(kernel_attrs={"conv_config": 2 | WIN}),
-    "LK_CONV_CONFIG window, 512-pixel tile": dict(kernel_attrs={"conv_config": 2 | WIN | WIN_Z}),
-    "LK_CONV_CONFIG window, four waves": dict(kernel_attrs={"conv_config": 2 | WIN | WIN_4}),
-    "LK_CONV_CONFIG chunk-major K order": dict(kernel_attrs={"conv_config": 2 | (1 << 19)}),
-    "LK_CONV_CONFIG chunk-major K order on 128 / 256 channels": dict(kernel_attrs={"conv_config": 2 | (1 << 25)}),
+    "LK_WINP=0 (generic fused launches)": dict(kernel_attrs={"use_winp": False}),
     "LK_CONV_CONFIG plain row order": dict(kernel_attrs={"conv_config": 2 | 32768}),
 }
 

@@ -224,32 +224,3 @@ def test_graphs_the_nhwc_walk_has_no_rule_for_are_rejected_before_any_gradient_i
     got = sweep.backward(seeds)
     for n in taps:
         assert torch.allclose(got[n].reshape(want[n].shape), want[n], atol=1e-5), n
-
-
-def test_fused_gram_partials_give_the_same_g_factors_as_the_stand_alone_gram():
-    """KronAccumulator on a network with 64-channel layers: with the Gram of a cotangent accumulated by the fused launch
-    that produces it (SplitTensor.gram_parts -> lk_gram_partials_reduce_f16x2) and with the stand-alone Gram kernel."""
-    from laplace_amd import HipGGN
-
-    model = _model(torch.relu)
-    X, y = torch.randn(6, 3, 8, 8), torch.randint(5, (6,))
-    K = get_kernels()
-    seen = []
-    orig = K.gram_partials_reduce
-    K.gram_partials_reduce = lambda x, a, out: (seen.append(tuple(out.shape)), orig(x, a, out))[1]
-    try:
-        res = {}
-        for on in (True, False):
-            K.fuse_gram = on
-            acc = HipGGN(model, "classification").kron_accumulator(6)
-            acc.add_batch(X, y)
-            acc.add_batch(X.flip(0), y.flip(0))
-            res[on] = acc.finalize()
-    finally:
-        K.fuse_gram = True
-        del K.gram_partials_reduce
-    assert seen and all(s_ == (64, 64) for s_ in seen), "no 64-channel cotangent took the fused-Gram path"
-    assert torch.allclose(res[True][0], res[False][0])
-    for F1, F2 in zip(res[True][1].kfacs, res[False][1].kfacs):
-        for a, b in zip(F1, F2):
-            assert torch.allclose(a, b, rtol=1e-5, atol=1e-7 * float(b.abs().max()))

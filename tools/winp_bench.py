@@ -1,4 +1,4 @@
-"""Persistent window kernel (config bit 27) against the generic and the window forms: fused backward-data launches of the c4
+"""Persistent window kernel against the generic form (config bit 27 = persistent form off): fused backward-data launches of the c4
 layer shapes, correctness against the generic kernel's result and time per launch.  Development tool."""
 import os, sys
 import torch
@@ -9,7 +9,7 @@ from laplace_amd._lib import get_kernels
 
 K = get_kernels()
 dev = "cuda"
-WIN, Z, W4, WP = 1 << 22, 1 << 23, 1 << 24, 1 << 27
+WP = 1 << 27
 
 
 def timeit(fn, n=10):
@@ -37,7 +37,7 @@ for Co, Ci, H, N in cases:  # conv Ci -> Co; backward-data: cotangent [N, H, H, 
     gf = 2.0 * N * H * H * Co * Ci * 9 / 1e9
     K.conv_config = 2 | WP
     ref = cv.conv_backward_data_vjp(prep, g, (H, H), add=add, mult=mask)
-    for name, cfg in (("generic", 2 | WP), ("window 8w", 2 | WIN | Z | WP), ("persistent", 2)):  # (bit 27 switches the persistent form OFF)
+    for name, cfg in (("generic", 2 | WP), ("persistent", 2)):  # (bit 27 switches the persistent form OFF)
         K.conv_config = cfg
         out = cv.conv_backward_data_vjp(prep, g, (H, H), add=add, mult=mask)
         torch.cuda.synchronize()
