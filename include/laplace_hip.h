@@ -235,6 +235,24 @@ int lk_conv_nhwc_f16x2_vjp_wc(const void* in_h, const void* in_l, const int* in_
                               const void* scale_amax, void* out_h, void* out_l, int* out_sexp, void* out_amax, int config,
                               void* stream);
 
+/* The backward-data of a STRIDED convolution (stride `os` = 2; reference: the torch.func Jacobians of curvature.py:94-147
+ * run it once per output class through autograd) with every residue class of the input-gradient pixels in ONE launch —
+ * class (oh0, ow0): dX[i*os + oh0, j*os + ow0] = sum over that class's taps of g[i + dh, j + dw] W[slice] — optionally
+ * together with a SECOND convolution that reads the same input (in2_* / w2_*, NULL without one: the 1 x 1 shortcut of a
+ * residual down-sampling block, with its own cotangent and weights), and with the element-wise VJP fused as in
+ * lk_conv_nhwc_f16x2_vjp: out = (dX + dX2 + add) * M * scale[channel] as a split tensor with its measured max|.|.
+ * taps: T <= 12 rows {dh, dw, weight slice, source (0 / 1), oh0, ow0}; every one of the os*os classes needs a tap;
+ * both cotangents are [N][Hi][Wi][Ci] with Hi = Ho / os, Wi = Wo / os; weights [slice][Co][Ci] per plane. */
+int lk_conv_nhwc_f16x2_vjp_strided(const void* in_h, const void* in_l, const int* in_sexp, const void* in_amax, const void* w_h,
+                                   const void* w_l, const int* w_sexp, const float* w_l1, const void* in2_h, const void* in2_l,
+                                   const int* in2_sexp, const void* in2_amax, const void* w2_h, const void* w2_l,
+                                   const int* w2_sexp, const float* w2_l1, int64_t N, int64_t Hi, int64_t Wi, int64_t Ci,
+                                   int64_t Co, int64_t Ho, int64_t Wo, int64_t os, int64_t T, const int* taps,
+                                   const void* zero16, const void* add_h, const void* add_l, const int* add_sexp,
+                                   const void* mask, int mask_is_float, const void* mult_amax, int64_t mask_rows,
+                                   const float* scale, const void* scale_amax, void* out_h, void* out_l, int* out_sexp,
+                                   void* out_amax, int config, void* stream);
+
 
 /* Element-wise VJP of the NHWC sweep with a split result (csrc/lk_sweep16.hip):
  *     out[s][e] = (g[s][e] + g2[s][e]) * M[e] * scale[e % C]      e < per = B*H*W*C,  s < S

@@ -72,6 +72,8 @@ SIGNATURES = {
     "lk_conv_nhwc_f16x2_vjp_wc": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64,
                                          _i64, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _int,
                                          _vp]),
+    "lk_conv_nhwc_f16x2_vjp_strided": (_int, [_vp] * 16 + [_i64] * 9 + [_vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _i64, _vp, _vp, _vp,
+                                               _vp, _vp, _vp, _int, _vp]),
     "lk_vjp_nhwc_split_f16x2": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "lk_bn_act_fwd_nhwc_f16x2": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "lk_unsplit_transpose_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
@@ -495,6 +497,56 @@ class HipKernels:
             None if add is None else _ptr(add.sexp), _ptr(mult), m_is_float, _ptr(mult_amax), mask_rows, _ptr(scale),
             _ptr(scale_amax), _ptr(planes[0]), _ptr(planes[1]), _ptr(sexp), _ptr(amax), int(cfg), self._stream(dev))),
             "lk_conv_nhwc_f16x2_vjp")
+        return SplitTensor(planes, sexp, amax)
+
+    def conv_nhwc_f16x2_vjp_strided(self, sources, Ho, Wo, os, taps, add=None, mult=None, mult_amax=None, scale=None,
+                                    scale_amax=None, amax_word=None):
+        """lk_conv_nhwc_f16x2_vjp_strided: the backward-data of one or two stride-``os`` convolutions that read the same
+        input, every residue class in one launch, with the element-wise VJP fused: ``(dX [+ dX2] + add) * mult * scale``
+        -> SplitTensor [N, Ho, Wo, Co] carrying its measured ``amax``.  ``sources``: one or two
+        ``(g SplitTensor [N, Ho/os, Wo/os, Ci], wplanes [2, T_w, Co, Ci], wsexp, w_l1)``; ``taps``: rows
+        ``(dh, dw, weight slice, source, oh0, ow0)``."""
+        x, wplanes, wsexp, w_l1 = sources[0]
+        N, Hi, Wi, Ci = x.planes.shape[1:]
+        Co = wplanes.shape[2]
+        dev = x.planes.device
+        if len(sources) not in (1, 2) or any(tuple(s_[0].planes.shape) != tuple(x.planes.shape) or s_[1].shape[2:] != wplanes.shape[2:]
+                                             for s_ in sources):
+            raise LaplaceHipError("conv_nhwc_f16x2_vjp_strided: one or two sources of the same shapes")
+        planes = torch.empty((2, N, Ho, Wo, Co), dtype=torch.float16, device=dev)
+        sexp = torch.empty(1, dtype=torch.int32, device=dev)
+        amax = amax_word if amax_word is not None else torch.zeros(1, dtype=torch.float32, device=dev)
+        m_is_float, mask_rows = 0, 0
+        if mult is not None:
+            if mult.dtype == torch.bool:
+                mult = mult.view(torch.uint8)
+            m_is_float = 1 if mult.dtype == torch.float32 else 0
+            if (not mult.is_contiguous() or mult.dtype not in (torch.uint8, torch.float32) or mult.dim() != 4
+                    or tuple(mult.shape[1:]) != (Ho, Wo, Co) or N % mult.shape[0]):
+                raise LaplaceHipError("conv_nhwc_f16x2_vjp_strided: multiplier must be a contiguous [B, Ho, Wo, Co] uint8 / float32 tensor")
+            mask_rows = mult.shape[0] * Ho * Wo
+        if add is not None and tuple(add.shape) != (N, Ho, Wo, Co):
+            raise LaplaceHipError("conv_nhwc_f16x2_vjp_strided: addend shape")
+        flat = (ctypes.c_int * (6 * len(taps)))(*[int(v) for t in taps for v in t])
+        work = 0.0
+        if self.profile is not None:
+            classes = {}
+            for t in taps:
+                classes.setdefault((t[4], t[5]), []).append(t)
+            work = 2.0 * N * Co * Ci * sum(self.conv_valid_pairs(Ho // os, Wo // os, 1, Hi, Wi, ts) for ts in classes.values())
+        src = []
+        for i in range(2):
+            if i < len(sources):
+                g_, wp_, ws_, l1_ = sources[i]
+                src += [_ptr(g_.planes[0]), _ptr(g_.planes[1]), _ptr(g_.sexp), _ptr(g_.amax), _ptr(wp_[0]), _ptr(wp_[1]), _ptr(ws_), _ptr(l1_)]
+            else:
+                src += [None] * 8
+        self._rc(self._timed("conv16", work, dev, lambda: self.lib.lk_conv_nhwc_f16x2_vjp_strided(
+            *src, N, Hi, Wi, Ci, Co, Ho, Wo, os, len(taps), flat, _ptr(self._zero16(dev)),
+            None if add is None else _ptr(add.planes[0]), None if add is None else _ptr(add.planes[1]),
+            None if add is None else _ptr(add.sexp), _ptr(mult), m_is_float, _ptr(mult_amax), mask_rows, _ptr(scale),
+            _ptr(scale_amax), _ptr(planes[0]), _ptr(planes[1]), _ptr(sexp), _ptr(amax), int(self.conv_config),
+            self._stream(dev))), "lk_conv_nhwc_f16x2_vjp_strided")
         return SplitTensor(planes, sexp, amax)
 
     def vjp_nhwc_split(self, g, g_amax, g2, mult, mult_amax, scale, scale_amax, S, out_shape):

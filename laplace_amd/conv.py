@@ -158,6 +158,48 @@ def conv_backward_data_vjp(prep: PreparedConv, g: SplitTensor, in_hw, cscale=Non
                                  mult_amax=mult_amax, scale=scale, scale_amax=scale_amax, **kw)
 
 
+def strided_fused_ok(m: nn.Conv2d, in_hw) -> bool:
+    """the backward-data of ``m`` can join a strided fused launch (:func:`conv_backward_data_vjp_strided`): stride 2 on an
+    even map, an 8-aligned channel count for the epilogue's 16-byte stores"""
+    Hin, Win = in_hw
+    return (supported(m) and m.stride[0] == 2 and m.stride[1] == 2 and Hin % 2 == 0 and Win % 2 == 0 and Hin >= 2 and Win >= 2
+            and m.in_channels % 8 == 0 and m.out_channels % 32 == 0
+            and (Hin + 2 * m.padding[0] - m.kernel_size[0]) // 2 + 1 == Hin // 2
+            and (Win + 2 * m.padding[1] - m.kernel_size[1]) // 2 + 1 == Win // 2)
+
+
+def strided_taps(descs, in_hw):
+    """tap rows ``(dh, dw, weight slice, source, oh0, ow0)`` of the strided fused launch for ``descs = [(prep, g, cscale)]``
+    (one or two convolutions that read the same ``in_hw`` input), or None when some residue class of the input pixels is
+    reached by no tap (a lone strided 1 x 1 convolution)"""
+    rows, classes = [], set()
+    for i, (prep, _, _) in enumerate(descs):
+        for Hc, Wc, oh0, ow0, taps in backward_plan(prep.m, *in_hw):
+            for dh, dw, sl in taps:
+                rows.append((dh, dw, sl, i, oh0, ow0))
+                classes.add((oh0, ow0))
+    s = descs[0][0].m.stride[0]
+    return rows if len(classes) == s * s and len(rows) <= 12 else None
+
+
+def conv_backward_data_vjp_strided(descs, in_hw, add=None, mult=None, mult_amax=None, scale=None, scale_amax=None,
+                                   amax_word=None) -> SplitTensor:
+    """``(sum of dX over descs + add) * mult * scale[channel]`` as a SplitTensor for one or two STRIDED convolutions
+    ``descs = [(prep, g, cscale)]`` that read the same input (the 3 x 3 main branch and the 1 x 1 shortcut of a residual
+    down-sampling block): all residue classes, both convolutions and the sweep's element-wise VJP in one launch
+    (lk_conv_nhwc_f16x2_vjp_strided) instead of five backward-data launches into an fp32 tensor and a pass over it."""
+    K = get_kernels()
+    Hin, Win = in_hw
+    rows = strided_taps(descs, in_hw)
+    assert rows is not None
+    sources = []
+    for prep, g, cscale in descs:
+        planes, sexp = prep.backward_planes(cscale)
+        sources.append((g, planes, sexp, prep.backward_l1(cscale)))
+    return K.conv_nhwc_f16x2_vjp_strided(sources, Hin, Win, descs[0][0].m.stride[0], rows, add=add, mult=mult,
+                                         mult_amax=mult_amax, scale=scale, scale_amax=scale_amax, amax_word=amax_word)
+
+
 def conv_forward(prep: PreparedConv, x: SplitTensor, out=None, amax_out=None):
     """``y [N, Hout, Wout, Cout]`` (fp32, NHWC, no bias) of ``prep.m`` from the split input ``x [N, Hin, Win, Cin]``"""
     K = get_kernels()

@@ -624,6 +624,356 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Strided form: the backward-data of a stride-s convolution with ALL residue classes of the input-gradient pixels in ONE
+// launch (class c = (oh0, ow0): dX[i*s + oh0, j*s + ow0] = sum over the taps of that class of g[i + dh, j + dw] W[tap]),
+// optionally together with a SECOND convolution that feeds the same input — the 1 x 1 shortcut of a residual
+// down-sampling block, its own cotangent and weights — and with the element-wise VJP fused into the epilogue, as in
+// conv_f16x2_kernel<CFG, true>.  What it replaces in a sweep over ResNet-18 (per down-sampling block): five launches of
+// 55 - 160 us that each fill the chip for ONE round (four classes of 1 / 2 / 2 / 4 taps and the shortcut, fp32 output
+// written with a stride, the shortcut's class read back and rewritten) plus the element-wise VJP kernel over the result.
+//   rows: (class-tile, class) interleaved, i.e. the four classes of the same cotangent pixels run next to each other and
+//   share the cotangent rows in L2; within a class the row order is (image, i, j) as in the generic kernel
+//   second source: its taps come first in the K loop; the two sources carry different fixed-point units
+//   (2^(sexp_a + sexp_w) each), so the accumulators are multiplied by the power of two between them once (exact) when the
+//   K loop passes from the second source's taps to the first's.
+struct StridedGeom {
+  int N, Hi, Wi, Ci;   // cotangent maps [N][Hi][Wi][Ci] of both sources (Ci = GEMM K per tap)
+  int Hc, Wc;          // class grid, the same for every class (Ho % os == 0, Wo % os == 0)
+  int Ho, Wo, Co, os;  // output tensor [N][Ho][Wo][Co]
+  int ncls;
+  int oh0[4], ow0[4];
+  unsigned cls_taps[4];  // bit t: tap t belongs to the class
+  unsigned second;       // bit t: tap t reads the second source (these taps are listed first)
+  int T;
+  int dh[12], dw[12], wt[12];
+  FastDiv div_hw, div_w, div_cls;
+};
+
+struct StridedSrc {
+  const _Float16 *ah, *al, *wh, *wl;  // cotangent planes, weight planes [slice][Co][Ci]
+  const int *a_sexp, *w_sexp;
+  const unsigned* in_amax;            // measured max|cotangent| or NULL
+  const float* w_l1;
+};
+
+template <typename CFG>
+__global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WPE, CFG::WPE))) void conv_strided_f16x2_kernel(
+    const StridedGeom g, const StridedSrc s1, const StridedSrc s2, const _Float16* __restrict__ zero16,
+    unsigned* __restrict__ amax_out, int nb_m, const ConvVjp fz) {
+  constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK, Q = CFG::Q, TM = CFG::TM, TN = CFG::TN, NT = CFG::NT;
+  static_assert(CFG::FUSABLE, "the strided form always runs the VJP epilogue");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nblk = gridDim.x;
+  int bid = blockIdx.x;
+  {  // XCD-contiguous tile ranges (see conv_f16x2_kernel)
+    const int q = nblk / 8, r = nblk % 8, x = bid % 8, j = bid / 8;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+  }
+  const int M = g.N * g.Hc * g.Wc;  // rows of ONE class
+  const int KC = g.Ci / BK;
+  const int nb_mc = nb_m * g.ncls;
+  const int tile_n = bid / nb_mc, tmc = bid - tile_n * nb_mc;
+  const int tile_m = fdiv(tmc, g.div_cls), cls = tmc - tile_m * g.ncls;
+  const int oh0 = g.oh0[cls], ow0 = g.ow0[cls];
+  const unsigned ctaps = g.cls_taps[cls];
+  const int HWc = g.Hc * g.Wc;
+
+  int64_t a_off[CFG::A_LD / 2];
+  unsigned a_valid[CFG::A_LD / 2];
+  int a_lq[CFG::A_LD / 2];
+#pragma unroll
+  for (int i = 0; i < CFG::A_LD / 2; ++i) {
+    const int slot = i * NT + tid;
+    const int row = slot / Q, pq = slot % Q;
+    a_lq[i] = pq ^ swz<Q>(row);
+    const int m = tile_m * BM + row;
+    unsigned valid = 0;
+    int64_t off = 0;
+    if (m < M) {
+      const int n = fdiv(m, g.div_hw), rem = m - n * HWc;
+      const int ih = fdiv(rem, g.div_w), iw = rem - ih * g.Wc;
+      off = (((int64_t)n * g.Hi + ih) * g.Wi + iw) * g.Ci;
+      for (int t = 0; t < g.T; ++t) {
+        const int hh = ih + g.dh[t], ww = iw + g.dw[t];
+        if (((ctaps >> t) & 1u) && hh >= 0 && hh < g.Hi && ww >= 0 && ww < g.Wi) valid |= 1u << t;
+      }
+    }
+    a_off[i] = off, a_valid[i] = valid;
+  }
+  int64_t b_off[CFG::B_LD];
+  bool b_ok[CFG::B_LD];
+  bool b_low[CFG::B_LD];
+#pragma unroll
+  for (int i = 0; i < CFG::B_LD; ++i) {
+    const int cs = i * NT + tid;
+    const int slot = cs % CFG::B_SLOTS;
+    const int row = slot / Q, pq = slot % Q;
+    const int n = tile_n * BN + row;
+    b_low[i] = cs >= CFG::B_SLOTS;
+    b_ok[i] = n < g.Co;
+    b_off[i] = (int64_t)n * g.Ci + (pq ^ swz<Q>(row)) * 8;
+  }
+  const int64_t w_tap = (int64_t)g.Co * g.Ci;
+
+  auto clampe = [](int e) { return e < -126 ? -126 : (e > 127 ? 127 : e); };
+  const int sexp_a = s1.a_sexp[0], sexp_w = s1.w_sexp[0];
+  const float inv = exp2i(clampe(-sexp_a)) * exp2i(clampe(-sexp_w));
+  float ratio = 1.f, inv2 = 0.f;
+  int so;
+  {
+    float bound = (s1.in_amax ? __uint_as_float(s1.in_amax[0]) : exp2i(clampe(15 - sexp_a))) * s1.w_l1[0];
+    if (g.second) {
+      const int sa2 = s2.a_sexp[0], sw2 = s2.w_sexp[0];
+      bound += (s2.in_amax ? __uint_as_float(s2.in_amax[0]) : exp2i(clampe(15 - sa2))) * s2.w_l1[0];
+      ratio = exp2i(clampe((sexp_a + sexp_w) - (sa2 + sw2)));
+    }
+    if (fz.add_h) {
+      const int sadd = fz.add_sexp[0];
+      bound += exp2i(clampe(15 - sadd));
+      inv2 = exp2i(clampe(-sadd));
+    }
+    if (fz.mask && fz.mask_float && fz.mult_amax) bound *= __uint_as_float(fz.mult_amax[0]);
+    if (fz.scale) bound *= __uint_as_float(fz.scale_amax[0]);
+    so = scale_exp_for(bound);
+  }
+  const float sc_out = exp2i(so);
+
+  // taps of this class that reach a row of this tile (uniform over the workgroup), the second source's first
+  unsigned long long tap_list = 0;
+  int ntap = 0, n_first = 0;
+  {
+    unsigned v = 0;
+#pragma unroll
+    for (int i = 0; i < CFG::A_LD / 2; ++i) v |= a_valid[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v |= (unsigned)__shfl_xor((int)v, off, 64);
+    unsigned* red = reinterpret_cast<unsigned*>(smem);
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    v = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) v |= red[w];
+    v = (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+    __syncthreads();
+    for (int t = 0; t < g.T; ++t)
+      if ((v >> t) & 1u) {
+        tap_list |= (unsigned long long)t << (4 * ntap), ++ntap;
+        if ((g.second >> t) & 1u) ++n_first;
+      }
+  }
+  const int nstage = ntap * KC;
+  const int s_switch = n_first * KC;  // first stage of the first source's taps
+
+  auto stage = [&](int s, int buf) {
+    const int tj = s / KC, kc = s - tj * KC;
+    const int t = (int)((tap_list >> (4 * tj)) & 15ull);
+    const bool sec = (g.second >> t) & 1u;
+    const _Float16* Ah = sec ? s2.ah : s1.ah;
+    const _Float16* Al = sec ? s2.al : s1.al;
+    const _Float16* Wh = sec ? s2.wh : s1.wh;
+    const _Float16* Wl = sec ? s2.wl : s1.wl;
+    char* base = smem + buf * CFG::STAGE;
+    const int64_t tap_off = ((int64_t)g.dh[t] * g.Wi + g.dw[t]) * g.Ci + kc * BK;
+#pragma unroll
+    for (int i = 0; i < CFG::A_LD / 2; ++i) {
+      const bool ok = (a_valid[i] >> t) & 1u;
+      const int64_t e = a_off[i] + tap_off + a_lq[i] * 8;
+      const _Float16* sh = ok ? Ah + e : zero16;
+      const _Float16* sl = ok ? Al + e : zero16;
+      char* dh_ = base + (i * NT + wave * 64) * 16;
+      __builtin_amdgcn_global_load_lds((gbl_void*)sh, (lds_void*)dh_, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void*)sl, (lds_void*)(dh_ + CFG::A_PLANE), 16, 0, 0);
+    }
+    const int64_t wbase = (int64_t)g.wt[t] * w_tap + kc * BK;
+#pragma unroll
+    for (int i = 0; i < CFG::B_LD; ++i) {
+      const int64_t e = wbase + b_off[i];
+      const _Float16* sp = b_ok[i] ? (b_low[i] ? Wl : Wh) + e : zero16;
+      char* db = base + 2 * CFG::A_PLANE + (i * NT + wave * 64) * 16;
+      __builtin_amdgcn_global_load_lds((gbl_void*)sp, (lds_void*)db, 16, 0, 0);
+    }
+  };
+
+  const int wm = wave / CFG::WN, wn = wave % CFG::WN;
+  const int lr = lane & 31, lh = lane >> 5;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  auto rescale = [&]() {
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] *= ratio;
+  };
+
+  // ---- epilogue context (see conv_f16x2_kernel: the addend planes / mask bytes of all of a lane's chunks are requested
+  // right behind the K loop)
+  constexpr int ROWS_W = TM * 32, COLS_W = TN * 32, PITCH = COLS_W + 4, C8 = COLS_W / 8, NIT = ROWS_W * C8 / 64;
+  int64_t e_[NIT];
+  int pix_[NIT];
+  bool ok_[NIT];
+  f16x8 h2_[NIT], l2_[NIT];
+  uint2 mk_[NIT];
+  const bool pre_mask = fz.mask && !fz.mask_float;
+  const int mrows = (int)fz.mask_rows;
+  auto mask_row = [&](int p) { return p - fdiv(p, fz.div_mask) * mrows; };
+  auto prefetch = [&](int it) {
+    const int idx = it * 64 + lane;
+    const int row = idx / C8, c8 = idx - row * C8;
+    const int m = tile_m * BM + wm * ROWS_W + row;
+    const int col0 = tile_n * BN + wn * COLS_W + c8 * 8;
+    ok_[it] = m < M && col0 < g.Co;
+    int opix = 0;
+    if (ok_[it]) {
+      const int n = fdiv(m, g.div_hw), rem = m - n * HWc;
+      const int ci_ = fdiv(rem, g.div_w);
+      opix = (n * g.Ho + ci_ * g.os + oh0) * g.Wo + (rem - ci_ * g.Wc) * g.os + ow0;
+    }
+    e_[it] = (int64_t)opix * g.Co + col0;
+    pix_[it] = opix;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h2_[it][j] = (_Float16)0.f, l2_[it][j] = (_Float16)0.f;
+    mk_[it] = make_uint2(0x01010101u, 0x01010101u);
+    if (fz.add_h && ok_[it]) {
+      h2_[it] = *reinterpret_cast<const f16x8*>(fz.add_h + e_[it]);
+      l2_[it] = *reinterpret_cast<const f16x8*>(fz.add_l + e_[it]);
+    }
+    if (pre_mask && ok_[it])
+      mk_[it] = *reinterpret_cast<const uint2*>((const unsigned char*)fz.mask + (int64_t)mask_row(opix) * g.Co + col0);
+  };
+
+  {
+    constexpr int LD_PER_STAGE = CFG::A_LD + CFG::B_LD;
+    static_assert(CFG::NBUF == 2, "two LDS stages");
+    (void)LD_PER_STAGE;
+    if (nstage > 0) stage(0, 0);
+    int buf = 0;
+    for (int s = 0; s < nstage; ++s) {
+      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): stage s has landed (one stage in flight)
+      __builtin_amdgcn_s_barrier();
+      if (s + 1 < nstage) stage(s + 1, buf ^ 1);
+      if (s == s_switch && n_first) rescale();
+      const char* base = smem + buf * CFG::STAGE;
+      buf ^= 1;
+      f16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+      auto load_frags = [&](int k16, int set) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+          const int row = (wm * TM + a) * 32 + lr;
+          const int off = (row * Q + ((k16 * 2 + lh) ^ swz<Q>(row))) * 16;
+          ah[set][a] = *reinterpret_cast<const f16x8*>(base + off);
+          al[set][a] = *reinterpret_cast<const f16x8*>(base + CFG::A_PLANE + off);
+        }
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          const int row = (wn * TN + b) * 32 + lr;
+          const int off = (row * Q + ((k16 * 2 + lh) ^ swz<Q>(row))) * 16;
+          bh[set][b] = *reinterpret_cast<const f16x8*>(base + 2 * CFG::A_PLANE + off);
+          bl[set][b] = *reinterpret_cast<const f16x8*>(base + 2 * CFG::A_PLANE + CFG::B_PLANE + off);
+        }
+      };
+      load_frags(0, 0);
+#pragma unroll
+      for (int k16 = 0; k16 < BK / 16; ++k16) {
+        const int set = k16 & 1;
+        if (k16 + 1 < BK / 16) load_frags(k16 + 1, set ^ 1);
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b) {
+            f32x16 c = acc[a][b];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[set][a], bh[set][b], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[set][a], bl[set][b], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[set][a], bh[set][b], c, 0, 0, 0);
+            acc[a][b] = c;
+          }
+      }
+    }
+    if (n_first && s_switch == nstage) rescale();  // (a tile that only the second source reaches)
+  }
+
+  unsigned vmax = 0;
+  if (blockIdx.x == 0 && tid == 0) fz.out_sexp[0] = so;
+  static_assert(CFG::EPI_LDS == CFG::WM * CFG::WN * ROWS_W * PITCH * 4 && CFG::EPI_LDS <= 80 * 1024, "staging image: two workgroups per CU");
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) prefetch(it);
+  __syncthreads();
+  float* img = reinterpret_cast<float*>(smem) + wave * (ROWS_W * PITCH);
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        img[(a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * PITCH + b * 32 + lr] = acc[a][b][r] * inv;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int idx = it * 64 + lane;
+    const int row = idx / C8, c8 = idx - row * C8;
+    if (!ok_[it]) continue;
+    const int col0 = tile_n * BN + wn * COLS_W + c8 * 8;
+    const f32x4 p0 = *reinterpret_cast<const f32x4*>(img + row * PITCH + c8 * 8);
+    const f32x4 p1 = *reinterpret_cast<const f32x4*>(img + row * PITCH + c8 * 8 + 4);
+    float v[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+    const int64_t e = e_[it];
+    if (fz.add_h) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += ((float)h2_[it][j] + (float)l2_[it][j]) * inv2;
+    }
+    float mult[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mult[j] = sc_out;
+    if (fz.mask) {
+      if (fz.mask_float) {
+        const int64_t em = (int64_t)mask_row(pix_[it]) * g.Co + col0;
+        const f32x4 a = *reinterpret_cast<const f32x4*>((const float*)fz.mask + em);
+        const f32x4 b = *reinterpret_cast<const f32x4*>((const float*)fz.mask + em + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mult[j] *= a[j], mult[4 + j] *= b[j];
+      } else {
+        const uint2 u = mk_[it];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (!((u.x >> (8 * j)) & 0xffu)) mult[j] = 0.f;
+          if (!((u.y >> (8 * j)) & 0xffu)) mult[4 + j] = 0.f;
+        }
+      }
+    }
+    if (fz.scale) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(fz.scale + col0), b = *reinterpret_cast<const f32x4*>(fz.scale + col0 + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mult[j] *= a[j], mult[4 + j] *= b[j];
+    }
+    f16x8 h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float xs = v[j] * mult[j];
+      asm volatile("" : "+v"(xs));
+      const _Float16 hh = (_Float16)xs;
+      h[j] = hh;
+      l[j] = (_Float16)(xs - (float)hh);
+      vmax = max(vmax, __float_as_uint(xs) & 0x7fffffffu);
+    }
+    *reinterpret_cast<f16x8*>(fz.out_h + e) = h;
+    *reinterpret_cast<f16x8*>(fz.out_l + e) = l;
+  }
+  if (amax_out) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) vmax = max(vmax, (unsigned)__shfl_xor((int)vmax, off, 64));
+    const int back = -so < -126 ? -126 : -so;
+    if (lane == 0 && vmax) atomicMax(amax_out, __float_as_uint(__uint_as_float(vmax) * exp2i(back)));
+  }
+}
+
+
 __device__ __forceinline__ int swz2(int row) { return (row >> 3) & 1; }  // two 16-byte slots per row (see swz<2>)
 
 // ---- persistent window form ------------------------------------------------------------------------------------------
@@ -1388,4 +1738,96 @@ extern "C" int lk_conv_nhwc_f16x2_vjp_wc(const void* in_h, const void* in_l, con
   return conv_vjp_impl(in_h, in_l, in_sexp, in_amax, N, Hi, Wi, Ci, w_h, w_l, w_sexp, w_l1, Co, Ho, Wo, T, taps, zero16, add_h,
                        add_l, add_sexp, mask, mask_is_float, mult_amax, mask_rows, scale, scale_amax, out_h, out_l, out_sexp,
                        out_amax, config, stream, wc_h, wc_l);
+}
+
+// Strided form (conv_strided_f16x2_kernel): the backward-data of a stride-`os` convolution — every residue class of the
+// input-gradient pixels — and optionally of a second convolution reading the same input (in2_* / w2_*: NULL without one),
+// with the fused VJP epilogue, in one launch.  `taps`: T x {dh, dw, weight slice, source (0 / 1), oh0, ow0}; every one of
+// the os * os classes must own at least one tap (the launch writes only pixels of listed classes), Ho % os == Wo % os == 0,
+// both cotangents are [N][Hi][Wi][Ci] with Hi == Ho / os, Wi == Wo / os.
+template <typename CFG>
+static int launch_strided(const lk::StridedGeom& g, const lk::StridedSrc& s1, const lk::StridedSrc& s2, const void* zero16,
+                          unsigned* amax_out, hipStream_t stream, const lk::ConvVjp& fz) {
+  const int64_t M = (int64_t)g.N * g.Hc * g.Wc;
+  const int nb_m = (int)((M + CFG::BM - 1) / CFG::BM), nb_n = (g.Co + CFG::BN - 1) / CFG::BN;
+  const size_t lds0 = (size_t)CFG::NBUF * CFG::STAGE;
+  const size_t lds = lds0 > (size_t)CFG::EPI_LDS ? lds0 : (size_t)CFG::EPI_LDS;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)lk::conv_strided_f16x2_kernel<CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((lk::conv_strided_f16x2_kernel<CFG>), dim3((unsigned)(nb_m * g.ncls * nb_n)), dim3(CFG::NT), lds, stream, g, s1,
+                     s2, (const _Float16*)zero16, amax_out, nb_m, fz);
+  return lk::check_launch("conv_strided_f16x2_kernel");
+}
+
+extern "C" int lk_conv_nhwc_f16x2_vjp_strided(
+    const void* in_h, const void* in_l, const int* in_sexp, const void* in_amax, const void* w_h, const void* w_l,
+    const int* w_sexp, const float* w_l1, const void* in2_h, const void* in2_l, const int* in2_sexp, const void* in2_amax,
+    const void* w2_h, const void* w2_l, const int* w2_sexp, const float* w2_l1, int64_t N, int64_t Hi, int64_t Wi, int64_t Ci,
+    int64_t Co, int64_t Ho, int64_t Wo, int64_t os, int64_t T, const int* taps, const void* zero16, const void* add_h,
+    const void* add_l, const int* add_sexp, const void* mask, int mask_is_float, const void* mult_amax, int64_t mask_rows,
+    const float* scale, const void* scale_amax, void* out_h, void* out_l, int* out_sexp, void* out_amax, int config,
+    void* stream) {
+  using namespace lk;
+  (void)config;
+  LK_REQUIRE(in_h && in_l && in_sexp && w_h && w_l && w_sexp && w_l1 && zero16 && taps && out_h && out_l && out_sexp && out_amax,
+             "lk_conv_nhwc_f16x2_vjp_strided: null pointer");
+  const bool two = in2_h != nullptr;
+  LK_REQUIRE(!two || (in2_l && in2_sexp && w2_h && w2_l && w2_sexp && w2_l1), "lk_conv_nhwc_f16x2_vjp_strided: incomplete second source");
+  LK_REQUIRE(os >= 1 && os <= 2 && Ho % os == 0 && Wo % os == 0 && Hi == Ho / os && Wi == Wo / os,
+             "lk_conv_nhwc_f16x2_vjp_strided: stride 1 or 2, Ho = os * Hi, Wo = os * Wi");
+  LK_REQUIRE(T >= 1 && T <= 12 && Ci >= 32 && Ci % 32 == 0 && Co >= 8 && Co % 8 == 0 && N >= 1,
+             "lk_conv_nhwc_f16x2_vjp_strided: 1..12 taps, Ci % 32 == 0, Co % 8 == 0");
+  LK_REQUIRE(N * Ho * Wo < (1ll << 31) && N * Ho * Wo * Co < (1ll << 40) && N * Hi * Wi * Ci < (1ll << 40),
+             "lk_conv_nhwc_f16x2_vjp_strided: tensor too large");
+  LK_REQUIRE(!add_h || (add_l && add_sexp), "lk_conv_nhwc_f16x2_vjp_strided: incomplete addend");
+  LK_REQUIRE(!mask || (mask_rows > 0 && mask_rows < (1ll << 31)), "lk_conv_nhwc_f16x2_vjp_strided: mask_rows");
+  LK_REQUIRE(!scale || scale_amax, "lk_conv_nhwc_f16x2_vjp_strided: scale needs its bound");
+  StridedGeom g;
+  g.N = (int)N, g.Hi = (int)Hi, g.Wi = (int)Wi, g.Ci = (int)Ci, g.Hc = (int)Hi, g.Wc = (int)Wi, g.Ho = (int)Ho, g.Wo = (int)Wo,
+  g.Co = (int)Co, g.os = (int)os, g.ncls = 0, g.second = 0, g.T = (int)T;
+  for (int c = 0; c < 4; ++c) g.oh0[c] = g.ow0[c] = 0, g.cls_taps[c] = 0;
+  for (int t = 0; t < 12; ++t) g.dh[t] = g.dw[t] = g.wt[t] = 0;
+  int k = 0;
+  for (int pass = 1; pass >= 0; --pass)  // the second source's taps first
+    for (int t = 0; t < T; ++t) {
+      const int* p = taps + 6 * t;
+      LK_REQUIRE(p[3] == 0 || (p[3] == 1 && two), "lk_conv_nhwc_f16x2_vjp_strided: tap source");
+      if (p[3] != pass) continue;
+      LK_REQUIRE(p[4] >= 0 && p[4] < os && p[5] >= 0 && p[5] < os, "lk_conv_nhwc_f16x2_vjp_strided: residue class of a tap");
+      int c = 0;
+      while (c < g.ncls && (g.oh0[c] != p[4] || g.ow0[c] != p[5])) ++c;
+      if (c == g.ncls) g.oh0[c] = p[4], g.ow0[c] = p[5], ++g.ncls;
+      g.dh[k] = p[0], g.dw[k] = p[1], g.wt[k] = p[2];
+      g.cls_taps[c] |= 1u << k;
+      if (pass) g.second |= 1u << k;
+      ++k;
+    }
+  LK_REQUIRE(g.ncls == os * os, "lk_conv_nhwc_f16x2_vjp_strided: a residue class without taps");
+  // heavy classes first within each group of tiles (the classes of one tile group run side by side)
+  for (int a = 0; a < g.ncls; ++a)
+    for (int b = a + 1; b < g.ncls; ++b)
+      if (__builtin_popcount(g.cls_taps[b]) > __builtin_popcount(g.cls_taps[a])) {
+        std::swap(g.cls_taps[a], g.cls_taps[b]), std::swap(g.oh0[a], g.oh0[b]), std::swap(g.ow0[a], g.ow0[b]);
+      }
+  g.div_hw = make_fastdiv((int)(Hi * Wi)), g.div_w = make_fastdiv((int)Wi), g.div_cls = make_fastdiv(g.ncls);
+  StridedSrc s1{(const _Float16*)in_h, (const _Float16*)in_l, (const _Float16*)w_h, (const _Float16*)w_l, in_sexp, w_sexp,
+                (const unsigned*)in_amax, w_l1};
+  StridedSrc s2 = s1;
+  if (two)
+    s2 = StridedSrc{(const _Float16*)in2_h, (const _Float16*)in2_l, (const _Float16*)w2_h, (const _Float16*)w2_l, in2_sexp, w2_sexp,
+                    (const unsigned*)in2_amax, w2_l1};
+  ConvVjp fz;
+  fz.in_amax = nullptr, fz.w_l1 = nullptr;
+  fz.add_h = (const _Float16*)add_h, fz.add_l = (const _Float16*)add_l, fz.add_sexp = add_sexp;
+  fz.mask = mask, fz.mask_float = mask_is_float, fz.mult_amax = (const unsigned*)mult_amax, fz.mask_rows = mask ? mask_rows : 1;
+  fz.div_mask = make_fastdiv((int)fz.mask_rows);
+  fz.scale = scale, fz.scale_amax = (const unsigned*)scale_amax;
+  fz.out_h = (_Float16*)out_h, fz.out_l = (_Float16*)out_l, fz.out_sexp = out_sexp;
+  fz.wc_h = fz.wc_l = nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  if (Co <= 64) return launch_strided<ConvCfg<256, 64, 32, 4, 1>>(g, s1, s2, zero16, (unsigned*)out_amax, st, fz);
+  return launch_strided<ConvCfg<128, 128, 32, 2, 2>>(g, s1, s2, zero16, (unsigned*)out_amax, st, fz);
 }

@@ -60,8 +60,41 @@ class _LazyConv:
         return self._fused(**kw)
 
 
+class _LazyStrided(_LazyConv):
+    """A STRIDED convolution's backward-data that has not run yet (``desc = (prep, g, cscale)``, input ``hw``): one or two
+    of them reaching the same node (the 3 x 3 main branch and the 1 x 1 shortcut of a residual down-sampling block) leave
+    ``_to_split`` as ONE launch over all residue classes with the element-wise VJP fused
+    (lk_conv_nhwc_f16x2_vjp_strided); ``f32(into)`` is the fallback: class by class into an fp32 tensor."""
+
+    __slots__ = ("desc", "hw", "_run")
+
+    def __init__(self, run, desc, hw):
+        super().__init__(None, None)
+        self._run, self.desc, self.hw = run, desc, hw
+
+    def f32(self, into=None) -> "_F32":
+        if self._done is None:
+            self._done = self._run(into)
+        return self._done
+
+
 def _materialize(parts):
-    return [p.f32() if isinstance(p, _LazyConv) else p for p in parts]
+    out, first = [], None
+    for p in parts:  # (plain tensors first: a pending strided convolution then adds into one instead of making its own)
+        if isinstance(p, _F32) and first is None:
+            first = p
+    for p in parts:
+        if isinstance(p, _LazyStrided):
+            if p._done is None and first is not None:
+                p.f32(first)  # accumulated into the tensor that is already there
+                continue
+            p = p.f32()
+            first = first if first is not None else p
+        elif isinstance(p, _LazyConv):
+            p = p.f32()
+            first = first if first is not None else p
+        out.append(p)
+    return out
 
 
 class SplitSweep(SeedBatchedSweep):
@@ -76,6 +109,9 @@ class SplitSweep(SeedBatchedSweep):
 
     #: ``False`` (env LK_FUSE_VJP=0): every backward-data writes fp32 and the element-wise VJP kernel runs on it
     fuse_vjp = os.environ.get("LK_FUSE_VJP", "1") != "0"
+    #: ``False`` (env LK_FUSE_STRIDED=0): strided convolutions run class by class into an fp32 tensor (one launch per
+    #: residue class and branch) instead of the strided fused launch
+    fuse_strided = os.environ.get("LK_FUSE_STRIDED", "1") != "0"
 
     def _consumes_lazily(self, node) -> bool:
         """nodes whose rule hands all incoming cotangent parts to ``_to_split`` (which can fuse a pending convolution)"""
@@ -298,7 +334,14 @@ class SplitSweep(SeedBatchedSweep):
         lazy = [p for p in parts if isinstance(p, _LazyConv)]
         if lazy:
             rest = [p for p in parts if not isinstance(p, _LazyConv)]
-            if len(lazy) == 1 and lazy[0]._done is None and len(rest) <= 1 and all(isinstance(p, SplitTensor) for p in rest):
+            strided = [p for p in lazy if isinstance(p, _LazyStrided)]
+            if (strided and len(strided) == len(lazy) <= 2 and all(p._done is None and p.hw == strided[0].hw for p in strided)
+                    and len(rest) <= 1 and all(isinstance(p, SplitTensor) for p in rest)
+                    and cv.strided_taps([p.desc for p in strided], strided[0].hw) is not None):
+                return cv.conv_backward_data_vjp_strided(
+                    [p.desc for p in strided], strided[0].hw, add=rest[0] if rest else None, mult=mult, mult_amax=mult_amax,
+                    scale=scale, scale_amax=scale_amax, amax_word=self._new_word() if self._new_word is not None else None)
+            if len(lazy) == 1 and not strided and lazy[0]._done is None and len(rest) <= 1 and all(isinstance(p, SplitTensor) for p in rest):
                 return lazy[0].fused(add=rest[0] if rest else None, mult=mult, mult_amax=mult_amax, scale=scale,
                                      scale_amax=scale_amax,
                                      amax_word=self._new_word() if self._new_word is not None else None)
@@ -437,6 +480,13 @@ class SplitSweep(SeedBatchedSweep):
                         cv.conv_backward_data(prep, g, hw, cscale=cscale, out=into.t, accumulate=True, amax_out=into.amax)
                         return into
 
+                    if (self.fuse_vjp and self.fuse_strided and cv.strided_fused_ok(m, hw) and src not in deferred
+                            and hasattr(K, "conv_nhwc_f16x2_vjp_strided")
+                            and all(isinstance(p, (_LazyStrided, SplitTensor)) for p in cot.get(src, []))):
+                        # (the consumer of the cotangent decides: alone or with the block's other strided branch in one
+                        # fused launch, or — something else joined — class by class into an fp32 tensor)
+                        push(src, _LazyStrided(run, (prep, g, cscale), hw))
+                        continue
                     if src in cot:
                         cot[src] = _materialize(cot[src])
                     existing = [p for p in cot.get(src, []) if isinstance(p, _F32)]

@@ -157,6 +157,42 @@ class EmulatedKernels:
         out.amax = out.float().abs().max().reshape(1).float()
         return out
 
+    def conv_nhwc_f16x2_vjp_strided(self, sources, Ho, Wo, os, taps, add=None, mult=None, mult_amax=None, scale=None,
+                                    scale_amax=None, amax_word=None):
+        """lk_conv_nhwc_f16x2_vjp_strided: every residue class of one or two strided convolutions' backward-data, then the
+        fused epilogue with the scale of the guaranteed bound sum_i max|in_i| * l1(W_i) (+ ...)"""
+        N = sources[0][0].shape[0]
+        Co = sources[0][1].shape[2]
+        assert Ho % os == 0 and Wo % os == 0 and {(t[4], t[5]) for t in taps} == {(a, b) for a in range(os) for b in range(os)}
+        v = torch.zeros(N, Ho, Wo, Co)
+        bound = 0.0
+        for i, (x, wplanes, wsexp, w_l1) in enumerate(sources):
+            assert tuple(x.shape[1:3]) == (Ho // os, Wo // os)
+            for oh0 in range(os):
+                for ow0 in range(os):
+                    ts = [(t[0], t[1], t[2]) for t in taps if t[3] == i and (t[4], t[5]) == (oh0, ow0)]
+                    if ts:
+                        self.conv_nhwc_f16x2(x, wplanes, wsexp, Ho // os, Wo // os, 1, v, os, oh0, ow0, ts, accumulate=True)
+            in_amax = float(x.amax[0]) if getattr(x, "amax", None) is not None else 2.0 ** (15 - int(x.sexp[0]))
+            bound += in_amax * float(w_l1[0])
+        assert float(v.abs().max()) <= bound * (1 + 1e-5) + 1e-30, "sum of max|in| * l1(W) does not bound the convolutions"
+        if add is not None:
+            v = v + add.float()
+            bound += 2.0 ** (15 - int(add.sexp[0]))
+        if mult is not None:
+            mf = mult.float() if mult.dtype not in (torch.uint8, torch.bool) else (mult != 0).float()
+            S = N // mf.shape[0]
+            v = (v.reshape(S, *mf.shape) * mf).reshape(v.shape)
+            if mult.dtype == torch.float32 and mult_amax is not None:
+                bound *= float(mult_amax[0])
+        if scale is not None:
+            v = v * scale
+            bound *= float(scale_amax[0])
+        assert float(v.abs().max()) <= bound * (1 + 1e-6) + 1e-30, "the guaranteed bound of the fused epilogue does not hold"
+        out = self._split(v, self._sexp_for(bound))
+        out.amax = out.float().abs().max().reshape(1).float()
+        return out
+
     def vjp_nhwc_split(self, g, g_amax, g2, mult, mult_amax, scale, scale_amax, S, out_shape):
         bound = 0.0
         v = torch.zeros(out_shape)

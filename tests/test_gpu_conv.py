@@ -317,6 +317,70 @@ def test_persistent_window_form_of_the_fused_launch(cin, cout, H, n_img):
         K.conv_config = prev
 
 
+STRIDED_CASES = [(64, 128, 32, 15, True), (64, 128, 32, 1152, True), (128, 256, 16, 75, True), (256, 512, 8, 300, True),
+                 (128, 256, 16, 33, False), (32, 64, 8, 12, True), (64, 96, 12, 21, True), (192, 64, 6, 40, True)]
+
+
+@pytest.mark.parametrize("cin,cout,H,n_img,shortcut", STRIDED_CASES, ids=[f"{c[0]}-{c[1]}-{c[2]}x{c[2]}-n{c[3]}-{'pair' if c[4] else 'single'}" for c in STRIDED_CASES])
+def test_strided_fused_launch_of_a_downsampling_block(cin, cout, H, n_img, shortcut):
+    """conv_strided_f16x2_kernel (lk_conv_nhwc_f16x2_vjp_strided): the backward-data of the 3 x 3 / stride-2 convolution of a
+    residual down-sampling block — four residue classes of 1 / 2 / 2 / 4 taps — together with the block's 1 x 1 / stride-2
+    shortcut (its own cotangent, weights and fixed-point units), with and without addend / mask / channel scale, against
+    fp64 and against the class-by-class route (five launches into an fp32 tensor + the element-wise VJP kernel); image
+    counts that leave the last tile of every class ragged; the 1152-image case is the first down-sampling block of c4."""
+    from laplace_amd import conv as cv
+    from laplace_amd._lib import get_kernels
+
+    K = get_kernels()
+    m1, m2 = _conv(cin, cout, 3, 2, 1), _conv(cin, cout, 1, 2, 0)
+    N, Ho = n_img, H // 2
+    torch.manual_seed(31)
+    g1 = torch.randn(N, cout, Ho, Ho, device=DEV) * 1e-2
+    g2 = torch.randn(N, cout, Ho, Ho, device=DEV) * 3.0  # (another magnitude: the two sources carry different units)
+    gs1 = K.split_f16x2(g1.permute(0, 2, 3, 1).contiguous())
+    gs2 = K.split_f16x2(g2.permute(0, 2, 3, 1).contiguous())
+    p1, p2 = cv.PreparedConv(m1), cv.PreparedConv(m2)
+    assert cv.strided_fused_ok(m1, (H, H)) and cv.strided_fused_ok(m2, (H, H))
+    cs2 = (torch.rand(cout, device=DEV) + 0.5).contiguous()  # a BatchNorm scale folded into the shortcut's weights
+    descs = [(p1, gs1, None)] + ([(p2, gs2, cs2)] if shortcut else [])
+    assert cv.strided_taps(descs, (H, H)) is not None and cv.strided_taps([(p2, gs2, None)], (H, H)) is None
+    S = 3 if N % 3 == 0 else 1
+    B = N // S
+    mask = (torch.rand(B, H, H, cin, device=DEV) > 0.4).to(torch.uint8)
+    fmult = (torch.rand(B, H, H, cin, device=DEV) * 2 - 0.5).contiguous()
+    addend = K.split_f16x2(torch.randn(N, H, H, cin, device=DEV) * 0.05)
+    sc = (torch.rand(cin, device=DEV) * 1.5 + 0.25).contiguous()
+    want_b = None
+    if N * H * H * cin <= 40e6:  # (the fp64 reference on the host: small cases only)
+        want_b = torch.nn.grad.conv2d_input((N, cin, H, H), m1.weight.double().cpu(), g1.double().cpu(), stride=2, padding=1)
+        if shortcut:
+            w2 = m2.weight.double().cpu() * cs2.double().cpu().reshape(-1, 1, 1, 1)
+            want_b = want_b + torch.nn.grad.conv2d_input((N, cin, H, H), w2, g2.double().cpu(), stride=2, padding=0)
+    for kw in ({}, {"add": addend}, {"mult": mask}, {"mult": fmult, "mult_amax": K.absmax(fmult)},
+               {"add": addend, "mult": mask, "scale": sc, "scale_amax": K.absmax(sc)}):
+        fused = cv.conv_backward_data_vjp_strided(descs, (H, H), **kw)
+        # the class-by-class route: fp32 tensor (the shortcut accumulates into it), then the element-wise VJP kernel
+        w = torch.zeros(1, dtype=torch.float32, device=DEV)
+        dx = cv.conv_backward_data(p1, gs1, (H, H), amax_out=w)
+        if shortcut:
+            cv.conv_backward_data(p2, gs2, (H, H), cscale=cs2, out=dx, accumulate=True, amax_out=w)
+        ref = K.vjp_nhwc_split(dx, K.absmax(dx), kw.get("add"), kw.get("mult"), kw.get("mult_amax"), kw.get("scale"),
+                               kw.get("scale_amax"), S, (N, H, H, cin))
+        assert rel(fused.float(), ref.float()) < 4e-6, sorted(kw)
+        assert abs(fused.amax.item() - fused.float().abs().max().item()) <= 1e-5 * fused.amax.item()
+        assert fused.planes[0].abs().max().item() < 2.0 ** 15  # the guaranteed bound holds: no fixed-point overflow
+        if want_b is not None:
+            want = want_b.permute(0, 2, 3, 1)
+            if "add" in kw:
+                want = want + addend.float().double().cpu()
+            if "mult" in kw:
+                mm = kw["mult"].double().cpu()
+                want = (want.reshape(S, B, H, H, cin) * mm).reshape(N, H, H, cin)
+            if "scale" in kw:
+                want = want * sc.double().cpu()
+            assert rel(fused.float(), want) < 1e-5, sorted(kw)
+
+
 @pytest.mark.parametrize("n,where", [(4096, 0), (4096, 4095), (4100, 2049), (4099, 4098), (1 << 22, 1234567), (3 * (1 << 20) + 8, 17)])
 def test_absmax_vector_and_scalar_forms(n, where):
     """lk_absmax_f32 streams float4s when it can (16-byte aligned, n % 4 == 0, n >= 4096) and falls back to the scalar

@@ -66,16 +66,17 @@ def _autograd_tap_grads(model, taps, x, seeds):
 
 @pytest.mark.parametrize("act", [torch.relu, torch.tanh])
 @pytest.mark.parametrize("defer", [False, True])
-@pytest.mark.parametrize("fuse", [True, False])
+@pytest.mark.parametrize("fuse", [True, False, "stride-1 only"])
 def test_split_sweep_matches_per_seed_autograd(act, defer, fuse):
     model = _model(act)
     taps = {n: m for n, m in model.named_modules() if isinstance(m, (nn.Conv2d, nn.Linear))}
     sw = SplitSweep(model, taps, kernels=get_kernels)
-    sw.fuse_vjp = fuse
+    sw.fuse_vjp = bool(fuse)
+    sw.fuse_strided = fuse is True
     assert sw.split_ok, sw.split_reason
     K = get_kernels()
-    calls = {"vjp": 0, "fused": 0}
-    for name, key in (("vjp_nhwc_split", "vjp"), ("conv_nhwc_f16x2_vjp", "fused")):
+    calls = {"vjp": 0, "fused": 0, "strided": 0}
+    for name, key in (("vjp_nhwc_split", "vjp"), ("conv_nhwc_f16x2_vjp", "fused"), ("conv_nhwc_f16x2_vjp_strided", "strided")):
         orig = getattr(K, name)
         setattr(K, name, lambda *a, _o=orig, _k=key, **k: (calls.__setitem__(_k, calls[_k] + 1), _o(*a, **k))[1])
     torch.manual_seed(0)
@@ -102,11 +103,14 @@ def test_split_sweep_matches_per_seed_autograd(act, defer, fuse):
     if defer:
         assert sw.grad_scale, "no BatchNorm scale was deferred"
     # stride-1 backward-data passes hand their result over already multiplied / joined / split: five of the seven
-    # convolutions of the three blocks (the strided block's two branches keep the fp32 route and its accumulate-into)
-    if fuse:
-        assert calls["fused"] == 5 and calls["vjp"] < 7, calls
+    # convolutions of the three blocks; the strided block's two branches (3 x 3 and the 1 x 1 shortcut) leave as ONE
+    # strided fused launch, or — switched off — keep the fp32 route and its accumulate-into
+    if fuse is True:
+        assert calls["fused"] == 5 and calls["strided"] == 1 and calls["vjp"] < 6, calls
+    elif fuse:
+        assert calls["fused"] == 5 and calls["strided"] == 0 and calls["vjp"] < 7, calls
     else:
-        assert calls["fused"] == 0
+        assert calls["fused"] == 0 and calls["strided"] == 0
     # consumers that want plain tensors get [S, B, C, H, W] fp32
     got2 = sw.backward(seeds)
     for n in taps:
