@@ -274,6 +274,11 @@ int lk_bn_act_fwd_nhwc_f16x2(const float* x, const unsigned* x_amax, const float
                              const unsigned* scale_amax, const unsigned* shift_amax, const float* addend,
                              const float* addend_bound, int act, int64_t C, int64_t per, float* y, void* mask, void* y_h,
                              void* y_l, int* y_sexp, float* y_bound, void* stream);
+/* y[0..n) = x[0..n) and *amax = max(*amax, max|x|) (bit pattern of a non-negative float; NOT reset: the word runs over the
+ * minibatches stacked for one pixel-pair launch, which are then split with it instead of being measured in a pass of
+ * their own).  16-byte aligned buffers, n % 4 == 0. */
+int lk_copy_absmax_f32(const float* x, float* y, int64_t n, unsigned* amax, void* stream);
+
 /* Spread of the per-sample magnitudes of a minibatch x [B][per]: words[0] = max_n max|x_n|, words[1] = min over the
  * samples that are not identically zero, both as bit patterns of non-negative floats (atomicMax / atomicMin: the caller
  * initialises words[0] = 0, words[1] = 0x7f800000 once and may let many minibatches fold into the same pair).  The split

@@ -60,6 +60,7 @@ SIGNATURES = {
     "lk_conv3x3_pixpair_assemble2_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _f32, _vp, _vp]),
     "lk_nchw_to_nhwc_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "lk_absmax_f32": (_int, [_vp, _i64, _vp, _i64, _i64, _vp, _vp]),
+    "lk_copy_absmax_f32": (_int, [_vp, _vp, _i64, _vp, _vp]),
     "lk_range_words_f32": (_int, [_vp, _i64, _i64, _vp, _vp]),
     "lk_split_f16x2": (_int, [_vp, _i64, _vp, _f32, _vp, _vp, _vp, _vp]),
     "lk_conv_prep_weights_f16x2": (_int, [_vp, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp]),
@@ -374,14 +375,31 @@ class HipKernels:
                  "lk_range_words_f32")
         return words
 
-    def split_f16x2(self, x, amax=None, bound_mul=1.0):
-        """fp32 tensor -> :class:`SplitTensor` of the same shape (scale from ``amax[0] * bound_mul``, measured if absent)"""
+    #: ``False`` (env LK_COPY_ABSMAX=0): the stacked pixel-pair inputs are copied by the runtime and measured in a pass of
+    #: their own before they are split
+    use_copy_absmax = os.environ.get("LK_COPY_ABSMAX", "1") != "0"
+
+    def copy_absmax(self, x, out, amax):
+        """``out[...] = x`` and ``amax[0] = max(amax[0], max|x|)`` in one pass (lk_copy_absmax_f32); ``amax`` is not reset"""
+        _check(x, "x"), _check(out, "out"), _check(amax, "amax")
+        if not (x.is_contiguous() and out.is_contiguous() and x.numel() == out.numel() and x.numel() % 4 == 0
+                and x.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0):
+            raise LaplaceHipError("copy_absmax: contiguous 16-byte aligned tensors of the same size, numel % 4 == 0")
+        self._rc(self.lib.lk_copy_absmax_f32(_ptr(x), _ptr(out), x.numel(), _ptr(amax), self._stream(x.device)), "lk_copy_absmax_f32")
+        return out
+
+    def split_f16x2(self, x, amax=None, bound_mul=1.0, out=None):
+        """fp32 tensor -> :class:`SplitTensor` of the same shape (scale from ``amax[0] * bound_mul``, measured if absent).
+        ``out``: fp16 ``[2, *x.shape]`` workspace for the planes (each plane contiguous), allocated if absent"""
         _check(x, "x")
         if x.numel() % 8:
             raise LaplaceHipError("split_f16x2: numel % 8 != 0")
         if amax is None:
             amax = self.absmax(x)
-        planes = torch.empty((2,) + tuple(x.shape), dtype=torch.float16, device=x.device)
+        planes = out if out is not None else torch.empty((2,) + tuple(x.shape), dtype=torch.float16, device=x.device)
+        if (planes.dtype != torch.float16 or tuple(planes.shape) != (2,) + tuple(x.shape) or planes.device != x.device
+                or not planes[0].is_contiguous() or not planes[1].is_contiguous()):
+            raise LaplaceHipError("split_f16x2: out must be fp16 [2, *x.shape] with contiguous planes on x's device")
         sexp = torch.empty(1, dtype=torch.int32, device=x.device)
         self._rc(self.lib.lk_split_f16x2(_ptr(x), x.numel(), _ptr(amax), float(bound_mul), _ptr(planes[0]), _ptr(planes[1]),
                                          _ptr(sexp), self._stream(x.device)), "lk_split_f16x2")

@@ -836,12 +836,24 @@ class KronAccumulator:
             pend = None
         if pend is None:
             stack = torch.empty(self.pix_group * B, geo[1], geo[2], geo[3], dtype=torch.float32, device=a.device)
-            pend = self._pix_pending[idx] = {"B": B, "alpha": alpha, "stack": stack, "n": 0}
+            # (the planes the stacked images are split into, allocated WITH the stack: a fit shorter than one group would
+            # otherwise leave the first full-size request to the middle of the next fit)
+            planes = (torch.empty((2,) + tuple(stack.shape), dtype=torch.float16, device=a.device)
+                      if getattr(K, "use_pixpair16", False) and stack.numel() % 8 == 0 else None)
+            # (max|.| of what is stacked, measured by the copies into the stack: the split then needs no pass of its own)
+            word = torch.zeros(1, dtype=torch.float32, device=a.device) if planes is not None and getattr(K, "use_copy_absmax", False) else None
+            pend = self._pix_pending[idx] = {"B": B, "alpha": alpha, "stack": stack, "n": 0, "planes": planes, "amax": word}
         slot = pend["stack"][pend["n"] * B:(pend["n"] + 1) * B]
-        if nhwc:
-            slot.copy_(a)
+        src = a if nhwc else (a.permute(0, 2, 3, 1) if K.is_channels_last(a) else None)
+        if (pend["amax"] is not None and src is not None and src.is_contiguous() and src.dtype == torch.float32
+                and src.numel() % 4 == 0 and src.data_ptr() % 16 == 0 and slot.data_ptr() % 16 == 0):
+            K.copy_absmax(src, slot, pend["amax"])
         else:
-            K.nchw_to_nhwc(a, out=slot)
+            pend["amax"] = None  # (this group is measured when it is split)
+            if nhwc:
+                slot.copy_(a)
+            else:
+                K.nchw_to_nhwc(a, out=slot)
         pend["n"] += 1
         if pend["n"] == self.pix_group:
             self._drain_pixpair(idx, keep=True)
@@ -893,13 +905,21 @@ class KronAccumulator:
             K = get_kernels()
             if getattr(K, "use_pixpair16", False) and xh.numel() % 8 == 0:
                 # one split of the stacked images (scale from their measured max), then the fp16 MFMA kernel
-                K.pixpair_accumulate_split(K.split_f16x2(xh), pend["alpha"], buf, geo[4])
+                ws = pend.get("planes")
+                K.pixpair_accumulate_split(K.split_f16x2(xh, amax=pend.get("amax"), out=None if ws is None else ws[:, :xh.shape[0]]),
+                                           pend["alpha"], buf, geo[4])
             else:
                 K.pixpair_accumulate_nhwc(xh, pend["alpha"], buf, geo[4])
             if cur is not None:
                 pend["stack"].record_stream(cur)  # filled on the side stream, possibly consumed on another one
+                if pend.get("planes") is not None:
+                    pend["planes"].record_stream(cur)
+                if pend.get("amax") is not None:
+                    pend["amax"].record_stream(cur)
         if keep:
             pend["n"] = 0
+            if pend.get("planes") is not None and getattr(get_kernels(), "use_copy_absmax", False):
+                pend["amax"] = torch.zeros(1, dtype=torch.float32, device=pend["stack"].device)  # the next group's word
         else:
             del self._pix_pending[idx]
 
@@ -1087,6 +1107,11 @@ class KronAccumulator:
                                 and bp["n"] + pend["n"] <= bp["stack"].shape[0] // B):
                             bp["stack"][bp["n"] * B:(bp["n"] + pend["n"]) * B].copy_(pend["stack"][:pend["n"] * B])
                             bp["n"] += pend["n"]
+                            if bp.get("amax") is not None:  # (words of non-negative floats: the float maximum is theirs)
+                                if pend.get("amax") is not None:
+                                    torch.maximum(bp["amax"], pend["amax"], out=bp["amax"])
+                                else:
+                                    bp["amax"] = None
                             if st is not None:
                                 pend["stack"].record_stream(st)
                         else:

@@ -60,6 +60,37 @@ __device__ __forceinline__ void split2(float x, float sc, _Float16& h, _Float16&
   l = (_Float16)(xs - (float)h);
 }
 
+// maximum of a 256-thread workgroup into the result word: ONE atomic per workgroup (same-address atomics serialise in L2 at
+// ~5-10 ns each: one per wave of a 2048-workgroup launch was a 40-80 us floor under every measurement, whatever its size)
+__device__ __forceinline__ void block_max_to_word(unsigned m, unsigned* __restrict__ out) {
+  __shared__ unsigned wave_max[4];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
+  if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
+    if (m) atomicMax(out, m);
+  }
+}
+
+// the same at the end of a convolution workgroup of NW waves: the waves' maxima meet in LDS, one atomic per workgroup
+// (`scale`: exact power-of-two factor applied to the float the bits stand for)
+template <int NW>
+__device__ __forceinline__ void conv_block_max(unsigned vmax, float scale, unsigned* __restrict__ out, char* smem) {
+  unsigned* conv_wave_max = reinterpret_cast<unsigned*>(smem);  // (the kernels' LDS budgets are exact: no static word beside them)
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) vmax = max(vmax, (unsigned)__shfl_xor((int)vmax, off, 64));
+  __syncthreads();  // every wave is done with what the arena held
+  if ((threadIdx.x & 63) == 0) conv_wave_max[threadIdx.x >> 6] = vmax;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 1; w < NW; ++w) vmax = max(vmax, conv_wave_max[w]);
+    if (vmax) atomicMax(out, __float_as_uint(__uint_as_float(vmax) * scale));
+  }
+}
+
 // ---- max |x| of a tensor as the bit pattern of a non-negative float (order-preserving as unsigned; atomicMax is
 //      order-independent, so the result is run-to-run deterministic) ----------------------------------------------------
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t n, const float* __restrict__ cscale,
@@ -70,9 +101,7 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
     if (cscale) v *= cscale[(i / inner) % C];
     m = max(m, __float_as_uint(v) & 0x7fffffffu);
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
-  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+  block_max_to_word(m, out);
 }
 // the same without a channel scale over float4s, four of them in flight per thread (x 16-byte aligned, n % 4 == 0): the
 // scalar form above streams at ~1.6 TB/s, and the stacked pixel-pair inputs it is asked to measure are up to 268 MB
@@ -89,9 +118,23 @@ __global__ __launch_bounds__(256) void absmax4_kernel(const float4* __restrict__
     fold(a), fold(b), fold(c), fold(d);
   }
   for (; i < n4; i += stride) fold(x[i]);
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
-  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+  block_max_to_word(m, out);
+}
+
+// copy + max|x| in one pass (float4s): the stacked pixel-pair inputs are copied into their group buffer minibatch by
+// minibatch anyway; measuring them on the way saves the separate pass over the whole stack before it is split
+// (`out` is NOT reset here: it runs over the minibatches of a group)
+__global__ __launch_bounds__(256) void copy_absmax4_kernel(const float4* __restrict__ x, float4* __restrict__ y, int64_t n4,
+                                                           unsigned* __restrict__ out) {
+  unsigned m = 0;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    const float4 v = x[i];
+    y[i] = v;
+    m = max(max(m, __float_as_uint(v.x) & 0x7fffffffu), __float_as_uint(v.y) & 0x7fffffffu);
+    m = max(max(m, __float_as_uint(v.z) & 0x7fffffffu), __float_as_uint(v.w) & 0x7fffffffu);
+  }
+  block_max_to_word(m, out);
 }
 
 // ---- spread of the per-sample magnitudes of a minibatch: words[0] = max over samples of max|x_n|, words[1] = min over
@@ -554,13 +597,8 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
       *reinterpret_cast<f16x8*>(fz.out_h + e) = h;
       *reinterpret_cast<f16x8*>(fz.out_l + e) = l;
     }
-    if (amax_out) {
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) vmax = max(vmax, (unsigned)__shfl_xor((int)vmax, off, 64));
-      // max|o| = max|o 2^so| * 2^-so (exact: a power of two), kept as the bit pattern of a non-negative float
-      const int back = -so < -126 ? -126 : -so;
-      if (lane == 0 && vmax) atomicMax(amax_out, __float_as_uint(__uint_as_float(vmax) * exp2i(back)));
-    }
+    // max|o| = max|o 2^so| * 2^-so (exact: a power of two), kept as the bit pattern of a non-negative float
+    if (amax_out) conv_block_max<NT / 64>(vmax, exp2i(-so < -126 ? -126 : -so), amax_out, smem);
     return;
   }
   if (g.out_nchw) {
@@ -616,11 +654,7 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
       }
     }
   }
-  if (amax_out) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) vmax = max(vmax, (unsigned)__shfl_xor((int)vmax, off, 64));
-    if (lane == 0 && vmax) atomicMax(amax_out, vmax);
-  }
+  if (amax_out) conv_block_max<NT / 64>(vmax, 1.f, amax_out, smem);
 }
 
 
@@ -965,12 +999,7 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
     *reinterpret_cast<f16x8*>(fz.out_h + e) = h;
     *reinterpret_cast<f16x8*>(fz.out_l + e) = l;
   }
-  if (amax_out) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) vmax = max(vmax, (unsigned)__shfl_xor((int)vmax, off, 64));
-    const int back = -so < -126 ? -126 : -so;
-    if (lane == 0 && vmax) atomicMax(amax_out, __float_as_uint(__uint_as_float(vmax) * exp2i(back)));
-  }
+  if (amax_out) conv_block_max<NT / 64>(vmax, exp2i(-so < -126 ? -126 : -so), amax_out, smem);
 }
 
 
@@ -1455,16 +1484,27 @@ extern "C" int lk_absmax_f32(const float* x, int64_t n, const float* cscale, int
   if (n == 0) return LK_OK;
   if (!cscale && n >= 4096 && n % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
     int64_t blocks = (n / 4 + 1023) / 1024;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(absmax4_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const float4*>(x), n / 4, out);
     return check_launch("absmax4_kernel");
   }
   int64_t blocks = (n + 2047) / 2048;
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, cscale,
                      cscale ? inner : 1, cscale ? (int)C : 1, out);
   return check_launch("absmax_kernel");
+}
+
+extern "C" int lk_copy_absmax_f32(const float* x, float* y, int64_t n, unsigned* amax, void* stream) {
+  LK_REQUIRE(x && y && amax && n >= 0 && n % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0,
+             "lk_copy_absmax_f32: 16-byte aligned buffers, n % 4 == 0");
+  if (n == 0) return LK_OK;
+  int64_t blocks = (n / 4 + 1023) / 1024;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(copy_absmax4_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(y), n / 4, amax);
+  return check_launch("copy_absmax4_kernel");
 }
 
 extern "C" int lk_range_words_f32(const float* x, int64_t B, int64_t per, unsigned* words, void* stream) {

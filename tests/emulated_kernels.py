@@ -70,6 +70,13 @@ class EmulatedKernels:
             return out
         return v
 
+    use_copy_absmax = True
+
+    def copy_absmax(self, x, out, amax):
+        out.copy_(x)
+        amax.copy_(torch.maximum(amax, x.abs().max().reshape(1).float()))
+        return out
+
     def range_words(self, x, words):
         a = x.detach().abs().reshape(x.shape[0], -1).amax(1).float()
         a = a[a > 0]
@@ -79,10 +86,17 @@ class EmulatedKernels:
             cur[1] = torch.minimum(cur[1], a.min())
         return words
 
-    def split_f16x2(self, x, amax=None, bound_mul=1.0):
+    def split_f16x2(self, x, amax=None, bound_mul=1.0, out=None):
         if amax is None:
             amax = self.absmax(x)
-        return self._split(x, self._sexp_for(float(amax[0]) * bound_mul))
+        st = self._split(x, self._sexp_for(float(amax[0]) * bound_mul))
+        if out is not None:
+            assert out.dtype == torch.float16 and tuple(out.shape) == (2,) + tuple(x.shape)
+            from laplace_amd._lib import SplitTensor
+
+            out.copy_(st.planes)
+            st = SplitTensor(out, st.sexp)
+        return st
 
     def conv_prep_weights(self, W, transpose, cscale=None):
         Wf = W.float()
