@@ -1000,7 +1000,8 @@ class KronAccumulator:
             streams = [None] * self.lanes
             if on_device:
                 cache = self.backend.__dict__.setdefault("_lane_streams", {})
-                streams = cache.setdefault((dev, self.lanes), [torch.cuda.Stream(dev) for _ in range(self.lanes)])
+                prio = -1 if os.environ.get("LK_LANE_PRIO", "0") == "1" else 0  # (experiment: sweeps ahead of factor kernels)
+                streams = cache.setdefault((dev, self.lanes, prio), [torch.cuda.Stream(dev, priority=prio) for _ in range(self.lanes)])
             self._lane_accs = []
             for k in range(self.lanes):
                 sub = KronAccumulator(self.backend, self.N, self.kfac_approx, self.overlap)

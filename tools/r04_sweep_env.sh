@@ -1,0 +1,6 @@
+export TMPDIR=/tmp
+for e in "LK_PIX_GROUP=8" "LK_PIX_GROUP=16" "LK_PIX_GROUP=12" "LK_LANES=3" "LK_PIX_GROUP=8"; do
+  echo "[$e] steps: $(env $e timeout 300 python tools/steps_only.py 64 2>&1 | tail -1)  $(env $e timeout 600 python bench.py --steps 20 --warmup 5 --no-extras --no-predictive --no-eigh --no-cpu-baseline --no-check 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('K20', round(d['ms_per_step'],3))")"
+done
