@@ -318,7 +318,7 @@ def pmc_traffic(kernel_prefix: str, kernel_suffix: str = ""):
 
     want = csrc_sha16(ROOT)
     newest = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_bench_c4*.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_bench_c4*.json")), reverse=True):  # newest round first
         try:
             with open(path) as fh:
                 table = json.load(fh)
@@ -476,9 +476,15 @@ def main():
                  "`achieved` = algorithmic fp32 flop / s, `peak` = 2500 / 3 TFLOP/s (the dense fp16 MFMA peak over the three "
                  "MFMAs of the scheme), i.e. `frac` IS the fraction of the fp16 matrix peak the kernel sustains")
         fams = {
-            "conv16": ("lk::conv_f16x2_kernel: implicit-GEMM convolution on NHWC split tensors — backward-data of the "
-                       "seed-batched reverse sweep (batch 9 x 128) and the forward; " + F16X2, "mfma16",
-                       "lk::conv_f16x2_kernel"),
+            "convp16": ("lk::conv_winp_f16x2_kernel: persistent window form of the implicit-GEMM convolution on NHWC split "
+                        "tensors — the 3x3 / stride-1 backward-data launches of the seed-batched reverse sweep (batch 9 x 128, "
+                        "13 per step) with the element-wise VJP fused into the epilogue; " + F16X2, "mfma16",
+                        "void lk::conv_winp_f16x2_kernel"),
+            "convs16": ("lk::conv_strided_f16x2_kernel: backward-data of the three down-sampling blocks (3x3 / stride 2, all "
+                        "four residue classes, + the 1x1 shortcut) with the fused VJP epilogue, one launch per block; " + F16X2,
+                        "mfma16", "lk::conv_strided_f16x2_kernel"),
+            "conv16": ("lk::conv_f16x2_kernel: the generic implicit-GEMM convolution — the forward pass (batch 128) and what "
+                       "the two fused forms do not cover; " + F16X2, "mfma16", "lk::conv_f16x2_kernel"),
             "gram16": ("lk::gram16_kernel (+ fixed-order reduce): G factors as Grams of the NHWC split cotangents through "
                        "transposing LDS reads; symmetric-half flop K*n*(n+1); " + F16X2, "mfma16", "lk::gram16_kernel", ",0>"),
             "vjp16": ("lk::vjp_nhwc_split_kernel: element-wise VJP (mask x folded BatchNorm scale x residual add) of all "
@@ -520,6 +526,13 @@ def main():
         roof = dict(fam_out[dominant]) if dominant else {"bound": "mfma", "achieved": 0.0, "peak": PEAK_F32_MFMA_TFLOPS,
                                                           "unit": "TFLOP/s", "frac": 0.0, "traffic": None}
         roof["family"] = dominant
+        conv_keys = [k for k in ("convp16", "convs16", "conv16") if k in fam_out]
+        if conv_keys:  # (all convolution launches together: the figure rounds 2 and 3 quoted for `conv16`)
+            c_ms = sum(fam_out[k]["ms_per_step"] for k in conv_keys)
+            c_tf = sum(fam_out[k]["achieved"] * fam_out[k]["ms_per_step"] for k in conv_keys) / c_ms
+            roof["all_convolution_launches"] = {"families": conv_keys, "ms_per_step": c_ms, "achieved": c_tf,
+                                                "frac": c_tf / PEAK_F16X2_TFLOPS,
+                                                "launches": sum(fam_out[k]["launches"] for k in conv_keys)}
         roof["flop_convention"] = ("convolution: 2 * Cout * Cin * (output pixel, tap) pairs that fall INSIDE the image "
                                    "(zero-padding taps are not counted: the figure does not move with the padding); "
                                    "Gram families: symmetric half K*n*(n+1)")
@@ -611,9 +624,9 @@ def main():
                 pfam = {}
                 for key, peak, what in (("quadconv", PEAK_BF16X3_TFLOPS, "lk::quadform_conv_kernel: per-layer quadratic form of "
                                          "the weight-sharing Jacobian, six bf16 MFMAs per fp32 product block"),
-                                        ("conv16", PEAK_F16X2_TFLOPS, "lk::conv_f16x2_kernel (forward + reverse sweep of the "
-                                         "10 identity seeds)")):
-                    evs = pprof.get(key, [])
+                                        ("conv16", PEAK_F16X2_TFLOPS, "lk::conv_f16x2_kernel / conv_winp / conv_strided (forward + "
+                                         "reverse sweep of the 10 identity seeds, eigenbasis rotations)")):
+                    evs = pprof.get(key, []) + (pprof.get("convp16", []) + pprof.get("convs16", []) if key == "conv16" else [])
                     ms_k = sum(e0.elapsed_time(e1) for e0, e1, _ in evs)
                     if evs and ms_k > 0:
                         tf = sum(w for _, _, w in evs) / (ms_k * 1e-3) / 1e12
@@ -634,8 +647,14 @@ def main():
             # what a fit pays besides its minibatches (the verdict of round 3 asked for it on the line): the timed K steps
             # against the steady-state rate of the 391-minibatch fit, and `finalize` alone behind a drained device
             steady = result["fit_50k"]["accumulate_s"] / result["fit_50k"]["minibatches"] * 1e3
+            torch.cuda.synchronize()
+            t_s = time.perf_counter()
             acc_f = backend.kron_accumulator(N_DATASET)
-            for i in range(8):
+            for i in range(2):  # (one minibatch per lane: allocation and zeroing of the factor / pixel-pair buffers, pipeline fill)
+                acc_f.add_batch(*batches[i % len(batches)])
+            torch.cuda.synchronize()
+            setup_ms = (time.perf_counter() - t_s) * 1e3 - 2 * steady
+            for i in range(2, 8):
                 acc_f.add_batch(*batches[i % len(batches)])
             torch.cuda.synchronize()
             t_f = time.perf_counter()
@@ -643,6 +662,7 @@ def main():
             torch.cuda.synchronize()
             result["fit_fixed_cost"] = {"steady_ms_per_step": steady, "timed_ms_per_step": dt / args.steps * 1e3,
                                         "fixed_ms_per_fit": dt * 1e3 - args.steps * steady,
+                                        "setup_ms_first_two_minibatches_minus_two_steady_steps": setup_ms,
                                         "finalize_ms_behind_a_drained_device": (time.perf_counter() - t_f) * 1e3}
             result["other_configs"] = small_config_legs(dev)
         if not args.no_cpu_baseline:

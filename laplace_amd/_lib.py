@@ -375,9 +375,9 @@ class HipKernels:
                  "lk_range_words_f32")
         return words
 
-    #: ``False`` (env LK_COPY_ABSMAX=0): the stacked pixel-pair inputs are copied by the runtime and measured in a pass of
-    #: their own before they are split
-    use_copy_absmax = os.environ.get("LK_COPY_ABSMAX", "1") != "0"
+    #: ``False``: the stacked pixel-pair inputs are copied by the runtime and measured in a pass of their own before they
+    #: are split (measured: no difference in the step; one pass less at the end of a fit)
+    use_copy_absmax = True
 
     def copy_absmax(self, x, out, amax):
         """``out[...] = x`` and ``amax[0] = max(amax[0], max|x|)`` in one pass (lk_copy_absmax_f32); ``amax`` is not reset"""
@@ -500,7 +500,8 @@ class HipKernels:
         if wplanes_chunked is not None:
             # [2, T, Ci / 16, Co, 16]: the persistent window form where the library finds the launch eligible
             assert wplanes_chunked.shape == (2, wplanes.shape[1], Ci // 16, Co, 16) and wplanes_chunked.is_contiguous()
-            self._rc(self._timed("conv16", work, dev, lambda: self.lib.lk_conv_nhwc_f16x2_vjp_wc(
+            # (profile family: the persistent window kernel unless config bit 27 sends the launch to the generic one)
+            self._rc(self._timed("conv16" if int(cfg) & (1 << 27) else "convp16", work, dev, lambda: self.lib.lk_conv_nhwc_f16x2_vjp_wc(
                 _ptr(x.planes[0]), _ptr(x.planes[1]), _ptr(x.sexp), _ptr(x.amax), N, Hi, Wi, Ci, _ptr(wplanes[0]),
                 _ptr(wplanes[1]), _ptr(wsexp), _ptr(w_l1), _ptr(wplanes_chunked[0]), _ptr(wplanes_chunked[1]), Co, Ho, Wo,
                 len(taps), flat, _ptr(z), None if add is None else _ptr(add.planes[0]),
@@ -559,7 +560,7 @@ class HipKernels:
                 src += [_ptr(g_.planes[0]), _ptr(g_.planes[1]), _ptr(g_.sexp), _ptr(g_.amax), _ptr(wp_[0]), _ptr(wp_[1]), _ptr(ws_), _ptr(l1_)]
             else:
                 src += [None] * 8
-        self._rc(self._timed("conv16", work, dev, lambda: self.lib.lk_conv_nhwc_f16x2_vjp_strided(
+        self._rc(self._timed("convs16", work, dev, lambda: self.lib.lk_conv_nhwc_f16x2_vjp_strided(
             *src, N, Hi, Wi, Ci, Co, Ho, Wo, os, len(taps), flat, _ptr(self._zero16(dev)),
             None if add is None else _ptr(add.planes[0]), None if add is None else _ptr(add.planes[1]),
             None if add is None else _ptr(add.sexp), _ptr(mult), m_is_float, _ptr(mult_amax), mask_rows, _ptr(scale),

@@ -704,6 +704,9 @@ class KronAccumulator:
         self.pix_group = max(1, int(os.environ.get("LK_PIX_GROUP", "8")))
         self._side = None
         self._side_done = None  # event at the end of the previous minibatch's side-stream work (lagged join)
+        self._side_older = []   # ... of the minibatches before that which the main stream has not waited for yet
+        #: minibatches whose factor kernels may still be running when the next one starts (env LK_LAG_DEPTH)
+        self.lag_depth = max(1, int(os.environ.get("LK_LAG_DEPTH", "1")))
         #: ``False`` (env LK_LAG_JOIN=0): the main stream waits for the factor kernels at the end of every minibatch
         self.lag_join = os.environ.get("LK_LAG_JOIN", "1") != "0"
         self.factors = None  # per tap: [G, A]
@@ -1000,7 +1003,9 @@ class KronAccumulator:
             streams = [None] * self.lanes
             if on_device:
                 cache = self.backend.__dict__.setdefault("_lane_streams", {})
-                prio = -1 if os.environ.get("LK_LANE_PRIO", "0") == "1" else 0  # (experiment: sweeps ahead of factor kernels)
+                # the lanes' streams (forward + reverse sweep: the critical path) get a higher queue priority than the streams
+                # the factor kernels run on (env LK_LANE_PRIO=0: all alike; measured 7.35 -> 6.96 ms per step)
+                prio = int(os.environ.get("LK_LANE_PRIO", "-1"))
                 streams = cache.setdefault((dev, self.lanes, prio), [torch.cuda.Stream(dev, priority=prio) for _ in range(self.lanes)])
             self._lane_accs = []
             for k in range(self.lanes):
@@ -1047,8 +1052,8 @@ class KronAccumulator:
         ts = list(m.parameters()) + list(m.buffers())
         return (tuple((t.data_ptr(), t._version) for t in ts), tuple(x.shape[1:]), x.dtype, x.device)
 
-    #: ``False`` (env LK_EARLY_FLUSH=0): the A-side work of reading a fit waits for the lanes' reverse sweeps
-    early_flush = os.environ.get("LK_EARLY_FLUSH", "1") != "0"
+    #: ``False``: the A-side work of reading a fit waits for the lanes' reverse sweeps
+    early_flush = True
 
     def _fold_lanes(self):
         """bring the lanes' partial sums together on the calling stream (before anything reads the accumulated state).
@@ -1308,7 +1313,9 @@ class KronAccumulator:
                     if torch.is_tensor(tap.a) and tap.a.is_cuda:
                         tap.a.record_stream(side)
                 if self._side_done is not None:
-                    main.wait_event(self._side_done)
+                    self._side_older.append(self._side_done)
+                while len(self._side_older) >= self.lag_depth and self._side_older:
+                    main.wait_event(self._side_older.pop(0))
                 self._side_done = torch.cuda.Event()
                 self._side_done.record(side)
             else:
@@ -1422,6 +1429,7 @@ class KronAccumulator:
         if self._side is not None:
             torch.cuda.current_stream(self._side.device).wait_stream(self._side)
             self._side_done = None
+            self._side_older = []
 
     def _flush_g_slabs(self, only=None):
         K = get_kernels()

@@ -1616,16 +1616,8 @@ static bool launch_winp(const ConvGeom& g, const void* Ah, const void* Al, const
   p.w_l1 = fz->w_l1, p.scale = fz->scale;
   p.add_h = fz->add_h, p.add_l = fz->add_l;
   p.mask = (const unsigned char*)fz->mask, p.mask_rows = (int)fz->mask_rows;
-  static const int stagger = [] {
-    const char* e = getenv("LK_WINP_STAGGER");  // (tuning knob: start delay of a CU's second workgroup, x 64 s_sleep cycles)
-    return e ? atoi(e) : 3;
-  }();
-  p.stagger = stagger * (g.Ci / 64);
-  static const int ablate = [] {
-    const char* e = getenv("LK_WINP_ABLATE");  // (development build only)
-    return e ? atoi(e) : 0;
-  }();
-  p.ablate = ablate;
+  p.stagger = 3 * (g.Ci / 64);  // start delay of a CU's second workgroup, x 64 s_sleep cycles (measured: 0 .. 8, flat around 3)
+  p.ablate = 0;
   p.out_h = fz->out_h, p.out_l = fz->out_l, p.out_sexp = fz->out_sexp;
   p.amax_out = amax_out;
   static bool attr_set = false;
@@ -1633,10 +1625,7 @@ static bool launch_winp(const ConvGeom& g, const void* Ah, const void* Al, const
     (void)hipFuncSetAttribute((const void*)conv_winp_f16x2_kernel<CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS);
     attr_set = true;
   }
-  static const int wg_per_cu = [] {
-    const char* e = getenv("LK_WINP_WGS");  // (tuning knob: persistent workgroups per CU, 1 or 2)
-    return e && atoi(e) == 1 ? 1 : 2;
-  }();
+  constexpr int wg_per_cu = 2;
   const int grid = p.n_tiles < wg_per_cu * cu_count() ? p.n_tiles : wg_per_cu * cu_count();  // two workgroups per CU
   hipLaunchKernelGGL((conv_winp_f16x2_kernel<CFG>), dim3((unsigned)grid), dim3(CFG::NT), CFG::LDS, stream, p);
   *rc = check_launch("conv_winp_f16x2_kernel");

@@ -746,24 +746,10 @@ static int eig_max_inner() {
   // inner sweeps per pivot visit.  One is best on the MI355X: the outer sweep count does not change (measured on the
   // ResNet-18 KFAC factors, tools/eig_study.py: 1065 ms vs 1479 ms with three) and the pivot solve -- the latency
   // chain of the whole solver -- is three times shorter.
-  static int v = [] {
-    int r = 1;
-    if (const char* e = getenv("LK_EIG_INNER")) {  // tuning knob (tools/eig_study.py)
-      const int t = atoi(e);
-      if (t >= 1 && t <= 8) r = t;
-    }
-    return r;
-  }();
-  return v;
+  return 1;
 }
 
-static int eig_cross_only() {
-  static int v = [] {
-    const char* e = getenv("LK_EIG_CROSS");  // tuning knob (tools/eig_study.py); default on
-    return (e && atoi(e) == 0) ? 0 : 1;
-  }();
-  return v;
-}
+static int eig_cross_only() { return 1; }
 
 static int eig_job_setup(EigJob& j, const float* A, int64_t n, float* w, float* Q, int clamp, int32_t* info, void* ws,
                          size_t ws_bytes) {

@@ -684,18 +684,9 @@ static size_t cfg_lds_bytes(int cfg, bool two_panels, bool ntb = false) {
   }
   return (size_t)2 * (two_panels ? 2 : 1) * cfg_bk(cfg) * (cfg_tile(cfg) + 4) * sizeof(float);
 }
-// The 128-tile's chunk depth.  16 rows per barrier (3 workgroups per CU) is the default; LK_GRAM_BK = 24 / 32 selects
-// the deeper variants (tuning knob, tools/microbench.py).  NT keeps 16 unless every image is a whole number of chunks.
-static int big_cfg(int64_t L_nt) {
-  static int pref = [] {
-    int v = 16;
-    if (const char* e = getenv("LK_GRAM_BK")) v = atoi(e);
-    return v;
-  }();
-  const int cfg = pref == 24 ? CFG_BIG24 : (pref == 32 ? CFG_BIG32 : CFG_BIG);
-  if (L_nt > 0 && L_nt % cfg_bk(cfg) != 0) return CFG_BIG;
-  return cfg;
-}
+// The 128-tile's chunk depth: 16 rows per barrier (3 workgroups per CU); the deeper variants (24 / 32) measured no better
+// (tools/microbench.py).
+static int big_cfg(int64_t) { return CFG_BIG; }
 
 static GramPlan make_plan(int64_t n, int64_t K, int64_t L_nt = 0) {
   GramPlan p;
@@ -771,8 +762,6 @@ static int launch_gram(const GramGeom& g, bool vec4, float alpha, float* C, unsi
   switch (p.cfg) {
     case CFG_SMALL: LK_LAUNCH_V(CFG_SMALL); break;
     case CFG_BIG: LK_LAUNCH_V(CFG_BIG); break;
-    case CFG_BIG24: LK_LAUNCH_V(CFG_BIG24); break;
-    case CFG_BIG32: LK_LAUNCH_V(CFG_BIG32); break;
     default: LK_LAUNCH_V(CFG_WIDE); break;
   }
 #undef LK_LAUNCH_V
@@ -860,8 +849,6 @@ static int launch_xcorr(const float* x, int64_t B, int H, int W, int Cin, const 
   } while (0)
   switch (p.cfg) {
     case CFG_SMALL: LK_LAUNCH_V(CFG_SMALL); break;
-    case CFG_BIG24: LK_LAUNCH_V(CFG_BIG24); break;
-    case CFG_BIG32: LK_LAUNCH_V(CFG_BIG32); break;
     default: LK_LAUNCH_V(CFG_BIG); break;
   }
 #undef LK_LAUNCH_V
@@ -1269,11 +1256,7 @@ extern "C" int lk_gram_nt_seg_f32(const float* const* segs, int64_t nseg, int64_
   }
   g.x = segs[0];
   // fp32 products from split-bf16 MFMAs (MODE_NTB) whenever the positions can be read four at a time
-  static const bool ntb = [] {
-    const char* e = getenv("LK_GRAM_NTB");  // development switch: 0 = the fp32-MFMA NT kernel
-    return e == nullptr || atoi(e) != 0;
-  }();
-  if (ntb && vec4 && BK % 16 == 0) return launch_gram<MODE_NTB>(g, vec4, alpha, C, flags, ws, ws_bytes, (hipStream_t)stream);
+  if (vec4 && BK % 16 == 0) return launch_gram<MODE_NTB>(g, vec4, alpha, C, flags, ws, ws_bytes, (hipStream_t)stream);
   return launch_gram<MODE_NT>(g, vec4, alpha, C, flags, ws, ws_bytes, (hipStream_t)stream);
 }
 
@@ -1423,11 +1406,7 @@ extern "C" int lk_conv3x3_pixpair_accumulate_f32(const float* x, int64_t B, int6
   GramGeom g{};
   g.x = x; g.K = B; g.n = (int)(H * W * Cin); g.ldx = H * W * Cin;
   g.tiles = tiles_dev; g.ldc = (int)Cin;
-  static const bool small16 = [] {
-    const char* e = getenv("LK_TNP_SMALL16");  // tuning knob
-    return !(e && atoi(e) == 0);
-  }();
-  const int cfg = T == 64 ? (small16 ? CFG_SMALL16 : CFG_SMALL) : CFG_BIG;
+  const int cfg = T == 64 ? CFG_SMALL16 : CFG_BIG;
   const int nchunks = (int)((B + cfg_bk(cfg) - 1) / cfg_bk(cfg));
   const size_t lds = cfg_lds_bytes(cfg, true);
   dim3 grid((unsigned)n_tiles, 1), block(256);
@@ -1435,10 +1414,6 @@ extern "C" int lk_conv3x3_pixpair_accumulate_f32(const float* x, int64_t B, int6
   if (cfg == CFG_SMALL16) {
     hipLaunchKernelGGL((gram_kernel<MODE_TNP, 4, CFG_SMALL16>), grid, block, lds, st, g, (float*)nullptr, 1, (int)n_tiles,
                        nchunks, nchunks, blocks, alpha);
-  } else if (cfg == CFG_SMALL) {
-    if (!allow_big_lds((const void*)gram_kernel<MODE_TNP, 4, CFG_SMALL>, lds)) return LK_ELAUNCH;
-    hipLaunchKernelGGL((gram_kernel<MODE_TNP, 4, CFG_SMALL>), grid, block, lds, st, g, (float*)nullptr, 1, (int)n_tiles, nchunks,
-                       nchunks, blocks, alpha);
   } else {
     if (!allow_big_lds((const void*)gram_kernel<MODE_TNP, 4, CFG_BIG>, lds)) return LK_ELAUNCH;
     hipLaunchKernelGGL((gram_kernel<MODE_TNP, 4, CFG_BIG>), grid, block, lds, st, g, (float*)nullptr, 1, (int)n_tiles, nchunks,

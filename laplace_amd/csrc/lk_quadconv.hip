@@ -494,13 +494,7 @@ __global__ __launch_bounds__(256) void diag_ggn_shared_reduce_kernel(const float
 
 using namespace lk;
 
-static int qc_b6_enabled() {
-  static const int on = [] {
-    const char* e = getenv("LK_QC_B6");  // development switch: 0 = the fp32-MFMA tile product everywhere
-    return (e == nullptr || atoi(e) != 0) ? 1 : 0;
-  }();
-  return on;
-}
+static int qc_b6_enabled() { return 1; }
 static bool qc_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 static int qc_class_tile(int64_t C) {

@@ -27,6 +27,25 @@ def pytest_sessionstart(session):
     stage_reference()
 
 
+def pytest_sessionfinish(session, exitstatus):
+    """a run of the -m gpu tests leaves the parity NUMBERS behind (tests/parity_log.py), not only pass / fail"""
+    from tests.parity_log import PARITY as _PARITY
+
+    if not _PARITY:
+        return
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        worker = os.environ.get("PYTEST_XDIST_WORKER", "")
+        with open(os.path.join(out, f"parity_errors{('_' + worker) if worker else ''}.log"), "w") as fh:
+            fh.write("# worst relative error (max|got - want| / max|want|) each test measured through its rel() helper; comparisons\n")
+            fh.write(f"# tests {len(_PARITY)}  device {'cuda' if torch.cuda.is_available() else 'cpu'}  exit {exitstatus}\n")
+            for tid, (n, worst) in sorted(_PARITY.items()):
+                fh.write(f"{worst:.3e}  n={n:<4d} {tid}\n")
+    except OSError:
+        pass
+
+
 def pytest_collection_modifyitems(config, items):
     """`gpu` tests need a ROCm device: skip them (instead of failing) on a machine without one, so that a plain
     `pytest` is green on a CPU-only box.  On a GPU box they always run — a missing liblaplace_hip.so must FAIL there."""

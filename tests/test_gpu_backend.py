@@ -39,7 +39,9 @@ CASES = [(n, l) for n in FIXTURES for l in LIKS]
 def rel(got, want):
     got = got.detach().double().cpu()
     want = torch.as_tensor(want).detach().double().cpu()
-    return (got - want).abs().max().item() / (want.abs().max().item() + 1e-30)
+    from tests.parity_log import record_error
+
+    return record_error((got - want).abs().max().item() / (want.abs().max().item() + 1e-30))
 
 
 def check(got, want, tol=1e-4, what=""):

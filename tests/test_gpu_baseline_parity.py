@@ -23,7 +23,9 @@ TOL = 1e-4
 
 def rel(a, b):
     a, b = a.double().cpu(), b.double().cpu()
-    return (a - b).abs().max().item() / (b.abs().max().item() + 1e-300)
+    from tests.parity_log import record_error
+
+    return record_error((a - b).abs().max().item() / (b.abs().max().item() + 1e-300))
 
 
 def _oracle():

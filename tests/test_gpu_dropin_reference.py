@@ -38,7 +38,9 @@ def ref():
 def rel(got, want):
     got = torch.as_tensor(got).detach().double().cpu()
     want = torch.as_tensor(want).detach().double().cpu()
-    return (got - want).abs().max().item() / (want.abs().max().item() + 1e-30)
+    from tests.parity_log import record_error
+
+    return record_error((got - want).abs().max().item() / (want.abs().max().item() + 1e-30))
 
 
 @pytest.mark.parametrize("name", ["mlp", "conv", "bnres"])

@@ -12,7 +12,9 @@ DEV = "cuda"
 
 def rel(a, b):
     a, b = a.double(), b.double()
-    return (a - b).abs().max().item() / (b.abs().max().item() + 1e-30)
+    from tests.parity_log import record_error
+
+    return record_error((a - b).abs().max().item() / (b.abs().max().item() + 1e-30))
 
 
 def _resnet_batch(bs, seed):

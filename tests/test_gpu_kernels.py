@@ -38,7 +38,9 @@ def relerr(got, want):
     got = got.detach().double().cpu()
     want = want.detach().double().cpu()
     scale = want.abs().max().item() + 1e-30
-    return (got - want).abs().max().item() / scale
+    from tests.parity_log import record_error
+
+    return record_error((got - want).abs().max().item() / scale)
 
 
 def assert_close(got, want, tol=1e-4, what=""):

@@ -10,7 +10,9 @@ DEV = "cuda"
 
 def rel(a, b):
     a, b = a.double().cpu(), b.double().cpu()
-    return (a - b).abs().max().item() / (b.abs().max().item() + 1e-300)
+    from tests.parity_log import record_error
+
+    return record_error((a - b).abs().max().item() / (b.abs().max().item() + 1e-300))
 
 
 @pytest.mark.parametrize("M,N,K,batch,ta,tb,use_e", [

@@ -12,7 +12,9 @@ DEV = "cuda"
 
 def rel(a, b):
     a, b = a.double().cpu(), b.double().cpu()
-    return (a - b).abs().max().item() / (b.abs().max().item() + 1e-300)
+    from tests.parity_log import record_error
+
+    return record_error((a - b).abs().max().item() / (b.abs().max().item() + 1e-300))
 
 
 def test_vjp_nhwc_split_all_operand_combinations():

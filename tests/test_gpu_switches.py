@@ -12,7 +12,9 @@ N = 50_000
 
 def rel(a, b):
     a, b = a.double(), b.double()
-    return (a - b).abs().max().item() / (b.abs().max().item() + 1e-300)
+    from tests.parity_log import record_error
+
+    return record_error((a - b).abs().max().item() / (b.abs().max().item() + 1e-300))
 
 
 @pytest.fixture(scope="module")

@@ -64,8 +64,13 @@ def main(fetch_db, write_db, out_json, out_md):
         head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
     except OSError:
         head = ""
+    if not head:  # (the GPU box's snapshot has no .git: tools/gpurun_stamped.sh leaves the head of the tree it sent in GIT_HEAD)
+        try:
+            head = open(os.path.join(ROOT, "GIT_HEAD")).read().strip()
+        except OSError:
+            head = ""
     res["_meta"] = {"csrc_sha16": csrc_sha16(), "git_head": head or None,
-                    "note": "git_head is empty on the GPU box (the snapshot has no .git): csrc_sha16 is the stamp"}
+                    "note": "csrc_sha16 (hash of laplace_amd/csrc) is the stamp bench.py checks; git_head: the commit of the tree that was sent to the GPU box (+ uncommitted changes if `dirty`)"}
     json.dump(res, open(out_json, "w"), indent=1)
     open(out_md, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
