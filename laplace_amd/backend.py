@@ -705,8 +705,9 @@ class KronAccumulator:
         self._side = None
         self._side_done = None  # event at the end of the previous minibatch's side-stream work (lagged join)
         self._side_older = []   # ... of the minibatches before that which the main stream has not waited for yet
-        #: minibatches whose factor kernels may still be running when the next one starts (env LK_LAG_DEPTH)
-        self.lag_depth = max(1, int(os.environ.get("LK_LAG_DEPTH", "1")))
+        #: minibatches whose factor kernels may still be running when the next one starts (measured with the lanes' streams
+        #: at high priority: 2 or 3 gain 1 % in the steady state and lose 3 - 5 % on a 20-minibatch fit, whose tail grows)
+        self.lag_depth = 1
         #: ``False`` (env LK_LAG_JOIN=0): the main stream waits for the factor kernels at the end of every minibatch
         self.lag_join = os.environ.get("LK_LAG_JOIN", "1") != "0"
         self.factors = None  # per tap: [G, A]
@@ -1012,6 +1013,7 @@ class KronAccumulator:
                 sub = KronAccumulator(self.backend, self.N, self.kfac_approx, self.overlap)
                 sub.lanes, sub._lane_id, sub._lane_stream = 1, k, streams[k]
                 sub.use_pixgram, sub.pix_group, sub.lag_join = self.use_pixgram, self.pix_group, self.lag_join
+                sub.lag_depth = self.lag_depth
                 sub._defer_bn, sub._persist_slabs = self._defer_bn, self._persist_slabs
                 self._lane_accs.append(sub)
         k = self._lane_next
