@@ -320,7 +320,7 @@ def test_ll_ggn_full_and_quadform(K, B, C, D, bias, cls):
 
 
 # ---- eigensolver ---------------------------------------------------------------------------------------
-def _eig_checks(K, A64, tol_rec=2e-5, tol_orth=2e-5, tol_val=2e-5):
+def _eig_checks(K, A64, tol_rec=5e-6, tol_orth=5e-6, tol_val=5e-6):  # (measured: <= 1.2e-6 up to n = 576, profiles/r04_parity_errors.log)
     n = A64.shape[0]
     w, Q, info = K.syevj(A64.float().to(DEV).contiguous())
     _sync()
@@ -329,10 +329,13 @@ def _eig_checks(K, A64, tol_rec=2e-5, tol_orth=2e-5, tol_val=2e-5):
     wref = torch.linalg.eigvalsh(A64).clamp(min=0)
     scale = wref.abs().max().item() + 1e-30
     assert torch.all(w64[1:] >= w64[:-1]), "eigenvalues not ascending"
-    assert (w64 - wref).abs().max().item() / scale < tol_val, f"eigenvalues off by {(w64 - wref).abs().max().item() / scale:.2e}"
-    orth = (Q64.T @ Q64 - torch.eye(n, dtype=torch.float64)).abs().max().item()
+    from tests.parity_log import record_error
+
+    val = record_error((w64 - wref).abs().max().item() / scale)
+    assert val < tol_val, f"eigenvalues off by {val:.2e}"
+    orth = record_error((Q64.T @ Q64 - torch.eye(n, dtype=torch.float64)).abs().max().item())
     assert orth < tol_orth, f"orthogonality {orth:.2e}"
-    rec = ((Q64 * w64) @ Q64.T - A64).abs().max().item() / scale
+    rec = record_error(((Q64 * w64) @ Q64.T - A64).abs().max().item() / scale)
     assert rec < tol_rec, f"reconstruction {rec:.2e}"
     return w, Q
 
