@@ -228,3 +228,58 @@ def test_graphs_the_nhwc_walk_has_no_rule_for_are_rejected_before_any_gradient_i
     got = sweep.backward(seeds)
     for n in taps:
         assert torch.allclose(got[n].reshape(want[n].shape), want[n], atol=1e-5), n
+
+
+class _MixedStrides(nn.Module):
+    """one feature map read by a stride-1 AND a stride-2 convolution (their cotangents meet as a pending stride-1 part and a
+    pending strided part: neither fused form applies, both must land in ONE fp32 tensor), next to a block whose two strided
+    convolutions do meet alone"""
+
+    def __init__(self, width=32):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, width, 3, 1, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(width)
+        self.conv_a = nn.Conv2d(width, width, 3, 1, 1, bias=False)
+        self.conv_c = nn.Conv2d(width, 2 * width, 3, 2, 1, bias=False)
+        self.conv_b = nn.Conv2d(width, 2 * width, 3, 2, 1, bias=False)
+        self.block = BasicBlock(2 * width, 4 * width, 2, torch.relu)
+        self.pool = nn.AdaptiveAvgPool2d(1)
+        self.fc = nn.Linear(4 * width, 5)
+
+    def forward(self, x):
+        x = torch.relu(self.bn1(self.conv1(x)))
+        y = torch.relu(self.conv_c(torch.relu(self.conv_a(x))) + self.conv_b(x))
+        return self.fc(torch.flatten(self.pool(self.block(y)), 1))
+
+
+@pytest.mark.parametrize("strided", [True, False])
+def test_a_strided_and_a_stride_1_consumer_of_the_same_map(strided):
+    torch.manual_seed(5)
+    model = _MixedStrides().eval()
+    for mod in model.modules():
+        if isinstance(mod, nn.BatchNorm2d):
+            mod.running_var.uniform_(0.5, 2.0), mod.weight.data.uniform_(0.5, 1.5)
+            mod.weight.requires_grad_(False), mod.bias.requires_grad_(False)
+    taps = {n: m for n, m in model.named_modules() if isinstance(m, (nn.Conv2d, nn.Linear))}
+    sw = SplitSweep(model, taps, kernels=get_kernels)
+    assert sw.split_ok, sw.split_reason
+    sw.fuse_strided = strided
+    K = get_kernels()
+    calls = []
+    orig = K.conv_nhwc_f16x2_vjp_strided
+    K.conv_nhwc_f16x2_vjp_strided = lambda sources, *a, **k: (calls.append(len(sources)), orig(sources, *a, **k))[1]
+    try:
+        x = torch.randn(3, 3, 16, 16)
+        seeds = torch.randn(2, 3, 5)
+        f = sw.forward(x)
+        got = sw.backward(seeds)
+    finally:
+        del K.conv_nhwc_f16x2_vjp_strided
+    f_ref, want = _autograd_tap_grads(model, taps, x, seeds)
+    assert torch.allclose(f, f_ref, atol=1e-5)
+    for n in taps:
+        err = (got[n] - want[n]).abs().max() / want[n].abs().max()
+        assert err < 2e-5, (n, float(err))
+    # the block's pair leaves as one launch of two sources, conv_c (alone at its node) as one launch of one source; conv_b
+    # meets the stride-1 conv_a at `x` and goes class by class into conv_a's tensor
+    assert sorted(calls) == ([1, 2] if strided else [])
