@@ -153,8 +153,10 @@ def test_c4_eigendecomposition_round_trip(resnet):
     from tests.parity_log import record_error
 
     print("c4 eigendecomposition, worst over the 43 factors (value, n):", worst)
+    # measured (round 4, worst at n = 4608): eigenvalues 4.3e-5 of the largest one, orthogonality 1.2e-6, reconstruction 1.8e-5
+    bounds = {"eigenvalues": 5e-5, "orthogonality": 5e-6, "reconstruction": 3e-5}
     for key, (v, n) in worst.items():
-        assert record_error(v) < 5e-5, f"{key} n={n}: {v:.2e}"
+        assert record_error(v) < bounds[key], f"{key} n={n}: {v:.2e}"
     # posterior log-determinant kernel (11.2 M terms) against fp64 math on the same eigenvalues; with
     # H_factor chosen so that curvature and prior are of comparable size (the informative regime)
     post = dec * 5.0e4 + torch.tensor(1.0, device=DEV)
