@@ -129,9 +129,11 @@ int lk_conv3x3_pixpair_accumulate_f32(const float* x, int64_t B, int64_t H, int6
 int lk_conv3x3_pixpair_assemble_f32(const float* blocks, const int32_t* slots_dev, int64_t H, int64_t W, int64_t Cin,
                                     float alpha, float* A, void* stream);
 /* _assemble of blocks + blocks2 (blocks2 optional): the accumulators of the two lanes of a fit with two minibatches in
- * flight are summed on the fly, element by element, in the same order as a separate addition would. */
+ * flight are summed on the fly, element by element, in the same order as a separate addition would.  upper_only != 0:
+ * only the (d, e) blocks with e >= d are written — the upper triangle of A, which is all lk_finalize_factors_f32 and
+ * lk_pack_upper_f32 read; the mirrored blocks are one 4-byte access per element and were half of the launch. */
 int lk_conv3x3_pixpair_assemble2_f32(const float* blocks, const float* blocks2, const int32_t* slots_dev, int64_t H, int64_t W,
-                                     int64_t Cin, float alpha, float* A, void* stream);
+                                     int64_t Cin, float alpha, float* A, int upper_only, void* stream);
 /* _accumulate on a split tensor (csrc/lk_sweep16.hip): x as two fp16 planes with one power-of-two scale (lk_split_f16x2 of
  * the NHWC images), three fp16 MFMAs per fp32 product block instead of the exact-fp32 MFMA; same tables, same blocks. */
 int lk_conv3x3_pixpair_accumulate_f16x2(const void* x_h, const void* x_l, const int* sexp, int64_t B, int64_t H, int64_t W,

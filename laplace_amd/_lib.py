@@ -57,7 +57,7 @@ SIGNATURES = {
     "lk_conv3x3_pixpair_accumulate_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _f32, _vp, _vp, _i64, _vp]),
     "lk_conv3x3_pixpair_accumulate_f16x2": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp, _vp, _i64, _vp, _vp]),
     "lk_conv3x3_pixpair_assemble_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _f32, _vp, _vp]),
-    "lk_conv3x3_pixpair_assemble2_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _f32, _vp, _vp]),
+    "lk_conv3x3_pixpair_assemble2_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _f32, _vp, _int, _vp]),
     "lk_nchw_to_nhwc_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "lk_absmax_f32": (_int, [_vp, _i64, _vp, _i64, _i64, _vp, _vp]),
     "lk_copy_absmax_f32": (_int, [_vp, _vp, _i64, _vp, _vp]),
@@ -818,16 +818,18 @@ class HipKernels:
                  "lk_conv3x3_pixpair_accumulate_f16x2")
         return blocks
 
-    def pixpair_assemble(self, blocks, plan, H, W, Cin, alpha, A_native, blocks2=None):
+    def pixpair_assemble(self, blocks, plan, H, W, Cin, alpha, A_native, blocks2=None, upper_only=False):
         """``A_native += alpha * assemble(blocks [+ blocks2])``: ``blocks2`` is a second accumulator set of the same geometry
-        (the other lane of a fit), summed on the fly"""
+        (the other lane of a fit), summed on the fly; ``upper_only``: only the upper triangle of ``A_native`` is written (what
+        :meth:`finalize_factors` and the packed exchange read)"""
         _check(blocks, "blocks"), _check(A_native, "A")
         if blocks2 is not None:
             _check(blocks2, "blocks2")
             assert blocks2.numel() == blocks.numel()
         self._rc(self.lib.lk_conv3x3_pixpair_assemble2_f32(_ptr(blocks), _ptr(blocks2), ctypes.c_void_p(plan[2].data_ptr()),
                                                            int(H), int(W), int(Cin), float(alpha), _ptr(A_native),
-                                                           self._stream(blocks.device)), "lk_conv3x3_pixpair_assemble2_f32")
+                                                           1 if upper_only else 0, self._stream(blocks.device)),
+                 "lk_conv3x3_pixpair_assemble2_f32")
         return A_native
 
     def permute_native_to_unfold(self, src, Cin, KK, dst, accumulate=False):

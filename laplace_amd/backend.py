@@ -972,7 +972,7 @@ class KronAccumulator:
             self._drain_pixpair(idx)
             geo, buf = self._pix.pop(idx)
             if geo[0] == "pair":
-                K.pixpair_assemble(buf, geo[4], geo[1], geo[2], geo[3], 1.0, self.factors[idx][1])
+                K.pixpair_assemble(buf, geo[4], geo[1], geo[2], geo[3], 1.0, self.factors[idx][1], upper_only=True)
             else:
                 K.pixgram_assemble(buf, geo[1], geo[2], geo[3], 1.0, self.factors[idx][1])
             return buf
@@ -1135,7 +1135,7 @@ class KronAccumulator:
                 for o in others[1:]:
                     buf.add_(o)
                 if geo[0] == "pair":
-                    K.pixpair_assemble(buf, geo[4], geo[1], geo[2], geo[3], 1.0, A, blocks2=others[0])
+                    K.pixpair_assemble(buf, geo[4], geo[1], geo[2], geo[3], 1.0, A, blocks2=others[0], upper_only=True)
                 else:
                     buf.add_(others[0])
                     K.pixgram_assemble(buf, geo[1], geo[2], geo[3], 1.0, A)

@@ -387,8 +387,8 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
 
   auto stage = [&](int s, int buf) {
     // K order: taps major, channel chunks minor.  (The other order — the nine taps of one 32-channel chunk back to back,
-    // so that only a quarter-to-sixteenth-depth window has to survive in L2 between them — was measured: better on the
-    // stride-2 classes, worse on the 64- and 512-channel layers, 10.66 vs 10.50 ms per step; config bit 19 selects it.)
+    // so that only a quarter-to-sixteenth-depth window has to survive in L2 between them — was measured in round 3: better
+    // on the stride-2 classes, worse on the 64- and 512-channel layers, 10.66 vs 10.50 ms per step; removed in round 4.)
     const int tj = s / KC, kc = s - tj * KC;
     const int t = (int)((tap_list >> (4 * tj)) & 15ull);
     char* base = smem + buf * CFG::STAGE;

@@ -960,49 +960,56 @@ static const signed char kHalfDx[13] = {0, 1, 2, -2, -1, 0, 1, 2, -2, -1, 0, 1, 
 // waves of a workgroup share 64 triples and split the map's pixels into P contiguous ranges (fixed-order sum of the P
 // partials through LDS: deterministic), and every thread requests eight block elements ahead of its chain of additions;
 // the slot table and all conditions are uniform over a wave when Cin % 64 == 0.
-__global__ __launch_bounds__(512) void pixpair_assemble_kernel(const float* __restrict__ blocks,
+template <bool MIRROR>
+__global__ __launch_bounds__(256) void pixpair_assemble_kernel(const float* __restrict__ blocks,
                                                                const float* __restrict__ blocks2,
                                                                const int* __restrict__ slots, int H, int W, int Cin,
                                                                float alpha, float* __restrict__ A) {
-  __shared__ float red[8 * 9 * 64];
+  // a thread owns FOUR consecutive elements of one shift's Cin x Cin block (16-byte loads: the one-element form issued four
+  // times the requests for the same bytes and ran at 1.6 TB/s); a wave one pixel range of the map
+  __shared__ float4 red[4 * 9 * 64];
   const int n = 9 * Cin;
   const int64_t bsz = (int64_t)Cin * Cin;
-  const int64_t total = 13 * bsz;
+  const int64_t total4 = 13 * bsz / 4;
   const int HW = H * W;
   const int lane = threadIdx.x & 63, part = threadIdx.x >> 6, P = blockDim.x >> 6;
   // this wave's pixels [q_lo, q_hi)
   const int per = (HW + P - 1) / P;
   const int q_lo = part * per < HW ? part * per : HW, q_hi = q_lo + per < HW ? q_lo + per : HW;
   constexpr int U = 8;
-  for (int64_t base = (int64_t)blockIdx.x * 64; base < total; base += (int64_t)gridDim.x * 64) {  // (uniform over the workgroup)
+  for (int64_t base = (int64_t)blockIdx.x * 64; base < total4; base += (int64_t)gridDim.x * 64) {  // (uniform over the workgroup)
     const int64_t idx = base + lane;
-    const bool live = idx < total;
-    const int h = (int)((live ? idx : base) / bsz);
-    const int64_t inner = (live ? idx : base) - (int64_t)h * bsz;
-    const int ci = (int)(inner / Cin), cj = (int)(inner - (int64_t)ci * Cin);
+    const bool live = idx < total4;
+    const int64_t el = (live ? idx : base) * 4;
+    const int h = (int)(el / bsz);
+    const int64_t inner = el - (int64_t)h * bsz;
+    const int ci = (int)(inner / Cin), cj = (int)(inner - (int64_t)ci * Cin);  // cj % 4 == 0 (Cin % 4 == 0)
     const int Dy = h < 3 ? 0 : (h < 8 ? 1 : 2);
     const int Dx = h < 3 ? h : (h < 8 ? h - 5 : h - 10);
     // patch offsets d = (dy, dx) with e = d + D still inside {-1,0,1}^2
     const int dy_lo = -1, dy_hi = 1 - Dy;
     const int dx_lo = Dx < 0 ? -1 - Dx : -1, dx_hi = Dx > 0 ? 1 - Dx : 1;
-    float acc[3][3];
+    float4 acc[3][3];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
-      for (int b = 0; b < 3; ++b) acc[a][b] = 0.f;
+      for (int b = 0; b < 3; ++b) acc[a][b] = make_float4(0.f, 0.f, 0.f, 0.f);
     int qy0 = q_lo / W, qx0 = q_lo - qy0 * W;  // pixel q0 (tracked incrementally: no division in the loop)
     for (int q0 = q_lo; q0 < q_hi; q0 += U) {
-      float v[U];
+      float4 v[U];
       bool have[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int q = q0 + u;
         const int slot = q < q_hi ? slots[q * 13 + h] : -1;
         have[u] = slot >= 0;
-        v[u] = 0.f;
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (have[u]) {
-          v[u] = blocks[(int64_t)slot * bsz + inner];
-          if (blocks2) v[u] += blocks2[(int64_t)slot * bsz + inner];
+          v[u] = *reinterpret_cast<const float4*>(blocks + (int64_t)slot * bsz + inner);
+          if (blocks2) {
+            const float4 w = *reinterpret_cast<const float4*>(blocks2 + (int64_t)slot * bsz + inner);
+            v[u].x += w.x, v[u].y += w.y, v[u].z += w.z, v[u].w += w.w;
+          }
         }
       }
       int qy = qy0, qx = qx0;
@@ -1017,7 +1024,7 @@ __global__ __launch_bounds__(512) void pixpair_assemble_kernel(const float* __re
             const int dy = a - 1, dx = b - 1;  // p = q - d has to be a pixel of the map
             if (dy >= dy_lo && dy <= dy_hi && dx >= dx_lo && dx <= dx_hi && qy - dy >= 0 && qy - dy < H && qx - dx >= 0 &&
                 qx - dx < W)
-              acc[a][b] += v[u];
+              acc[a][b].x += v[u].x, acc[a][b].y += v[u].y, acc[a][b].z += v[u].z, acc[a][b].w += v[u].w;
           }
       }
       if (qx == W) qx = 0, ++qy;
@@ -1030,8 +1037,11 @@ __global__ __launch_bounds__(512) void pixpair_assemble_kernel(const float* __re
       if (part == 0) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-          float t = red[k * 64 + lane];
-          for (int p_ = 1; p_ < P; ++p_) t += red[(p_ * 9 + k) * 64 + lane];
+          float4 t = red[k * 64 + lane];
+          for (int p_ = 1; p_ < P; ++p_) {
+            const float4 w = red[(p_ * 9 + k) * 64 + lane];
+            t.x += w.x, t.y += w.y, t.z += w.z, t.w += w.w;
+          }
           acc[k / 3][k % 3] = t;
         }
       }
@@ -1045,9 +1055,17 @@ __global__ __launch_bounds__(512) void pixpair_assemble_kernel(const float* __re
         const int dy = a - 1, dx = b - 1;
         if (!(dy >= dy_lo && dy <= dy_hi && dx >= dx_lo && dx <= dx_hi)) continue;
         const int d = a * 3 + b, e = (dy + Dy + 1) * 3 + (dx + Dx + 1);
-        const float v = alpha * acc[a][b];
-        A[(int64_t)(d * Cin + ci) * n + e * Cin + cj] += v;
-        if (h != 0) A[(int64_t)(e * Cin + cj) * n + d * Cin + ci] += v;  // the mirrored block (shift -D)
+        const float4 t = acc[a][b];
+        const float v4[4] = {alpha * t.x, alpha * t.y, alpha * t.z, alpha * t.w};
+        float4* dst = reinterpret_cast<float4*>(A + (int64_t)(d * Cin + ci) * n + e * Cin + cj);
+        float4 o = *dst;
+        o.x += v4[0], o.y += v4[1], o.z += v4[2], o.w += v4[3];
+        *dst = o;
+        if (MIRROR && h != 0) {  // the mirrored block (shift -D): a column of four rows, one 4-byte access per row — left out
+                                 // when the consumer reads the upper triangle only (every (d, e) block written above has e >= d)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) A[(int64_t)(e * Cin + cj + j) * n + d * Cin + ci] += v4[j];
+        }
       }
   }
 }
@@ -1424,24 +1442,30 @@ extern "C" int lk_conv3x3_pixpair_accumulate_f32(const float* x, int64_t B, int6
 
 // blocks2 (optional): a second accumulator set of the same geometry; what is assembled is blocks + blocks2
 extern "C" int lk_conv3x3_pixpair_assemble2_f32(const float* blocks, const float* blocks2, const int32_t* slots_dev, int64_t H,
-                                                int64_t W, int64_t Cin, float alpha, float* A, void* stream) {
+                                                int64_t W, int64_t Cin, float alpha, float* A, int upper_only, void* stream) {
   LK_REQUIRE(blocks && slots_dev && A && H >= 1 && W >= 1 && Cin >= 1 && 9 * Cin < (1ll << 24) && H * W < (1ll << 24),
              "lk_conv3x3_pixpair_assemble_f32: bad arguments");
-  const int64_t total = 13 * Cin * Cin;
-  int64_t nblk = (total + 63) / 64;
+  LK_REQUIRE(Cin % 4 == 0 && ((reinterpret_cast<uintptr_t>(blocks) | reinterpret_cast<uintptr_t>(blocks2) | reinterpret_cast<uintptr_t>(A)) & 15) == 0,
+             "lk_conv3x3_pixpair_assemble_f32: Cin % 4 == 0 and 16-byte aligned buffers");
+  const int64_t total4 = 13 * Cin * Cin / 4;
+  int64_t nblk = (total4 + 63) / 64;
   if (nblk > 65536) nblk = 65536;
   // waves per workgroup = pixel ranges: enough threads for the chip on the few-channel / large-map layers, at least 32
   // pixels per range
   int P = 1;
-  while (P < 8 && nblk * 64 * P < (1 << 19) && H * W >= 64 * P) P *= 2;
-  hipLaunchKernelGGL(pixpair_assemble_kernel, dim3((unsigned)nblk), dim3(64 * P), 0, (hipStream_t)stream, blocks, blocks2,
-                     slots_dev, (int)H, (int)W, (int)Cin, alpha, A);
+  while (P < 4 && nblk * 64 * P < (1 << 18) && H * W >= 64 * P) P *= 2;
+  if (upper_only)
+    hipLaunchKernelGGL(pixpair_assemble_kernel<false>, dim3((unsigned)nblk), dim3(64 * P), 0, (hipStream_t)stream, blocks, blocks2,
+                       slots_dev, (int)H, (int)W, (int)Cin, alpha, A);
+  else
+    hipLaunchKernelGGL(pixpair_assemble_kernel<true>, dim3((unsigned)nblk), dim3(64 * P), 0, (hipStream_t)stream, blocks, blocks2,
+                       slots_dev, (int)H, (int)W, (int)Cin, alpha, A);
   return check_launch("pixpair_assemble_kernel");
 }
 
 extern "C" int lk_conv3x3_pixpair_assemble_f32(const float* blocks, const int32_t* slots_dev, int64_t H, int64_t W,
                                                int64_t Cin, float alpha, float* A, void* stream) {
-  return lk_conv3x3_pixpair_assemble2_f32(blocks, nullptr, slots_dev, H, W, Cin, alpha, A, stream);
+  return lk_conv3x3_pixpair_assemble2_f32(blocks, nullptr, slots_dev, H, W, Cin, alpha, A, 0, stream);
 }
 
 extern "C" int lk_conv3x3_pixgram_assemble_f32(const float* Cp, int64_t H, int64_t W, int64_t Cin, float alpha, float* A,

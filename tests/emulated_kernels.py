@@ -460,7 +460,7 @@ class EmulatedKernels:
     def pixpair_accumulate_split(self, xs, alpha, blocks, plan):
         return self.pixpair_accumulate_nhwc(xs.float(), alpha, blocks, plan)
 
-    def pixpair_assemble(self, blocks, plan, H, W, Cin, alpha, A_native, blocks2=None):
+    def pixpair_assemble(self, blocks, plan, H, W, Cin, alpha, A_native, blocks2=None, upper_only=False):
         if blocks2 is not None:
             blocks = blocks + blocks2
         blk = blocks.view(plan[0], Cin, Cin)

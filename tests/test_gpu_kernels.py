@@ -751,6 +751,11 @@ def test_conv3x3_banded_pixel_pair_form_two_accumulator_sets(K, B, Cin, H, W):
     assert_close(got, want, what="banded pixel-pair form, two accumulator sets")
     nat1 = K.pixpair_assemble(sets[0] + sets[1], plan, H, W, Cin, 1.0, torch.zeros(n, n, device=DEV))
     assert torch.equal(nat, nat1)  # the same additions in the same order
+    # upper_only: the upper triangle is the same, bit for bit; nothing below the block diagonal is written on the device
+    natu = K.pixpair_assemble(sets[0], plan, H, W, Cin, 1.0, torch.zeros(n, n, device=DEV), blocks2=sets[1], upper_only=True)
+    assert torch.equal(torch.triu(natu), torch.triu(nat))
+    if DEV != "cpu":
+        assert float(torch.tril(natu, -Cin).abs().max()) == 0.0
 
 
 def test_finalize_factors_is_symmetrize_scale_and_permute_in_one_launch(K):
