@@ -159,8 +159,12 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     return lib
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (lambda idx: torch.cuda.current_stream(idx).cuda_stream)
+
+
 def _ptr(t: Optional[torch.Tensor]):
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+    """device address for a ``c_void_p`` argument (a plain int: ctypes converts it; ~1000 of these per fit step)"""
+    return None if t is None else t.data_ptr()
 
 
 def _check(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
@@ -218,11 +222,14 @@ class HipKernels:
         return rc
 
     # ---- plumbing -----------------------------------------------------------------------------
-    def _stream(self, dev) -> ctypes.c_void_p:
-        return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    def _stream(self, dev) -> int:
+        """raw handle of torch's current stream on ``dev`` (the C call behind ``torch.cuda.current_stream(dev).cuda_stream``
+        without the Stream object and its device look-ups: ~170 of these per fit step)"""
+        idx = dev.index if isinstance(dev, torch.device) else torch.device(dev).index
+        return _raw_stream(torch.cuda.current_device() if idx is None else idx)
 
     def _workspace(self, nbytes: int, dev) -> torch.Tensor:
-        key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+        key = (dev.index, self._stream(dev))
         buf = self._ws.get(key)
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=dev)

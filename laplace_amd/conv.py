@@ -7,6 +7,8 @@ seeds at once through :func:`conv_backward_data`.
 """
 from __future__ import annotations
 
+import functools
+
 import torch
 from torch import nn
 
@@ -94,7 +96,13 @@ def backward_plan(m: nn.Conv2d, Hin: int, Win: int):
     """Launches of the backward-data of ``m`` for an input of ``Hin x Win`` pixels: one per residue class
     ``(h % s, w % s)`` of the input-gradient pixels, ``(Hc, Wc, oh0, ow0, taps)`` with ``taps = [(dh, dw, slice)]``:
     ``dX[i*s + oh0, j*s + ow0] = sum_taps g[i + dh, j + dw] W[:, :, kh, kw]``, where ``kh = oh0 + p - dh*s``."""
-    s, (ph, pw), (KH, KW) = m.stride[0], m.padding, m.kernel_size
+    return _backward_plan(int(m.stride[0]), tuple(int(p) for p in m.padding), tuple(int(k) for k in m.kernel_size), int(Hin), int(Win))
+
+
+@functools.lru_cache(maxsize=512)
+def _backward_plan(s, padding, kernel_size, Hin, Win):
+    # (a pure function of the geometry, asked ~45 times per fit step: cached; callers must not modify the lists)
+    (ph, pw), (KH, KW) = padding, kernel_size
     plans = []
     for rh in range(min(s, Hin)):
         for rw in range(min(s, Win)):

@@ -107,7 +107,10 @@ class SeedBatchedSweep:
         """Returns ``f``; fills ``self.saved`` (per node: what the VJP needs) and ``self.taps[name]['a']``.
         ``need_vjp=False``: inference only (the feature pass of the last-layer flavours) — nothing is kept for a
         reverse sweep, only the tapped inputs."""
-        if self.gm.training or any(m.training for m in self.gm.modules() if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d, nn.Dropout))):
+        mode_mods = self.__dict__.get("_mode_mods")
+        if mode_mods is None:  # (the modules whose VJP rules assume eval mode; the graph does not change after tracing)
+            mode_mods = self._mode_mods = [m for m in self.gm.modules() if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d, nn.Dropout))]
+        if self.gm.training or any(m.training for m in mode_mods):
             raise SweepUnsupported("model must be in eval mode (BatchNorm / Dropout VJPs assume it)")
         env: dict[fx.Node, Any] = {}
         self.saved: dict[fx.Node, Any] = {}
