@@ -14,6 +14,7 @@ Prints ONE JSON line on rank 0.
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -189,6 +190,7 @@ def fit_50k_leg(backend, dev):
           for _ in range(4)]
     n_full, rest = divmod(N_DATASET, BATCH)
     last = (bs[1][0][:rest].contiguous(), bs[1][1][:rest].contiguous()) if rest else None
+    gc.collect()  # (the legs before this one leave a large heap behind: the host side of a step is 60 % of its device time)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     acc = backend.kron_accumulator(N_DATASET)
@@ -401,6 +403,7 @@ def main():
     barrier()
 
     # ---- timed region: exactly K steps (+ the fit's single all-reduce and layout finalisation) --------------
+    gc.collect()  # (measurement hygiene: no full collection of the warm-up's garbage inside the timed steps)
     barrier()
     t0 = time.perf_counter()
     loss, H = fit_steps(backend, batches, args.steps, world, overlap)
