@@ -596,6 +596,7 @@ def main():
         literal(n_lit)
         sync()
         result["dropin_fit_samples_per_s"] = n_lit * BATCH / (time.perf_counter() - t0)
+    pred_dec = None
     if rank == 0 and world == 1:
         if not args.no_eigh:
             sync()
@@ -640,8 +641,8 @@ def main():
                     "workload": "c4 posterior: ResNet-18 full-network KFAC, GLM predictive variance [B,10,10], batch 128",
                     "samples_per_s": pred_rate, "ms_per_call": pred_ms, "finite": bool(torch.isfinite(f_var).all()),
                     "roofline": dict(pfam[dom], family=dom) if dom else None, "roofline_families": pfam}
-                if not args.no_cpu_baseline:
-                    result["predictive_kron_c4"]["cpu_baseline"] = cpu_predictive_baseline(dec, 1.0, args.cpu_seconds)
+                pred_dec = dec  # (its CPU baseline runs LAST, with the other one: 128 host threads for 12 s right in front of
+                                # the 50 000-sample leg, whose host side is 60 - 85 % of its device time, is no fair start)
             del dec
         if not args.no_predictive and not SELFTEST:
             result["predictive"] = predictive_leg(dev)
@@ -669,7 +670,10 @@ def main():
                                         "finalize_ms_behind_a_drained_device": (time.perf_counter() - t_f) * 1e3}
             result["other_configs"] = small_config_legs(dev)
         if not args.no_cpu_baseline:
+            if pred_dec is not None:
+                result["predictive_kron_c4"]["cpu_baseline"] = cpu_predictive_baseline(pred_dec, 1.0, args.cpu_seconds)
             result["cpu_baseline"] = cpu_baseline(0.0 if SELFTEST else args.cpu_seconds)
+        pred_dec = None
     if world > 1:
         # the fit's ONE collective: message size against what the model's factor shapes say it must be (a wrong pack /
         # a missed factor shows here, not as a silently wrong posterior), and its stand-alone time on the same buffer size
