@@ -283,3 +283,36 @@ def test_a_strided_and_a_stride_1_consumer_of_the_same_map(strided):
     # the block's pair leaves as one launch of two sources, conv_c (alone at its node) as one launch of one source; conv_b
     # meets the stride-1 conv_a at `x` and goes class by class into conv_a's tensor
     assert sorted(calls) == ([1, 2] if strided else [])
+
+
+@pytest.mark.parametrize("k,p,H,W", [(3, 1, 8, 8), (3, 1, 6, 10), (1, 0, 8, 8), (2, 0, 8, 6), (3, 1, 2, 2)])
+def test_strided_launch_tables_against_conv2d_input(k, p, H, W):
+    """`conv.strided_taps` + the (emulated) strided fused launch == the input gradient of the strided convolutions (one
+    and two sources, with the folded channel scale of the second), for the geometries `strided_fused_ok` admits"""
+    from laplace_amd import conv as cv
+
+    torch.manual_seed(k * 10 + p + H)
+    cin, cout, N = 32, 32, 3
+    m1 = nn.Conv2d(cin, cout, k, 2, p, bias=False)
+    m2 = nn.Conv2d(cin, cout, 1, 2, 0, bias=False)
+    assert cv.strided_fused_ok(m2, (H, W))
+    if not cv.strided_fused_ok(m1, (H, W)):
+        pytest.skip("geometry outside the strided form (output grid is not H/2 x W/2)")
+    K = get_kernels()
+    Ho, Wo = H // 2, W // 2
+    g1, g2 = torch.randn(N, cout, Ho, Wo), 5.0 * torch.randn(N, cout, Ho, Wo)
+    cs = torch.rand(cout) + 0.5
+    p1, p2 = cv.PreparedConv(m1), cv.PreparedConv(m2)
+    s1, s2 = K.split_f16x2(g1.permute(0, 2, 3, 1).contiguous()), K.split_f16x2(g2.permute(0, 2, 3, 1).contiguous())
+    want1 = torch.nn.grad.conv2d_input((N, cin, H, W), m1.weight.double(), g1.double(), stride=2, padding=p)
+    want2 = torch.nn.grad.conv2d_input((N, cin, H, W), m2.weight.double() * cs.double().reshape(-1, 1, 1, 1), g2.double(), stride=2)
+    rows1 = cv.strided_taps([(p1, s1, None)], (H, W))
+    if rows1 is None:  # (a kernel that leaves residue classes untouched, e.g. 1 x 1: only valid next to one that covers them)
+        assert k == 1
+    else:
+        got = cv.conv_backward_data_vjp_strided([(p1, s1, None)], (H, W))
+        assert (got.float().permute(0, 3, 1, 2).double() - want1).abs().max() < 2e-5 * want1.abs().max()
+    if k != 1:
+        got = cv.conv_backward_data_vjp_strided([(p1, s1, None), (p2, s2, cs)], (H, W))
+        want = want1 + want2
+        assert (got.float().permute(0, 3, 1, 2).double() - want).abs().max() < 2e-5 * want.abs().max()
