@@ -176,8 +176,12 @@ int lk_finalize_factors_f32(int64_t count, const float* const* src, float* const
  * Replaces the backward-data convolutions inside the C reverse passes of curvlinops' KFACLinearOperator._compute_kfac
  * as driven by CurvlinopsInterface.kron (laplace/curvature/curvlinops.py:87-100); the same GEMM is the forward conv.
  *
- * A "split tensor" is a pair of fp16 planes (h, l) of the tensor's layout plus a device int `sexp`:
- *     x * 2^sexp = h + l (+ e, |e| <= max(2^-22 |x 2^sexp|, 2^-25)),   max|x| * 2^sexp < 2^15.
+ * A "split tensor" is a pair of fp16 planes (h, l) of the tensor's layout plus device ints `sexp`:
+ *     x * 2^sexp = h + l (+ e, |e| <= max(2^-22 |x 2^sexp|, 2^-25)),   max|x| * 2^sexp < 2^15,
+ * ONE scale for the tensor (the reverse sweep's cotangents: what consumes them are sums over samples) or ONE PER IMAGE of
+ * the leading dimension, sexp[n] (the forward's activations: lk_split_images_f16x2, lk_bn_act_fwd_nhwc_f16x2) — the
+ * reference computes every sample in fp32 whatever else is in its minibatch (laplace/curvature/curvature.py:375-433), and
+ * a ReLU mask decided on an activation resolved only relative to the LARGEST image of the minibatch is not that.
  * ------------------------------------------------------------------------------------------- */
 /* out[0] = bit pattern of max_i |x[i] * cscale[(i / inner) % C]| (cscale may be NULL); deterministic. */
 int lk_absmax_f32(const float* x, int64_t n, const float* cscale, int64_t inner, int64_t C, unsigned* out, void* stream);
@@ -185,13 +189,18 @@ int lk_absmax_f32(const float* x, int64_t n, const float* cscale, int64_t inner,
  * n % 8 == 0. */
 int lk_split_f16x2(const float* x, int64_t n, const float* amax, float bound_mul, void* planes_h, void* planes_l,
                    int* sexp, void* stream);
+/* x [N][per] fp32 -> split tensor with one scale per image: sexp[n] from the image's own max|x_n|, which is also left in
+ * amax[n] (bit pattern of a float: the measured maximum the next producer derives its bound from).  per % 8 == 0. */
+int lk_split_images_f16x2(const float* x, int64_t N, int64_t per, void* planes_h, void* planes_l, int* sexp, unsigned* amax,
+                          void* stream);
 /* W[Co][Ci][taps] (* cscale[co], e.g. a folded BatchNorm scale) -> planes[2][taps][N][K] fp16 + sexp;
  * transpose = 1 (backward-data): n = ci, k = co; 0 (forward): n = co, k = ci.  amax_ws: one device word. */
 int lk_conv_prep_weights_f16x2(const float* W, int64_t Co, int64_t Ci, int64_t taps, int transpose, const float* cscale,
                                unsigned* amax_ws, void* planes, int* sexp, void* stream);
 /* One launch of the implicit GEMM
  *     out[n][i*out_step + oh0][j*out_step + ow0][co] (+)= sum_t sum_c in[n][i*in_mul + dh_t][j*in_mul + dw_t][c] * Wt[wt_t][co][c]
- * for i < Hc, j < Wc (taps outside the [Hi][Wi] image contribute zero).  in: split tensor [N][Hi][Wi][Ci], Ci % 32 == 0;
+ * for i < Hc, j < Wc (taps outside the [Hi][Wi] image contribute zero).  in: split tensor [N][Hi][Wi][Ci], Ci % 32 == 0,
+ * with in_nsexp = 1 scale or in_nsexp = N scales (one per image: GEMM rows never mix images, the epilogue un-scales row by row);
  * w: split planes [.][Co][Ci]; taps: T x {dh, dw, wt} (T <= 9, host array); zero16: >= 16 zero bytes on the device;
  * out: fp32 [N][Ho][Wo][Co]; accumulate != 0 adds into out; amax_out (may be NULL): atomicMax of the bit patterns of
  * |out| (zero it first).  Stride-1 backward-data and forward convs are one launch, a stride-s backward-data is one
@@ -201,8 +210,8 @@ int lk_conv_prep_weights_f16x2(const float* W, int64_t Co, int64_t Ci, int64_t t
  * bits 12..14: tile shape of the generic form — 0: chosen from the shapes by occupancy (a pure function of the arguments),
  * 1: 64x64, 2: 128x64, 3: 64x128, 4: 128x128, 5: 256x64, 6: the big tile by output width only; the remaining bits select
  * development variants of the K pipeline (csrc/lk_conv.hip).  Every choice computes the same sums in the same order. */
-int lk_conv_nhwc_f16x2(const void* in_h, const void* in_l, const int* in_sexp, int64_t N, int64_t Hi, int64_t Wi,
-                       int64_t Ci, const void* w_h, const void* w_l, const int* w_sexp, int64_t Co, int64_t Hc,
+int lk_conv_nhwc_f16x2(const void* in_h, const void* in_l, const int* in_sexp, int64_t in_nsexp, int64_t N, int64_t Hi,
+                       int64_t Wi, int64_t Ci, const void* w_h, const void* w_l, const int* w_sexp, int64_t Co, int64_t Hc,
                        int64_t Wc, int64_t in_mul, int64_t Ho, int64_t Wo, int64_t out_step, int64_t oh0, int64_t ow0,
                        int64_t T, const int* taps, const void* zero16, float* out, int accumulate, unsigned* amax_out,
                        int config, void* stream);
@@ -266,27 +275,25 @@ int lk_vjp_nhwc_split_f16x2(const float* g, const unsigned* g_amax, const void* 
                             const void* m, int m_is_float, const unsigned* m_amax, const float* scale,
                             const unsigned* scale_amax, int64_t C, int64_t S, int64_t per, void* out_h, void* out_l,
                             int* out_sexp, void* stream);
-/* Forward of the NHWC sweep: y = act(x * scale[c] + shift[c] + addend) on fp32 NHWC tensors, act 0 none / 1 ReLU / 2 tanh
- * (replaces BatchNorm2d-eval + add + activation, three library launches per layer, and produces in the same pass the
- * ReLU mask as NHWC bytes, the split planes of y for the next convolution and the guaranteed bound of max|y|:
- *     y_bound = max|x| max|scale| + max|shift| + addend_bound   (tanh: 1).
- * x_amax / scale_amax / shift_amax: device words with bit patterns of the maxima; addend (+ addend_bound), mask, y_h / y_l
- * may be NULL.  C % 8 == 0. */
-int lk_bn_act_fwd_nhwc_f16x2(const float* x, const unsigned* x_amax, const float* scale, const float* shift,
-                             const unsigned* scale_amax, const unsigned* shift_amax, const float* addend,
-                             const float* addend_bound, int act, int64_t C, int64_t per, float* y, void* mask, void* y_h,
-                             void* y_l, int* y_sexp, float* y_bound, void* stream);
+/* Forward of the NHWC sweep: y = act(x * scale[c] + shift[c] + addend) on fp32 NHWC tensors x [N][per], act 0 none /
+ * 1 ReLU / 2 tanh (replaces BatchNorm2d-eval + add + activation, three library launches per layer), producing in the same
+ * pass the ReLU mask as NHWC bytes and the split planes of y for the next convolution with ONE SCALE PER IMAGE, image n
+ * scaled from the guaranteed bound
+ *     y_bound[n] = bx_n max|scale| + max|shift| + addend_bound[n],   bx_n = x_amax[n] * x_mul[0] + x_add[0] >= max|x_n|   (tanh: 1)
+ * x_amax: x_namax = 1 or N words (bit patterns; for a convolution's output: the measured maxima of its INPUT images, with
+ * x_mul = the l1 norm of its weights and x_add = max|bias|; x_mul / x_add may be NULL = 1 / 0); addend_bound: 1 or N floats.
+ * y_amax (N words, zeroed by the caller; may be NULL) receives the MEASURED max|y_n| — the next layer's x_amax, so the
+ * slack of the bound does not compound.  scale_amax / shift_amax: device words with bit patterns of the maxima; addend,
+ * mask, y_h / y_l may be NULL.  C % 8 == 0, per % C == 0, N <= 65535. */
+int lk_bn_act_fwd_nhwc_f16x2(const float* x, const unsigned* x_amax, int64_t x_namax, const float* x_mul, const float* x_add,
+                             const float* scale, const float* shift, const unsigned* scale_amax, const unsigned* shift_amax,
+                             const float* addend, const float* addend_bound, int64_t addend_nbound, int act, int64_t C,
+                             int64_t N, int64_t per, float* y, void* mask, void* y_h, void* y_l, int* y_sexp, float* y_bound,
+                             unsigned* y_amax, void* stream);
 /* y[0..n) = x[0..n) and *amax = max(*amax, max|x|) (bit pattern of a non-negative float; NOT reset: the word runs over the
  * minibatches stacked for one pixel-pair launch, which are then split with it instead of being measured in a pass of
  * their own).  16-byte aligned buffers, n % 4 == 0. */
 int lk_copy_absmax_f32(const float* x, float* y, int64_t n, unsigned* amax, void* stream);
-
-/* Spread of the per-sample magnitudes of a minibatch x [B][per]: words[0] = max_n max|x_n|, words[1] = min over the
- * samples that are not identically zero, both as bit patterns of non-negative floats (atomicMax / atomicMin: the caller
- * initialises words[0] = 0, words[1] = 0x7f800000 once and may let many minibatches fold into the same pair).  The split
- * tensors of the sweep carry one power-of-two scale per TENSOR (lk_split_f16x2): samples more than ~2^16 apart in
- * magnitude inside one minibatch are outside what that resolves per sample; the host reads the words once per fit. */
-int lk_range_words_f32(const float* x, int64_t B, int64_t per, unsigned* words, void* stream);
 
 /* Row-major packed upper triangle of a symmetric n x n factor (what the ranks of a data-parallel fit exchange: half the
  * bytes of the square): packed[i n - i (i - 1) / 2 + (j - i)] = A[i][j], j >= i.  Unpacking writes the upper triangle only. */

@@ -61,10 +61,10 @@ SIGNATURES = {
     "lk_nchw_to_nhwc_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "lk_absmax_f32": (_int, [_vp, _i64, _vp, _i64, _i64, _vp, _vp]),
     "lk_copy_absmax_f32": (_int, [_vp, _vp, _i64, _vp, _vp]),
-    "lk_range_words_f32": (_int, [_vp, _i64, _i64, _vp, _vp]),
     "lk_split_f16x2": (_int, [_vp, _i64, _vp, _f32, _vp, _vp, _vp, _vp]),
+    "lk_split_images_f16x2": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "lk_conv_prep_weights_f16x2": (_int, [_vp, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp]),
-    "lk_conv_nhwc_f16x2": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64,
+    "lk_conv_nhwc_f16x2": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64,
                                   _i64, _i64, _i64, _i64, _vp, _vp, _vp, _int, _vp, _int, _vp]),
     "lk_conv_nhwc_f16x2_vjp": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64,
                                       _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _i64, _vp, _vp, _vp, _vp, _vp,
@@ -76,7 +76,8 @@ SIGNATURES = {
     "lk_conv_nhwc_f16x2_vjp_strided": (_int, [_vp] * 16 + [_i64] * 9 + [_vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _i64, _vp, _vp, _vp,
                                                _vp, _vp, _vp, _int, _vp]),
     "lk_vjp_nhwc_split_f16x2": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
-    "lk_bn_act_fwd_nhwc_f16x2": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "lk_bn_act_fwd_nhwc_f16x2": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _i64, _i64, _i64, _vp, _vp,
+                                        _vp, _vp, _vp, _vp, _vp, _vp]),
     "lk_unsplit_transpose_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "lk_gram_tn_f16x2_workspace_bytes": (_sz, [_i64, _i64]),
     "lk_gram_tn_f16x2": (_int, [_vp, _vp, _vp, _i64, _i64, _f32, _vp, _vp, _vp, _sz, _vp]),
@@ -127,22 +128,31 @@ class LaplaceHipError(RuntimeError):
 
 
 class SplitTensor:
-    """Two fp16 planes ``planes[0] + planes[1] ~= x * 2**sexp`` of a tensor (include/laplace_hip.h, lk_split_f16x2)."""
+    """Two fp16 planes ``planes[0] + planes[1] ~= x * 2**sexp`` of a tensor (include/laplace_hip.h, lk_split_f16x2).
+    ``sexp``: int32 ``[1]`` — one scale for the tensor (the reverse sweep's cotangents) — or ``[N]``, one per image of the
+    leading dimension (the forward's activations: lk_split_images_f16x2, lk_bn_act_fwd_nhwc_f16x2)."""
 
     __slots__ = ("planes", "sexp", "amax")
 
     def __init__(self, planes: torch.Tensor, sexp: torch.Tensor, amax: torch.Tensor | None = None):
-        #: ``amax``: device word with the MEASURED max|x| when the producer provides one (fused convolution epilogue);
-        #: consumers that need a bound otherwise use 2**(15 - sexp)
+        #: ``amax``: device word(s) with the MEASURED max|x| (per scale entry) when the producer provides them (fused
+        #: convolution epilogue, per-image forward); consumers that need a bound otherwise use 2**(15 - sexp)
         self.planes, self.sexp, self.amax = planes, sexp, amax
 
     @property
     def shape(self):
         return self.planes.shape[1:]
 
+    @property
+    def per_image(self) -> bool:
+        return self.sexp.numel() > 1
+
     def float(self) -> torch.Tensor:
         """fp32 reconstruction (tests / fallbacks)"""
-        return (self.planes[0].float() + self.planes[1].float()) * torch.exp2(-self.sexp.float())
+        s = self.sexp.float()
+        if s.numel() > 1:
+            s = s.reshape(-1, *([1] * (self.planes.dim() - 2)))
+        return (self.planes[0].float() + self.planes[1].float()) * torch.exp2(-s)
 
 
 def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
@@ -177,6 +187,14 @@ def _check(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
     if not t.is_contiguous():
         raise LaplaceHipError(f"{name}: tensor must be contiguous")
     return t
+
+
+def _one_scale(x: "SplitTensor", what: str) -> "SplitTensor":
+    """consumers whose GEMM rows or reductions run ACROSS images (the reverse sweep's kernels) take one scale per tensor"""
+    if x is not None and x.sexp.numel() != 1:
+        raise LaplaceHipError(f"{what}: a split tensor with one scale per image is a forward operand (lk_conv_nhwc_f16x2); "
+                              "this kernel reduces across images and needs one scale for the tensor")
+    return x
 
 
 def is_channels_last(x) -> bool:
@@ -373,15 +391,6 @@ class HipKernels:
         self._rc(self.lib.lk_absmax_f32(_ptr(x), x.numel(), None, 1, 1, _ptr(out), self._stream(x.device)), "lk_absmax_f32")
         return out
 
-    def range_words(self, x, words):
-        """fold max / min-nonzero over the samples of ``x [B, ...]`` of the per-sample max|.| into ``words`` (int32 [2],
-        initialised to [0, 0x7f800000]; bit patterns of floats) — see lk_range_words_f32"""
-        _check(x, "x")
-        B = x.shape[0]
-        self._rc(self.lib.lk_range_words_f32(_ptr(x), B, x.numel() // max(B, 1), _ptr(words), self._stream(x.device)),
-                 "lk_range_words_f32")
-        return words
-
     #: ``False``: the stacked pixel-pair inputs are copied by the runtime and measured in a pass of their own before they
     #: are split (measured: no difference in the step; one pass less at the end of a fit)
     use_copy_absmax = True
@@ -411,6 +420,21 @@ class HipKernels:
         self._rc(self.lib.lk_split_f16x2(_ptr(x), x.numel(), _ptr(amax), float(bound_mul), _ptr(planes[0]), _ptr(planes[1]),
                                          _ptr(sexp), self._stream(x.device)), "lk_split_f16x2")
         return SplitTensor(planes, sexp)
+
+    def split_images_f16x2(self, x):
+        """fp32 ``[N, ...]`` -> :class:`SplitTensor` with ONE SCALE PER IMAGE (lk_split_images_f16x2): ``sexp [N]`` from
+        each image's own ``max|x_n|``, which rides along as ``amax [N]``"""
+        _check(x, "x")
+        N = x.shape[0]
+        per = x.numel() // max(N, 1)
+        if per % 8:
+            raise LaplaceHipError("split_images_f16x2: elements per image % 8 != 0")
+        planes = torch.empty((2,) + tuple(x.shape), dtype=torch.float16, device=x.device)
+        sexp = torch.empty(N, dtype=torch.int32, device=x.device)
+        amax = torch.empty(N, dtype=torch.float32, device=x.device)
+        self._rc(self.lib.lk_split_images_f16x2(_ptr(x), N, per, _ptr(planes[0]), _ptr(planes[1]), _ptr(sexp), _ptr(amax),
+                                                self._stream(x.device)), "lk_split_images_f16x2")
+        return SplitTensor(planes, sexp, amax)
 
     def conv_prep_weights(self, W, transpose, cscale=None):
         """conv weight ``[Co, Ci, KH, KW]`` -> (planes ``[2, T, N, K]`` fp16, sexp); see lk_conv_prep_weights_f16x2"""
@@ -462,7 +486,7 @@ class HipKernels:
         # algorithmic work: the fp32 multiply-adds of the convolution (each is three fp16 MFMA multiply-adds on the chip)
         work = 2.0 * N * Co * Ci * self.conv_valid_pairs(Hc, Wc, in_mul, Hi, Wi, taps) if self.profile is not None else 0.0
         self._rc(self._timed("conv16", work, out.device, lambda: self.lib.lk_conv_nhwc_f16x2(
-            _ptr(x.planes[0]), _ptr(x.planes[1]), _ptr(x.sexp), N, Hi, Wi, Ci, _ptr(wplanes[0]), _ptr(wplanes[1]),
+            _ptr(x.planes[0]), _ptr(x.planes[1]), _ptr(x.sexp), x.sexp.numel(), N, Hi, Wi, Ci, _ptr(wplanes[0]), _ptr(wplanes[1]),
             _ptr(wsexp), Co, Hc, Wc, in_mul, out.shape[1], out.shape[2], out_step, oh0, ow0, len(taps), flat, _ptr(z),
             _ptr(out), 1 if accumulate else 0, _ptr(amax_out), int(cfg), self._stream(out.device))), "lk_conv_nhwc_f16x2")
         return out
@@ -486,6 +510,7 @@ class HipKernels:
         Co = wplanes.shape[2]
         dev = x.planes.device
         assert wplanes.shape[3] == Ci
+        _one_scale(x, "conv_nhwc_f16x2_vjp"), _one_scale(add, "conv_nhwc_f16x2_vjp")
         planes = torch.empty((2, N, Ho, Wo, Co), dtype=torch.float16, device=dev)
         sexp = torch.empty(1, dtype=torch.int32, device=dev)
         amax = amax_word if amax_word is not None else torch.zeros(1, dtype=torch.float32, device=dev)
@@ -539,6 +564,9 @@ class HipKernels:
         if len(sources) not in (1, 2) or any(tuple(s_[0].planes.shape) != tuple(x.planes.shape) or s_[1].shape[2:] != wplanes.shape[2:]
                                              for s_ in sources):
             raise LaplaceHipError("conv_nhwc_f16x2_vjp_strided: one or two sources of the same shapes")
+        for s_ in sources:
+            _one_scale(s_[0], "conv_nhwc_f16x2_vjp_strided")
+        _one_scale(add, "conv_nhwc_f16x2_vjp_strided")
         planes = torch.empty((2, N, Ho, Wo, Co), dtype=torch.float16, device=dev)
         sexp = torch.empty(1, dtype=torch.int32, device=dev)
         amax = amax_word if amax_word is not None else torch.zeros(1, dtype=torch.float32, device=dev)
@@ -580,6 +608,7 @@ class HipKernels:
         ``g``: fp32 NHWC with ``g_amax`` (device word, lk_absmax / conv epilogue) or None; ``g2``: SplitTensor or None;
         ``mult``: [B, H, W, C] uint8 / bool mask or fp32 multiplier (``mult_amax`` for fp32) or None."""
         dev = (g if g is not None else g2.planes).device
+        _one_scale(g2, "vjp_nhwc_split")
         planes = torch.empty((2,) + tuple(out_shape), dtype=torch.float16, device=dev)
         sexp = torch.empty(1, dtype=torch.int32, device=dev)
         n = planes[0].numel()
@@ -603,31 +632,41 @@ class HipKernels:
         return SplitTensor(planes, sexp)
 
     def bn_act_forward_nhwc(self, x, x_amax, scale, shift, scale_amax, shift_amax, act, addend=None, addend_bound=None,
-                            want_mask=True, want_split=True):
+                            want_mask=True, want_split=True, x_mul=None, x_add=None, amax_words=None):
         """``y = act(x * scale[c] + shift[c] + addend)`` on fp32 NHWC ``x [B, H, W, C]`` -> ``(y, mask, split, bound)``:
-        ``mask`` NHWC uint8 (ReLU only), ``split`` the SplitTensor of ``y``, ``bound`` a device word >= max|y|"""
+        ``mask`` NHWC uint8 (ReLU only), ``split`` the SplitTensor of ``y`` with ONE SCALE PER IMAGE and its measured
+        per-image maxima as ``split.amax`` (``[B]``), ``bound [B]`` the guaranteed bounds the scales were derived from.
+        ``x_amax``: 1 or B words bounding ``x`` per image after ``* x_mul[0] + x_add[0]`` (device words; a convolution's
+        output: the measured maxima of its input images, the l1 norm of its weights, max|bias|); ``addend_bound``: 1 or B
+        floats; ``amax_words``: zeroed ``[B]`` float32 buffer for the measured maxima (allocated if absent)."""
         _check(x, "x")
         C = x.shape[-1]
+        B = x.shape[0]
         y = torch.empty_like(x)
         mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if (act == 1 and want_mask) else None
         planes = torch.empty((2,) + tuple(x.shape), dtype=torch.float16, device=x.device) if want_split else None
-        sexp = torch.empty(1, dtype=torch.int32, device=x.device)
-        bound = torch.empty(1, dtype=torch.float32, device=x.device)
+        sexp = torch.empty(B, dtype=torch.int32, device=x.device)
+        bound = torch.empty(B, dtype=torch.float32, device=x.device)
+        amax = amax_words if amax_words is not None else torch.zeros(B, dtype=torch.float32, device=x.device)
         if addend is not None:
             _check(addend, "addend")
+        if x_amax.numel() not in (1, B) or (addend is not None and addend_bound.numel() not in (1, B)) or amax.numel() != B:
+            raise LaplaceHipError("bn_act_forward_nhwc: x_amax / addend_bound have 1 or B entries, amax_words B")
         nbytes = x.numel() * (4.0 + 4.0 + (4.0 if addend is not None else 0.0) + (4.0 if want_split else 0.0)
                               + (1.0 if mask is not None else 0.0))
         self._rc(self._timed("bnact16", nbytes, x.device, lambda: self.lib.lk_bn_act_fwd_nhwc_f16x2(
-            _ptr(x), _ptr(x_amax), _ptr(scale), _ptr(shift), _ptr(scale_amax), _ptr(shift_amax), _ptr(addend),
-            _ptr(addend_bound), int(act), C, x.numel(), _ptr(y), _ptr(mask), None if planes is None else _ptr(planes[0]),
-            None if planes is None else _ptr(planes[1]), _ptr(sexp), _ptr(bound), self._stream(x.device))),
+            _ptr(x), _ptr(x_amax), x_amax.numel(), _ptr(x_mul), _ptr(x_add), _ptr(scale), _ptr(shift), _ptr(scale_amax),
+            _ptr(shift_amax), _ptr(addend), _ptr(addend_bound), 1 if addend_bound is None else addend_bound.numel(), int(act),
+            C, B, x.numel() // max(B, 1), _ptr(y), _ptr(mask), None if planes is None else _ptr(planes[0]),
+            None if planes is None else _ptr(planes[1]), _ptr(sexp), _ptr(bound), _ptr(amax), self._stream(x.device))),
             "lk_bn_act_fwd_nhwc_f16x2")
-        return y, mask, (SplitTensor(planes, sexp) if planes is not None else None), bound
+        return y, mask, (SplitTensor(planes, sexp, amax) if planes is not None else None), bound
 
     def unsplit_transpose(self, x, S, B):
         """SplitTensor ``[S*B, H, W, C]`` (seed-major) -> fp32 ``[B, S, C, H*W]``"""
         N, H, W, C = x.shape
         assert N == S * B
+        _one_scale(x, "unsplit_transpose")
         out = torch.empty(B, S, C, H * W, dtype=torch.float32, device=x.planes.device)
         self._rc(self.lib.lk_unsplit_transpose_f32(_ptr(x.planes[0]), _ptr(x.planes[1]), _ptr(x.sexp), S, B, H * W, C,
                                                    _ptr(out), self._stream(out.device)), "lk_unsplit_transpose_f32")
@@ -636,6 +675,7 @@ class HipKernels:
     def gram_tn_f16x2(self, x, alpha, out):
         """``out[upper tiles] += alpha * X^T X`` for a SplitTensor ``x`` viewed as ``[rows, C]``"""
         _check(out, "out")
+        _one_scale(x, "gram_tn_f16x2")
         C = x.planes.shape[-1]
         R = x.planes[0].numel() // C
         nbytes = int(self.lib.lk_gram_tn_f16x2_workspace_bytes(R, C))
@@ -813,6 +853,7 @@ class HipKernels:
     def pixpair_accumulate_split(self, xs, alpha, blocks, plan):
         """:meth:`pixpair_accumulate_nhwc` on a SplitTensor ``xs [B, H, W, Cin]`` (three fp16 MFMAs per product block)."""
         _check(blocks, "blocks")
+        _one_scale(xs, "pixpair_accumulate_split")
         B, H, W, Cin = xs.shape
         nb, tiles, _ = plan
         assert blocks.numel() == nb * Cin * Cin

@@ -124,38 +124,6 @@ def shared_operands(tap, g, B, C, Q1=None, Q2=None, bounds=None):
     return u.contiguous(), v.contiguous(), gsum
 
 
-#: largest spread (in powers of two) of the per-sample input magnitudes that one sweep takes: the split-fp16 tensors of
-#: the sweep carry ONE scale per tensor (csrc/lk_conv.hip), whose fixed-point floor is 2^-39 of the tensor's largest
-#: element — a sample 2^-16 below the largest one still keeps 2^-23 of ITS OWN maximum, and the quadratic growth of the
-#: variance with the activations is covered twice over.  Wider minibatches are swept in magnitude groups.
-RANGE_GUARD_LOG2 = 16
-
-
-def range_groups(x, max_log2: int = RANGE_GUARD_LOG2):
-    """``None`` (one sweep) or index tensors of sub-batches whose per-sample input magnitudes stay within
-    ``2^max_log2`` of each other.  The predictive is per sample (``f_var[n]`` must be right relative to ITS OWN size,
-    tests/test_baselaplace.py:334-410 of the reference compare element-wise), unlike the factors of a fit, which are
-    sums over the minibatch.  Costs one [B]-float read-back per call."""
-    if not torch.is_tensor(x) or not x.is_floating_point() or x.dim() < 2 or x.shape[0] < 2:
-        return None
-    amax = x.detach().abs().reshape(x.shape[0], -1).amax(1).float().cpu()
-    nz = amax > 0
-    if not bool(nz.any()):
-        return None
-    e = torch.floor(torch.log2(amax.clamp_min(1e-38)))
-    e = torch.where(nz, e, e[nz].max())  # an all-zero sample is exact under any scale: it joins the largest group
-    if float(e.max() - e.min()) <= max_log2:
-        return None
-    order = torch.argsort(e)
-    groups, start = [], 0
-    for i in range(1, len(order) + 1):
-        if i == len(order) or float(e[order[i]] - e[order[start]]) > max_log2:
-            groups.append(order[start:i].sort().values.to(x.device))
-            start = i
-    return groups
-
-
-
 class CachedFeatures:
     """Head input ``phi [B, D]`` and output ``f [B, C]`` of one batch; accepted wherever a last-layer backend takes ``x``."""
 
@@ -170,13 +138,6 @@ class CachedFeatures:
 
 class _HipCurvatureMixin:
     """Shared machinery of :class:`HipGGN` and :class:`HipEF`."""
-
-    #: What happens when the samples of ONE minibatch differ by more than ``2**RANGE_GUARD_LOG2`` in input magnitude
-    #: (the split-fp16 tensors of the sweep carry one scale per tensor, see :func:`range_groups`):
-    #: ``"check"`` (default) — per-sample results (predictive, Jacobians) sweep such a minibatch in magnitude groups; a fit
-    #: records the spread on the device (no sync per step) and RAISES at the end if a minibatch was outside the range;
-    #: ``"group"`` — fits also sweep in magnitude groups (exact, costs one read-back per minibatch); ``"off"`` — no check.
-    range_guard = "check"
 
     # ---- forward / taps -------------------------------------------------------------------------
     def _tape(self) -> Tape:
@@ -233,7 +194,7 @@ class _HipCurvatureMixin:
                     a.copy_(b)  # (casts)
             cur[0] = sig
         twin = cur[1]
-        for k in ("range_guard", "use_sweep", "use_split_sweep", "generator"):
+        for k in ("use_sweep", "use_split_sweep", "generator"):
             if k in self.__dict__:
                 setattr(twin, k, self.__dict__[k])
         return twin, dt
@@ -242,8 +203,15 @@ class _HipCurvatureMixin:
     def _to32(x):
         if torch.is_tensor(x):
             return x.float() if x.is_floating_point() and x.dtype != torch.float32 else x
-        if isinstance(x, MutableMapping) or isinstance(x, dict):
-            return type(x)({k: _HipCurvatureMixin._to32(v) for k, v in x.items()}) if isinstance(x, dict) else x
+        if isinstance(x, (dict, MutableMapping)):  # dict-style inputs (HuggingFace BatchEncoding, UserDict): same container type
+            import copy
+
+            out = copy.copy(x)
+            for k in list(x.keys()):
+                out[k] = _HipCurvatureMixin._to32(x[k])
+            return out
+        if isinstance(x, (tuple, list)):
+            return type(x)(_HipCurvatureMixin._to32(v) for v in x)
         return x
 
     @staticmethod
@@ -669,8 +637,8 @@ class _HipCurvatureMixin:
 
 
 class CurvatureExchange(list):
-    """What `KronAccumulator.tensors` hands to `allreduce_curvature`: the tensors of the exchange, plus the accumulator
-    whose range verdict (`_range_msg`) must be agreed on by all ranks before anybody raises."""
+    """What `KronAccumulator.tensors` hands to `allreduce_curvature`: the tensors of the exchange and the accumulator they
+    belong to."""
 
     owner = None
 
@@ -694,6 +662,12 @@ class KronAccumulator:
     """
 
     def __init__(self, backend, N: int, kfac_approx: str = "expand", overlap: bool = True):
+        # a model in another floating dtype is served by the backend's fp32 twin (see `_twin`): minibatches go in as fp32,
+        # the factors come back in the model's dtype — like `backend.kron`, which the reference's literal loop calls
+        twin, dt = backend._twin() if hasattr(backend, "_twin") else (None, torch.float32)
+        self._caller, self._out_dtype = (backend, dt) if twin is not None else (None, torch.float32)
+        if twin is not None:
+            backend = twin
         self.backend, self.N, self.kfac_approx = backend, N, kfac_approx
         self.overlap = overlap
         self.use_pixgram = os.environ.get("LK_PIXGRAM", "1") != "0"
@@ -713,13 +687,13 @@ class KronAccumulator:
         self.factors = None  # per tap: [G, A]
         self.loss = None
         self._taps_meta = None
-        self._range_tab, self._range_n, self._range_full = None, 0, []  # see _note_range
         #: ``True`` (set by ``backend.kron`` for the minibatches of the reference's literal loop): the banded pixel-pair
         #: products of the 3x3 A factors are NOT computed here — the minibatch keeps its NHWC inputs (`_pix_inputs`) and
         #: the running sum that absorbs it (`merge_`) stacks them and runs the grouped kernel into ITS accumulators, as
         #: the fused accumulator does.  A minibatch nobody absorbs computes them the per-minibatch way when it is read.
         self.defer_pix = False
         self._pix_inputs = {}  # tap index -> list of (geometry, alpha, NHWC fp32 tensor [B, H, W, C], module)
+        self._pix_early = set()  # taps whose pixel-pair blocks were folded into this accumulator's A factor mid-fit
         #: minibatches in flight on the device (env LK_LANES): with 2, consecutive minibatches go alternately to two
         #: sub-accumulators, each with its own stream (and side stream) and its own factor buffers, summed when the fit
         #: is read — the forward pass of one minibatch (small grids at batch 128) then runs beside the reverse sweep of
@@ -727,7 +701,6 @@ class KronAccumulator:
         self.lanes = max(1, int(os.environ.get("LK_LANES", "2")))
         self._lane_accs, self._lane_next, self._lane_id, self._lane_stream = None, 0, 0, None
         self._lane_sig = None
-        self._range_msg = None  # verdict of `_range_verdict` a data-parallel fit carries through its all-reduce
         self._a_done = None  # event on the side stream behind the A-side work of the latest minibatch
         self._lanes_anywhere = False  # (tests: the lanes' host logic on the CPU emulation of the kernels, without streams)
 
@@ -937,6 +910,7 @@ class KronAccumulator:
                 if (old[1], old[2]) == tuple(int(v) for v in tap.a.shape[-2:]):
                     continue
                 self._flush_pixgrams(only=idx)  # the input size changed within the fit: fold what there is, start anew
+                self._pix_early.add(idx)  # (this accumulator's own A factor of the tap is no longer untouched: `_fold_lanes`)
             geo = self._pix_geometry(tap)
             if geo is None:
                 continue
@@ -1173,78 +1147,29 @@ class KronAccumulator:
             else:
                 if set(self._gscale) != set(sub._gscale):
                     raise RuntimeError("the lanes of a fit disagree about the deferred BatchNorm scales")
-                skip = merged if not first else set()  # (those A factors were never written in the other lanes: zeros)
+                # (those A factors were never written in the other lanes: zeros — unless the input size changed within the
+                #  fit and the lane folded its blocks early into its OWN factor: that partial sum must be added)
+                skip = (merged - sub._pix_early) if not first else set()
                 mine = [t for i, F in enumerate(self.factors) for j, t in enumerate(F) if not (j == 1 and i in skip)] + [self.loss]
                 theirs = [t for i, F in enumerate(sub.factors) for j, t in enumerate(F) if not (j == 1 and i in skip)] + [sub.loss]
                 torch._foreach_add_(mine, theirs)
             first = False
-            if sub._range_tab is not None or sub._range_full:
-                self._range_full += list(sub._range_full) + ([sub._range_tab[:sub._range_n]] if sub._range_tab is not None else [])
             if on_device:
                 for t in sub._raw_tensors():  # allocated on the lane's stream, read (and from now on owned) here
                     t.record_stream(cur)
 
     def add_batch(self, x, y):
+        if self._caller is not None:
+            twin, _ = self._caller._twin()  # (re-synchronises the fp32 copy if a parameter or buffer changed)
+            x, y = twin._to32(x), twin._to32(y)
         b = self.backend
         if self.lanes > 1 and self.overlap and not self.defer_pix and torch.is_tensor(x) and (x.is_cuda or self._lanes_anywhere):
             return self._lane_add_batch(x, y)
-        mode = getattr(b, "range_guard", "check")
-        # The guard concerns the split-fp16 NHWC sweep only (one scale per tensor): a model that runs through the NCHW sweep
-        # or the autograd tape computes per element in fp32 like the reference and takes any data (a 1-D regression set
-        # with one sample near zero used to raise here).  Before the first forward of a model the path is not known yet:
-        # `_add_batch` records the range once it is (mode "check"); mode "group" then groups to be safe.
-        if (mode == "group" and b._split_sweep_state() is not False and torch.is_tensor(x) and x.is_floating_point()
-                and x.dim() >= 2 and x.shape[0] > 1):
-            groups = range_groups(x)  # (one read-back; the sum over samples is additive, so sub-minibatches are exact)
-            if groups is not None:
-                for idx in groups:
-                    self._add_batch(x.index_select(0, idx).contiguous(), y.index_select(0, idx).contiguous())
-                return
         self._add_batch(x, y)
-
-    def _note_range(self, x):
-        """record max / min-nonzero of the per-sample input magnitudes of this minibatch in a device table (one tiny
-        launch, no synchronisation); :meth:`_check_range` reads the table once, when the fit ends"""
-        cap = 1024
-        if self._range_tab is None or self._range_n == cap:
-            if self._range_tab is not None:
-                self._range_full.append(self._range_tab)
-            tab = torch.empty(cap, 2, dtype=torch.int32, device=x.device)
-            tab[:, 0] = 0
-            tab[:, 1] = 0x7F800000
-            self._range_tab, self._range_n = tab, 0
-        get_kernels().range_words(x, self._range_tab[self._range_n])
-        self._range_n += 1
-
-    def _range_verdict(self):
-        """read (and clear) the recorded per-minibatch magnitude spreads: ``None`` or what is wrong with them"""
-        tabs = list(self._range_full) + ([self._range_tab[:self._range_n]] if self._range_tab is not None else [])
-        self._range_tab, self._range_n, self._range_full = None, 0, []
-        if not tabs:
-            return None
-        w = torch.cat(tabs).cpu().view(torch.float32)
-        bad = (w[:, 0] > 0) & (w[:, 0] > w[:, 1] * float(2 ** RANGE_GUARD_LOG2))
-        if not bool(bad.any()):
-            return None
-        i = int(bad.nonzero()[0])
-        return (f"minibatch {i} of this fit mixes samples whose input magnitudes differ by "
-                f"{float(w[i, 0] / w[i, 1]):.1e} (max|x_n| from {float(w[i, 1]):.1e} to {float(w[i, 0]):.1e}): beyond the "
-                f"2^{RANGE_GUARD_LOG2} the split-fp16 sweep resolves per sample with one scale per tensor. Set "
-                "`backend.range_guard = 'group'` (such minibatches are then swept in magnitude groups; exact), normalise "
-                "the inputs, or `'off'` to accept reduced accuracy of the small-magnitude samples.")
-
-    def _check_range(self):
-        msg = self._range_verdict() or self._range_msg
-        self._range_msg = None
-        if msg:
-            raise RuntimeError(msg)
 
     def _add_batch(self, x, y):
         b = self.backend
         f, tape, grad_fn = b._forward(x)
-        if (getattr(b, "range_guard", "check") == "check" and b._split_sweep_state() is True and torch.is_tensor(x)
-                and x.dtype == torch.float32 and x.dim() >= 2 and x.shape[0] > 1 and x.is_contiguous()):
-            self._note_range(x)  # (only minibatches the split-fp16 sweep serves)
         if tape.uncovered:
             raise NotImplementedError("KFAC supports nn.Linear / nn.Conv2d parameters only")
         if self.factors is None:
@@ -1365,6 +1290,7 @@ class KronAccumulator:
         self._fold_lanes()
         self._join_side()
         new = KronAccumulator(self.backend, self.N, self.kfac_approx, self.overlap)
+        new._caller, new._out_dtype = self._caller, self._out_dtype
         new.use_pixgram, new._persist_slabs = self.use_pixgram, self._persist_slabs
         new.defer_pix, new.pix_group = self.defer_pix, self.pix_group
         new._pix_inputs = {k: list(v) for k, v in self._pix_inputs.items()}  # (the tensors themselves are never written)
@@ -1380,7 +1306,6 @@ class KronAccumulator:
             new._tap_index = dict(self._tap_index)
             new._pix = {idx: (geo, buf.clone()) for idx, (geo, buf) in self._pix.items()}
             new._pix_pending, new._gslabs = {}, {}
-            new._range_full = list(self._range_full) + ([self._range_tab[:self._range_n]] if self._range_tab is not None else [])
             new._side = self._side
         return new
 
@@ -1420,10 +1345,6 @@ class KronAccumulator:
                     t.record_stream(side)
             self._side_done = torch.cuda.Event()
             self._side_done.record(side)
-        # (the merged minibatches' magnitude records come along: checked when the sum is finalised)
-        self._range_full += list(other._range_full)
-        if other._range_tab is not None:
-            self._range_full.append(other._range_tab[:other._range_n])
         return True
 
     def _join_side(self):
@@ -1466,10 +1387,6 @@ class KronAccumulator:
         scales are applied HERE, before the exchange: ``diag(s) G diag(s)`` is linear in G, so scaled factors add
         exactly, and a rank with an empty shard — which never learned a scale and contributes zeros — needs none."""
         self._fold_lanes()
-        # The range verdict of THIS rank's shard must not be raised here: the other ranks would enter the all-reduce and
-        # hang until the collective times out.  It travels with the exchange (one flag word, `allreduce_curvature`) and
-        # every rank raises after the collective; without a process group `allreduce_curvature` / `finalize` raise it.
-        self._range_msg = self._range_verdict() or self._range_msg
         self._resolve_pix_inputs()
         self._flush_pixgrams()  # the assembled factors are what is exchanged, not the larger pixel-pair Grams
         self._flush_g_slabs()
@@ -1505,9 +1422,6 @@ class KronAccumulator:
             done.append((G, A, has_bias))
         K.finalize_factors(items)
         self._gscale = {}
-        # (the range verdict is a device-to-host read: taken once everything of the fit has been enqueued, so that the
-        # device does not idle behind the host's round trip)
-        self._check_range()
         kfacs = []
         for G, A, has_bias in done:
             if G.numel() == 1 and A.numel() == 1 and not has_bias:
@@ -1517,6 +1431,8 @@ class KronAccumulator:
             if has_bias:
                 kfacs.append([G * rt])
         self.factors = None
+        if self._out_dtype != torch.float32:
+            return _HipCurvatureMixin._cast((self.loss[0], HipKron(kfacs)), self._out_dtype)
         return self.loss[0], HipKron(kfacs)
 
 
@@ -1626,16 +1542,7 @@ class HipGGN(_HipCurvatureMixin, GGNInterface):
             eye = torch.eye(C, dtype=f.dtype, device=f.device)
             return eye[:, None, :].expand(C, B, C).contiguous()
 
-        groups = range_groups(x) if self.range_guard not in (False, "off") and self._split_sweep_state() is not False else None
-        if groups is None:
-            Js, f = self._rows(x, seeds_fn)
-        else:  # per-sample results: a minibatch of very different magnitudes is swept in magnitude groups (range_groups)
-            Js = f = None
-            for idx in groups:
-                J_g, f_g = self._rows(x.index_select(0, idx).contiguous(), seeds_fn)
-                if Js is None:
-                    Js, f = J_g.new_empty(x.shape[0], *J_g.shape[1:]), f_g.new_empty(x.shape[0], *f_g.shape[1:])
-                Js[idx], f[idx] = J_g, f_g
+        Js, f = self._rows(x, seeds_fn)
         if self.subnetwork_indices is not None:
             Js = Js[:, :, self.subnetwork_indices]
         return Js, f

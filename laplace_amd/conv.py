@@ -88,8 +88,21 @@ class PreparedConv:
                 Wp[:, :W.shape[1]] = W
                 W = Wp
             planes, sexp = get_kernels().conv_prep_weights(W.contiguous(), False, None)
-            self._fwd = (key, planes, sexp)
+            # l1 bound of the forward GEMM: max|conv(x)_n| <= max|x_n| * max_co sum_{ci,kh,kw} |W| — what the forward's fused
+            # BatchNorm / activation kernel scales an image's planes from (lk_bn_act_fwd_nhwc_f16x2: x_mul), and max|bias|
+            l1 = W.abs().float().sum(dim=(1, 2, 3)).max().reshape(1).contiguous()
+            b = self.m.bias
+            bmax = None if b is None else b.detach().abs().float().max().reshape(1).contiguous()
+            self._fwd = (key, planes, sexp, l1, bmax, None if b is None else (b._version, b.data_ptr()))
         return self._fwd[1], self._fwd[2]
+
+    def forward_l1(self):
+        """(l1, max|bias| or None): device words with ``max|conv(x)_n + bias| <= max|x_n| * l1 + max|bias|``"""
+        self.forward_planes()
+        b = self.m.bias
+        if b is not None and self._fwd[5] != (b._version, b.data_ptr()):
+            self._fwd = self._fwd[:4] + (b.detach().abs().float().max().reshape(1).contiguous(), (b._version, b.data_ptr()))
+        return self._fwd[3], self._fwd[4]
 
 
 def backward_plan(m: nn.Conv2d, Hin: int, Win: int):
@@ -181,6 +194,12 @@ def strided_taps(descs, in_hw):
     (one or two convolutions that read the same ``in_hw`` input), or None when some residue class of the input pixels is
     reached by no tap (a lone strided 1 x 1 convolution)"""
     rows, classes = [], set()
+    g0, w0 = descs[0][1], descs[0][0].m.weight
+    for prep, g, _ in descs[1:]:
+        # one launch = one GEMM shape: both cotangents [N, H/2, W/2, Cout] and both weights [Cout, Cin, ., .] must agree in
+        # their channel counts (a 3x3 branch 32 -> 64 beside a 1x1 branch 32 -> 32 reading the same input does not fuse)
+        if tuple(g.planes.shape) != tuple(g0.planes.shape) or tuple(prep.m.weight.shape[:2]) != tuple(w0.shape[:2]):
+            return None
     for i, (prep, _, _) in enumerate(descs):
         for Hc, Wc, oh0, ow0, taps in backward_plan(prep.m, *in_hw):
             for dh, dw, sl in taps:
@@ -240,7 +259,7 @@ def conv_forward_filters(m: nn.Conv2d, a: torch.Tensor, filt: torch.Tensor, key_
     planes, sexp = hit[1]
     if xs is None or tuple(xs.shape) != (a.shape[0], a.shape[2], a.shape[3], a.shape[1]):
         xh = a.permute(0, 2, 3, 1).contiguous()  # (a view when `a` is NHWC in memory already)
-        xs = K.split_f16x2(xh)               # (``xs``: the split copy the forward pass already made of ``a``)
+        xs = K.split_images_f16x2(xh)        # (``xs``: the split copy the forward pass already made of ``a``; one scale per image)
     N, Hin, Win, _ = xs.shape
     s, (ph, pw), (KH, KW) = m.stride[0], m.padding, m.kernel_size
     Ho, Wo = (Hin + 2 * ph - KH) // s + 1, (Win + 2 * pw - KW) // s + 1

@@ -137,25 +137,6 @@ __global__ __launch_bounds__(256) void copy_absmax4_kernel(const float4* __restr
   block_max_to_word(m, out);
 }
 
-// ---- spread of the per-sample magnitudes of a minibatch: words[0] = max over samples of max|x_n|, words[1] = min over
-//      the samples that are not identically zero (bit patterns; atomicMax / atomicMin are order-independent).  The split
-//      tensors of a sweep carry ONE scale per tensor: a minibatch whose samples differ by more than ~2^16 in magnitude is
-//      outside what that scheme resolves per sample, and the host checks these words for it (once per fit, no sync per step).
-__global__ __launch_bounds__(256) void range_words_kernel(const float* __restrict__ x, int64_t per, unsigned* __restrict__ words) {
-  const float* xs = x + (int64_t)blockIdx.x * per;
-  unsigned m = 0;
-  for (int64_t i = threadIdx.x; i < per; i += 256) m = max(m, __float_as_uint(xs[i]) & 0x7fffffffu);
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
-  __shared__ unsigned red[4];
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    m = max(max(red[0], red[1]), max(red[2], red[3]));
-    if (m) atomicMax(words, m), atomicMin(words + 1, m);
-  }
-}
-
 // ---- fp32 [rows][C] (NHWC) -> two fp16 planes, scale from the device-side bound `amax[0]` (* bound_mul) --------------
 __global__ __launch_bounds__(256) void split_f16x2_kernel(const float* __restrict__ x, int64_t n8,
                                                           const float* __restrict__ amax, float bound_mul,
@@ -176,6 +157,46 @@ __global__ __launch_bounds__(256) void split_f16x2_kernel(const float* __restric
     }
     reinterpret_cast<f16x8*>(ph)[i] = h;
     reinterpret_cast<f16x8*>(pl)[i] = l;
+  }
+}
+
+// ---- the same with ONE SCALE PER IMAGE (leading dimension): x [N][per] -> planes, sexp[N], amax[N] --------------------------
+// The forward activations of a minibatch are split image by image: a ReLU network is positively homogeneous, so the
+// activations of an image follow ITS magnitude through every layer, and a mask decided on values resolved only to 2^-39 of
+// the minibatch's largest image flips signs that fp32 would not (measured: one G block 3e-3 off on a minibatch spanning
+// 1e-3 .. 1e+3).  GEMM rows never mix images in the forward (conv_f16x2_kernel: the epilogue un-scales row by row), so the
+// per-image scale costs nothing there; the reverse sweep's cotangents keep one scale per tensor (their Grams sum over
+// samples).  Two launches: per-image max|x| (one atomic per workgroup into amax[n]), then the split.
+__global__ __launch_bounds__(256) void absmax_images_kernel(const float* __restrict__ x, int64_t per4, unsigned* __restrict__ amax) {
+  const float4* xs = reinterpret_cast<const float4*>(x) + (int64_t)blockIdx.y * per4;
+  unsigned m = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per4; i += (int64_t)gridDim.x * 256) {
+    const float4 v = xs[i];
+    m = max(max(m, __float_as_uint(v.x) & 0x7fffffffu), __float_as_uint(v.y) & 0x7fffffffu);
+    m = max(max(m, __float_as_uint(v.z) & 0x7fffffffu), __float_as_uint(v.w) & 0x7fffffffu);
+  }
+  block_max_to_word(m, amax + blockIdx.y);
+}
+__global__ __launch_bounds__(256) void split_images_f16x2_kernel(const float* __restrict__ x, int64_t per8,
+                                                                 const unsigned* __restrict__ amax, _Float16* __restrict__ ph,
+                                                                 _Float16* __restrict__ pl, int* __restrict__ sexp) {
+  const int n = blockIdx.y;
+  const int s = scale_exp_for(__uint_as_float(amax[n]));
+  if (blockIdx.x == 0 && threadIdx.x == 0) sexp[n] = s;
+  const float sc = exp2i(s);
+  const int64_t base = (int64_t)n * per8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per8; i += (int64_t)gridDim.x * 256) {
+    const float4 a = reinterpret_cast<const float4*>(x)[2 * (base + i)], b = reinterpret_cast<const float4*>(x)[2 * (base + i) + 1];
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    f16x8 h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      _Float16 hh, ll;
+      split2(v[j], sc, hh, ll);
+      h[j] = hh, l[j] = ll;
+    }
+    reinterpret_cast<f16x8*>(ph)[base + i] = h;
+    reinterpret_cast<f16x8*>(pl)[base + i] = l;
   }
 }
 
@@ -217,6 +238,7 @@ struct ConvGeom {
                             // so the taps that fall outside the image there are skipped as whole K stages
   int dense;                // the output grid is the output tensor (os = 1, Hc = Ho, Wc = Wo): output pixel = m
   int out_nchw;             // write out[n][co][pixel] (dense grids with Ho*Wo % 4 == 0 only): float4 along the pixels
+  int a_nsexp;              // entries of a_sexp: 1 (one scale for the tensor) or N (one per image: the forward's activations)
 };
 
 template <int BM_, int BN_, int BK_, int WM_, int WN_, int NBUF_ = 2, int WPE_ = 2>
@@ -601,6 +623,13 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
     if (amax_out) conv_block_max<NT / 64>(vmax, exp2i(-so < -126 ? -126 : -so), amax_out, smem);
     return;
   }
+  // A operand with one scale per image (the forward's activations, lk_split_images_f16x2 / lk_bn_act_fwd_nhwc_f16x2): GEMM
+  // rows never mix images, so the accumulators are un-scaled row by row here (the K loop does not know about it)
+  const bool per_img = g.a_nsexp > 1;
+  auto image_inv = [&](int n) {
+    const int s = a_sexp[n];
+    return exp2i(-s < -126 ? -126 : -s);
+  };
   if (g.out_nchw) {
     // position-contiguous output [n][co][pixel] (what the predictive's quadratic-form kernel reads): a lane owns one
     // channel, registers r = 4q .. 4q+3 are four consecutive pixels of it -> one 16-byte store
@@ -612,6 +641,7 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
         const int m = tile_m * BM + (wm * TM + a) * 32 + 8 * q + 4 * lh;
         if (m >= M) continue;
         const int n = fdiv(m, g.div_hw), pix = m - n * HW;
+        const float inv_an = per_img ? image_inv(n) : inv_a;  // (the four pixels of a register quad belong to one image: HW % 4 == 0)
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
           const int col = tile_n * BN + (wn * TN + b) * 32 + lr;
@@ -619,7 +649,7 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
           f32x4 v;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            v[j] = acc[a][b][4 * q + j] * inv_a * inv_w;
+            v[j] = acc[a][b][4 * q + j] * inv_an * inv_w;
             vmax = max(vmax, __float_as_uint(v[j]) & 0x7fffffffu);
           }
           *reinterpret_cast<f32x4*>(out + ((int64_t)n * g.Co + col) * HW + pix) = v;
@@ -634,19 +664,23 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
       const int m = tile_m * BM + row;
       if (m >= M) continue;
       int64_t opix = m;
+      int n = 0;
       if (g.pmajor || !g.dense) {
-        int n, rem;
+        int rem;
         if (g.pmajor) rem = fdiv(m, g.div_n), n = m - rem * g.N;
         else n = fdiv(m, g.div_hw), rem = m - n * (g.Hc * g.Wc);
         const int ci_ = fdiv(rem, g.div_w);
         opix = ((int64_t)n * g.Ho + ci_ * g.os + g.oh0) * g.Wo + (rem - ci_ * g.Wc) * g.os + g.ow0;
+      } else if (per_img) {
+        n = fdiv(m, g.div_hw);
       }
+      const float inv_an = per_img ? image_inv(n) : inv_a;  // one scale per image: un-scaled row by row
       float* orow = out + opix * g.Co;
 #pragma unroll
       for (int b = 0; b < TN; ++b) {
         const int col = tile_n * BN + (wn * TN + b) * 32 + lr;
         if (col < g.Co) {
-          float v = acc[a][b][r] * inv_a * inv_w;
+          float v = acc[a][b][r] * inv_an * inv_w;
           if (accumulate) v += orow[col];
           orow[col] = v;
           vmax = max(vmax, __float_as_uint(v) & 0x7fffffffu);
@@ -1507,13 +1541,6 @@ extern "C" int lk_copy_absmax_f32(const float* x, float* y, int64_t n, unsigned*
   return check_launch("copy_absmax4_kernel");
 }
 
-extern "C" int lk_range_words_f32(const float* x, int64_t B, int64_t per, unsigned* words, void* stream) {
-  LK_REQUIRE(x && words && B >= 0 && per >= 0 && B < (1ll << 31), "lk_range_words_f32: bad arguments");
-  if (B == 0 || per == 0) return LK_OK;
-  hipLaunchKernelGGL(range_words_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, x, per, words);
-  return check_launch("range_words_kernel");
-}
-
 extern "C" int lk_split_f16x2(const float* x, int64_t n, const float* amax, float bound_mul, void* planes_h,
                               void* planes_l, int* sexp, void* stream) {
   LK_REQUIRE(x && amax && planes_h && planes_l && sexp && n >= 0 && n % 8 == 0, "lk_split_f16x2: bad arguments (n % 8 == 0)");
@@ -1523,6 +1550,30 @@ extern "C" int lk_split_f16x2(const float* x, int64_t n, const float* amax, floa
   hipLaunchKernelGGL(split_f16x2_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n / 8, amax,
                      bound_mul, (_Float16*)planes_h, (_Float16*)planes_l, sexp);
   return check_launch("split_f16x2_kernel");
+}
+
+// x [N][per] fp32 -> planes with ONE SCALE PER IMAGE: sexp[n] from the image's own max|x|, which is also left in amax[n]
+// (bit pattern of a float; what the next producer derives its bound from).  per % 8 == 0.
+extern "C" int lk_split_images_f16x2(const float* x, int64_t N, int64_t per, void* planes_h, void* planes_l, int* sexp,
+                                     unsigned* amax, void* stream) {
+  LK_REQUIRE(x && planes_h && planes_l && sexp && amax && N >= 0 && per >= 0 && per % 8 == 0 && N < 65536,
+             "lk_split_images_f16x2: bad arguments (per % 8 == 0, N < 65536)");
+  if (N == 0) return LK_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(amax, 0, sizeof(unsigned) * (size_t)N, st);
+  if (e != hipSuccess) {
+    set_error("lk_split_images_f16x2: memset: %s", hipGetErrorString(e));
+    return LK_ELAUNCH;
+  }
+  if (per == 0) return LK_OK;
+  int64_t bx = (per / 8 + 255) / 256;
+  if (bx * N > 8192) bx = (8192 + N - 1) / N;
+  hipLaunchKernelGGL(absmax_images_kernel, dim3((unsigned)bx, (unsigned)N), dim3(256), 0, st, x, per / 4, amax);
+  int rc = check_launch("absmax_images_kernel");
+  if (rc != LK_OK) return rc;
+  hipLaunchKernelGGL(split_images_f16x2_kernel, dim3((unsigned)bx, (unsigned)N), dim3(256), 0, st, x, per / 8, amax,
+                     (_Float16*)planes_h, (_Float16*)planes_l, sexp);
+  return check_launch("split_images_f16x2_kernel");
 }
 
 extern "C" int lk_conv_prep_weights_f16x2(const float* W, int64_t Co, int64_t Ci, int64_t taps, int transpose,
@@ -1633,7 +1684,7 @@ static bool launch_winp(const ConvGeom& g, const void* Ah, const void* Al, const
 }
 
 // One launch of the implicit GEMM.  `taps`: T x {dh, dw, weight slice}.
-static int conv_dispatch(const void* in_h, const void* in_l, const int* in_sexp, int64_t N, int64_t Hi, int64_t Wi,
+static int conv_dispatch(const void* in_h, const void* in_l, const int* in_sexp, int64_t in_nsexp, int64_t N, int64_t Hi, int64_t Wi,
                          int64_t Ci, const void* w_h, const void* w_l, const int* w_sexp, int64_t Co,
                          int64_t Hc, int64_t Wc, int64_t in_mul, int64_t Ho, int64_t Wo, int64_t out_step,
                          int64_t oh0, int64_t ow0, int64_t T, const int* taps, const void* zero16, float* out,
@@ -1641,8 +1692,10 @@ static int conv_dispatch(const void* in_h, const void* in_l, const int* in_sexp,
   LK_REQUIRE(in_h && in_l && in_sexp && w_h && w_l && w_sexp && zero16 && (out || fz) && taps, "lk_conv_nhwc_f16x2: null pointer");
   LK_REQUIRE(T >= 1 && T <= 9 && Ci >= 32 && Ci % 32 == 0 && Co >= 1 && N >= 1, "lk_conv_nhwc_f16x2: Ci % 32 == 0, 1..9 taps");
   LK_REQUIRE(N * Hc * Wc < (1ll << 31) && N * Hi * Wi * Ci < (1ll << 40), "lk_conv_nhwc_f16x2: tensor too large");
+  LK_REQUIRE(in_nsexp == 1 || (in_nsexp == N && !fz), "lk_conv_nhwc_f16x2: in_nsexp is 1 or N (one scale per image: plain epilogue only)");
   if (Hc == 0 || Wc == 0) return LK_OK;
   ConvGeom g;
+  g.a_nsexp = (int)in_nsexp;
   g.N = (int)N, g.Hi = (int)Hi, g.Wi = (int)Wi, g.Ci = (int)Ci, g.Hc = (int)Hc, g.Wc = (int)Wc, g.Ho = (int)Ho,
   g.Wo = (int)Wo, g.Co = (int)Co, g.os = (int)out_step, g.oh0 = (int)oh0, g.ow0 = (int)ow0, g.im = (int)in_mul, g.T = (int)T;
   for (int t = 0; t < 9; ++t) g.dh[t] = g.dw[t] = g.wt[t] = 0;
@@ -1705,12 +1758,12 @@ extern "C" int lk_conv_winp_eligible(int64_t N, int64_t Hi, int64_t Wi, int64_t 
              : 0;
 }
 
-extern "C" int lk_conv_nhwc_f16x2(const void* in_h, const void* in_l, const int* in_sexp, int64_t N, int64_t Hi, int64_t Wi,
-                                  int64_t Ci, const void* w_h, const void* w_l, const int* w_sexp, int64_t Co,
+extern "C" int lk_conv_nhwc_f16x2(const void* in_h, const void* in_l, const int* in_sexp, int64_t in_nsexp, int64_t N, int64_t Hi,
+                                  int64_t Wi, int64_t Ci, const void* w_h, const void* w_l, const int* w_sexp, int64_t Co,
                                   int64_t Hc, int64_t Wc, int64_t in_mul, int64_t Ho, int64_t Wo, int64_t out_step,
                                   int64_t oh0, int64_t ow0, int64_t T, const int* taps, const void* zero16, float* out,
                                   int accumulate, unsigned* amax_out, int config, void* stream) {
-  return conv_dispatch(in_h, in_l, in_sexp, N, Hi, Wi, Ci, w_h, w_l, w_sexp, Co, Hc, Wc, in_mul, Ho, Wo, out_step, oh0, ow0, T,
+  return conv_dispatch(in_h, in_l, in_sexp, in_nsexp, N, Hi, Wi, Ci, w_h, w_l, w_sexp, Co, Hc, Wc, in_mul, Ho, Wo, out_step, oh0, ow0, T,
                        taps, zero16, out, accumulate, amax_out, config, stream, nullptr);
 }
 
@@ -1738,7 +1791,7 @@ static int conv_vjp_impl(const void* in_h, const void* in_l, const int* in_sexp,
   fz.scale = scale, fz.scale_amax = (const unsigned*)scale_amax;
   fz.out_h = (_Float16*)out_h, fz.out_l = (_Float16*)out_l, fz.out_sexp = out_sexp;
   fz.wc_h = (const _Float16*)wc_h, fz.wc_l = (const _Float16*)wc_l;
-  return conv_dispatch(in_h, in_l, in_sexp, N, Hi, Wi, Ci, w_h, w_l, w_sexp, Co, Ho, Wo, 1, Ho, Wo, 1, 0, 0, T, taps, zero16,
+  return conv_dispatch(in_h, in_l, in_sexp, 1, N, Hi, Wi, Ci, w_h, w_l, w_sexp, Co, Ho, Wo, 1, Ho, Wo, 1, 0, 0, T, taps, zero16,
                        nullptr, 0, (unsigned*)out_amax, config & ~16, stream, &fz);
 }
 

@@ -104,65 +104,91 @@ __global__ __launch_bounds__(256) void vjp_nhwc_split_kernel(
 }
 
 // ---- forward of the NHWC sweep: eval-mode BatchNorm (per-channel affine map) + residual add + activation, one pass ------
-//   y[e] = act(x[e] * scale[e % C] + shift[e % C] + addend[e])          e < per = B*H*W*C     act: 0 none, 1 ReLU, 2 tanh
-// x: fp32 NHWC, the forward convolution kernel's output, with max|x| in a device word.  Emits what the rest of the step
-// needs in ONE pass: y in fp32 (A-factor kernels, later residual joins), the ReLU mask as NHWC bytes (the reverse sweep
-// reads it as is), the split planes of y (next convolution) scaled from the guaranteed bound
-//   max|y| <= max|x| max|scale| + max|shift| + bound(addend)      (tanh: 1)
-// and that bound itself as a device word (it is the `bound(addend)` of a later join).
+//   y[e] = act(x[e] * scale[e % C] + shift[e % C] + addend[e])          e < N * per     act: 0 none, 1 ReLU, 2 tanh
+// x: fp32 NHWC [N][per], the forward convolution kernel's output.  Emits what the rest of the step needs in ONE pass: y in
+// fp32 (A-factor kernels, later residual joins), the ReLU mask as NHWC bytes (the reverse sweep reads it as is), and the
+// split planes of y (next convolution) with ONE SCALE PER IMAGE (see lk_split_images_f16x2), image n scaled from the
+// guaranteed bound
+//   max|y_n| <= bx_n max|scale| + max|shift| + bound(addend_n),     bx_n = x_amax[n] * x_mul + x_add  >= max|x_n|
+// (x_amax: measured max of the convolution's INPUT image, x_mul: l1 norm of its weights, x_add: max|bias| — a bound of
+// the convolution's output that needs no pass over it; tanh: 1).  The bound is loose by the l1 slack of ONE layer
+// (2^7 - 2^8 for random weights), which only costs fixed-point range; it does not compound, because the kernel also
+// MEASURES max|y_n| (y_amax[n], one atomic per workgroup; zeroed by the caller) and that is what the next layer starts from.
+// Grid: (chunks of an image, N) — a workgroup never straddles two images.
 __global__ __launch_bounds__(256) void bn_act_fwd_nhwc_kernel(
-    const float* __restrict__ x, const unsigned* __restrict__ x_amax, const float* __restrict__ scale,
-    const float* __restrict__ shift, const unsigned* __restrict__ scale_amax, const unsigned* __restrict__ shift_amax,
-    const float* __restrict__ addend, const float* __restrict__ addend_bound, int act, int C, int64_t per8,
-    float* __restrict__ y, unsigned char* __restrict__ mask, _Float16* __restrict__ yh, _Float16* __restrict__ yl,
-    int* __restrict__ y_sexp, float* __restrict__ y_bound) {
-  float bound = __uint_as_float(x_amax[0]) * __uint_as_float(scale_amax[0]) + __uint_as_float(shift_amax[0]);
-  if (addend) bound += addend_bound[0];
+    const float* __restrict__ x, const unsigned* __restrict__ x_amax, int x_namax, const float* __restrict__ x_mul,
+    const float* __restrict__ x_add, const float* __restrict__ scale, const float* __restrict__ shift,
+    const unsigned* __restrict__ scale_amax, const unsigned* __restrict__ shift_amax, const float* __restrict__ addend,
+    const float* __restrict__ addend_bound, int addend_nbound, int act, int C, int64_t per8, float* __restrict__ y,
+    unsigned char* __restrict__ mask, _Float16* __restrict__ yh, _Float16* __restrict__ yl, int* __restrict__ y_sexp,
+    float* __restrict__ y_bound, unsigned* __restrict__ y_amax) {
+  const int n = blockIdx.y;
+  float bx = __uint_as_float(x_amax[n < x_namax ? n : x_namax - 1]);
+  if (x_mul) bx *= x_mul[0];
+  if (x_add) bx += x_add[0];
+  float bound = bx * __uint_as_float(scale_amax[0]) + __uint_as_float(shift_amax[0]);
+  if (addend) bound += addend_bound[n < addend_nbound ? n : addend_nbound - 1];
   if (act == 2) bound = 1.f;
   const int so = scale_exp_for16(bound);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    y_sexp[0] = so;
-    y_bound[0] = bound;
+    y_sexp[n] = so;
+    y_bound[n] = bound;
   }
   const float sc_out = exp2i16(so);
-  const int64_t e8 = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e8 >= per8) return;
-  const int c0 = (int)((e8 * 8) % C);
-  const float4 s0 = *reinterpret_cast<const float4*>(scale + c0), s1 = *reinterpret_cast<const float4*>(scale + c0 + 4);
-  const float4 t0 = *reinterpret_cast<const float4*>(shift + c0), t1 = *reinterpret_cast<const float4*>(shift + c0 + 4);
-  const float4 a = reinterpret_cast<const float4*>(x)[2 * e8], b = reinterpret_cast<const float4*>(x)[2 * e8 + 1];
-  float v[8] = {a.x * s0.x + t0.x, a.y * s0.y + t0.y, a.z * s0.z + t0.z, a.w * s0.w + t0.w,
-                b.x * s1.x + t1.x, b.y * s1.y + t1.y, b.z * s1.z + t1.z, b.w * s1.w + t1.w};
-  if (addend) {
-    const float4 p = reinterpret_cast<const float4*>(addend)[2 * e8], q = reinterpret_cast<const float4*>(addend)[2 * e8 + 1];
-    v[0] += p.x, v[1] += p.y, v[2] += p.z, v[3] += p.w, v[4] += q.x, v[5] += q.y, v[6] += q.z, v[7] += q.w;
-  }
-  if (act == 1) {
-    unsigned m0 = 0, m1 = 0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      v[j] = fmaxf(v[j], 0.f);
-      if (v[j] > 0.f) (j < 4 ? m0 : m1) |= 1u << (8 * (j & 3));
+  const int64_t i8 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  unsigned vmax = 0;
+  if (i8 < per8) {
+    const int64_t e8 = (int64_t)n * per8 + i8;
+    const int c0 = (int)((i8 * 8) % C);  // (per % C == 0: an image starts at channel 0)
+    const float4 s0 = *reinterpret_cast<const float4*>(scale + c0), s1 = *reinterpret_cast<const float4*>(scale + c0 + 4);
+    const float4 t0 = *reinterpret_cast<const float4*>(shift + c0), t1 = *reinterpret_cast<const float4*>(shift + c0 + 4);
+    const float4 a = reinterpret_cast<const float4*>(x)[2 * e8], b = reinterpret_cast<const float4*>(x)[2 * e8 + 1];
+    float v[8] = {a.x * s0.x + t0.x, a.y * s0.y + t0.y, a.z * s0.z + t0.z, a.w * s0.w + t0.w,
+                  b.x * s1.x + t1.x, b.y * s1.y + t1.y, b.z * s1.z + t1.z, b.w * s1.w + t1.w};
+    if (addend) {
+      const float4 p = reinterpret_cast<const float4*>(addend)[2 * e8], q = reinterpret_cast<const float4*>(addend)[2 * e8 + 1];
+      v[0] += p.x, v[1] += p.y, v[2] += p.z, v[3] += p.w, v[4] += q.x, v[5] += q.y, v[6] += q.z, v[7] += q.w;
     }
-    if (mask) reinterpret_cast<uint2*>(mask)[e8] = make_uint2(m0, m1);
-  } else if (act == 2) {
+    if (act == 1) {
+      unsigned m0 = 0, m1 = 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = tanhf(v[j]);
-  }
-  reinterpret_cast<float4*>(y)[2 * e8] = make_float4(v[0], v[1], v[2], v[3]);
-  reinterpret_cast<float4*>(y)[2 * e8 + 1] = make_float4(v[4], v[5], v[6], v[7]);
-  if (yh) {
-    f16x8 h, l;
+      for (int j = 0; j < 8; ++j) {
+        v[j] = fmaxf(v[j], 0.f);
+        if (v[j] > 0.f) (j < 4 ? m0 : m1) |= 1u << (8 * (j & 3));
+      }
+      if (mask) reinterpret_cast<uint2*>(mask)[e8] = make_uint2(m0, m1);
+    } else if (act == 2) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float xs = v[j] * sc_out;
-      asm volatile("" : "+v"(xs));  // see vjp_nhwc_split_kernel: split an opaque value
-      const _Float16 hh = (_Float16)xs;
-      h[j] = hh;
-      l[j] = (_Float16)(xs - (float)hh);
+      for (int j = 0; j < 8; ++j) v[j] = tanhf(v[j]);
     }
-    reinterpret_cast<f16x8*>(yh)[e8] = h;
-    reinterpret_cast<f16x8*>(yl)[e8] = l;
+    reinterpret_cast<float4*>(y)[2 * e8] = make_float4(v[0], v[1], v[2], v[3]);
+    reinterpret_cast<float4*>(y)[2 * e8 + 1] = make_float4(v[4], v[5], v[6], v[7]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) vmax = max(vmax, __float_as_uint(v[j]) & 0x7fffffffu);
+    if (yh) {
+      f16x8 h, l;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float xs = v[j] * sc_out;
+        asm volatile("" : "+v"(xs));  // see vjp_nhwc_split_kernel: split an opaque value
+        const _Float16 hh = (_Float16)xs;
+        h[j] = hh;
+        l[j] = (_Float16)(xs - (float)hh);
+      }
+      reinterpret_cast<f16x8*>(yh)[e8] = h;
+      reinterpret_cast<f16x8*>(yl)[e8] = l;
+    }
+  }
+  if (y_amax) {  // (uniform) measured max|y_n|: the waves' maxima meet in LDS, one atomic per workgroup
+    __shared__ unsigned wave_max[4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) vmax = max(vmax, (unsigned)__shfl_xor((int)vmax, off, 64));
+    if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = vmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      vmax = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
+      if (vmax) atomicMax(y_amax + n, vmax);
+    }
   }
 }
 
@@ -554,21 +580,27 @@ extern "C" int lk_vjp_nhwc_split_f16x2(const float* g, const unsigned* g_amax, c
   return check_launch("vjp_nhwc_split_kernel");
 }
 
-extern "C" int lk_bn_act_fwd_nhwc_f16x2(const float* x, const unsigned* x_amax, const float* scale, const float* shift,
+extern "C" int lk_bn_act_fwd_nhwc_f16x2(const float* x, const unsigned* x_amax, int64_t x_namax, const float* x_mul,
+                                       const float* x_add, const float* scale, const float* shift,
                                        const unsigned* scale_amax, const unsigned* shift_amax, const float* addend,
-                                       const float* addend_bound, int act, int64_t C, int64_t per, float* y, void* mask,
-                                       void* y_h, void* y_l, int* y_sexp, float* y_bound, void* stream) {
-  LK_REQUIRE(x && x_amax && scale && shift && scale_amax && shift_amax && y && y_sexp && y_bound && per >= 0,
+                                       const float* addend_bound, int64_t addend_nbound, int act, int64_t C, int64_t N,
+                                       int64_t per, float* y, void* mask, void* y_h, void* y_l, int* y_sexp, float* y_bound,
+                                       unsigned* y_amax, void* stream) {
+  LK_REQUIRE(x && x_amax && scale && shift && scale_amax && shift_amax && y && y_sexp && y_bound && per >= 0 && N >= 0,
              "lk_bn_act_fwd_nhwc_f16x2: null pointer");
   LK_REQUIRE(C >= 8 && C % 8 == 0 && per % C == 0 && act >= 0 && act <= 2, "lk_bn_act_fwd_nhwc_f16x2: C % 8 == 0, act in 0..2");
-  LK_REQUIRE(!addend || addend_bound, "lk_bn_act_fwd_nhwc_f16x2: the addend needs its bound word");
+  LK_REQUIRE(x_namax == 1 || x_namax == N, "lk_bn_act_fwd_nhwc_f16x2: x_amax has 1 or N words");
+  LK_REQUIRE(!addend || (addend_bound && (addend_nbound == 1 || addend_nbound == N)),
+             "lk_bn_act_fwd_nhwc_f16x2: the addend needs its bound (1 or N words)");
   LK_REQUIRE((y_h == nullptr) == (y_l == nullptr), "lk_bn_act_fwd_nhwc_f16x2: both planes or none");
-  if (per == 0) return LK_OK;
+  LK_REQUIRE(N <= 65535, "lk_bn_act_fwd_nhwc_f16x2: at most 65535 images");
+  if (per == 0 || N == 0) return LK_OK;
   const int64_t per8 = per / 8, nb = (per8 + 255) / 256;
   LK_REQUIRE(nb < (1ll << 31), "lk_bn_act_fwd_nhwc_f16x2: grid too large");
-  hipLaunchKernelGGL(bn_act_fwd_nhwc_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, x_amax, scale, shift,
-                     scale_amax, shift_amax, addend, addend_bound, act, (int)C, per8, y, (unsigned char*)mask,
-                     (_Float16*)y_h, (_Float16*)y_l, y_sexp, y_bound);
+  hipLaunchKernelGGL(bn_act_fwd_nhwc_kernel, dim3((unsigned)nb, (unsigned)N), dim3(256), 0, (hipStream_t)stream, x, x_amax,
+                     (int)x_namax, x_mul, x_add, scale, shift, scale_amax, shift_amax, addend, addend_bound,
+                     (int)(addend ? addend_nbound : 1), act, (int)C, per8, y, (unsigned char*)mask, (_Float16*)y_h,
+                     (_Float16*)y_l, y_sexp, y_bound, y_amax);
   return check_launch("bn_act_fwd_nhwc_kernel");
 }
 

@@ -129,21 +129,12 @@ def allreduce_curvature(tensors: list[torch.Tensor], group=None, mirror: bool = 
     lower triangles afterwards (callers that symmetrise later anyway pass ``False``).  Returns what was exchanged
     (``{"bytes": .., "tensors": .., "packed": ..}``; ``None`` without a process group) so that a launch script can assert
     the message size it expects (ResNet-18: 188 MB of packed upper triangles)."""
-    owner = getattr(tensors, "owner", None)  # (a KronAccumulator's exchange: carries its range verdict)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        if owner is not None:
-            owner._check_range()
         return None
     from laplace_amd._lib import get_kernels
 
     K = get_kernels()
     tensors = list(tensors)
-    if owner is not None:
-        # one flag word travels with the factors: a rank whose shard held a minibatch outside the range the split-fp16 sweep
-        # resolves must not raise BEFORE the collective (the others would wait in it until the timeout) — everybody raises
-        # after it
-        flag = torch.full((1,), 1.0 if owner._range_msg else 0.0, dtype=tensors[0].dtype, device=tensors[0].device)
-        tensors.append(flag)
     sym = [t.dim() == 2 and t.shape[0] == t.shape[1] and t.shape[0] > 1 and t.dtype == torch.float32 and t.is_contiguous()
            for t in tensors]
     sizes = [t.shape[0] * (t.shape[0] + 1) // 2 if s_ else t.numel() for t, s_ in zip(tensors, sym)]
@@ -165,12 +156,6 @@ def allreduce_curvature(tensors: list[torch.Tensor], group=None, mirror: bool = 
         else:
             t.copy_(flat[off:off + n].view_as(t))
         off += n
-    if owner is not None:
-        bad_ranks = float(tensors.pop().item())
-        msg, owner._range_msg = owner._range_msg, None
-        if bad_ranks > 0:
-            raise RuntimeError(msg or f"{int(bad_ranks)} other rank(s) of this data-parallel fit saw a minibatch whose samples "
-                                      "differ by more than the split-fp16 sweep resolves per sample (see `backend.range_guard`)")
     return {"bytes": int(flat.numel() * flat.element_size()), "tensors": len(tensors), "packed": int(sum(sym))}
 
 
@@ -187,7 +172,7 @@ def expected_exchange_bytes(model_or_shapes) -> int:
                 sizes += [m.out_channels, m.in_channels * m.kernel_size[0] * m.kernel_size[1]]
     else:
         sizes = list(model_or_shapes)
-    return 4 * (sum(n * (n + 1) // 2 if n > 1 else 1 for n in sizes) + 2)  # + the loss word + the range-verdict flag
+    return 4 * (sum(n * (n + 1) // 2 if n > 1 else 1 for n in sizes) + 1)  # + the loss word
 
 
 def _share_n_outputs(la, group=None) -> None:

@@ -26,7 +26,6 @@ from __future__ import annotations
 import torch
 
 from laplace_amd._lib import get_kernels
-from laplace_amd.backend import range_groups as _range_groups
 from laplace_amd.backend import shared_operands as _shared_operands
 
 
@@ -43,20 +42,14 @@ def _grads(grad_fn, seeds):
     return grad_fn(seeds)  # autograd-tape / last-layer grad_fn
 
 
-def _by_range_groups(fn, backend, x, *args):
-    """run a per-sample predictive over magnitude groups of the minibatch and put the rows back in order"""
-    state = backend._split_sweep_state() if hasattr(backend, "_split_sweep_state") else None
-    groups = _range_groups(x) if getattr(backend, "range_guard", "check") not in (False, "off") and state is not False else None
-    if groups is None:
-        return None
-    f = fvar = None
-    for idx in groups:
-        f_g, v_g = fn(backend, x.index_select(0, idx).contiguous(), *args, _grouped=True)
-        if f is None:
-            f = f_g.new_empty(x.shape[0], *f_g.shape[1:])
-            fvar = v_g.new_empty(x.shape[0], *v_g.shape[1:])
-        f[idx], fvar[idx] = f_g, v_g
-    return f, fvar
+def _fp32_only(backend):
+    """The fused predictives run the fp32 kernels on the caller's own posterior tensors.  A model in another floating
+    dtype (served by an fp32 twin elsewhere, backend._twin) takes the reference's route instead — Jacobians from
+    ``backend.jacobians`` (which does use the twin) through the posterior in the model's dtype: NotImplementedError is
+    what the callers (laplace_amd/laplace.py, dropin.py) fall back on."""
+    twin = backend._twin()[0] if hasattr(backend, "_twin") else None
+    if twin is not None:
+        raise NotImplementedError("fused predictive computes in float32; this model is not float32")
 
 
 def _as_nchw(g, B, C):
@@ -116,13 +109,10 @@ def _shared_quadform(K, call, u, v, fvar, weight_sharing_only: bool):
     return True
 
 
-def glm_variance_kron(backend, x, post, _grouped: bool = False):
+def glm_variance_kron(backend, x, post):
     """``(f_mu, f_var)`` under a :class:`HipKronDecomposed` posterior precision ``post``
     (= ``H * H_factor + prior_precision``), i.e. KronLaplace.functional_variance."""
-    if not _grouped:
-        out = _by_range_groups(glm_variance_kron, backend, x, post)
-        if out is not None:
-            return out
+    _fp32_only(backend)
     K = get_kernels()
     f, tape, grad_fn = backend._forward(x, keep_tap_splits=True)  # the eigenbasis rotations re-use the split inputs
     if tape.uncovered:
@@ -189,12 +179,9 @@ def glm_variance_kron(backend, x, post, _grouped: bool = False):
     return f, fvar
 
 
-def glm_variance_diag(backend, x, post_var: torch.Tensor, _grouped: bool = False):
+def glm_variance_diag(backend, x, post_var: torch.Tensor):
     """``(f_mu, f_var)`` under a diagonal posterior with variances ``post_var[P]``."""
-    if not _grouped:
-        out = _by_range_groups(glm_variance_diag, backend, x, post_var)
-        if out is not None:
-            return out
+    _fp32_only(backend)
     K = get_kernels()
     f, tape, grad_fn = backend._forward(x)
     if tape.uncovered:
@@ -228,6 +215,7 @@ def glm_variance_diag(backend, x, post_var: torch.Tensor, _grouped: bool = False
 
 def glm_variance_full_last_layer(backend, x, Sigma: torch.Tensor):
     """``(f_mu, f_var)`` for a last-layer Laplace with dense posterior covariance ``Sigma[P, P]``."""
+    _fp32_only(backend)
     K = get_kernels()
     if not backend.last_layer:
         raise NotImplementedError("dense fused predictive is implemented for last-layer Laplace")

@@ -222,7 +222,9 @@ class SplitSweep(SeedBatchedSweep):
         ``release()`` — only the Kron predictive's eigenbasis rotation reads it; a fit would hold a second
         activation-sized copy through the whole reverse sweep for nothing."""
         self._keep_tap_splits = keep_tap_splits
-        self._aux = {}  # data_ptr of a feature map produced here -> {"amax": word} / {"split": SplitTensor, "bound": word}
+        # data_ptr of a feature map produced here -> {"in_amax": [B] words, "mul": word, "add": word | None} (a convolution's
+        # output: a per-image bound without a pass over it) / {"split": SplitTensor, "bound": [B] words} (an activation)
+        self._aux = {}
         self.tap_splits = {}  # tap name -> NHWC SplitTensor of the tap's input (what its forward convolution consumed)
         self._fwd_words = None
         try:
@@ -230,12 +232,12 @@ class SplitSweep(SeedBatchedSweep):
         finally:
             self._aux = {}  # (the split copies of the activations are only needed while the forward runs)
 
-    def _fwd_word(self, dev):
-        """a zeroed device word out of a per-forward pool (one fill launch per 64 words)"""
-        if self._fwd_words is None or self._fwd_words[1] == self._fwd_words[0].numel():
-            self._fwd_words = [torch.zeros(64, dtype=torch.float32, device=dev), 0]
-        w = self._fwd_words[0][self._fwd_words[1]:self._fwd_words[1] + 1]
-        self._fwd_words[1] += 1
+    def _fwd_word(self, dev, n=1):
+        """``n`` zeroed device words out of a per-forward pool (one fill launch per pool)"""
+        if self._fwd_words is None or self._fwd_words[1] + n > self._fwd_words[0].numel():
+            self._fwd_words = [torch.zeros(max(64, 32 * n), dtype=torch.float32, device=dev), 0]
+        w = self._fwd_words[0][self._fwd_words[1]:self._fwd_words[1] + n]
+        self._fwd_words[1] += n
         return w
 
     def _use_nhwc_forward(self, t) -> bool:
@@ -252,7 +254,7 @@ class SplitSweep(SeedBatchedSweep):
             xp = xh.new_zeros(*xh.shape[:3], pad_to)
             xp[..., :xh.shape[-1]] = xh
             xh = xp
-        return K.split_f16x2(xh)
+        return K.split_images_f16x2(xh)  # one scale per image (lk_split_images_f16x2)
 
     def _run_conv(self, node, m, inp):
         if not (self._use_nhwc_forward(inp) and cv.forward_supported(m)):
@@ -265,13 +267,14 @@ class SplitSweep(SeedBatchedSweep):
             # consumers of the tap's input that run our convolution on it again (the Kron predictive's eigenbasis
             # rotation) take the split copy instead of measuring and splitting the activation a second time
             self.tap_splits[node.target] = xs
-        w = self._fwd_word(inp.device)
-        out = cv.conv_forward(prep, xs, amax_out=w)
+        out = cv.conv_forward(prep, xs)
         if m.bias is not None:
             out += m.bias
-            w = self.kernels().absmax(out)
         y = out.permute(0, 3, 1, 2)  # logical [B, C, H, W] over NHWC memory
-        self._aux[y.data_ptr()] = {"amax": w}
+        if xs.amax is not None:
+            # per-image bound of the output without a pass over it: measured max of the input image * l1(W) + max|bias|
+            l1, bmax = prep.forward_l1()
+            self._aux[y.data_ptr()] = {"in_amax": xs.amax, "mul": l1, "add": bmax}
         return y
 
     def _run_bn_act(self, node, inp, scale, shift, relu, addend, want_mask):
@@ -281,7 +284,11 @@ class SplitSweep(SeedBatchedSweep):
             return super()._run_bn_act(node, inp, scale, shift, relu, addend, want_mask)
         aux = self._aux.get(inp.data_ptr())
         xh = inp.permute(0, 2, 3, 1)
-        x_amax = aux["amax"] if aux is not None and "amax" in aux else K.absmax(xh)
+        x_mul = x_add = None
+        if aux is not None and "in_amax" in aux:
+            x_amax, x_mul, x_add = aux["in_amax"], aux["mul"], aux["add"]
+        else:
+            x_amax = K.absmax(xh)  # (one bound for every image: coarser scales, still guaranteed)
         a_h = a_bound = None
         if addend is not None:
             a_h = addend.permute(0, 2, 3, 1)
@@ -291,9 +298,11 @@ class SplitSweep(SeedBatchedSweep):
         shift = shift.to(torch.float32).contiguous()
         y, mask, split, bound = K.bn_act_forward_nhwc(xh, x_amax, scale, shift, self._amax_of((node.target, "s"), scale),
                                                       self._amax_of((node.target, "t"), shift), 1 if relu else 0,
-                                                      addend=a_h, addend_bound=a_bound, want_mask=want_mask)
+                                                      addend=a_h, addend_bound=a_bound, want_mask=want_mask, x_mul=x_mul,
+                                                      x_add=x_add, amax_words=self._fwd_word(inp.device, inp.shape[0]))
         out = y.permute(0, 3, 1, 2)
-        self._aux[out.data_ptr()] = {"split": split, "bound": bound}
+        # (the MEASURED per-image maxima are the bound a later residual join adds: tighter than the guaranteed one)
+        self._aux[out.data_ptr()] = {"split": split, "bound": split.amax if split is not None else bound}
         if mask is not None:
             mask = mask.view(torch.bool).permute(0, 3, 1, 2)  # logical NCHW view of the NHWC mask bytes
         return out, mask

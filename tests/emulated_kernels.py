@@ -77,14 +77,17 @@ class EmulatedKernels:
         amax.copy_(torch.maximum(amax, x.abs().max().reshape(1).float()))
         return out
 
-    def range_words(self, x, words):
-        a = x.detach().abs().reshape(x.shape[0], -1).amax(1).float()
-        a = a[a > 0]
-        if a.numel():
-            cur = words.view(torch.float32)
-            cur[0] = torch.maximum(cur[0], a.max())
-            cur[1] = torch.minimum(cur[1], a.min())
-        return words
+    def split_images_f16x2(self, x):
+        """lk_split_images_f16x2: one scale per image of the leading dimension, from the image's own max|x_n| (-> amax [N])"""
+        from laplace_amd._lib import SplitTensor
+
+        N = x.shape[0]
+        am = x.detach().abs().reshape(N, -1).amax(1).float() if x.numel() else torch.zeros(N)
+        s = torch.tensor([self._sexp_for(a) for a in am.tolist()], dtype=torch.int32)
+        xs = x.float() * torch.exp2(s.float()).reshape(N, *([1] * (x.dim() - 1)))
+        h = xs.half()
+        l = (xs - h.float()).half()
+        return SplitTensor(torch.stack([h, l]), s, am)
 
     def split_f16x2(self, x, amax=None, bound_mul=1.0, out=None):
         if amax is None:
@@ -137,8 +140,8 @@ class EmulatedKernels:
 
     def conv_winp_eligible(self, N, Hi, Wi, Ci, Co, T, mask_is_float=False) -> bool:
         # (mirrors lk_conv_winp_eligible, so that the host logic around the chunk-major weights is exercised on the CPU)
-        return bool(T == 9 and Wi <= 47 and Hi * Wi >= 64 and Ci % 32 == 0 and Ci >= 32 and Co >= 64 and Co % 64 == 0 and N * Hi * Wi >= 512
-                    and not mask_is_float)
+        return bool(T == 9 and Wi <= 47 and Hi * Wi >= 16 and Ci % 32 == 0 and Ci >= 32 and Co >= 64 and Co % 64 == 0
+                    and N * Hi * Wi * Ci < (1 << 30) and N * Hi * Wi * Co < (1 << 31) and N * Hi * Wi >= 512 and not mask_is_float)
 
     def conv_nhwc_f16x2_vjp(self, x, wplanes, wsexp, w_l1, Ho, Wo, taps, add=None, mult=None, mult_amax=None, scale=None,
                             scale_amax=None, config=None, amax_word=None, wplanes_chunked=None):
@@ -149,6 +152,9 @@ class EmulatedKernels:
         guaranteed bound max|in| * l1(W) (+ ...); the measured max|.| rides along as ``amax``"""
         N = x.shape[0]
         Co = wplanes.shape[2]
+        from laplace_amd._lib import _one_scale
+
+        _one_scale(x, "conv_nhwc_f16x2_vjp"), _one_scale(add, "conv_nhwc_f16x2_vjp")  # (as the library's wrapper)
         conv = self.conv_nhwc_f16x2(x, wplanes, wsexp, Ho, Wo, 1, torch.zeros(N, Ho, Wo, Co), 1, 0, 0, taps)
         in_amax = float(x.amax[0]) if getattr(x, "amax", None) is not None else 2.0 ** (15 - int(x.sexp[0]))
         bound = in_amax * float(w_l1[0])
@@ -175,6 +181,12 @@ class EmulatedKernels:
                                     scale_amax=None, amax_word=None):
         """lk_conv_nhwc_f16x2_vjp_strided: every residue class of one or two strided convolutions' backward-data, then the
         fused epilogue with the scale of the guaranteed bound sum_i max|in_i| * l1(W_i) (+ ...)"""
+        from laplace_amd._lib import LaplaceHipError
+
+        x0, w0 = sources[0][0], sources[0][1]
+        if len(sources) not in (1, 2) or any(tuple(s_[0].planes.shape) != tuple(x0.planes.shape) or s_[1].shape[2:] != w0.shape[2:]
+                                             for s_ in sources):  # (as the library's wrapper: _lib.conv_nhwc_f16x2_vjp_strided)
+            raise LaplaceHipError("conv_nhwc_f16x2_vjp_strided: one or two sources of the same shapes")
         N = sources[0][0].shape[0]
         Co = sources[0][1].shape[2]
         assert Ho % os == 0 and Wo % os == 0 and {(t[4], t[5]) for t in taps} == {(a, b) for a in range(os) for b in range(os)}
@@ -182,6 +194,7 @@ class EmulatedKernels:
         bound = 0.0
         for i, (x, wplanes, wsexp, w_l1) in enumerate(sources):
             assert tuple(x.shape[1:3]) == (Ho // os, Wo // os)
+            __import__("laplace_amd._lib", fromlist=["_one_scale"])._one_scale(x, "conv_nhwc_f16x2_vjp_strided")
             for oh0 in range(os):
                 for ow0 in range(os):
                     ts = [(t[0], t[1], t[2]) for t in taps if t[3] == i and (t[4], t[5]) == (oh0, ow0)]
@@ -214,6 +227,7 @@ class EmulatedKernels:
             v = v + g
             bound += float(g_amax[0])
         if g2 is not None:
+            __import__("laplace_amd._lib", fromlist=["_one_scale"])._one_scale(g2, "vjp_nhwc_split")
             v = v + g2.float()
             bound += 2.0 ** (15 - int(g2.sexp[0]))
         if mult is not None:
@@ -230,27 +244,49 @@ class EmulatedKernels:
     is_channels_last = staticmethod(lambda x: __import__("laplace_amd._lib", fromlist=["x"]).is_channels_last(x))
 
     def bn_act_forward_nhwc(self, x, x_amax, scale, shift, scale_amax, shift_amax, act, addend=None, addend_bound=None,
-                            want_mask=True, want_split=True):
-        bound = float(x_amax[0]) * float(scale_amax[0]) + float(shift_amax[0])
+                            want_mask=True, want_split=True, x_mul=None, x_add=None, amax_words=None):
+        """lk_bn_act_fwd_nhwc_f16x2: planes with one scale per image from the guaranteed per-image bound, measured maxima"""
+        from laplace_amd._lib import SplitTensor
+
+        B = x.shape[0]
+        assert x_amax.numel() in (1, B) and (addend is None or addend_bound.numel() in (1, B))
+        bx = x_amax.float().reshape(-1).expand(B).clone()
+        if x_mul is not None:
+            bx = bx * float(x_mul[0])
+        if x_add is not None:
+            bx = bx + float(x_add[0])
+        assert bool((x.abs().reshape(B, -1).amax(1) <= bx * (1 + 1e-5) + 1e-30).all()), "the bound of the forward's input does not hold"
+        bound = bx * float(scale_amax[0]) + float(shift_amax[0])
         y = x * scale + shift
         if addend is not None:
             y = y + addend
-            bound += float(addend_bound[0])
+            bound = bound + addend_bound.float().reshape(-1).expand(B)
         mask = None
         if act == 1:
             y = y.clamp_min(0)
             mask = (y > 0).to(torch.uint8) if want_mask else None
         elif act == 2:
-            y, bound = torch.tanh(y), 1.0
-        assert float(y.abs().max()) <= bound * (1 + 1e-6) + 1e-30, "the guaranteed bound of the forward does not hold"
-        split = self._split(y, self._sexp_for(bound)) if want_split else None
-        return y.contiguous(), mask, split, torch.tensor([bound], dtype=torch.float32)
+            y, bound = torch.tanh(y), torch.ones(B)
+        amax = y.abs().reshape(B, -1).amax(1).float()
+        assert bool((amax <= bound * (1 + 1e-6) + 1e-30).all()), "the guaranteed bound of the forward does not hold"
+        split = None
+        if want_split:
+            s = torch.tensor([self._sexp_for(a) for a in bound.tolist()], dtype=torch.int32)
+            ys = y.float() * torch.exp2(s.float()).reshape(B, 1, 1, 1)
+            h = ys.half()
+            l = (ys - h.float()).half()
+            if amax_words is not None:
+                amax_words.copy_(torch.maximum(amax_words, amax))
+                amax = amax_words
+            split = SplitTensor(torch.stack([h, l]), s, amax)
+        return y.contiguous(), mask, split, bound.float()
 
     def unsplit_transpose(self, x, S, B):
         N, H, W, C = x.shape
         return x.float().reshape(S, B, H * W, C).permute(1, 0, 3, 2).contiguous()
 
     def gram_tn_f16x2(self, x, alpha, out):
+        __import__("laplace_amd._lib", fromlist=["_one_scale"])._one_scale(x, "gram_tn_f16x2")
         C = x.planes.shape[-1]
         X = x.float().reshape(-1, C)
         Gm = X.T @ X

@@ -6,8 +6,10 @@ import os
 PARITY = {}  # test id -> [comparisons, worst relative error]
 
 
-def record_error(value: float) -> float:
-    tid = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
+def record_error(value: float, tag: str | None = None) -> float:
+    """``tag``: a separate log entry of the same test (e.g. what the fp32 CPU oracle itself measures against fp64, kept
+    apart from the kernels' own error)"""
+    tid = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0] + (f" <{tag}>" if tag else "")
     ent = PARITY.setdefault(tid, [0, 0.0])
     ent[0] += 1
     if value == value:

@@ -179,7 +179,7 @@ def test_sharded_loader_refuses_a_shuffle_that_the_ranks_cannot_reproduce():
 
 def test_expected_exchange_bytes_of_resnet18():
     """what bench.py asserts on a multi-GPU run: the fit's one all-reduce moves the packed upper triangles of the 42 dense
-    factors + the loss word + the range-verdict flag — 188 MB for ResNet-18 (376 MB as squares)"""
+    factors + the loss word — 188 MB for ResNet-18 (376 MB as squares)"""
     from laplace_amd.laplace import expected_exchange_bytes
     from laplace_amd.nets import ResNet18
 
@@ -191,7 +191,7 @@ def test_expected_exchange_bytes_of_resnet18():
             sizes += [mod.out_channels, mod.in_channels * 9 if mod.kernel_size[0] == 3 else mod.in_channels]
         elif isinstance(mod, torch.nn.Linear):
             sizes += [mod.out_features, mod.in_features]
-    assert len(sizes) == 42 and want == 4 * (sum(n * (n + 1) // 2 for n in sizes) + 2)
+    assert len(sizes) == 42 and want == 4 * (sum(n * (n + 1) // 2 for n in sizes) + 1)
     assert 187e6 < want < 189e6
 
 
@@ -207,31 +207,45 @@ def _range_worker(rank, world, port, out_path):
         _lib.set_kernels_for_testing(EmulatedKernels())
         from tests.test_sweep_nhwc import _model
 
-        model = _model(torch.relu)  # (a model the split-fp16 sweep serves: the guard concerns that path only)
-        torch.manual_seed(11)
+        model = _model(torch.relu)  # (a model the split-fp16 sweep serves)
+        torch.manual_seed(11 + rank)
         X, y = torch.randn(6, 3, 8, 8), torch.randint(5, (6,))
-        if rank == 1:  # only THIS rank's shard holds a minibatch outside the range
+        if rank == 1:  # only THIS rank's shard holds a minibatch that spans eight decades
             X = X.clone()
             X[0] *= 1e-4
             X[1] *= 1e4
         acc = HipGGN(model, "classification").kron_accumulator(20)
         acc.add_batch(X, y)
         try:
-            allreduce_curvature(acc.tensors(), mirror=False)  # must not raise BEFORE the collective on rank 1 alone
+            allreduce_curvature(acc.tensors(), mirror=False)
             verdict = "no error"
         except RuntimeError as e:
             verdict = str(e)
-        dist.barrier()  # (a rank that raised early would have left the others hanging in the all-reduce)
-        torch.save(verdict, f"{out_path}.{rank}")
+        dist.barrier()
+        _, kron = acc.finalize()
+        torch.save((verdict, X, y, [[M.clone() for M in F] for F in kron.kfacs]), f"{out_path}.{rank}")
     finally:
         dist.destroy_process_group()
 
 
-def test_range_verdict_of_one_rank_is_raised_on_every_rank_after_the_collective(tmp_path):
-    """ADVICE (round 3): the range check was rank-local and ran right BEFORE the all-reduce — a rank whose shard held a
-    wide-range minibatch raised while the others entered the collective and hung until its timeout."""
+def test_a_shard_with_a_wide_range_minibatch_needs_no_verdict(tmp_path):
+    """Rounds 3 - 4 fenced minibatches whose samples differ by more than 2^16 in magnitude (a refusal that had to travel
+    with the all-reduce so that every rank raised).  The forward's split tensors now carry one scale per image: such a
+    minibatch is computed like any other — no flag word in the exchange, no error on any rank, and the reduced factors are
+    the fp64 Grams of the union of the shards (curvlinops.py:77-108 accepts any finite input)."""
+    from oracle import curvature_oracle as co
+    from tests.test_sweep_nhwc import _model
+
     out = str(tmp_path / "verdict")
     mp.spawn(_range_worker, args=(2, _free_port(), out), nprocs=2, join=True)
-    v0, v1 = torch.load(out + ".0", weights_only=False), torch.load(out + ".1", weights_only=False)
-    assert "range_guard" in v0 and "other rank" in v0     # rank 0's own data was fine: it learns about it from the flag
-    assert "range_guard" in v1 and "minibatch 0" in v1
+    r0, r1 = torch.load(out + ".0", weights_only=False), torch.load(out + ".1", weights_only=False)
+    assert r0[0] == "no error" and r1[0] == "no error"
+    m64 = _model(torch.relu).double()
+    ref = None
+    for _, X, y, _ in (r0, r1):
+        _, kf = co.kfac_ggn(m64, X.double(), y, 20, "classification")
+        ref = kf if ref is None else [[a + b for a, b in zip(Fa, Fb)] for Fa, Fb in zip(ref, kf)]
+    for got in (r0[3], r1[3]):
+        for F_, G_ in zip(got, ref):
+            for a_, w_ in zip(F_, G_):
+                assert (a_.double() - w_).abs().max() <= 1e-4 * w_.abs().max()

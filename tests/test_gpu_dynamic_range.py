@@ -1,17 +1,14 @@
-"""The split-fp16 scheme uses ONE power-of-two scale per tensor (all seeds x all samples x all pixels of a cotangent, a
-whole minibatch of activations; csrc/lk_conv.hip).  A norm-wise tolerance over the whole tensor cannot see what that
-costs an element far below the tensor's maximum, so these tests are PER IMAGE / PER SAMPLE / PER BLOCK — each compared
-with its own largest magnitude, as the reference's element-wise assertions imply (tests/test_baselaplace.py:334-410,
-``rtol=1e-4``) — on inputs built to stress the shared scale: minibatches mixing images of very different magnitudes,
-seed columns of a saturated softmax (root columns of ~1e-6 next to ~0.5), ReLU.  Tolerance 1e-4 (BASELINE.json).
+"""Dynamic range of the split-fp16 scheme (csrc/lk_conv.hip), PER IMAGE / PER SAMPLE / PER BLOCK — each compared with
+its own largest magnitude, as the reference's element-wise assertions imply (tests/test_baselaplace.py:334-410,
+``rtol=1e-4``) — on inputs built to stress the scales: minibatches mixing images of very different magnitudes, seed
+columns of a saturated softmax (root columns of ~1e-6 next to ~0.5), ReLU.  Tolerance 1e-4 (BASELINE.json).
 
-What the scheme guarantees: absolute error <= 2^-39 of the tensor's largest element (times the
-slack of the producer's bound), i.e. a sample whose own maximum is r times the tensor's keeps a relative accuracy of
-2^-39 / r.  The product therefore keeps the samples of one sweep within 2^16 of each other wherever a result is per
-sample (laplace_amd/backend.py: range_groups — the predictive and the Jacobians sweep wider minibatches in magnitude
-groups; a fit records the spread and refuses a minibatch outside it unless ``range_guard = "group"``), which leaves
-2^-23 of every sample's own maximum.  Sums over samples (the factors of a fit) only need the tensor-wide bound.
--m gpu only."""
+Round 5: the FORWARD's split tensors carry one scale per image (tests/test_gpu_per_image.py), so an image keeps 2^-22 of
+its own maximum whatever else is in its minibatch; the reverse sweep's cotangents keep one scale per tensor (absolute
+error <= 2^-39 of the tensor's largest element): what consumes them are sums over samples (the factors of a fit), or
+per-sample rows whose seeds are identity columns (the predictive, the Jacobians), where the samples' cotangents are of
+one magnitude by construction.  The `range_guard` of rounds 3 - 4 (refuse / sweep in magnitude groups) is gone: the
+whole-model test below runs ONE sweep.  -m gpu only."""
 import copy
 import math
 
@@ -21,7 +18,21 @@ import torch.nn.functional as F
 from torch import nn
 
 pytestmark = pytest.mark.gpu
-DEV = "cuda"
+# LK_TEST_DEVICE=cpu: self-check of this file's host logic on the kernel emulation (GPU-less box)
+DEV = __import__("os").environ.get("LK_TEST_DEVICE", "cuda")
+
+
+@pytest.fixture(autouse=True)
+def _kernels():
+    if DEV != "cpu":
+        yield
+        return
+    from laplace_amd import _lib
+    from tests.emulated_kernels import EmulatedKernels
+
+    prev = _lib.set_kernels_for_testing(EmulatedKernels())
+    yield
+    _lib.set_kernels_for_testing(prev)
 TOL = 1e-4
 
 # the stride-1 3x3 convolutions of c4 (fused epilogue) and the strided ones (plain epilogue)
@@ -172,19 +183,21 @@ def test_c4_factors_and_predictive_per_sample_on_adversarial_inputs(act):
     against the oracle's Jacobians pushed through matrix.py:406-461 — a small-gradient test point in a batch with a
     large-gradient one is where a tensor-wide scale would show.
 
-    The minibatch spans six decades, more than the 2^16 one sweep resolves per sample: by default a fit REFUSES it
-    (asserted), with ``range_guard = "group"`` it is swept in magnitude groups and must meet the bar; the predictive
-    groups by itself.  tanh pins the kernels; ReLU (what bench.py times) additionally flips the pre-activations that
-    sit within fp32 rounding of zero between two executions, which at 8 samples — of which the
-    saturated softmax leaves three that carry the G factors — moves a block by up to ~1e-3: looser bar, stated."""
+    ONE sweep, no guard (rounds 3 - 4 refused this minibatch by default and needed magnitude groups to meet the bar: with
+    one scale per tensor the small images' activations were resolved to 2^-39 of the LARGEST image, and the ReLU masks
+    decided on them moved one G block by 3e-3).  Bar: 1e-4 block by block, tanh AND ReLU.  ReLU additionally flips the
+    pre-activations that sit within fp32 rounding of zero between any two executions; how much that moves a block is not
+    asserted from an explanation but MEASURED here: the same oracle run in fp32 on the CPU against its fp64 run — the
+    kernels must be within 2x of that where it exceeds the bar (it does not on this input: recorded in the parity log)."""
     from laplace_amd import HipGGN
     from laplace_amd import predictive as Pr
     from oracle import curvature_oracle as co
+    from tests.parity_log import record_error
 
     m32 = _adversarial_c4(torch.relu if act == "relu" else torch.tanh)
     m64 = copy.deepcopy(m32).double().cpu().eval()
+    m32cpu = copy.deepcopy(m32).cpu().eval()
     m32 = m32.to(DEV).eval()
-    tol_fit = TOL if act == "tanh" else 2e-3
     g = torch.Generator().manual_seed(11)
     B = 8
     X = torch.randn(B, 3, 32, 32, generator=g)
@@ -192,25 +205,23 @@ def test_c4_factors_and_predictive_per_sample_on_adversarial_inputs(act):
     y = torch.randint(10, (B,), generator=g)
     N = 50_000
     b = HipGGN(m32, "classification")
+    assert not hasattr(b, "range_guard")
     acc = b.kron_accumulator(N)
     acc.add_batch(X.to(DEV), y.to(DEV))
-    with pytest.raises(RuntimeError, match="range_guard"):
-        acc.finalize()
+    loss, kron = acc.finalize()                       # (rounds 3 - 4: RuntimeError here)
     loss_ref, kf_ref = co.kfac_ggn(m64, X.double(), y, N, "classification")
-    worst = {}
-    for mode in ("off", "group"):
-        b.range_guard = mode
-        acc = b.kron_accumulator(N)
-        acc.add_batch(X.to(DEV), y.to(DEV))
-        loss, kron = acc.finalize()
-        assert rel(loss, loss_ref) < TOL
-        worst[mode] = max(rel(a_, w_) for F_, G_ in zip(kron.kfacs, kf_ref) for a_, w_ in zip(F_, G_))
-    print(f"adversarial c4 / {act}: worst factor block, one sweep {worst['off']:.2e}, magnitude groups {worst['group']:.2e}")
-    for i, (F_, G_) in enumerate(zip(kron.kfacs, kf_ref)):  # (the "group" fit)
-        for j, (a_, w_) in enumerate(zip(F_, G_)):
+    _, kf_32 = co.kfac_ggn(m32cpu, X, y, N, "classification")   # the reference's arithmetic: fp32 on the CPU
+    assert rel(loss, loss_ref) < TOL
+    worst = worst32 = 0.0
+    for i, (F_, G_, G32) in enumerate(zip(kron.kfacs, kf_ref, kf_32)):
+        for j, (a_, w_, w32) in enumerate(zip(F_, G_, G32)):
             r = rel(a_, w_)
-            assert r < tol_fit, f"{act}, block {i} factor {j} (n={a_.shape[0]}): rel to the block's own max {r:.2e}"
-    b.range_guard = "check"
+            r32 = (w32.double() - w_).abs().max().item() / (w_.abs().max().item() + 1e-300)
+            worst, worst32 = max(worst, r), max(worst32, r32)
+            assert r < max(TOL, 2.0 * r32), (f"{act}, block {i} factor {j} (n={a_.shape[0]}): rel to the block's own max "
+                                             f"{r:.2e}; the fp32 oracle is at {r32:.2e}")
+    record_error(worst32, "fp32-oracle")  # what fp32 arithmetic itself does to the worst block (its own log entry)
+    print(f"adversarial c4 / {act}: worst factor block in one sweep {worst:.2e} (the fp32 CPU oracle: {worst32:.2e})")
     if act == "relu":
         return  # (the predictive half runs once, on the smooth network: the fp64 Jacobians of the oracle take a minute)
     # ONE posterior on both sides (the predictive kernels are what is compared here; the eigensolver has its own tests):
@@ -226,29 +237,41 @@ def test_c4_factors_and_predictive_per_sample_on_adversarial_inputs(act):
     # so that a 1e-4 bar on a variance measures the kernels and not the fp32 storage of H
     prior = 1e-2 * max(math.prod(float(l.max()) for l in blk) for blk in ls)
     post = dec_ref * hf + torch.tensor(prior, device=DEV, dtype=torch.float32)
-    Xt = torch.stack([X[0] * 1e-4, X[1] * 1e3, X[2]])   # 1e-7, 1e+6, 1: thirteen decades in one call
-    assert Pr._range_groups(Xt.to(DEV)) is not None
-    assert Pr._range_groups(X[2:3].expand(4, -1, -1, -1).to(DEV)) is None
+    Xt = torch.stack([X[0] * 1e-4, X[1] * 1e3, X[2]])   # 1e-7, 1e+6, 1: thirteen decades in one call, ONE sweep
     f_mu, f_var = Pr.glm_variance_kron(b, Xt.to(DEV), post)
     Jt, ft = co.jacobians(m64, Xt.double())
     want = co.krondecomposed_inv_square_form_blocks(Qs, ls, prior, Jt.to(DEV))
     r_mu, r_var = rel_rows(f_mu, ft), rel_rows(f_var, want)
     print(f"adversarial c4 / {act}, thirteen decades in one predictive call: per-sample f_mu {r_mu:.2e}, f_var {r_var:.2e}; "
           f"variance maxima {[f'{v:.1e}' for v in want.abs().flatten(1).amax(1).tolist()]}")
-    tol_pred = TOL if act == "tanh" else 1e-3
-    assert r_mu < tol_pred
-    assert r_var < tol_pred, f"{act}: per-sample f_var error {r_var:.2e}"
-    # ... and what the shared scale alone would have made of it (reported, not asserted: it is why the guard exists)
-    b.range_guard = "off"
-    _, f_var_one = Pr.glm_variance_kron(b, Xt.to(DEV), post)
-    b.range_guard = "check"
-    print(f"adversarial c4 / {act}: the same call as ONE sweep: per-sample f_var error {rel_rows(f_var_one, want):.2e}")
+    assert r_mu < TOL
+    assert r_var < TOL, f"{act}: per-sample f_var error {r_var:.2e}"
 
 
-def test_range_limit_of_the_shared_scale_is_where_the_design_says():
-    """2^-39 of the tensor's largest element is the floor: an image 1e-9 below the largest one in its minibatch keeps
-    ~2^-9 — outside the 1e-4 bar.  Pinned so that the limit is a documented number, not a surprise: minibatches beyond
-    2^16 are swept in magnitude groups / refused (laplace_amd/backend.py: `range_groups`, `range_guard`)."""
+def test_per_sample_jacobians_of_a_homogeneous_network_over_twelve_decades():
+    """`backend.jacobians` (curvature.py:88-129) on a ReLU network — positively homogeneous: the Jacobian rows of the
+    first layers scale with the image — for a minibatch spanning twelve decades in ONE sweep: every sample's Jacobian
+    against the fp64 oracle relative to that sample's own largest entry, and through the reference's own quadratic form
+    `J diag(v) J^T` sample by sample."""
+    from laplace_amd import HipGGN
+    from laplace_amd.nets import ResNet18
+    from oracle import curvature_oracle as co
+
+    torch.manual_seed(3)
+    m32 = ResNet18(10)
+    m64 = copy.deepcopy(m32).double().cpu().eval()
+    m32 = m32.to(DEV).eval()
+    X = torch.randn(4, 3, 32, 32) * torch.tensor([1e-6, 1e6, 1.0, 1e-3]).reshape(4, 1, 1, 1)
+    Js, f = HipGGN(m32, "classification").jacobians(X.to(DEV))
+    Jt, ft = co.jacobians(m64, X.double())
+    assert rel_rows(f, ft) < TOL
+    assert rel_rows(Js, Jt) < TOL
+
+
+def test_one_scale_per_tensor_floor_and_what_the_per_image_split_makes_of_it():
+    """2^-39 of the tensor's largest element is the floor of ONE scale per tensor: an image 1e-9 below the largest one in
+    its minibatch keeps ~2^-9 — pinned, so that the limit of the reverse sweep's format is a documented number; the
+    forward's per-image split (lk_split_images_f16x2) gives the same image 2^-21."""
     from laplace_amd._lib import get_kernels
 
     K = get_kernels()
@@ -257,3 +280,5 @@ def test_range_limit_of_the_shared_scale_is_where_the_design_says():
     back = K.split_f16x2(x.contiguous()).float()
     assert rel_rows(back[:1], x[:1]) < 2.0 ** -21
     assert 2.0 ** -14 < rel_rows(back[1:], x[1:]) < 2.0 ** -6
+    back = K.split_images_f16x2(x.contiguous()).float()
+    assert rel_rows(back, x) < 2.0 ** -21

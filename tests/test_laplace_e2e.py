@@ -170,3 +170,42 @@ def test_parameters_outside_linear_and_conv_take_the_generic_route():
                 b.kron(X, y, 5)
     finally:
         _lib.set_kernels_for_testing(prev)
+
+
+@pytest.mark.parametrize("name,lik", [("mlp", "regression"), ("conv", "classification")])
+@pytest.mark.parametrize("fused", [True, False])
+def test_fp64_model_through_the_default_kron_fit_and_predictive(emulated, name, lik, fused):
+    """ADVICE (round 4): the fp32 twin wrapped `kron` / `diag` / `full` / `jacobians` only — `HipLaplace(model.double())
+    .fit(loader)` (the default fused accumulator) and the fused predictive ended in TypeError, which nothing falls back
+    from.  The accumulator now runs on the twin (factors come back in the model's dtype) and the fused predictive
+    hands a non-fp32 model to the reference's route.  Reference: its tests run fp64 models through every backend
+    (tests/test_baselaplace.py:895-934)."""
+    from laplace_amd.laplace import HipLaplace
+
+    g = load_golden(name, lik)
+    model, X, y = golden_model(name, g, dtype=torch.float64, device="cpu")
+    sig = SIGMA_NOISE if lik == "regression" else 1.0
+    la = HipLaplace(model, lik, "all", "kron", prior_precision=PRIOR_PREC, sigma_noise=sig)
+    la.fit(DataLoader(TensorDataset(X, y), batch_size=5), fused=fused)
+    tag = "la.all.kron"
+    for F_, G_ in zip(la.H_facs.kfacs, golden_kfacs(g, f"{tag}.H")):
+        for a, w in zip(F_, G_):
+            assert a.dtype == torch.float64 and rel(a, w) < 1e-4
+    f_mu, f_var = la._glm_predictive_distribution(X)
+    assert f_mu.dtype == torch.float64 and f_var.dtype == torch.float64
+    assert rel(f_mu, g[f"{tag}.f_mu"]) < 1e-4 and rel(f_var, g[f"{tag}.f_var"]) < 1e-4
+
+
+def test_dict_style_inputs_are_cast_for_the_fp32_twin():
+    """ADVICE (round 4): `_to32` returned a non-dict MutableMapping (UserDict, BatchEncoding) unchanged and did not look
+    into tuples / lists"""
+    from collections import UserDict
+
+    from laplace_amd.backend import _HipCurvatureMixin as M
+
+    d = UserDict({"input_ids": torch.ones(2, 3, dtype=torch.long), "feat": torch.ones(2, 3, dtype=torch.float64)})
+    out = M._to32(d)
+    assert isinstance(out, UserDict) and out["feat"].dtype == torch.float32 and out["input_ids"].dtype == torch.long
+    assert d["feat"].dtype == torch.float64  # (the caller's container is not modified)
+    t = M._to32((torch.ones(2, dtype=torch.float16), [torch.ones(2, dtype=torch.float64)]))
+    assert t[0].dtype == torch.float32 and t[1][0].dtype == torch.float32 and isinstance(t, tuple) and isinstance(t[1], list)

@@ -1,0 +1,167 @@
+"""One power-of-two scale PER IMAGE on the forward's split tensors (lk_split_images_f16x2, lk_bn_act_fwd_nhwc_f16x2,
+lk_conv_nhwc_f16x2 with in_nsexp = N) — host logic on the CPU emulation of the kernels (the kernels themselves:
+tests/test_gpu_per_image.py).
+
+Why: the reference computes every sample in fp32 whatever else is in its minibatch (laplace/curvature/curvature.py:
+375-433, curvlinops.py:77-108).  With one scale per TENSOR an image 1e-6 below the largest one of its minibatch had its
+activations resolved to 2^-39 * 1e6 of its own size — for a ReLU network enough to flip masks that fp32 decides the
+other way: G factors 3e-3 off the fp64 oracle (rounds 3 - 4 fenced such minibatches: `range_guard`, removed in round 5)."""
+import copy
+
+import pytest
+import torch
+from torch import nn
+
+from laplace_amd import HipGGN, _lib
+from laplace_amd._lib import LaplaceHipError, SplitTensor, get_kernels
+from laplace_amd.sweep_nhwc import SplitSweep
+from oracle import curvature_oracle as co
+from tests.emulated_kernels import EmulatedKernels
+from tests.test_sweep_nhwc import TinyResNet, _model
+
+
+@pytest.fixture(autouse=True)
+def _emulated():
+    prev = _lib.set_kernels_for_testing(EmulatedKernels())
+    yield
+    _lib.set_kernels_for_testing(prev)
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return (a - b).abs().max().item() / (b.abs().max().item() + 1e-300)
+
+
+def rel_rows(a, b):
+    a, b = a.double().flatten(1), b.double().flatten(1)
+    return ((a - b).abs().amax(1) / (b.abs().amax(1) + 1e-300)).max().item()
+
+
+def test_split_images_resolves_every_image_against_its_own_maximum():
+    K = get_kernels()
+    torch.manual_seed(0)
+    x = torch.randn(6, 4, 4, 32) * torch.tensor([1e-9, 1e6, 1.0, 3e-4, 0.0, 7.0]).reshape(6, 1, 1, 1)
+    st = K.split_images_f16x2(x)
+    assert st.per_image and tuple(st.sexp.shape) == (6,) and tuple(st.amax.shape) == (6,)
+    assert torch.equal(st.amax, x.abs().reshape(6, -1).amax(1))
+    assert rel_rows(st.float()[[0, 1, 2, 3, 5]], x[[0, 1, 2, 3, 5]]) < 2.0 ** -21   # one scale per tensor: image 0 keeps 2^-9
+    assert float(st.float()[4].abs().max()) == 0.0
+    # every image's largest element lands in [2^14, 2^15)
+    top = (x.abs().reshape(6, -1).amax(1) * torch.exp2(st.sexp.float()))[[0, 1, 2, 3, 5]]
+    assert bool(((top >= 2.0 ** 14) & (top < 2.0 ** 15)).all())
+
+
+def test_kernels_that_reduce_across_images_refuse_a_per_image_operand():
+    """the reverse sweep's consumers (Gram over rows, fused launches) take one scale per tensor: said loudly, not computed
+    with image 0's scale"""
+    from laplace_amd._lib import HipKernels, _one_scale
+
+    st = get_kernels().split_images_f16x2(torch.randn(4, 2, 2, 64))
+    with pytest.raises(LaplaceHipError, match="one scale per image"):
+        _one_scale(st, "gram_tn_f16x2")
+    assert _one_scale(get_kernels().split_f16x2(torch.randn(4, 2, 2, 64)), "x") is not None
+    for name in ("gram_tn_f16x2", "unsplit_transpose", "conv_nhwc_f16x2_vjp", "vjp_nhwc_split", "pixpair_accumulate_split"):
+        import inspect
+
+        assert "_one_scale(" in inspect.getsource(getattr(HipKernels, name)), name
+
+
+def test_forward_keeps_fp32_resolution_per_image_over_twelve_decades():
+    """every activation the sweep's forward hands to the next convolution, image by image against fp64"""
+    m = _model(torch.relu)
+    taps = {n: mod for n, mod in m.named_modules() if isinstance(mod, (nn.Conv2d, nn.Linear))}
+    sw = SplitSweep(m, taps, kernels=get_kernels)
+    torch.manual_seed(5)
+    X = torch.randn(6, 3, 8, 8) * torch.tensor([1e-6, 1e6, 1.0, 1e-3, 30.0, 1e-6]).reshape(6, 1, 1, 1)
+    m64 = copy.deepcopy(m).double()
+    ins64 = {}
+    hs = [mod.register_forward_hook(lambda m_, i, o, n=n: ins64.__setitem__(n, i[0].detach()))
+          for n, mod in m64.named_modules() if isinstance(mod, (nn.Conv2d, nn.Linear))]
+    m64(X.double())
+    sw.forward(X, keep_tap_splits=True)
+    assert sw.tap_splits and all(s.per_image for s in sw.tap_splits.values())
+    for n, s in sw.tap_splits.items():  # the split copy each convolution consumed
+        want = ins64[n].permute(0, 2, 3, 1)
+        assert rel_rows(s.float()[..., :want.shape[-1]], want) < 5e-6, n
+    for n in taps:
+        if n in ins64 and sw.taps[n].get("a") is not None:
+            assert rel_rows(sw.taps[n]["a"], ins64[n]) < 5e-6, n
+
+
+@pytest.mark.parametrize("act", [torch.relu, torch.tanh])
+def test_fit_of_a_minibatch_spanning_six_decades_is_one_sweep_and_meets_the_bar_block_by_block(act):
+    """what `range_guard` used to refuse (or sweep in magnitude groups after a read-back): every KFAC factor of a ReLU /
+    tanh residual network on a minibatch mixing images scaled 1e-3 ... 1e+3, against the fp64 oracle
+    (curvlinops.py:77-108), relative to the block's own maximum — ONE sweep, no grouping, no error"""
+    m = _model(act)
+    with torch.no_grad():
+        m.fc.weight.mul_(20.0)  # saturated softmax: seed columns of ~1e-6 next to ~0.5
+    m64 = copy.deepcopy(m).double()
+    torch.manual_seed(9)
+    X = torch.randn(8, 3, 8, 8) * torch.tensor([1e-3, 1e3, 1.0, 1e-2, 30.0, 1e-3, 1e3, 0.3]).reshape(8, 1, 1, 1)
+    y = torch.randint(5, (8,))
+    b = HipGGN(m, "classification")
+    assert not hasattr(b, "range_guard")
+    sweeps = []
+    orig = SplitSweep.forward
+    SplitSweep.forward = lambda self, x, *a, **k: (sweeps.append(x.shape[0]), orig(self, x, *a, **k))[1]
+    try:
+        acc = b.kron_accumulator(100)
+        acc.add_batch(X, y)
+        loss, kron = acc.finalize()
+    finally:
+        SplitSweep.forward = orig
+    assert sweeps == [8]
+    loss_ref, kf_ref = co.kfac_ggn(m64, X.double(), y, 100, "classification")
+    assert rel(loss, loss_ref) < 1e-6
+    worst = max(rel(a_, w_) for F_, G_ in zip(kron.kfacs, kf_ref) for a_, w_ in zip(F_, G_))
+    assert worst < 2e-5, f"worst factor block {worst:.2e}"
+
+
+def test_strided_branches_of_unequal_width_do_not_fuse():
+    """ADVICE (round 4): a 3x3 / stride-2 convolution 32 -> 64 and a 1x1 / stride-2 convolution 32 -> 32 reading the same
+    ReLU output passed `strided_taps` and reached the fused launch with cotangents of different channel counts — which the
+    library refuses (and the emulation did not check).  They now run class by class; the emulation checks shapes too."""
+    from laplace_amd import conv as cv
+
+    class TwoBranch(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.stem, self.bn = nn.Conv2d(3, 32, 3, 1, 1, bias=False), nn.BatchNorm2d(32)
+            self.a, self.bna = nn.Conv2d(32, 64, 3, 2, 1, bias=False), nn.BatchNorm2d(64)
+            self.b, self.bnb = nn.Conv2d(32, 32, 1, 2, 0, bias=False), nn.BatchNorm2d(32)
+            self.pool = nn.AdaptiveAvgPool2d(1)
+            self.fa, self.fb = nn.Linear(64, 5), nn.Linear(32, 5)
+
+        def forward(self, x):
+            h = torch.relu(self.bn(self.stem(x)))
+            ya, yb = torch.relu(self.bna(self.a(h))), torch.relu(self.bnb(self.b(h)))
+            return self.fa(torch.flatten(self.pool(ya), 1)) + self.fb(torch.flatten(self.pool(yb), 1))
+
+    torch.manual_seed(0)
+    m = TwoBranch().eval()
+    taps = {n: mod for n, mod in m.named_modules() if isinstance(mod, (nn.Conv2d, nn.Linear))}
+    sw = SplitSweep(m, taps, kernels=get_kernels)
+    assert sw.split_ok, sw.split_reason
+    x = torch.randn(4, 3, 8, 8)
+    f = sw.forward(x)
+    seeds = torch.eye(5)[:, None, :].expand(5, 4, 5).contiguous()
+    got = sw.backward(seeds)
+    outs = {}
+    hs = [mod.register_forward_hook(lambda m_, i, o, n=n: outs.__setitem__(n, o)) for n, mod in taps.items()]
+    f2 = m(x)
+    for h in hs:
+        h.remove()
+    assert rel(f, f2) < 1e-5
+    for s in range(5):
+        grads = torch.autograd.grad(f2, [outs[n] for n in taps], grad_outputs=seeds[s], retain_graph=True)
+        for n, g in zip(taps, grads):
+            assert rel(got[n][s], g) < 1e-5, (n, s)
+    # the shape rule itself, and the emulation's mirror of the library's check
+    K = get_kernels()
+    ga, gb = K.split_f16x2(torch.randn(4, 4, 4, 64)), K.split_f16x2(torch.randn(4, 4, 4, 32))
+    pa, pb = cv.PreparedConv(m.a), cv.PreparedConv(m.b)
+    assert cv.strided_taps([(pa, ga, None), (pb, gb, None)], (8, 8)) is None
+    with pytest.raises(LaplaceHipError, match="same shapes"):
+        K.conv_nhwc_f16x2_vjp_strided([(ga, *pa.backward_planes(), pa.backward_l1()), (gb, *pb.backward_planes(), pb.backward_l1())],
+                                      8, 8, 2, [(0, 0, 0, 0, 0, 0)])
