@@ -562,6 +562,7 @@ class _HipCurvatureMixin:
             acc.use_pixgram = False
         acc._persist_slabs = False
         acc.lanes = 1  # (one minibatch: nothing to run beside it)
+        acc.coalesce = False  # (... and nothing to stack it with: its raw form is read right away)
         try:
             acc.add_batch(x, y)
         except NotImplementedError as e:
@@ -694,6 +695,15 @@ class KronAccumulator:
         self.defer_pix = False
         self._pix_inputs = {}  # tap index -> list of (geometry, alpha, NHWC fp32 tensor [B, H, W, C], module)
         self._pix_early = set()  # taps whose pixel-pair blocks were folded into this accumulator's A factor mid-fit
+        #: ``True`` (env LK_COALESCE=0 turns it off): consecutive SMALL minibatches of a small model are stacked and swept
+        #: together.  The curvature is a sum over samples with per-sample terms that do not depend on the minibatch they
+        #: arrive in (curvlinops.py:77-108: G sums over samples, A carries 1/N with the GLOBAL N), so minibatch boundaries
+        #: are the caller's choice, not part of the result — and a 151-parameter MLP at batch 100 (BASELINE config c1) is
+        #: ~50 launches of a few microseconds each per minibatch, i.e. bound by the host's enqueue rate, not by the device
+        #: ("batch into one launch").  Stacking keeps copies of the inputs (2 small launches per
+        #: minibatch) and sweeps `coalesce_target` samples at a time; models whose minibatch fills the chip never stack.
+        self.coalesce = os.environ.get("LK_COALESCE", "1") != "0"
+        self._stash, self._stash_n = [], 0
         #: minibatches in flight on the device (env LK_LANES): with 2, consecutive minibatches go alternately to two
         #: sub-accumulators, each with its own stream (and side stream) and its own factor buffers, summed when the fit
         #: is read — the forward pass of one minibatch (small grids at batch 128) then runs beside the reverse sweep of
@@ -986,6 +996,7 @@ class KronAccumulator:
             for k in range(self.lanes):
                 sub = KronAccumulator(self.backend, self.N, self.kfac_approx, self.overlap)
                 sub.lanes, sub._lane_id, sub._lane_stream = 1, k, streams[k]
+                sub.coalesce = False  # (the parent stacks)
                 sub.use_pixgram, sub.pix_group, sub.lag_join = self.use_pixgram, self.pix_group, self.lag_join
                 sub.lag_depth = self.lag_depth
                 sub._defer_bn, sub._persist_slabs = self._defer_bn, self._persist_slabs
@@ -1040,6 +1051,7 @@ class KronAccumulator:
         behind the event at the end of each lane's latest A-side work and runs UNDER the reverse sweeps that are still in
         flight; the lanes' blocks are summed inside the assembly (`blocks2`) instead of by a pass of their own.  Only the G
         side (one multi-tensor add) waits for the sweeps."""
+        self._flush_stash()  # (stacked small minibatches that have not been swept yet)
         subs, self._lane_accs = self._lane_accs, None
         if not subs:
             return
@@ -1158,10 +1170,45 @@ class KronAccumulator:
                 for t in sub._raw_tensors():  # allocated on the lane's stream, read (and from now on owned) here
                     t.record_stream(cur)
 
+    def coalesce_target(self, x) -> int:
+        """samples per stacked sweep for minibatches shaped like ``x`` (0: this model / minibatch does not stack): work per
+        sample grows with the parameter count, and 2^26 parameter-samples per sweep is still a sub-millisecond step"""
+        b = self.backend
+        if (not self.coalesce or not torch.is_tensor(x) or not x.is_floating_point() or x.dim() < 2
+                or getattr(b, "stochastic", False) or b.last_layer):
+            return 0
+        n_params = sum(p.numel() for p in b.params)
+        target = min(8192, (1 << 26) // max(n_params, 1), (1 << 24) // max(x[0].numel(), 1))
+        return target if target >= 2 * x.shape[0] else 0
+
+    def _flush_stash(self):
+        if not self._stash:
+            return
+        stash, self._stash, self._stash_n = self._stash, [], 0
+        if len(stash) == 1:
+            self._dispatch(*stash[0])
+        else:
+            self._dispatch(torch.cat([x for x, _ in stash]), torch.cat([y for _, y in stash]))
+
     def add_batch(self, x, y):
         if self._caller is not None:
             twin, _ = self._caller._twin()  # (re-synchronises the fp32 copy if a parameter or buffer changed)
             x, y = twin._to32(x), twin._to32(y)
+        target = self.coalesce_target(x) if torch.is_tensor(x) and torch.is_tensor(y) and y.shape[:1] == x.shape[:1] else 0
+        if target:
+            if self._stash and (self._stash[0][0].shape[1:] != x.shape[1:] or self._stash[0][0].dtype != x.dtype
+                                or self._stash[0][1].shape[1:] != y.shape[1:] or self._stash[0][1].dtype != y.dtype
+                                or self._stash[0][0].device != x.device or self._stash_n + x.shape[0] > target):
+                self._flush_stash()
+            self._stash.append((x.clone(), y.clone()))  # (private copies: the caller may refill its buffers)
+            self._stash_n += x.shape[0]
+            if self._stash_n >= target:
+                self._flush_stash()
+            return
+        self._flush_stash()
+        self._dispatch(x, y)
+
+    def _dispatch(self, x, y):
         b = self.backend
         if self.lanes > 1 and self.overlap and not self.defer_pix and torch.is_tensor(x) and (x.is_cuda or self._lanes_anywhere):
             return self._lane_add_batch(x, y)
@@ -1290,7 +1337,7 @@ class KronAccumulator:
         self._fold_lanes()
         self._join_side()
         new = KronAccumulator(self.backend, self.N, self.kfac_approx, self.overlap)
-        new._caller, new._out_dtype = self._caller, self._out_dtype
+        new._caller, new._out_dtype, new.coalesce = self._caller, self._out_dtype, self.coalesce
         new.use_pixgram, new._persist_slabs = self.use_pixgram, self._persist_slabs
         new.defer_pix, new.pix_group = self.defer_pix, self.pix_group
         new._pix_inputs = {k: list(v) for k, v in self._pix_inputs.items()}  # (the tensors themselves are never written)

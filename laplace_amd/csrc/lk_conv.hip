@@ -1073,7 +1073,7 @@ struct WinPCfg {
 };
 
 struct WinPArgs {  // (a slim argument block: everything here stays in scalar registers for the whole launch)
-  int M, Hi, Wi, Ci, Co, HW, n_tiles, nb_m, wt0, wtstep, stagger, ablate;
+  int M, Hi, Wi, Ci, Co, HW, n_tiles, nb_m, wt0, wtstep, stagger, ablate, halo_all, coloc;
   FastDiv div_hw, div_w, div_mask;
   const _Float16 *Ah, *Al, *Wh, *Wl;
   const int *a_sexp, *w_sexp, *add_sexp;
@@ -1112,7 +1112,24 @@ void conv_winp_f16x2_kernel(const WinPArgs p) {
     const int q = G / 8, r = G % 8, x = tile % 8, j = tile / 8;
     tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
   }
-  if (tile >= p.n_tiles) return;  // (uniform)
+  // tile index -> (first pixel, first output channel); false behind the last tile of this workgroup's walk.  Plain order:
+  // the column tiles of a pixel tile are consecutive indices, i.e. run at the same time on DIFFERENT XCDs (index % 8), each
+  // XCD always on the same column(s): its weight slice stays hot in its L2, every window is fetched by Co / 64 L2s.
+  // coloc = c > 1 (host: config bits 28-29): an XCD walks c columns of every pixel tile it owns side by side — a window is
+  // fetched by Co / 64 / c L2s, an L2 holds c weight slices.  x = index % 8 is the XCD (the grid is a multiple of 8).
+  const int nb_n = p.Co / 64;
+  auto coords = [&](int v, int& m0_, int& n0_) {
+    if (p.coloc > 1) {
+      const int x = v & 7, j = v >> 3, ng = nb_n / p.coloc, per = 8 / ng;
+      const int pt = (j / p.coloc) * per + x / ng;
+      m0_ = pt * BM, n0_ = ((x % ng) * p.coloc + j % p.coloc) * 64;
+      return pt < p.nb_m;
+    }
+    m0_ = (v / nb_n) * BM, n0_ = (v % nb_n) * 64;
+    return v < p.n_tiles;
+  };
+  int m0, n0;
+  if (!coords(tile, m0, n0)) return;  // (uniform)
 #ifdef LK_WINP_ABLATE  // development switches, compile-time (a run-time switch perturbs this kernel's schedule beyond
   constexpr int ablate = LK_WINP_ABLATE;  // comparison): 1 skip the epilogue, 2 the MFMAs, 4 the in-loop staging
 #else
@@ -1151,12 +1168,23 @@ void conv_winp_f16x2_kernel(const WinPArgs p) {
     return i < CFG::W_INSTR ? i : wave;
   };
   auto setup_window = [&](int m0) {
+    // What of the PP-pixel window is ever READ: the tile's own BM pixels, the Wi + 1 above them unless the tile starts at an
+    // image boundary, the Wi + 1 below unless it ends at one (taps never leave the image of their row: they read the zero
+    // block instead) — and nothing of the padding behind 2 Wi + 2 + BM.  The staging instructions are a fixed count (the
+    // counted waits rely on it), so the slots nobody reads are pointed at the nearest pixel that IS read: same cache lines
+    // as their neighbours' requests, no traffic of their own.  Maps of up to 16 x 16 (a tile = whole images) fetch BM
+    // pixels instead of 352; the padding alone was 9 % (32 x 32) to 24 % (4 x 4) of every window fetched.
+    const int r0 = m0 - fdiv(m0, p.div_hw) * p.HW;
+    const int e0 = m0 + BM >= M ? 0 : (m0 + BM) - fdiv(m0 + BM, p.div_hw) * p.HW;
+    const int px_lo = p.halo_all ? 0 : (r0 == 0 ? Wi + 1 : 0);
+    const int px_hi = (p.halo_all ? PP : (e0 == 0 ? BM + Wi + 1 : BM + 2 * Wi + 2)) - 1;
 #pragma unroll
     for (int it = 0; it < CFG::W_IT; ++it) {
       const int i = w_instr(it);
       const int rem = (i * 64) % (2 * PP) + lane;  // (whole instructions lie inside one plane: 2 PP % 64 == 0)
       const int px = rem >> 1, pq = rem & 1;
-      int raster = m0 - (Wi + 1) + px;
+      const int pxs = px < px_lo ? px_lo : (px > px_hi ? px_hi : px);  // (source pixel; the LDS slot stays px's)
+      int raster = m0 - (Wi + 1) + pxs;
       // rows outside the tensor (and the window's padding) are only reached by taps that read the zero block instead: any
       // mapped address will do for them
       raster = raster < 0 ? 0 : (raster > M - 1 ? M - 1 : raster);
@@ -1222,7 +1250,6 @@ void conv_winp_f16x2_kernel(const WinPArgs p) {
       a_valid[a] = v;
     }
   };
-  const int nb_n = p.Co / 64;
   const bool frag_const = G % nb_n == 0 && ((int64_t)(G / nb_n) * BM) % p.HW == 0 && (int64_t)p.nb_m * BM <= M;
   int b_addr[TN];
 #pragma unroll
@@ -1242,7 +1269,6 @@ void conv_winp_f16x2_kernel(const WinPArgs p) {
   // one step = three taps behind one hand-over barrier.  A tile = (pixel tile, 64 output channels); the n-tiles of one
   // pixel tile are consecutive tile indices, i.e. run at the same time on neighbouring workgroups: the second one finds the
   // window's lines in L2.
-  int m0 = (tile / nb_n) * BM, n0 = (tile % nb_n) * 64;
   int next_m0 = -1, next_n0 = 0;
   bool fresh = false;  // the next step follows an epilogue, which has drained this wave's loads itself (see there)
   auto step = [&](int kc, bool last_tile, auto r_c) {
@@ -1462,8 +1488,7 @@ void conv_winp_f16x2_kernel(const WinPArgs p) {
 #define LK_WINP_STAMP(k)
 #endif
   while (true) {
-    const bool last_tile = tile + G >= p.n_tiles;
-    next_m0 = ((tile + G) / nb_n) * BM, next_n0 = ((tile + G) % nb_n) * 64;
+    const bool last_tile = !coords(tile + G, next_m0, next_n0);
     LK_WINP_STAMP(0)
     for (int kc = 0; kc < KC; ++kc) {
       if (kc == KC - 1) epi_request(m0, n0, 0, NH);
@@ -1640,9 +1665,16 @@ static int cu_count() {
 // persistent window form (fused VJP epilogue only): one workgroup per CU walks through the pixel tiles.  The taps are put
 // into raster order here (the sum over taps is commutative); their weight slices must then form an arithmetic sequence
 // (forward: 0, 1, ..; backward-data: 8, 7, ..) — returns false (caller takes another kernel) otherwise.
+// default number of column tiles of a pixel tile that share an XCD in the persistent window form (measured per shape:
+// profiles/r05_winp_coloc.md); config bits 28-29 of a launch override it
+static int coloc_default(int Ci, int Co) {
+  (void)Ci, (void)Co;
+  return 1;
+}
+
 template <typename CFG>
 static bool launch_winp(const ConvGeom& g, const void* Ah, const void* Al, const void* Wh /* chunk-major */, const void* Wl, const int* a_sexp,
-                        const int* w_sexp, unsigned* amax_out, hipStream_t stream, const ConvVjp* fz, int* rc) {
+                        const int* w_sexp, unsigned* amax_out, hipStream_t stream, const ConvVjp* fz, int* rc, int config) {
   int wt[9];
   for (int t = 0; t < 9; ++t) wt[t] = -1;
   for (int t = 0; t < 9; ++t) {
@@ -1669,6 +1701,8 @@ static bool launch_winp(const ConvGeom& g, const void* Ah, const void* Al, const
   p.mask = (const unsigned char*)fz->mask, p.mask_rows = (int)fz->mask_rows;
   p.stagger = 3 * (g.Ci / 64);  // start delay of a CU's second workgroup, x 64 s_sleep cycles (measured: 0 .. 8, flat around 3)
   p.ablate = 0;
+  p.halo_all = (config >> 30) & 1;  // (development: stage the whole PP-pixel window as round 4 did)
+  p.coloc = 1;
   p.out_h = fz->out_h, p.out_l = fz->out_l, p.out_sexp = fz->out_sexp;
   p.amax_out = amax_out;
   static bool attr_set = false;
@@ -1678,6 +1712,13 @@ static bool launch_winp(const ConvGeom& g, const void* Ah, const void* Al, const
   }
   constexpr int wg_per_cu = 2;
   const int grid = p.n_tiles < wg_per_cu * cu_count() ? p.n_tiles : wg_per_cu * cu_count();  // two workgroups per CU
+  {
+    // columns of a pixel tile that share an XCD (see `coords` in the kernel): config bits 28-29 = log2, 0 = the default below
+    const int nb_n = g.Co / 64;
+    int c = 1 << ((config >> 28) & 3);
+    if (c == 1) c = coloc_default(g.Ci, g.Co);
+    if (c > 1 && c <= nb_n && nb_n % c == 0 && nb_n / c <= 8 && 8 % (nb_n / c) == 0 && grid % 8 == 0 && (grid / 8) % c == 0) p.coloc = c;
+  }
   hipLaunchKernelGGL((conv_winp_f16x2_kernel<CFG>), dim3((unsigned)grid), dim3(CFG::NT), CFG::LDS, stream, p);
   *rc = check_launch("conv_winp_f16x2_kernel");
   return true;
@@ -1713,7 +1754,7 @@ static int conv_dispatch(const void* in_h, const void* in_l, const int* in_sexp,
   if (fz && fz->wc_h && !(config & 134217728) && lk_conv_winp_eligible(N, Hi, Wi, Ci, Co, T, fz->mask && fz->mask_float) &&
       in_mul == 1 && Hc == Hi && Wc == Wi && g.dense) {
     int rc = LK_OK;
-    if (launch_winp<WinPCfg<256>>(g, in_h, in_l, fz->wc_h, fz->wc_l, in_sexp, w_sexp, amax_out, st, fz, &rc)) return rc;
+    if (launch_winp<WinPCfg<256>>(g, in_h, in_l, fz->wc_h, fz->wc_l, in_sexp, w_sexp, amax_out, st, fz, &rc, config)) return rc;
   }
 #define LK_CONV_GO(...) return launch_conv<ConvCfg<__VA_ARGS__>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz)
   switch ((config >> 12) & 7) {  // explicit tile shape (bits 12..14; the tests walk through them); 0: chosen below

@@ -115,6 +115,7 @@ __global__ __launch_bounds__(256) void vjp_nhwc_split_kernel(
 // (2^7 - 2^8 for random weights), which only costs fixed-point range; it does not compound, because the kernel also
 // MEASURES max|y_n| (y_amax[n], one atomic per workgroup; zeroed by the caller) and that is what the next layer starts from.
 // Grid: (chunks of an image, N) — a workgroup never straddles two images.
+constexpr int BN_ACT_IT = 4;
 __global__ __launch_bounds__(256) void bn_act_fwd_nhwc_kernel(
     const float* __restrict__ x, const unsigned* __restrict__ x_amax, int x_namax, const float* __restrict__ x_mul,
     const float* __restrict__ x_add, const float* __restrict__ scale, const float* __restrict__ shift,
@@ -135,9 +136,11 @@ __global__ __launch_bounds__(256) void bn_act_fwd_nhwc_kernel(
     y_bound[n] = bound;
   }
   const float sc_out = exp2i16(so);
-  const int64_t i8 = (int64_t)blockIdx.x * 256 + threadIdx.x;
   unsigned vmax = 0;
-  if (i8 < per8) {
+  // a workgroup walks BN_ACT_IT x 256 float8s of its image (the header's dependent loads and the atomic below are paid once
+  // per 8192 elements: one atomic per 2048 elements — 4096 per launch into the 128 words of a minibatch, i.e. four cache
+  // lines of one L2 channel — cost the layer-1 launches a third of their time)
+  for (int64_t i8 = (int64_t)blockIdx.x * (256 * BN_ACT_IT) + threadIdx.x, it = 0; it < BN_ACT_IT && i8 < per8; ++it, i8 += 256) {
     const int64_t e8 = (int64_t)n * per8 + i8;
     const int c0 = (int)((i8 * 8) % C);  // (per % C == 0: an image starts at channel 0)
     const float4 s0 = *reinterpret_cast<const float4*>(scale + c0), s1 = *reinterpret_cast<const float4*>(scale + c0 + 4);
@@ -595,7 +598,7 @@ extern "C" int lk_bn_act_fwd_nhwc_f16x2(const float* x, const unsigned* x_amax, 
   LK_REQUIRE((y_h == nullptr) == (y_l == nullptr), "lk_bn_act_fwd_nhwc_f16x2: both planes or none");
   LK_REQUIRE(N <= 65535, "lk_bn_act_fwd_nhwc_f16x2: at most 65535 images");
   if (per == 0 || N == 0) return LK_OK;
-  const int64_t per8 = per / 8, nb = (per8 + 255) / 256;
+  const int64_t per8 = per / 8, nb = (per8 + 256 * BN_ACT_IT - 1) / (256 * BN_ACT_IT);
   LK_REQUIRE(nb < (1ll << 31), "lk_bn_act_fwd_nhwc_f16x2: grid too large");
   hipLaunchKernelGGL(bn_act_fwd_nhwc_kernel, dim3((unsigned)nb, (unsigned)N), dim3(256), 0, (hipStream_t)stream, x, x_amax,
                      (int)x_namax, x_mul, x_add, scale, shift, scale_amax, shift_amax, addend, addend_bound,

@@ -14,6 +14,13 @@ from laplace_amd.sweep import SeedBatchedSweep, SweepUnsupported
 from oracle.fixtures import FIXTURES, build_model, input_shape
 
 
+@pytest.fixture(autouse=True)
+def _one_sweep_per_minibatch(monkeypatch):
+    """these tests look at the accumulator's state minibatch by minibatch (lanes, pixel-pair groups, deferred scales) on
+    models small enough for `KronAccumulator.coalesce` to stack their minibatches (tests/test_coalesce.py): off here"""
+    monkeypatch.setenv("LK_COALESCE", "0")
+
+
 class Residual(nn.Module):
     def __init__(self):
         super().__init__()
