@@ -225,10 +225,12 @@ class HipKernels:
         # optional per-launch timing (bench.py's roofline leg): name -> list of (start_evt, end_evt, work)
         self.profile: Optional[dict] = None
         # 3x3/stride-1 conv A factors through the shift-correlation identity (lk_conv3x3_shiftcorr_f32)
-        self.use_shiftcorr = os.environ.get("LK_SHIFTCORR", "1") != "0"
+        self.use_shiftcorr = True
 
-    def _timed(self, name: str, work: float, dev, call):
-        """Run ``call()``; when profiling is on, bracket it with HIP events on the launch stream."""
+    def _timed(self, name: str, work: float, dev, call, nbytes: float | None = None):
+        """Run ``call()``; when profiling is on, bracket it with HIP events on the launch stream.  ``work``: algorithmic flop
+        (matrix families) or bytes (streaming families) of the launch; ``nbytes``: algorithmic HBM bytes of a matrix-family
+        launch — every operand read once, every result written once (what bench.py prices its measured traffic against)."""
         if self.profile is None:
             return call()
         st = torch.cuda.current_stream(dev)
@@ -236,7 +238,7 @@ class HipKernels:
         e0.record(st)
         rc = call()
         e1.record(st)
-        self.profile.setdefault(name, []).append((e0, e1, work))
+        self.profile.setdefault(name, []).append((e0, e1, work, nbytes))
         return rc
 
     # ---- plumbing -----------------------------------------------------------------------------
@@ -491,8 +493,8 @@ class HipKernels:
             _ptr(out), 1 if accumulate else 0, _ptr(amax_out), int(cfg), self._stream(out.device))), "lk_conv_nhwc_f16x2")
         return out
 
-    #: ``False`` (env LK_WINP=0): fused 64-channel launches stay on the generic kernel (see :meth:`conv_winp_eligible`)
-    use_winp = os.environ.get("LK_WINP", "1") != "0"
+    #: ``False``: fused 64-channel launches stay on the generic kernel (see :meth:`conv_winp_eligible`)
+    use_winp = True
 
     def conv_winp_eligible(self, N, Hi, Wi, Ci, Co, T, mask_is_float=False) -> bool:
         """does a fused 3 x 3 / stride-1 launch of this shape run the persistent window form (lk_conv_nhwc_f16x2_vjp_wc)?  The
@@ -529,6 +531,9 @@ class HipKernels:
         cfg = self.conv_config if config is None else config
         z = self._zero16(dev)
         work = 2.0 * N * Co * Ci * self.conv_valid_pairs(Ho, Wo, 1, Hi, Wi, taps) if self.profile is not None else 0.0
+        # algorithmic bytes: cotangent planes in, result planes out, the addend's planes, the multiplier once per sample, weights
+        nbytes = (4.0 * N * Hi * Wi * Ci + 4.0 * N * Ho * Wo * Co * (2 if add is not None else 1)
+                  + (mult.numel() * mult.element_size() if mult is not None else 0) + 4.0 * wplanes[0].numel())
         if wplanes_chunked is not None:
             # [2, T, Ci / 16, Co, 16]: the persistent window form where the library finds the launch eligible
             assert wplanes_chunked.shape == (2, wplanes.shape[1], Ci // 16, Co, 16) and wplanes_chunked.is_contiguous()
@@ -539,14 +544,14 @@ class HipKernels:
                 len(taps), flat, _ptr(z), None if add is None else _ptr(add.planes[0]),
                 None if add is None else _ptr(add.planes[1]), None if add is None else _ptr(add.sexp), _ptr(mult), m_is_float,
                 _ptr(mult_amax), mask_rows, _ptr(scale), _ptr(scale_amax), _ptr(planes[0]), _ptr(planes[1]), _ptr(sexp),
-                _ptr(amax), int(cfg), self._stream(dev))), "lk_conv_nhwc_f16x2_vjp_wc")
+                _ptr(amax), int(cfg), self._stream(dev)), nbytes=nbytes), "lk_conv_nhwc_f16x2_vjp_wc")
             return SplitTensor(planes, sexp, amax)
         self._rc(self._timed("conv16", work, dev, lambda: self.lib.lk_conv_nhwc_f16x2_vjp(
             _ptr(x.planes[0]), _ptr(x.planes[1]), _ptr(x.sexp), _ptr(x.amax), N, Hi, Wi, Ci, _ptr(wplanes[0]), _ptr(wplanes[1]),
             _ptr(wsexp), _ptr(w_l1), Co, Ho, Wo, len(taps), flat, _ptr(z),
             None if add is None else _ptr(add.planes[0]), None if add is None else _ptr(add.planes[1]),
             None if add is None else _ptr(add.sexp), _ptr(mult), m_is_float, _ptr(mult_amax), mask_rows, _ptr(scale),
-            _ptr(scale_amax), _ptr(planes[0]), _ptr(planes[1]), _ptr(sexp), _ptr(amax), int(cfg), self._stream(dev))),
+            _ptr(scale_amax), _ptr(planes[0]), _ptr(planes[1]), _ptr(sexp), _ptr(amax), int(cfg), self._stream(dev)), nbytes=nbytes),
             "lk_conv_nhwc_f16x2_vjp")
         return SplitTensor(planes, sexp, amax)
 
@@ -845,10 +850,10 @@ class HipKernels:
                                  tiles.shape[0], self._stream(x.device))), "lk_conv3x3_pixpair_accumulate_f32")
         return blocks
 
-    #: ``False`` (env LK_PIXPAIR16=0): the pixel-pair products stay on the exact-fp32 MFMA kernel.  The split-fp16 kernel
+    #: ``False``: the pixel-pair products stay on the exact-fp32 MFMA kernel.  The split-fp16 kernel
     #: requests the block it read-modify-writes at the START of its (short) tile: 0.87 vs 1.39 ms per c4 step — the
     #: dependent 16 KB read at the end of every 8-stage tile, not traffic or the matrix pipe, was what bound the product
-    use_pixpair16 = os.environ.get("LK_PIXPAIR16", "1") != "0"
+    use_pixpair16 = True
 
     def pixpair_accumulate_split(self, xs, alpha, blocks, plan):
         """:meth:`pixpair_accumulate_nhwc` on a SplitTensor ``xs [B, H, W, Cin]`` (three fp16 MFMAs per product block)."""
@@ -1025,11 +1030,12 @@ class HipKernels:
             C = (H.shape[0]) // (D + (1 if has_bias else 0))
         nb = self.lib.lk_ll_ggn_workspace_bytes(B, C, D)
         ws = self._workspace(nb, phi.device)
-        self._rc(
-            self.lib.lk_ll_ggn_full_f32(_ptr(phi), _ptr(probs), B, C, D, 1 if has_bias else 0, float(alpha), _ptr(H),
-                                        _ptr(ws), ws.numel(), self._stream(phi.device)),
-            "lk_ll_ggn_full_f32",
-        )
+        Dt = D + (1 if has_bias else 0)
+        # structured form: C block-diagonal Grams of sqrt(p_j) phi~ minus the Gram of Y = [p_j phi~]_j — about 2 C^2 Dt^2 flop per
+        # sample against the 2 C^3 Dt^2 of J^T Lambda J as the reference writes it (curvature.py:375-411)
+        self._rc(self._timed("llggn", 2.0 * B * C * C * Dt * Dt, phi.device, lambda: self.lib.lk_ll_ggn_full_f32(
+            _ptr(phi), _ptr(probs), B, C, D, 1 if has_bias else 0, float(alpha), _ptr(H), _ptr(ws), ws.numel(),
+            self._stream(phi.device)), nbytes=4.0 * (B * D + B * C + (C * Dt) ** 2)), "lk_ll_ggn_full_f32")
         return H
 
     # ---- eigensolver --------------------------------------------------------------------------
@@ -1171,11 +1177,11 @@ class HipKernels:
     #: most outputs the fused weight-sharing predictive holds in accumulators at once
     quadform_shared_max_outputs = 10
 
-    #: ``True`` (env LK_QUAD16=1): the quadratic-form kernel uses the two-piece fp16 products when its caller knows
+    #: ``True``: the quadratic-form kernel uses the two-piece fp16 products when its caller knows
     #: bounds of the operands.  Off by default: measured equal on the c4 predictive (3.6 k samples/s either way) — the
     #: kernel is bound by the L2 -> register traffic of its operand chunks (28 KB per 1.3 MFLOP chunk and workgroup) and
     #: by the in-flight splitting, not by the matrix pipe
-    use_quad16 = os.environ.get("LK_QUAD16", "0") != "0"
+    use_quad16 = False
 
     def kron_quadform_shared(self, u, v, l1, l2, delta, fvar, u_bound=None, v_bound=None, seed_major=False):
         """``u [B, C, Do, L]`` (``seed_major``: ``[C, B, Do, L]``), ``v [B, Dk, L]`` (eigenbasis projections);
@@ -1279,11 +1285,12 @@ class HipKernels:
         fvar = torch.empty(B, C, C, dtype=torch.float32, device=phi.device)
         nb = self.lib.lk_dense_quadform_ll_workspace_bytes(B, C, D)
         ws = self._workspace(nb, phi.device)
-        self._rc(
-            self.lib.lk_dense_quadform_ll_f32(_ptr(phi), _ptr(Sigma), B, C, D, 1 if has_bias else 0, _ptr(fvar), _ptr(ws),
-                                              ws.numel(), self._stream(phi.device)),
-            "lk_dense_quadform_ll_f32",
-        )
+        Dt = D + (1 if has_bias else 0)
+        # phi~^T Sigma_ck phi~ for the C (C + 1) / 2 class pairs: C (C + 1) Dt^2 flop per sample (as written in the reference,
+        # baselaplace.py:1683-1684 through [B, C, P] Jacobians: 2 C P^2)
+        self._rc(self._timed("llquad", float(B) * C * (C + 1) * Dt * Dt, phi.device, lambda: self.lib.lk_dense_quadform_ll_f32(
+            _ptr(phi), _ptr(Sigma), B, C, D, 1 if has_bias else 0, _ptr(fvar), _ptr(ws), ws.numel(), self._stream(phi.device)),
+            nbytes=4.0 * (B * D + (C * Dt) ** 2 + B * C * C)), "lk_dense_quadform_ll_f32")
         return fvar
 
 

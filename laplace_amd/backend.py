@@ -41,8 +41,8 @@ from laplace_amd.kron import HipKron
 from laplace_amd.refapi import EFInterface, GGNInterface
 
 
-#: ``LK_ROT_CONV=0``: the Kron predictive's eigenbasis rotation of the unfolded inputs stays a library convolution
-_OWN_ROTATION = os.environ.get("LK_ROT_CONV", "1") != "0"
+#: ``False``: the Kron predictive's eigenbasis rotation of the unfolded inputs stays a library convolution
+_OWN_ROTATION = True
 
 
 def shared_operands(tap, g, B, C, Q1=None, Q2=None, bounds=None):
@@ -577,10 +577,10 @@ class _HipCurvatureMixin:
             return acc.loss[0].clone(), HipKron(None, pending=acc)
         return acc.finalize()
 
-    #: ``False`` (env LK_LAZY_KRON=0): ``kron`` returns its minibatch already in the reference's layout
-    lazy_kron = os.environ.get("LK_LAZY_KRON", "1") != "0"
-    #: ``False`` (env LK_LAZY_PIXPAIR=0): a lazily handed-over minibatch computes its 3x3 A factors itself
-    lazy_pixpair = os.environ.get("LK_LAZY_PIXPAIR", "1") != "0"
+    #: ``False``: ``kron`` returns its minibatch already in the reference's layout
+    lazy_kron = True
+    #: ``False``: a lazily handed-over minibatch computes its 3x3 A factors itself
+    lazy_pixpair = True
 
     def _diag_impl(self, x, y, seeds_fn, alpha):
         K = get_kernels()
@@ -662,6 +662,21 @@ class KronAccumulator:
     read.  ``overlap=False`` switches all of it off (the serial schedule the tests compare against).
     """
 
+    # ---- path selectors (class attributes; an instance may override them before its first minibatch; each is exercised
+    #      against the default path by tests/test_gpu_switches.py).  Environment switches are kept only for what a USER
+    #      chooses per run: LK_LANES, LK_COALESCE (here), LK_SWEEP / LK_SPLIT_SWEEP (backend), LK_LIB, LK_CONV_CONFIG (_lib).
+    #: ``False``: A factors of 3x3 / stride-1 convolutions per minibatch instead of through the pixel-pair accumulators
+    use_pixgram = True
+    #: ``False``: the BatchNorm scale of a shortcut branch is applied to every minibatch's cotangent instead of once per fit
+    _defer_bn = True
+    #: ``False``: the split-K slabs of the NCHW route's G factors are reduced per launch instead of once per fit
+    _persist_slabs = True
+    #: minibatches stacked per pixel-pair launch: the kernel is bound by the read-modify-write of its blocks, which
+    #: happens once per LAUNCH, so stacking the NHWC inputs of consecutive minibatches divides that traffic
+    pix_group = 8
+    #: ``False``: the main stream waits for the factor kernels at the end of every minibatch
+    lag_join = True
+
     def __init__(self, backend, N: int, kfac_approx: str = "expand", overlap: bool = True):
         # a model in another floating dtype is served by the backend's fp32 twin (see `_twin`): minibatches go in as fp32,
         # the factors come back in the model's dtype — like `backend.kron`, which the reference's literal loop calls
@@ -671,20 +686,12 @@ class KronAccumulator:
             backend = twin
         self.backend, self.N, self.kfac_approx = backend, N, kfac_approx
         self.overlap = overlap
-        self.use_pixgram = os.environ.get("LK_PIXGRAM", "1") != "0"
-        self._defer_bn = os.environ.get("LK_DEFER_BN", "1") != "0"
-        self._persist_slabs = os.environ.get("LK_PERSIST_SLABS", "1") != "0"
-        #: minibatches stacked per pixel-pair launch: the kernel is bound by the read-modify-write of its blocks, which
-        #: happens once per LAUNCH, so stacking the NHWC inputs of consecutive minibatches divides that traffic
-        self.pix_group = max(1, int(os.environ.get("LK_PIX_GROUP", "8")))
         self._side = None
         self._side_done = None  # event at the end of the previous minibatch's side-stream work (lagged join)
         self._side_older = []   # ... of the minibatches before that which the main stream has not waited for yet
         #: minibatches whose factor kernels may still be running when the next one starts (measured with the lanes' streams
         #: at high priority: 2 or 3 gain 1 % in the steady state and lose 3 - 5 % on a 20-minibatch fit, whose tail grows)
         self.lag_depth = 1
-        #: ``False`` (env LK_LAG_JOIN=0): the main stream waits for the factor kernels at the end of every minibatch
-        self.lag_join = os.environ.get("LK_LAG_JOIN", "1") != "0"
         self.factors = None  # per tap: [G, A]
         self.loss = None
         self._taps_meta = None
@@ -939,8 +946,10 @@ class KronAccumulator:
             self._pix[idx] = (geo, flat[off:off + n].view(shape))
             off += pad(n)
 
-    #: streams the per-tap work of `_flush_pixgrams` is dealt to (env LK_FLUSH_STREAMS; 1 = the calling stream only)
-    flush_streams = max(1, int(os.environ.get("LK_FLUSH_STREAMS", "3")))
+    #: streams the per-tap work of `_flush_pixgrams` is dealt to (1 = the calling stream only)
+    flush_streams = 3
+    #: queue priority of the lanes' streams (the device's range is 0 .. -1; 0: all streams alike)
+    lane_priority = -1
 
     def _flush_pixgrams(self, only=None):
         """fold the pixel-pair accumulators into the (native-order) A factors; idempotent.  The taps are independent of
@@ -989,8 +998,8 @@ class KronAccumulator:
             if on_device:
                 cache = self.backend.__dict__.setdefault("_lane_streams", {})
                 # the lanes' streams (forward + reverse sweep: the critical path) get a higher queue priority than the streams
-                # the factor kernels run on (env LK_LANE_PRIO=0: all alike; measured 7.35 -> 6.96 ms per step)
-                prio = int(os.environ.get("LK_LANE_PRIO", "-1"))
+                # the factor kernels run on (`lane_priority = 0`: all alike; measured 7.35 -> 6.96 ms per step)
+                prio = int(self.lane_priority)
                 streams = cache.setdefault((dev, self.lanes, prio), [torch.cuda.Stream(dev, priority=prio) for _ in range(self.lanes)])
             self._lane_accs = []
             for k in range(self.lanes):
@@ -1172,13 +1181,14 @@ class KronAccumulator:
 
     def coalesce_target(self, x) -> int:
         """samples per stacked sweep for minibatches shaped like ``x`` (0: this model / minibatch does not stack): work per
-        sample grows with the parameter count, and 2^26 parameter-samples per sweep is still a sub-millisecond step"""
+        sample grows with the parameter count; 2^27 parameter-samples per sweep keeps a sweep around a millisecond (LeNet-5:
+        eight loader batches of 256; ResNet-18 at batch 128: never)"""
         b = self.backend
         if (not self.coalesce or not torch.is_tensor(x) or not x.is_floating_point() or x.dim() < 2
                 or getattr(b, "stochastic", False) or b.last_layer):
             return 0
         n_params = sum(p.numel() for p in b.params)
-        target = min(8192, (1 << 26) // max(n_params, 1), (1 << 24) // max(x[0].numel(), 1))
+        target = min(8192, (1 << 27) // max(n_params, 1), (1 << 24) // max(x[0].numel(), 1))
         return target if target >= 2 * x.shape[0] else 0
 
     def _flush_stash(self):

@@ -1668,8 +1668,11 @@ static int cu_count() {
 // default number of column tiles of a pixel tile that share an XCD in the persistent window form (measured per shape:
 // profiles/r05_winp_coloc.md); config bits 28-29 of a launch override it
 static int coloc_default(int Ci, int Co) {
-  (void)Ci, (void)Co;
-  return 1;
+  // stand-alone launches at batch 9 x 128 (profiles/r05_winp_variants.md): 128 channels 270 -> 262 us with 2, 256 channels
+  // 250 -> 240 with 4, 512 channels 262 -> 257 with 4 (8 = every column on one XCD: back to 261, its L2 then streams all eight
+  // weight slices); 64 channels have one column tile
+  (void)Ci;
+  return Co >= 256 ? 4 : (Co == 128 ? 2 : 1);
 }
 
 template <typename CFG>

@@ -107,11 +107,11 @@ class SplitSweep(SeedBatchedSweep):
         self.split_reason = self._split_eligible()
         self.split_ok = self.split_reason is None
 
-    #: ``False`` (env LK_FUSE_VJP=0): every backward-data writes fp32 and the element-wise VJP kernel runs on it
-    fuse_vjp = os.environ.get("LK_FUSE_VJP", "1") != "0"
-    #: ``False`` (env LK_FUSE_STRIDED=0): strided convolutions run class by class into an fp32 tensor (one launch per
+    #: ``False``: every backward-data writes fp32 and the element-wise VJP kernel runs on it
+    fuse_vjp = True
+    #: ``False``: strided convolutions run class by class into an fp32 tensor (one launch per
     #: residue class and branch) instead of the strided fused launch
-    fuse_strided = os.environ.get("LK_FUSE_STRIDED", "1") != "0"
+    fuse_strided = True
 
     def _consumes_lazily(self, node) -> bool:
         """nodes whose rule hands all incoming cotangent parts to ``_to_split`` (which can fuse a pending convolution)"""
@@ -213,8 +213,8 @@ class SplitSweep(SeedBatchedSweep):
         return None
 
     # ---- forward: own convolution + fused BatchNorm/add/activation kernels on NHWC -----------------------------------
-    #: ``False`` (env LK_NHWC_FORWARD=0): the forward stays on the library's NCHW convolutions
-    nhwc_forward = __import__("os").environ.get("LK_NHWC_FORWARD", "1") != "0"
+    #: ``False``: the forward stays on the library's NCHW convolutions
+    nhwc_forward = True
 
     @torch.no_grad()
     def forward(self, x, need_vjp: bool = True, keep_tap_splits: bool = False):

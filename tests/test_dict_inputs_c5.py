@@ -108,3 +108,94 @@ def test_dict_inputs_last_layer_kron_on_emulation():
 @pytest.mark.gpu
 def test_dict_inputs_last_layer_kron_gpu():
     _run("cuda")
+
+
+# ---- c5 at its BASELINE shape: BERT-base features (BertConfig(): 12 x 768, random init), Linear(768, 2) head -------------
+def _run_bert(dev, n, T, bs):
+    """Last-layer KFAC + GLM predictive of `BertForSequenceClassification(BertConfig(num_labels=2))` on dict batches
+    (docs/huggingface_example.md of the reference; lllaplace.py:212-237 feeds the head's input features to the backend):
+    factors against the fp64 oracle on fp64 FEATURES of the same weights (the whole encoder run in fp64 on the CPU), the
+    predictive variance against the oracle's last-layer Jacobians pushed through matrix.py:406-461."""
+    import copy
+
+    transformers = pytest.importorskip("transformers")
+    from laplace_amd.laplace import HipLaplace
+
+    class BertHead(nn.Module):  # the wrapper of the reference's HuggingFace example: dict batch in, logits out
+        def __init__(self, cfg):
+            super().__init__()
+            self.hf = transformers.BertForSequenceClassification(cfg)
+
+        def forward(self, data):
+            return self.hf(input_ids=data["input_ids"], attention_mask=data["attention_mask"]).logits
+
+    torch.manual_seed(711)
+    cfg = transformers.BertConfig(num_labels=2)
+    assert (cfg.hidden_size, cfg.num_hidden_layers) == (768, 12)
+    model = BertHead(cfg).eval()
+    m64 = copy.deepcopy(model).double().eval()
+    model = model.to(dev)
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(cfg.vocab_size, (n, T), generator=g)
+    mask = torch.ones(n, T, dtype=torch.long)
+    lens = torch.randint(T // 2, T + 1, (n,), generator=g)
+    mask[torch.arange(T)[None, :] >= lens[:, None]] = 0
+    yy = torch.randint(2, (n,), generator=g)
+
+    class Loader(list):
+        dataset = range(n)
+
+    batches = [{"input_ids": ids[i:i + bs], "attention_mask": mask[i:i + bs], "labels": yy[i:i + bs]} for i in range(0, n, bs)]
+    train = Loader([{k: v.to(dev) for k, v in b.items()} for b in batches])
+    la = HipLaplace(model, "classification", "last_layer", "kron", last_layer_name="hf.classifier", prior_precision=1.0)
+    la.fit(train)
+    head64 = nn.Linear(768, 2).double()
+    head64.load_state_dict(m64.hf.classifier.state_dict())
+    acc, feats = None, []
+    with torch.no_grad():
+        for b in batches:
+            feats.append(m64.hf.bert(input_ids=b["input_ids"], attention_mask=b["attention_mask"]).pooler_output)  # (dropout: eval)
+    for b, phi in zip(batches, feats):
+        _, kf = co.kfac_ggn(head64, phi, b["labels"], n, "classification")
+        acc = kf if acc is None else co.kron_add(acc, kf)
+    worst = 0.0
+    for F_, G_ in zip(la.H_facs.kfacs, acc):
+        for a, w in zip(F_, G_):
+            assert a.shape == w.shape
+            worst = max(worst, (a.double().cpu() - w).abs().max().item() / (w.abs().max().item() + 1e-30))
+    assert la.H_facs.kfacs[0][1].shape[0] == 768
+    assert worst < 1e-4, f"c5 factors vs the fp64 oracle on fp64 BERT features: {worst:.2e}"
+    f_mu, f_var = la._glm_predictive_distribution(train[0])
+    Qs, ls = co.kron_decompose(acc)
+    Js = co.last_layer_jacobians(feats[0], 2, True)
+    want = co.functional_variance_kron(Js, Qs, ls, float(la.prior_precision))
+    err = (f_var.double().cpu() - want).abs().max().item() / want.abs().max().item()
+    err_mu = (f_mu.double().cpu() - head64(feats[0]).detach()).abs().max().item() / head64(feats[0]).abs().max().item()
+    assert err < 1e-4 and err_mu < 1e-4, (err, err_mu)
+    before = la.log_marginal_likelihood().item()
+    la.optimize_prior_precision(pred_type="glm", method="marglik", n_steps=20, lr=0.1, prior_structure="layerwise")
+    assert la.log_marginal_likelihood().item() >= before - 1e-3
+    try:
+        from tests.parity_log import record_error
+
+        record_error(worst), record_error(err)
+    except Exception:
+        pass
+
+
+def test_c5_bert_base_features_last_layer_kfac_on_emulation():
+    """host logic of the BASELINE c5 shape (BertConfig() encoder, Linear(768, 2) head) at a short sequence, on the emulation"""
+    from laplace_amd import _lib
+    from tests.emulated_kernels import EmulatedKernels
+
+    prev = _lib.set_kernels_for_testing(EmulatedKernels())
+    try:
+        _run_bert("cpu", n=8, T=16, bs=4)
+    finally:
+        _lib.set_kernels_for_testing(prev)
+
+
+@pytest.mark.gpu
+def test_c5_bert_base_features_last_layer_kfac_at_the_baseline_shape_gpu():
+    """BASELINE.json c5 as quoted: sequence 128, batch 32 (two minibatches), on the device"""
+    _run_bert("cuda", n=64, T=128, bs=32)

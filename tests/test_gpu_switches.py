@@ -1,4 +1,5 @@
-"""Every path selector of the product (the ``LK_*`` environment switches, read into class / instance attributes) gives
+"""Every path selector of the product (class / instance attributes; the case names are the environment switches most of
+them were up to round 4 — round 5 kept LK_LANES, LK_COALESCE, LK_SWEEP, LK_SPLIT_SWEEP, LK_LIB, LK_CONV_CONFIG as switches) gives
 the same curvature and the same predictive as the default path: a c4-shaped KFAC fit (ResNet-18, two minibatches of 16,
 one of 5) + Kron GLM predictive with ONE selector flipped at a time, against the default run.  A switch nobody tests is a
 code path nobody knows to work (-m gpu)."""
@@ -105,6 +106,10 @@ CASES = {
     "LK_QUAD16=1": dict(kernel_attrs={"use_quad16": True}),
     "LK_WINP=0 (generic fused launches)": dict(kernel_attrs={"use_winp": False}),
     "LK_CONV_CONFIG plain row order": dict(kernel_attrs={"conv_config": 2 | 32768}),
+    "LK_CONV_CONFIG round-4 window staging": dict(kernel_attrs={"conv_config": 2 | (1 << 30)}),
+    "LK_CONV_CONFIG two columns per XCD": dict(kernel_attrs={"conv_config": 2 | (1 << 28)}),
+    "LK_CONV_CONFIG eight columns per XCD": dict(kernel_attrs={"conv_config": 2 | (3 << 28)}),
+    "lane_priority=0": dict(acc_attrs={"lane_priority": 0}),
 }
 
 

@@ -120,8 +120,10 @@ def test_eleven_minibatches_of_128_with_default_scheduling(resnet, monkeypatch):
     loss, H = acc.finalize()
 
     # (2) every scheduling feature off
-    monkeypatch.setenv("LK_PIX_GROUP", "1")
-    monkeypatch.setenv("LK_LAG_JOIN", "0")
+    from laplace_amd.backend import KronAccumulator
+
+    monkeypatch.setattr(KronAccumulator, "pix_group", 1)
+    monkeypatch.setattr(KronAccumulator, "lag_join", False)
     ser = b.kron_accumulator(N, overlap=False)
     assert ser.pix_group == 1 and not ser.lag_join and not ser.overlap
     for X, y in batches:
@@ -191,8 +193,10 @@ def test_a_ragged_last_minibatch_as_in_a_50k_fit(resnet, monkeypatch):
     for X, y in batches:
         acc.add_batch(X, y)
     loss, H = acc.finalize()
-    monkeypatch.setenv("LK_PIX_GROUP", "1")
-    monkeypatch.setenv("LK_LAG_JOIN", "0")
+    from laplace_amd.backend import KronAccumulator
+
+    monkeypatch.setattr(KronAccumulator, "pix_group", 1)
+    monkeypatch.setattr(KronAccumulator, "lag_join", False)
     ser = b.kron_accumulator(N, overlap=False)
     for X, y in batches:
         ser.add_batch(X, y)

@@ -97,7 +97,9 @@ def test_literal_loop_leaves_the_pixel_pair_products_to_the_running_sum(dev, gro
     does.  Same factors as the eager per-minibatch kernels, whatever is read when, and no operand is changed."""
     from laplace_amd import HipGGN, HipKron
 
-    monkeypatch.setenv("LK_PIX_GROUP", str(group))
+    from laplace_amd.backend import KronAccumulator
+
+    monkeypatch.setattr(KronAccumulator, "pix_group", group)
     C = 64 if dev == "cuda" else 8
     torch.manual_seed(3)
     model = torch.nn.Sequential(

@@ -1,14 +1,57 @@
-# Secondary measurements with the final kernels: small configs, c5 (BERT-base), prior sweep on the c4 posterior, PMC
-# pass over the weight-sharing predictive kernel.  Writes under gpurun_out/.
-mkdir -p gpurun_out
+#!/bin/bash
+# The evidence pass of a round on the MI355X box, on the FINAL kernel sources (the PMC table's stamp must match them):
+#   1. the whole -m gpu suite; the parity numbers its rel() helpers measured -> gpurun_out/<R>_parity_errors_<tag>.log
+#   2. PMC traffic passes over the bench command (FETCH_SIZE / WRITE_SIZE in separate runs, kernel-trace only)
+#   3. rocprofv3 --kernel-trace --stats of the driver's bench command, and of 20 serial steady-state steps
+#   4. the bench lines: the driver's `--steps 20 --warmup 5` and the default flags
+#   5. smoke()
+# Writes under gpurun_out/; copy what is to be judged into profiles/.
+# usage: bash tools/gpu_evidence.sh <round, e.g. r05> [tag] [notests] [nodefault]
+R5=${1:-r05}; TAG=${2:-v1}
+mkdir -p gpurun_out profiles
 export TMPDIR=/tmp
-timeout 300 python tools/small_configs.py > gpurun_out/small.log 2>&1; echo "small rc=$?" > gpurun_out/summary_ev.log
-timeout 600 python tools/c5_bert.py > gpurun_out/c5.log 2>&1; echo "c5 rc=$?" >> gpurun_out/summary_ev.log
-timeout 300 python tools/marglik_bench.py > gpurun_out/marglik.log 2>&1; echo "marglik rc=$?" >> gpurun_out/summary_ev.log
-rm -rf gpurun_out/pmc_qc
-cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE -d $GRAFT_REPO_ROOT/gpurun_out/pmc_qc -o qc -- python $GRAFT_REPO_ROOT/tools/quadconv_bench.py > $GRAFT_REPO_ROOT/gpurun_out/pmc_qc.log 2>&1
-echo "pmc rc=$?" >> $GRAFT_REPO_ROOT/gpurun_out/summary_ev.log
-cd $GRAFT_REPO_ROOT
-python tools/rocpd_pmc.py gpurun_out/pmc_quadconv.md gpurun_out/pmc_qc/qc_results.db >> gpurun_out/summary_ev.log 2>&1
-rm -rf gpurun_out/pmc_qc
-tail -1 gpurun_out/small.log | cut -c1-600; tail -1 gpurun_out/c5.log | cut -c1-700; tail -1 gpurun_out/marglik.log; cat gpurun_out/pmc_quadconv.md | cut -c1-330; cat gpurun_out/summary_ev.log
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R
+S=gpurun_out/${R5}_summary_$TAG.log; : > $S
+if [[ " $* " != *" notests "* ]]; then
+  timeout 1500 python -m pytest tests -m gpu -q -rs --durations=10 > gpurun_out/${R5}_gpu_tests_$TAG.log 2>&1; echo "tests rc=$?" >> $S
+  tail -4 gpurun_out/${R5}_gpu_tests_$TAG.log >> $S
+  cp gpurun_out/parity_errors.log gpurun_out/${R5}_parity_errors_$TAG.log 2>/dev/null
+fi
+LIGHT="--no-cpu-baseline --no-predictive --no-eigh --no-extras --no-check"
+rm -rf gpurun_out/pmc gpurun_out/prof_$TAG gpurun_out/ks_$TAG
+for c in FETCH_SIZE WRITE_SIZE; do
+  cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/pmc -o pmc_$c -- python $R/bench.py --steps 2 --warmup 1 $LIGHT > $R/gpurun_out/pmc_$c.log 2>&1
+  echo "pmc $c rc=$?" >> $R/$S
+  cd $R
+done
+python tools/pmc_traffic.py $(find gpurun_out/pmc -name "*FETCH_SIZE*.db" | head -1) $(find gpurun_out/pmc -name "*WRITE_SIZE*.db" | head -1) gpurun_out/${R5}_pmc_traffic_bench_c4_$TAG.json gpurun_out/${R5}_pmc_traffic_bench_c4_$TAG.md > /dev/null 2>> $S
+rm -rf gpurun_out/pmc
+cp gpurun_out/${R5}_pmc_traffic_bench_c4_$TAG.json profiles/   # (so that the bench runs below find a table with a matching stamp)
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o p -- python $R/bench.py --steps 20 --warmup 5 $LIGHT > $R/gpurun_out/prof_$TAG.log 2>&1; echo "trace rc=$?" >> $R/$S
+cd $R
+python tools/rocpd_stats.py $(find gpurun_out/prof_$TAG -name "*.db" | head -1) gpurun_out/${R5}_bench_c4_kernel_stats_$TAG.md > /dev/null 2>&1
+rm -rf gpurun_out/prof_$TAG
+cd /tmp && timeout 600 rocprofv3 --kernel-trace -d $R/gpurun_out/ks_$TAG -o p -- python $R/tools/steps_only.py 20 serial > $R/gpurun_out/ks_$TAG.log 2>&1; echo "serial steps trace rc=$?" >> $R/$S
+cd $R
+python tools/rocpd_stats.py $(find gpurun_out/ks_$TAG -name "*.db" | head -1) gpurun_out/${R5}_steps_serial_kernel_stats_$TAG.md > /dev/null 2>&1
+rm -rf gpurun_out/ks_$TAG
+timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/${R5}_bench_k20_$TAG.log 2>&1; echo "bench k20 rc=$?" >> $S
+grep '^{' gpurun_out/${R5}_bench_k20_$TAG.log | tail -1 > gpurun_out/${R5}_bench_c4_k20_$TAG.json
+if [[ " $* " != *" nodefault "* ]]; then
+  timeout 900 python bench.py > gpurun_out/${R5}_bench_$TAG.log 2>&1; echo "bench rc=$?" >> $S
+  grep '^{' gpurun_out/${R5}_bench_$TAG.log | tail -1 > gpurun_out/${R5}_bench_c4_$TAG.json
+fi
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" >> $S 2>&1
+cat $S; python - <<PY
+import json
+for f in ("gpurun_out/${R5}_bench_c4_k20_$TAG.json", "gpurun_out/${R5}_bench_c4_$TAG.json"):
+    try:
+        d = json.loads(open(f).read())
+    except Exception as e:
+        print(f, "missing", e); continue
+    r = d["roofline"]
+    print(f, round(d["value"]), round(d["ms_per_step"], 3), "frac", round(r["frac"], 3), "bound", r.get("bound"), "frac_hbm", r.get("frac_hbm"),
+          "traffic", r["traffic"], str(r.get("traffic_source"))[:90])
+    print("  predictive", d.get("predictive_samples_per_s"), "eigh_ms", d.get("eigh_ms"), "others", {k: round(v.get("fit_ms", 0), 1) for k, v in (d.get("other_configs") or {}).items() if isinstance(v, dict)})
+PY

@@ -1,6 +1,6 @@
 """The reference's literal fit loop on c4 (ResNet-18, batch 128): ``H += backend.kron(X, y, N)[1]`` per minibatch
 (laplace/baselaplace.py:969-985), read into the public layout at the end — with the pixel-pair products left to the
-running sum (default) and with every minibatch computing its own A factors (LK_LAZY_PIXPAIR=0), beside the fused
+running sum (default) and with every minibatch computing its own A factors (`backend.lazy_pixpair = False`), beside the fused
 accumulator, all in one process.  usage: literal_loop_bench.py [n_minibatches]"""
 import os, sys, time
 import torch
