@@ -235,3 +235,40 @@ def test_a_caller_that_refills_one_device_buffer_per_minibatch():
     for F_, G_ in zip(H.kfacs, Hr.kfacs):
         for a, w in zip(F_, G_):
             assert (a - w).abs().max().item() <= 1e-5 * w.abs().max().item()
+
+
+def test_the_relu_margin_is_what_fp32_arithmetic_itself_does():
+    """The ReLU rows of this file sit at 4e-5 against fp64 products of a stock fp32 tape, tanh at 3e-7, and the explanation
+    (pre-activations within fp32 rounding of zero are decided differently by any two fp32 executions) was so far
+    asserted, not measured.  Measured here: 64 samples of the timed configuration through the kernels and through the oracle
+    (curvlinops.py:77-108 restated) run in fp32 AND in fp64 on the CPU — per factor block, the kernels' distance from the
+    fp64 oracle must be within 2 x of the fp32 oracle's own distance from it, or inside 1e-4 where fp32 itself is
+    (it is: both are logged separately, tests/parity_log.py)."""
+    import copy
+
+    from laplace_amd import HipGGN
+    from laplace_amd.nets import ResNet18
+    from oracle import curvature_oracle as co
+    from tests.parity_log import record_error
+
+    torch.manual_seed(711)
+    m32 = ResNet18(10, act=torch.relu).eval()
+    m64 = copy.deepcopy(m32).double()
+    n = 64 if DEV != "cpu" else 2
+    X, y = _batch(0)
+    X, y = X[:n].cpu(), y[:n].cpu()
+    acc = HipGGN(copy.deepcopy(m32).to(DEV), "classification").kron_accumulator(N)
+    acc.add_batch(X.to(DEV), y.to(DEV))
+    loss, H = acc.finalize()
+    _, kf64 = co.kfac_ggn(m64, X.double(), y, N, "classification")
+    _, kf32 = co.kfac_ggn(m32, X, y, N, "classification")
+    worst = worst32 = 0.0
+    for i, (F_, G64, G32) in enumerate(zip(H.kfacs, kf64, kf32)):
+        for j, (a, w, w32) in enumerate(zip(F_, G64, G32)):
+            r = (a.double().cpu() - w).abs().max().item() / (w.abs().max().item() + 1e-300)
+            r32 = (w32.double() - w).abs().max().item() / (w.abs().max().item() + 1e-300)
+            worst, worst32 = max(worst, r), max(worst32, r32)
+            assert r < max(1e-4, 2.0 * r32), f"block {i} factor {j}: kernels {r:.2e} from fp64, the fp32 oracle {r32:.2e}"
+    record_error(worst, "kernels-vs-fp64-oracle")
+    record_error(worst32, "fp32-oracle-vs-fp64-oracle")
+    print(f"timed configuration, {n} samples, ReLU: worst block kernels {worst:.2e}, fp32 CPU oracle {worst32:.2e} (both against the fp64 oracle)")

@@ -18,6 +18,7 @@ from laplace_amd.nets import ResNet18  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--profile", action="store_true")
 ap.add_argument("--batch", type=int, default=128)
+ap.add_argument("--quad16", action="store_true", help="also time the quadratic-form kernel on two-piece fp16 products (use_quad16)")
 args = ap.parse_args()
 dev = "cuda"
 torch.manual_seed(711)
@@ -50,6 +51,25 @@ def rate(x, reps):
 
 
 out["fused_samples_per_s"], fv = rate(X, 5)
+if args.quad16:  # A/B in one process (box-to-box variation exceeds what is compared here): default, quad16, default, quad16
+    ab = {"bf16x3": [out["fused_samples_per_s"]], "f16x2": []}
+    for _ in range(2):
+        K.use_quad16 = True
+        r, fv16 = rate(X, 5)
+        ab["f16x2"].append(r)
+        K.use_quad16 = False
+        ab["bf16x3"].append(rate(X, 5)[0])
+    out["quad16_ab_samples_per_s"] = ab
+    out["quad16_max_rel_diff"] = float((fv16 - fv).abs().max() / fv.abs().max())
+    prof = {}
+    for flag in (False, True):
+        K.use_quad16 = flag
+        K.profile = prof = {}
+        P.glm_variance_kron(backend, X, post)
+        torch.cuda.synchronize()
+        K.profile = None
+        out["families_ms_" + ("f16x2" if flag else "bf16x3")] = {k: round(sum(e[0].elapsed_time(e[1]) for e in v), 3) for k, v in prof.items()}
+    K.use_quad16 = False
 if not args.profile:
     small = X[:8]
     _, fv_small = rate(small, 1)
