@@ -216,6 +216,20 @@ int lk_conv_nhwc_f16x2(const void* in_h, const void* in_l, const int* in_sexp, i
                        int64_t T, const int* taps, const void* zero16, float* out, int accumulate, unsigned* amax_out,
                        int config, void* stream);
 
+/* lk_conv_nhwc_f16x2 with a dense, POSITION-contiguous output emitted as a split tensor: out_h / out_l [N][Co][Ho * Wo] fp16,
+ * scaled per entry of in_sexp (the whole tensor, or image by image) from the guaranteed bound
+ *     max|out_n| <= in_amax[n] * w_l1[0]        (in_amax: in_nsexp words, bit patterns, or NULL = 2^(15 - in_sexp[n]); w_l1:
+ *                                                max_co sum_{t,c} |Wt[t][co][c]|, device word)
+ * with the scale left in out_sexp[n].  (Ho * Wo) % 4 == 0; in_mul = the convolution's stride.  This is how the Kron predictive's
+ * eigenbasis rotations (laplace/utils/matrix.py:406-456: Q1^T over the output cotangents as a 1x1 convolution, the unfolded
+ * inputs times Q2 as a convolution whose filters are the eigenvectors) hand their results to
+ * lk_kron_quadform_shared_planes_f16x2: no fp32 round trip, nothing left to split inside the quadratic-form kernel. */
+int lk_conv_nhwc_f16x2_planes(const void* in_h, const void* in_l, const int* in_sexp, int64_t in_nsexp, const void* in_amax,
+                              int64_t N, int64_t Hi, int64_t Wi, int64_t Ci, const void* w_h, const void* w_l,
+                              const int* w_sexp, const float* w_l1, int64_t Co, int64_t Ho, int64_t Wo, int64_t in_mul, int64_t T,
+                              const int* taps, const void* zero16, void* out_h, void* out_l, int* out_sexp, int config,
+                              void* stream);
+
 /* lk_conv_nhwc_f16x2 with the element-wise VJP of the sweep fused into its epilogue (one dense launch: forward / stride-1
  * backward-data; Co % 8 == 0):
  *     o[n][i][j][c] = (conv[n][i][j][c] + add[n][i][j][c]) * M[(n,i,j) mod mask_rows][c] * scale[c]
@@ -472,6 +486,15 @@ int lk_kron_quadform_shared_f32(const float* u, const float* v, const float* l1,
 int lk_kron_quadform_shared_seedmajor_f32(const float* u, const float* v, const float* l1, const float* l2, const float* delta,
                                           int64_t B, int64_t C, int64_t Do, int64_t Dk, int64_t L, float* fvar, void* ws,
                                           size_t ws_bytes, void* stream);
+/* The same quadratic form on operands that ARRIVE split (round 5): u_h / u_l [C][B][Do][L] fp16 planes with the scale
+ * u_sexp[0] (seed-major), v_h / v_l [B][Dk][L] with one scale per sample (v_nsexp = B) or one for the tensor (v_nsexp = 1),
+ * as lk_conv_nhwc_f16x2_planes leaves them.  A chunk of 16 positions is then 8-byte copies into LDS, two 16-byte loads and
+ * C x three v_mfma_f32_32x32x16_f16 — the fp32-operand forms above spend as many vector-pipe cycles splitting in flight as
+ * their matrix pipe spends on the products.  L % 16 == 0, Do % 32 == 0, C <= 10; same workspace. */
+int lk_kron_quadform_shared_planes_f16x2(const void* u_h, const void* u_l, const int* u_sexp, const void* v_h, const void* v_l,
+                                         const int* v_sexp, int64_t v_nsexp, const float* l1, const float* l2,
+                                         const float* delta, int64_t B, int64_t C, int64_t Do, int64_t Dk, int64_t L, float* fvar,
+                                         void* ws, size_t ws_bytes, void* stream);
 /* lk_kron_quadform_shared_f32 with the products in the two-piece fp16 split (three v_mfma_f32_32x32x16_f16 per product
  * block instead of six bf16 ones): u_bound / v_bound are device words >= max|u|, max|v| from which the kernel derives
  * the power-of-two scales of its in-flight split (loose bounds only cost fixed-point range). */

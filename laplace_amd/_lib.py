@@ -66,6 +66,8 @@ SIGNATURES = {
     "lk_conv_prep_weights_f16x2": (_int, [_vp, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp]),
     "lk_conv_nhwc_f16x2": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64,
                                   _i64, _i64, _i64, _i64, _vp, _vp, _vp, _int, _vp, _int, _vp]),
+    "lk_conv_nhwc_f16x2_planes": (_int, [_vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64,
+                                         _i64, _vp, _vp, _vp, _vp, _vp, _int, _vp]),
     "lk_conv_nhwc_f16x2_vjp": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64,
                                       _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _i64, _vp, _vp, _vp, _vp, _vp,
                                       _vp, _int, _vp]),
@@ -110,6 +112,8 @@ SIGNATURES = {
     "lk_kron_quadform_linear_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "lk_diag_quadform_linear_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "lk_quadform_shared_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
+    "lk_kron_quadform_shared_planes_f16x2": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
+                                                    _vp, _vp, _sz, _vp]),
     "lk_kron_quadform_shared_f16x2": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "lk_kron_quadform_shared_seedmajor_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "lk_kron_quadform_shared_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
@@ -492,6 +496,26 @@ class HipKernels:
             _ptr(wsexp), Co, Hc, Wc, in_mul, out.shape[1], out.shape[2], out_step, oh0, ow0, len(taps), flat, _ptr(z),
             _ptr(out), 1 if accumulate else 0, _ptr(amax_out), int(cfg), self._stream(out.device))), "lk_conv_nhwc_f16x2")
         return out
+
+    def conv_nhwc_f16x2_planes(self, x, wplanes, wsexp, w_l1, Ho, Wo, in_mul, taps, config=None):
+        """lk_conv_nhwc_f16x2_planes: the convolution of SplitTensor ``x [N, Hi, Wi, Ci]`` with ``wplanes [2, T, Co, Ci]``,
+        position-contiguous and ALREADY SPLIT: SplitTensor ``[N, Co, Ho * Wo]`` with the scales of ``x``'s granularity
+        (one for the tensor or one per image), each from the bound ``max|x_n| * w_l1`` (no pass over the output)"""
+        N, Hi, Wi, Ci = x.planes.shape[1:]
+        Co = wplanes.shape[2]
+        dev = x.planes.device
+        assert wplanes.shape[3] == Ci and (Ho * Wo) % 4 == 0
+        planes = torch.empty((2, N, Co, Ho * Wo), dtype=torch.float16, device=dev)
+        sexp = torch.empty(x.sexp.numel(), dtype=torch.int32, device=dev)
+        flat = (ctypes.c_int * (3 * len(taps)))(*[int(v) for t in taps for v in t])
+        cfg = self.conv_config if config is None else config
+        amax = x.amax if (x.amax is not None and x.amax.numel() == x.sexp.numel()) else None
+        work = 2.0 * N * Co * Ci * self.conv_valid_pairs(Ho, Wo, in_mul, Hi, Wi, taps) if self.profile is not None else 0.0
+        self._rc(self._timed("conv16", work, dev, lambda: self.lib.lk_conv_nhwc_f16x2_planes(
+            _ptr(x.planes[0]), _ptr(x.planes[1]), _ptr(x.sexp), x.sexp.numel(), _ptr(amax), N, Hi, Wi, Ci, _ptr(wplanes[0]),
+            _ptr(wplanes[1]), _ptr(wsexp), _ptr(w_l1), Co, Ho, Wo, in_mul, len(taps), flat, _ptr(self._zero16(dev)),
+            _ptr(planes[0]), _ptr(planes[1]), _ptr(sexp), int(cfg), self._stream(dev))), "lk_conv_nhwc_f16x2_planes")
+        return SplitTensor(planes, sexp)
 
     #: ``False``: fused 64-channel launches stay on the generic kernel (see :meth:`conv_winp_eligible`)
     use_winp = True
@@ -1218,6 +1242,26 @@ class HipKernels:
                 self._stream(u.device))),
             "lk_kron_quadform_shared_f32",
         )
+        return fvar
+
+    #: ``False``: the Kron predictive's rotations emit fp32 and the quadratic-form kernel splits in flight (three bf16 pieces)
+    use_quad_planes = True
+
+    def kron_quadform_shared_planes(self, u, v, l1, l2, delta, fvar, C):
+        """lk_kron_quadform_shared_planes_f16x2: ``u`` SplitTensor ``[C * B, Do, L]`` (seed-major, one scale), ``v`` SplitTensor
+        ``[B, Dk, L]`` (one scale per sample or one) — the outputs of :meth:`conv_nhwc_f16x2_planes`; ``fvar [B, C, C] +=``"""
+        for t, nm in ((l1, "l1"), (l2, "l2"), (delta, "delta"), (fvar, "fvar")):
+            _check(t, nm)
+        _one_scale(u, "kron_quadform_shared_planes (u)")
+        CB, Do, L = u.shape
+        B, Dk = v.shape[0], v.shape[1]
+        if CB != C * B or v.shape[2] != L or L % 16 or Do % 32:
+            raise LaplaceHipError("kron_quadform_shared_planes: u [C * B, Do, L], v [B, Dk, L], L % 16 == 0, Do % 32 == 0")
+        ws = self._workspace(self.lib.lk_quadform_shared_workspace_bytes(B, C, Do, Dk), fvar.device)
+        self._rc(self._timed("quadconv", 2.0 * B * C * L * Do * Dk, fvar.device, lambda: self.lib.lk_kron_quadform_shared_planes_f16x2(
+            _ptr(u.planes[0]), _ptr(u.planes[1]), _ptr(u.sexp), _ptr(v.planes[0]), _ptr(v.planes[1]), _ptr(v.sexp), v.sexp.numel(),
+            _ptr(l1), _ptr(l2), _ptr(delta), B, C, Do, Dk, L, _ptr(fvar), _ptr(ws), ws.numel(), self._stream(fvar.device))),
+            "lk_kron_quadform_shared_planes_f16x2")
         return fvar
 
     def diag_quadform_shared(self, u, v, var_w, fvar):

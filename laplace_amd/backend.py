@@ -61,6 +61,19 @@ def shared_operands(tap, g, B, C, Q1=None, Q2=None, bounds=None):
         Do = m.out_channels
         Dk = m.weight[0].numel()
         rotated = False
+        own_v = (Q2 is not None and _OWN_ROTATION and hasattr(K, "conv_nhwc_f16x2") and cv._geometry_ok(m)
+                 and m.in_channels % 32 == 0 and Dk % 8 == 0)
+        if (isinstance(g, SplitTensor) and Q1 is not None and bounds is not None and not tap.has_bias and _OWN_ROTATION and own_v
+                and getattr(K, "use_quad_planes", False) and Do % 32 == 0 and (g.shape[1] * g.shape[2]) % 16 == 0
+                and C <= K.quadform_shared_max_outputs):
+            # both rotations on our convolution kernel with SPLIT, position-contiguous outputs (lk_conv_nhwc_f16x2_planes):
+            # u = Q1^T g seed-major [C * B, Do, L] with one scale, v = the unfolded inputs in Q2's basis [B, Dk, L] with one
+            # scale per sample — what lk_kron_quadform_shared_planes_f16x2 stages without splitting anything
+            u = cv.rotate_channels(g, Q1, Q1, planes=True)
+            filt = Q2.T.reshape(Dk, *m.weight.shape[1:])
+            v = cv.conv_forward_filters(m, a, filt, Q2, xs=getattr(tap, "a_split", None), planes=True)
+            bounds["planes"] = True
+            return u, v, None
         if (isinstance(g, SplitTensor) and Q1 is not None and bounds is not None and not tap.has_bias and _OWN_ROTATION
                 and Do % 32 == 0 and (g.shape[1] * g.shape[2]) % 4 == 0 and C <= K.quadform_shared_max_outputs
                 and hasattr(K, "conv_nhwc_f16x2")):

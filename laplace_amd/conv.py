@@ -242,21 +242,28 @@ def conv_forward(prep: PreparedConv, x: SplitTensor, out=None, amax_out=None):
     return out
 
 
+def _filter_l1(W: torch.Tensor) -> torch.Tensor:
+    """device word ``max_co sum |W[co]|``: ``max|conv(x, W)_n| <= max|x_n| * l1`` (the bound the split-planes epilogue scales from)"""
+    return W.abs().float().reshape(W.shape[0], -1).sum(1).max().reshape(1).contiguous()
+
+
 def conv_forward_filters(m: nn.Conv2d, a: torch.Tensor, filt: torch.Tensor, key_tensor: torch.Tensor, amax_out=None,
-                         xs: SplitTensor | None = None) -> torch.Tensor:
+                         xs: SplitTensor | None = None, planes: bool = False):
     """``conv2d(a, filt)`` with the geometry of ``m`` and an arbitrary filter bank ``filt [Dk, Cin, kh, kw]`` (the
     eigenvectors of an A factor: the Kron predictive's rotation of the unfolded inputs, matrix.py:406-456) on the
-    implicit-GEMM kernel; returns ``[B, Dk, Ho, Wo]`` fp32 with POSITIONS contiguous.  The split planes of the filters
-    are cached ON ``key_tensor`` (the eigenvector matrix they were cut from; an attribute of that tensor object, so the
-    cache lives exactly as long as the decomposition — a table keyed by address would serve stale planes to the next
-    decomposition allocated at the same place).  ``amax_out``: zeroed device word that receives max|result|."""
+    implicit-GEMM kernel; returns ``[B, Dk, Ho, Wo]`` fp32 with POSITIONS contiguous — or, ``planes=True``, the same as a
+    SplitTensor ``[B, Dk, Ho * Wo]`` with one scale per image (lk_conv_nhwc_f16x2_planes: what the quadratic-form kernel stages
+    as it is).  The split planes of the filters are cached ON ``key_tensor`` (the eigenvector matrix they were cut from; an
+    attribute of that tensor object, so the cache lives exactly as long as the decomposition — a table keyed by address
+    would serve stale planes to the next decomposition allocated at the same place).  ``amax_out``: zeroed device word
+    that receives max|result| (fp32 form only)."""
     K = get_kernels()
     key = (key_tensor._version, tuple(filt.shape))
     hit = getattr(key_tensor, "_lk_filter_planes", None)
     if hit is None or hit[0] != key:
-        hit = (key, K.conv_prep_weights(filt.contiguous(), False, None))
+        hit = (key, K.conv_prep_weights(filt.contiguous(), False, None), _filter_l1(filt))
         key_tensor._lk_filter_planes = hit
-    planes, sexp = hit[1]
+    planes_w, sexp = hit[1]
     if xs is None or tuple(xs.shape) != (a.shape[0], a.shape[2], a.shape[3], a.shape[1]):
         xh = a.permute(0, 2, 3, 1).contiguous()  # (a view when `a` is NHWC in memory already)
         xs = K.split_images_f16x2(xh)        # (``xs``: the split copy the forward pass already made of ``a``; one scale per image)
@@ -264,27 +271,33 @@ def conv_forward_filters(m: nn.Conv2d, a: torch.Tensor, filt: torch.Tensor, key_
     s, (ph, pw), (KH, KW) = m.stride[0], m.padding, m.kernel_size
     Ho, Wo = (Hin + 2 * ph - KH) // s + 1, (Win + 2 * pw - KW) // s + 1
     Dk = filt.shape[0]
-    out = torch.empty(N, Dk, Ho, Wo, dtype=torch.float32, device=a.device)
     taps = [(kh - ph, kw - pw, kh * KW + kw) for kh in range(KH) for kw in range(KW)]
+    if planes:
+        return K.conv_nhwc_f16x2_planes(xs, planes_w, sexp, hit[2], Ho, Wo, s, taps, config=(K.conv_config | 2))
+    out = torch.empty(N, Dk, Ho, Wo, dtype=torch.float32, device=a.device)
     # config bit 4: position-contiguous output; the wrapper reads shapes off an NHWC-shaped view of the same memory
-    K.conv_nhwc_f16x2(xs, planes, sexp, Ho, Wo, s, out.view(N, Ho, Wo, Dk), 1, 0, 0, taps, amax_out=amax_out,
+    K.conv_nhwc_f16x2(xs, planes_w, sexp, Ho, Wo, s, out.view(N, Ho, Wo, Dk), 1, 0, 0, taps, amax_out=amax_out,
                       config=(K.conv_config | 2 | 16))
     return out
 
 
-def rotate_channels(g: SplitTensor, Q: torch.Tensor, key_tensor: torch.Tensor) -> torch.Tensor:
+def rotate_channels(g: SplitTensor, Q: torch.Tensor, key_tensor: torch.Tensor, planes: bool = False):
     """``out[n, :, p] = Q^T g[n, p, :]`` for an NHWC split tensor ``g [N, H, W, C]`` and a square ``Q [C, C]`` — the Kron
     predictive's rotation of the output cotangents into a G factor's eigenbasis (matrix.py:406-456) — as a 1x1
-    convolution on the implicit-GEMM kernel with POSITION-contiguous output ``[N, C, H*W]`` fp32: what the quadratic-form
-    kernel reads, without the un-split / transpose copy and the library GEMM.  Filter planes cached on ``key_tensor``."""
+    convolution on the implicit-GEMM kernel with POSITION-contiguous output ``[N, C, H*W]``: fp32, or (``planes=True``) a
+    SplitTensor with ``g``'s one scale re-derived from the bound ``max|g| * l1(Q^T)`` — what the quadratic-form kernel
+    reads, without the un-split / transpose copy and the library GEMM.  Filter planes cached on ``key_tensor``."""
     K = get_kernels()
     N, H, W, C = g.shape
     key = (key_tensor._version, "rot", C)
     hit = getattr(key_tensor, "_lk_rot_planes", None)
     if hit is None or hit[0] != key:
-        hit = (key, K.conv_prep_weights(Q.T.reshape(C, C, 1, 1).contiguous(), False, None))
+        Wq = Q.T.reshape(C, C, 1, 1).contiguous()
+        hit = (key, K.conv_prep_weights(Wq, False, None), _filter_l1(Wq))
         key_tensor._lk_rot_planes = hit
-    planes, sexp = hit[1]
+    planes_w, sexp = hit[1]
+    if planes:
+        return K.conv_nhwc_f16x2_planes(g, planes_w, sexp, hit[2], H, W, 1, [(0, 0, 0)], config=(K.conv_config | 2))
     out = torch.empty(N, C, H * W, dtype=torch.float32, device=g.planes.device)
-    K.conv_nhwc_f16x2(g, planes, sexp, H, W, 1, out.view(N, H, W, C), 1, 0, 0, [(0, 0, 0)], config=(K.conv_config | 2 | 16))
+    K.conv_nhwc_f16x2(g, planes_w, sexp, H, W, 1, out.view(N, H, W, C), 1, 0, 0, [(0, 0, 0)], config=(K.conv_config | 2 | 16))
     return out

@@ -239,6 +239,9 @@ struct ConvGeom {
   int dense;                // the output grid is the output tensor (os = 1, Hc = Ho, Wc = Wo): output pixel = m
   int out_nchw;             // write out[n][co][pixel] (dense grids with Ho*Wo % 4 == 0 only): float4 along the pixels
   int a_nsexp;              // entries of a_sexp: 1 (one scale for the tensor) or N (one per image: the forward's activations)
+  int out_planes;           // with out_nchw: emit the position-contiguous output as two fp16 planes [n][co][pixel] scaled per
+                            // a_sexp entry from the bound in_amax * l1(W) (ConvVjp::out_h / out_l / out_sexp / in_amax / w_l1) —
+                            // what the predictive's quadratic-form kernel stages without splitting anything itself
 };
 
 template <int BM_, int BN_, int BK_, int WM_, int WN_, int NBUF_ = 2, int WPE_ = 2>
@@ -642,6 +645,34 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
         if (m >= M) continue;
         const int n = fdiv(m, g.div_hw), pix = m - n * HW;
         const float inv_an = per_img ? image_inv(n) : inv_a;  // (the four pixels of a register quad belong to one image: HW % 4 == 0)
+        if (g.out_planes) {
+          // split planes: image n (or the whole tensor) scaled from the guaranteed bound max|in_n| * l1(W)
+          const int ns = per_img ? n : 0;
+          const int sa = a_sexp[ns];
+          float bound = fz.in_amax ? __uint_as_float(fz.in_amax[ns]) : exp2i(15 - sa < -126 ? -126 : (15 - sa > 127 ? 127 : 15 - sa));
+          bound *= fz.w_l1[0];
+          const int so = scale_exp_for(bound);
+          const float sc = exp2i(so);
+#pragma unroll
+          for (int b = 0; b < TN; ++b) {
+            const int col = tile_n * BN + (wn * TN + b) * 32 + lr;
+            if (col >= g.Co) continue;
+            if (col == 0 && pix == 0 && (per_img || n == 0)) fz.out_sexp[ns] = so;
+            f16x4 h4, l4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float xs = acc[a][b][4 * q + j] * inv_an * inv_w * sc;
+              asm volatile("" : "+v"(xs));  // h and the residual from the SAME fp32 value (see split2)
+              const _Float16 hh = (_Float16)xs;
+              h4[j] = hh;
+              l4[j] = (_Float16)(xs - (float)hh);
+            }
+            const int64_t e = ((int64_t)n * g.Co + col) * HW + pix;
+            *reinterpret_cast<f16x4*>(fz.out_h + e) = h4;
+            *reinterpret_cast<f16x4*>(fz.out_l + e) = l4;
+          }
+          continue;
+        }
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
           const int col = tile_n * BN + (wn * TN + b) * 32 + lr;
@@ -1621,6 +1652,8 @@ template <typename CFG>
 static int launch_conv(const ConvGeom& g, const void* Ah, const void* Al, const void* Wh, const void* Wl, const int* a_sexp,
                        const int* w_sexp, const void* zero16, float* out, int accumulate, unsigned* amax_out,
                        hipStream_t stream, const ConvVjp* fz = nullptr) {
+  const ConvVjp plain = (fz && g.out_planes) ? *fz : ConvVjp{};  // (the plain epilogue's split-planes output rides in a ConvVjp)
+  if (g.out_planes) fz = nullptr;
   const int64_t M = (int64_t)g.N * g.Hc * g.Wc;
   const int nb_m = (int)((M + CFG::BM - 1) / CFG::BM), nb_n = (g.Co + CFG::BN - 1) / CFG::BN;
   const size_t lds = (size_t)CFG::NBUF * CFG::STAGE;
@@ -1648,7 +1681,7 @@ static int launch_conv(const ConvGeom& g, const void* Ah, const void* Al, const 
   }
   hipLaunchKernelGGL((conv_f16x2_kernel<CFG, false>), dim3((unsigned)(nb_m * nb_n)), dim3(CFG::NT), lds, stream, g, (const _Float16*)Ah,
                      (const _Float16*)Al, (const _Float16*)Wh, (const _Float16*)Wl, a_sexp, w_sexp, (const _Float16*)zero16,
-                     out, accumulate, amax_out, nb_m, ConvVjp{});
+                     out, accumulate, amax_out, nb_m, plain);
   return check_launch("conv_f16x2_kernel");
 }
 
@@ -1736,7 +1769,8 @@ static int conv_dispatch(const void* in_h, const void* in_l, const int* in_sexp,
   LK_REQUIRE(in_h && in_l && in_sexp && w_h && w_l && w_sexp && zero16 && (out || fz) && taps, "lk_conv_nhwc_f16x2: null pointer");
   LK_REQUIRE(T >= 1 && T <= 9 && Ci >= 32 && Ci % 32 == 0 && Co >= 1 && N >= 1, "lk_conv_nhwc_f16x2: Ci % 32 == 0, 1..9 taps");
   LK_REQUIRE(N * Hc * Wc < (1ll << 31) && N * Hi * Wi * Ci < (1ll << 40), "lk_conv_nhwc_f16x2: tensor too large");
-  LK_REQUIRE(in_nsexp == 1 || (in_nsexp == N && !fz), "lk_conv_nhwc_f16x2: in_nsexp is 1 or N (one scale per image: plain epilogue only)");
+  LK_REQUIRE(in_nsexp == 1 || (in_nsexp == N && (!fz || (config & 16))),
+             "lk_conv_nhwc_f16x2: in_nsexp is 1 or N (one scale per image: plain epilogue only)");
   if (Hc == 0 || Wc == 0) return LK_OK;
   ConvGeom g;
   g.a_nsexp = (int)in_nsexp;
@@ -1749,12 +1783,13 @@ static int conv_dispatch(const void* in_h, const void* in_l, const int* in_sexp,
   g.pmajor = (Hc * Wc <= (64 << (2 * ((config >> 16) & 3))) && N >= 64 && !(config & 16) && !(config & 32768)) ? 1 : 0;
   g.dense = out_step == 1 && oh0 == 0 && ow0 == 0 && Hc == Ho && Wc == Wo;
   g.out_nchw = (config & 16) ? 1 : 0;
+  g.out_planes = (fz && fz->out_h && (config & 16)) ? 1 : 0;  // (fused launches never carry bit 4: conv_vjp_impl clears it)
   LK_REQUIRE(!g.out_nchw || (g.dense && (Ho * Wo) % 4 == 0 && !accumulate),
              "lk_conv_nhwc_f16x2: position-contiguous output needs a dense grid with Ho*Wo % 4 == 0 and no accumulate");
   hipStream_t st = (hipStream_t)stream;
   // persistent window form (fused launches with 64 output channels whose caller also handed over chunk-major weights;
   // config bit 27 switches it off): see conv_winp_f16x2_kernel
-  if (fz && fz->wc_h && !(config & 134217728) && lk_conv_winp_eligible(N, Hi, Wi, Ci, Co, T, fz->mask && fz->mask_float) &&
+  if (fz && !g.out_planes && fz->wc_h && !(config & 134217728) && lk_conv_winp_eligible(N, Hi, Wi, Ci, Co, T, fz->mask && fz->mask_float) &&
       in_mul == 1 && Hc == Hi && Wc == Wi && g.dense) {
     int rc = LK_OK;
     if (launch_winp<WinPCfg<256>>(g, in_h, in_l, fz->wc_h, fz->wc_l, in_sexp, w_sexp, amax_out, st, fz, &rc, config)) return rc;
@@ -1809,6 +1844,25 @@ extern "C" int lk_conv_nhwc_f16x2(const void* in_h, const void* in_l, const int*
                                   int accumulate, unsigned* amax_out, int config, void* stream) {
   return conv_dispatch(in_h, in_l, in_sexp, in_nsexp, N, Hi, Wi, Ci, w_h, w_l, w_sexp, Co, Hc, Wc, in_mul, Ho, Wo, out_step, oh0, ow0, T,
                        taps, zero16, out, accumulate, amax_out, config, stream, nullptr);
+}
+
+// lk_conv_nhwc_f16x2 with the output POSITION-contiguous as two fp16 planes, out_h / out_l [N][Co][Ho * Wo], instead of
+// fp32: scaled per entry of in_sexp (the whole tensor, or image by image) from the guaranteed bound
+//   max|out_n| <= in_amax[n] * w_l1[0]      (in_amax: in_nsexp words, bit patterns, or NULL = 2^(15 - in_sexp[n]))
+// with the scale left in out_sexp[n].  Dense grid, (Ho * Wo) % 4 == 0.  What the predictive's eigenbasis rotations hand to
+// lk_kron_quadform_shared_planes_f16x2: no fp32 round trip, no splitting inside the quadratic-form kernel.
+extern "C" int lk_conv_nhwc_f16x2_planes(const void* in_h, const void* in_l, const int* in_sexp, int64_t in_nsexp,
+                                         const void* in_amax, int64_t N, int64_t Hi, int64_t Wi, int64_t Ci, const void* w_h,
+                                         const void* w_l, const int* w_sexp, const float* w_l1, int64_t Co, int64_t Ho,
+                                         int64_t Wo, int64_t in_mul, int64_t T, const int* taps, const void* zero16,
+                                         void* out_h, void* out_l, int* out_sexp, int config, void* stream) {
+  LK_REQUIRE(w_l1 && out_h && out_l && out_sexp, "lk_conv_nhwc_f16x2_planes: null pointer");
+  ConvVjp fz{};
+  fz.in_amax = (const unsigned*)in_amax, fz.w_l1 = w_l1;
+  fz.out_h = (_Float16*)out_h, fz.out_l = (_Float16*)out_l, fz.out_sexp = out_sexp;
+  fz.mask_rows = 1, fz.div_mask = make_fastdiv(1);
+  return conv_dispatch(in_h, in_l, in_sexp, in_nsexp, N, Hi, Wi, Ci, w_h, w_l, w_sexp, Co, Ho, Wo, in_mul, Ho, Wo, 1, 0, 0, T, taps,
+                       zero16, reinterpret_cast<float*>(out_h), 0, nullptr, config | 16, stream, &fz);
 }
 
 // The same launch with the fused VJP epilogue (see ConvVjp): dense output grid (the output tensor IS the class grid), no

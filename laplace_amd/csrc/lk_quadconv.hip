@@ -422,6 +422,162 @@ __global__ __launch_bounds__(256) void quadform_conv_kernel(const float* __restr
   if (tid < NP) partial[((size_t)n * split + sp) * NP + tid] = (sR[0][tid] + sR[1][tid]) + (sR[2][tid] + sR[3][tid]);
 }
 
+// ---- the quadratic form on PRE-SPLIT operands (round 5) ------------------------------------------------------------------
+// quadform_conv_kernel spends as many vector-pipe cycles splitting its fp32 operands in flight (three bf16 pieces of 28 values
+// per thread and chunk) as its matrix pipe spends on the six MFMAs per block: one wave per SIMD, nothing to hide either
+// under.  Here the operands ARRIVE split — two fp16 planes each, position-contiguous, written that way by the epilogue of
+// the rotation convolutions that produce them (lk_conv_nhwc_f16x2_planes: u = Q1^T g as a 1x1 convolution over the split
+// cotangent, v = the unfolded activations in the A factor's eigenbasis) — so a chunk is 8-byte copies into LDS (A), two
+// 16-byte loads (B) and CT x three v_mfma_f32_32x32x16_f16.  u: [C][B][Do][L] halfs (seed-major) with ONE scale, v: [B][Dk][L]
+// with one scale per sample (v_nsexp = B) or one for the tensor; L % 16 == 0 (whole chunks), Do % 32 == 0.
+template <int CT>
+struct QcStageP {
+  u32x2 ah[(CT + 1) / 2], al[(CT + 1) / 2];
+  u32x4 bh, bl;
+};
+
+template <int CT>
+__device__ __forceinline__ void qc_fetch_p2(QcStageP<CT>& st, int j_lo, int j_hi, bool with_b, const _Float16* uh,
+                                            const _Float16* ul, const _Float16* vh, const _Float16* vl, unsigned cs, int o0,
+                                            int icol, int l0, int C, int Dk, int L) {
+  const int tid = threadIdx.x, hi = (tid & 63) >> 5;
+  const int k4 = 4 * (tid & 3), o = (tid >> 2) & 31, c0 = tid >> 7;
+#pragma unroll
+  for (int j = j_lo; j < j_hi; ++j) {
+    const bool ok = c0 + 2 * j < C;
+    const unsigned off = ok ? (unsigned)((c0 + 2 * j) * cs + (o0 + o) * L + l0 + k4) : 0u;
+    st.ah[j] = *reinterpret_cast<const u32x2*>(uh + off);
+    st.al[j] = *reinterpret_cast<const u32x2*>(ul + off);
+  }
+  if (with_b) {
+    const unsigned off = icol < Dk ? (unsigned)(icol * L + l0 + 8 * hi) : 0u;
+    st.bh = *reinterpret_cast<const u32x4*>(vh + off);
+    st.bl = *reinterpret_cast<const u32x4*>(vl + off);
+  }
+}
+
+template <int CT>
+__global__ __launch_bounds__(256) void quadform_conv_planes_kernel(
+    const _Float16* __restrict__ uh, const _Float16* __restrict__ ul, const int* __restrict__ u_sexp,
+    const _Float16* __restrict__ vh, const _Float16* __restrict__ vl, const int* __restrict__ v_sexp, int v_nsexp,
+    const float* __restrict__ w0, const float* __restrict__ w1, const float* __restrict__ delta, int B, int C, int Do, int Dk,
+    int L, int split, float* __restrict__ partial) {
+  constexpr int NP = CT * (CT + 1) / 2, NA4 = (CT + 1) / 2, PIECE = CT * 32 * 16 * 2;
+  __shared__ __attribute__((aligned(16))) char lds[2 * 2 * PIECE];
+  __shared__ float sR[4][NP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
+  const int k4 = 4 * (tid & 3), o = (tid >> 2) & 31, c0 = tid >> 7;
+  int n = blockIdx.x / split, sp = blockIdx.x % split;
+  if (gridDim.x % (8 * split) == 0) {  // (all workgroups of one sample on ONE XCD: its L2 holds the sample's operands)
+    const int xcd = blockIdx.x % 8, j = blockIdx.x / 8;
+    n = xcd + 8 * (j / split), sp = j % split;
+  }
+  const int nOt = Do / 32, nIg = (Dk + 127) / 128, ntiles = nOt * nIg;
+  const unsigned cs = (unsigned)B * Do * L;
+  const _Float16* __restrict__ uhn = uh + (size_t)n * Do * L;
+  const _Float16* __restrict__ uln = ul + (size_t)n * Do * L;
+  const _Float16* __restrict__ vhn = vh + (size_t)n * Dk * L;
+  const _Float16* __restrict__ vln = vl + (size_t)n * Dk * L;
+  const int su = u_sexp[0], sv = v_sexp[n < v_nsexp ? n : v_nsexp - 1];
+  const float un_u = qc_exp2i(-su), un_v = qc_exp2i(-sv);
+  const float dlt = delta[0];
+
+  float pair[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) pair[p] = 0.f;
+  QcStageP<CT> st;
+  auto tile_o0 = [&](int t) { return (t % nOt) * 32; };
+  auto tile_icol = [&](int t) { return (t / nOt) * 128 + wave * 32 + lo; };
+  if (sp < ntiles) qc_fetch_p2<CT>(st, 0, NA4, true, uhn, uln, vhn, vln, cs, tile_o0(sp), tile_icol(sp), 0, C, Dk, L);
+  for (int t = sp; t < ntiles; t += split) {
+    const int o0 = tile_o0(t), icol = tile_icol(t);
+    const bool has_next = t + split < ntiles;
+    const int o0n = has_next ? tile_o0(t + split) : o0, icoln = has_next ? tile_icol(t + split) : icol;
+    f32x16 acc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+    const bool okI = icol < Dk;
+    int buf = 0;
+    for (int l0 = 0; l0 < L; l0 += QC_KC) {
+      char* wr = lds + buf * 2 * PIECE;
+#pragma unroll
+      for (int j = 0; j < NA4; ++j)
+        if (c0 + 2 * j < CT) {
+          const bool ok = c0 + 2 * j < C;
+          char* dst = wr + (((c0 + 2 * j) * 32 + o) * 16 + k4) * 2;
+          *reinterpret_cast<u32x2*>(dst) = ok ? st.ah[j] : u32x2{0u, 0u};
+          *reinterpret_cast<u32x2*>(dst + PIECE) = ok ? st.al[j] : u32x2{0u, 0u};
+        }
+      qf16x8 b[2];
+      b[0] = __builtin_bit_cast(qf16x8, okI ? st.bh : u32x4{0u, 0u, 0u, 0u});
+      b[1] = __builtin_bit_cast(qf16x8, okI ? st.bl : u32x4{0u, 0u, 0u, 0u});
+      __syncthreads();
+      const bool more = l0 + QC_KC < L;
+      const int so0 = more ? o0 : o0n, sic = more ? icol : icoln, lsrc = more ? l0 + QC_KC : 0;
+      const char* rd = lds + buf * 2 * PIECE + (lo * 16 + 8 * hi) * 2;
+      qf16x8 a_cur[2], a_nxt[2];
+#pragma unroll
+      for (int p = 0; p < 2; ++p) a_cur[p] = *reinterpret_cast<const qf16x8*>(rd + p * PIECE);
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        if (c + 1 < CT) {
+#pragma unroll
+          for (int p = 0; p < 2; ++p) a_nxt[p] = *reinterpret_cast<const qf16x8*>(rd + p * PIECE + (c + 1) * 32 * 16 * 2);
+        }
+        // the next chunk's (or the next tile's first chunk's) loads go out one slot per output between the MFMA groups
+        qc_fetch_p2<CT>(st, c < NA4 ? c : NA4, c < NA4 ? c + 1 : NA4, c == 0, uhn, uln, vhn, vln, cs, so0, sic, lsrc, C, Dk, L);
+        f32x16 d = acc[c];
+        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[1], b[0], d, 0, 0, 0);  // small terms first
+        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[0], b[1], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[0], b[0], d, 0, 0, 0);
+        acc[c] = d;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) a_cur[p] = a_nxt[p];
+      }
+      buf ^= 1;  // the other buffer was last read two chunks ago: one barrier per chunk suffices
+    }
+    __syncthreads();
+    // weights of this lane's 16 (o, i) positions and the pair sums, four accumulator rows at a time
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      float wgt[4], a[CT][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int oo = o0 + j + 8 * rg + 4 * hi;
+        const bool ok = oo < Do && icol < Dk;
+        const float d = w0[ok ? oo : 0] * w1[ok ? icol : 0] + dlt;
+        wgt[j] = ok ? __builtin_amdgcn_rcpf(d) : 0.f;
+      }
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[c][j] = (acc[c][4 * rg + j] * un_u) * un_v;
+      int p = 0;
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        float sc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sc[j] = a[c][j] * wgt[j];
+#pragma unroll
+        for (int k = c; k < CT; ++k) {
+          pair[p] += (sc[0] * a[k][0] + sc[1] * a[k][1]) + (sc[2] * a[k][2] + sc[3] * a[k][3]);
+          ++p;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const float s = wave_sum(pair[p]);
+    if (lane == 0) sR[wave][p] = s;
+  }
+  __syncthreads();
+  if (tid < NP) partial[((size_t)n * split + sp) * NP + tid] = (sR[0][tid] + sR[1][tid]) + (sR[2][tid] + sR[3][tid]);
+}
+
 // fvar[n][c][k] (and [k][c]) += sum over the workgroups of sample n, in fixed order
 __global__ __launch_bounds__(256) void quadform_conv_reduce_kernel(const float* __restrict__ partial, int64_t B, int C,
                                                                    int CT, int split, float* __restrict__ fvar) {
@@ -606,6 +762,58 @@ extern "C" int lk_kron_quadform_shared_seedmajor_f32(const float* u, const float
              "lk_kron_quadform_shared_seedmajor_f32: sizes out of range");
   return launch_quadform_conv<0>(u, v, l1, l2, delta, B, C, Do, Dk, L, fvar, ws, ws_bytes, (hipStream_t)stream,
                                  "lk_kron_quadform_shared_seedmajor_f32", nullptr, nullptr, true);
+}
+
+// The Kronecker quadratic form of a weight-sharing layer on operands that arrive as fp16 planes (quadform_conv_planes_kernel):
+// u_h / u_l [C][B][Do][L] with the scale u_sexp[0] (seed-major: the rotation convolution over a seed-batched sweep's cotangent),
+// v_h / v_l [B][Dk][L] with v_sexp[n] per sample (v_nsexp = B) or v_sexp[0] (v_nsexp = 1) — both as lk_conv_nhwc_f16x2_planes
+// leaves them.  L % 16 == 0, Do % 32 == 0, C <= 10.  fvar [B][C][C] +=.  Same workspace as lk_kron_quadform_shared_f32.
+extern "C" int lk_kron_quadform_shared_planes_f16x2(const void* u_h, const void* u_l, const int* u_sexp, const void* v_h,
+                                                    const void* v_l, const int* v_sexp, int64_t v_nsexp, const float* l1,
+                                                    const float* l2, const float* delta, int64_t B, int64_t C, int64_t Do,
+                                                    int64_t Dk, int64_t L, float* fvar, void* ws, size_t ws_bytes, void* stream_) {
+  const char* what = "lk_kron_quadform_shared_planes_f16x2";
+  LK_REQUIRE(u_h && u_l && u_sexp && v_h && v_l && v_sexp && l1 && l2 && delta && fvar && B >= 0 && C >= 1 && Do >= 1 && Dk >= 1 && L >= 1,
+             "lk_kron_quadform_shared_planes_f16x2: bad arguments");
+  LK_REQUIRE(L % 16 == 0 && Do % 32 == 0 && (v_nsexp == 1 || v_nsexp == B), "lk_kron_quadform_shared_planes_f16x2: L % 16 == 0, Do % 32 == 0, v_nsexp in {1, B}");
+  LK_REQUIRE(B * 64 < (1ll << 31) && C * B * L * Do < (1ll << 31) && L * Dk < (1ll << 29),
+             "lk_kron_quadform_shared_planes_f16x2: sizes out of range");
+  LK_REQUIRE(qc_aligned16(u_h) && qc_aligned16(u_l) && qc_aligned16(v_h) && qc_aligned16(v_l), "lk_kron_quadform_shared_planes_f16x2: 16-byte aligned planes");
+  const int ct = qc_class_tile(C);
+  if (ct == 0) {
+    set_error("%s: more than 10 outputs are not supported by the fused kernel", what);
+    return LK_EINVAL;
+  }
+  if (B == 0) return LK_OK;
+  if (ws == nullptr || ws_bytes < lk_quadform_shared_workspace_bytes(B, C, Do, Dk)) {
+    set_error("%s: workspace too small", what);
+    return LK_EWORKSPACE;
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  const int split = qc_split(B, Do, Dk);
+  float* partial = static_cast<float*>(ws);
+  const dim3 grid((unsigned)(B * split));
+#define LK_QP_CASE(CT)                                                                                                      \
+  case CT:                                                                                                                  \
+    hipLaunchKernelGGL((quadform_conv_planes_kernel<CT>), grid, dim3(256), 0, stream, (const _Float16*)u_h,                 \
+                       (const _Float16*)u_l, u_sexp, (const _Float16*)v_h, (const _Float16*)v_l, v_sexp, (int)v_nsexp, l1, l2, \
+                       delta, (int)B, (int)C, (int)Do, (int)Dk, (int)L, split, partial);                                    \
+    break;
+  switch (ct) {
+    LK_QP_CASE(1)
+    LK_QP_CASE(2)
+    LK_QP_CASE(3)
+    LK_QP_CASE(4)
+    LK_QP_CASE(5)
+    LK_QP_CASE(6)
+    LK_QP_CASE(8)
+    LK_QP_CASE(10)
+  }
+#undef LK_QP_CASE
+  const int64_t total = B * (ct * (ct + 1) / 2);
+  hipLaunchKernelGGL(quadform_conv_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, partial, B,
+                     (int)C, ct, split, fvar);
+  return check_launch(what);
 }
 
 extern "C" int lk_diag_quadform_shared_f32(const float* u, const float* v, const float* var_w, int64_t B, int64_t C,

@@ -154,7 +154,10 @@ def glm_variance_kron(backend, x, post):
             u, v, gsum = _shared_operands(tap, g, B, C, Q1, Q2, bounds=bnd)
             l1c, l2c = l1.contiguous(), l2.contiguous()
             ub, vb = bnd.get("u"), bnd.get("v")  # both known: the fp16x2 form of the kernel (three MFMAs per block)
-            if bnd.get("u_seed_major"):  # u is [C, B, Do, L] (C within the kernel's accumulators): one launch
+            if bnd.get("planes"):  # both operands arrive as split planes from the rotation convolutions: one launch
+                K.kron_quadform_shared_planes(u, v, l1c, l2c, d1, fvar, C)
+                done = True
+            elif bnd.get("u_seed_major"):  # u is [C, B, Do, L] (C within the kernel's accumulators): one launch
                 K.kron_quadform_shared(u, v, l1c, l2c, d1, fvar, seed_major=True)
                 done = True
             else:

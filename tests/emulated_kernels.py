@@ -138,6 +138,28 @@ class EmulatedKernels:
             amax_out.copy_(torch.maximum(amax_out, view.abs().max().reshape(1)))
         return out
 
+    def conv_nhwc_f16x2_planes(self, x, wplanes, wsexp, w_l1, Ho, Wo, in_mul, taps, config=None):
+        """lk_conv_nhwc_f16x2_planes: position-contiguous output as a SplitTensor [N, Co, Ho * Wo], scaled per entry of x.sexp
+        from the bound max|x_n| * w_l1"""
+        from laplace_amd._lib import SplitTensor
+
+        N = x.shape[0]
+        Co = wplanes.shape[2]
+        res = torch.zeros(N, Ho, Wo, Co)
+        self.conv_nhwc_f16x2(x, wplanes, wsexp, Ho, Wo, in_mul, res, 1, 0, 0, taps)
+        res = res.permute(0, 3, 1, 2).reshape(N, Co, Ho * Wo)
+        ns = x.sexp.numel()
+        in_amax = (x.amax.float().reshape(-1) if getattr(x, "amax", None) is not None and x.amax.numel() == ns
+                   else torch.exp2(15.0 - x.sexp.float()))
+        bound = in_amax * float(w_l1[0])
+        got = res.abs().reshape(N, -1).amax(1) if ns > 1 else res.abs().max().reshape(1)
+        assert bool((got <= bound * (1 + 1e-5) + 1e-30).all()), "max|in| * l1(W) does not bound the convolution"
+        s = torch.tensor([self._sexp_for(b) for b in bound.tolist()], dtype=torch.int32)
+        rs = res * torch.exp2(s.float()).reshape(-1, 1, 1)
+        h = rs.half()
+        l = (rs - h.float()).half()
+        return SplitTensor(torch.stack([h, l]), s)
+
     def conv_winp_eligible(self, N, Hi, Wi, Ci, Co, T, mask_is_float=False) -> bool:
         # (mirrors lk_conv_winp_eligible, so that the host logic around the chunk-major weights is exercised on the CPU)
         return bool(T == 9 and Wi <= 47 and Hi * Wi >= 16 and Ci % 32 == 0 and Ci >= 32 and Co >= 64 and Co % 64 == 0
@@ -550,6 +572,21 @@ class EmulatedKernels:
             assert float(u.abs().max()) <= float(u_bound[0]) * (1 + 1e-6) + 1e-30, "u_bound does not bound u"
             assert float(v.abs().max()) <= float(v_bound[0]) * (1 + 1e-6) + 1e-30, "v_bound does not bound v"
         M = torch.einsum("ncol,nil->ncoi", u, v)
+        fvar += torch.einsum("ncoi,nkoi,oi->nck", M, M, 1.0 / (torch.outer(l1, l2) + delta.reshape(())))
+        return fvar
+
+    use_quad_planes = True
+
+    def kron_quadform_shared_planes(self, u, v, l1, l2, delta, fvar, C):
+        """lk_kron_quadform_shared_planes_f16x2: u SplitTensor [C * B, Do, L] (one scale), v SplitTensor [B, Dk, L]"""
+        from laplace_amd._lib import _one_scale
+
+        _one_scale(u, "kron_quadform_shared_planes (u)")
+        CB, Do, L = u.shape
+        B = v.shape[0]
+        assert CB == C * B and v.shape[2] == L and L % 16 == 0 and Do % 32 == 0 and C <= self.quadform_shared_max_outputs
+        uu = u.float().reshape(C, B, Do, L).permute(1, 0, 2, 3)
+        M = torch.einsum("ncol,nil->ncoi", uu, v.float())
         fvar += torch.einsum("ncoi,nkoi,oi->nck", M, M, 1.0 / (torch.outer(l1, l2) + delta.reshape(())))
         return fvar
 

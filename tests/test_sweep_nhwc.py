@@ -151,14 +151,18 @@ def test_kron_predictive_through_the_nhwc_rotations():
 
     la.fit(L([(X[:6], y[:6]), (X[6:], y[6:])]))
     K = get_kernels()
-    seen = {"seed_major": 0, "other": 0}
-    orig = K.kron_quadform_shared
+    seen = {"seed_major": 0, "other": 0, "planes": 0}
+    orig, orig_p = K.kron_quadform_shared, K.kron_quadform_shared_planes
 
     def counting(*a, seed_major=False, **k):
         seen["seed_major" if seed_major else "other"] += 1
         return orig(*a, seed_major=seed_major, **k)
 
-    K.kron_quadform_shared = counting
+    def counting_p(*a, **k):
+        seen["planes"] += 1
+        return orig_p(*a, **k)
+
+    K.kron_quadform_shared, K.kron_quadform_shared_planes = counting, counting_p
     try:
         f1, v1 = la._glm_predictive_distribution(X[:5])
         n_fast = dict(seen)
@@ -169,8 +173,10 @@ def test_kron_predictive_through_the_nhwc_rotations():
         finally:
             be._OWN_ROTATION = prev
     finally:
-        del K.kron_quadform_shared
-    assert n_fast["seed_major"] >= 6, n_fast  # every 32- / 64-channel convolution of the three blocks
+        del K.kron_quadform_shared, K.kron_quadform_shared_planes
+    # every 32- / 64-channel convolution of the three blocks: both rotations on our convolution kernel, operands handed to the
+    # quadratic-form kernel as split planes (maps whose positions are no multiple of 16 keep the fp32 seed-major form)
+    assert n_fast["planes"] + n_fast["seed_major"] >= 6 and n_fast["planes"] >= 3, n_fast
     assert torch.allclose(f1, f2, atol=1e-6)
     assert (v1 - v2).abs().max() / v2.abs().max() < 2e-5
 
