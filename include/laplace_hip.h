@@ -490,11 +490,13 @@ int lk_kron_quadform_shared_seedmajor_f32(const float* u, const float* v, const 
  * u_sexp[0] (seed-major), v_h / v_l [B][Dk][L] with one scale per sample (v_nsexp = B) or one for the tensor (v_nsexp = 1),
  * as lk_conv_nhwc_f16x2_planes leaves them.  A chunk of 16 positions is then 8-byte copies into LDS, two 16-byte loads and
  * C x three v_mfma_f32_32x32x16_f16 — the fp32-operand forms above spend as many vector-pipe cycles splitting in flight as
- * their matrix pipe spends on the products.  L % 16 == 0, Do % 32 == 0, C <= 10; same workspace. */
+ * their matrix pipe spends on the products; the operands are staged by LDS-DMA into a ring of four stages, requested three
+ * chunks ahead (one wave per SIMD: nothing else hides a load).  L % 16 == 0, Do % 32 == 0, C <= 10; zero16: >= 16 zero bytes
+ * on the device; same workspace. */
 int lk_kron_quadform_shared_planes_f16x2(const void* u_h, const void* u_l, const int* u_sexp, const void* v_h, const void* v_l,
                                          const int* v_sexp, int64_t v_nsexp, const float* l1, const float* l2,
-                                         const float* delta, int64_t B, int64_t C, int64_t Do, int64_t Dk, int64_t L, float* fvar,
-                                         void* ws, size_t ws_bytes, void* stream);
+                                         const float* delta, int64_t B, int64_t C, int64_t Do, int64_t Dk, int64_t L,
+                                         const void* zero16, float* fvar, void* ws, size_t ws_bytes, void* stream);
 /* lk_kron_quadform_shared_f32 with the products in the two-piece fp16 split (three v_mfma_f32_32x32x16_f16 per product
  * block instead of six bf16 ones): u_bound / v_bound are device words >= max|u|, max|v| from which the kernel derives
  * the power-of-two scales of its in-flight split (loose bounds only cost fixed-point range). */

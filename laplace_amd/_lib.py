@@ -113,7 +113,7 @@ SIGNATURES = {
     "lk_diag_quadform_linear_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "lk_quadform_shared_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "lk_kron_quadform_shared_planes_f16x2": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
-                                                    _vp, _vp, _sz, _vp]),
+                                                    _vp, _vp, _vp, _sz, _vp]),
     "lk_kron_quadform_shared_f16x2": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "lk_kron_quadform_shared_seedmajor_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "lk_kron_quadform_shared_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
@@ -1260,8 +1260,8 @@ class HipKernels:
         ws = self._workspace(self.lib.lk_quadform_shared_workspace_bytes(B, C, Do, Dk), fvar.device)
         self._rc(self._timed("quadconv", 2.0 * B * C * L * Do * Dk, fvar.device, lambda: self.lib.lk_kron_quadform_shared_planes_f16x2(
             _ptr(u.planes[0]), _ptr(u.planes[1]), _ptr(u.sexp), _ptr(v.planes[0]), _ptr(v.planes[1]), _ptr(v.sexp), v.sexp.numel(),
-            _ptr(l1), _ptr(l2), _ptr(delta), B, C, Do, Dk, L, _ptr(fvar), _ptr(ws), ws.numel(), self._stream(fvar.device))),
-            "lk_kron_quadform_shared_planes_f16x2")
+            _ptr(l1), _ptr(l2), _ptr(delta), B, C, Do, Dk, L, _ptr(self._zero16(fvar.device)), _ptr(fvar), _ptr(ws), ws.numel(),
+            self._stream(fvar.device))), "lk_kron_quadform_shared_planes_f16x2")
         return fvar
 
     def diag_quadform_shared(self, u, v, var_w, fvar):

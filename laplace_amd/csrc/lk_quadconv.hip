@@ -430,49 +430,45 @@ __global__ __launch_bounds__(256) void quadform_conv_kernel(const float* __restr
 // cotangent, v = the unfolded activations in the A factor's eigenbasis) — so a chunk is 8-byte copies into LDS (A), two
 // 16-byte loads (B) and CT x three v_mfma_f32_32x32x16_f16.  u: [C][B][Do][L] halfs (seed-major) with ONE scale, v: [B][Dk][L]
 // with one scale per sample (v_nsexp = B) or one for the tensor; L % 16 == 0 (whole chunks), Do % 32 == 0.
-template <int CT>
-struct QcStageP {
-  u32x2 ah[(CT + 1) / 2], al[(CT + 1) / 2];
-  u32x4 bh, bl;
-};
+typedef __attribute__((address_space(3))) void qc_lds_void;
+typedef __attribute__((address_space(1))) const void qc_gbl_void;
 
+// Staging: LDS-DMA (global_load_lds, 16 bytes per lane, no register round trip) into a ring of NS stages, requested NS - 1
+// chunks ahead and waited for by COUNT — with one wave per SIMD (160 accumulator registers for ten outputs) nothing else
+// hides a load, and the first form of this kernel, which fetched one chunk ahead through registers, ran at the latency of
+// its loads (14 ms per c4 call, as the fp32-operand kernel before it: neither its MFMAs, 1.7 ms at the nominal rate, nor its
+// bytes, 4.7 ms at the CU's ~12 B / clock ingest rate, were the bound).  A stage: A = [piece][output][32 rows][16 k] (one
+// wave-instruction = one (piece, output): 32 rows x 32 bytes = a lane-linear kilobyte), B = [wave][piece][lane] (a lane's
+// own 8 positions of its column).  The stream of chunks runs across tiles; the pair sums of a tile touch registers only.
 template <int CT>
-__device__ __forceinline__ void qc_fetch_p2(QcStageP<CT>& st, int j_lo, int j_hi, bool with_b, const _Float16* uh,
-                                            const _Float16* ul, const _Float16* vh, const _Float16* vl, unsigned cs, int o0,
-                                            int icol, int l0, int C, int Dk, int L) {
-  const int tid = threadIdx.x, hi = (tid & 63) >> 5;
-  const int k4 = 4 * (tid & 3), o = (tid >> 2) & 31, c0 = tid >> 7;
-#pragma unroll
-  for (int j = j_lo; j < j_hi; ++j) {
-    const bool ok = c0 + 2 * j < C;
-    const unsigned off = ok ? (unsigned)((c0 + 2 * j) * cs + (o0 + o) * L + l0 + k4) : 0u;
-    st.ah[j] = *reinterpret_cast<const u32x2*>(uh + off);
-    st.al[j] = *reinterpret_cast<const u32x2*>(ul + off);
-  }
-  if (with_b) {
-    const unsigned off = icol < Dk ? (unsigned)(icol * L + l0 + 8 * hi) : 0u;
-    st.bh = *reinterpret_cast<const u32x4*>(vh + off);
-    st.bl = *reinterpret_cast<const u32x4*>(vl + off);
-  }
-}
+struct QcPlanesCfg {
+  static constexpr int NS = CT <= 5 ? 6 : 4;                 // ring stages
+  static constexpr int A_BYTES = 2 * CT * 1024, B_BYTES = 4 * 2 * 1024, STAGE = A_BYTES + B_BYTES;
+  static constexpr int NA = (2 * CT + 3) / 4;                // A instructions per wave and chunk (padded: a repeat)
+  static constexpr int LD = NA + 2;                          // LDS-DMA instructions per wave and chunk
+  static constexpr int LDS = NS * STAGE;
+  static_assert(LD * (NS - 2) <= 63, "vmcnt is a 6-bit counter");
+};
 
 template <int CT>
 __global__ __launch_bounds__(256) void quadform_conv_planes_kernel(
     const _Float16* __restrict__ uh, const _Float16* __restrict__ ul, const int* __restrict__ u_sexp,
     const _Float16* __restrict__ vh, const _Float16* __restrict__ vl, const int* __restrict__ v_sexp, int v_nsexp,
     const float* __restrict__ w0, const float* __restrict__ w1, const float* __restrict__ delta, int B, int C, int Do, int Dk,
-    int L, int split, float* __restrict__ partial) {
-  constexpr int NP = CT * (CT + 1) / 2, NA4 = (CT + 1) / 2, PIECE = CT * 32 * 16 * 2;
-  __shared__ __attribute__((aligned(16))) char lds[2 * 2 * PIECE];
+    int L, int split, float* __restrict__ partial, const _Float16* __restrict__ zero16, int w_in_lds) {
+  using CFG = QcPlanesCfg<CT>;
+  constexpr int NP = CT * (CT + 1) / 2, NS = CFG::NS;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
   __shared__ float sR[4][NP];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
-  const int k4 = 4 * (tid & 3), o = (tid >> 2) & 31, c0 = tid >> 7;
+  const int tid = threadIdx.x, lane = tid & 63, lo = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int n = blockIdx.x / split, sp = blockIdx.x % split;
   if (gridDim.x % (8 * split) == 0) {  // (all workgroups of one sample on ONE XCD: its L2 holds the sample's operands)
     const int xcd = blockIdx.x % 8, j = blockIdx.x / 8;
     n = xcd + 8 * (j / split), sp = j % split;
   }
   const int nOt = Do / 32, nIg = (Dk + 127) / 128, ntiles = nOt * nIg;
+  const int NCH = L / QC_KC;
   const unsigned cs = (unsigned)B * Do * L;
   const _Float16* __restrict__ uhn = uh + (size_t)n * Do * L;
   const _Float16* __restrict__ uln = ul + (size_t)n * Do * L;
@@ -481,65 +477,96 @@ __global__ __launch_bounds__(256) void quadform_conv_planes_kernel(
   const int su = u_sexp[0], sv = v_sexp[n < v_nsexp ? n : v_nsexp - 1];
   const float un_u = qc_exp2i(-su), un_v = qc_exp2i(-sv);
   const float dlt = delta[0];
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+  // the eigenvalues behind the ring (host: w_in_lds when they fit): read in every tile's epilogue — from memory those loads
+  // would sit in the same in-order counter as the ring's requests and drain it once per tile (a tile of a 4 x 4 map is ONE chunk)
+  float* ldsw = reinterpret_cast<float*>(lds + CFG::LDS);
+  if (w_in_lds) {
+    for (int i = tid; i < Do; i += 256) ldsw[i] = w0[i];
+    for (int i = tid; i < Dk; i += 256) ldsw[Do + i] = w1[i];
+    __syncthreads();
+  }
 
   float pair[NP];
 #pragma unroll
   for (int p = 0; p < NP; ++p) pair[p] = 0.f;
-  QcStageP<CT> st;
-  auto tile_o0 = [&](int t) { return (t % nOt) * 32; };
-  auto tile_icol = [&](int t) { return (t / nOt) * 128 + wave * 32 + lo; };
-  if (sp < ntiles) qc_fetch_p2<CT>(st, 0, NA4, true, uhn, uln, vhn, vln, cs, tile_o0(sp), tile_icol(sp), 0, C, Dk, L);
-  for (int t = sp; t < ntiles; t += split) {
-    const int o0 = tile_o0(t), icol = tile_icol(t);
-    const bool has_next = t + split < ntiles;
-    const int o0n = has_next ? tile_o0(t + split) : o0, icoln = has_next ? tile_icol(t + split) : icol;
+  const int my_tiles = sp < ntiles ? (ntiles - sp + split - 1) / split : 0;
+  const int Q = my_tiles * NCH;  // chunks of this workgroup's walk
+
+  // ---- the producer side: chunk (tile ordinal kt, chunk ch) -> stage `st`
+  int p_kt = 0, p_ch = 0, p_stage = 0;  // next chunk to request
+  auto request = [&]() {
+    const int t = sp + p_kt * split;
+    const int o0 = (t % nOt) * 32, icol = (t / nOt) * 128 + wave * 32 + lo, l0 = p_ch * QC_KC;
+    const unsigned base = lds0 + p_stage * CFG::STAGE;
+    const unsigned a_lane = (unsigned)((o0 + (lane >> 1)) * L + l0 + 8 * (lane & 1));
+#pragma unroll
+    for (int j = 0; j < CFG::NA; ++j) {
+      int a = j * 4 + wave;                 // (scalar) instruction index = piece * CT + output
+      if (a >= 2 * CT) a = a % (2 * CT);    // padding (uniform counts for the counted waits): repeat one (same bytes, same place)
+      const int piece = a >= CT ? 1 : 0, c = a - piece * CT;
+      const _Float16* src = (c < C ? (piece ? uln : uhn) + (unsigned)(c * cs) + a_lane : zero16);
+      __builtin_amdgcn_global_load_lds((qc_gbl_void*)src, (qc_lds_void*)(uintptr_t)(base + a * 1024), 16, 0, 0);
+    }
+    const unsigned b_lane = (unsigned)(icol * L + l0 + 8 * hi);
+#pragma unroll
+    for (int piece = 0; piece < 2; ++piece) {
+      const _Float16* src = icol < Dk ? (piece ? vln : vhn) + b_lane : zero16;
+      __builtin_amdgcn_global_load_lds((qc_gbl_void*)src, (qc_lds_void*)(uintptr_t)(base + CFG::A_BYTES + (wave * 2 + piece) * 1024),
+                                       16, 0, 0);
+    }
+    p_stage = p_stage + 1 == NS ? 0 : p_stage + 1;
+    if (++p_ch == NCH) p_ch = 0, ++p_kt;
+  };
+#pragma unroll
+  for (int i = 0; i < NS - 1; ++i)
+    if (i < Q) request();
+
+  int c_stage = 0, q = 0;
+  for (int kt = 0; kt < my_tiles; ++kt) {
+    const int t = sp + kt * split;
+    const int o0 = (t % nOt) * 32, icol = (t / nOt) * 128 + wave * 32 + lo;
     f32x16 acc[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
-    const bool okI = icol < Dk;
-    int buf = 0;
-    for (int l0 = 0; l0 < L; l0 += QC_KC) {
-      char* wr = lds + buf * 2 * PIECE;
-#pragma unroll
-      for (int j = 0; j < NA4; ++j)
-        if (c0 + 2 * j < CT) {
-          const bool ok = c0 + 2 * j < C;
-          char* dst = wr + (((c0 + 2 * j) * 32 + o) * 16 + k4) * 2;
-          *reinterpret_cast<u32x2*>(dst) = ok ? st.ah[j] : u32x2{0u, 0u};
-          *reinterpret_cast<u32x2*>(dst + PIECE) = ok ? st.al[j] : u32x2{0u, 0u};
-        }
-      qf16x8 b[2];
-      b[0] = __builtin_bit_cast(qf16x8, okI ? st.bh : u32x4{0u, 0u, 0u, 0u});
-      b[1] = __builtin_bit_cast(qf16x8, okI ? st.bl : u32x4{0u, 0u, 0u, 0u});
-      __syncthreads();
-      const bool more = l0 + QC_KC < L;
-      const int so0 = more ? o0 : o0n, sic = more ? icol : icoln, lsrc = more ? l0 + QC_KC : 0;
-      const char* rd = lds + buf * 2 * PIECE + (lo * 16 + 8 * hi) * 2;
-      qf16x8 a_cur[2], a_nxt[2];
-#pragma unroll
-      for (int p = 0; p < 2; ++p) a_cur[p] = *reinterpret_cast<const qf16x8*>(rd + p * PIECE);
+    for (int ch = 0; ch < NCH; ++ch, ++q) {
+      // chunk q has landed (this wave's part: all but the NS - 2 younger requests), then everybody's; and nobody reads the
+      // stage that the request below overwrites any more (it was consumed one iteration ago)
+      if (q + NS - 1 <= Q) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(CFG::LD * (NS - 2)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // tail: fewer requests in flight
+      if (q + NS - 1 < Q) request();
+      const unsigned stage = lds0 + c_stage * CFG::STAGE;
+      c_stage = c_stage + 1 == NS ? 0 : c_stage + 1;
+      // Fragment reads as asm, two register sets, waited for by COUNT: left to hipcc every read sat directly in front of
+      // the MFMA that consumes it behind an lgkmcnt(0) (one register set, ISA checked) — 20 exposed LDS round trips per
+      // chunk on a SIMD whose only wave this is.  The reads of output c + 1 are in flight under the three MFMAs of output c.
+      auto lds_read = [&](qf16x8& dst, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr)); };
+      qf16x8 bh, bl, ah[2], al[2];
+      const unsigned rd = stage + lo * 32 + hi * 16;  // this lane's (row, k half) of output 0, piece h
+      lds_read(bh, stage + CFG::A_BYTES + (wave * 2) * 1024 + lane * 16);
+      lds_read(bl, stage + CFG::A_BYTES + (wave * 2 + 1) * 1024 + lane * 16);
+      lds_read(ah[0], rd);
+      lds_read(al[0], rd + CT * 1024);
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
+        const int set = c & 1;
         if (c + 1 < CT) {
-#pragma unroll
-          for (int p = 0; p < 2; ++p) a_nxt[p] = *reinterpret_cast<const qf16x8*>(rd + p * PIECE + (c + 1) * 32 * 16 * 2);
+          lds_read(ah[set ^ 1], rd + (c + 1) * 1024);
+          lds_read(al[set ^ 1], rd + (CT + c + 1) * 1024);
+          asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ah[set]), "+v"(al[set]), "+v"(bh), "+v"(bl));
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[set]), "+v"(al[set]), "+v"(bh), "+v"(bl));
         }
-        // the next chunk's (or the next tile's first chunk's) loads go out one slot per output between the MFMA groups
-        qc_fetch_p2<CT>(st, c < NA4 ? c : NA4, c < NA4 ? c + 1 : NA4, c == 0, uhn, uln, vhn, vln, cs, so0, sic, lsrc, C, Dk, L);
         f32x16 d = acc[c];
-        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[1], b[0], d, 0, 0, 0);  // small terms first
-        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[0], b[1], d, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[0], b[0], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[set], bh, d, 0, 0, 0);  // small terms first
+        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[set], bl, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[set], bh, d, 0, 0, 0);
         acc[c] = d;
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int p = 0; p < 2; ++p) a_cur[p] = a_nxt[p];
       }
-      buf ^= 1;  // the other buffer was last read two chunks ago: one barrier per chunk suffices
     }
-    __syncthreads();
     // weights of this lane's 16 (o, i) positions and the pair sums, four accumulator rows at a time
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
@@ -548,7 +575,7 @@ __global__ __launch_bounds__(256) void quadform_conv_planes_kernel(
       for (int j = 0; j < 4; ++j) {
         const int oo = o0 + j + 8 * rg + 4 * hi;
         const bool ok = oo < Do && icol < Dk;
-        const float d = w0[ok ? oo : 0] * w1[ok ? icol : 0] + dlt;
+        const float d = (w_in_lds ? ldsw[ok ? oo : 0] * ldsw[Do + (ok ? icol : 0)] : w0[ok ? oo : 0] * w1[ok ? icol : 0]) + dlt;
         wgt[j] = ok ? __builtin_amdgcn_rcpf(d) : 0.f;
       }
 #pragma unroll
@@ -767,13 +794,15 @@ extern "C" int lk_kron_quadform_shared_seedmajor_f32(const float* u, const float
 // The Kronecker quadratic form of a weight-sharing layer on operands that arrive as fp16 planes (quadform_conv_planes_kernel):
 // u_h / u_l [C][B][Do][L] with the scale u_sexp[0] (seed-major: the rotation convolution over a seed-batched sweep's cotangent),
 // v_h / v_l [B][Dk][L] with v_sexp[n] per sample (v_nsexp = B) or v_sexp[0] (v_nsexp = 1) — both as lk_conv_nhwc_f16x2_planes
-// leaves them.  L % 16 == 0, Do % 32 == 0, C <= 10.  fvar [B][C][C] +=.  Same workspace as lk_kron_quadform_shared_f32.
+// leaves them.  L % 16 == 0, Do % 32 == 0, C <= 10; zero16: >= 16 zero bytes on the device (what padded outputs / columns
+// stage).  fvar [B][C][C] +=.  Same workspace as lk_kron_quadform_shared_f32.
 extern "C" int lk_kron_quadform_shared_planes_f16x2(const void* u_h, const void* u_l, const int* u_sexp, const void* v_h,
                                                     const void* v_l, const int* v_sexp, int64_t v_nsexp, const float* l1,
                                                     const float* l2, const float* delta, int64_t B, int64_t C, int64_t Do,
-                                                    int64_t Dk, int64_t L, float* fvar, void* ws, size_t ws_bytes, void* stream_) {
+                                                    int64_t Dk, int64_t L, const void* zero16, float* fvar, void* ws,
+                                                    size_t ws_bytes, void* stream_) {
   const char* what = "lk_kron_quadform_shared_planes_f16x2";
-  LK_REQUIRE(u_h && u_l && u_sexp && v_h && v_l && v_sexp && l1 && l2 && delta && fvar && B >= 0 && C >= 1 && Do >= 1 && Dk >= 1 && L >= 1,
+  LK_REQUIRE(u_h && u_l && u_sexp && v_h && v_l && v_sexp && l1 && l2 && delta && fvar && zero16 && B >= 0 && C >= 1 && Do >= 1 && Dk >= 1 && L >= 1,
              "lk_kron_quadform_shared_planes_f16x2: bad arguments");
   LK_REQUIRE(L % 16 == 0 && Do % 32 == 0 && (v_nsexp == 1 || v_nsexp == B), "lk_kron_quadform_shared_planes_f16x2: L % 16 == 0, Do % 32 == 0, v_nsexp in {1, B}");
   LK_REQUIRE(B * 64 < (1ll << 31) && C * B * L * Do < (1ll << 31) && L * Dk < (1ll << 29),
@@ -793,12 +822,21 @@ extern "C" int lk_kron_quadform_shared_planes_f16x2(const void* u_h, const void*
   const int split = qc_split(B, Do, Dk);
   float* partial = static_cast<float*>(ws);
   const dim3 grid((unsigned)(B * split));
+  const size_t w_bytes = (size_t)(Do + Dk) * sizeof(float);
+  const int w_in_lds = w_bytes <= 40960 ? 1 : 0;  // (the eigenvalues behind the ring: ResNet-18's widest layer needs 20 KB)
 #define LK_QP_CASE(CT)                                                                                                      \
-  case CT:                                                                                                                  \
-    hipLaunchKernelGGL((quadform_conv_planes_kernel<CT>), grid, dim3(256), 0, stream, (const _Float16*)u_h,                 \
-                       (const _Float16*)u_l, u_sexp, (const _Float16*)v_h, (const _Float16*)v_l, v_sexp, (int)v_nsexp, l1, l2, \
-                       delta, (int)B, (int)C, (int)Do, (int)Dk, (int)L, split, partial);                                    \
-    break;
+  case CT: {                                                                                                                \
+    static bool attr_set = false;                                                                                           \
+    if (!attr_set) {                                                                                                        \
+      (void)hipFuncSetAttribute((const void*)quadform_conv_planes_kernel<CT>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                QcPlanesCfg<CT>::LDS + 40960);                                                              \
+      attr_set = true;                                                                                                      \
+    }                                                                                                                       \
+    hipLaunchKernelGGL((quadform_conv_planes_kernel<CT>), grid, dim3(256), QcPlanesCfg<CT>::LDS + (w_in_lds ? w_bytes : 0),   \
+                       stream, (const _Float16*)u_h, (const _Float16*)u_l, u_sexp, (const _Float16*)v_h, (const _Float16*)v_l, \
+                       v_sexp, (int)v_nsexp, l1, l2, delta, (int)B, (int)C, (int)Do, (int)Dk, (int)L, split, partial,         \
+                       (const _Float16*)zero16, w_in_lds);                                                                  \
+  } break;
   switch (ct) {
     LK_QP_CASE(1)
     LK_QP_CASE(2)
