@@ -637,6 +637,10 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
     // position-contiguous output [n][co][pixel] (what the predictive's quadratic-form kernel reads): a lane owns one
     // channel, registers r = 4q .. 4q+3 are four consecutive pixels of it -> one 16-byte store
     const int HW = g.Hc * g.Wc;
+    int pl_ns = -1, pl_so = 0;
+    float pl_sc = 0.f;
+    const float pl_l1 = g.out_planes ? fz.w_l1[0] : 0.f;
+    const bool pl_pair = g.out_planes && HW % 8 == 0;  // 8-pixel runs never straddle an image: the half-wave exchange applies
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -646,30 +650,50 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
         const int n = fdiv(m, g.div_hw), pix = m - n * HW;
         const float inv_an = per_img ? image_inv(n) : inv_a;  // (the four pixels of a register quad belong to one image: HW % 4 == 0)
         if (g.out_planes) {
-          // split planes: image n (or the whole tensor) scaled from the guaranteed bound max|in_n| * l1(W)
+          // split planes: image n (or the whole tensor) scaled from the guaranteed bound max|in_n| * l1(W); the scale words
+          // are re-read only when the image changes (a tile of a large map lies in one or two images)
           const int ns = per_img ? n : 0;
-          const int sa = a_sexp[ns];
-          float bound = fz.in_amax ? __uint_as_float(fz.in_amax[ns]) : exp2i(15 - sa < -126 ? -126 : (15 - sa > 127 ? 127 : 15 - sa));
-          bound *= fz.w_l1[0];
-          const int so = scale_exp_for(bound);
-          const float sc = exp2i(so);
+          if (ns != pl_ns) {
+            const int sa = a_sexp[ns];
+            float bound = fz.in_amax ? __uint_as_float(fz.in_amax[ns]) : exp2i(15 - sa < -126 ? -126 : (15 - sa > 127 ? 127 : 15 - sa));
+            pl_so = scale_exp_for(bound * pl_l1);
+            pl_sc = exp2i(pl_so) * inv_w;
+            pl_ns = ns;
+          }
+          // Lanes l and l + 32 hold the two 4-pixel halves of an 8-pixel run of the same channel (rows 8q + 4 lh + j): they
+          // swap one half each, so that lane l stores 16 bytes of the h plane and lane l + 32 16 bytes of the l plane — one
+          // store instruction of 64 x 16 B per (a, q, b) instead of two of 64 x 8 B.
+          const bool pair_ok = (m - 4 * lh) + 8 <= M;  // (the partner's rows exist: M % 8 == 0 on every dense grid with HW % 8 == 0)
 #pragma unroll
           for (int b = 0; b < TN; ++b) {
             const int col = tile_n * BN + (wn * TN + b) * 32 + lr;
-            if (col >= g.Co) continue;
-            if (col == 0 && pix == 0 && (per_img || n == 0)) fz.out_sexp[ns] = so;
             f16x4 h4, l4;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              float xs = acc[a][b][4 * q + j] * inv_an * inv_w * sc;
+              float xs = acc[a][b][4 * q + j] * inv_an * pl_sc;
               asm volatile("" : "+v"(xs));  // h and the residual from the SAME fp32 value (see split2)
               const _Float16 hh = (_Float16)xs;
               h4[j] = hh;
               l4[j] = (_Float16)(xs - (float)hh);
             }
-            const int64_t e = ((int64_t)n * g.Co + col) * HW + pix;
-            *reinterpret_cast<f16x4*>(fz.out_h + e) = h4;
-            *reinterpret_cast<f16x4*>(fz.out_l + e) = l4;
+            if (col == 0 && pix == 0 && (per_img || n == 0) && col < g.Co) fz.out_sexp[ns] = pl_so;
+            if (pl_pair && pair_ok) {
+              // lh == 0 keeps h4 and receives the partner's h4; lh == 1 keeps l4 and receives the partner's l4
+              uint2 mine = lh ? __builtin_bit_cast(uint2, h4) : __builtin_bit_cast(uint2, l4);  // what the partner wants
+              uint2 got;
+              got.x = (unsigned)__shfl_xor((int)mine.x, 32, 64);
+              got.y = (unsigned)__shfl_xor((int)mine.y, 32, 64);
+              if (col < g.Co) {
+                const uint2 keep = lh ? __builtin_bit_cast(uint2, l4) : __builtin_bit_cast(uint2, h4);
+                const u32x4 out8 = lh ? u32x4{got.x, got.y, keep.x, keep.y} : u32x4{keep.x, keep.y, got.x, got.y};
+                const int64_t e = ((int64_t)n * g.Co + col) * HW + (pix - 4 * lh);  // (the run starts at the lh == 0 lane's pixel)
+                *reinterpret_cast<u32x4*>((lh ? fz.out_l : fz.out_h) + e) = out8;
+              }
+            } else if (col < g.Co) {
+              const int64_t e = ((int64_t)n * g.Co + col) * HW + pix;
+              *reinterpret_cast<f16x4*>(fz.out_h + e) = h4;
+              *reinterpret_cast<f16x4*>(fz.out_l + e) = l4;
+            }
           }
           continue;
         }
