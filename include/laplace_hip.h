@@ -497,12 +497,6 @@ int lk_kron_quadform_shared_planes_f16x2(const void* u_h, const void* u_l, const
                                          const int* v_sexp, int64_t v_nsexp, const float* l1, const float* l2,
                                          const float* delta, int64_t B, int64_t C, int64_t Do, int64_t Dk, int64_t L,
                                          const void* zero16, float* fvar, void* ws, size_t ws_bytes, void* stream);
-/* lk_kron_quadform_shared_f32 with the products in the two-piece fp16 split (three v_mfma_f32_32x32x16_f16 per product
- * block instead of six bf16 ones): u_bound / v_bound are device words >= max|u|, max|v| from which the kernel derives
- * the power-of-two scales of its in-flight split (loose bounds only cost fixed-point range). */
-int lk_kron_quadform_shared_f16x2(const float* u, const float* v, const float* u_bound, const float* v_bound, const float* l1,
-                                  const float* l2, const float* delta, int64_t B, int64_t C, int64_t Do, int64_t Dk, int64_t L,
-                                  float* fvar, void* ws, size_t ws_bytes, void* stream);
 int lk_diag_quadform_shared_f32(const float* u, const float* v, const float* var_w, int64_t B, int64_t C, int64_t Do,
                                 int64_t Dk, int64_t L, float* fvar, void* ws, size_t ws_bytes, void* stream);
 

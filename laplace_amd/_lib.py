@@ -114,7 +114,6 @@ SIGNATURES = {
     "lk_quadform_shared_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "lk_kron_quadform_shared_planes_f16x2": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
                                                     _vp, _vp, _vp, _sz, _vp]),
-    "lk_kron_quadform_shared_f16x2": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "lk_kron_quadform_shared_seedmajor_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "lk_kron_quadform_shared_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "lk_diag_quadform_shared_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
@@ -1201,16 +1200,9 @@ class HipKernels:
     #: most outputs the fused weight-sharing predictive holds in accumulators at once
     quadform_shared_max_outputs = 10
 
-    #: ``True``: the quadratic-form kernel uses the two-piece fp16 products when its caller knows
-    #: bounds of the operands.  Off by default: measured equal on the c4 predictive (3.6 k samples/s either way) — the
-    #: kernel is bound by the L2 -> register traffic of its operand chunks (28 KB per 1.3 MFLOP chunk and workgroup) and
-    #: by the in-flight splitting, not by the matrix pipe
-    use_quad16 = False
-
-    def kron_quadform_shared(self, u, v, l1, l2, delta, fvar, u_bound=None, v_bound=None, seed_major=False):
-        """``u [B, C, Do, L]`` (``seed_major``: ``[C, B, Do, L]``), ``v [B, Dk, L]`` (eigenbasis projections);
-        ``fvar [B, C, C] +=``.  With device words ``u_bound >= max|u|``, ``v_bound >= max|v|`` the products run in the
-        two-piece fp16 split (three MFMAs per block, lk_kron_quadform_shared_f16x2) instead of the three-piece bf16 one."""
+    def kron_quadform_shared(self, u, v, l1, l2, delta, fvar, seed_major=False):
+        """``u [B, C, Do, L]`` (``seed_major``: ``[C, B, Do, L]``), ``v [B, Dk, L]`` (eigenbasis projections), fp32;
+        ``fvar [B, C, C] +=`` (three-piece bf16 products; operands that arrive split: :meth:`kron_quadform_shared_planes`)"""
         for t, nm in ((u, "u"), (v, "v"), (l1, "l1"), (l2, "l2"), (delta, "delta"), (fvar, "fvar")):
             _check(t, nm)
         if seed_major:
@@ -1225,15 +1217,6 @@ class HipKernels:
                     _ptr(u), _ptr(v), _ptr(l1), _ptr(l2), _ptr(delta), B, C, Do, Dk, L, _ptr(fvar), _ptr(ws), ws.numel(),
                     self._stream(u.device))),
                 "lk_kron_quadform_shared_seedmajor_f32",
-            )
-            return fvar
-        if u_bound is not None and v_bound is not None and self.use_quad16:
-            _check(u_bound, "u_bound"), _check(v_bound, "v_bound")
-            self._rc(
-                self._timed("quadconv16", 2.0 * B * C * L * Do * Dk, u.device, lambda: self.lib.lk_kron_quadform_shared_f16x2(
-                    _ptr(u), _ptr(v), _ptr(u_bound), _ptr(v_bound), _ptr(l1), _ptr(l2), _ptr(delta), B, C, Do, Dk, L,
-                    _ptr(fvar), _ptr(ws), ws.numel(), self._stream(u.device))),
-                "lk_kron_quadform_shared_f16x2",
             )
             return fvar
         self._rc(

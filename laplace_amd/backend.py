@@ -49,9 +49,9 @@ def shared_operands(tap, g, B, C, Q1=None, Q2=None, bounds=None):
     """``u [B, C, Do, L]`` and ``v [B, Dk, L]`` (both position-contiguous) of a weight-sharing layer (Conv2d, or Linear
     along a sequence), whose per-sample Jacobian of output / seed ``c`` is ``sum_l u[n, c, :, l] v[n, :, l]^T``
     (:mod:`laplace_amd.predictive`), rotated into the eigenbases ``Q1`` / ``Q2`` if given; plus the position-summed
-    output gradient ``[C, B, Do]`` for the bias.  ``bounds``: a dict that receives device words ``u`` / ``v`` with
-    guaranteed bounds of max|u|, max|v| when they are known without another pass over the data (the split-fp16
-    quadratic-form kernel scales its operands by them)."""
+    output gradient ``[C, B, Do]`` for the bias.  ``bounds``: a dict that receives the FORM the operands come back in —
+    ``planes``: both are SplitTensors (lk_conv_nhwc_f16x2_planes: ``u [C * B, Do, L]`` seed-major with one scale, ``v [B, Dk, L]``
+    with one scale per sample), ``u_seed_major``: fp32 with ``u [C, B, Do, L]``."""
     m = tap.module
     a = tap.a.to(torch.float32)
     if tap.kind == "conv2d":
@@ -88,11 +88,6 @@ def shared_operands(tap, g, B, C, Q1=None, Q2=None, bounds=None):
             u = K.unsplit_transpose(g, C, B)                           # [B, C, Do, L]
             L = u.shape[-1]
             gsum = u.sum(-1).permute(1, 0, 2) if tap.has_bias else None  # [C, B, Do]: only a bias block reads it
-            if bounds is not None:
-                # max|g| from the split tensor itself (measured, or 2^(15 - sexp)); an orthonormal rotation of the
-                # Do channels grows the largest element by at most sqrt(Do)
-                ub = g.amax.float() if getattr(g, "amax", None) is not None else torch.exp2(15.0 - g.sexp.float())
-                bounds["u"] = (ub * (math.sqrt(Do) if Q1 is not None else 1.0)).reshape(1).contiguous()
         else:
             g4 = g.reshape(C, B, Do, -1)                               # [C, B, Do, L]
             L = g4.shape[-1]
@@ -108,10 +103,7 @@ def shared_operands(tap, g, B, C, Q1=None, Q2=None, bounds=None):
                     and L % 4 == 0):
                 # our implicit-GEMM convolution (fp32-level products on the fp16 matrix cores), eigenvector filters
                 # kept as split planes per decomposition
-                vb = torch.zeros(1, dtype=torch.float32, device=a.device) if bounds is not None else None
-                v = cv.conv_forward_filters(m, a, filt, Q2, amax_out=vb, xs=getattr(tap, "a_split", None)).reshape(B, Dk, L)
-                if vb is not None:
-                    bounds["v"] = vb  # measured by the convolution's epilogue
+                v = cv.conv_forward_filters(m, a, filt, Q2, xs=getattr(tap, "a_split", None)).reshape(B, Dk, L)
             elif Dk <= 32:
                 # a very thin layer (the 3 x 3 RGB stem: Dk = 27): unfold + ONE small batched GEMM.  The library convolution
                 # runs this shape as im2col + GEMM PER IMAGE (256 launches of ~6 us for a minibatch of 128: 1.5 ms of a

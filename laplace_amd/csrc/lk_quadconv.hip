@@ -227,11 +227,10 @@ __device__ __forceinline__ void qc_tile_gemm_b6(const QcOperands& cur, const QcO
   __syncthreads();
 }
 
-// ---- the same tile product from TWO fp16 pieces per operand (three MFMAs) ---------------------------------------------
-// x 2^s = h + l with h, l fp16 and s from a bound of max|x| known before the launch (device words; lk_conv.hip explains
-// the scheme and why a loose bound is harmless):  x y 2^(su+sv) ~= h h' + h l' + l h'  ->  three v_mfma_f32_32x32x16_f16
-// per chunk and output where the three-piece bf16 form needs six.  Same staging, same pipeline as qc_tile_gemm_b6; the
-// accumulators come out scaled by 2^(su+sv) and are un-scaled where they are consumed.
+// ---- helpers of the two-piece fp16 form on PRE-SPLIT operands (quadform_conv_planes_kernel below): x 2^s = h + l with h, l
+// fp16, x y 2^(su+sv) ~= h h' + h l' + l h' -> three v_mfma_f32_32x32x16_f16 per chunk and output where the three-piece bf16
+// form needs six.  (An in-flight variant of it — fp32 operands split by the staging threads — existed in rounds 2 - 4 and
+// measured equal to the bf16 form: the kernel was never bound by its matrix pipe.  Removed in round 5.)
 typedef _Float16 qf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ int qc_scale_exp(float amax) {  // amax * 2^s in [2^14, 2^15)
   int be = (int)((__float_as_uint(amax) >> 23) & 0xffu);
@@ -243,107 +242,16 @@ __device__ __forceinline__ float qc_exp2i(int s) {
   s = s < -126 ? -126 : (s > 127 ? 127 : s);
   return __uint_as_float((unsigned)(127 + s) << 23);
 }
-__device__ __forceinline__ void qc_split2(float x, float sc, unsigned& h, unsigned& l) {
-  float xs = x * sc;
-  asm volatile("" : "+v"(xs));  // h and the residual from the SAME fp32 value (no fused re-rounding, see lk_conv.hip)
-  const _Float16 hh = (_Float16)xs;
-  const _Float16 ll = (_Float16)(xs - (float)hh);
-  h = (unsigned)__builtin_bit_cast(unsigned short, hh);
-  l = (unsigned)__builtin_bit_cast(unsigned short, ll);
-}
-__device__ __forceinline__ unsigned qc_pack16(unsigned even, unsigned odd) { return even | (odd << 16); }
-
-template <int CT>
-__device__ __forceinline__ void qc_tile_gemm_h3(const QcOperands& cur, const QcOperands& nxt, bool has_next, int C,
-                                                int Do, int Dk, int L, char* lds, f32x16 (&acc)[CT], QcStage<CT>& st,
-                                                float sc_u, float sc_v) {
-  constexpr int NA4 = (CT + 1) / 2;
-  constexpr int PIECE = CT * 32 * 16 * 2;
-  const int tid = threadIdx.x, lane = tid & 63, lo = lane & 31, hi = lane >> 5;
-  const int k4 = 4 * (tid & 3), o = (tid >> 2) & 31, c0 = tid >> 7;
-#pragma unroll
-  for (int c = 0; c < CT; ++c)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
-  const bool okO = cur.o0 + o < Do, okI = cur.icol < Dk;
-  int buf = 0;
-  for (int l0 = 0; l0 < L; l0 += QC_KC) {
-    char* wr = lds + buf * 2 * PIECE;
-#pragma unroll
-    for (int j = 0; j < NA4; ++j)
-      if (c0 + 2 * j < CT) {
-        const bool ok = okO && c0 + 2 * j < C && l0 + k4 < L;
-        const f32x4 x = ok ? st.ra[j] : f32x4{0.f, 0.f, 0.f, 0.f};
-        unsigned h[4], l[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) qc_split2(x[q], sc_u, h[q], l[q]);
-        char* dst = wr + (((c0 + 2 * j) * 32 + o) * 16 + k4) * 2;
-        *reinterpret_cast<u32x2*>(dst) = u32x2{qc_pack16(h[0], h[1]), qc_pack16(h[2], h[3])};
-        *reinterpret_cast<u32x2*>(dst + PIECE) = u32x2{qc_pack16(l[0], l[1]), qc_pack16(l[2], l[3])};
-      }
-    u32x4 bp[2];
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      const bool ok = okI && l0 + 8 * hi + 4 * hh < L;
-      const f32x4 x = ok ? st.rb[hh] : f32x4{0.f, 0.f, 0.f, 0.f};
-      unsigned h[4], l[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) qc_split2(x[q], sc_v, h[q], l[q]);
-      bp[0][2 * hh] = qc_pack16(h[0], h[1]);
-      bp[0][2 * hh + 1] = qc_pack16(h[2], h[3]);
-      bp[1][2 * hh] = qc_pack16(l[0], l[1]);
-      bp[1][2 * hh + 1] = qc_pack16(l[2], l[3]);
-    }
-    qf16x8 b[2];
-#pragma unroll
-    for (int p = 0; p < 2; ++p) b[p] = __builtin_bit_cast(qf16x8, bp[p]);
-    __syncthreads();
-    const bool more = l0 + QC_KC < L;
-    const QcOperands src = more ? cur : (has_next ? nxt : cur);
-    const int lsrc = more ? l0 + QC_KC : 0;
-    const char* rd = lds + buf * 2 * PIECE + (lo * 16 + 8 * hi) * 2;
-    qf16x8 a_cur[2], a_nxt[2];
-#pragma unroll
-    for (int p = 0; p < 2; ++p) a_cur[p] = *reinterpret_cast<const qf16x8*>(rd + p * PIECE);
-#pragma unroll
-    for (int c = 0; c < CT; ++c) {
-      if (c + 1 < CT) {
-#pragma unroll
-        for (int p = 0; p < 2; ++p) a_nxt[p] = *reinterpret_cast<const qf16x8*>(rd + p * PIECE + (c + 1) * 32 * 16 * 2);
-      }
-      qc_fetch_b6<CT>(st, c, c < NA4 ? c + 1 : c, c < 2 ? c : 2, (c < 2 ? c + 1 : 2) + (CT == 1 ? 1 : 0), src, lsrc, C, Do,
-                      Dk, L);
-      f32x16 d = acc[c];
-      d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[1], b[0], d, 0, 0, 0);  // small terms first
-      d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[0], b[1], d, 0, 0, 0);
-      d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[0], b[0], d, 0, 0, 0);
-      acc[c] = d;
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int p = 0; p < 2; ++p) a_cur[p] = a_nxt[p];
-    }
-    buf ^= 1;
-  }
-  __syncthreads();
-}
-
 // grid = B * split workgroups of 4 waves; workgroup (n, sp) walks the super-tiles (32 rows o) x (128 columns i)
 // t = sp, sp + split, ...; wave w owns columns [32 w, 32 w + 32) of the super-tile for all CT outputs.
-// ARITH: 0 = fp32 MFMA (any L), 1 = three-piece bf16 (six MFMAs), 2 = two-piece fp16 (three MFMAs; needs the bounds)
+// ARITH: 0 = fp32 MFMA (any L), 1 = three-piece bf16 (six MFMAs)
 template <int CT, int MODE, int ARITH>
 __global__ __launch_bounds__(256) void quadform_conv_kernel(const float* __restrict__ u, const float* __restrict__ v,
                                                             const float* __restrict__ w0, const float* __restrict__ w1,
                                                             const float* __restrict__ delta, int C, int Do, int Dk, int L,
                                                             int split, float* __restrict__ partial,
-                                                            const float* __restrict__ u_bound,
-                                                            const float* __restrict__ v_bound, int64_t u_sample_stride,
-                                                            unsigned u_class_stride) {
+                                                            int64_t u_sample_stride, unsigned u_class_stride) {
   constexpr bool B6 = ARITH != 0;
-  float sc_u = 1.f, sc_v = 1.f, un_u = 1.f, un_v = 1.f;
-  if constexpr (ARITH == 2) {
-    const int su = qc_scale_exp(u_bound[0]), sv = qc_scale_exp(v_bound[0]);
-    sc_u = qc_exp2i(su), sc_v = qc_exp2i(sv), un_u = qc_exp2i(-su), un_v = qc_exp2i(-sv);
-  }
   constexpr int NP = CT * (CT + 1) / 2;
   __shared__ __attribute__((aligned(16))) char lds[QcLds<CT>::BYTES];
   __shared__ float sR[4][NP];
@@ -371,9 +279,7 @@ __global__ __launch_bounds__(256) void quadform_conv_kernel(const float* __restr
     const QcOperands cur = operands(t);
     const int o0 = cur.o0, icol = cur.icol;
     f32x16 acc[CT];
-    if constexpr (ARITH == 2)
-      qc_tile_gemm_h3<CT>(cur, operands(t + split), t + split < ntiles, C, Do, Dk, L, lds, acc, st, sc_u, sc_v);
-    else if constexpr (ARITH == 1)
+    if constexpr (ARITH == 1)
       qc_tile_gemm_b6<CT>(cur, operands(t + split), t + split < ntiles, C, Do, Dk, L, lds, acc, st);
     else
       qc_tile_gemm<CT>(cur, C, Do, Dk, L, lds, acc);
@@ -397,7 +303,7 @@ __global__ __launch_bounds__(256) void quadform_conv_kernel(const float* __restr
 #pragma unroll
       for (int c = 0; c < CT; ++c)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) a[c][j] = ARITH == 2 ? (acc[c][4 * rg + j] * un_u) * un_v : acc[c][4 * rg + j];
+        for (int j = 0; j < 4; ++j) a[c][j] = acc[c][4 * rg + j];
       int p = 0;
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
@@ -703,8 +609,7 @@ extern "C" size_t lk_quadform_shared_workspace_bytes(int64_t B, int64_t C, int64
 template <int MODE>
 static int launch_quadform_conv(const float* u, const float* v, const float* w0, const float* w1, const float* delta,
                                 int64_t B, int64_t C, int64_t Do, int64_t Dk, int64_t L, float* fvar, void* ws,
-                                size_t ws_bytes, hipStream_t stream, const char* what, const float* u_bound = nullptr,
-                                const float* v_bound = nullptr, bool seed_major = false) {
+                                size_t ws_bytes, hipStream_t stream, const char* what, bool seed_major = false) {
   // u is [B][C][Do][L] (sample-major) or, seed_major, [C][B][Do][L] (how a seed-batched sweep leaves it)
   const int64_t uss = seed_major ? Do * L : C * Do * L;
   const unsigned ucs = (unsigned)(seed_major ? B * Do * L : Do * L);
@@ -722,18 +627,14 @@ static int launch_quadform_conv(const float* u, const float* v, const float* w0,
   float* partial = static_cast<float*>(ws);
   const dim3 grid((unsigned)(B * split));
   const bool v4 = (L % 4 == 0) && qc_aligned16(u) && qc_aligned16(v) && qc_b6_enabled();
-  const bool h3 = v4 && u_bound && v_bound && MODE == 0;
 #define LK_QC_CASE(CT)                                                                                              \
   case CT:                                                                                                          \
-    if (h3)                                                                                                         \
-      hipLaunchKernelGGL((quadform_conv_kernel<CT, 0, 2>), grid, dim3(256), 0, stream, u, v, w0, w1, delta,         \
-                         (int)C, (int)Do, (int)Dk, (int)L, split, partial, u_bound, v_bound, uss, ucs);                       \
-    else if (v4)                                                                                                    \
+    if (v4)                                                                                                         \
       hipLaunchKernelGGL((quadform_conv_kernel<CT, MODE, 1>), grid, dim3(256), 0, stream, u, v, w0, w1, delta,      \
-                         (int)C, (int)Do, (int)Dk, (int)L, split, partial, nullptr, nullptr, uss, ucs);             \
+                         (int)C, (int)Do, (int)Dk, (int)L, split, partial, uss, ucs);                               \
     else                                                                                                            \
       hipLaunchKernelGGL((quadform_conv_kernel<CT, MODE, 0>), grid, dim3(256), 0, stream, u, v, w0, w1, delta,      \
-                         (int)C, (int)Do, (int)Dk, (int)L, split, partial, nullptr, nullptr, uss, ucs);             \
+                         (int)C, (int)Do, (int)Dk, (int)L, split, partial, uss, ucs);                               \
     break;
   switch (ct) {
     LK_QC_CASE(1)
@@ -763,21 +664,6 @@ extern "C" int lk_kron_quadform_shared_f32(const float* u, const float* v, const
                                  "lk_kron_quadform_shared_f32");
 }
 
-// The same result with the products on the fp16 matrix cores in the two-piece split (three MFMAs per product block):
-// u_bound / v_bound are device words >= max|u|, max|v| (loose bounds only cost fixed-point range).  Falls back to the
-// three-piece bf16 form when L % 4 != 0 or the operands are not 16-byte aligned.
-extern "C" int lk_kron_quadform_shared_f16x2(const float* u, const float* v, const float* u_bound, const float* v_bound,
-                                             const float* l1, const float* l2, const float* delta, int64_t B, int64_t C,
-                                             int64_t Do, int64_t Dk, int64_t L, float* fvar, void* ws, size_t ws_bytes,
-                                             void* stream) {
-  LK_REQUIRE(u && v && u_bound && v_bound && l1 && l2 && delta && fvar && B >= 0 && C >= 1 && Do >= 1 && Dk >= 1 && L >= 1,
-             "lk_kron_quadform_shared_f16x2: bad arguments");
-  LK_REQUIRE(B * 64 < (1ll << 31) && C * L * Do < (1ll << 29) && L * Dk < (1ll << 29),
-             "lk_kron_quadform_shared_f16x2: sizes out of range");
-  return launch_quadform_conv<0>(u, v, l1, l2, delta, B, C, Do, Dk, L, fvar, ws, ws_bytes, (hipStream_t)stream,
-                                 "lk_kron_quadform_shared_f16x2", u_bound, v_bound);
-}
-
 // lk_kron_quadform_shared_f32 for u stored SEED-major, [C][B][Do][L] — what one seed-batched reverse sweep (and the
 // position-contiguous output of the rotation convolution over it) leaves in memory: no transposed copy is needed.
 extern "C" int lk_kron_quadform_shared_seedmajor_f32(const float* u, const float* v, const float* l1, const float* l2,
@@ -788,7 +674,7 @@ extern "C" int lk_kron_quadform_shared_seedmajor_f32(const float* u, const float
   LK_REQUIRE(B * 64 < (1ll << 31) && C * B * L * Do < (1ll << 31) && L * Dk < (1ll << 29),
              "lk_kron_quadform_shared_seedmajor_f32: sizes out of range");
   return launch_quadform_conv<0>(u, v, l1, l2, delta, B, C, Do, Dk, L, fvar, ws, ws_bytes, (hipStream_t)stream,
-                                 "lk_kron_quadform_shared_seedmajor_f32", nullptr, nullptr, true);
+                                 "lk_kron_quadform_shared_seedmajor_f32", true);
 }
 
 // The Kronecker quadratic form of a weight-sharing layer on operands that arrive as fp16 planes (quadform_conv_planes_kernel):

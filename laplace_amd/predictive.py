@@ -153,7 +153,6 @@ def glm_variance_kron(backend, x, post):
             bnd = {}
             u, v, gsum = _shared_operands(tap, g, B, C, Q1, Q2, bounds=bnd)
             l1c, l2c = l1.contiguous(), l2.contiguous()
-            ub, vb = bnd.get("u"), bnd.get("v")  # both known: the fp16x2 form of the kernel (three MFMAs per block)
             if bnd.get("planes"):  # both operands arrive as split planes from the rotation convolutions: one launch
                 K.kron_quadform_shared_planes(u, v, l1c, l2c, d1, fvar, C)
                 done = True
@@ -161,7 +160,7 @@ def glm_variance_kron(backend, x, post):
                 K.kron_quadform_shared(u, v, l1c, l2c, d1, fvar, seed_major=True)
                 done = True
             else:
-                done = _shared_quadform(K, lambda uu, vv, out: K.kron_quadform_shared(uu, vv, l1c, l2c, d1, out, ub, vb), u, v,
+                done = _shared_quadform(K, lambda uu, vv, out: K.kron_quadform_shared(uu, vv, l1c, l2c, d1, out), u, v,
                                         fvar, weight_sharing_only=tap.kind != "conv2d")
             if done:
                 if Qb is not None:

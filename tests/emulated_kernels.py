@@ -564,13 +564,10 @@ class EmulatedKernels:
 
     quadform_shared_max_outputs = 10
 
-    def kron_quadform_shared(self, u, v, l1, l2, delta, fvar, u_bound=None, v_bound=None, seed_major=False):
+    def kron_quadform_shared(self, u, v, l1, l2, delta, fvar, seed_major=False):
         if seed_major:
             u = u.permute(1, 0, 2, 3)
         assert u.shape[1] <= self.quadform_shared_max_outputs, "the HIP kernel holds at most 10 outputs"
-        if u_bound is not None and v_bound is not None:  # the fp16x2 form relies on these being bounds
-            assert float(u.abs().max()) <= float(u_bound[0]) * (1 + 1e-6) + 1e-30, "u_bound does not bound u"
-            assert float(v.abs().max()) <= float(v_bound[0]) * (1 + 1e-6) + 1e-30, "v_bound does not bound v"
         M = torch.einsum("ncol,nil->ncoi", u, v)
         fvar += torch.einsum("ncoi,nkoi,oi->nck", M, M, 1.0 / (torch.outer(l1, l2) + delta.reshape(())))
         return fvar

@@ -103,7 +103,7 @@ CASES = {
     "LK_NHWC_FORWARD=0": dict(sweep_attrs={"nhwc_forward": False}),
     "LK_PIXPAIR16=0": dict(kernel_attrs={"use_pixpair16": False}),
     "LK_SHIFTCORR=0": dict(kernel_attrs={"use_shiftcorr": False}, acc_attrs={"use_pixgram": False}),
-    "LK_QUAD16=1": dict(kernel_attrs={"use_quad16": True}),
+    "fp32-operand quadratic form": dict(kernel_attrs={"use_quad_planes": False}),
     "LK_WINP=0 (generic fused launches)": dict(kernel_attrs={"use_winp": False}),
     "LK_CONV_CONFIG plain row order": dict(kernel_attrs={"conv_config": 2 | 32768}),
     "LK_CONV_CONFIG round-4 window staging": dict(kernel_attrs={"conv_config": 2 | (1 << 30)}),

@@ -18,7 +18,6 @@ from laplace_amd.nets import ResNet18  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--profile", action="store_true")
 ap.add_argument("--batch", type=int, default=128)
-ap.add_argument("--quad16", action="store_true", help="also time the quadratic-form kernel on two-piece fp16 products (use_quad16)")
 args = ap.parse_args()
 dev = "cuda"
 torch.manual_seed(711)
@@ -51,6 +50,21 @@ def rate(x, reps):
 
 
 out["fused_samples_per_s"], fv = rate(X, 5)
+K.profile = prof0 = {}
+P.glm_variance_kron(backend, X, post)
+torch.cuda.synchronize()
+K.profile = None
+out["families_ms"] = {k: round(sum(e[0].elapsed_time(e[1]) for e in v), 3) for k, v in prof0.items()}
+if hasattr(K, "use_quad_planes"):  # the fp32-operand route (rotations emit fp32, in-flight three-piece bf16 split) beside it
+    K.use_quad_planes = False
+    out["fp32_operand_route_samples_per_s"], fv32 = rate(X, 5)
+    K.profile = prof1 = {}
+    P.glm_variance_kron(backend, X, post)
+    torch.cuda.synchronize()
+    K.profile = None
+    out["families_ms_fp32_operand_route"] = {k: round(sum(e[0].elapsed_time(e[1]) for e in v), 3) for k, v in prof1.items()}
+    out["planes_vs_fp32_route_max_rel_diff"] = float((fv - fv32).abs().max() / fv32.abs().max())
+    K.use_quad_planes = True
 K.profile = prof0 = {}
 P.glm_variance_kron(backend, X, post)
 torch.cuda.synchronize()
