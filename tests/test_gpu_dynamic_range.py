@@ -279,6 +279,7 @@ def test_one_scale_per_tensor_floor_and_what_the_per_image_split_makes_of_it():
     x[1] *= 1e-9
     back = K.split_f16x2(x.contiguous()).float()
     assert rel_rows(back[:1], x[:1]) < 2.0 ** -21
-    assert 2.0 ** -14 < rel_rows(back[1:], x[1:]) < 2.0 ** -6
+    floor = ((back[1:] - x[1:]).abs().max() / x[1:].abs().max()).item()  # (the pinned LIMIT, not a parity number: not logged)
+    assert 2.0 ** -14 < floor < 2.0 ** -6
     back = K.split_images_f16x2(x.contiguous()).float()
     assert rel_rows(back, x) < 2.0 ** -21

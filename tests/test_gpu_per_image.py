@@ -139,7 +139,8 @@ def test_forward_convolution_on_a_per_image_operand_over_thirteen_decades(cfg):
     assert r < 1e-5, f"per-image error {r:.2e}"
     # the same through one scale per tensor: what the per-image operand is for (reported, and pinned to be far worse)
     y1 = cv.conv_forward(prep, K.split_f16x2(x.permute(0, 2, 3, 1).contiguous())).permute(0, 3, 1, 2)
-    assert rel_rows(y1, want) > 1e-3
+    d1, w1 = y1.double().cpu().flatten(1), want.double().flatten(1)   # (not through rel_rows: this is no parity number)
+    assert ((d1 - w1).abs().amax(1) / (w1.abs().amax(1) + 1e-300)).max().item() > 1e-3
     Ho = want.shape[-1]
     if (Ho * Ho) % 4 == 0:  # the predictive's rotation: arbitrary filter bank, position-contiguous output
         filt = torch.randn(96, cin, k, k, device=DEV)

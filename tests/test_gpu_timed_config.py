@@ -318,6 +318,4 @@ def test_where_the_relu_margin_comes_from(act):
         ratio = max(ratio, errs["kernels"] / (errs["stock"] + 1e-300))
     print(f"  masks differing from the fp64 forward: kernels {flips['kernels']}, stock fp32 on the device {flips['stock']}; "
           f"worst ratio of the activation errors {ratio:.1f}")
-    record_error(float(flips["kernels"]), "mask-flips-kernels")
-    record_error(float(flips["stock"]), "mask-flips-stock-fp32-device")
     assert ratio < 6.0 and flips["kernels"] <= 4 * flips["stock"] + 8  # (measured: 3.2, 5 vs 5)
