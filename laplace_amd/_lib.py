@@ -437,9 +437,14 @@ class HipKernels:
         planes = torch.empty((2,) + tuple(x.shape), dtype=torch.float16, device=x.device)
         sexp = torch.empty(N, dtype=torch.int32, device=x.device)
         amax = torch.empty(N, dtype=torch.float32, device=x.device)
-        self._rc(self.lib.lk_split_images_f16x2(_ptr(x), N, per, _ptr(planes[0]), _ptr(planes[1]), _ptr(sexp), _ptr(amax),
-                                                self._stream(x.device)), "lk_split_images_f16x2")
+        for i in range(0, max(N, 1), self.MAX_IMAGES_PER_LAUNCH):  # (the image index is a grid dimension: 65535 per launch)
+            n = min(self.MAX_IMAGES_PER_LAUNCH, N - i)
+            self._rc(self.lib.lk_split_images_f16x2(_ptr(x[i:i + n]), n, per, _ptr(planes[0][i:i + n]), _ptr(planes[1][i:i + n]),
+                                                    _ptr(sexp[i:i + n]), _ptr(amax[i:i + n]), self._stream(x.device)),
+                     "lk_split_images_f16x2")
         return SplitTensor(planes, sexp, amax)
+
+    MAX_IMAGES_PER_LAUNCH = 65535
 
     def conv_prep_weights(self, W, transpose, cscale=None):
         """conv weight ``[Co, Ci, KH, KW]`` -> (planes ``[2, T, N, K]`` fp16, sexp); see lk_conv_prep_weights_f16x2"""
@@ -682,12 +687,23 @@ class HipKernels:
             raise LaplaceHipError("bn_act_forward_nhwc: x_amax / addend_bound have 1 or B entries, amax_words B")
         nbytes = x.numel() * (4.0 + 4.0 + (4.0 if addend is not None else 0.0) + (4.0 if want_split else 0.0)
                               + (1.0 if mask is not None else 0.0))
-        self._rc(self._timed("bnact16", nbytes, x.device, lambda: self.lib.lk_bn_act_fwd_nhwc_f16x2(
-            _ptr(x), _ptr(x_amax), x_amax.numel(), _ptr(x_mul), _ptr(x_add), _ptr(scale), _ptr(shift), _ptr(scale_amax),
-            _ptr(shift_amax), _ptr(addend), _ptr(addend_bound), 1 if addend_bound is None else addend_bound.numel(), int(act),
-            C, B, x.numel() // max(B, 1), _ptr(y), _ptr(mask), None if planes is None else _ptr(planes[0]),
-            None if planes is None else _ptr(planes[1]), _ptr(sexp), _ptr(bound), _ptr(amax), self._stream(x.device))),
-            "lk_bn_act_fwd_nhwc_f16x2")
+        per = x.numel() // max(B, 1)
+        sl = lambda t, i, n: None if t is None else (t if t.numel() == 1 else t[i:i + n])  # a per-image vector, or one word
+
+        def launch(i, n):
+            return self.lib.lk_bn_act_fwd_nhwc_f16x2(
+                _ptr(x[i:i + n]), _ptr(sl(x_amax, i, n)), min(x_amax.numel(), n), _ptr(x_mul), _ptr(x_add), _ptr(scale), _ptr(shift),
+                _ptr(scale_amax), _ptr(shift_amax), None if addend is None else _ptr(addend[i:i + n]), _ptr(sl(addend_bound, i, n)),
+                1 if addend_bound is None else min(addend_bound.numel(), n), int(act), C, n, per, _ptr(y[i:i + n]),
+                None if mask is None else _ptr(mask[i:i + n]), None if planes is None else _ptr(planes[0][i:i + n]),
+                None if planes is None else _ptr(planes[1][i:i + n]), _ptr(sexp[i:i + n]), _ptr(bound[i:i + n]), _ptr(amax[i:i + n]),
+                self._stream(x.device))
+
+        if B <= self.MAX_IMAGES_PER_LAUNCH:
+            self._rc(self._timed("bnact16", nbytes, x.device, lambda: launch(0, B)), "lk_bn_act_fwd_nhwc_f16x2")
+        else:  # (the image index is a grid dimension: 65535 per launch)
+            for i in range(0, B, self.MAX_IMAGES_PER_LAUNCH):
+                self._rc(launch(i, min(self.MAX_IMAGES_PER_LAUNCH, B - i)), "lk_bn_act_fwd_nhwc_f16x2")
         return y, mask, (SplitTensor(planes, sexp, amax) if planes is not None else None), bound
 
     def unsplit_transpose(self, x, S, B):
