@@ -79,7 +79,7 @@ def test_rotation_convolutions_emit_split_planes(cfg):
             vg = cv.conv_forward_filters(m, x, filt, Q2, planes=True)
         finally:
             K.conv_config = prev
-        assert torch.equal(vg.sexp, v.sexp) and rel_rows(vg.float(), v.float()) < 2e-6
+        assert torch.equal(vg.sexp, v.sexp) and rel_rows(vg.float(), v.float()) < 5e-6  # (another order of the K sum)
     # u: 1x1 rotation of a split cotangent (ONE scale), [S * B, Ho, Ho, cout] -> [S * B, cout, L]
     S = 3
     g = torch.randn(S * B, Ho, Ho, cout, device=DEV)

@@ -65,40 +65,6 @@ if hasattr(K, "use_quad_planes"):  # the fp32-operand route (rotations emit fp32
     out["families_ms_fp32_operand_route"] = {k: round(sum(e[0].elapsed_time(e[1]) for e in v), 3) for k, v in prof1.items()}
     out["planes_vs_fp32_route_max_rel_diff"] = float((fv - fv32).abs().max() / fv32.abs().max())
     K.use_quad_planes = True
-K.profile = prof0 = {}
-P.glm_variance_kron(backend, X, post)
-torch.cuda.synchronize()
-K.profile = None
-out["families_ms"] = {k: round(sum(e[0].elapsed_time(e[1]) for e in v), 3) for k, v in prof0.items()}
-if hasattr(K, "use_quad_planes"):  # the fp32-operand route (rotations emit fp32, in-flight three-piece bf16 split) beside it
-    K.use_quad_planes = False
-    out["fp32_operand_route_samples_per_s"], fv32 = rate(X, 5)
-    K.profile = prof1 = {}
-    P.glm_variance_kron(backend, X, post)
-    torch.cuda.synchronize()
-    K.profile = None
-    out["families_ms_fp32_operand_route"] = {k: round(sum(e[0].elapsed_time(e[1]) for e in v), 3) for k, v in prof1.items()}
-    out["planes_vs_fp32_route_max_rel_diff"] = float((fv - fv32).abs().max() / fv32.abs().max())
-    K.use_quad_planes = True
-if args.quad16:  # A/B in one process (box-to-box variation exceeds what is compared here): default, quad16, default, quad16
-    ab = {"bf16x3": [out["fused_samples_per_s"]], "f16x2": []}
-    for _ in range(2):
-        K.use_quad16 = True
-        r, fv16 = rate(X, 5)
-        ab["f16x2"].append(r)
-        K.use_quad16 = False
-        ab["bf16x3"].append(rate(X, 5)[0])
-    out["quad16_ab_samples_per_s"] = ab
-    out["quad16_max_rel_diff"] = float((fv16 - fv).abs().max() / fv.abs().max())
-    prof = {}
-    for flag in (False, True):
-        K.use_quad16 = flag
-        K.profile = prof = {}
-        P.glm_variance_kron(backend, X, post)
-        torch.cuda.synchronize()
-        K.profile = None
-        out["families_ms_" + ("f16x2" if flag else "bf16x3")] = {k: round(sum(e[0].elapsed_time(e[1]) for e in v), 3) for k, v in prof.items()}
-    K.use_quad16 = False
 if not args.profile:
     small = X[:8]
     _, fv_small = rate(small, 1)
