@@ -223,14 +223,12 @@ int lk_conv_nhwc_f16x2(const void* in_h, const void* in_l, const int* in_sexp, i
  * with the scale left in out_sexp[n].  (Ho * Wo) % 4 == 0; in_mul = the convolution's stride.  This is how the Kron predictive's
  * eigenbasis rotations (laplace/utils/matrix.py:406-456: Q1^T over the output cotangents as a 1x1 convolution, the unfolded
  * inputs times Q2 as a convolution whose filters are the eigenvectors) hand their results to
- * lk_kron_quadform_shared_planes_f16x2: no fp32 round trip, nothing left to split inside the quadratic-form kernel.  wc_h / wc_l
- * (may be NULL): the filters also chunk-major as for lk_conv_nhwc_f16x2_vjp_wc — eligible 3 x 3 / stride-1 shapes with
- * (Ho * Wo) % 8 == 0 then run the persistent window kernel with this epilogue. */
+ * lk_kron_quadform_shared_planes_f16x2: no fp32 round trip, nothing left to split inside the quadratic-form kernel. */
 int lk_conv_nhwc_f16x2_planes(const void* in_h, const void* in_l, const int* in_sexp, int64_t in_nsexp, const void* in_amax,
                               int64_t N, int64_t Hi, int64_t Wi, int64_t Ci, const void* w_h, const void* w_l,
                               const int* w_sexp, const float* w_l1, int64_t Co, int64_t Ho, int64_t Wo, int64_t in_mul, int64_t T,
-                              const int* taps, const void* zero16, const void* wc_h, const void* wc_l, void* out_h, void* out_l,
-                              int* out_sexp, int config, void* stream);
+                              const int* taps, const void* zero16, void* out_h, void* out_l, int* out_sexp, int config,
+                              void* stream);
 
 /* lk_conv_nhwc_f16x2 with the element-wise VJP of the sweep fused into its epilogue (one dense launch: forward / stride-1
  * backward-data; Co % 8 == 0):

@@ -67,7 +67,7 @@ SIGNATURES = {
     "lk_conv_nhwc_f16x2": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64,
                                   _i64, _i64, _i64, _i64, _vp, _vp, _vp, _int, _vp, _int, _vp]),
     "lk_conv_nhwc_f16x2_planes": (_int, [_vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64,
-                                         _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp]),
+                                         _i64, _vp, _vp, _vp, _vp, _vp, _int, _vp]),
     "lk_conv_nhwc_f16x2_vjp": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64,
                                       _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _i64, _vp, _vp, _vp, _vp, _vp,
                                       _vp, _int, _vp]),
@@ -501,12 +501,10 @@ class HipKernels:
             _ptr(out), 1 if accumulate else 0, _ptr(amax_out), int(cfg), self._stream(out.device))), "lk_conv_nhwc_f16x2")
         return out
 
-    def conv_nhwc_f16x2_planes(self, x, wplanes, wsexp, w_l1, Ho, Wo, in_mul, taps, config=None, wplanes_chunked=None):
+    def conv_nhwc_f16x2_planes(self, x, wplanes, wsexp, w_l1, Ho, Wo, in_mul, taps, config=None):
         """lk_conv_nhwc_f16x2_planes: the convolution of SplitTensor ``x [N, Hi, Wi, Ci]`` with ``wplanes [2, T, Co, Ci]``,
         position-contiguous and ALREADY SPLIT: SplitTensor ``[N, Co, Ho * Wo]`` with the scales of ``x``'s granularity
-        (one for the tensor or one per image), each from the bound ``max|x_n| * w_l1`` (no pass over the output).
-        ``wplanes_chunked`` ``[2, T, Ci / 16, Co, 16]``: the same filters chunk-major — eligible 3 x 3 / stride-1 shapes then
-        run the persistent window kernel"""
+        (one for the tensor or one per image), each from the bound ``max|x_n| * w_l1`` (no pass over the output)"""
         N, Hi, Wi, Ci = x.planes.shape[1:]
         Co = wplanes.shape[2]
         dev = x.planes.device
@@ -517,12 +515,9 @@ class HipKernels:
         cfg = self.conv_config if config is None else config
         amax = x.amax if (x.amax is not None and x.amax.numel() == x.sexp.numel()) else None
         work = 2.0 * N * Co * Ci * self.conv_valid_pairs(Ho, Wo, in_mul, Hi, Wi, taps) if self.profile is not None else 0.0
-        if wplanes_chunked is not None:
-            assert wplanes_chunked.shape == (2, wplanes.shape[1], Ci // 16, Co, 16) and wplanes_chunked.is_contiguous()
-        self._rc(self._timed("conv16" if wplanes_chunked is None else "convp16", work, dev, lambda: self.lib.lk_conv_nhwc_f16x2_planes(
+        self._rc(self._timed("conv16", work, dev, lambda: self.lib.lk_conv_nhwc_f16x2_planes(
             _ptr(x.planes[0]), _ptr(x.planes[1]), _ptr(x.sexp), x.sexp.numel(), _ptr(amax), N, Hi, Wi, Ci, _ptr(wplanes[0]),
             _ptr(wplanes[1]), _ptr(wsexp), _ptr(w_l1), Co, Ho, Wo, in_mul, len(taps), flat, _ptr(self._zero16(dev)),
-            None if wplanes_chunked is None else _ptr(wplanes_chunked[0]), None if wplanes_chunked is None else _ptr(wplanes_chunked[1]),
             _ptr(planes[0]), _ptr(planes[1]), _ptr(sexp), int(cfg), self._stream(dev))), "lk_conv_nhwc_f16x2_planes")
         return SplitTensor(planes, sexp)
 

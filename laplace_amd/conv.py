@@ -273,18 +273,7 @@ def conv_forward_filters(m: nn.Conv2d, a: torch.Tensor, filt: torch.Tensor, key_
     Dk = filt.shape[0]
     taps = [(kh - ph, kw - pw, kh * KW + kw) for kh in range(KH) for kw in range(KW)]
     if planes:
-        wc = None
-        if (s == 1 and (KH, KW) == (3, 3) and (ph, pw) == (1, 1) and planes_w.shape[3] % 16 == 0 and (Ho * Wo) % 8 == 0
-                and K.conv_winp_eligible(N, Hin, Win, planes_w.shape[3], Dk, 9)):
-            # 3 x 3 / stride-1 layers: the persistent window kernel (as much matrix work as a backward-data launch of the fit),
-            # which stages its weights chunk-major — cached with the planes
-            wc = getattr(key_tensor, "_lk_filter_planes_chunked", None)
-            if wc is None or wc[0] != key:
-                two, T, Nf, Kd = planes_w.shape
-                wc = (key, planes_w.view(two, T, Nf, Kd // 16, 16).permute(0, 1, 3, 2, 4).contiguous())
-                key_tensor._lk_filter_planes_chunked = wc
-            wc = wc[1]
-        return K.conv_nhwc_f16x2_planes(xs, planes_w, sexp, hit[2], Ho, Wo, s, taps, config=(K.conv_config | 2), wplanes_chunked=wc)
+        return K.conv_nhwc_f16x2_planes(xs, planes_w, sexp, hit[2], Ho, Wo, s, taps, config=(K.conv_config | 2))
     out = torch.empty(N, Dk, Ho, Wo, dtype=torch.float32, device=a.device)
     # config bit 4: position-contiguous output; the wrapper reads shapes off an NHWC-shaped view of the same memory
     K.conv_nhwc_f16x2(xs, planes_w, sexp, Ho, Wo, s, out.view(N, Ho, Wo, Dk), 1, 0, 0, taps, amax_out=amax_out,

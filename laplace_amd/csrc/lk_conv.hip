@@ -1128,7 +1128,7 @@ struct WinPCfg {
 };
 
 struct WinPArgs {  // (a slim argument block: everything here stays in scalar registers for the whole launch)
-  int M, Hi, Wi, Ci, Co, HW, n_tiles, nb_m, wt0, wtstep, stagger, ablate, halo_all, coloc, a_nsexp;
+  int M, Hi, Wi, Ci, Co, HW, n_tiles, nb_m, wt0, wtstep, stagger, ablate, halo_all, coloc;
   FastDiv div_hw, div_w, div_mask;
   const _Float16 *Ah, *Al, *Wh, *Wl;
   const int *a_sexp, *w_sexp, *add_sexp;
@@ -1148,12 +1148,7 @@ struct WinPArgs {  // (a slim argument block: everything here stays in scalar re
 __device__ unsigned long long g_winp_trace[1024 * 16 * 3];
 #endif
 
-// EPI = 0: the fused VJP epilogue (reverse sweep); EPI = 1 (round 5): the output POSITION-contiguous as two fp16 planes,
-// out[n][co][pixel], scaled per entry of a_sexp from the bound in_amax[n] * l1(W) — the Kron predictive's rotation of the
-// unfolded inputs into an A factor's eigenbasis (a 3 x 3 convolution with 9 Ci output "channels": as much matrix work per
-// layer as a backward-data launch of the fit), which ran on the generic kernel at 0.25 of the peak.  Same K loop; the
-// epilogue needs no LDS image: the MFMA layout already has lane = channel, registers = four consecutive pixels.
-template <typename CFG, int EPI = 0>
+template <typename CFG>
 __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WPE, CFG::WPE)))
 void conv_winp_f16x2_kernel(const WinPArgs p) {
   constexpr int BM = CFG::BM, NW = CFG::NW, PP = CFG::PP, TM = 2, TN = 2, PITCH = CFG::EPI_PITCH, NS = CFG::NSLICE;
@@ -1204,20 +1199,19 @@ void conv_winp_f16x2_kernel(const WinPArgs p) {
 
   // ---- scales (see conv_f16x2_kernel): the result's scale from the guaranteed bound
   const int sexp_a = p.a_sexp[0], sexp_w = p.w_sexp[0];
-  const float inv_w = exp2i(-sexp_w < -126 ? -126 : -sexp_w);
-  const float inv = exp2i(-sexp_a < -126 ? -126 : -sexp_a) * inv_w;
+  const float inv = exp2i(-sexp_a < -126 ? -126 : -sexp_a) * exp2i(-sexp_w < -126 ? -126 : -sexp_w);
   float inv2 = 0.f;
   float bound = p.in_amax ? __uint_as_float(p.in_amax[0]) : exp2i(15 - sexp_a < -126 ? -126 : (15 - sexp_a > 127 ? 127 : 15 - sexp_a));
   bound *= p.w_l1[0];
-  if (EPI == 0 && p.add_h) {
+  if (p.add_h) {
     const int s2 = p.add_sexp[0];
     bound += exp2i(15 - s2 < -126 ? -126 : (15 - s2 > 127 ? 127 : 15 - s2));
     inv2 = exp2i(-s2 < -126 ? -126 : -s2);
   }
-  if (EPI == 0 && p.scale) bound *= __uint_as_float(p.scale_amax[0]);
+  if (p.scale) bound *= __uint_as_float(p.scale_amax[0]);
   const int so = scale_exp_for(bound);
   const float sc_out = exp2i(so);
-  if (EPI == 0 && blockIdx.x == 0 && tid == 0) p.out_sexp[0] = so;  // (EPI 1: one scale per a_sexp entry, written by the epilogue)
+  if (blockIdx.x == 0 && tid == 0) p.out_sexp[0] = so;
 
   // ---- window staging: wave-instruction i = it * NW + wave covers slots [64 i, 64 i + 64) of [plane][pixel][2].
   //      Addresses are (scalar base) + (32-bit lane offset): the lane offsets are the only registers the staging keeps.
@@ -1526,54 +1520,6 @@ void conv_winp_f16x2_kernel(const WinPArgs p) {
     fresh = true;
   };
 
-  // ---- EPI 1: position-contiguous split planes straight from the accumulators (lane = channel, registers 4 q .. 4 q + 3 =
-  //      four consecutive pixels; lanes l / l + 32 hold the two halves of an 8-pixel run and swap one each, so that every
-  //      lane stores 16 bytes of ONE plane: see the same epilogue of conv_f16x2_kernel)
-  int pl_ns = -1, pl_so = 0;
-  float pl_sc = 0.f;
-  auto epilogue_planes = [&](int m0_t, int n0_t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (as the fused epilogue: nothing of this wave's requests behind its stores)
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int m = m0_t + wave * 64 + a * 32 + 8 * q + 4 * lh;  // first of this lane's four pixels
-        if (m - 4 * lh >= M) continue;                              // (M % 8 == 0: a run exists or it does not, for both lanes)
-        const int n = fdiv(m, p.div_hw), pix = m - n * p.HW;
-        const int ns = p.a_nsexp > 1 ? n : 0;
-        if (ns != pl_ns) {
-          const int sa = p.a_sexp[ns];
-          const float b_in = p.in_amax ? __uint_as_float(p.in_amax[ns]) : exp2i(15 - sa < -126 ? -126 : (15 - sa > 127 ? 127 : 15 - sa));
-          pl_so = scale_exp_for(b_in * p.w_l1[0]);
-          pl_sc = exp2i(pl_so) * inv_w * exp2i(-sa < -126 ? -126 : -sa);
-          pl_ns = ns;
-        }
-#pragma unroll
-        for (int b = 0; b < TN; ++b) {
-          const int col = n0_t + b * 32 + lr;
-          f16x4 h4, l4;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float xs = acc[a][b][4 * q + j] * pl_sc;
-            asm volatile("" : "+v"(xs));
-            const _Float16 hh = (_Float16)xs;
-            h4[j] = hh;
-            l4[j] = (_Float16)(xs - (float)hh);
-          }
-          if (col == 0 && pix == 0 && (p.a_nsexp > 1 || n == 0)) p.out_sexp[ns] = pl_so;
-          const uint2 mine = lh ? __builtin_bit_cast(uint2, h4) : __builtin_bit_cast(uint2, l4);  // what the partner stores
-          uint2 got;
-          got.x = (unsigned)__shfl_xor((int)mine.x, 32, 64);
-          got.y = (unsigned)__shfl_xor((int)mine.y, 32, 64);
-          const uint2 keep = lh ? __builtin_bit_cast(uint2, l4) : __builtin_bit_cast(uint2, h4);
-          const u32x4 out8 = lh ? u32x4{got.x, got.y, keep.x, keep.y} : u32x4{keep.x, keep.y, got.x, got.y};
-          const int64_t e = ((int64_t)n * p.Co + col) * p.HW + (pix - 4 * lh);
-          __builtin_nontemporal_store(out8, reinterpret_cast<u32x4*>((lh ? p.out_l : p.out_h) + e));
-        }
-      }
-    fresh = true;
-  };
-
   // prologue: the first tile's first window and first three taps
   setup_window(m0);
   setup_frag(m0);
@@ -1600,14 +1546,13 @@ void conv_winp_f16x2_kernel(const WinPArgs p) {
     const bool last_tile = !coords(tile + G, next_m0, next_n0);
     LK_WINP_STAMP(0)
     for (int kc = 0; kc < KC; ++kc) {
-      if (EPI == 0 && kc == KC - 1) epi_request(m0, n0, 0, NH);
+      if (kc == KC - 1) epi_request(m0, n0, 0, NH);
       step(kc, last_tile, std::integral_constant<int, 0>{});
       step(kc, last_tile, std::integral_constant<int, 1>{});
       step(kc, last_tile, std::integral_constant<int, 2>{});
     }
     LK_WINP_STAMP(1)
-    if constexpr (EPI == 1) epilogue_planes(m0, n0);
-    else if (!(ablate & 1)) epilogue(m0, n0);
+    if (!(ablate & 1)) epilogue(m0, n0);
     else if (acc[0][0][0] == 12345.678f) p.out_h[0] = (_Float16)1.f;
     LK_WINP_STAMP(2)
 #ifdef LK_WINP_TRACE
@@ -1624,7 +1569,7 @@ void conv_winp_f16x2_kernel(const WinPArgs p) {
     m0 = next_m0, n0 = next_n0;
     if (!frag_const) setup_frag(m0);
   }
-  if (EPI == 0 && p.amax_out) {
+  if (p.amax_out) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) vmax = max(vmax, (unsigned)__shfl_xor((int)vmax, off, 64));
     const int back = -so < -126 ? -126 : -so;
@@ -1787,7 +1732,7 @@ static int coloc_default(int Ci, int Co) {
   return Co >= 256 ? 4 : (Co == 128 ? 2 : 1);
 }
 
-template <typename CFG, int EPI = 0>
+template <typename CFG>
 static bool launch_winp(const ConvGeom& g, const void* Ah, const void* Al, const void* Wh /* chunk-major */, const void* Wl, const int* a_sexp,
                         const int* w_sexp, unsigned* amax_out, hipStream_t stream, const ConvVjp* fz, int* rc, int config) {
   int wt[9];
@@ -1816,14 +1761,13 @@ static bool launch_winp(const ConvGeom& g, const void* Ah, const void* Al, const
   p.mask = (const unsigned char*)fz->mask, p.mask_rows = (int)fz->mask_rows;
   p.stagger = 3 * (g.Ci / 64);  // start delay of a CU's second workgroup, x 64 s_sleep cycles (measured: 0 .. 8, flat around 3)
   p.ablate = 0;
-  p.a_nsexp = g.a_nsexp;
   p.halo_all = (config >> 30) & 1;  // (development: stage the whole PP-pixel window as round 4 did)
   p.coloc = 1;
   p.out_h = fz->out_h, p.out_l = fz->out_l, p.out_sexp = fz->out_sexp;
   p.amax_out = amax_out;
-  static bool attr_set = false;  // (one per instantiation: EPI is a template parameter of this function)
+  static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_winp_f16x2_kernel<CFG, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS);
+    (void)hipFuncSetAttribute((const void*)conv_winp_f16x2_kernel<CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS);
     attr_set = true;
   }
   constexpr int wg_per_cu = 2;
@@ -1835,7 +1779,7 @@ static bool launch_winp(const ConvGeom& g, const void* Ah, const void* Al, const
     if (c == 1) c = coloc_default(g.Ci, g.Co);
     if (c > 1 && c <= nb_n && nb_n % c == 0 && nb_n / c <= 8 && 8 % (nb_n / c) == 0 && grid % 8 == 0 && (grid / 8) % c == 0) p.coloc = c;
   }
-  hipLaunchKernelGGL((conv_winp_f16x2_kernel<CFG, EPI>), dim3((unsigned)grid), dim3(CFG::NT), CFG::LDS, stream, p);
+  hipLaunchKernelGGL((conv_winp_f16x2_kernel<CFG>), dim3((unsigned)grid), dim3(CFG::NT), CFG::LDS, stream, p);
   *rc = check_launch("conv_winp_f16x2_kernel");
   return true;
 }
@@ -1869,12 +1813,6 @@ static int conv_dispatch(const void* in_h, const void* in_l, const int* in_sexp,
   hipStream_t st = (hipStream_t)stream;
   // persistent window form (fused launches with 64 output channels whose caller also handed over chunk-major weights;
   // config bit 27 switches it off): see conv_winp_f16x2_kernel
-  if (fz && g.out_planes && fz->wc_h && !(config & 134217728) && lk_conv_winp_eligible(N, Hi, Wi, Ci, Co, T, 0) && in_mul == 1 &&
-      Hc == Hi && Wc == Wi && g.dense && (Hi * Wi) % 8 == 0 && N * Hi * Wi * Co < (1ll << 40)) {
-    // the predictive's 3 x 3 rotation on the persistent window kernel, split planes out (EPI 1)
-    int rc = LK_OK;
-    if (launch_winp<WinPCfg<256>, 1>(g, in_h, in_l, fz->wc_h, fz->wc_l, in_sexp, w_sexp, nullptr, st, fz, &rc, config)) return rc;
-  }
   if (fz && !g.out_planes && fz->wc_h && !(config & 134217728) && lk_conv_winp_eligible(N, Hi, Wi, Ci, Co, T, fz->mask && fz->mask_float) &&
       in_mul == 1 && Hc == Hi && Wc == Wi && g.dense) {
     int rc = LK_OK;
@@ -1936,19 +1874,14 @@ extern "C" int lk_conv_nhwc_f16x2(const void* in_h, const void* in_l, const int*
 // fp32: scaled per entry of in_sexp (the whole tensor, or image by image) from the guaranteed bound
 //   max|out_n| <= in_amax[n] * w_l1[0]      (in_amax: in_nsexp words, bit patterns, or NULL = 2^(15 - in_sexp[n]))
 // with the scale left in out_sexp[n].  Dense grid, (Ho * Wo) % 4 == 0.  What the predictive's eigenbasis rotations hand to
-// lk_kron_quadform_shared_planes_f16x2: no fp32 round trip, no splitting inside the quadratic-form kernel.  wc_h / wc_l (may be
-// NULL): the filters also chunk-major, [tap][Ci / 16][Co][16] per plane — 3 x 3 / stride-1 shapes lk_conv_winp_eligible accepts
-// (and (Ho * Wo) % 8 == 0) then run the persistent window kernel with this epilogue.
+// lk_kron_quadform_shared_planes_f16x2: no fp32 round trip, no splitting inside the quadratic-form kernel.
 extern "C" int lk_conv_nhwc_f16x2_planes(const void* in_h, const void* in_l, const int* in_sexp, int64_t in_nsexp,
                                          const void* in_amax, int64_t N, int64_t Hi, int64_t Wi, int64_t Ci, const void* w_h,
                                          const void* w_l, const int* w_sexp, const float* w_l1, int64_t Co, int64_t Ho,
                                          int64_t Wo, int64_t in_mul, int64_t T, const int* taps, const void* zero16,
-                                         const void* wc_h, const void* wc_l, void* out_h, void* out_l, int* out_sexp, int config,
-                                         void* stream) {
+                                         void* out_h, void* out_l, int* out_sexp, int config, void* stream) {
   LK_REQUIRE(w_l1 && out_h && out_l && out_sexp, "lk_conv_nhwc_f16x2_planes: null pointer");
-  LK_REQUIRE(!wc_h == !wc_l, "lk_conv_nhwc_f16x2_planes: incomplete chunk-major filters");
   ConvVjp fz{};
-  fz.wc_h = (const _Float16*)wc_h, fz.wc_l = (const _Float16*)wc_l;
   fz.in_amax = (const unsigned*)in_amax, fz.w_l1 = w_l1;
   fz.out_h = (_Float16*)out_h, fz.out_l = (_Float16*)out_l, fz.out_sexp = out_sexp;
   fz.mask_rows = 1, fz.div_mask = make_fastdiv(1);

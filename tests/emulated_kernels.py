@@ -138,10 +138,7 @@ class EmulatedKernels:
             amax_out.copy_(torch.maximum(amax_out, view.abs().max().reshape(1)))
         return out
 
-    def conv_nhwc_f16x2_planes(self, x, wplanes, wsexp, w_l1, Ho, Wo, in_mul, taps, config=None, wplanes_chunked=None):
-        if wplanes_chunked is not None:  # the same filters, chunk-major: must agree with the GEMM-natural planes
-            two, T, N_, Kd = wplanes.shape
-            assert torch.equal(wplanes_chunked, wplanes.view(two, T, N_, Kd // 16, 16).permute(0, 1, 3, 2, 4))
+    def conv_nhwc_f16x2_planes(self, x, wplanes, wsexp, w_l1, Ho, Wo, in_mul, taps, config=None):
         """lk_conv_nhwc_f16x2_planes: position-contiguous output as a SplitTensor [N, Co, Ho * Wo], scaled per entry of x.sexp
         from the bound max|x_n| * w_l1"""
         from laplace_amd._lib import SplitTensor
