@@ -96,3 +96,45 @@ def test_the_callers_buffers_may_be_refilled_between_minibatches():
     for F1, F0 in zip(k1.kfacs, k0.kfacs):
         for a, c in zip(F1, F0):
             assert rel(a, c) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["c1_mlp", "c2_lenet"])
+def test_stacked_minibatches_on_the_device(which):
+    """the BASELINE small configs on the real kernels: the stacked fit against the minibatch-by-minibatch fit (same kernels,
+    other sweep sizes) and, for c1, against the fp64 oracle"""
+    from laplace_amd import _lib
+    from laplace_amd.nets import lenet5, mlp_1_50_1
+
+    prev = _lib.set_kernels_for_testing(None)  # (this file's fixture installed the emulation: back to the HIP library)
+    try:
+        dev = "cuda"
+        torch.manual_seed(711)
+        if which == "c1_mlp":
+            model, lik = mlp_1_50_1().to(dev), "regression"
+            X = (8 * torch.rand(1000, 1)).to(dev)
+            y = (torch.sin(X) + 0.3 * torch.randn_like(X)).to(dev)
+            bs = 100
+        else:
+            model, lik = lenet5().to(dev), "classification"
+            X = torch.randn(2560, 3, 32, 32, device=dev)
+            y = torch.randint(0, 10, (2560,), device=dev)
+            bs = 256
+        batches = [(X[i:i + bs], y[i:i + bs]) for i in range(0, len(X), bs)]
+        l1, k1, s1 = _fit(model, lik, batches, len(X), True)
+        l0, k0, s0 = _fit(model, lik, batches, len(X), False)
+        assert len(s1) < len(s0) and sum(s1) == sum(s0) == len(X)
+        assert rel(l1.cpu(), l0.cpu()) < 1e-5
+        for F1, F0 in zip(k1.kfacs, k0.kfacs):
+            for a, b in zip(F1, F0):
+                assert rel(a.cpu(), b.cpu()) < 1e-5
+        if which == "c1_mlp":
+            import copy
+
+            m64 = copy.deepcopy(model).double().cpu()
+            _, kf_ref = co.kfac_ggn(m64, X.double().cpu(), y.double().cpu(), len(X), lik)
+            for F1, G in zip(k1.kfacs, kf_ref):
+                for a, w in zip(F1, G):
+                    assert rel(a.cpu(), w) < 1e-5
+    finally:
+        _lib.set_kernels_for_testing(prev)
