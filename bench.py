@@ -528,8 +528,9 @@ def main():
             "convs16": ("lk::conv_strided_f16x2_kernel: backward-data of the three down-sampling blocks (3x3 / stride 2, all "
                         "four residue classes, + the 1x1 shortcut) with the fused VJP epilogue, one launch per block; " + F16X2,
                         "mfma16", "lk::conv_strided_f16x2_kernel"),
-            "conv16": ("lk::conv_f16x2_kernel: the generic implicit-GEMM convolution — the forward pass (batch 128) and what "
-                       "the two fused forms do not cover; " + F16X2, "mfma16", "lk::conv_f16x2_kernel"),
+            "conv16": ("lk::conv_f16x2_kernel: the generic implicit-GEMM convolution — the forward pass (batch 128, eval-mode "
+                       "BatchNorm / residual add / ReLU in its epilogue) and what the two fused backward forms do not cover; "
+                       + F16X2, "mfma16", "lk::conv_f16x2_kernel"),
             "gram16": ("lk::gram16_kernel (+ fixed-order reduce): G factors as Grams of the NHWC split cotangents through "
                        "transposing LDS reads; symmetric-half flop K*n*(n+1); " + F16X2, "mfma16", "lk::gram16_kernel", ",0>"),
             "vjp16": ("lk::vjp_nhwc_split_kernel: element-wise VJP (mask x folded BatchNorm scale x residual add) of all "

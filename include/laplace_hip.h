@@ -230,6 +230,24 @@ int lk_conv_nhwc_f16x2_planes(const void* in_h, const void* in_l, const int* in_
                               const int* taps, const void* zero16, void* out_h, void* out_l, int* out_sexp, int config,
                               void* stream);
 
+/* lk_conv_nhwc_f16x2 (dense output grid; in_mul = the convolution's stride) with the forward's eval-mode BatchNorm, residual
+ * add and ReLU in its epilogue — the model's forward pass inside GGNInterface / CurvlinopsInterface
+ * (laplace/curvature/curvature.py:309-311 `self.model(x)`; torchvision-style conv -> bn -> (+ identity) -> relu blocks):
+ *     y[n][i][j][c] = act(conv[n][i][j][c] * scale[c] + shift[c] + addend[n][i][j][c])        act: 0 none, 1 ReLU
+ * To the bit what lk_conv_nhwc_f16x2 followed by lk_bn_act_fwd_nhwc_f16x2 (x_mul = w_l1, no x_add) computes — the same fp32
+ * operations in the same order — in one launch and without the fp32 round trip of the convolution's output.  in_amax:
+ * in_namax (1 or N) words with the measured max|in_n|; w_l1: max_co sum |W[co]| (device word).  Outputs: y fp32 NHWC, mask
+ * (NHWC bytes y > 0, may be NULL), y_h / y_l (both or none: the split planes of y with one scale per image, y_sexp[N], from the
+ * guaranteed bound y_bound[N] = in_amax[n] w_l1 max|scale| + max|shift| + addend_bound[n]), y_amax[N] (measured max|y_n| as bit
+ * patterns; zeroed by the caller).  Co % 8 == 0; addend_bound: 1 or N floats. */
+int lk_conv_bn_act_nhwc_f16x2(const void* in_h, const void* in_l, const int* in_sexp, int64_t in_nsexp, const void* in_amax,
+                              int64_t in_namax, int64_t N, int64_t Hi, int64_t Wi, int64_t Ci, const void* w_h, const void* w_l,
+                              const int* w_sexp, const float* w_l1, int64_t Co, int64_t Ho, int64_t Wo, int64_t in_mul,
+                              int64_t T, const int* taps, const void* zero16, const float* scale, const float* shift,
+                              const void* scale_amax, const void* shift_amax, const float* addend, const float* addend_bound,
+                              int64_t addend_nbound, int act, float* y, void* mask, void* y_h, void* y_l, int* y_sexp,
+                              float* y_bound, void* y_amax, int config, void* stream);
+
 /* lk_conv_nhwc_f16x2 with the element-wise VJP of the sweep fused into its epilogue (one dense launch: forward / stride-1
  * backward-data; Co % 8 == 0):
  *     o[n][i][j][c] = (conv[n][i][j][c] + add[n][i][j][c]) * M[(n,i,j) mod mask_rows][c] * scale[c]

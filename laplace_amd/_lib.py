@@ -68,6 +68,9 @@ SIGNATURES = {
                                   _i64, _i64, _i64, _i64, _vp, _vp, _vp, _int, _vp, _int, _vp]),
     "lk_conv_nhwc_f16x2_planes": (_int, [_vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64,
                                          _i64, _vp, _vp, _vp, _vp, _vp, _int, _vp]),
+    "lk_conv_bn_act_nhwc_f16x2": (_int, [_vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64,
+                                         _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp, _vp, _vp, _vp, _vp,
+                                         _vp, _vp, _int, _vp]),
     "lk_conv_nhwc_f16x2_vjp": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64,
                                       _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _i64, _vp, _vp, _vp, _vp, _vp,
                                       _vp, _int, _vp]),
@@ -520,6 +523,46 @@ class HipKernels:
             _ptr(wplanes[1]), _ptr(wsexp), _ptr(w_l1), Co, Ho, Wo, in_mul, len(taps), flat, _ptr(self._zero16(dev)),
             _ptr(planes[0]), _ptr(planes[1]), _ptr(sexp), int(cfg), self._stream(dev))), "lk_conv_nhwc_f16x2_planes")
         return SplitTensor(planes, sexp)
+
+    #: ``False``: the forward's convolutions and their BatchNorm / add / ReLU stay two launches (lk_conv_nhwc_f16x2 +
+    #: lk_bn_act_fwd_nhwc_f16x2) instead of one (lk_conv_bn_act_nhwc_f16x2); the results are the same to the bit
+    use_conv_bn_act = True
+
+    def conv_bn_act_nhwc(self, x, wplanes, wsexp, w_l1, Ho, Wo, in_mul, taps, scale, shift, scale_amax, shift_amax, act,
+                         addend=None, addend_bound=None, want_mask=True, want_split=True, amax_words=None, config=None):
+        """lk_conv_bn_act_nhwc_f16x2: ``act(conv(x, W) * scale[c] + shift[c] + addend)`` for the per-image SplitTensor
+        ``x [N, Hi, Wi, Ci]`` (``x.amax``: the measured per-image maxima) -> ``(y, mask, split, bound)`` exactly as
+        :meth:`conv_nhwc_f16x2` followed by :meth:`bn_act_forward_nhwc` returns them (``y`` fp32 NHWC ``[N, Ho, Wo, Co]``)"""
+        N, Hi, Wi, Ci = x.planes.shape[1:]
+        Co = wplanes.shape[2]
+        dev = x.planes.device
+        if x.amax is None or x.amax.numel() not in (1, N) or wplanes.shape[3] != Ci or Co % 8:
+            raise LaplaceHipError("conv_bn_act_nhwc: per-image maxima of the input, matching channels, Co % 8 == 0")
+        if N > self.MAX_IMAGES_PER_LAUNCH:
+            raise LaplaceHipError("conv_bn_act_nhwc: at most %d images per launch" % self.MAX_IMAGES_PER_LAUNCH)
+        y = torch.empty((N, Ho, Wo, Co), dtype=torch.float32, device=dev)
+        mask = torch.empty(y.shape, dtype=torch.uint8, device=dev) if (act == 1 and want_mask) else None
+        planes = torch.empty((2,) + tuple(y.shape), dtype=torch.float16, device=dev) if want_split else None
+        sexp = torch.empty(N, dtype=torch.int32, device=dev)
+        bound = torch.empty(N, dtype=torch.float32, device=dev)
+        amax = amax_words if amax_words is not None else torch.zeros(N, dtype=torch.float32, device=dev)
+        if addend is not None:
+            _check(addend, "addend")
+            if tuple(addend.shape) != tuple(y.shape) or addend_bound is None or addend_bound.numel() not in (1, N):
+                raise LaplaceHipError("conv_bn_act_nhwc: the addend has the output's shape and a bound of 1 or N entries")
+        if amax.numel() != N:
+            raise LaplaceHipError("conv_bn_act_nhwc: amax_words has N entries")
+        flat = (ctypes.c_int * (3 * len(taps)))(*[int(v) for t in taps for v in t])
+        cfg = self.conv_config if config is None else config
+        work = 2.0 * N * Co * Ci * self.conv_valid_pairs(Ho, Wo, in_mul, Hi, Wi, taps) if self.profile is not None else 0.0
+        self._rc(self._timed("conv16", work, dev, lambda: self.lib.lk_conv_bn_act_nhwc_f16x2(
+            _ptr(x.planes[0]), _ptr(x.planes[1]), _ptr(x.sexp), x.sexp.numel(), _ptr(x.amax), x.amax.numel(), N, Hi, Wi, Ci,
+            _ptr(wplanes[0]), _ptr(wplanes[1]), _ptr(wsexp), _ptr(w_l1), Co, Ho, Wo, in_mul, len(taps), flat,
+            _ptr(self._zero16(dev)), _ptr(scale), _ptr(shift), _ptr(scale_amax), _ptr(shift_amax), _ptr(addend),
+            _ptr(addend_bound), 1 if addend_bound is None else addend_bound.numel(), int(act), _ptr(y), _ptr(mask),
+            None if planes is None else _ptr(planes[0]), None if planes is None else _ptr(planes[1]), _ptr(sexp), _ptr(bound),
+            _ptr(amax), int(cfg), self._stream(dev))), "lk_conv_bn_act_nhwc_f16x2")
+        return y, mask, (SplitTensor(planes, sexp, amax) if planes is not None else None), bound
 
     #: ``False``: fused 64-channel launches stay on the generic kernel (see :meth:`conv_winp_eligible`)
     use_winp = True

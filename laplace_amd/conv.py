@@ -242,6 +242,23 @@ def conv_forward(prep: PreparedConv, x: SplitTensor, out=None, amax_out=None):
     return out
 
 
+def conv_forward_bn_act(prep: PreparedConv, x: SplitTensor, scale, shift, scale_amax, shift_amax, act: int, addend=None,
+                        addend_bound=None, want_mask: bool = True, amax_words=None):
+    """``act(conv(x) * scale[c] + shift[c] + addend)`` of the bias-free ``prep.m`` in ONE launch (lk_conv_bn_act_nhwc_f16x2):
+    ``(y, mask, split, bound)`` as ``bn_act_forward_nhwc`` returns them for :func:`conv_forward`'s output — the same bits"""
+    K = get_kernels()
+    m = prep.m
+    N, Hin, Win, _ = x.shape
+    s, (ph, pw), (KH, KW) = m.stride[0], m.padding, m.kernel_size
+    Ho, Wo = (Hin + 2 * ph - KH) // s + 1, (Win + 2 * pw - KW) // s + 1
+    planes, sexp = prep.forward_planes()
+    l1, bmax = prep.forward_l1()
+    assert bmax is None, "conv_forward_bn_act: bias-free convolutions only"
+    taps = [(kh - ph, kw - pw, kh * KW + kw) for kh in range(KH) for kw in range(KW)]
+    return K.conv_bn_act_nhwc(x, planes, sexp, l1, Ho, Wo, s, taps, scale, shift, scale_amax, shift_amax, act, addend=addend,
+                              addend_bound=addend_bound, want_mask=want_mask, amax_words=amax_words)
+
+
 def _filter_l1(W: torch.Tensor) -> torch.Tensor:
     """device word ``max_co sum |W[co]|``: ``max|conv(x, W)_n| <= max|x_n| * l1`` (the bound the split-planes epilogue scales from)"""
     return W.abs().float().reshape(W.shape[0], -1).sum(1).max().reshape(1).contiguous()

@@ -295,9 +295,21 @@ struct ConvVjp {
   _Float16 *out_h, *out_l;
   int* out_sexp;
   const _Float16 *wc_h, *wc_l;  // the same weights chunk-major, [tap][Ci / 16][Co][16] per plane (persistent window form), or NULL
+  // ---- forward epilogue (conv_f16x2_kernel<CFG, true, true>, lk_conv_bn_act_nhwc_f16x2): eval-mode BatchNorm + residual add
+  //      + ReLU on the accumulators, y = act(conv * fwd_scale[co] + fwd_shift[co] + fwd_addend); in_amax / a_sexp per image,
+  //      w_l1 = l1 norm of the weights (the bound of the convolution's output), out_h / out_l / out_sexp[N] the split planes
+  float* fwd_y;                   // fp32 NHWC result
+  unsigned char* fwd_mask;        // NHWC bytes y > 0, or NULL
+  const float *fwd_scale, *fwd_shift;             // [Co]
+  const unsigned *fwd_scale_amax, *fwd_shift_amax;  // words
+  const float* fwd_addend;        // fp32 NHWC or NULL
+  const float* fwd_addend_bound;  // 1 or N floats
+  int fwd_addend_nbound, fwd_in_namax, fwd_act;
+  float* fwd_bound;               // [N] guaranteed bound of max|y_n| (what out_sexp[n] was derived from)
+  unsigned* fwd_amax;             // [N] measured max|y_n| (bit patterns; zeroed by the caller)
 };
 
-template <typename CFG, bool FUSE>
+template <typename CFG, bool FUSE, bool FWD = false>
 __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WPE, CFG::WPE))) void conv_f16x2_kernel(const ConvGeom g, const _Float16* __restrict__ Ah,
                                                          const _Float16* __restrict__ Al, const _Float16* __restrict__ Wh,
                                                          const _Float16* __restrict__ Wl, const int* __restrict__ a_sexp,
@@ -371,7 +383,8 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
   const float inv_a = exp2i(-sexp_a < -126 ? -126 : -sexp_a), inv_w = exp2i(-sexp_w < -126 ? -126 : -sexp_w);
   int so = 0;
   float sc_out = 1.f, inv2 = 0.f;
-  if constexpr (FUSE) {
+  static_assert(FUSE || !FWD, "the forward epilogue uses the fused epilogue's staging");
+  if constexpr (FUSE && !FWD) {
     // scale of the result from the guaranteed bound (every thread computes the same few flops; one writes the word)
     float bound = fz.in_amax ? __uint_as_float(fz.in_amax[0]) : exp2i(15 - sexp_a < -126 ? -126 : (15 - sexp_a > 127 ? 127 : 15 - sexp_a));
     bound *= fz.w_l1[0];
@@ -481,6 +494,13 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
 #pragma unroll
     for (int j = 0; j < 8; ++j) h2_[it][j] = (_Float16)0.f, l2_[it][j] = (_Float16)0.f;
     mk_[it] = make_uint2(0x01010101u, 0x01010101u);
+    if constexpr (FWD) {  // (the fp32 addend's eight values ride in the registers of the two addend planes)
+      if (fz.fwd_addend && ok_[it]) {
+        h2_[it] = *reinterpret_cast<const f16x8*>(fz.fwd_addend + e_[it]);
+        l2_[it] = *reinterpret_cast<const f16x8*>(fz.fwd_addend + e_[it] + 4);
+      }
+      return;
+    }
     if (fz.add_h && ok_[it]) {
       h2_[it] = *reinterpret_cast<const f16x8*>(fz.add_h + e_[it]);
       l2_[it] = *reinterpret_cast<const f16x8*>(fz.add_l + e_[it]);
@@ -551,6 +571,120 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
 
   // ---- epilogue: un-scale, store NHWC (a half-wave writes 32 consecutive channels = 128 B), max|out|
   unsigned vmax = 0;
+  if constexpr (FWD) {
+    // ---- forward epilogue: eval-mode BatchNorm + residual add + ReLU on the accumulators — what lk_conv_nhwc_f16x2 followed
+    // by lk_bn_act_fwd_nhwc_f16x2 computes, to the bit (the same fp32 operations in the same order: un-scale by two powers of
+    // two, one fma with the channel's scale / shift, one add of the addend), without the fp32 round trip of the
+    // convolution's output and the second launch.  Emits y (fp32 NHWC), the ReLU mask bytes, y's split planes with ONE SCALE
+    // PER IMAGE from the guaranteed bound (see bn_act_fwd_nhwc_kernel), that bound, and the measured max|y_n|: the rows'
+    // maxima meet in LDS (slot = image - first image of the tile; position-major tiles: slot = row), one global atomic
+    // per (workgroup, image).  Staging as in the VJP epilogue below: lane = 8 consecutive channels of one pixel.
+    const bool per_img = g.a_nsexp > 1;
+    const int m_first = tile_m * BM;
+    const int n_lo = g.pmajor ? 0 : fdiv(m_first, g.div_hw);
+    unsigned* amax_slot = reinterpret_cast<unsigned*>(smem + CFG::EPI_LDS);  // BM + 1 words behind the staging image
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) prefetch(it);
+    __syncthreads();  // every wave is done with the K loop's stage buffers
+    for (int i = tid; i < BM + 1; i += NT) amax_slot[i] = 0u;
+    float* img = reinterpret_cast<float*>(smem) + wave * (ROWS_W * PITCH);
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          img[(a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * PITCH + b * 32 + lr] = acc[a][b][r];
+    __syncthreads();  // the slots are zero before anybody's maximum arrives
+    auto clampe = [](int e) { return e < -126 ? -126 : (e > 127 ? 127 : e); };
+    const float s_amax = __uint_as_float(fz.fwd_scale_amax[0]), t_amax = __uint_as_float(fz.fwd_shift_amax[0]);
+    const float x_mul = fz.w_l1[0];
+    int c_n = -1, c_so = 0;
+    float c_inv = 0.f, c_sc = 0.f, c_bound = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = it * 64 + lane;
+      const int row = idx / C8, c8 = idx - row * C8;
+      const bool ok = ok_[it];
+      const int col0 = tile_n * BN + wn * COLS_W + c8 * 8;
+      const int opix = pix_[it];
+      const int n = fdiv(opix, g.div_hw);
+      unsigned rmax = 0;
+      if (ok) {
+        if (n != c_n) {  // (a tile of a large map lies in one or two images)
+          const int sa = a_sexp[per_img ? n : 0];
+          c_inv = exp2i(clampe(-sa));
+          float bx = __uint_as_float(fz.in_amax[n < fz.fwd_in_namax ? n : fz.fwd_in_namax - 1]) * x_mul;
+          c_bound = __fmaf_rn(bx, s_amax, t_amax);
+          if (fz.fwd_addend) c_bound += fz.fwd_addend_bound[n < fz.fwd_addend_nbound ? n : fz.fwd_addend_nbound - 1];
+          c_so = scale_exp_for(c_bound);
+          c_sc = exp2i(clampe(c_so));
+          c_n = n;
+        }
+        const f32x4 p0 = *reinterpret_cast<const f32x4*>(img + row * PITCH + c8 * 8);
+        const f32x4 p1 = *reinterpret_cast<const f32x4*>(img + row * PITCH + c8 * 8 + 4);
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(fz.fwd_scale + col0), s1 = *reinterpret_cast<const f32x4*>(fz.fwd_scale + col0 + 4);
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(fz.fwd_shift + col0), t1 = *reinterpret_cast<const f32x4*>(fz.fwd_shift + col0 + 4);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] = __fmaf_rn(p0[j] * c_inv * inv_w, s0[j], t0[j]);
+          v[4 + j] = __fmaf_rn(p1[j] * c_inv * inv_w, s1[j], t1[j]);
+        }
+        if (fz.fwd_addend) {
+          const f32x4 q0 = __builtin_bit_cast(f32x4, h2_[it]), q1 = __builtin_bit_cast(f32x4, l2_[it]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += q0[j], v[4 + j] += q1[j];
+        }
+        const int64_t e = e_[it];
+        if (fz.fwd_act == 1) {
+          unsigned m0 = 0, m1 = 0;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            v[j] = fmaxf(v[j], 0.f);
+            if (v[j] > 0.f) (j < 4 ? m0 : m1) |= 1u << (8 * (j & 3));
+          }
+          if (fz.fwd_mask) *reinterpret_cast<uint2*>(fz.fwd_mask + e) = make_uint2(m0, m1);
+        }
+        *reinterpret_cast<f32x4*>(fz.fwd_y + e) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(fz.fwd_y + e + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        f16x8 h, l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          rmax = max(rmax, __float_as_uint(v[j]) & 0x7fffffffu);
+          float xs = v[j] * c_sc;
+          asm volatile("" : "+v"(xs));  // h and the residual from the SAME fp32 value (see split2)
+          const _Float16 hh = (_Float16)xs;
+          h[j] = hh;
+          l[j] = (_Float16)(xs - (float)hh);
+        }
+        if (fz.out_h) {
+          *reinterpret_cast<f16x8*>(fz.out_h + e) = h;
+          *reinterpret_cast<f16x8*>(fz.out_l + e) = l;
+        }
+        if (col0 == 0 && opix == n * HWc) fz.out_sexp[n] = c_so, fz.fwd_bound[n] = c_bound;
+      }
+      // the C8 lanes of a row sit next to each other: their maxima meet in the row's first lane, which books the row
+#pragma unroll
+      for (int off = 1; off < C8; off <<= 1) rmax = max(rmax, (unsigned)__shfl_xor((int)rmax, off, 64));
+      if (c8 == 0 && rmax) {
+        const int slot = g.pmajor ? (wm * ROWS_W + row) : (n - n_lo);
+        atomicMax(amax_slot + slot, rmax);
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < BM + 1; i += NT) {
+      const unsigned v = amax_slot[i];
+      if (!v) continue;
+      int n = n_lo + i;
+      if (g.pmajor) {
+        const int m = m_first + i;
+        n = m - fdiv(m, g.div_n) * g.N;
+      }
+      atomicMax(fz.fwd_amax + n, v);
+    }
+    return;
+  }
   if constexpr (FUSE) {
     if (blockIdx.x == 0 && tid == 0) fz.out_sexp[0] = so;
     // the wave's 64 x 64 (32 x 32, ...) block goes through LDS: MFMA layout (lane = channel, registers = pixels) ->
@@ -1681,6 +1815,24 @@ static int launch_conv(const ConvGeom& g, const void* Ah, const void* Al, const 
   const int64_t M = (int64_t)g.N * g.Hc * g.Wc;
   const int nb_m = (int)((M + CFG::BM - 1) / CFG::BM), nb_n = (g.Co + CFG::BN - 1) / CFG::BN;
   const size_t lds = (size_t)CFG::NBUF * CFG::STAGE;
+  if (fz && fz->fwd_y) {  // forward epilogue (BatchNorm / add / ReLU): the staging image + BM + 1 words for the images' maxima
+    if constexpr (CFG::FUSABLE) {
+      const size_t need = (size_t)CFG::EPI_LDS + 4 * (CFG::BM + 1);
+      const size_t lds_w = lds > need ? lds : (need + 15) / 16 * 16;
+      static bool attr_set_w = false;
+      if (!attr_set_w) {
+        (void)hipFuncSetAttribute((const void*)conv_f16x2_kernel<CFG, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w);
+        attr_set_w = true;
+      }
+      hipLaunchKernelGGL((conv_f16x2_kernel<CFG, true, true>), dim3((unsigned)(nb_m * nb_n)), dim3(CFG::NT), lds_w, stream, g,
+                         (const _Float16*)Ah, (const _Float16*)Al, (const _Float16*)Wh, (const _Float16*)Wl, a_sexp, w_sexp,
+                         (const _Float16*)zero16, out, accumulate, amax_out, nb_m, *fz);
+      return check_launch("conv_f16x2_kernel(bn_act)");
+    } else {
+      set_error("lk_conv_bn_act_nhwc_f16x2: this tile shape has no fused epilogue");
+      return LK_EINVAL;
+    }
+  }
   if (fz) {
     if constexpr (CFG::FUSABLE) {
       const size_t lds_f = lds > (size_t)CFG::EPI_LDS ? lds : (size_t)CFG::EPI_LDS;
@@ -1793,8 +1945,8 @@ static int conv_dispatch(const void* in_h, const void* in_l, const int* in_sexp,
   LK_REQUIRE(in_h && in_l && in_sexp && w_h && w_l && w_sexp && zero16 && (out || fz) && taps, "lk_conv_nhwc_f16x2: null pointer");
   LK_REQUIRE(T >= 1 && T <= 9 && Ci >= 32 && Ci % 32 == 0 && Co >= 1 && N >= 1, "lk_conv_nhwc_f16x2: Ci % 32 == 0, 1..9 taps");
   LK_REQUIRE(N * Hc * Wc < (1ll << 31) && N * Hi * Wi * Ci < (1ll << 40), "lk_conv_nhwc_f16x2: tensor too large");
-  LK_REQUIRE(in_nsexp == 1 || (in_nsexp == N && (!fz || (config & 16))),
-             "lk_conv_nhwc_f16x2: in_nsexp is 1 or N (one scale per image: plain epilogue only)");
+  LK_REQUIRE(in_nsexp == 1 || (in_nsexp == N && (!fz || (config & 16) || fz->fwd_y)),
+             "lk_conv_nhwc_f16x2: in_nsexp is 1 or N (one scale per image: plain and forward epilogues only)");
   if (Hc == 0 || Wc == 0) return LK_OK;
   ConvGeom g;
   g.a_nsexp = (int)in_nsexp;
@@ -1813,7 +1965,7 @@ static int conv_dispatch(const void* in_h, const void* in_l, const int* in_sexp,
   hipStream_t st = (hipStream_t)stream;
   // persistent window form (fused launches with 64 output channels whose caller also handed over chunk-major weights;
   // config bit 27 switches it off): see conv_winp_f16x2_kernel
-  if (fz && !g.out_planes && fz->wc_h && !(config & 134217728) && lk_conv_winp_eligible(N, Hi, Wi, Ci, Co, T, fz->mask && fz->mask_float) &&
+  if (fz && !g.out_planes && !fz->fwd_y && fz->wc_h && !(config & 134217728) && lk_conv_winp_eligible(N, Hi, Wi, Ci, Co, T, fz->mask && fz->mask_float) &&
       in_mul == 1 && Hc == Hi && Wc == Wi && g.dense) {
     int rc = LK_OK;
     if (launch_winp<WinPCfg<256>>(g, in_h, in_l, fz->wc_h, fz->wc_l, in_sexp, w_sexp, amax_out, st, fz, &rc, config)) return rc;
@@ -1889,6 +2041,42 @@ extern "C" int lk_conv_nhwc_f16x2_planes(const void* in_h, const void* in_l, con
                        zero16, reinterpret_cast<float*>(out_h), 0, nullptr, config | 16, stream, &fz);
 }
 
+// lk_conv_nhwc_f16x2 (dense output grid, stride `in_mul`) with the forward's BatchNorm / residual add / ReLU in its epilogue:
+//   y = act(conv(in, W) * scale[co] + shift[co] + addend)         act: 0 none, 1 ReLU
+// — to the bit what lk_conv_nhwc_f16x2 followed by lk_bn_act_fwd_nhwc_f16x2 (x_mul = w_l1, no x_add) computes, in one launch
+// and without the fp32 round trip of the convolution's output.  in_amax: in_namax (1 or N) words with the measured max|in_n|;
+// outputs: y fp32 NHWC [N][Ho][Wo][Co], mask bytes (or NULL), y_h / y_l planes (or NULL) with y_sexp[N], y_bound[N] (the
+// guaranteed bound behind each scale), y_amax[N] (measured max|y_n|, zeroed by the caller).  Co % 8 == 0.
+extern "C" int lk_conv_bn_act_nhwc_f16x2(const void* in_h, const void* in_l, const int* in_sexp, int64_t in_nsexp,
+                                         const void* in_amax, int64_t in_namax, int64_t N, int64_t Hi, int64_t Wi, int64_t Ci,
+                                         const void* w_h, const void* w_l, const int* w_sexp, const float* w_l1, int64_t Co,
+                                         int64_t Ho, int64_t Wo, int64_t in_mul, int64_t T, const int* taps, const void* zero16,
+                                         const float* scale, const float* shift, const void* scale_amax, const void* shift_amax,
+                                         const float* addend, const float* addend_bound, int64_t addend_nbound, int act,
+                                         float* y, void* mask, void* y_h, void* y_l, int* y_sexp, float* y_bound, void* y_amax,
+                                         int config, void* stream) {
+  LK_REQUIRE(in_amax && w_l1 && scale && shift && scale_amax && shift_amax && y && y_sexp && y_bound && y_amax,
+             "lk_conv_bn_act_nhwc_f16x2: null pointer");
+  LK_REQUIRE(Co % 8 == 0 && (act == 0 || act == 1), "lk_conv_bn_act_nhwc_f16x2: Co % 8 == 0, act in 0..1");
+  LK_REQUIRE(in_namax == 1 || in_namax == N, "lk_conv_bn_act_nhwc_f16x2: in_amax has 1 or N words");
+  LK_REQUIRE(!addend || (addend_bound && (addend_nbound == 1 || addend_nbound == N)),
+             "lk_conv_bn_act_nhwc_f16x2: the addend needs its bound (1 or N floats)");
+  LK_REQUIRE((y_h == nullptr) == (y_l == nullptr), "lk_conv_bn_act_nhwc_f16x2: both planes or none");
+  LK_REQUIRE(N * Ho * Wo * Co < (1ll << 40), "lk_conv_bn_act_nhwc_f16x2: tensor too large");
+  ConvVjp fz{};
+  fz.in_amax = (const unsigned*)in_amax, fz.w_l1 = w_l1;
+  fz.mask_rows = 1, fz.div_mask = make_fastdiv(1);
+  fz.out_h = (_Float16*)y_h, fz.out_l = (_Float16*)y_l, fz.out_sexp = y_sexp;
+  fz.fwd_y = y, fz.fwd_mask = (unsigned char*)mask;
+  fz.fwd_scale = scale, fz.fwd_shift = shift;
+  fz.fwd_scale_amax = (const unsigned*)scale_amax, fz.fwd_shift_amax = (const unsigned*)shift_amax;
+  fz.fwd_addend = addend, fz.fwd_addend_bound = addend_bound, fz.fwd_addend_nbound = (int)(addend ? addend_nbound : 1);
+  fz.fwd_in_namax = (int)in_namax, fz.fwd_act = act;
+  fz.fwd_bound = y_bound, fz.fwd_amax = (unsigned*)y_amax;
+  return conv_dispatch(in_h, in_l, in_sexp, in_nsexp, N, Hi, Wi, Ci, w_h, w_l, w_sexp, Co, Ho, Wo, in_mul, Ho, Wo, 1, 0, 0, T, taps,
+                       zero16, y, 0, nullptr, config & ~16, stream, &fz);
+}
+
 // The same launch with the fused VJP epilogue (see ConvVjp): dense output grid (the output tensor IS the class grid), no
 // accumulate, Co % 8 == 0.  Emits the split tensor out_h / out_l / out_sexp and max|result| (out_amax, zeroed by the caller).
 static int conv_vjp_impl(const void* in_h, const void* in_l, const int* in_sexp, const void* in_amax, int64_t N,
@@ -1904,7 +2092,7 @@ static int conv_vjp_impl(const void* in_h, const void* in_l, const int* in_sexp,
   LK_REQUIRE(!add_h || (add_l && add_sexp), "lk_conv_nhwc_f16x2_vjp: incomplete addend");
   LK_REQUIRE(!mask || mask_rows > 0, "lk_conv_nhwc_f16x2_vjp: mask_rows");
   LK_REQUIRE(!scale || scale_amax, "lk_conv_nhwc_f16x2_vjp: scale needs its bound");
-  ConvVjp fz;
+  ConvVjp fz{};
   fz.in_amax = (const unsigned*)in_amax, fz.w_l1 = w_l1;
   fz.add_h = (const _Float16*)add_h, fz.add_l = (const _Float16*)add_l, fz.add_sexp = add_sexp;
   fz.mask = mask, fz.mask_float = mask_is_float, fz.mult_amax = (const unsigned*)mult_amax, fz.mask_rows = mask ? mask_rows : 1;
@@ -2023,7 +2211,7 @@ extern "C" int lk_conv_nhwc_f16x2_vjp_strided(
   if (two)
     s2 = StridedSrc{(const _Float16*)in2_h, (const _Float16*)in2_l, (const _Float16*)w2_h, (const _Float16*)w2_l, in2_sexp, w2_sexp,
                     (const unsigned*)in2_amax, w2_l1};
-  ConvVjp fz;
+  ConvVjp fz{};
   fz.in_amax = nullptr, fz.w_l1 = nullptr;
   fz.add_h = (const _Float16*)add_h, fz.add_l = (const _Float16*)add_l, fz.add_sexp = add_sexp;
   fz.mask = mask, fz.mask_float = mask_is_float, fz.mult_amax = (const unsigned*)mult_amax, fz.mask_rows = mask ? mask_rows : 1;

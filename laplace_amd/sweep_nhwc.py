@@ -40,6 +40,25 @@ class _F32:
         self.t, self.amax = t, amax
 
 
+class _PendingConv:
+    """A forward convolution that has not run yet: its only consumer is an eval-mode BatchNorm, which runs it with the
+    per-channel affine map, the residual add and the ReLU in the convolution's epilogue (lk_conv_bn_act_nhwc_f16x2) —
+    or, where that launch does not apply, materialises it as before.  Quacks like its fp32 ``[N, C, H, W]`` result as far
+    as the traced forward looks at it (``shape``, ``dtype``, ``dim()``)."""
+
+    __slots__ = ("prep", "xs", "shape", "dtype", "device", "_run")
+
+    def __init__(self, prep, xs, shape, run):
+        self.prep, self.xs, self.shape, self._run = prep, xs, torch.Size(shape), run
+        self.dtype, self.device = torch.float32, xs.planes.device
+
+    def dim(self) -> int:
+        return len(self.shape)
+
+    def materialize(self) -> torch.Tensor:
+        return self._run()
+
+
 class _LazyConv:
     """A stride-1 convolution's backward-data that has not run yet: whoever consumes the cotangent decides whether it is
     materialised as an fp32 tensor (``f32()``) or comes out of the convolution kernel already multiplied / joined / split
@@ -267,18 +286,64 @@ class SplitSweep(SeedBatchedSweep):
             # consumers of the tap's input that run our convolution on it again (the Kron predictive's eigenbasis
             # rotation) take the split copy instead of measuring and splitting the activation a second time
             self.tap_splits[node.target] = xs
-        out = cv.conv_forward(prep, xs)
-        if m.bias is not None:
-            out += m.bias
-        y = out.permute(0, 3, 1, 2)  # logical [B, C, H, W] over NHWC memory
-        if xs.amax is not None:
-            # per-image bound of the output without a pass over it: measured max of the input image * l1(W) + max|bias|
-            l1, bmax = prep.forward_l1()
-            self._aux[y.data_ptr()] = {"in_amax": xs.amax, "mul": l1, "add": bmax}
-        return y
+
+        def run():
+            out = cv.conv_forward(prep, xs)
+            if m.bias is not None:
+                out += m.bias
+            y = out.permute(0, 3, 1, 2)  # logical [B, C, H, W] over NHWC memory
+            if xs.amax is not None:
+                # per-image bound of the output without a pass over it: measured max of the input image * l1(W) + max|bias|
+                l1, bmax = prep.forward_l1()
+                self._aux[y.data_ptr()] = {"in_amax": xs.amax, "mul": l1, "add": bmax}
+            return y
+
+        if self._bn_takes_conv(node, m, xs):
+            s_, (ph, pw), (KH, KW) = m.stride[0], m.padding, m.kernel_size
+            Ho, Wo = (xs.shape[1] + 2 * ph - KH) // s_ + 1, (xs.shape[2] + 2 * pw - KW) // s_ + 1
+            return _PendingConv(prep, xs, (xs.shape[0], m.out_channels, Ho, Wo), run)
+        return run()
+
+    #: ``False``: a convolution and the BatchNorm / add / ReLU behind it stay two launches
+    fuse_conv_bn = True
+
+    def _bn_takes_conv(self, node, m, xs) -> bool:
+        """does this convolution's output go to exactly one consumer, an eval-mode BatchNorm2d that the traced forward
+        hands to ``_run_bn_act`` (laplace_amd/sweep.py: the conditions of its BatchNorm branch), so that both run as one
+        launch?"""
+        K = self.kernels()
+        if not (self.fuse_conv_bn and getattr(K, "use_conv_bn_act", False) and m.bias is None and xs.amax is not None
+                and xs.shape[0] <= getattr(K, "MAX_IMAGES_PER_LAUNCH", 65535) and m.out_channels % 8 == 0
+                and len(node.users) == 1):
+            return False
+        nxt = next(iter(node.users))
+        if not (nxt.op == "call_module" and len(nxt.args) == 1 and nxt.args[0] is node and not nxt.kwargs):
+            return False
+        bn = self.modules.get(nxt.target)
+        return isinstance(bn, nn.BatchNorm2d) and bn.running_var is not None and nxt.target not in self.tap_names
 
     def _run_bn_act(self, node, inp, scale, shift, relu, addend, want_mask):
         K = self.kernels()
+        if isinstance(inp, _PendingConv):
+            if addend is None or (torch.is_tensor(addend) and addend.dtype == torch.float32 and K.is_channels_last(addend)
+                                  and addend.shape == inp.shape):
+                a_h = a_bound = None
+                if addend is not None:
+                    a_h = addend.permute(0, 2, 3, 1)
+                    a_aux = self._aux.get(addend.data_ptr())
+                    a_bound = a_aux["bound"] if a_aux is not None and "bound" in a_aux else K.absmax(a_h)
+                scale = scale.to(torch.float32).contiguous()
+                shift = shift.to(torch.float32).contiguous()
+                y, mask, split, bound = cv.conv_forward_bn_act(
+                    inp.prep, inp.xs, scale, shift, self._amax_of((node.target, "s"), scale),
+                    self._amax_of((node.target, "t"), shift), 1 if relu else 0, addend=a_h, addend_bound=a_bound,
+                    want_mask=want_mask, amax_words=self._fwd_word(inp.device, inp.shape[0]))
+                out = y.permute(0, 3, 1, 2)
+                self._aux[out.data_ptr()] = {"split": split, "bound": split.amax if split is not None else bound}
+                if mask is not None:
+                    mask = mask.view(torch.bool).permute(0, 3, 1, 2)
+                return out, mask
+            inp = inp.materialize()
         if not (self._use_nhwc_forward(inp) and K.is_channels_last(inp) and inp.shape[1] % 8 == 0
                 and (addend is None or K.is_channels_last(addend))):
             return super()._run_bn_act(node, inp, scale, shift, relu, addend, want_mask)
