@@ -232,6 +232,8 @@ def fit_50k_leg(backend, dev):
     n_full, rest = divmod(N_DATASET, BATCH)
     last = (bs[1][0][:rest].contiguous(), bs[1][1][:rest].contiguous()) if rest else None
     gc.collect()  # (the legs before this one leave a large heap behind: the host side of a step is 60 % of its device time)
+    gc.freeze()   # ... and that heap — the event lists of the instrumented passes, the other legs' models — is not this leg's
+                  # to traverse: the collector's full passes over it made a step of THIS leg host-bound in long runs
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     acc = backend.kron_accumulator(N_DATASET)
@@ -245,6 +247,7 @@ def fit_50k_leg(backend, dev):
     dec = H.decompose()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
+    gc.unfreeze()
     ok = all(int(i[0].item()) == 0 for i in dec._eig_info)
     return {"samples": N_DATASET, "minibatches": n_full + (1 if rest else 0), "wall_s": t2 - t0, "accumulate_s": t1 - t0,
             "decompose_s": t2 - t1, "samples_per_s": N_DATASET / (t2 - t0), "eigh_converged": bool(ok),

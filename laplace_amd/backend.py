@@ -25,6 +25,7 @@ dense GGN, per-sample Jacobian assembly — is a HIP entry point of ``include/la
 """
 from __future__ import annotations
 
+import collections
 import math
 import os
 from collections.abc import MutableMapping
@@ -649,6 +650,22 @@ class CurvatureExchange(list):
     owner = None
 
 
+_PROCESS_STREAMS: dict = {}
+
+
+def _process_streams(key, make):
+    """The HIP streams of the fit (lanes, their side streams, the flush streams) exist ONCE per process and device, not once
+    per backend object: PyTorch's caching allocator keeps a pool of freed blocks per stream, so every backend with streams
+    of its own reserved another ~100 GB for the same c4 fit (measured, `tools/fuse_ab.py`) — a loop that builds a new
+    `Laplace` object per epoch (marglik training) ran the device out of memory after two of them and the allocator into
+    freeing and re-allocating every step (7 -> 49 ms).  Streams are only queues: accumulators that share them are ordered
+    by the same waits / events as before, work of different fits on one stream merely serialises."""
+    hit = _PROCESS_STREAMS.get(key)
+    if hit is None:
+        hit = _PROCESS_STREAMS[key] = make()
+    return hit
+
+
 class KronAccumulator:
     """Running KFAC factors of one ``fit`` kept in the kernels' own form.
 
@@ -723,6 +740,7 @@ class KronAccumulator:
         self.lanes = max(1, int(os.environ.get("LK_LANES", "2")))
         self._lane_accs, self._lane_next, self._lane_id, self._lane_stream = None, 0, 0, None
         self._lane_sig = None
+        self._ahead = collections.deque()  # events behind the minibatches the host has enqueued and not waited for (`max_ahead`)
         self._a_done = None  # event on the side stream behind the A-side work of the latest minibatch
         self._lanes_anywhere = False  # (tests: the lanes' host logic on the CPU emulation of the kernels, without streams)
 
@@ -980,8 +998,7 @@ class KronAccumulator:
             for idx in todo:
                 one(idx)
             return
-        cache = self.backend.__dict__.setdefault("_flush_streams", {})
-        streams = cache.setdefault((dev, self.flush_streams), [torch.cuda.Stream(dev) for _ in range(self.flush_streams)])
+        streams = _process_streams(("flush", dev, self.flush_streams), lambda: [torch.cuda.Stream(dev) for _ in range(self.flush_streams)])
         cur = torch.cuda.current_stream(dev)
         for st in streams:
             st.wait_stream(cur)
@@ -1001,11 +1018,11 @@ class KronAccumulator:
         if self._lane_accs is None:
             streams = [None] * self.lanes
             if on_device:
-                cache = self.backend.__dict__.setdefault("_lane_streams", {})
                 # the lanes' streams (forward + reverse sweep: the critical path) get a higher queue priority than the streams
                 # the factor kernels run on (`lane_priority = 0`: all alike; measured 7.35 -> 6.96 ms per step)
                 prio = int(self.lane_priority)
-                streams = cache.setdefault((dev, self.lanes, prio), [torch.cuda.Stream(dev, priority=prio) for _ in range(self.lanes)])
+                streams = _process_streams(("lanes", dev, self.lanes, prio),
+                                           lambda: [torch.cuda.Stream(dev, priority=prio) for _ in range(self.lanes)])
             self._lane_accs = []
             for k in range(self.lanes):
                 sub = KronAccumulator(self.backend, self.N, self.kfac_approx, self.overlap)
@@ -1045,6 +1062,8 @@ class KronAccumulator:
         for t in (x, y):
             if torch.is_tensor(t) and t.is_cuda:
                 t.record_stream(st)
+        sub.max_ahead = self.max_ahead
+        sub._throttle(st)
 
     def _shared_signature(self, x):
         """what the lazily built state shared by the lanes depends on: every parameter / buffer of the model (storage and
@@ -1080,9 +1099,8 @@ class KronAccumulator:
                  and any(sub._pix for sub in live))
         fstreams = None
         if early:
-            cache = self.backend.__dict__.setdefault("_flush_streams", {})
             nfs = max(self.flush_streams, 1)
-            fstreams = cache.setdefault((dev, nfs), [torch.cuda.Stream(dev) for _ in range(nfs)])
+            fstreams = _process_streams(("flush", dev, nfs), lambda: [torch.cuda.Stream(dev) for _ in range(nfs)])
             for st in fstreams:
                 st.wait_stream(cur)
                 for sub in live:
@@ -1223,11 +1241,31 @@ class KronAccumulator:
         self._flush_stash()
         self._dispatch(x, y)
 
+    #: minibatches per stream the host may run ahead of the device (0: unbounded).  The host enqueues a ResNet-18 step in
+    #: 4.3 ms, the device works 6.8 ms on it: left alone the host runs ~150 steps ahead (until the runtime's queues push
+    #: back), and every tensor a side stream still has to read (`record_stream`) stays unavailable to the allocator until
+    #: the device gets there — 160 GiB reserved for a fit whose live tensors are 12 GiB.  Waiting for the minibatch
+    #: enqueued `max_ahead` steps ago costs nothing (the device still has that many steps queued per lane: same 6.7 ms per
+    #: step) and bounds the lead: 42 / 87 GiB reserved at 4 / 12 (`tools/session_age.py`, `profiles/r05_box_session_age.log`;
+    #: on a box whose later processes ran a 400-step loop at 13 ms per step it also brought them back to 6.8 - 8.0).
+    max_ahead = 8
+
+    def _throttle(self, stream):
+        if not self.max_ahead or stream is None:
+            return
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        self._ahead.append(ev)
+        if len(self._ahead) > self.max_ahead:
+            self._ahead.popleft().synchronize()
+
     def _dispatch(self, x, y):
         b = self.backend
         if self.lanes > 1 and self.overlap and not self.defer_pix and torch.is_tensor(x) and (x.is_cuda or self._lanes_anywhere):
             return self._lane_add_batch(x, y)
         self._add_batch(x, y)
+        if torch.is_tensor(x) and x.is_cuda and self._lane_stream is None:
+            self._throttle(torch.cuda.current_stream(x.device))
 
     def _add_batch(self, x, y):
         b = self.backend
@@ -1243,12 +1281,8 @@ class KronAccumulator:
         # overlap the C reverse passes (whose late, small-spatial conv kernels do not fill the chip).
         side = None
         if self.overlap and f.is_cuda:
-            if self._side is None:  # one side stream per backend object, shared by all its accumulators
-                cache = b.__dict__.setdefault("_side_streams", {})
-                key = f.device if self._lane_id == 0 else (f.device, self._lane_id)
-                if key not in cache:
-                    cache[key] = torch.cuda.Stream(f.device)
-                self._side = cache[key]
+            if self._side is None:  # one side stream per device and lane, shared by all accumulators of the process
+                self._side = _process_streams(("side", f.device, self._lane_id), lambda: torch.cuda.Stream(f.device))
             side = self._side
             main = torch.cuda.current_stream(f.device)
             side.wait_stream(main)
