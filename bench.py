@@ -351,12 +351,13 @@ def _c5_leg(dev):
             "note": "dominated by the encoder forward (stock PyTorch-ROCm: not part of the path)"}
 
 
-def pmc_traffic(kernel_prefix: str, kernel_suffix: str = ""):
+def pmc_traffic(kernel_prefix: str, kernel_suffix: str = "", table: str = "bench_c4", per: str = "launch"):
     """HBM bytes per launch of a kernel family from the rocprofv3 PMC passes over this very command (FETCH_SIZE /
     WRITE_SIZE in separate passes, gfx950 correction applied: tools/pmc_traffic.py).  Counters cannot be collected from
     inside the process, so the figure is read from profiles/ — but ONLY from a table stamped with the hash of the
     kernel sources it was collected on (`_meta.csrc_sha16`) equal to the sources of this run; anything else is stale
-    and reported as null with the reason."""
+    and reported as null with the reason.  ``table``: which command the passes ran over (`bench_c4`: this one;
+    `predictive_c4`: tools/kron_predictive_c4.py, `_meta.calls` predictive calls); ``per``: "launch" or "call"."""
     import glob
 
     sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -364,24 +365,28 @@ def pmc_traffic(kernel_prefix: str, kernel_suffix: str = ""):
 
     want = csrc_sha16(ROOT)
     newest = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_bench_c4*.json")), reverse=True):  # newest round first
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic_{table}*.json")), reverse=True):  # newest round first
         try:
             with open(path) as fh:
-                table = json.load(fh)
+                tab = json.load(fh)
         except (OSError, ValueError):
             continue
-        meta = table.get("_meta") or {}
+        meta = tab.get("_meta") or {}
         newest = newest or os.path.basename(path)
         if meta.get("csrc_sha16") != want:
             continue
-        rows = [v for k, v in table.items() if k != "_meta" and k.startswith(kernel_prefix) and k.endswith(kernel_suffix)]
+        rows = [v for k, v in tab.items() if k != "_meta" and k.startswith(kernel_prefix) and k.endswith(kernel_suffix)]
         launches = sum(r["launches"] for r in rows)
         if not launches:
             return None, f"profiles/{os.path.basename(path)}: no launch of this family in the PMC pass"
         total = sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows)
-        return total / launches, (f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2x read "
-                                  f"correction; kernel sources {want}, git {meta.get('git_head')})")
-    return None, (f"stale: no PMC table under profiles/ was collected on these kernel sources ({want}); newest is "
+        src = (f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2x read "
+               f"correction; kernel sources {want}, git {meta.get('git_head')})")
+        if per == "call":
+            calls = meta.get("calls")
+            return (total / calls, src) if calls else (None, f"profiles/{os.path.basename(path)}: no `calls` in _meta")
+        return total / launches, src
+    return None, (f"stale: no PMC table `{table}` under profiles/ was collected on these kernel sources ({want}); newest is "
                   f"{newest} — rerun tools/gpu_evidence.sh")
 
 
@@ -701,17 +706,24 @@ def main():
                 K.profile = None
                 pred_ms = len(Xp) / pred_rate * 1e3
                 pfam = {}
-                for key, peak, what in (("quadconv", PEAK_BF16X3_TFLOPS, "lk::quadform_conv_kernel: per-layer quadratic form of "
-                                         "the weight-sharing Jacobian, six bf16 MFMAs per fp32 product block"),
-                                        ("conv16", PEAK_F16X2_TFLOPS, "lk::conv_f16x2_kernel / conv_winp / conv_strided (forward + "
-                                         "reverse sweep of the 10 identity seeds, eigenbasis rotations)")):
+                # every family against the ceiling of the scheme the LAUNCHED kernel uses (keyed on the wrapper's profile tag)
+                for key, peak, what, pmc_name in (
+                        ("quadconv16", PEAK_F16X2_TFLOPS, "lk::quadform_conv_planes_kernel (lk_kron_quadform_shared_planes_f16x2): per-layer quadratic "
+                         "form of the weight-sharing Jacobian on split fp16 planes, three fp16 MFMAs per fp32 product block", "lk::quadform_conv_planes"),
+                        ("quadconv", PEAK_BF16X3_TFLOPS, "lk::quadform_conv_kernel (fp32 operands split in flight): six bf16 MFMAs per fp32 "
+                         "product block", "lk::quadform_conv_kernel"),
+                        ("conv16", PEAK_F16X2_TFLOPS, "lk::conv_f16x2_kernel / conv_winp / conv_strided (forward + reverse sweep of the 10 "
+                         "identity seeds, eigenbasis rotations)", "lk::conv_")):
                     evs = pprof.get(key, []) + (pprof.get("convp16", []) + pprof.get("convs16", []) if key == "conv16" else [])
                     ms_k = sum(ev[0].elapsed_time(ev[1]) for ev in evs)
                     if evs and ms_k > 0:
                         tf = sum(ev[2] for ev in evs) / (ms_k * 1e-3) / 1e12
+                        traffic, traffic_src = pmc_traffic(pmc_name, table="predictive_c4", per="call")
                         pfam[key] = {"kernel": what, "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s",
-                                     "frac": tf / peak, "ms_per_call": ms_k, "launches": len(evs)}
-                dom = max(pfam, key=lambda k: pfam[k]["ms_per_call"]) if pfam else None
+                                     "frac": tf / peak, "ms_per_call": ms_k, "launches": len(evs), "traffic": traffic,
+                                     "traffic_unit": "HBM bytes per predictive call (all launches of the family)", "traffic_source": traffic_src}
+                # the family to look at first: the most time lost to the distance from its own roof
+                dom = max(pfam, key=lambda k: pfam[k]["ms_per_call"] * (1.0 - pfam[k]["frac"])) if pfam else None
                 result["predictive_kron_c4"] = {
                     "workload": "c4 posterior: ResNet-18 full-network KFAC, GLM predictive variance [B,10,10], batch 128",
                     "samples_per_s": pred_rate, "ms_per_call": pred_ms, "finite": bool(torch.isfinite(f_var).all()),

@@ -1300,7 +1300,8 @@ class HipKernels:
         if CB != C * B or v.shape[2] != L or L % 16 or Do % 32:
             raise LaplaceHipError("kron_quadform_shared_planes: u [C * B, Do, L], v [B, Dk, L], L % 16 == 0, Do % 32 == 0")
         ws = self._workspace(self.lib.lk_quadform_shared_workspace_bytes(B, C, Do, Dk), fvar.device)
-        self._rc(self._timed("quadconv", 2.0 * B * C * L * Do * Dk, fvar.device, lambda: self.lib.lk_kron_quadform_shared_planes_f16x2(
+        # (its own profile tag: three fp16 MFMAs per product block — bench.py prices the fp32-operand forms, six bf16 MFMAs, apart)
+        self._rc(self._timed("quadconv16", 2.0 * B * C * L * Do * Dk, fvar.device, lambda: self.lib.lk_kron_quadform_shared_planes_f16x2(
             _ptr(u.planes[0]), _ptr(u.planes[1]), _ptr(u.sexp), _ptr(v.planes[0]), _ptr(v.planes[1]), _ptr(v.sexp), v.sexp.numel(),
             _ptr(l1), _ptr(l2), _ptr(delta), B, C, Do, Dk, L, _ptr(self._zero16(fvar.device)), _ptr(fvar), _ptr(ws), ws.numel(),
             self._stream(fvar.device))), "lk_kron_quadform_shared_planes_f16x2")

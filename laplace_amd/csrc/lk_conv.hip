@@ -31,7 +31,10 @@
 // device word (what the next producer needs to choose ITS scale).
 #include "lk_common.h"
 
+#include <map>
+#include <mutex>
 #include <type_traits>
+#include <utility>
 
 namespace lk {
 
@@ -1258,7 +1261,8 @@ struct WinPCfg {
   static constexpr int LDS = ZERO_OFF + 32;
   static constexpr int NSLICE = 8;                       // 64 rows per wave = 8 slices of 8 rows
   static_assert((2 * PP) % 64 == 0, "a window plane is a whole number of wave-instructions");
-  static_assert(2 * LDS <= 160 * 1024, "two workgroups per CU");
+  static constexpr int WG_PER_CU = BM_ <= 256 ? 2 : 1;  // (512 rows: eight waves = the CU's two waves per SIMD in ONE workgroup)
+  static_assert(WG_PER_CU * LDS <= 160 * 1024, "workgroups per CU");
 };
 
 struct WinPArgs {  // (a slim argument block: everything here stays in scalar registers for the whole launch)
@@ -1274,6 +1278,10 @@ struct WinPArgs {  // (a slim argument block: everything here stays in scalar re
   _Float16 *out_h, *out_l;
   int* out_sexp;
   unsigned* amax_out;
+  // split tail (see `item` in the kernel): walk indices from split_v0 on are K slices of the split_L leftover tiles
+  int split_S, split_L, split_v0;
+  float* slabs;    // [split_L * split_S][16][NT][4] partial accumulators
+  int* arrivals;   // [split_L] arrival counters, zero between launches
 };
 
 #ifdef LK_WINP_TRACE
@@ -1317,8 +1325,30 @@ void conv_winp_f16x2_kernel(const WinPArgs p) {
     m0_ = (v / nb_n) * BM, n0_ = (v % nb_n) * 64;
     return v < p.n_tiles;
   };
+  // The walk's last round is rarely full: 1152 images at 512 channels are 576 tiles for 512 workgroups — 64 of them would
+  // run a second tile while 448 idle, and the launch lasts two tiles for 1.125 tiles of work (measured: workgroups end at
+  // 140 .. 270 us).  The host therefore splits the split_L leftover tiles of that round along K into split_S slices each
+  // (split_L * split_S <= grid): an item of that round is (tile, chunk range), its accumulators go to a slab, the slice that
+  // arrives last at the tile's counter adds the slabs IN SLICE ORDER (a fixed order: the result does not depend on who
+  // arrives last) and runs the fused epilogue.  Chunk ranges are even in start and length (the LDS buffers' parity).
+  // (an item's chunk range and slab index travel as ONE word — first chunk | end chunk << 8 | (slab + 1) << 16 — : the kernel
+  //  sits at the register limit, and values carried around the persistent loop are booked as vector registers)
+  auto item = [&](int v, int& m0_, int& n0_, int& desc_) {
+    desc_ = KC << 8;
+    if (p.split_S > 1 && v >= p.split_v0) {
+      const int j = v - p.split_v0;
+      if (j >= p.split_L * p.split_S) return false;
+      // (uniform values, but integer division runs in the vector unit: back into scalar registers for the staging bases)
+      const int tl = __builtin_amdgcn_readfirstlane(j / p.split_S), len = __builtin_amdgcn_readfirstlane(KC / p.split_S);
+      const int sl = j - tl * p.split_S;
+      desc_ = (sl * len) | ((sl * len + len) << 8) | ((j + 1) << 16);
+      return coords(p.split_v0 + tl, m0_, n0_);
+    }
+    return coords(v, m0_, n0_);
+  };
+  int desc = 0, next_desc = 0, kc1 = KC, next_kc0 = 0;
   int m0, n0;
-  if (!coords(tile, m0, n0)) return;  // (uniform)
+  if (!item(tile, m0, n0, desc)) return;  // (uniform)
 #ifdef LK_WINP_ABLATE  // development switches, compile-time (a run-time switch perturbs this kernel's schedule beyond
   constexpr int ablate = LK_WINP_ABLATE;  // comparison): 1 skip the epilogue, 2 the MFMAs, 4 the in-loop staging
 #else
@@ -1455,24 +1485,78 @@ void conv_winp_f16x2_kernel(const WinPArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  // one step = three taps behind one hand-over barrier.  A tile = (pixel tile, 64 output channels); the n-tiles of one
-  // pixel tile are consecutive tile indices, i.e. run at the same time on neighbouring workgroups: the second one finds the
-  // window's lines in L2.
+  // ---- the K loop as ONE explicit instruction stream.  A step = three taps x 16 channels = 36 MFMAs per wave, 32 cycles of
+  //      the matrix pipe each, and a wave issues in order: whatever else it has to issue in a step — 24 fragment reads with
+  //      their address selects, its share of the LDS-DMA requests for later steps — sits in the gaps BETWEEN the MFMAs, one
+  //      item per gap, pinned by sched_barrier (blocks of reads / requests in front of blocks of MFMAs left the pipe idle for
+  //      their issue time: a workgroup alone on its CU ran at half the pipe's rate, profiles/r06_winp_alone.md).  Per step:
+  //        T0: tap 0 (fragments requested during the PREVIOUS step's T2)    gaps: reads of tap 1
+  //        T1: tap 1                                                         gaps: reads of tap 2
+  //        hand-over: own reads of this step done, vmcnt, s_barrier — the next step's operands have landed, and nobody reads
+  //                   this step's weight slot any more
+  //        T2: tap 2                                                         gaps: reads of the NEXT step's tap 0, the
+  //                   requests for the weights of the step after next (into the slot just released), the next chunk's window
+  //      The fragment sets alternate per MFMA block, i.e. per step with three blocks: set of a step's tap 0 = (kc + r) & 1 =
+  //      its weight slot; the loop is unrolled over two chunks so that both are compile-time.  A tile = (pixel tile, 64 output
+  //      channels).  The requests run one uniform stream across tile boundaries (the next tile's first window and first two
+  //      weight steps are requested during this tile's last chunk and land under its epilogue).
   int next_m0 = -1, next_n0 = 0;
   bool fresh = false;  // the next step follows an epilogue, which has drained this wave's loads itself (see there)
-  auto step = [&](int kc, bool last_tile, auto r_c) {
-    constexpr int r = decltype(r_c)::value;
-    const int slot = (kc + r) & 1;  // = (3 kc + r) & 1
-    // this wave's parts of this step have landed — at r == 1 the window requested one step ago (behind the weights, in
-    // issue order) may stay in flight: it is not read before the next chunk (no window was requested in the last chunk of
-    // the last tile: counting on it there let the weights of its second step slip through the wait)
-    // (inline asm with a memory clobber: the s_barrier builtin is no memory operation to the optimiser, which may move the
-    //  fragment reads of this step above it — it did, intermittently wrong results on the device)
-    if ((r == 0 && fresh) || (ablate & 8)) asm volatile("s_barrier" ::: "memory");  // (8: loads requested, never waited for: WRONG results, timing only)
-    else if (r == 1 && (kc + 1 < KC || !last_tile)) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(CFG::W_IT) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // ... everybody's; and nobody reads the buffers that are loaded next any more
-    if (r == 0) fresh = false;
-    __builtin_amdgcn_sched_barrier(0);
+  f16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+  static_assert(TM == 2 && TN == 2, "wait_set names eight registers");
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  auto lds_read = [&](f16x8& dst, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr)); };
+  // (the reads are asm and waited for by COUNT: hipcc books the LDS-DMA instructions between them as possible LDS traffic and
+  //  would wait lgkmcnt(0) in front of every MFMA; wait_set ties the set's registers to the wait)
+  auto wait_set = [&](int set) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(ah[set][0]), "+v"(ah[set][1]), "+v"(al[set][0]), "+v"(al[set][1]), "+v"(bh[set][0]), "+v"(bh[set][1]),
+                   "+v"(bl[set][0]), "+v"(bl[set][1]));
+  };
+  // one fragment read: u = 0 - 3 window (row tile u >> 1, plane u & 1), 4 - 7 weights (column tile (u - 4) >> 1, plane u & 1);
+  // tap j of step r_ whose window chunk lies at wb and whose weights lie in slot sl_
+  auto read_unit = [&](int u, int r_, int j, int set, int wb, int sl_, const unsigned* av, int apx) {
+    const int t = r_ * 3 + j;
+    if (u < 4) {
+      const int a = u >> 1;
+      const int px = apx + 32 * a + (t / 3) * Wi + t % 3;  // window pixel of this lane's row at tap t (raster order)
+      const int ad = wb + (px * 2 + (lh ^ ((px >> 3) & 1))) * 16;
+      const bool ok = (av[a] >> t) & 1u;
+      if (u & 1) lds_read(al[set][a], lds0 + (unsigned)(ok ? ad + CFG::W_PLANE : (int)CFG::ZERO_OFF));
+      else lds_read(ah[set][a], lds0 + (unsigned)(ok ? ad : (int)CFG::ZERO_OFF));
+    } else {
+      const int b = (u - 4) >> 1;
+      const unsigned pbo = lds0 + 2 * CFG::WIN + sl_ * CFG::B_STEP;
+      if (u & 1) lds_read(bl[set][b], pbo + b_addr[b] + (j * 2 + 1) * CFG::B_TAP);
+      else lds_read(bh[set][b], pbo + b_addr[b] + (j * 2) * CFG::B_TAP);
+    }
+  };
+  auto mfma_k = [&](int k, int set) {  // k = 0 .. 11: small terms first (l h, h l, h h), the four accumulators in turn
+    const int term = k >> 2, a = (k >> 1) & 1, b = k & 1;
+    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 0 ? al[set][a] : ah[set][a], term == 1 ? bl[set][b] : bh[set][b], acc[a][b], 0, 0, 0);
+  };
+  auto stage_b_one = [&](int kc_, int r_, int slot_, int bn0, int j) {
+    const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + 2 * CFG::WIN + slot_ * CFG::B_STEP;
+    const int i = (wave * CFG::B_IT + j) % CFG::B_INSTR;  // (scalar)
+    const int jp = i >> 1;                                 // (tap of the step, plane)
+    const int t = r_ * 3 + (jp >> 1);
+    const char* sb = reinterpret_cast<const char*>((jp & 1) ? p.Wl : p.Wh) + (int64_t)(p.wt0 + t * p.wtstep) * w_tap_bytes + (kc_ * p.Co + bn0) * 32;
+    // (the lane offset opaque at its use: (scalar base) + (32-bit lane offset) is one instruction; hipcc otherwise folds the
+    //  loop-invariant half of the sum into 64-bit lane addresses per request, keeps all of them and spills)
+    unsigned off = b_off[j];
+    asm volatile("" : "+v"(off));
+    __builtin_amdgcn_global_load_lds((gbl_void*)(sb + off), (lds_void*)(uintptr_t)(base + i * 1024), 16, 0, 0);
+  };
+  auto stage_win_one = [&](int kc_, int buf, int it) {
+    const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + buf * CFG::WIN;
+    const int i = w_instr(it);  // (scalar)
+    const char* sb = reinterpret_cast<const char*>((i * 64 >= 2 * PP) ? p.Al : p.Ah) + kc_ * 32;  // (scalar)
+    unsigned off = w_off[it];
+    asm volatile("" : "+v"(off));
+    __builtin_amdgcn_global_load_lds((gbl_void*)(sb + off), (lds_void*)(uintptr_t)(base + i * 1024), 16, 0, 0);
+  };
+  auto step = [&](int kc, bool first, bool last_step, bool last_tile, auto r_c, auto p_c) {
+    constexpr int r = decltype(r_c)::value, P = decltype(p_c)::value;  // P = (kc + r) & 1: this step's weight slot and tap-0 set
     // (opaque to the optimiser: the fragment addresses and tap-validity selects below are invariant over the K loop, and
     //  hipcc otherwise hoists all 2 x 18 of them — and their 18 lane masks — out of it and spills them)
     int wbase = (kc & 1) * CFG::WIN;
@@ -1483,89 +1567,74 @@ void conv_winp_f16x2_kernel(const WinPArgs p) {
       av[a] = a_valid[a];
       asm volatile("" : "+v"(av[a]));
     }
-    // Fragments of tap j + 1 are requested before the MFMAs of tap j are issued (two register sets): while this workgroup's
-    // partner on the CU is in its epilogue nobody else covers the LDS round trip.  The reads are issued as asm and waited
-    // for by COUNT: hipcc books the LDS-DMA instructions between them as possible LDS traffic and would wait lgkmcnt(0) —
-    // for both sets — in front of the first MFMA (it did: the first sixteen reads of every step were paid in the open).
-    // wait_set ties the set's registers to the wait, so that no use of them can be placed above it.
-    f16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
-    static_assert(TM == 2 && TN == 2, "wait_set names eight registers");
-    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    auto lds_read = [&](f16x8& dst, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr)); };
-    auto load_frags = [&](int j, int set) {
-      const int t = r * 3 + j;  // compile-time after unrolling
-      const int shift = (t / 3) * Wi + t % 3;  // window pixel shift of tap t (raster order)
+    int apx = a_px0;  // (likewise: eighteen per-tap lane offsets, invariant over the loop, would be kept — three of them in scratch)
+    asm volatile("" : "+v"(apx));
+    const bool more = kc + 1 < kc1;  // (another chunk of this tile behind this one)
+    if (r == 0 && first) {
+      // a tile's first step: everybody's requests for it have landed (behind an epilogue this wave has drained its own
+      // already, see there), its tap 0 is read in the open
+      // (inline asm with a memory clobber: the s_barrier builtin is no memory operation to the optimiser, which may move
+      //  fragment reads above it — it did, intermittently wrong results on the device)
+      if (fresh) asm volatile("s_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      fresh = false;
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int a = 0; a < TM; ++a) {
-        const int px = a_px0 + 32 * a + shift;
-        const int ad = wbase + (px * 2 + (lh ^ ((px >> 3) & 1))) * 16;
-        const bool ok = (av[a] >> t) & 1u;
-        lds_read(ah[set][a], lds0 + (unsigned)(ok ? ad : (int)CFG::ZERO_OFF));
-        lds_read(al[set][a], lds0 + (unsigned)(ok ? ad + CFG::W_PLANE : (int)CFG::ZERO_OFF));
-      }
-      const unsigned pbo = lds0 + 2 * CFG::WIN + slot * CFG::B_STEP;
-#pragma unroll
-      for (int b = 0; b < TN; ++b) {
-        lds_read(bh[set][b], pbo + b_addr[b] + (j * 2) * CFG::B_TAP);
-        lds_read(bl[set][b], pbo + b_addr[b] + (j * 2 + 1) * CFG::B_TAP);
-      }
-    };
-    auto wait_set = [&](int set, bool younger) {  // the set has arrived (`younger`: the eight reads issued after it may still fly)
-      if (younger)
-        asm volatile("s_waitcnt lgkmcnt(8)"
-                     : "+v"(ah[set][0]), "+v"(ah[set][1]), "+v"(al[set][0]), "+v"(al[set][1]), "+v"(bh[set][0]),
-                       "+v"(bh[set][1]), "+v"(bl[set][0]), "+v"(bl[set][1]));
-      else
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(ah[set][0]), "+v"(ah[set][1]), "+v"(al[set][0]), "+v"(al[set][1]), "+v"(bh[set][0]),
-                       "+v"(bh[set][1]), "+v"(bl[set][0]), "+v"(bl[set][1]));
-    };
-    load_frags(0, 0);
-    // the next step's operands are requested BEHIND this step's first fragment reads: the LDS round trip of those reads
-    // (in the open behind every hand-over barrier) then runs under the issue of the staging instructions instead of after it
-    __builtin_amdgcn_sched_barrier(0);
-    {
-      const bool more = kc + 1 < KC;
-      if (ablate & 4) {
-      } else if (r < 2) stage_b(kc, r + 1, slot ^ 1, n0);
-      else if (more) stage_b(kc + 1, 0, slot ^ 1, n0);
-      else if (!last_tile) stage_b(0, 0, slot ^ 1, next_n0);
-      if (r == 0 && !(ablate & 4)) {
-        if (more) stage_win(kc + 1, (kc + 1) & 1);
-        else if (!last_tile) {
-          setup_window(next_m0);
-          stage_win(0, (kc + 1) & 1);
-        }
-      }
+      for (int u = 0; u < 8; ++u) read_unit(u, 0, 0, P, wbase, P, av, apx);
     }
     __builtin_amdgcn_sched_barrier(0);
+    // ---- T0
+    wait_set(P);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int set = j & 1;
-      if (j + 1 < 3) load_frags(j + 1, set ^ 1);
-      wait_set(set, j + 1 < 3);
+    for (int k = 0; k < 12; ++k) {
+      mfma_k(k, P);
       __builtin_amdgcn_sched_barrier(0);
-#ifdef LK_WINP_ABLATE
-      if (ablate & 2) {
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-          for (int b = 0; b < TN; ++b) acc[a][b][0] += (float)ah[set][a][0] + (float)al[set][a][1] + (float)bh[set][b][2] + (float)bl[set][b][3];
-        continue;
-      }
-#endif
-#pragma unroll
-      for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b) {
-          f32x16 c = acc[a][b];
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[set][a], bh[set][b], c, 0, 0, 0);  // small terms first
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[set][a], bl[set][b], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[set][a], bh[set][b], c, 0, 0, 0);
-          acc[a][b] = c;
-        }
+      if (k < 8) read_unit(k, r, 1, P ^ 1, wbase, P, av, apx);
+      else if (r == 1 && (more || !last_tile) && k - 7 < CFG::W_IT) stage_win_one(more ? kc + 1 : next_kc0, (kc + 1) & 1, k - 7);  // window pieces 1 .. 4
       __builtin_amdgcn_sched_barrier(0);
     }
+    // ---- T1
+    wait_set(P ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      mfma_k(k, P ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (k < 8) read_unit(k, r, 2, P, wbase, P, av, apx);
+      else if (r == 1 && (more || !last_tile) && k - 3 < CFG::W_IT) stage_win_one(more ? kc + 1 : next_kc0, (kc + 1) & 1, k - 3);  // pieces 5 ..
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    static_assert(CFG::W_IT <= 9, "window pieces: one in T2 of step 0, four in T0 and up to four in T1 of step 1");
+    // ---- hand-over: this wave's reads of the step are done; the next step's operands have landed — at r == 1 the window
+    //      requested since the last hand-over (behind the weights, in issue order) may stay in flight: it is not read before
+    //      the next chunk (none is requested in the last chunk of the last tile)
+    wait_set(P);
+    if (r == 1 && (more || !last_tile)) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(CFG::W_IT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- T2
+    // what is requested behind this hand-over: the weights of the step after next into the slot just released — step
+    // (kc, 2) behind step 0, (next chunk, 0 / 1) behind steps 1 / 2 (the next TILE's first chunk behind this tile's last) —
+    // and, behind step 0, the first piece of the next chunk's window
+    const bool w_here = r == 0 || more, w_next = !w_here && !last_tile;
+    const int w_kc = r == 0 ? kc : (more ? kc + 1 : next_kc0), w_r = r == 0 ? 2 : r - 1, w_n0 = w_here ? n0 : next_n0;
+    if (r == 0 && !more && !last_tile) setup_window(next_m0);
+    int wnext = ((r == 2 ? kc + 1 : kc) & 1) * CFG::WIN;  // window buffer of the next step
+    asm volatile("" : "+s"(wnext));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      mfma_k(k, P);
+      __builtin_amdgcn_sched_barrier(0);
+      if (k < 8) {
+        if (!last_step) read_unit(k, r == 2 ? 0 : r + 1, 0, P ^ 1, wnext, P ^ 1, av, apx);
+      } else if (k - 8 < CFG::B_IT) {
+        if (w_here || w_next) stage_b_one(w_kc, w_r, P, w_n0, k - 8);
+      } else if (k == 11 && r == 0 && (more || !last_tile)) stage_win_one(more ? kc + 1 : next_kc0, (kc + 1) & 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    static_assert(CFG::B_IT <= 3, "weight requests of a step fit the gaps 8 .. 10 of T2");
   };
 
   // ---- fused epilogue of one tile: eight 8-row slices per wave, lane = (row lane >> 3 of the slice, channels (lane & 7) * 8 ..)
@@ -1654,11 +1723,79 @@ void conv_winp_f16x2_kernel(const WinPArgs p) {
     fresh = true;
   };
 
+  // ---- a K slice of a split tile: accumulators -> slab, arrive, and the LAST slice of its tile sums the slabs in slice order
+  //      (true: `acc` now holds the tile's sums, the caller runs the epilogue).  Cross-CU visibility by the book
+  //      (MI355X_MICROARCH.md, inter-workgroup visibility): plain stores, workgroup barrier, one lane's agent-scope release
+  //      + drained vmcnt, relaxed agent-scope arrival; the last arriver: agent-scope acquire (invalidates THIS CU's L1),
+  //      workgroup barrier, plain loads.  A split item is the last of its workgroup's walk: nothing else is in flight.
+  auto combine = [&](int part_) -> bool {
+    const int tl = __builtin_amdgcn_readfirstlane(part_ / p.split_S);
+    f32x4* slab = reinterpret_cast<f32x4*>(p.slabs) + (size_t)part_ * (16 * CFG::NT);
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 v;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = acc[a][b][4 * q + i];
+          slab[((a * TN + b) * 4 + q) * CFG::NT + tid] = v;
+        }
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(smem + CFG::ZERO_OFF + 16);  // (behind the 16 zero bytes fragment reads use; re-zeroed below)
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int old = __hip_atomic_fetch_add(p.arrivals + tl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = old == p.split_S - 1;
+      if (last) {
+        __hip_atomic_store(p.arrivals + tl, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (every slice has arrived: clean for the next launch)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      *flag = last;
+    }
+    __syncthreads();
+    const bool last = __builtin_amdgcn_readfirstlane(*flag) != 0;  // (uniform: the epilogue behind it keeps scalar control flow)
+    __syncthreads();
+    if (tid == 0) *flag = 0;
+    if (!last) return false;
+    // (all sixteen loads of TWO slabs in flight before the first add: read one dependent load at a time this sum took 55 us
+    //  for eight slabs — three times the slice's own K loop.  split_S is even.)
+    const f32x4* src = reinterpret_cast<const f32x4*>(p.slabs) + (size_t)tl * p.split_S * (16 * CFG::NT) + tid;
+    f32x4 v[16], w0[16], w1[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = src[e * CFG::NT], w0[e] = src[(16 + e) * CFG::NT];
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[e][i] += w0[e][i];
+    for (int sl = 2; sl < p.split_S; sl += 2) {
+      const f32x4* s2 = src + (size_t)sl * (16 * CFG::NT);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) w0[e] = s2[e * CFG::NT], w1[e] = s2[(16 + e) * CFG::NT];
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[e][i] = (v[e][i] + w0[e][i]) + w1[e][i];
+    }
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[a][b][4 * q + i] = v[(a * TN + b) * 4 + q][i];
+    return true;
+  };
+
   // prologue: the first tile's first window and first three taps
   setup_window(m0);
   setup_frag(m0);
-  stage_win(0, 0);
-  stage_b(0, 0, 0, n0);
+  stage_win(__builtin_amdgcn_readfirstlane(desc & 0xff), 0);
+  stage_b(__builtin_amdgcn_readfirstlane(desc & 0xff), 0, 0, n0);
+  stage_b(__builtin_amdgcn_readfirstlane(desc & 0xff), 1, 1, n0);  // (the request stream runs two steps ahead of the MFMAs)
   // the second workgroup of a CU starts half a tile late (the host passes the delay in units of 64 s_sleep cycles): from
   // then on one workgroup's epilogue runs beside the other's K loop
   if (blockIdx.x >= (unsigned)(G / 2))
@@ -1670,6 +1807,8 @@ void conv_winp_f16x2_kernel(const WinPArgs p) {
   if (tid == 0 && blockIdx.x < 1024) {
     g_winp_trace[(blockIdx.x * 16 + 15) * 3] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
     g_winp_trace[(blockIdx.x * 16 + 15) * 3 + 1] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
+    g_winp_trace[(blockIdx.x * 16 + 15) * 3 + 2] = __builtin_amdgcn_s_memtime();
+    g_winp_trace[(blockIdx.x * 16 + 14) * 3] = wall_clock64();  // (100 MHz, one counter for the device: slot 14 = wall start, wall end, s_memtime end)
   }
 #define LK_WINP_STAMP(k) \
   if (tid == 0 && blockIdx.x < 1024 && trace_it < 15) g_winp_trace[(blockIdx.x * 16 + trace_it) * 3 + (k)] = __builtin_amdgcn_s_memtime();
@@ -1677,16 +1816,31 @@ void conv_winp_f16x2_kernel(const WinPArgs p) {
 #define LK_WINP_STAMP(k)
 #endif
   while (true) {
-    const bool last_tile = !coords(tile + G, next_m0, next_n0);
+    const bool last_tile = !item(tile + G, next_m0, next_n0, next_desc);
+    // (uniform by construction; said explicitly — carried around the persistent loop hipcc books them as divergent, and the
+    //  staging bases and LDS buffer selects below live in scalar registers)
+    const int kc0 = __builtin_amdgcn_readfirstlane(desc & 0xff), part = __builtin_amdgcn_readfirstlane(desc >> 16) - 1;
+    kc1 = __builtin_amdgcn_readfirstlane((desc >> 8) & 0xff), next_kc0 = __builtin_amdgcn_readfirstlane(next_desc & 0xff);
     LK_WINP_STAMP(0)
-    for (int kc = 0; kc < KC; ++kc) {
-      if (kc == KC - 1) epi_request(m0, n0, 0, NH);
-      step(kc, last_tile, std::integral_constant<int, 0>{});
-      step(kc, last_tile, std::integral_constant<int, 1>{});
-      step(kc, last_tile, std::integral_constant<int, 2>{});
+    for (int kc = kc0; kc < kc1; kc += 2) {  // (chunk ranges are even in start and length)
+      using I0 = std::integral_constant<int, 0>;
+      using I1 = std::integral_constant<int, 1>;
+      using I2 = std::integral_constant<int, 2>;
+      step(kc, kc == kc0, false, last_tile, I0{}, I0{});
+      step(kc, false, false, last_tile, I1{}, I1{});
+      step(kc, false, false, last_tile, I2{}, I0{});
+      step(kc + 1, false, false, last_tile, I0{}, I1{});
+      step(kc + 1, false, false, last_tile, I1{}, I0{});
+      step(kc + 1, false, kc + 2 >= kc1, last_tile, I2{}, I1{});
     }
+    // (the fragment sets are dead here — the next tile's first step reads its tap 0 itself — which the optimiser cannot see
+    //  through the run-time `first` / `last_step`: without this it keeps 32 registers alive across the epilogue and spills)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      asm volatile("" : "=v"(ah[0][i]), "=v"(al[0][i]), "=v"(bh[0][i]), "=v"(bl[0][i]), "=v"(ah[1][i]), "=v"(al[1][i]), "=v"(bh[1][i]), "=v"(bl[1][i]));
     LK_WINP_STAMP(1)
-    if (!(ablate & 1)) epilogue(m0, n0);
+    if (part >= 0 && !combine(part)) {
+    } else if (!(ablate & 1)) epilogue(m0, n0);
     else if (acc[0][0][0] == 12345.678f) p.out_h[0] = (_Float16)1.f;
     LK_WINP_STAMP(2)
 #ifdef LK_WINP_TRACE
@@ -1700,8 +1854,8 @@ void conv_winp_f16x2_kernel(const WinPArgs p) {
         for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     if (last_tile) break;
     tile += G;
-    m0 = next_m0, n0 = next_n0;
-    if (!frag_const) setup_frag(m0);
+    m0 = next_m0, n0 = next_n0, desc = next_desc;
+    if (!frag_const || (desc >> 16)) setup_frag(m0);
   }
   if (p.amax_out) {
 #pragma unroll
@@ -1709,6 +1863,12 @@ void conv_winp_f16x2_kernel(const WinPArgs p) {
     const int back = -so < -126 ? -126 : -so;
     if (lane == 0 && vmax) atomicMax(p.amax_out, __float_as_uint(__uint_as_float(vmax) * exp2i(back)));
   }
+#ifdef LK_WINP_TRACE
+  if (tid == 0 && blockIdx.x < 1024) {
+    g_winp_trace[(blockIdx.x * 16 + 14) * 3 + 1] = wall_clock64();
+    g_winp_trace[(blockIdx.x * 16 + 14) * 3 + 2] = __builtin_amdgcn_s_memtime();
+  }
+#endif
 }
 
 }  // namespace lk
@@ -1884,6 +2044,35 @@ static int coloc_default(int Ci, int Co) {
   return Co >= 256 ? 4 : (Co == 128 ? 2 : 1);
 }
 
+// Slabs and arrival counters of the split tail, one set per stream (launches on one stream are ordered; the two lanes of a
+// fit run this kernel side by side on their own streams).  Allocated at a stream's first split launch — 512 slabs of one
+// tile's accumulators = 32 MB (64 MB for the eight-wave form) — and kept for the life of the process.
+struct WinpScratch {
+  float* slabs = nullptr;
+  int* arrivals = nullptr;
+  size_t slab_bytes = 0;
+};
+static WinpScratch* winp_scratch(hipStream_t stream, size_t slab_bytes, int n_arrivals) {
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, WinpScratch> pool;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  WinpScratch& w = pool[{dev, stream}];
+  if (w.slab_bytes < slab_bytes || !w.arrivals) {
+    // (growing: the old block stays allocated — a launch in flight may still use it)
+    float* sl = nullptr;
+    int* ar = nullptr;
+    if (hipMalloc(&sl, slab_bytes) != hipSuccess) return nullptr;
+    if (!w.arrivals) {
+      if (hipMalloc(&ar, sizeof(int) * n_arrivals) != hipSuccess || hipMemset(ar, 0, sizeof(int) * n_arrivals) != hipSuccess) return nullptr;
+      w.arrivals = ar;
+    }
+    w.slabs = sl, w.slab_bytes = slab_bytes;
+  }
+  return &w;
+}
+
 template <typename CFG>
 static bool launch_winp(const ConvGeom& g, const void* Ah, const void* Al, const void* Wh /* chunk-major */, const void* Wl, const int* a_sexp,
                         const int* w_sexp, unsigned* amax_out, hipStream_t stream, const ConvVjp* fz, int* rc, int config) {
@@ -1911,7 +2100,12 @@ static bool launch_winp(const ConvGeom& g, const void* Ah, const void* Al, const
   p.w_l1 = fz->w_l1, p.scale = fz->scale;
   p.add_h = fz->add_h, p.add_l = fz->add_l;
   p.mask = (const unsigned char*)fz->mask, p.mask_rows = (int)fz->mask_rows;
-  p.stagger = 3 * (g.Ci / 64);  // start delay of a CU's second workgroup, x 64 s_sleep cycles (measured: 0 .. 8, flat around 3)
+  // start delay of a CU's second workgroup, x 64 s_sleep cycles.  Round 4 started it half a tile late so that one workgroup's
+  // epilogue would run beside the other's K loop; measured again in round 6 (tools/winp_bench.py, profiles/r06_winp_study.md):
+  // with the reads and requests in the MFMA gaps a lone workgroup no longer runs at half rate, and the delay only idles the
+  // second workgroup at the start — 0 is 2 - 4 % faster on every c4 shape
+  p.stagger = 0;
+  if ((config >> 20) & 31) p.stagger = ((config >> 20) & 31) - 1;  // (development: bits 20-24 = delay + 1)
   p.ablate = 0;
   p.halo_all = (config >> 30) & 1;  // (development: stage the whole PP-pixel window as round 4 did)
   p.coloc = 1;
@@ -1922,7 +2116,8 @@ static bool launch_winp(const ConvGeom& g, const void* Ah, const void* Al, const
     (void)hipFuncSetAttribute((const void*)conv_winp_f16x2_kernel<CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS);
     attr_set = true;
   }
-  constexpr int wg_per_cu = 2;
+  const int wg_per_cu = (config & 524288) ? 1 : CFG::WG_PER_CU;  // (development: bit 19 = one workgroup per CU)
+  if (wg_per_cu == 1) p.stagger = 0;
   const int grid = p.n_tiles < wg_per_cu * cu_count() ? p.n_tiles : wg_per_cu * cu_count();  // two workgroups per CU
   {
     // columns of a pixel tile that share an XCD (see `coords` in the kernel): config bits 28-29 = log2, 0 = the default below
@@ -1930,6 +2125,24 @@ static bool launch_winp(const ConvGeom& g, const void* Ah, const void* Al, const
     int c = 1 << ((config >> 28) & 3);
     if (c == 1) c = coloc_default(g.Ci, g.Co);
     if (c > 1 && c <= nb_n && nb_n % c == 0 && nb_n / c <= 8 && 8 % (nb_n / c) == 0 && grid % 8 == 0 && (grid / 8) % c == 0) p.coloc = c;
+  }
+  // split tail (see `item` in the kernel; config bit 25 switches it ON — measured 15 - 30 us slower per c4 launch than leaving
+  // the last round ragged: the slab round trip costs what the balance gains, profiles/r06_winp_study.md): the leftover tiles of the last round in S slices
+  // each — S the largest divisor of the chunk count with L * S <= grid and an even number (>= 2) of chunks per slice
+  p.split_S = 1, p.split_L = 0, p.split_v0 = 0, p.slabs = nullptr, p.arrivals = nullptr;
+  {
+    const int KC = g.Ci / 16, L = p.n_tiles % grid;
+    int holes = 0;
+    if (p.coloc > 1) holes = p.nb_m % (8 / ((g.Co / 64) / p.coloc));  // (`coords` with co-located columns: index space = tiles only then)
+    if (L > 0 && p.n_tiles > grid && !holes && (config & 33554432)) {
+      int S = 1;
+      for (int d = 2; d <= 8 && d <= KC && d * L <= grid; d += 2)  // (even: the combine reads slabs in pairs)
+        if (KC % d == 0 && (KC / d) % 2 == 0) S = d;
+      if (S > 1) {
+        WinpScratch* w = winp_scratch(stream, (size_t)cu_count() * wg_per_cu * 16 * CFG::NT * sizeof(float) * 4, cu_count() * wg_per_cu);
+        if (w) p.split_S = S, p.split_L = L, p.split_v0 = p.n_tiles - L, p.slabs = w->slabs, p.arrivals = w->arrivals;
+      }
+    }
   }
   hipLaunchKernelGGL((conv_winp_f16x2_kernel<CFG>), dim3((unsigned)grid), dim3(CFG::NT), CFG::LDS, stream, p);
   *rc = check_launch("conv_winp_f16x2_kernel");
@@ -1968,6 +2181,7 @@ static int conv_dispatch(const void* in_h, const void* in_l, const int* in_sexp,
   if (fz && !g.out_planes && !fz->fwd_y && fz->wc_h && !(config & 134217728) && lk_conv_winp_eligible(N, Hi, Wi, Ci, Co, T, fz->mask && fz->mask_float) &&
       in_mul == 1 && Hc == Hi && Wc == Wi && g.dense) {
     int rc = LK_OK;
+    if ((config & 67108864) && launch_winp<WinPCfg<512>>(g, in_h, in_l, fz->wc_h, fz->wc_l, in_sexp, w_sexp, amax_out, st, fz, &rc, config)) return rc;
     if (launch_winp<WinPCfg<256>>(g, in_h, in_l, fz->wc_h, fz->wc_l, in_sexp, w_sexp, amax_out, st, fz, &rc, config)) return rc;
   }
 #define LK_CONV_GO(...) return launch_conv<ConvCfg<__VA_ARGS__>>(g, in_h, in_l, w_h, w_l, in_sexp, w_sexp, zero16, out, accumulate, amax_out, st, fz)

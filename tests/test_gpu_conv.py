@@ -269,7 +269,9 @@ def test_position_major_rows_on_small_maps(shape, config):
 
 
 WINP_CASES = [(64, 64, 32, 131), (64, 64, 20, 131), (128, 64, 16, 290), (128, 128, 16, 37), (256, 256, 8, 300), (64, 128, 12, 75),
-              (512, 512, 4, 200), (64, 64, 32, 1152), (64, 96, 9, 64)]
+              (512, 512, 4, 200), (64, 64, 32, 1152), (64, 96, 9, 64),
+              # the split tail (leftover tiles of the last round in K slices): the c4 launches, and counts that leave 40 / 88 tiles
+              (128, 128, 16, 1152), (256, 256, 8, 1152), (512, 512, 4, 1152), (512, 512, 4, 1100), (128, 128, 16, 300)]
 
 
 @pytest.mark.parametrize("cin,cout,H,n_img", WINP_CASES, ids=[f"{c[0]}-{c[1]}-{c[2]}x{c[2]}-n{c[3]}" for c in WINP_CASES])
@@ -302,9 +304,13 @@ def test_persistent_window_form_of_the_fused_launch(cin, cout, H, n_img):
         for kw in ({}, {"add": addend}, {"mult": mask}, {"add": addend, "mult": mask, "scale": sc, "scale_amax": K.absmax(sc)}):
             K.conv_config = 2
             fused = cv.conv_backward_data_vjp(prep, gs, (H, H), **kw)
+            K.conv_config = 2 | (1 << 25)  # (bit 25: the last round's leftover tiles in K slices, summed through slabs in slice order)
+            split = cv.conv_backward_data_vjp(prep, gs, (H, H), **kw)
             K.conv_config = 2 | (1 << 27)  # (bit 27: the persistent form off)
             ref = cv.conv_backward_data_vjp(prep, gs, (H, H), **kw)
             assert torch.equal(fused.sexp, ref.sexp) and rel(fused.float(), ref.float()) < 4e-6, sorted(kw)  # (other order of the K steps)
+            assert torch.equal(split.sexp, ref.sexp) and rel(split.float(), ref.float()) < 4e-6, sorted(kw)
+            assert abs(split.amax.item() - split.float().abs().max().item()) <= 1e-5 * split.amax.item()
             assert abs(fused.amax.item() - fused.float().abs().max().item()) <= 1e-5 * fused.amax.item()
             if want_b is not None:
                 want = want_b.permute(0, 2, 3, 1)

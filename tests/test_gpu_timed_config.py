@@ -319,3 +319,24 @@ def test_where_the_relu_margin_comes_from(act):
     print(f"  masks differing from the fp64 forward: kernels {flips['kernels']}, stock fp32 on the device {flips['stock']}; "
           f"worst ratio of the activation errors {ratio:.1f}")
     assert ratio < 6.0 and flips["kernels"] <= 4 * flips["stock"] + 8  # (measured: 3.2, 5 vs 5)
+    # ... and the FACTORS of that stock device forward (the autograd tape: library convolutions forward and backward, one
+    # reverse pass per seed, `use_sweep = False`; the Gram kernels are exact-fp32 MFMA products) against the same fp64 oracle,
+    # block by block: the 1e-3 above is earned if the kernels' blocks are no further from fp64 than twice what a stock fp32
+    # execution of curvlinops.py:77-108 on this device is — the rest is the masks, which no fp32 execution gets right
+    bs = HipGGN(copy.deepcopy(m32).to(DEV), "classification")
+    bs.use_sweep = False
+    accs = bs.kron_accumulator(N)
+    accs.add_batch(X.to(DEV), y.to(DEV))
+    _, Hs = accs.finalize()
+    worst_stock = worst_ratio = 0.0
+    for F_, Fs, G64 in zip(H.kfacs, Hs.kfacs, kf64):
+        for a, st, w in zip(F_, Fs, G64):
+            scale = w.abs().max().item() + 1e-300
+            ek = (a.double().cpu() - w).abs().max().item() / scale
+            es = (st.double().cpu() - w).abs().max().item() / scale
+            worst_stock = max(worst_stock, es)
+            worst_ratio = max(worst_ratio, ek / max(es, 2e-6))  # (blocks where both sit at fp32 rounding: ratio of noise)
+    record_error(worst_stock, "stock-device-tape-vs-fp64-oracle")
+    record_error(worst_ratio, "worst-block-ratio-kernels-over-stock-device")
+    print(f"  factors of the stock fp32 device tape against fp64: worst block {worst_stock:.2e}; worst per-block ratio kernels / stock {worst_ratio:.2f}")
+    assert worst_ratio <= 2.0

@@ -28,6 +28,16 @@ done
 python tools/pmc_traffic.py $(find gpurun_out/pmc -name "*FETCH_SIZE*.db" | head -1) $(find gpurun_out/pmc -name "*WRITE_SIZE*.db" | head -1) gpurun_out/${R5}_pmc_traffic_bench_c4_$TAG.json gpurun_out/${R5}_pmc_traffic_bench_c4_$TAG.md > /dev/null 2>> $S
 rm -rf gpurun_out/pmc
 cp gpurun_out/${R5}_pmc_traffic_bench_c4_$TAG.json profiles/   # (so that the bench runs below find a table with a matching stamp)
+# PMC traffic of the GLM predictive (the metric's second half): four passes, with 4 calls and with none; the difference is theirs
+rm -rf gpurun_out/pmcp
+for n in 0 4; do for c in FETCH_SIZE WRITE_SIZE; do
+  cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/pmcp -o p${n}_$c -- python $R/tools/kron_predictive_c4.py --calls $n > $R/gpurun_out/pmcp_${n}_$c.log 2>&1
+  echo "pmc predictive $n $c rc=$?" >> $R/$S
+  cd $R
+done; done
+python tools/pmc_traffic.py --diff $(find gpurun_out/pmcp -name "*p0_FETCH_SIZE*.db" | head -1) $(find gpurun_out/pmcp -name "*p0_WRITE_SIZE*.db" | head -1) $(find gpurun_out/pmcp -name "*p4_FETCH_SIZE*.db" | head -1) $(find gpurun_out/pmcp -name "*p4_WRITE_SIZE*.db" | head -1) 4 gpurun_out/${R5}_pmc_traffic_predictive_c4_$TAG.json gpurun_out/${R5}_pmc_traffic_predictive_c4_$TAG.md > /dev/null 2>> $S
+rm -rf gpurun_out/pmcp
+cp gpurun_out/${R5}_pmc_traffic_predictive_c4_$TAG.json profiles/
 cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o p -- python $R/bench.py --steps 20 --warmup 5 $LIGHT > $R/gpurun_out/prof_$TAG.log 2>&1; echo "trace rc=$?" >> $R/$S
 cd $R
 python tools/rocpd_stats.py $(find gpurun_out/prof_$TAG -name "*.db" | head -1) gpurun_out/${R5}_bench_c4_kernel_stats_$TAG.md > /dev/null 2>&1

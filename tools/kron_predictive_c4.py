@@ -18,6 +18,7 @@ from laplace_amd.nets import ResNet18  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--profile", action="store_true")
 ap.add_argument("--batch", type=int, default=128)
+ap.add_argument("--calls", type=int, default=-1, help="set up, one warm-up call, then exactly this many fused calls and exit (PMC passes: tools/gpu_evidence.sh)")
 args = ap.parse_args()
 dev = "cuda"
 torch.manual_seed(711)
@@ -37,6 +38,12 @@ _, H = acc.finalize()
 post = H.decompose() + torch.ones(1, device=dev)
 K = get_kernels()
 out = {"batch": args.batch}
+if args.calls >= 0:
+    P.glm_variance_kron(backend, X, post)
+    for _ in range(args.calls):
+        P.glm_variance_kron(backend, X, post)
+    torch.cuda.synchronize()
+    sys.exit(0)
 
 
 def rate(x, reps):

@@ -76,5 +76,38 @@ def main(fetch_db, write_db, out_json, out_md):
     print("\n".join(lines))
 
 
+def main_diff(fetch0, write0, fetchk, writek, calls, out_json, out_md):
+    """Traffic of `calls` repetitions of a phase: the passes over the command WITH them minus the passes without (both runs
+    do the same set-up; usage: pmc_traffic.py --diff fetch0.db write0.db fetchK.db writeK.db K out.json out.md)"""
+    calls = int(calls)
+    f0, _ = collect(fetch0, "FETCH_SIZE")
+    w0, _ = collect(write0, "WRITE_SIZE")
+    fk, dur = collect(fetchk, "FETCH_SIZE")
+    wk, _ = collect(writek, "WRITE_SIZE")
+    res = {}
+    lines = [f"| kernel | launches per call | HBM read MB per call (2x) | HBM write MB per call | HBM MB per call |", "|---|---|---|---|---|"]
+    for k in sorted(fk):
+        n = len(fk[k]) - len(f0.get(k, []))
+        if n <= 0:
+            continue
+        rd = 2.0 * 1024.0 * (sum(fk[k]) - sum(f0.get(k, [])))
+        wr = 1024.0 * (sum(wk.get(k, [])) - sum(w0.get(k, [])))
+        res[k] = {"launches": n, "hbm_read_bytes": rd / n, "hbm_write_bytes": wr / n, "hbm_bytes_per_launch": (rd + wr) / n}
+        lines.append(f"| `{k}` | {n / calls:.1f} | {rd / calls / 1e6:.1f} | {wr / calls / 1e6:.1f} | {(rd + wr) / calls / 1e6:.1f} |")
+    head = ""
+    try:
+        head = open(os.path.join(ROOT, "GIT_HEAD")).read().strip()
+    except OSError:
+        pass
+    res["_meta"] = {"csrc_sha16": csrc_sha16(), "git_head": head or None, "calls": calls,
+                    "note": "difference of two PMC runs of the same command with / without `calls` repetitions of the phase"}
+    json.dump(res, open(out_json, "w"), indent=1)
+    open(out_md, "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+
 if __name__ == "__main__":
-    main(*sys.argv[1:5])
+    if sys.argv[1] == "--diff":
+        main_diff(*sys.argv[2:9])
+    else:
+        main(*sys.argv[1:5])
