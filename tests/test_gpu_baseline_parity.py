@@ -40,13 +40,34 @@ def _pair(model32):
     return model32.to(DEV).eval(), m64
 
 
-def _assert_kfacs(kron, kf_ref, what):
+def elementwise_excess(a, b, rtol=1e-4, floor=1e-6):
+    """The reference's own assertions are ELEMENT-wise (`allclose(rtol=1e-4 .. 5e-5)`, tests/test_curv_backends_curvlinops.py:
+    144-155, tests/test_baselaplace.py:334-410); `rel` above constrains a block only against its largest entry.  This is
+    the element-wise reading with the absolute floor any fp32 sum needs — `|a - b| <= rtol |b| + floor max|b|` — as the
+    worst ratio of error to allowance (<= 1: every element passes) and the fraction of elements above it."""
+    a, b = a.double().cpu(), b.double().cpu()
+    allow = rtol * b.abs() + floor * b.abs().max()
+    ratio = (a - b).abs() / (allow + 1e-300)
+    return ratio.max().item(), (ratio > 1.0).double().mean().item()
+
+
+def _assert_kfacs(kron, kf_ref, what, elementwise=None):
+    from tests.parity_log import record_error
+
     assert len(kron.kfacs) == len(kf_ref), what
+    worst_ex = worst_frac = 0.0
     for i, (F_, G_) in enumerate(zip(kron.kfacs, kf_ref)):
         assert len(F_) == len(G_)
         for j, (a, b) in enumerate(zip(F_, G_)):
             assert tuple(a.shape) == tuple(b.shape)
             assert rel(a, b) < TOL, f"{what}: block {i} factor {j} (n={a.shape[0]}) rel {rel(a, b):.2e}"
+            ex, frac = elementwise_excess(a, b)
+            worst_ex, worst_frac = max(worst_ex, ex), max(worst_frac, frac)
+    record_error(worst_ex, "elementwise: worst |a-b| / (1e-4 |b| + 1e-6 max|b|) over all factors")
+    record_error(worst_frac, "elementwise: worst fraction of a factor's entries above that allowance")
+    print(f"{what}: element-wise |a-b| <= 1e-4 |b| + 1e-6 max|b|: worst ratio {worst_ex:.2f}, worst fraction of entries above {worst_frac:.2e}")
+    if elementwise is not None:
+        assert worst_ex <= elementwise, f"{what}: element-wise excess {worst_ex:.2f}"
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -98,7 +119,7 @@ def test_c1_mlp_diag_kron_full_fit_against_the_oracle(c1):
         assert rel(l_, loss_kf) < TOL
     assert rel(loss_kf, loss_ref) < 1e-10
     # stored factors carry the scalar split of utils/matrix.py:100-118 on both sides alike
-    _assert_kfacs(kron, kf_ref, "c1")
+    _assert_kfacs(kron, kf_ref, "c1", elementwise=1.0)
     assert rel(kron.diag(), co.kron_diag(kf_ref)) < TOL
 
 
@@ -168,12 +189,12 @@ def test_c2_lenet5_kfac_factors_and_kron_predictive_against_the_oracle():
     loss, kron = b.kron(X.to(DEV), y.to(DEV), N=N)
     loss_ref, kf_ref = co.kfac_ggn(m64, X.double(), y, N, "classification")
     assert rel(loss, loss_ref) < TOL
-    _assert_kfacs(kron, kf_ref, "c2")
+    _assert_kfacs(kron, kf_ref, "c2", elementwise=1.0)
     # fused accumulator == literal call
     acc = b.kron_accumulator(N)
     acc.add_batch(X.to(DEV), y.to(DEV))
     _, kron2 = acc.finalize()
-    _assert_kfacs(kron2, kf_ref, "c2 fused")
+    _assert_kfacs(kron2, kf_ref, "c2 fused", elementwise=1.0)
     # Kron GLM predictive (Jacobian-free kernels) vs matrix.py:406-461 on the oracle's Jacobians and fp64 eigenpairs
     dec = kron.decompose()
     dec.check_converged()
@@ -257,8 +278,8 @@ def test_c4_resnet18_every_kfac_factor_and_kron_predictive_against_the_oracle(ac
     assert rel(loss, loss_ref) < TOL and rel(loss2, loss_ref) < TOL
     # ReLU: individual gradients may flip where a pre-activation sits within fp32 rounding of zero; the
     # factors — sums over 8 x 9 x L outer products — still agree to the bar
-    _assert_kfacs(kron, kf_ref, f"c4/{act}")
-    _assert_kfacs(kron2, kf_ref, f"c4/{act} fused")
+    _assert_kfacs(kron, kf_ref, f"c4/{act}", elementwise=1.0)  # (measured 0.10 ReLU, 0.42 tanh)
+    _assert_kfacs(kron2, kf_ref, f"c4/{act} fused", elementwise=1.0)
     # GLM predictive under this posterior: device eigendecomposition + Jacobian-free quadratic-form kernels vs the
     # oracle's Jacobians (host, fp64) pushed through matrix.py:406-461 with fp64 eigenpairs of the ORACLE's factors
     dec = kron.decompose()

@@ -71,7 +71,10 @@ def test_a_bounded_lead_of_the_host_bounds_the_reserved_memory(monkeypatch):
         del acc, H
     gib = 2.0 ** 30
     print(f"reserved by a 160-minibatch fit: lead 4: {out[4][0] / gib:.0f} GiB, unbounded: {out[0][0] / gib:.0f} GiB")
-    assert out[4][0] < 0.8 * out[0][0]  # (measured 42 against 68 GiB after 160 minibatches; the unbounded lead keeps growing to 160)
+    # an ABSOLUTE bound: what a lead of 4 reserves is (lead x lanes x one minibatch's buffers), the same on every box
+    # (42 - 45 GiB in five processes, profiles/r05_box_session_age.log); what the unbounded lead reserves depends on how far
+    # the host of that box gets ahead in 160 minibatches (68 - 160 GiB) — a ratio of the two passed or failed with the box
+    assert out[4][0] < 50 * gib, f"lead 4 reserved {out[4][0] / gib:.0f} GiB"
     assert torch.allclose(out[4][1], out[0][1], rtol=1e-6)
     for Fa, Fb in zip(out[4][2], out[0][2]):
         for a, b_ in zip(Fa, Fb):
