@@ -1074,6 +1074,12 @@ class KronAccumulator:
 
     #: ``False``: the A-side work of reading a fit waits for the lanes' reverse sweeps
     early_flush = True
+    #: the HOST waits for the lanes' streams before it enqueues the once-per-fit work.  The host runs up to `max_ahead`
+    #: minibatches per lane ahead of the device; enqueued at that moment, the flush streams' and the calling stream's waits sit
+    #: unsatisfied in their queues for ~60 ms beside the lanes' ~210 launches per minibatch — measured (tools/finalize_variants.py,
+    #: profiles/r06_finalize_variants.log): a 20-minibatch fit 7.34 ms per step that way, 6.91 with the host waiting first and
+    #: enqueueing onto a drained device (the finalize work itself is 7 ms either way).  ``False``: enqueue at once.
+    drain_before_fold = True
 
     def _fold_lanes(self):
         """bring the lanes' partial sums together on the calling stream (before anything reads the accumulated state).
@@ -1095,6 +1101,11 @@ class KronAccumulator:
         dev = subs[0]._lane_stream.device if on_device else None
         cur = torch.cuda.current_stream(dev) if on_device else None
         live = [sub for sub in subs if sub.factors is not None]
+        if on_device and self.drain_before_fold:
+            for sub in subs:
+                sub._lane_stream.synchronize()
+                if sub._side is not None:
+                    sub._side.synchronize()
         early = (on_device and self.overlap and self.early_flush and bool(live) and all(sub._a_done is not None for sub in live)
                  and any(sub._pix for sub in live))
         fstreams = None
