@@ -1259,7 +1259,10 @@ class KronAccumulator:
     #: enqueued `max_ahead` steps ago costs nothing (the device still has that many steps queued per lane: same 6.7 ms per
     #: step) and bounds the lead: 42 / 87 GiB reserved at 4 / 12 (`tools/session_age.py`, `profiles/r05_box_session_age.log`;
     #: on a box whose later processes ran a 400-step loop at 13 ms per step it also brought them back to 6.8 - 8.0).
-    max_ahead = 8
+    #: Round 6 measured the lead itself (300 steps, `tools/session_age.py`, profiles/r06_host_lead.log): 6.56 - 6.63 ms per
+    #: step at 1, 2 and 8 alike, 29 / 32 - 34 / 44 GiB reserved — two steps per lane keep every queue fed (the device works on
+    #: one, the next is already there) and that is all a lead is for.
+    max_ahead = 2
 
     def _throttle(self, stream):
         if not self.max_ahead or stream is None:
