@@ -27,6 +27,7 @@ from __future__ import annotations
 
 import collections
 import math
+import threading
 import os
 from collections.abc import MutableMapping
 
@@ -66,7 +67,10 @@ def shared_operands(tap, g, B, C, Q1=None, Q2=None, bounds=None):
                  and m.in_channels % 32 == 0 and Dk % 8 == 0)
         if (isinstance(g, SplitTensor) and Q1 is not None and bounds is not None and not tap.has_bias and _OWN_ROTATION and own_v
                 and getattr(K, "use_quad_planes", False) and Do % 32 == 0 and (g.shape[1] * g.shape[2]) % 16 == 0
-                and C <= K.quadform_shared_max_outputs):
+                and C <= K.quadform_shared_max_outputs
+                # (the planes kernel indexes u with 32 bits: a predictive batch beyond that takes the chunked fp32 route below
+                #  instead of failing behind both rotations)
+                and C * B * g.shape[1] * g.shape[2] * Do < (1 << 31)):
             # both rotations on our convolution kernel with SPLIT, position-contiguous outputs (lk_conv_nhwc_f16x2_planes):
             # u = Q1^T g seed-major [C * B, Do, L] with one scale, v = the unfolded inputs in Q2's basis [B, Dk, L] with one
             # scale per sample — what lk_kron_quadform_shared_planes_f16x2 stages without splitting anything
@@ -210,12 +214,17 @@ class _HipCurvatureMixin:
         if torch.is_tensor(x):
             return x.float() if x.is_floating_point() and x.dtype != torch.float32 else x
         if isinstance(x, (dict, MutableMapping)):  # dict-style inputs (HuggingFace BatchEncoding, UserDict): same container type
-            import copy
-
-            out = copy.copy(x)
-            for k in list(x.keys()):
-                out[k] = _HipCurvatureMixin._to32(x[k])
-            return out
+            # (a NEW container built from a plain dict: `copy.copy` of a mapping without `__copy__` shares its inner storage,
+            #  and assigning into the copy rewrote the caller's batch in place)
+            out = {k: _HipCurvatureMixin._to32(x[k]) for k in list(x.keys())}
+            if type(x) is dict:
+                return out
+            try:
+                return type(x)(out)
+            except Exception:
+                return out
+        if isinstance(x, tuple) and hasattr(x, "_fields"):  # namedtuple: positional constructor
+            return type(x)(*(_HipCurvatureMixin._to32(v) for v in x))
         if isinstance(x, (tuple, list)):
             return type(x)(_HipCurvatureMixin._to32(v) for v in x)
         return x
@@ -651,6 +660,7 @@ class CurvatureExchange(list):
 
 
 _PROCESS_STREAMS: dict = {}
+_PROCESS_STREAMS_LOCK = threading.Lock()  # (fits from different threads share the queues: work of both merely serialises)
 
 
 def _process_streams(key, make):
@@ -660,6 +670,11 @@ def _process_streams(key, make):
     `Laplace` object per epoch (marglik training) ran the device out of memory after two of them and the allocator into
     freeing and re-allocating every step (7 -> 49 ms).  Streams are only queues: accumulators that share them are ordered
     by the same waits / events as before, work of different fits on one stream merely serialises."""
+    with _PROCESS_STREAMS_LOCK:
+        return _process_streams_locked(key, make)
+
+
+def _process_streams_locked(key, make):
     hit = _PROCESS_STREAMS.get(key)
     if hit is None:
         hit = _PROCESS_STREAMS[key] = make()
@@ -733,6 +748,8 @@ class KronAccumulator:
         #: minibatch) and sweeps `coalesce_target` samples at a time; models whose minibatch fills the chip never stack.
         self.coalesce = os.environ.get("LK_COALESCE", "1") != "0"
         self._stash, self._stash_n = [], 0
+        self._dispatched = 0   # minibatches swept so far (the first one is never stacked)
+        self._act_numel = 0    # largest per-sample activation of this model, measured by the first forward pass
         #: minibatches in flight on the device (env LK_LANES): with 2, consecutive minibatches go alternately to two
         #: sub-accumulators, each with its own stream (and side stream) and its own factor buffers, summed when the fit
         #: is read — the forward pass of one minibatch (small grids at batch 128) then runs beside the reverse sweep of
@@ -1062,6 +1079,7 @@ class KronAccumulator:
         for t in (x, y):
             if torch.is_tensor(t) and t.is_cuda:
                 t.record_stream(st)
+        self._act_numel = max(self._act_numel, sub._act_numel)
         sub.max_ahead = self.max_ahead
         sub._throttle(st)
 
@@ -1213,16 +1231,28 @@ class KronAccumulator:
                 for t in sub._raw_tensors():  # allocated on the lane's stream, read (and from now on owned) here
                     t.record_stream(cur)
 
+    #: stacked sweeps hold at most this many activation floats (forward activations, masks and the seed-batched cotangents of
+    #: a sweep all scale with it): 2^28 floats = 1 GiB per fp32 copy
+    coalesce_act_floats = 1 << 28
+    #: ... and at most this many of the caller's minibatches: the batch size is the caller's memory knob
+    coalesce_max_batches = 32
+
     def coalesce_target(self, x) -> int:
         """samples per stacked sweep for minibatches shaped like ``x`` (0: this model / minibatch does not stack): work per
         sample grows with the parameter count; 2^27 parameter-samples per sweep keeps a sweep around a millisecond (LeNet-5:
-        eight loader batches of 256; ResNet-18 at batch 128: never)"""
+        eight loader batches of 256; ResNet-18 at batch 128: never).  Bounded by memory as well: by the largest per-sample
+        ACTIVATION the first (never stacked) minibatch's forward pass measured — a few-parameter convolutional model on large
+        images has small parameter and input counts and large maps —, by the input size, and by a multiple of the loader's
+        batch.  The fit's first minibatch is always swept alone: unsupported-model and shape errors surface on the first
+        `add_batch`, as they do without stacking."""
         b = self.backend
         if (not self.coalesce or not torch.is_tensor(x) or not x.is_floating_point() or x.dim() < 2
-                or getattr(b, "stochastic", False) or b.last_layer):
+                or getattr(b, "stochastic", False) or b.last_layer or not self._dispatched):
             return 0
         n_params = sum(p.numel() for p in b.params)
-        target = min(8192, (1 << 27) // max(n_params, 1), (1 << 24) // max(x[0].numel(), 1))
+        act = max(int(self._act_numel), x[0].numel(), 1)  # (per sample, times the seeds of its reverse sweep)
+        target = min(8192, (1 << 27) // max(n_params, 1), (1 << 24) // max(x[0].numel(), 1),
+                     int(self.coalesce_act_floats) // act, int(self.coalesce_max_batches) * x.shape[0])
         return target if target >= 2 * x.shape[0] else 0
 
     def _flush_stash(self):
@@ -1275,6 +1305,7 @@ class KronAccumulator:
 
     def _dispatch(self, x, y):
         b = self.backend
+        self._dispatched += 1
         if self.lanes > 1 and self.overlap and not self.defer_pix and torch.is_tensor(x) and (x.is_cuda or self._lanes_anywhere):
             return self._lane_add_batch(x, y)
         self._add_batch(x, y)
@@ -1288,6 +1319,10 @@ class KronAccumulator:
             raise NotImplementedError("KFAC supports nn.Linear / nn.Conv2d parameters only")
         if self.factors is None:
             self._alloc(tape, f.device)
+        if not self._act_numel:  # (what bounds a stacked sweep's memory: `coalesce_target`)
+            nb = max(int(f.shape[0]), 1)
+            acts = [int(t.a.numel()) // nb for t in tape.taps if torch.is_tensor(getattr(t, "a", None))]
+            self._act_numel = max(acts + [1]) * max(int(f.shape[-1]) - 1, 1)
         rt = math.sqrt(float(b.factor))
         if not self.defer_pix:
             self._ensure_pixgrams(tape)
@@ -1565,7 +1600,10 @@ class HipGGN(_HipCurvatureMixin, GGNInterface):
 
     def kron_accumulator(self, N: int, **kwargs) -> KronAccumulator:
         """Fused-accumulation form of :meth:`kron` for a whole fit (see :class:`KronAccumulator`)."""
-        return KronAccumulator(self, N, kwargs.get("kfac_approx", "expand"), kwargs.get("overlap", True))
+        acc = KronAccumulator(self, N, kwargs.get("kfac_approx", "expand"), kwargs.get("overlap", True))
+        if kwargs.get("coalesce") is not None:  # (``coalesce=False``: every minibatch is swept as it arrives)
+            acc.coalesce = bool(kwargs["coalesce"])
+        return acc
 
     # KFAC — replaces CurvlinopsInterface.kron (laplace/curvature/curvlinops.py:77-108)
     def kron(self, x, y, N, **kwargs):
@@ -1668,7 +1706,10 @@ class HipEF(_HipCurvatureMixin, EFInterface):
     _kron_seeds = _ef_seeds
 
     def kron_accumulator(self, N: int, **kwargs) -> KronAccumulator:
-        return KronAccumulator(self, N, kwargs.get("kfac_approx", "expand"))
+        acc = KronAccumulator(self, N, kwargs.get("kfac_approx", "expand"))
+        if kwargs.get("coalesce") is not None:
+            acc.coalesce = bool(kwargs["coalesce"])
+        return acc
 
     def kron(self, x, y, N, **kwargs):
         twin, dt = self._twin()

@@ -21,6 +21,8 @@ from __future__ import annotations
 import operator
 import os
 
+import weakref
+
 import torch
 import torch.fx as fx
 import torch.nn.functional as F
@@ -251,6 +253,20 @@ class SplitSweep(SeedBatchedSweep):
         finally:
             self._aux = {}  # (the split copies of the activations are only needed while the forward runs)
 
+    def _aux_put(self, t, entry):
+        """register what is known about the feature map ``t`` (keyed by address, OWNED by the tensor object: a map that was
+        freed — a materialised convolution output behind its BatchNorm launch — may hand its address to a later tensor that
+        registers nothing, which must not inherit a stale per-image bound: too small a bound saturates fp16 planes silently)"""
+        entry["_owner"] = weakref.ref(t)
+        self._aux[t.data_ptr()] = entry
+
+    def _aux_get(self, t):
+        entry = self._aux.get(t.data_ptr())
+        if entry is not None and entry["_owner"]() is not t:
+            del self._aux[t.data_ptr()]
+            return None
+        return entry
+
     def _fwd_word(self, dev, n=1):
         """``n`` zeroed device words out of a per-forward pool (one fill launch per pool)"""
         if self._fwd_words is None or self._fwd_words[1] + n > self._fwd_words[0].numel():
@@ -264,7 +280,7 @@ class SplitSweep(SeedBatchedSweep):
             and t.shape[0] > 0
 
     def _split_input(self, inp, pad_to=None):
-        aux = self._aux.get(inp.data_ptr())
+        aux = self._aux_get(inp)
         if aux is not None and "split" in aux and aux["split"] is not None and pad_to is None:
             return aux["split"]
         K = self.kernels()
@@ -295,7 +311,7 @@ class SplitSweep(SeedBatchedSweep):
             if xs.amax is not None:
                 # per-image bound of the output without a pass over it: measured max of the input image * l1(W) + max|bias|
                 l1, bmax = prep.forward_l1()
-                self._aux[y.data_ptr()] = {"in_amax": xs.amax, "mul": l1, "add": bmax}
+                self._aux_put(y, {"in_amax": xs.amax, "mul": l1, "add": bmax})
             return y
 
         if self._bn_takes_conv(node, m, xs):
@@ -330,7 +346,7 @@ class SplitSweep(SeedBatchedSweep):
                 a_h = a_bound = None
                 if addend is not None:
                     a_h = addend.permute(0, 2, 3, 1)
-                    a_aux = self._aux.get(addend.data_ptr())
+                    a_aux = self._aux_get(addend)
                     a_bound = a_aux["bound"] if a_aux is not None and "bound" in a_aux else K.absmax(a_h)
                 scale = scale.to(torch.float32).contiguous()
                 shift = shift.to(torch.float32).contiguous()
@@ -339,7 +355,7 @@ class SplitSweep(SeedBatchedSweep):
                     self._amax_of((node.target, "t"), shift), 1 if relu else 0, addend=a_h, addend_bound=a_bound,
                     want_mask=want_mask, amax_words=self._fwd_word(inp.device, inp.shape[0]))
                 out = y.permute(0, 3, 1, 2)
-                self._aux[out.data_ptr()] = {"split": split, "bound": split.amax if split is not None else bound}
+                self._aux_put(out, {"split": split, "bound": split.amax if split is not None else bound})
                 if mask is not None:
                     mask = mask.view(torch.bool).permute(0, 3, 1, 2)
                 return out, mask
@@ -347,7 +363,7 @@ class SplitSweep(SeedBatchedSweep):
         if not (self._use_nhwc_forward(inp) and K.is_channels_last(inp) and inp.shape[1] % 8 == 0
                 and (addend is None or K.is_channels_last(addend))):
             return super()._run_bn_act(node, inp, scale, shift, relu, addend, want_mask)
-        aux = self._aux.get(inp.data_ptr())
+        aux = self._aux_get(inp)
         xh = inp.permute(0, 2, 3, 1)
         x_mul = x_add = None
         if aux is not None and "in_amax" in aux:
@@ -357,7 +373,7 @@ class SplitSweep(SeedBatchedSweep):
         a_h = a_bound = None
         if addend is not None:
             a_h = addend.permute(0, 2, 3, 1)
-            a_aux = self._aux.get(addend.data_ptr())
+            a_aux = self._aux_get(addend)
             a_bound = a_aux["bound"] if a_aux is not None and "bound" in a_aux else K.absmax(a_h)
         scale = scale.to(torch.float32).contiguous()
         shift = shift.to(torch.float32).contiguous()
@@ -367,7 +383,7 @@ class SplitSweep(SeedBatchedSweep):
                                                       x_add=x_add, amax_words=self._fwd_word(inp.device, inp.shape[0]))
         out = y.permute(0, 3, 1, 2)
         # (the MEASURED per-image maxima are the bound a later residual join adds: tighter than the guaranteed one)
-        self._aux[out.data_ptr()] = {"split": split, "bound": split.amax if split is not None else bound}
+        self._aux_put(out, {"split": split, "bound": split.amax if split is not None else bound})
         if mask is not None:
             mask = mask.view(torch.bool).permute(0, 3, 1, 2)  # logical NCHW view of the NHWC mask bytes
         return out, mask

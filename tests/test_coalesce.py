@@ -47,7 +47,7 @@ def test_stacked_minibatches_give_the_unstacked_fit(lik):
     batches = [(X[i:i + 100], y[i:i + 100]) for i in range(0, 1000, 100)]
     l1, k1, s1 = _fit(model, lik, batches, 1000, True)
     l0, k0, s0 = _fit(model, lik, batches, 1000, False)
-    assert s0 == [100] * 10 and s1 == [1000]
+    assert s0 == [100] * 10 and s1 == [100, 900]  # (the fit's first minibatch is swept alone: errors surface on the first call)
     assert rel(l1, l0) < 1e-6
     for F1, F0 in zip(k1.kfacs, k0.kfacs):
         for a, b in zip(F1, F0):
@@ -67,13 +67,19 @@ def test_ragged_and_changing_minibatches_and_the_target():
     batches = [mk(16, 8), mk(16, 8), mk(5, 8), mk(16, 6), mk(16, 6)]
     l1, k1, s1 = _fit(model, "classification", batches, 69, True)
     l0, k0, s0 = _fit(model, "classification", batches, 69, False)
-    assert s0 == [16, 16, 5, 16, 16] and s1 == [37, 32]
+    assert s0 == [16, 16, 5, 16, 16] and s1 == [16, 21, 32]
     assert rel(l1, l0) < 1e-6
     for F1, F0 in zip(k1.kfacs, k0.kfacs):
         for a, b in zip(F1, F0):
             assert rel(a, b) < 1e-5
     acc = HipGGN(model, "classification").kron_accumulator(69)
-    assert acc.coalesce_target(batches[0][0]) == 8192 and acc.coalesce_target(torch.randn(5000, 3, 8, 8)) == 0
+    assert acc.coalesce_target(batches[0][0]) == 0  # (nothing swept yet)
+    acc._dispatched = 1
+    assert acc.coalesce_target(batches[0][0]) == 32 * 16 and acc.coalesce_target(torch.randn(5000, 3, 8, 8)) == 0  # (at most 32 loader batches)
+    # a few-parameter model on large maps: the measured per-sample activation (times the seeds of its sweep) bounds the stack
+    acc._act_numel = 3 * 8 * 256 * 256
+    assert acc.coalesce_target(torch.randn(16, 3, 8, 8)) == (1 << 28) // (3 * 8 * 256 * 256)
+    assert HipGGN(model, "classification").kron_accumulator(69, coalesce=False).coalesce is False
     from laplace_amd.nets import ResNet18
 
     big = HipGGN(ResNet18(10), "classification").kron_accumulator(50000)
