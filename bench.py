@@ -646,7 +646,7 @@ def main():
             "config": {"workload": "c4: ResNet-18 (CIFAR stem, BN frozen) full-network KFAC exact GGN fit, "
                                    "per-GPU minibatch 128, synthetic N(0,1) 3x32x32, 10 classes, N=50000",
                        "per_gpu_batch": BATCH, "parallelism": f"dp{world}",
-                       "minibatches_in_flight": int(os.environ.get("LK_LANES", "2"))},
+                       "minibatches_in_flight": int(__import__("laplace_amd.backend", fromlist=["KronAccumulator"]).KronAccumulator.default_lanes)},
             "roofline": roof,  # the family with the largest share of the WHOLE step (measured without stream overlap)
             "roofline_families": fam_out,
             "whole_step": whole_step,

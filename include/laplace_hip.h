@@ -546,6 +546,17 @@ size_t lk_dense_quadform_ll_workspace_bytes(int64_t B, int64_t C, int64_t D);
 int lk_dense_quadform_ll_f32(const float* phi, const float* Sigma, int64_t B, int64_t C, int64_t D, int has_bias,
                              float* fvar, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- the fit's one collective (replaces nothing in the reference, which has no multi-GPU fit: the loop of
+ * laplace/baselaplace.py:969-985 sharded over ranks needs ONE sum of the accumulated factors at epoch end) -------------------
+ * Thin wrappers over RCCL (ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce(ncclFloat, ncclSum, in place)),
+ * bound by dlopen at the first call, for hosts that are not PyTorch; the Python host of this repository uses
+ * torch.distributed's "nccl" backend (the same RCCL) and the packed upper-triangle buffer of `KronAccumulator.tensors()`.
+ * `id128`: 128 bytes (ncclUniqueId) made on rank 0 and handed to the other ranks by the host's own means. */
+int lk_comm_unique_id(void* id128);
+int lk_comm_init_rank(void** comm, int nranks, const void* id128, int rank);
+int lk_comm_destroy(void* comm);
+int lk_allreduce_sum_f32(void* comm, float* buf, int64_t count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,6 +35,10 @@ _u32 = ctypes.c_uint
 SIGNATURES = {
     "lk_version": (_int, []),
     "lk_last_error": (ctypes.c_char_p, []),
+    "lk_comm_unique_id": (_int, [_vp]),
+    "lk_comm_init_rank": (_int, [ctypes.POINTER(ctypes.c_void_p), _int, _vp, _int]),
+    "lk_comm_destroy": (_int, [_vp]),
+    "lk_allreduce_sum_f32": (_int, [_vp, _vp, _i64, _vp]),
     "lk_loss_workspace_bytes": (_sz, [_i64]),
     "lk_softmax_hess_sqrt_f32": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     "lk_softmax_hess_chol_f32": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),
@@ -221,7 +225,7 @@ class HipKernels:
     """Tensor-level wrappers; every method enqueues on torch's current stream and returns at once."""
 
     name = "hip"
-    conv_config = int(os.environ.get("LK_CONV_CONFIG", "2"))  # lk_conv_nhwc_f16x2: bit 0 = 64-deep K chunks, bit 1 = never use the patch form (default: measured faster inside
+    conv_config = 2  # lk_conv_nhwc_f16x2: bit 0 = 64-deep K chunks, bit 1 = never use the patch form (default: measured faster inside
     # the step, 12.2 vs 13.0 ms), bit 2 = 16-deep chunks in four LDS stages
     softmax_chol_max_c = 2000  # LK_SOFTMAX_CHOL_MAX_C (include/laplace_hip.h): wider outputs use the symmetric root
 

@@ -270,10 +270,11 @@ class _HipCurvatureMixin:
         return (f.detach().contiguous(), tape,
                 lambda seeds, stack=True, f_graph=f: tape.output_grads(f_graph, seeds, stack=stack))
 
-    #: ``False`` forces the autograd tape (one reverse pass per seed); env LK_SWEEP=0 does the same.
-    use_sweep = os.environ.get("LK_SWEEP", "1") != "0"
-    #: ``False`` (env LK_SPLIT_SWEEP=0) keeps the reverse sweep on NCHW fp32 cotangents and the library's backward-data
-    use_split_sweep = os.environ.get("LK_SPLIT_SWEEP", "1") != "0"
+    #: ``False`` forces the autograd tape (one reverse pass per seed).  (Path selectors are plain attributes — of the class
+    #: for a process-wide default, of an object for one backend; nothing here reads the environment.)
+    use_sweep = True
+    #: ``False`` keeps the reverse sweep on NCHW fp32 cotangents and the library's backward-data
+    use_split_sweep = True
     #: largest batch (seeds x samples) of one reverse sweep and the memory its cotangents may take (4 live tensors of
     #: the largest activation are assumed); more seeds are processed in chunks
     sweep_max_rows = 8192
@@ -700,8 +701,8 @@ class KronAccumulator:
     """
 
     # ---- path selectors (class attributes; an instance may override them before its first minibatch; each is exercised
-    #      against the default path by tests/test_gpu_switches.py).  Environment switches are kept only for what a USER
-    #      chooses per run: LK_LANES, LK_COALESCE (here), LK_SWEEP / LK_SPLIT_SWEEP (backend), LK_LIB, LK_CONV_CONFIG (_lib).
+    #      against the default path by tests/test_gpu_switches.py).  The one environment variable the package reads is
+    #      LK_LIB (_lib.py: which build of the shared library to load — A/B builds of a development session).
     #: ``False``: A factors of 3x3 / stride-1 convolutions per minibatch instead of through the pixel-pair accumulators
     use_pixgram = True
     #: ``False``: the BatchNorm scale of a shortcut branch is applied to every minibatch's cotangent instead of once per fit
@@ -739,22 +740,22 @@ class KronAccumulator:
         self.defer_pix = False
         self._pix_inputs = {}  # tap index -> list of (geometry, alpha, NHWC fp32 tensor [B, H, W, C], module)
         self._pix_early = set()  # taps whose pixel-pair blocks were folded into this accumulator's A factor mid-fit
-        #: ``True`` (env LK_COALESCE=0 turns it off): consecutive SMALL minibatches of a small model are stacked and swept
+        #: ``True`` (`default_coalesce`, or `kron_accumulator(N, coalesce=False)`): consecutive SMALL minibatches of a small model are stacked and swept
         #: together.  The curvature is a sum over samples with per-sample terms that do not depend on the minibatch they
         #: arrive in (curvlinops.py:77-108: G sums over samples, A carries 1/N with the GLOBAL N), so minibatch boundaries
         #: are the caller's choice, not part of the result — and a 151-parameter MLP at batch 100 (BASELINE config c1) is
         #: ~50 launches of a few microseconds each per minibatch, i.e. bound by the host's enqueue rate, not by the device
         #: ("batch into one launch").  Stacking keeps copies of the inputs (2 small launches per
         #: minibatch) and sweeps `coalesce_target` samples at a time; models whose minibatch fills the chip never stack.
-        self.coalesce = os.environ.get("LK_COALESCE", "1") != "0"
+        self.coalesce = bool(type(self).default_coalesce)
         self._stash, self._stash_n = [], 0
         self._dispatched = 0   # minibatches swept so far (the first one is never stacked)
         self._act_numel = 0    # largest per-sample activation of this model, measured by the first forward pass
-        #: minibatches in flight on the device (env LK_LANES): with 2, consecutive minibatches go alternately to two
+        #: minibatches in flight on the device (`default_lanes`): with 2, consecutive minibatches go alternately to two
         #: sub-accumulators, each with its own stream (and side stream) and its own factor buffers, summed when the fit
         #: is read — the forward pass of one minibatch (small grids at batch 128) then runs beside the reverse sweep of
         #: the one before it.  The sum over minibatches is linear: same factors up to the order of fp32 additions.
-        self.lanes = max(1, int(os.environ.get("LK_LANES", "2")))
+        self.lanes = max(1, int(type(self).default_lanes))
         self._lane_accs, self._lane_next, self._lane_id, self._lane_stream = None, 0, 0, None
         self._lane_sig = None
         self._ahead = collections.deque()  # events behind the minibatches the host has enqueued and not waited for (`max_ahead`)
@@ -1231,6 +1232,9 @@ class KronAccumulator:
                 for t in sub._raw_tensors():  # allocated on the lane's stream, read (and from now on owned) here
                     t.record_stream(cur)
 
+    #: class-level defaults of the per-accumulator attributes `coalesce` / `lanes`
+    default_coalesce = True
+    default_lanes = 2
     #: stacked sweeps hold at most this many activation floats (forward activations, masks and the seed-batched cotangents of
     #: a sweep all scale with it): 2^28 floats = 1 GiB per fp32 copy
     coalesce_act_floats = 1 << 28

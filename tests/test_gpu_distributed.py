@@ -102,3 +102,29 @@ def test_two_ranks_on_the_real_kernels_equal_the_single_process_fit(tmp_path):
     for ls0, ls1 in zip(got[0]["l"], got[1]["l"]):
         for l0, l1 in zip(ls0, ls1):
             assert torch.equal(l0, l1)
+
+
+def test_the_c_abi_collective_on_a_one_rank_communicator():
+    """lk_comm_unique_id / lk_comm_init_rank / lk_allreduce_sum_f32 / lk_comm_destroy (include/laplace_hip.h: RCCL bound by
+    dlopen, for hosts that are not PyTorch): a world of ONE rank sums to itself — the binding, the argument order and the
+    stream ordering; RCCL refuses two ranks on one device, and the box has one."""
+    import ctypes
+
+    from laplace_amd._lib import load_library
+
+    lib = load_library()
+    uid = ctypes.create_string_buffer(128)
+    assert lib.lk_comm_unique_id(uid) == 0, lib.lk_last_error()
+    comm = ctypes.c_void_p()
+    assert lib.lk_comm_init_rank(ctypes.byref(comm), 1, uid, 0) == 0, lib.lk_last_error()
+    try:
+        x = torch.randn(1 << 20, device="cuda")
+        want = x.clone()
+        st = torch.cuda.current_stream()
+        assert lib.lk_allreduce_sum_f32(comm, x.data_ptr(), x.numel(), st.cuda_stream) == 0, lib.lk_last_error()
+        torch.cuda.synchronize()
+        assert torch.equal(x, want)
+        assert lib.lk_allreduce_sum_f32(comm, None, 0, st.cuda_stream) == 0
+        assert lib.lk_allreduce_sum_f32(None, x.data_ptr(), 4, st.cuda_stream) < 0 and b"bad arguments" in lib.lk_last_error()
+    finally:
+        assert lib.lk_comm_destroy(comm) == 0

@@ -1,5 +1,5 @@
 """Every path selector of the product (class / instance attributes; the case names are the environment switches most of
-them were up to round 4 — round 5 kept LK_LANES, LK_COALESCE, LK_SWEEP, LK_SPLIT_SWEEP, LK_LIB, LK_CONV_CONFIG as switches) gives
+them were up to round 4 — round 6 keeps LK_LIB alone) gives
 the same curvature and the same predictive as the default path: a c4-shaped KFAC fit (ResNet-18, two minibatches of 16,
 one of 5) + Kron GLM predictive with ONE selector flipped at a time, against the default run.  A switch nobody tests is a
 code path nobody knows to work (-m gpu)."""
@@ -81,8 +81,8 @@ def default(setup):
 
 CASES = {
     # env switch                          what is flipped
-    "LK_SWEEP=0": dict(backend_attrs={"use_sweep": False}),
-    "LK_SPLIT_SWEEP=0": dict(backend_attrs={"use_split_sweep": False}),
+    "use_sweep False": dict(backend_attrs={"use_sweep": False}),
+    "use_split_sweep False": dict(backend_attrs={"use_split_sweep": False}),
     "LK_LAZY_KRON=0 (literal loop)": dict(backend_attrs={"lazy_kron": False}, literal=True),
     "LK_LAZY_KRON=1 (literal loop)": dict(literal=True),
     "LK_PIXGRAM=0": dict(acc_attrs={"use_pixgram": False}),
@@ -95,8 +95,8 @@ CASES = {
     "LK_FUSE_STRIDED=0": dict(sweep_attrs={"fuse_strided": False}),
     "copies + a separate absmax pass": dict(kernel_attrs={"use_copy_absmax": False}),
     "overlap=False": dict(acc_attrs={"overlap": False}),
-    "LK_LANES=1": dict(acc_attrs={"lanes": 1}),
-    "LK_LANES=3": dict(acc_attrs={"lanes": 3}),
+    "lanes 1": dict(acc_attrs={"lanes": 1}),
+    "lanes 3": dict(acc_attrs={"lanes": 3}),
     "LK_FLUSH_STREAMS=1": dict(acc_attrs={"flush_streams": 1}),
     "LK_FLUSH_STREAMS=5": dict(acc_attrs={"flush_streams": 5}),
     "LK_FUSE_VJP=0": dict(sweep_attrs={"fuse_vjp": False}),
@@ -105,10 +105,10 @@ CASES = {
     "LK_SHIFTCORR=0": dict(kernel_attrs={"use_shiftcorr": False}, acc_attrs={"use_pixgram": False}),
     "fp32-operand quadratic form": dict(kernel_attrs={"use_quad_planes": False}),
     "LK_WINP=0 (generic fused launches)": dict(kernel_attrs={"use_winp": False}),
-    "LK_CONV_CONFIG plain row order": dict(kernel_attrs={"conv_config": 2 | 32768}),
-    "LK_CONV_CONFIG round-4 window staging": dict(kernel_attrs={"conv_config": 2 | (1 << 30)}),
-    "LK_CONV_CONFIG two columns per XCD": dict(kernel_attrs={"conv_config": 2 | (1 << 28)}),
-    "LK_CONV_CONFIG eight columns per XCD": dict(kernel_attrs={"conv_config": 2 | (3 << 28)}),
+    "conv_config plain row order": dict(kernel_attrs={"conv_config": 2 | 32768}),
+    "conv_config round-4 window staging": dict(kernel_attrs={"conv_config": 2 | (1 << 30)}),
+    "conv_config two columns per XCD": dict(kernel_attrs={"conv_config": 2 | (1 << 28)}),
+    "conv_config eight columns per XCD": dict(kernel_attrs={"conv_config": 2 | (3 << 28)}),
     "lane_priority=0": dict(acc_attrs={"lane_priority": 0}),
 }
 

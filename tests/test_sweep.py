@@ -18,7 +18,9 @@ from oracle.fixtures import FIXTURES, build_model, input_shape
 def _one_sweep_per_minibatch(monkeypatch):
     """these tests look at the accumulator's state minibatch by minibatch (lanes, pixel-pair groups, deferred scales) on
     models small enough for `KronAccumulator.coalesce` to stack their minibatches (tests/test_coalesce.py): off here"""
-    monkeypatch.setenv("LK_COALESCE", "0")
+    from laplace_amd.backend import KronAccumulator
+
+    monkeypatch.setattr(KronAccumulator, "default_coalesce", False)
 
 
 class Residual(nn.Module):

@@ -16,7 +16,7 @@ g = K.split_f16x2((torch.randn(N, H, H, Co, device=dev) * 1e-3).contiguous())
 add = K.split_f16x2((torch.randn(N, H, H, Ci, device=dev) * 1e-2).contiguous())
 mask = (torch.rand(N // 9, H, H, Ci, device=dev) > 0.5).to(torch.uint8)
 prep = cv.PreparedConv(m)
-K.conv_config = int(os.environ.get("LK_CONV_CONFIG", "2"))
+K.conv_config = int(sys.argv[6]) if len(sys.argv) > 6 else 2
 for _ in range(3):
     cv.conv_backward_data_vjp(prep, g, (H, H), add=add, mult=mask)
 torch.cuda.synchronize()
