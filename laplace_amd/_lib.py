@@ -142,16 +142,30 @@ class SplitTensor:
     ``sexp``: int32 ``[1]`` — one scale for the tensor (the reverse sweep's cotangents) — or ``[N]``, one per image of the
     leading dimension (the forward's activations: lk_split_images_f16x2, lk_bn_act_fwd_nhwc_f16x2)."""
 
-    __slots__ = ("planes", "sexp", "amax")
+    __slots__ = ("planes", "sexp", "amax", "chunked")
 
-    def __init__(self, planes: torch.Tensor, sexp: torch.Tensor, amax: torch.Tensor | None = None):
+    def __init__(self, planes: torch.Tensor, sexp: torch.Tensor, amax: torch.Tensor | None = None, chunked: bool = False):
         #: ``amax``: device word(s) with the MEASURED max|x| (per scale entry) when the producer provides them (fused
         #: convolution epilogue, per-image forward); consumers that need a bound otherwise use 2**(15 - sexp)
-        self.planes, self.sexp, self.amax = planes, sexp, amax
+        #: ``chunked``: the planes of a position-contiguous ``[N, D, L]`` tensor stored CHUNK-major, ``planes [2, N, L / 16, D, 16]``
+        #: (lk_conv_nhwc_f16x2_planes -> lk_kron_quadform_shared_planes_f16x2: a staged block of 16 positions x 32 rows is one
+        #: contiguous kilobyte); ``shape`` and ``float()`` stay the logical ``[N, D, L]``
+        self.planes, self.sexp, self.amax, self.chunked = planes, sexp, amax, bool(chunked)
 
     @property
     def shape(self):
+        if self.chunked:
+            _, N, nch, D, w = self.planes.shape
+            return torch.Size((N, D, nch * w))
         return self.planes.shape[1:]
+
+    def chunk_major(self) -> "SplitTensor":
+        """the same ``[N, D, L]`` tensor with chunk-major planes (a copy unless it already is; ``L % 16 == 0``)"""
+        if self.chunked:
+            return self
+        _, N, D, L = self.planes.shape
+        pl = self.planes.view(2, N, D, L // 16, 16).permute(0, 1, 3, 2, 4).contiguous()
+        return SplitTensor(pl, self.sexp, self.amax, chunked=True)
 
     @property
     def per_image(self) -> bool:
@@ -160,9 +174,13 @@ class SplitTensor:
     def float(self) -> torch.Tensor:
         """fp32 reconstruction (tests / fallbacks)"""
         s = self.sexp.float()
+        pl = self.planes
+        if self.chunked:
+            _, N, nch, D, w = pl.shape
+            pl = pl.permute(0, 1, 3, 2, 4).reshape(2, N, D, nch * w)
         if s.numel() > 1:
-            s = s.reshape(-1, *([1] * (self.planes.dim() - 2)))
-        return (self.planes[0].float() + self.planes[1].float()) * torch.exp2(-s)
+            s = s.reshape(-1, *([1] * (pl.dim() - 2)))
+        return (pl[0].float() + pl[1].float()) * torch.exp2(-s)
 
 
 def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
@@ -515,8 +533,8 @@ class HipKernels:
         N, Hi, Wi, Ci = x.planes.shape[1:]
         Co = wplanes.shape[2]
         dev = x.planes.device
-        assert wplanes.shape[3] == Ci and (Ho * Wo) % 4 == 0
-        planes = torch.empty((2, N, Co, Ho * Wo), dtype=torch.float16, device=dev)
+        assert wplanes.shape[3] == Ci and (Ho * Wo) % 16 == 0
+        planes = torch.empty((2, N, (Ho * Wo) // 16, Co, 16), dtype=torch.float16, device=dev)  # chunk-major (SplitTensor.chunked)
         sexp = torch.empty(x.sexp.numel(), dtype=torch.int32, device=dev)
         flat = (ctypes.c_int * (3 * len(taps)))(*[int(v) for t in taps for v in t])
         cfg = self.conv_config if config is None else config
@@ -526,7 +544,7 @@ class HipKernels:
             _ptr(x.planes[0]), _ptr(x.planes[1]), _ptr(x.sexp), x.sexp.numel(), _ptr(amax), N, Hi, Wi, Ci, _ptr(wplanes[0]),
             _ptr(wplanes[1]), _ptr(wsexp), _ptr(w_l1), Co, Ho, Wo, in_mul, len(taps), flat, _ptr(self._zero16(dev)),
             _ptr(planes[0]), _ptr(planes[1]), _ptr(sexp), int(cfg), self._stream(dev))), "lk_conv_nhwc_f16x2_planes")
-        return SplitTensor(planes, sexp)
+        return SplitTensor(planes, sexp, chunked=True)
 
     #: ``False``: the forward's convolutions and their BatchNorm / add / ReLU stay two launches (lk_conv_nhwc_f16x2 +
     #: lk_bn_act_fwd_nhwc_f16x2) instead of one (lk_conv_bn_act_nhwc_f16x2); the results are the same to the bit
@@ -1303,6 +1321,7 @@ class HipKernels:
         B, Dk = v.shape[0], v.shape[1]
         if CB != C * B or v.shape[2] != L or L % 16 or Do % 32:
             raise LaplaceHipError("kron_quadform_shared_planes: u [C * B, Do, L], v [B, Dk, L], L % 16 == 0, Do % 32 == 0")
+        u, v = u.chunk_major(), v.chunk_major()  # (what the rotation convolutions emit; a copy for operands split elsewhere)
         ws = self._workspace(self.lib.lk_quadform_shared_workspace_bytes(B, C, Do, Dk), fvar.device)
         # (its own profile tag: three fp16 MFMAs per product block — bench.py prices the fp32-operand forms, six bf16 MFMAs, apart)
         self._rc(self._timed("quadconv16", 2.0 * B * C * L * Do * Dk, fvar.device, lambda: self.lib.lk_kron_quadform_shared_planes_f16x2(

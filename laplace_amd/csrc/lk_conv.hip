@@ -823,11 +823,14 @@ __global__ __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::WP
               if (col < g.Co) {
                 const uint2 keep = lh ? __builtin_bit_cast(uint2, l4) : __builtin_bit_cast(uint2, h4);
                 const u32x4 out8 = lh ? u32x4{got.x, got.y, keep.x, keep.y} : u32x4{keep.x, keep.y, got.x, got.y};
-                const int64_t e = ((int64_t)n * g.Co + col) * HW + (pix - 4 * lh);  // (the run starts at the lh == 0 lane's pixel)
+                // (planes are CHUNK-major, [n][pixel / 16][co][16]: the quadratic-form kernel stages 16 positions of 32 rows per
+                //  request — one contiguous kilobyte this way, 32 pieces of 32 bytes at stride 2 HW from [n][co][pixel])
+                const int p0 = pix - 4 * lh;  // (the run starts at the lh == 0 lane's pixel)
+                const int64_t e = (((int64_t)n * (HW >> 4) + (p0 >> 4)) * g.Co + col) * 16 + (p0 & 15);
                 *reinterpret_cast<u32x4*>((lh ? fz.out_l : fz.out_h) + e) = out8;
               }
             } else if (col < g.Co) {
-              const int64_t e = ((int64_t)n * g.Co + col) * HW + pix;
+              const int64_t e = (((int64_t)n * (HW >> 4) + (pix >> 4)) * g.Co + col) * 16 + (pix & 15);
               *reinterpret_cast<f16x4*>(fz.out_h + e) = h4;
               *reinterpret_cast<f16x4*>(fz.out_l + e) = l4;
             }
@@ -2247,6 +2250,7 @@ extern "C" int lk_conv_nhwc_f16x2_planes(const void* in_h, const void* in_l, con
                                          int64_t Wo, int64_t in_mul, int64_t T, const int* taps, const void* zero16,
                                          void* out_h, void* out_l, int* out_sexp, int config, void* stream) {
   LK_REQUIRE(w_l1 && out_h && out_l && out_sexp, "lk_conv_nhwc_f16x2_planes: null pointer");
+  LK_REQUIRE((Ho * Wo) % 16 == 0, "lk_conv_nhwc_f16x2_planes: Ho * Wo % 16 == 0 (the planes are written in chunks of 16 positions)");
   ConvVjp fz{};
   fz.in_amax = (const unsigned*)in_amax, fz.w_l1 = w_l1;
   fz.out_h = (_Float16*)out_h, fz.out_l = (_Float16*)out_l, fz.out_sexp = out_sexp;

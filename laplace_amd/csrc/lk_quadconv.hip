@@ -334,8 +334,13 @@ __global__ __launch_bounds__(256) void quadform_conv_kernel(const float* __restr
 // under.  Here the operands ARRIVE split — two fp16 planes each, position-contiguous, written that way by the epilogue of
 // the rotation convolutions that produce them (lk_conv_nhwc_f16x2_planes: u = Q1^T g as a 1x1 convolution over the split
 // cotangent, v = the unfolded activations in the A factor's eigenbasis) — so a chunk is 8-byte copies into LDS (A), two
-// 16-byte loads (B) and CT x three v_mfma_f32_32x32x16_f16.  u: [C][B][Do][L] halfs (seed-major) with ONE scale, v: [B][Dk][L]
-// with one scale per sample (v_nsexp = B) or one for the tensor; L % 16 == 0 (whole chunks), Do % 32 == 0.
+// 16-byte loads (B) and CT x three v_mfma_f32_32x32x16_f16.  u: [C][B] images (seed-major) with ONE scale, v: [B] images with
+// one scale per sample (v_nsexp = B) or one for the tensor; L % 16 == 0 (whole chunks), Do % 32 == 0.  An image is
+// CHUNK-major, [L / 16][rows][16 positions] (round 6): a request — 16 positions of 32 rows — is one contiguous kilobyte.  From
+// the position-contiguous [rows][L] of round 5 it was 32 pieces of 32 bytes 2 L bytes apart: every piece its own cache line, of
+// which the next three chunks use the rest only if it is still cached — the 64-channel layers (L = 1024, operands of 640 MB per
+// layer) ran at 62 TFLOP/s against 190 at L = 64, four times the compulsory bytes from HBM (profiles/r06_quad_layers.log).
+typedef float qf32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void qc_lds_void;
 typedef __attribute__((address_space(1))) const void qc_gbl_void;
 
@@ -393,9 +398,9 @@ __global__ __launch_bounds__(256) void quadform_conv_planes_kernel(
     __syncthreads();
   }
 
-  float pair[NP];
+  qf32x2 pair2[NP];  // (two-wide running pair sums: see the tile epilogue)
 #pragma unroll
-  for (int p = 0; p < NP; ++p) pair[p] = 0.f;
+  for (int p = 0; p < NP; ++p) pair2[p] = qf32x2{0.f, 0.f};
   const int my_tiles = sp < ntiles ? (ntiles - sp + split - 1) / split : 0;
   const int Q = my_tiles * NCH;  // chunks of this workgroup's walk
 
@@ -405,7 +410,7 @@ __global__ __launch_bounds__(256) void quadform_conv_planes_kernel(
     const int t = sp + p_kt * split;
     const int o0 = (t % nOt) * 32, icol = (t / nOt) * 128 + wave * 32 + lo, l0 = p_ch * QC_KC;
     const unsigned base = lds0 + p_stage * CFG::STAGE;
-    const unsigned a_lane = (unsigned)((o0 + (lane >> 1)) * L + l0 + 8 * (lane & 1));
+    const unsigned a_lane = (unsigned)(((p_ch * Do + o0 + (lane >> 1)) << 4) + 8 * (lane & 1));
 #pragma unroll
     for (int j = 0; j < CFG::NA; ++j) {
       int a = j * 4 + wave;                 // (scalar) instruction index = piece * CT + output
@@ -414,7 +419,7 @@ __global__ __launch_bounds__(256) void quadform_conv_planes_kernel(
       const _Float16* src = (c < C ? (piece ? uln : uhn) + (unsigned)(c * cs) + a_lane : zero16);
       __builtin_amdgcn_global_load_lds((qc_gbl_void*)src, (qc_lds_void*)(uintptr_t)(base + a * 1024), 16, 0, 0);
     }
-    const unsigned b_lane = (unsigned)(icol * L + l0 + 8 * hi);
+    const unsigned b_lane = (unsigned)(((p_ch * Dk + icol) << 4) + 8 * hi);
 #pragma unroll
     for (int piece = 0; piece < 2; ++piece) {
       const _Float16* src = icol < Dk ? (piece ? vln : vhn) + b_lane : zero16;
@@ -473,35 +478,44 @@ __global__ __launch_bounds__(256) void quadform_conv_planes_kernel(
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    // weights of this lane's 16 (o, i) positions and the pair sums, four accumulator rows at a time
+    // weights of this lane's 16 (o, i) positions and the pair sums, four accumulator rows at a time.  At 512 channels a tile is
+    // ONE chunk (L = 16) and this block — 55 pair sums x 16 positions per lane — is most of the kernel: those launches ran at
+    // 1.7 ms where the 64-channel ones (64 chunks per tile) take 0.43 (profiles/r06_pmc_quad_launches.log: 8 x the
+    // instructions).  Written on PAIRS of positions (v_pk_mul_f32 / v_pk_fma_f32: two products per instruction) with two-wide
+    // running sums: 2 instructions per (pair, four positions) instead of the 6 of `(s0 a0 + s1 a1) + (s2 a2 + s3 a3)`.
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
-      float wgt[4], a[CT][4];
+      qf32x2 wgt[2], a[CT][2];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int oo = o0 + j + 8 * rg + 4 * hi;
         const bool ok = oo < Do && icol < Dk;
         const float d = (w_in_lds ? ldsw[ok ? oo : 0] * ldsw[Do + (ok ? icol : 0)] : w0[ok ? oo : 0] * w1[ok ? icol : 0]) + dlt;
-        wgt[j] = ok ? __builtin_amdgcn_rcpf(d) : 0.f;
+        wgt[j >> 1][j & 1] = ok ? __builtin_amdgcn_rcpf(d) : 0.f;
       }
 #pragma unroll
       for (int c = 0; c < CT; ++c)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) a[c][j] = (acc[c][4 * rg + j] * un_u) * un_v;
+        for (int h = 0; h < 2; ++h) {
+          const qf32x2 r = {acc[c][4 * rg + 2 * h], acc[c][4 * rg + 2 * h + 1]};
+          a[c][h] = (r * un_u) * un_v;
+        }
       int p = 0;
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
-        float sc[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) sc[j] = a[c][j] * wgt[j];
+        const qf32x2 s0 = a[c][0] * wgt[0], s1 = a[c][1] * wgt[1];
 #pragma unroll
         for (int k = c; k < CT; ++k) {
-          pair[p] += (sc[0] * a[k][0] + sc[1] * a[k][1]) + (sc[2] * a[k][2] + sc[3] * a[k][3]);
+          pair2[p] = __builtin_elementwise_fma(s0, a[k][0], pair2[p]);
+          pair2[p] = __builtin_elementwise_fma(s1, a[k][1], pair2[p]);
           ++p;
         }
       }
     }
   }
+  float pair[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) pair[p] = pair2[p][0] + pair2[p][1];
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
     const float s = wave_sum(pair[p]);
@@ -596,6 +610,9 @@ static int qc_class_tile(int64_t C) {
 static int qc_split(int64_t B, int64_t Do, int64_t Dk) {
   const int64_t ntiles = ((Do + 31) / 32) * ((Dk + 127) / 128);
   int64_t want = (2048 + B - 1) / B;
+#ifdef LK_QC_MIN_SPLIT
+  if (want < LK_QC_MIN_SPLIT) want = LK_QC_MIN_SPLIT;
+#endif
   if (want < 1) want = 1;
   return (int)(want < ntiles ? want : ntiles);
 }

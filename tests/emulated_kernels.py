@@ -158,7 +158,7 @@ class EmulatedKernels:
         rs = res * torch.exp2(s.float()).reshape(-1, 1, 1)
         h = rs.half()
         l = (rs - h.float()).half()
-        return SplitTensor(torch.stack([h, l]), s)
+        return SplitTensor(torch.stack([h, l]), s).chunk_major()  # (the layout the HIP kernel writes)
 
     def conv_winp_eligible(self, N, Hi, Wi, Ci, Co, T, mask_is_float=False) -> bool:
         # (mirrors lk_conv_winp_eligible, so that the host logic around the chunk-major weights is exercised on the CPU)
