@@ -1244,9 +1244,14 @@ __device__ __forceinline__ int swz2(int row) { return (row >> 3) & 1; }  // two 
 // against exactly those: TWO four-wave workgroups per CU stay for the whole launch and walk through pixel tiles tile,
 // tile + G, ...; the stream of K steps runs across tile boundaries (the next tile's first window and weights are requested
 // during the current tile's last chunk and land under its epilogue); the window is waited for only where it is read; and
-// the second workgroup of a CU starts half a tile late, so that one workgroup's epilogue (memory) runs beside the other's
-// K loop (matrix pipe) for the whole launch.  (A one-workgroup form with the epilogue interleaved into the next tile's K
-// steps was built first: two accumulator sets do not fit 256 registers, and hipcc spilled the second one.)
+// the two workgroups of a CU drift into different phases, so that one's epilogue (memory) runs beside the other's K loop
+// (matrix pipe).  (A one-workgroup form with the epilogue interleaved into the next tile's K steps was built first: two
+// accumulator sets do not fit 256 registers, and hipcc spilled the second one; an eight-wave workgroup on a 512-pixel tile
+// with the epilogue in the open — WinPCfg<512>, config bit 26 — halves the weight requests per MFMA and is 5 - 30 % SLOWER.)
+// Round 6 (profiles/r06_winp_study.md): the K loop is one explicit instruction stream (`step`); what the launch is bound by
+// is the chip's power budget — back to back these launches hold the socket at 1.28 - 1.40 kW of 1.4 and the clock at 1.78 -
+// 1.85 of 2.4 GHz (profiles/r06_power_kernels.log); with only its MFMAs left (no requests, reads, waits) the same launch
+// takes 77 % of its time.
 // Output channels = 64 (the 64-channel layers: the HBM-bound ones); nine taps in raster order (the host sorts them), weight
 // slice of tap t = wt0 + t * wtstep; multipliers: none or a byte mask.
 template <int BM_, int WPE_ = 2>
@@ -1269,7 +1274,7 @@ struct WinPCfg {
 };
 
 struct WinPArgs {  // (a slim argument block: everything here stays in scalar registers for the whole launch)
-  int M, Hi, Wi, Ci, Co, HW, n_tiles, nb_m, wt0, wtstep, stagger, ablate, halo_all, coloc;
+  int M, Hi, Wi, Ci, Co, HW, n_tiles, nb_m, wt0, wtstep, stagger, halo_all, coloc;
   FastDiv div_hw, div_w, div_mask;
   const _Float16 *Ah, *Al, *Wh, *Wl;
   const int *a_sexp, *w_sexp, *add_sexp;
@@ -1352,8 +1357,8 @@ void conv_winp_f16x2_kernel(const WinPArgs p) {
   int desc = 0, next_desc = 0, kc1 = KC, next_kc0 = 0;
   int m0, n0;
   if (!item(tile, m0, n0, desc)) return;  // (uniform)
-#ifdef LK_WINP_ABLATE  // development switches, compile-time (a run-time switch perturbs this kernel's schedule beyond
-  constexpr int ablate = LK_WINP_ABLATE;  // comparison): 1 skip the epilogue, 2 the MFMAs, 4 the in-loop staging
+#ifdef LK_WINP_ABLATE  // development switch, compile-time: 1 skip the epilogue (timing only).  (Round 6's finer ablations — no
+  constexpr int ablate = LK_WINP_ABLATE;  // MFMAs / requests / waits / fragment reads / barriers — lived in the round-5 form of `step`)
 #else
   constexpr int ablate = 0;
 #endif
@@ -2109,7 +2114,6 @@ static bool launch_winp(const ConvGeom& g, const void* Ah, const void* Al, const
   // second workgroup at the start — 0 is 2 - 4 % faster on every c4 shape
   p.stagger = 0;
   if ((config >> 20) & 31) p.stagger = ((config >> 20) & 31) - 1;  // (development: bits 20-24 = delay + 1)
-  p.ablate = 0;
   p.halo_all = (config >> 30) & 1;  // (development: stage the whole PP-pixel window as round 4 did)
   p.coloc = 1;
   p.out_h = fz->out_h, p.out_l = fz->out_l, p.out_sexp = fz->out_sexp;
