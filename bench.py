@@ -423,7 +423,8 @@ def pmc_traffic(kernel_prefix: str, kernel_suffix: str = "", table: str = "bench
         newest = newest or os.path.basename(path)
         if meta.get("csrc_sha16") != want:
             continue
-        rows = [v for k, v in tab.items() if k != "_meta" and k.startswith(kernel_prefix) and k.endswith(kernel_suffix)]
+        rows = [v for k, v in tab.items() if k != "_meta" and (k.startswith(kernel_prefix) or k.startswith("void " + kernel_prefix))
+                and k.endswith(kernel_suffix)]
         launches = sum(r["launches"] for r in rows)
         if not launches:
             return None, f"profiles/{os.path.basename(path)}: no launch of this family in the PMC pass"
