@@ -37,8 +37,9 @@ for Co, Ci, H, N in cases:  # conv Ci -> Co; backward-data: cotangent [N, H, H, 
     gf = 2.0 * N * H * H * Co * Ci * 9 / 1e9
     K.conv_config = 2 | WP
     ref = cv.conv_backward_data_vjp(prep, g, (H, H), add=add, mult=mask)
-    variants = [("generic", 2 | WP), ("persistent", 2), ("split", 2 | (1 << 25))]
-    variants += [("stagger%d" % k, 2 | ((k + 1) << 20)) for k in (3,)] + [("persistent", 2)]
+    variants = [("generic", 2 | WP), ("persistent", 2), ("split", 2 | (1 << 25)), ("wide512", 2 | (1 << 26))]
+    variants += [("stagger%d" % k, 2 | ((k + 1) << 20)) for k in (3,)]
+    variants += [("coloc%d" % (1 << k), 2 | (k << 28)) for k in (1, 2, 3)] + [("persistent", 2)]  # (bits 28-29: log2 of the columns per XCD; 0 = default)
     for name, cfg in variants:  # (bit 27 switches the persistent form OFF)
         K.conv_config = cfg
         out = cv.conv_backward_data_vjp(prep, g, (H, H), add=add, mult=mask)
