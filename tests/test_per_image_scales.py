@@ -165,3 +165,24 @@ def test_strided_branches_of_unequal_width_do_not_fuse():
     with pytest.raises(LaplaceHipError, match="same shapes"):
         K.conv_nhwc_f16x2_vjp_strided([(ga, *pa.backward_planes(), pa.backward_l1()), (gb, *pb.backward_planes(), pb.backward_l1())],
                                       8, 8, 2, [(0, 0, 0, 0, 0, 0)])
+
+
+def test_chunk_major_planes_are_the_same_tensor():
+    """`SplitTensor.chunked` (what lk_conv_nhwc_f16x2_planes writes and lk_kron_quadform_shared_planes_f16x2 stages: planes
+    `[2, N, L / 16, D, 16]`): the logical `[N, D, L]` shape, `float()` and a second `chunk_major()` do not depend on the storage
+    order."""
+    import torch
+
+    from laplace_amd._lib import SplitTensor
+
+    torch.manual_seed(3)
+    N, D, L = 3, 5, 48
+    planes = torch.randn(2, N, D, L).half()
+    sexp = torch.tensor([2, -1, 7], dtype=torch.int32)
+    plain = SplitTensor(planes, sexp)
+    ch = plain.chunk_major()
+    assert ch.chunked and tuple(ch.planes.shape) == (2, N, L // 16, D, 16) and tuple(ch.shape) == (N, D, L)
+    assert ch.chunk_major() is ch and ch.per_image
+    assert torch.equal(ch.float(), plain.float())
+    # element (n, d, l) lives at [n, l // 16, d, l % 16]
+    assert ch.planes[1, 2, 1, 4, 3] == planes[1, 2, 4, 19]
