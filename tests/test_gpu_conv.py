@@ -306,10 +306,13 @@ def test_persistent_window_form_of_the_fused_launch(cin, cout, H, n_img):
             fused = cv.conv_backward_data_vjp(prep, gs, (H, H), **kw)
             K.conv_config = 2 | (1 << 25)  # (bit 25: the last round's leftover tiles in K slices, summed through slabs in slice order)
             split = cv.conv_backward_data_vjp(prep, gs, (H, H), **kw)
+            K.conv_config = 2 | (1 << 26)  # (bit 26: one eight-wave workgroup per CU on 512-pixel tiles)
+            wide = cv.conv_backward_data_vjp(prep, gs, (H, H), **kw)
             K.conv_config = 2 | (1 << 27)  # (bit 27: the persistent form off)
             ref = cv.conv_backward_data_vjp(prep, gs, (H, H), **kw)
             assert torch.equal(fused.sexp, ref.sexp) and rel(fused.float(), ref.float()) < 4e-6, sorted(kw)  # (other order of the K steps)
             assert torch.equal(split.sexp, ref.sexp) and rel(split.float(), ref.float()) < 4e-6, sorted(kw)
+            assert torch.equal(wide.sexp, ref.sexp) and rel(wide.float(), ref.float()) < 4e-6, sorted(kw)
             assert abs(split.amax.item() - split.float().abs().max().item()) <= 1e-5 * split.amax.item()
             assert abs(fused.amax.item() - fused.float().abs().max().item()) <= 1e-5 * fused.amax.item()
             if want_b is not None:
