@@ -603,6 +603,8 @@ def main():
                           "product block); priced on its algorithmic bytes, 2 x blocks + input", "hbm", "lk::gram16_kernel", ",1>"),
             "gram_conv": ("lk::gram_kernel<MODE_CONV> (+ slab reduce): implicit-im2col A-factor accumulation, "
                           "exact-fp32 MFMA", "mfma", "void lk::gram_kernel<2,"),
+            "im2col16": ("lk::im2col_split_f16x2_kernel: the patch matrix of the strided / stem convolutions as split planes (its Gram — "
+                         "their A factor — then runs on lk::gram16_kernel, counted under gram16)", "hbm", "lk::im2col_split_f16x2_kernel"),
             "shiftcorr": ("lk_conv3x3_shiftcorr_f32: shift-correlation A factors", "mfma", "void lk::gram_kernel<3,"),
             "gram_tn": ("lk::gram_kernel<MODE_TN>: Linear-layer factors", "mfma", "void lk::gram_kernel<0,"),
         }

@@ -193,6 +193,15 @@ int lk_split_f16x2(const float* x, int64_t n, const float* amax, float bound_mul
  * amax[n] (bit pattern of a float: the measured maximum the next producer derives its bound from).  per % 8 == 0. */
 int lk_split_images_f16x2(const float* x, int64_t N, int64_t per, void* planes_h, void* planes_l, int* sexp, unsigned* amax,
                           void* stream);
+
+/* Patch matrix of a convolution (the rows F.unfold produces, laplace/curvature/curvlinops.py:55-75: the A factor of a Conv2d is the
+ * Gram of its unfolded inputs) as split planes with ONE scale: x [B][H][W][C] fp32 NHWC -> planes [B * Ho * Wo][Kp], column
+ * k = (kh * KW + kw) * C + c (the kernels' native order), zero outside the image and for k >= KH * KW * C (Kp: 64 or a multiple of 128,
+ * what lk_gram_tn_f16x2 takes), scale from amax[0] = max|x|.  lk_gram_tn_f16x2 on the result is the A factor of a strided or stem
+ * convolution on the fp16 matrix cores at fp32 level (2.6 x faster than lk_gram_conv_nhwc_f32's exact-fp32 MFMA on the c4 layers). */
+int lk_im2col_split_f16x2(const float* x, int64_t B, int64_t H, int64_t W, int64_t C, int64_t KH, int64_t KW, int64_t stride,
+                          int64_t pad, int64_t Ho, int64_t Wo, int64_t Kp, const float* amax, void* planes_h, void* planes_l,
+                          int* sexp, void* stream);
 /* W[Co][Ci][taps] (* cscale[co], e.g. a folded BatchNorm scale) -> planes[2][taps][N][K] fp16 + sexp;
  * transpose = 1 (backward-data): n = ci, k = co; 0 (forward): n = co, k = ci.  amax_ws: one device word. */
 int lk_conv_prep_weights_f16x2(const float* W, int64_t Co, int64_t Ci, int64_t taps, int transpose, const float* cscale,

@@ -35,6 +35,7 @@ _u32 = ctypes.c_uint
 SIGNATURES = {
     "lk_version": (_int, []),
     "lk_last_error": (ctypes.c_char_p, []),
+    "lk_im2col_split_f16x2": (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "lk_comm_unique_id": (_int, [_vp]),
     "lk_comm_init_rank": (_int, [ctypes.POINTER(ctypes.c_void_p), _int, _vp, _int]),
     "lk_comm_destroy": (_int, [_vp]),
@@ -449,6 +450,31 @@ class HipKernels:
         sexp = torch.empty(1, dtype=torch.int32, device=x.device)
         self._rc(self.lib.lk_split_f16x2(_ptr(x), x.numel(), _ptr(amax), float(bound_mul), _ptr(planes[0]), _ptr(planes[1]),
                                          _ptr(sexp), self._stream(x.device)), "lk_split_f16x2")
+        return SplitTensor(planes, sexp)
+
+    #: ``False``: the A factors of strided / stem convolutions stay on the exact-fp32 MFMA kernel (lk_gram_conv_nhwc_f32)
+    use_gram_conv16 = True
+
+    def im2col_split(self, x, kernel_size, stride, padding, Kp, amax=None):
+        """lk_im2col_split_f16x2: the patch matrix of a convolution over ``x`` (logical ``[B, C, H, W]`` over NHWC memory, fp32) as a
+        :class:`SplitTensor` ``[B * Ho * Wo, Kp]`` with one scale — columns in the kernels' native order ``(kh, kw, ci)``, zero
+        padded to ``Kp`` columns"""
+        if x.dim() != 4:
+            raise LaplaceHipError("im2col_split: a [B, C, H, W] tensor")
+        if not self.is_channels_last(x):
+            _check(x, "x")
+        B, C, H, W = x.shape
+        xh = self.nchw_to_nhwc(x)  # (a view when x is NHWC in memory already)
+        (KH, KW), s, p = kernel_size, int(stride), int(padding)
+        Ho, Wo = (H + 2 * p - KH) // s + 1, (W + 2 * p - KW) // s + 1
+        if amax is None:
+            amax = self.absmax(xh)
+        rows = B * Ho * Wo
+        planes = torch.empty((2, rows, Kp), dtype=torch.float16, device=x.device)
+        sexp = torch.empty(1, dtype=torch.int32, device=x.device)
+        self._rc(self._timed("im2col16", 4.0 * xh.numel() + 4.0 * rows * Kp, x.device, lambda: self.lib.lk_im2col_split_f16x2(
+            _ptr(xh), B, H, W, C, KH, KW, s, p, Ho, Wo, int(Kp), _ptr(amax), _ptr(planes[0]), _ptr(planes[1]), _ptr(sexp),
+            self._stream(x.device))), "lk_im2col_split_f16x2")
         return SplitTensor(planes, sexp)
 
     def split_images_f16x2(self, x):

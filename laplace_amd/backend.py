@@ -472,7 +472,25 @@ class _HipCurvatureMixin:
                 K.gram_tn(a.reshape(a.shape[0], L, Di).mean(1).contiguous(), alpha_a_scale / N, A, upper_only=fused)
             return A
         if kfac_approx == "expand":
-            K.gram_conv(keep_layout(a), m.kernel_size, m.stride, m.padding, m.dilation, alpha_a_scale / (N * L), A,
+            ak = keep_layout(a)
+            n = A.shape[0]
+            if (fused and getattr(K, "use_gram_conv16", False) and hasattr(K, "im2col_split") and m.kernel_size[0] * m.kernel_size[1] > 1
+                    and tuple(m.dilation) == (1, 1) and m.stride[0] == m.stride[1] and m.padding[0] == m.padding[1]
+                    and m.groups == 1 and isinstance(m.padding[0], int) and ak.is_cuda == A.is_cuda
+                    and (n + 127) // 128 * 128 <= 4096 and ak.shape[0] * L * ((n + 127) // 128 * 128) < (1 << 33)):  # (the Gram engine's widest matrix)
+                # the patch matrix as split planes (one pass: im2col + split), then the split-fp16 Gram engine — the strided and
+                # stem convolutions of c4 took 170 - 190 us each on the exact-fp32 MFMA kernel, 67 - 70 + the pass this way.
+                # The engine takes 64 or a multiple of 128 columns: other widths are zero padded and the block copied out.
+                Kp = n if (n == 64 or n % 128 == 0) else (64 if n < 64 else (n + 127) // 128 * 128)
+                pm = K.im2col_split(ak, m.kernel_size, m.stride[0], m.padding[0], Kp)
+                if Kp == n:
+                    K.gram_tn_f16x2(pm, alpha_a_scale / (N * L), A)
+                else:
+                    Ap = torch.zeros(Kp, Kp, dtype=torch.float32, device=A.device)
+                    K.gram_tn_f16x2(pm, alpha_a_scale / (N * L), Ap)
+                    A += Ap[:n, :n]  # (upper tiles of the padded Gram; the lower triangle of A is mirrored once per fit)
+                return A
+            K.gram_conv(ak, m.kernel_size, m.stride, m.padding, m.dilation, alpha_a_scale / (N * L), A,
                         upper_only=fused, native=fused)
         else:
             cols = torch.nn.functional.unfold(a, m.kernel_size, dilation=m.dilation, padding=m.padding, stride=m.stride)

@@ -163,6 +163,62 @@ __global__ __launch_bounds__(256) void split_f16x2_kernel(const float* __restric
   }
 }
 
+// ---- patch matrix of a convolution as split planes: x [B][H][W][C] fp32 -> [B Ho Wo][Kp] x (h, l), ONE scale ------------------
+// Row (b, oh, ow), column k = (kh kw) C + c of the unfolded input (the kernels' native column order, taps outermost), zero for the
+// taps outside the image and for the padding columns k >= KH KW C up to Kp (the split Gram engine takes 64 or a multiple of 128
+// columns).  What the A factors of the strided and stem convolutions are the Gram of: round 6 moved them from the exact-fp32
+// MFMA kernel (lk_gram_conv_nhwc_f32: 170 - 190 us per c4 layer on the pipe that is 16 x slower) onto lk_gram_tn_f16x2 (67 - 70 us)
+// behind this pass (profiles/r06_gramconv16_bench.log).  A thread = 8 consecutive columns of one row.
+struct Im2colGeom {
+  int B, H, W, C, KH, KW, stride, pad, Ho, Wo, Kp, n;
+  FastDiv div_wo, div_howo, div_c, div_kw, div_k8;
+};
+__global__ __launch_bounds__(256) void im2col_split_f16x2_kernel(const float* __restrict__ x, const Im2colGeom g,
+                                                                 const float* __restrict__ amax, _Float16* __restrict__ ph,
+                                                                 _Float16* __restrict__ pl, int* __restrict__ sexp, int64_t total8) {
+  const int s = scale_exp_for(amax[0]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) sexp[0] = s;
+  const float sc = exp2i(s);
+  const int k8n = g.Kp >> 3;
+  const bool vec = (g.C & 7) == 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += (int64_t)gridDim.x * 256) {
+    const int row = (int)fdiv((int)i, g.div_k8), k0 = ((int)i - row * k8n) * 8;  // (total8 < 2^31: checked by the host)
+    const int b = fdiv(row, g.div_howo), rem = row - b * g.Ho * g.Wo, oh = fdiv(rem, g.div_wo), ow = rem - oh * g.Wo;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    if (vec) {  // the 8 columns are 8 channels of ONE tap
+      if (k0 < g.n) {
+        const int t = fdiv(k0, g.div_c), c = k0 - t * g.C, dy = fdiv(t, g.div_kw), dx = t - dy * g.KW;
+        const int ih = oh * g.stride + dy - g.pad, iw = ow * g.stride + dx - g.pad;
+        if (ih >= 0 && ih < g.H && iw >= 0 && iw < g.W) {
+          const float4* src = reinterpret_cast<const float4*>(x + (((int64_t)b * g.H + ih) * g.W + iw) * g.C + c);
+          const float4 a = src[0], bb = src[1];
+          v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = bb.x, v[5] = bb.y, v[6] = bb.z, v[7] = bb.w;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = k0 + j;
+        if (k >= g.n) continue;
+        const int t = fdiv(k, g.div_c), c = k - t * g.C, dy = fdiv(t, g.div_kw), dx = t - dy * g.KW;
+        const int ih = oh * g.stride + dy - g.pad, iw = ow * g.stride + dx - g.pad;
+        if (ih >= 0 && ih < g.H && iw >= 0 && iw < g.W) v[j] = x[(((int64_t)b * g.H + ih) * g.W + iw) * g.C + c];
+      }
+    }
+    f16x8 h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      _Float16 hh, ll;
+      split2(v[j], sc, hh, ll);
+      h[j] = hh, l[j] = ll;
+    }
+    reinterpret_cast<f16x8*>(ph)[i] = h;
+    reinterpret_cast<f16x8*>(pl)[i] = l;
+  }
+}
+
 // ---- the same with ONE SCALE PER IMAGE (leading dimension): x [N][per] -> planes, sexp[N], amax[N] --------------------------
 // The forward activations of a minibatch are split image by image: a ReLU network is positively homogeneous, so the
 // activations of an image follow ITS magnitude through every layer, and a mask decided on values resolved only to 2^-39 of
@@ -1932,6 +1988,31 @@ extern "C" int lk_split_f16x2(const float* x, int64_t n, const float* amax, floa
   hipLaunchKernelGGL(split_f16x2_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n / 8, amax,
                      bound_mul, (_Float16*)planes_h, (_Float16*)planes_l, sexp);
   return check_launch("split_f16x2_kernel");
+}
+
+// Patch matrix of a convolution as split planes (see im2col_split_f16x2_kernel): planes [B * Ho * Wo][Kp] with one scale from
+// amax[0] = max|x| (every entry of the matrix is an entry of x or zero).  Kp % 8 == 0, Kp >= KH * KW * C.
+extern "C" int lk_im2col_split_f16x2(const float* x, int64_t B, int64_t H, int64_t W, int64_t C, int64_t KH, int64_t KW,
+                                     int64_t stride, int64_t pad, int64_t Ho, int64_t Wo, int64_t Kp, const float* amax,
+                                     void* planes_h, void* planes_l, int* sexp, void* stream) {
+  LK_REQUIRE(x && amax && planes_h && planes_l && sexp && B >= 0 && H >= 1 && W >= 1 && C >= 1 && KH >= 1 && KW >= 1 && stride >= 1 &&
+                 pad >= 0 && Ho >= 1 && Wo >= 1 && Kp % 8 == 0 && Kp >= KH * KW * C,
+             "lk_im2col_split_f16x2: bad arguments (Kp % 8 == 0, Kp >= KH * KW * C)");
+  LK_REQUIRE((Ho - 1) * stride - pad < H && (Wo - 1) * stride - pad < W, "lk_im2col_split_f16x2: output grid outside the input");
+  const int64_t rows = B * Ho * Wo, total8 = rows * (Kp / 8);
+  LK_REQUIRE(total8 < (1ll << 31) && B * H * W * C < (1ll << 40), "lk_im2col_split_f16x2: too large");
+  LK_REQUIRE(C % 8 != 0 || (reinterpret_cast<uintptr_t>(x) & 15) == 0, "lk_im2col_split_f16x2: x must be 16-byte aligned");
+  if (total8 == 0) return LK_OK;
+  Im2colGeom g;
+  g.B = (int)B, g.H = (int)H, g.W = (int)W, g.C = (int)C, g.KH = (int)KH, g.KW = (int)KW, g.stride = (int)stride, g.pad = (int)pad;
+  g.Ho = (int)Ho, g.Wo = (int)Wo, g.Kp = (int)Kp, g.n = (int)(KH * KW * C);
+  g.div_wo = make_fastdiv((int)Wo), g.div_howo = make_fastdiv((int)(Ho * Wo)), g.div_c = make_fastdiv((int)C);
+  g.div_kw = make_fastdiv((int)KW), g.div_k8 = make_fastdiv((int)(Kp / 8));
+  int64_t blocks = (total8 + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(im2col_split_f16x2_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, g, amax,
+                     (_Float16*)planes_h, (_Float16*)planes_l, sexp, total8);
+  return check_launch("im2col_split_f16x2_kernel");
 }
 
 // x [N][per] fp32 -> planes with ONE SCALE PER IMAGE: sexp[n] from the image's own max|x|, which is also left in amax[n]

@@ -360,6 +360,21 @@ class EmulatedKernels:
         out += alpha * slabs[: n * n * 8].view(torch.float64).view(n, n).to(out.dtype)
         return out
 
+    use_gram_conv16 = True
+
+    def im2col_split(self, x, kernel_size, stride, padding, Kp, amax=None):
+        """lk_im2col_split_f16x2: patch matrix [B * Ho * Wo, Kp] in (kh, kw, ci) column order, zero padded, one scale"""
+        import torch.nn.functional as F_
+
+        B, C = x.shape[0], x.shape[1]
+        KH, KW = kernel_size
+        cols = F_.unfold(x.float().contiguous(), kernel_size, 1, int(padding), int(stride))  # [B, C KH KW, L] in (ci, kh, kw) order
+        L = cols.shape[2]
+        cols = cols.reshape(B, C, KH * KW, L).permute(0, 3, 2, 1).reshape(B * L, KH * KW * C)
+        if Kp > cols.shape[1]:
+            cols = torch.cat([cols, cols.new_zeros(cols.shape[0], Kp - cols.shape[1])], 1)
+        return self.split_f16x2(cols.contiguous(), amax=amax if amax is not None else self.absmax(x))
+
     def gram_conv(self, x, kernel_size, stride, padding, dilation, alpha, out, upper_only=False, native=False):
         cols = F.unfold(x, kernel_size, dilation=dilation, padding=padding, stride=stride)  # [B, D, L]
         G = alpha * torch.einsum("bil,bjl->ij", cols, cols)

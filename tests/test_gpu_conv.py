@@ -407,3 +407,40 @@ def test_absmax_vector_and_scalar_forms(n, where):
         assert float(K.absmax(y[:n])[0]) == 77.5  # (a leading slice of a 1-D tensor is contiguous and keeps the alignment)
         tail = y[1:]  # data pointer 4 bytes past a 16-byte boundary: the scalar form
         assert float(K.absmax(tail)[0]) == float(tail.abs().max())
+
+
+IM2COL_CASES = [(64, 32, 3, 2, 1, 6), (128, 16, 3, 2, 1, 5), (256, 8, 3, 2, 1, 9), (3, 32, 3, 1, 1, 4), (64, 32, 1, 2, 0, 3), (24, 10, 3, 1, 0, 2),
+                (16, 9, 5, 2, 2, 3)]
+
+
+@pytest.mark.parametrize("cin,H,k,s,p,B", IM2COL_CASES, ids=[f"c{c[0]}-{c[1]}x{c[1]}-k{c[2]}s{c[3]}p{c[4]}-b{c[5]}" for c in IM2COL_CASES])
+def test_patch_matrix_as_split_planes_and_its_gram(cin, H, k, s, p, B):
+    """lk_im2col_split_f16x2 (the unfolded inputs of a convolution as split planes, native column order, zero padded) against
+    F.unfold in fp64, and lk_gram_tn_f16x2 on it against the exact-fp32 MFMA kernel it replaces for the A factors of strided / stem
+    convolutions (lk_gram_conv_nhwc_f32) and against the fp64 Gram (curvlinops.py:55-75: A = sum of patch outer products)."""
+    from laplace_amd._lib import get_kernels, keep_layout
+
+    K = get_kernels()
+    torch.manual_seed(cin + H + k)
+    x = (torch.randn(B, cin, H, H, device=DEV).relu_() * 3.0).contiguous(memory_format=torch.channels_last)
+    n = cin * k * k
+    Kp = n if (n == 64 or n % 128 == 0) else (64 if n < 64 else (n + 127) // 128 * 128)
+    pm = K.im2col_split(keep_layout(x), (k, k), s, p, Kp)
+    cols = F.unfold(x.double().cpu().contiguous(), k, 1, p, s)                    # [B, cin k k, L], (ci, kh, kw)
+    L = cols.shape[2]
+    want = cols.reshape(B, cin, k * k, L).permute(0, 3, 2, 1).reshape(B * L, n)   # rows (b, oh, ow), columns (kh, kw, ci)
+    got = pm.float().double().cpu()
+    assert tuple(got.shape) == (B * L, Kp) and not pm.per_image
+    assert rel(got[:, :n], want) < 1e-6 and float(got[:, n:].abs().max() if Kp > n else 0.0) == 0.0
+    top = got.abs().max() * 2.0 ** float(pm.sexp.item())
+    assert 2.0 ** 13 < top < 2.0 ** 15   # the scale puts the largest entry under 2^15
+    A16 = torch.zeros(Kp, Kp, device=DEV)
+    K.gram_tn_f16x2(pm, 0.25, A16)
+    G = 0.25 * (want.T @ want)
+    blk = torch.arange(Kp) // 32
+    upper = (blk[:, None] <= blk[None, :])[:n, :n]
+    assert rel(A16.double().cpu()[:n, :n] * upper, G * upper) < 2e-6
+    A32 = torch.zeros(n, n, device=DEV)
+    K.gram_conv(keep_layout(x), (k, k), (s, s), (p, p), (1, 1), 0.25, A32, upper_only=True, native=True)
+    tri = torch.triu(torch.ones(n, n, dtype=torch.bool))
+    assert rel(A16.double().cpu()[:n, :n] * tri, A32.double().cpu() * tri) < 2e-6

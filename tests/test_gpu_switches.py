@@ -104,6 +104,7 @@ CASES = {
     "LK_PIXPAIR16=0": dict(kernel_attrs={"use_pixpair16": False}),
     "LK_SHIFTCORR=0": dict(kernel_attrs={"use_shiftcorr": False}, acc_attrs={"use_pixgram": False}),
     "fp32-operand quadratic form": dict(kernel_attrs={"use_quad_planes": False}),
+    "A factors of strided / stem convolutions on the exact-fp32 MFMA kernel": dict(kernel_attrs={"use_gram_conv16": False}),
     "LK_WINP=0 (generic fused launches)": dict(kernel_attrs={"use_winp": False}),
     "conv_config plain row order": dict(kernel_attrs={"conv_config": 2 | 32768}),
     "conv_config round-4 window staging": dict(kernel_attrs={"conv_config": 2 | (1 << 30)}),
