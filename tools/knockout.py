@@ -33,7 +33,8 @@ def run():
 
 
 cases = [("nothing", []), ("G factors (gram_split)", ["gram_tn_f16x2"]), ("pixel-pair products", ["pixpair_accumulate_split"]),
-         ("fp32-MFMA A factors (gram_conv)", ["gram_conv"]), ("all three", ["gram_tn_f16x2", "pixpair_accumulate_split", "gram_conv"]),
+         ("fp32-MFMA A factors (gram_conv)", ["gram_conv"]), ("copies into the pixel-pair stacks (copy_absmax)", ["copy_absmax"]),
+         ("patch matrices + their Grams (im2col_split)", ["im2col_split"]), ("all three", ["gram_tn_f16x2", "pixpair_accumulate_split", "gram_conv"]),
          ("nothing", [])]
 base = None
 for name, names in cases:
