@@ -351,9 +351,9 @@ typedef __attribute__((address_space(1))) const void qc_gbl_void;
 // bytes, 4.7 ms at the CU's ~12 B / clock ingest rate, were the bound).  A stage: A = [piece][output][32 rows][16 k] (one
 // wave-instruction = one (piece, output): 32 rows x 32 bytes = a lane-linear kilobyte), B = [wave][piece][lane] (a lane's
 // own 8 positions of its column).  The stream of chunks runs across tiles; the pair sums of a tile touch registers only.
-template <int CT>
+template <int CT, int OCC = 1>
 struct QcPlanesCfg {
-  static constexpr int NS = CT <= 5 ? 6 : 4;                 // ring stages
+  static constexpr int NS = OCC == 2 ? 2 : (CT <= 5 ? 6 : 4);                 // ring stages
   static constexpr int A_BYTES = 2 * CT * 1024, B_BYTES = 4 * 2 * 1024, STAGE = A_BYTES + B_BYTES;
   static constexpr int NA = (2 * CT + 3) / 4;                // A instructions per wave and chunk (padded: a repeat)
   static constexpr int LD = NA + 2;                          // LDS-DMA instructions per wave and chunk
@@ -361,13 +361,13 @@ struct QcPlanesCfg {
   static_assert(LD * (NS - 2) <= 63, "vmcnt is a 6-bit counter");
 };
 
-template <int CT>
-__global__ __launch_bounds__(256) void quadform_conv_planes_kernel(
+template <int CT, int OCC = 1>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void quadform_conv_planes_kernel(
     const _Float16* __restrict__ uh, const _Float16* __restrict__ ul, const int* __restrict__ u_sexp,
     const _Float16* __restrict__ vh, const _Float16* __restrict__ vl, const int* __restrict__ v_sexp, int v_nsexp,
     const float* __restrict__ w0, const float* __restrict__ w1, const float* __restrict__ delta, int B, int C, int Do, int Dk,
     int L, int split, float* __restrict__ partial, const _Float16* __restrict__ zero16, int w_in_lds) {
-  using CFG = QcPlanesCfg<CT>;
+  using CFG = QcPlanesCfg<CT, OCC>;
   constexpr int NP = CT * (CT + 1) / 2, NS = CFG::NS;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   __shared__ float sR[4][NP];
@@ -398,9 +398,12 @@ __global__ __launch_bounds__(256) void quadform_conv_planes_kernel(
     __syncthreads();
   }
 
-  qf32x2 pair2[NP];  // (two-wide running pair sums: see the tile epilogue)
+  qf32x2 pair2[OCC == 2 ? 1 : NP];  // (two-wide running pair sums: see the tile epilogue)
+  float pair1[OCC == 2 ? NP : 1];
 #pragma unroll
-  for (int p = 0; p < NP; ++p) pair2[p] = qf32x2{0.f, 0.f};
+  for (int p = 0; p < (OCC == 2 ? 1 : NP); ++p) pair2[p] = qf32x2{0.f, 0.f};
+#pragma unroll
+  for (int p = 0; p < (OCC == 2 ? NP : 1); ++p) pair1[p] = 0.f;
   const int my_tiles = sp < ntiles ? (ntiles - sp + split - 1) / split : 0;
   const int Q = my_tiles * NCH;  // chunks of this workgroup's walk
 
@@ -408,7 +411,7 @@ __global__ __launch_bounds__(256) void quadform_conv_planes_kernel(
   int p_kt = 0, p_ch = 0, p_stage = 0;  // next chunk to request
   auto request = [&]() {
     const int t = sp + p_kt * split;
-    const int o0 = (t % nOt) * 32, icol = (t / nOt) * 128 + wave * 32 + lo, l0 = p_ch * QC_KC;
+    const int o0 = (t % nOt) * 32, icol = (t / nOt) * 128 + wave * 32 + lo;
     const unsigned base = lds0 + p_stage * CFG::STAGE;
     const unsigned a_lane = (unsigned)(((p_ch * Do + o0 + (lane >> 1)) << 4) + 8 * (lane & 1));
 #pragma unroll
@@ -483,6 +486,35 @@ __global__ __launch_bounds__(256) void quadform_conv_planes_kernel(
     // 1.7 ms where the 64-channel ones (64 chunks per tile) take 0.43 (profiles/r06_pmc_quad_launches.log: 8 x the
     // instructions).  Written on PAIRS of positions (v_pk_mul_f32 / v_pk_fma_f32: two products per instruction) with two-wide
     // running sums: 2 instructions per (pair, four positions) instead of the 6 of `(s0 a0 + s1 a1) + (s2 a2 + s3 a3)`.
+    if constexpr (OCC == 2) {
+      // two waves per SIMD (256 registers): one-wide running sums, two positions at a time
+#pragma unroll
+      for (int rh = 0; rh < 8; ++rh) {
+        qf32x2 wg, a1[CT];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int oo = o0 + (2 * (rh & 1) + j) + 8 * (rh >> 1) + 4 * hi;
+          const bool ok = oo < Do && icol < Dk;
+          const float d = (w_in_lds ? ldsw[ok ? oo : 0] * ldsw[Do + (ok ? icol : 0)] : w0[ok ? oo : 0] * w1[ok ? icol : 0]) + dlt;
+          wg[j] = ok ? __builtin_amdgcn_rcpf(d) : 0.f;
+        }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          const qf32x2 r = {acc[c][2 * rh], acc[c][2 * rh + 1]};
+          a1[c] = (r * un_u) * un_v;
+        }
+        int p = 0;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          const qf32x2 s0 = a1[c] * wg;
+#pragma unroll
+          for (int k = c; k < CT; ++k) {
+            pair1[p] = __builtin_fmaf(s0[0], a1[k][0], __builtin_fmaf(s0[1], a1[k][1], pair1[p]));
+            ++p;
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
       qf32x2 wgt[2], a[CT][2];
@@ -513,9 +545,10 @@ __global__ __launch_bounds__(256) void quadform_conv_planes_kernel(
       }
     }
   }
+    }
   float pair[NP];
 #pragma unroll
-  for (int p = 0; p < NP; ++p) pair[p] = pair2[p][0] + pair2[p][1];
+  for (int p = 0; p < NP; ++p) pair[p] = OCC == 2 ? pair1[p] : pair2[p][0] + pair2[p][1];
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
     const float s = wave_sum(pair[p]);
@@ -727,19 +760,30 @@ extern "C" int lk_kron_quadform_shared_planes_f16x2(const void* u_h, const void*
   const dim3 grid((unsigned)(B * split));
   const size_t w_bytes = (size_t)(Do + Dk) * sizeof(float);
   const int w_in_lds = w_bytes <= 40960 ? 1 : 0;  // (the eigenvalues behind the ring: ResNet-18's widest layer needs 20 KB)
-#define LK_QP_CASE(CT)                                                                                                      \
-  case CT: {                                                                                                                \
+#define LK_QP_LAUNCH(CT, OCC)                                                                                               \
+  {                                                                                                                         \
     static bool attr_set = false;                                                                                           \
     if (!attr_set) {                                                                                                        \
-      (void)hipFuncSetAttribute((const void*)quadform_conv_planes_kernel<CT>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                                QcPlanesCfg<CT>::LDS + 40960);                                                              \
+      (void)hipFuncSetAttribute((const void*)quadform_conv_planes_kernel<CT, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                QcPlanesCfg<CT, OCC>::LDS + (OCC == 2 ? 24576 : 40960));                                      \
       attr_set = true;                                                                                                      \
     }                                                                                                                       \
-    hipLaunchKernelGGL((quadform_conv_planes_kernel<CT>), grid, dim3(256), QcPlanesCfg<CT>::LDS + (w_in_lds ? w_bytes : 0),   \
-                       stream, (const _Float16*)u_h, (const _Float16*)u_l, u_sexp, (const _Float16*)v_h, (const _Float16*)v_l, \
-                       v_sexp, (int)v_nsexp, l1, l2, delta, (int)B, (int)C, (int)Do, (int)Dk, (int)L, split, partial,         \
-                       (const _Float16*)zero16, w_in_lds);                                                                  \
-  } break;
+    hipLaunchKernelGGL((quadform_conv_planes_kernel<CT, OCC>), grid, dim3(256),                                              \
+                       (QcPlanesCfg<CT, OCC>::LDS + (w_in_lds ? w_bytes : 0)), stream, (const _Float16*)u_h, (const _Float16*)u_l,  \
+                       u_sexp, (const _Float16*)v_h, (const _Float16*)v_l, v_sexp, (int)v_nsexp, l1, l2, delta, (int)B, (int)C,      \
+                       (int)Do, (int)Dk, (int)L, split, partial, (const _Float16*)zero16, w_in_lds);                         \
+  }
+#define LK_QP_CASE(CT)         \
+  case CT:                     \
+    if (occ2) LK_QP_LAUNCH(CT, 2) \
+    else LK_QP_LAUNCH(CT, 1)   \
+    break;
+  // Two workgroups per CU — two waves per SIMD — (round 6, `OCC = 2`): one wave's pair-sum arithmetic and load latency run beside
+  // the other's MFMAs.  256 registers per wave: one-wide running pair sums, a two-stage ring (the partner covers what the
+  // deeper ring covered); ten outputs spill 17 registers outside the chunk loop.  Measured on the c4 layers, ms per launch
+  // (profiles/r06_quad_layers.log): 64 channels 0.42 -> 0.34, 128: 0.49 -> 0.38, 256: 0.65 -> 0.48, 512: 1.37 -> 1.10; a
+  // predictive call 10.5 -> 8.8 ms of quadratic forms.  One per CU only where the eigenvalues do not fit beside two rings.
+  const bool occ2 = w_bytes <= 24576;
   switch (ct) {
     LK_QP_CASE(1)
     LK_QP_CASE(2)
@@ -751,6 +795,7 @@ extern "C" int lk_kron_quadform_shared_planes_f16x2(const void* u_h, const void*
     LK_QP_CASE(10)
   }
 #undef LK_QP_CASE
+#undef LK_QP_LAUNCH
   const int64_t total = B * (ct * (ct + 1) / 2);
   hipLaunchKernelGGL(quadform_conv_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, partial, B,
                      (int)C, ct, split, fvar);
