@@ -281,6 +281,7 @@ def fit_50k_leg(backend, dev):
     gc.freeze()   # ... and that heap — the event lists of the instrumented passes, the other legs' models — is not this leg's
                   # to traverse: the collector's full passes over it made a step of THIS leg host-bound in long runs
     torch.cuda.synchronize()
+    ms0 = torch.cuda.memory_stats(dev)
     sampler = PowerSampler()
     t0 = time.perf_counter()
     with sampler:
@@ -289,6 +290,7 @@ def fit_50k_leg(backend, dev):
             acc.add_batch(*bs[i % 4])
         if last is not None:
             acc.add_batch(*last)
+        t_host = time.perf_counter()  # (the host has enqueued every minibatch; `max_ahead` keeps it within two of the device)
         loss, H = acc.finalize()
         torch.cuda.synchronize()
     t1 = time.perf_counter()
@@ -297,8 +299,14 @@ def fit_50k_leg(backend, dev):
     t2 = time.perf_counter()
     gc.unfreeze()
     ok = all(int(i[0].item()) == 0 for i in dec._eig_info)
-    return {"samples": N_DATASET, "minibatches": n_full + (1 if rest else 0), "wall_s": t2 - t0, "accumulate_s": t1 - t0,
-            "decompose_s": t2 - t1, "samples_per_s": N_DATASET / (t2 - t0), "eigh_converged": bool(ok),
+    ms1 = torch.cuda.memory_stats(dev)
+    alloc = {"device_mallocs_during_the_fit": ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0),
+             "device_frees_during_the_fit": ms1.get("num_device_free", 0) - ms0.get("num_device_free", 0),
+             "allocator_retries_so_far": ms1.get("num_alloc_retries", 0), "ooms_so_far": ms1.get("num_ooms", 0),
+             "reserved_gib_before": ms0.get("reserved_bytes.all.current", 0) / 2**30,
+             "reserved_gib_after": ms1.get("reserved_bytes.all.current", 0) / 2**30}
+    return {"allocator": alloc, "samples": N_DATASET, "minibatches": n_full + (1 if rest else 0), "wall_s": t2 - t0, "accumulate_s": t1 - t0,
+            "decompose_s": t2 - t1, "host_loop_s": t_host - t0, "samples_per_s": N_DATASET / (t2 - t0), "eigh_converged": bool(ok),
             "loss_finite": bool(torch.isfinite(loss).all()), "power": sampler.summary()}
 
 
@@ -787,7 +795,12 @@ def main():
             result["predictive"] = predictive_leg(dev)
             result.setdefault("predictive_samples_per_s", {})["c3_dense_last_layer"] = result["predictive"]["predictive_samples_per_s"]
         if not args.no_extras and not SELFTEST:
+            # twice: the first fit of this process state pays the device allocations of its working set (~280 hipMalloc calls,
+            # 32 GiB: 0.05 - 0.9 s from box to box and run to run); the second runs in the pool the first left, which is
+            # what every fit after the first of a process sees.  The line carries the second, and the first beside it.
+            cold = fit_50k_leg(backend, dev)
             result["fit_50k"] = fit_50k_leg(backend, dev)
+            result["fit_50k"]["first_fit_of_the_process"] = {k: cold[k] for k in ("wall_s", "accumulate_s", "decompose_s", "samples_per_s", "allocator")}
             pw = result["fit_50k"].get("power")
             if pw and isinstance(result.get("roofline"), dict) and result["roofline"].get("unit") == "TFLOP/s":
                 # the same fraction against the matrix peak AT THE CLOCK THE CHIP RAN (the fit holds the socket at its power

@@ -232,6 +232,7 @@ __device__ __forceinline__ void qc_tile_gemm_b6(const QcOperands& cur, const QcO
 // form needs six.  (An in-flight variant of it — fp32 operands split by the staging threads — existed in rounds 2 - 4 and
 // measured equal to the bf16 form: the kernel was never bound by its matrix pipe.  Removed in round 5.)
 typedef _Float16 qf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 qf16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int qc_scale_exp(float amax) {  // amax * 2^s in [2^14, 2^15)
   int be = (int)((__float_as_uint(amax) >> 23) & 0xffu);
   if (be == 0) be = 1;
@@ -361,7 +362,28 @@ struct QcPlanesCfg {
   static_assert(LD * (NS - 2) <= 63, "vmcnt is a 6-bit counter");
 };
 
-template <int CT, int OCC = 1>
+// SUB (one-chunk tiles: L == 16, the 4 x 4 maps of the deepest layers; OCC = 2, eigenvalues in LDS): a tile is ONE chunk there
+// and the pair sums — 55 x 16 positions per lane — are the kernel (profiles/r06_pmc_quad_launches.log: instruction issue,
+// not the matrix pipe or bytes).  The wave's 32 x 32 region is walked as four 16 x 16 sub-tiles on v_mfma_f32_16x16x32_f16:
+// 4 accumulator registers per output instead of 16 leave room for TWO-wide running pair sums beside two waves per SIMD, i.e.
+// v_pk_fma_f32 on pairs of positions without the register shuffles the one-wide sums of the 32 x 32 form cost (~700 vector
+// instructions per tile instead of ~1900).
+template <int CT>
+struct QcSubPlan {  // SUB: the classes whose products are issued during pair-sum row c (front-loaded like the rows: CT - c pairs)
+  int cnt[10], first[10];
+  constexpr QcSubPlan() : cnt{}, first{} {
+    constexpr int base[10] = {3, 2, 2, 1, 1, 1, 0, 0, 0, 0};
+    int before = 0;
+    for (int c = 0; c < 10; ++c) {
+      const int left = CT - before;
+      cnt[c] = left <= 0 ? 0 : (base[c] < left ? base[c] : left);
+      first[c] = before;
+      before += cnt[c];
+    }
+  }
+};
+
+template <int CT, int OCC = 1, bool SUB = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void quadform_conv_planes_kernel(
     const _Float16* __restrict__ uh, const _Float16* __restrict__ ul, const int* __restrict__ u_sexp,
     const _Float16* __restrict__ vh, const _Float16* __restrict__ vl, const int* __restrict__ v_sexp, int v_nsexp,
@@ -398,12 +420,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     __syncthreads();
   }
 
-  qf32x2 pair2[OCC == 2 ? 1 : NP];  // (two-wide running pair sums: see the tile epilogue)
-  float pair1[OCC == 2 ? NP : 1];
+  constexpr bool ONE_WIDE = OCC == 2;
+  qf32x2 pair2[ONE_WIDE ? 1 : NP];  // (two-wide running pair sums: see the tile epilogue)
+  float pair1[ONE_WIDE ? NP : 1];
 #pragma unroll
-  for (int p = 0; p < (OCC == 2 ? 1 : NP); ++p) pair2[p] = qf32x2{0.f, 0.f};
+  for (int p = 0; p < (ONE_WIDE ? 1 : NP); ++p) pair2[p] = qf32x2{0.f, 0.f};
 #pragma unroll
-  for (int p = 0; p < (OCC == 2 ? NP : 1); ++p) pair1[p] = 0.f;
+  for (int p = 0; p < (ONE_WIDE ? NP : 1); ++p) pair1[p] = 0.f;
   const int my_tiles = sp < ntiles ? (ntiles - sp + split - 1) / split : 0;
   const int Q = my_tiles * NCH;  // chunks of this workgroup's walk
 
@@ -440,6 +463,84 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
   for (int kt = 0; kt < my_tiles; ++kt) {
     const int t = sp + kt * split;
     const int o0 = (t % nOt) * 32, icol = (t / nOt) * 128 + wave * 32 + lo;
+    if constexpr (SUB) {
+      // (the tile's one chunk: same hand-over as in the chunk loop below)
+      if (q + NS - 1 <= Q) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(CFG::LD * (NS - 2)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      if (q + NS - 1 < Q) request();
+      const unsigned stage = lds0 + c_stage * CFG::STAGE;
+      c_stage = c_stage + 1 == NS ? 0 : c_stage + 1;
+      ++q;
+      // fragment lane of v_mfma_f32_16x16x32_f16: row / column l16, k = 8 kg .. + 7 of 32.  The 16 positions of the chunk take
+      // HALF of that depth, so the two planes ride in the other half: A' = [a_h | a_l] against B' = [b_h | b_h] and then
+      // [b_l | b_l] — all four plane products (the l l term included) in two instructions instead of three of the k = 16 form.
+      // The products of sub-tile s + 1 are issued INSIDE the pair sums of sub-tile s (one-wide v_fma_f32 runs beside the
+      // matrix pipe — csrc/Makefile —; with two waves per SIMD a wave that only waits for its MFMAs leaves the other one issuing
+      // a vector instruction every ~5 clocks instead of the pair's 2.7).
+      const int l16 = lane & 15, kg = lane >> 4;
+      auto lds_read128 = [&](qf16x8& dst, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr)); };
+      const float un = un_u * un_v;  // (a power of two: one factor rides on the weights, the other on the final sums — exact)
+      const unsigned rb0 = stage + CFG::A_BYTES + (wave * 2) * 1024 + (l16 + 32 * (kg & 1)) * 16;  // + 256 sk
+      const unsigned ra0 = stage + (kg >> 1) * (CT * 1024) + l16 * 32 + (kg & 1) * 16;              // + 512 so + 1024 c
+      f32x4 accs[2][CT];
+      qf16x8 bh, bl, a2[2];
+      // classes whose products are issued during pair-sum row c (row c holds CT - c pairs): front-loaded like the rows
+      constexpr QcSubPlan<CT> plan{};
+      auto products = [&](int sub, int c) {  // class c of sub-tile `sub` (fragment set c & 1; class c + 1 requested first)
+        const unsigned ra = ra0 + (sub >> 1) * 512;
+        const int set = c & 1;
+        if (c + 1 < CT) {
+          lds_read128(a2[set ^ 1], ra + (c + 1) * 1024);
+          asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(a2[set]), "+v"(bh), "+v"(bl));
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a2[set]), "+v"(bh), "+v"(bl));
+        }
+        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[set], bl, d, 0, 0, 0);  // small terms first
+        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[set], bh, d, 0, 0, 0);
+        accs[sub & 1][c] = d;
+      };
+      auto first_reads = [&](int sub) {
+        lds_read128(bh, rb0 + (sub & 1) * 256);
+        lds_read128(bl, rb0 + (sub & 1) * 256 + 1024);
+        lds_read128(a2[0], ra0 + (sub >> 1) * 512);
+      };
+      first_reads(0);
+#pragma unroll
+      for (int c = 0; c < CT; ++c) products(0, c);
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub) {
+        const int so = sub >> 1, sk = sub & 1;
+        // this lane's four positions: rows o0 + 16 so + 4 kg .. + 3 of column (icol - lo) + 16 sk + l16
+        const int oo = o0 + so * 16 + 4 * kg, col = icol - lo + sk * 16 + l16;
+        const bool ok = col < Dk;
+        const float wc = ldsw[Do + (ok ? col : 0)];
+        const f32x4 wr = *reinterpret_cast<const f32x4*>(ldsw + oo);
+        float wg[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wg[j] = ok ? __builtin_amdgcn_rcpf(wr[j] * wc + dlt) * un : 0.f;
+        if (sub + 1 < 4) first_reads(sub + 1);
+        int p = 0;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          if (sub + 1 < 4) {
+#pragma unroll
+            for (int i = 0; i < plan.cnt[c]; ++i) products(sub + 1, plan.first[c] + i);
+          }
+          float sw[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sw[r] = accs[sub & 1][c][r] * wg[r];
+          // (position-major: consecutive instructions belong to different sums — a wave's dependent v_fma_f32 issue ~8 clocks apart)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int k = c; k < CT; ++k) pair1[p + k - c] = __builtin_fmaf(sw[r], accs[sub & 1][k][r], pair1[p + k - c]);
+          p += CT - c;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      continue;
+    }
     f32x16 acc[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c)
@@ -486,32 +587,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     // 1.7 ms where the 64-channel ones (64 chunks per tile) take 0.43 (profiles/r06_pmc_quad_launches.log: 8 x the
     // instructions).  Written on PAIRS of positions (v_pk_mul_f32 / v_pk_fma_f32: two products per instruction) with two-wide
     // running sums: 2 instructions per (pair, four positions) instead of the 6 of `(s0 a0 + s1 a1) + (s2 a2 + s3 a3)`.
-    if constexpr (OCC == 2) {
-      // two waves per SIMD (256 registers): one-wide running sums, two positions at a time
+    if constexpr (ONE_WIDE) {
+      // two waves per SIMD (256 registers): one-wide running sums on one-wide instructions (the library is built without the
+      // packed fp32 forms — csrc/Makefile —: v_fma_f32 runs beside the partner wave's MFMAs, v_pk_fma_f32 does not), two
+      // positions at a time; one factor of the operands' scale rides on the weights, the other on the final sums (powers of
+      // two: exact)
+      const float un = un_u * un_v;
 #pragma unroll
       for (int rh = 0; rh < 8; ++rh) {
-        qf32x2 wg, a1[CT];
+        float wg[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int oo = o0 + (2 * (rh & 1) + j) + 8 * (rh >> 1) + 4 * hi;
           const bool ok = oo < Do && icol < Dk;
           const float d = (w_in_lds ? ldsw[ok ? oo : 0] * ldsw[Do + (ok ? icol : 0)] : w0[ok ? oo : 0] * w1[ok ? icol : 0]) + dlt;
-          wg[j] = ok ? __builtin_amdgcn_rcpf(d) : 0.f;
-        }
-#pragma unroll
-        for (int c = 0; c < CT; ++c) {
-          const qf32x2 r = {acc[c][2 * rh], acc[c][2 * rh + 1]};
-          a1[c] = (r * un_u) * un_v;
+          wg[j] = ok ? __builtin_amdgcn_rcpf(d) * un : 0.f;
         }
         int p = 0;
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
-          const qf32x2 s0 = a1[c] * wg;
+          const float s0 = acc[c][2 * rh] * wg[0], s1 = acc[c][2 * rh + 1] * wg[1];
 #pragma unroll
-          for (int k = c; k < CT; ++k) {
-            pair1[p] = __builtin_fmaf(s0[0], a1[k][0], __builtin_fmaf(s0[1], a1[k][1], pair1[p]));
-            ++p;
-          }
+          for (int k = c; k < CT; ++k) pair1[p + k - c] = __builtin_fmaf(s0, acc[k][2 * rh], pair1[p + k - c]);
+#pragma unroll
+          for (int k = c; k < CT; ++k) pair1[p + k - c] = __builtin_fmaf(s1, acc[k][2 * rh + 1], pair1[p + k - c]);
+          p += CT - c;
         }
       }
     } else {
@@ -548,7 +648,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     }
   float pair[NP];
 #pragma unroll
-  for (int p = 0; p < NP; ++p) pair[p] = OCC == 2 ? pair1[p] : pair2[p][0] + pair2[p][1];
+  for (int p = 0; p < NP; ++p) pair[p] = ONE_WIDE ? pair1[p] * ((SUB || OCC == 2) ? un_u * un_v : 1.f) : pair2[p][0] + pair2[p][1];
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
     const float s = wave_sum(pair[p]);
@@ -760,23 +860,24 @@ extern "C" int lk_kron_quadform_shared_planes_f16x2(const void* u_h, const void*
   const dim3 grid((unsigned)(B * split));
   const size_t w_bytes = (size_t)(Do + Dk) * sizeof(float);
   const int w_in_lds = w_bytes <= 40960 ? 1 : 0;  // (the eigenvalues behind the ring: ResNet-18's widest layer needs 20 KB)
-#define LK_QP_LAUNCH(CT, OCC)                                                                                               \
+#define LK_QP_LAUNCH(CT, OCC, SUB)                                                                                          \
   {                                                                                                                         \
     static bool attr_set = false;                                                                                           \
     if (!attr_set) {                                                                                                        \
-      (void)hipFuncSetAttribute((const void*)quadform_conv_planes_kernel<CT, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+      (void)hipFuncSetAttribute((const void*)quadform_conv_planes_kernel<CT, OCC, SUB>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 QcPlanesCfg<CT, OCC>::LDS + (OCC == 2 ? 24576 : 40960));                                      \
       attr_set = true;                                                                                                      \
     }                                                                                                                       \
-    hipLaunchKernelGGL((quadform_conv_planes_kernel<CT, OCC>), grid, dim3(256),                                              \
+    hipLaunchKernelGGL((quadform_conv_planes_kernel<CT, OCC, SUB>), grid, dim3(256),                                         \
                        (QcPlanesCfg<CT, OCC>::LDS + (w_in_lds ? w_bytes : 0)), stream, (const _Float16*)u_h, (const _Float16*)u_l,  \
                        u_sexp, (const _Float16*)v_h, (const _Float16*)v_l, v_sexp, (int)v_nsexp, l1, l2, delta, (int)B, (int)C,      \
                        (int)Do, (int)Dk, (int)L, split, partial, (const _Float16*)zero16, w_in_lds);                         \
   }
-#define LK_QP_CASE(CT)         \
-  case CT:                     \
-    if (occ2) LK_QP_LAUNCH(CT, 2) \
-    else LK_QP_LAUNCH(CT, 1)   \
+#define LK_QP_CASE(CT)                    \
+  case CT:                                \
+    if (sub) LK_QP_LAUNCH(CT, 2, true)    \
+    else if (occ2) LK_QP_LAUNCH(CT, 2, false) \
+    else LK_QP_LAUNCH(CT, 1, false)       \
     break;
   // Two workgroups per CU — two waves per SIMD — (round 6, `OCC = 2`): one wave's pair-sum arithmetic and load latency run beside
   // the other's MFMAs.  256 registers per wave: one-wide running pair sums, a two-stage ring (the partner covers what the
@@ -784,6 +885,12 @@ extern "C" int lk_kron_quadform_shared_planes_f16x2(const void* u_h, const void*
   // (profiles/r06_quad_layers.log): 64 channels 0.42 -> 0.34, 128: 0.49 -> 0.38, 256: 0.65 -> 0.48, 512: 1.37 -> 1.10; a
   // predictive call 10.5 -> 8.8 ms of quadratic forms.  One per CU only where the eigenvalues do not fit beside two rings.
   const bool occ2 = w_bytes <= 24576;
+  // one-chunk tiles (4 x 4 maps): the sub-tile form with two-wide pair sums (see the kernel; -DLK_QC_NO_SUB: development build)
+#ifdef LK_QC_NO_SUB
+  const bool sub = false;
+#else
+  const bool sub = occ2 && w_in_lds && L == 16;
+#endif
   switch (ct) {
     LK_QP_CASE(1)
     LK_QP_CASE(2)
