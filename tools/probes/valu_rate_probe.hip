@@ -62,7 +62,8 @@ static void mrun(float* out, int waves_per_simd, const char* what) {
 
 // Co-execution: PARTNER = true: odd waves issue matrix instructions, even waves `nv` vector instructions per matrix instruction
 // of the partner; PARTNER = false: every wave issues both, interleaved (nv vector instructions behind each matrix instruction).
-// PK: v_pk_fma_f32 instead of v_fma_f32.  Per loop trip: 16 matrix instructions (four chains) and 16 nv vector instructions.
+// PK: v_pk_fma_f32 instead of v_fma_f32 (not run: hipcc keeps that variant's accumulators in scratch; the packed stream beside a
+// partner's MFMAs is what `probe<4>` measures).  Per loop trip: 16 matrix instructions (four chains) and 16 nv vector instructions.
 template <bool PARTNER, bool PK, int NV>
 __global__ __launch_bounds__(1024) void coprobe(int iters, float seed, float* out, int do_m, int do_v) {
   const int wave = threadIdx.x >> 6;
@@ -70,8 +71,10 @@ __global__ __launch_bounds__(1024) void coprobe(int iters, float seed, float* ou
   for (int i = 0; i < 8; ++i) a[i] = (_Float16)(seed + i), b[i] = (_Float16)(seed - i);
   f4 d[4] = {f4{0, 0, 0, 0}, f4{0, 0, 0, 0}, f4{0, 0, 0, 0}, f4{0, 0, 0, 0}};
   f2 acc[16];
+  float acc1[16];
   f2 x = {seed, seed + 1}, y = {seed * 0.5f, seed};
-  for (int i = 0; i < 16; ++i) acc[i] = f2{(float)i, 1.f};
+  const float x1 = seed, y1 = seed * 0.5f;
+  for (int i = 0; i < 16; ++i) acc[i] = f2{(float)i, 1.f}, acc1[i] = i;
   const bool m = do_m && (!PARTNER || (wave & 1)), v = do_v && (!PARTNER || !(wave & 1));
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -80,14 +83,14 @@ __global__ __launch_bounds__(1024) void coprobe(int iters, float seed, float* ou
       if (v) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-          if (PK) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[(j * NV + i) & 15]) : "v"(x), "v"(y));
-          else asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[(j * NV + i) & 15][0]) : "v"(x[0]), "v"(y[0]));
+          if constexpr (PK) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[(j * NV + i) & 15]) : "v"(x), "v"(y));
+          else asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc1[(j * NV + i) & 15]) : "v"(x1), "v"(y1));
         }
       }
     }
   }
   float s = d[0][0] + d[1][1] + d[2][2] + d[3][3];
-  for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1];
+  for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc1[i];
   if (s == 12345.f) out[threadIdx.x] = s;
 }
 
@@ -207,12 +210,9 @@ int main() {
     hipEventElapsedTime(&ms, e0, e1);
     printf("one wave per SIMD: 320 000 v_mfma_f32_16x16x32_f16; its partner: %d x 320 000 v_pk_fma_f32: %.3f ms together\n", vmul, ms);
   }
-  corun<true, true, 2>(out, 2);
   corun<true, false, 4>(out, 2);
   corun<true, false, 2>(out, 2);
-  corun<false, true, 2>(out, 1);
   corun<false, false, 4>(out, 1);
-  corun<false, true, 2>(out, 2);
   corun<false, false, 4>(out, 2);
   corun<false, false, 2>(out, 2);
   corun<true, false, 4>(out, 4);
