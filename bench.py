@@ -431,8 +431,10 @@ def pmc_traffic(kernel_prefix: str, kernel_suffix: str = "", table: str = "bench
         newest = newest or os.path.basename(path)
         if meta.get("csrc_sha16") != want:
             continue
-        rows = [v for k, v in tab.items() if k != "_meta" and (k.startswith(kernel_prefix) or k.startswith("void " + kernel_prefix))
-                and k.endswith(kernel_suffix)]
+        # (a family may be several kernels: `kernel_prefix` = a sequence of (prefix, suffix) then)
+        alts = [(kernel_prefix, kernel_suffix)] if isinstance(kernel_prefix, str) else list(kernel_prefix)
+        rows = [v for k, v in tab.items() if k != "_meta" and any((k.startswith(pre) or k.startswith("void " + pre)) and k.endswith(suf)
+                                                                   for pre, suf in alts)]
         launches = sum(r["launches"] for r in rows)
         if not launches:
             return None, f"profiles/{os.path.basename(path)}: no launch of this family in the PMC pass"
@@ -606,9 +608,11 @@ def main():
                         "sweep); six bf16 MFMAs per fp32 product block", "mfma", "void lk::gram_kernel<5,"),
             "pixpair": ("lk::gram_kernel<MODE_TNP>: banded pixel-pair accumulation of the 3x3-conv A factors "
                         "(block read-modify-write)", "hbm", "void lk::gram_kernel<4,"),
-            "pixpair16": ("lk::gram16_kernel<.., TNP>: banded pixel-pair accumulation of the 3x3-conv A factors from the split "
-                          "images (block read-modify-write once per four stacked minibatches; three fp16 MFMAs per fp32 "
-                          "product block); priced on its algorithmic bytes, 2 x blocks + input", "hbm", "lk::gram16_kernel", ",1>"),
+            "pixpair16": ("lk::gram16_kernel<.., TNP> / lk::pixpair13_kernel (64-channel maps: one workgroup per pixel, its panel staged "
+                          "once for all 13 shifts): banded pixel-pair accumulation of the 3x3-conv A factors from the split "
+                          "images (block read-modify-write once per eight stacked minibatches; three fp16 MFMAs per fp32 "
+                          "product block); priced on its algorithmic bytes, 2 x blocks + input", "hbm",
+                          (("lk::gram16_kernel", ",1>"), ("lk::pixpair13_kernel", ""))),
             "gram_conv": ("lk::gram_kernel<MODE_CONV> (+ slab reduce): implicit-im2col A-factor accumulation, "
                           "exact-fp32 MFMA", "mfma", "void lk::gram_kernel<2,"),
             "im2col16": ("lk::im2col_split_f16x2_kernel: the patch matrix of the strided / stem convolutions as split planes (its Gram — "
@@ -827,7 +831,10 @@ def main():
             result["fit_fixed_cost"] = {"steady_ms_per_step": steady, "timed_ms_per_step": dt / args.steps * 1e3,
                                         "fixed_ms_per_fit": dt * 1e3 - args.steps * steady,
                                         "setup_ms_first_two_minibatches_minus_two_steady_steps": setup_ms,
-                                        "finalize_ms_behind_a_drained_device": (time.perf_counter() - t_f) * 1e3}
+                                        "finalize_ms_behind_a_drained_device": (time.perf_counter() - t_f) * 1e3,
+                                        "note": "steady = the 391-minibatch fit's average, which runs 1 - 2 % slower than a short burst of steps "
+                                                "(power / temperature): a negative fixed_ms_per_fit says the timed burst was faster than that "
+                                                "average, not that a fit costs less than its minibatches"}
             result["other_configs"] = small_config_legs(dev)
         if not args.no_cpu_baseline:
             if pred_dec is not None:

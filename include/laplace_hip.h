@@ -139,6 +139,12 @@ int lk_conv3x3_pixpair_assemble2_f32(const float* blocks, const float* blocks2, 
 int lk_conv3x3_pixpair_accumulate_f16x2(const void* x_h, const void* x_l, const int* sexp, int64_t B, int64_t H, int64_t W,
                                         int64_t Cin, float alpha, float* blocks, const int32_t* tiles_dev, int64_t n_tiles,
                                         const void* zero16, void* stream);
+/* The same for Cin == 64 with one workgroup per pixel: the pixel's panel is staged once for its (up to) 13 shifts instead of
+ * once per (pixel, shift) block — the launch was bound by what a CU ingests, not by the matrix pipe.  slots_dev: the
+ * [H W][13] slot table of lk_conv3x3_pixpair_tables (-1: the shifted pixel is outside the map). */
+int lk_conv3x3_pixpair_accumulate13_f16x2(const void* x_h, const void* x_l, const int* sexp, int64_t B, int64_t H, int64_t W,
+                                          int64_t Cin, float alpha, float* blocks, const int32_t* slots_dev, const void* zero16,
+                                          void* stream);
 
 /* Same result as lk_gram_conv_nhwc_f32 for a 3x3 / stride 1 / padding 1 / dilation 1 convolution, through the
  * shift-correlation identity (the input grid equals the output grid, so the 81 (offset, offset) blocks of the

@@ -61,6 +61,7 @@ SIGNATURES = {
     "lk_conv3x3_pixpair_tables": (_int, [_i64, _i64, _i64, _vp, _vp]),
     "lk_conv3x3_pixpair_accumulate_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _f32, _vp, _vp, _i64, _vp]),
     "lk_conv3x3_pixpair_accumulate_f16x2": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp, _vp, _i64, _vp, _vp]),
+    "lk_conv3x3_pixpair_accumulate13_f16x2": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp, _vp, _vp, _vp]),
     "lk_conv3x3_pixpair_assemble_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _f32, _vp, _vp]),
     "lk_conv3x3_pixpair_assemble2_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _f32, _vp, _int, _vp]),
     "lk_nchw_to_nhwc_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
@@ -984,16 +985,26 @@ class HipKernels:
     #: requests the block it read-modify-writes at the START of its (short) tile: 0.87 vs 1.39 ms per c4 step — the
     #: dependent 16 KB read at the end of every 8-stage tile, not traffic or the matrix pipe, was what bound the product
     use_pixpair16 = True
+    #: 64-channel maps: one workgroup per pixel with all 13 shifts (`lk_conv3x3_pixpair_accumulate13_f16x2`: the pixel's panel is
+    #: staged once instead of 13 times); ``False``: one workgroup per (pixel, shift) block as for the wider maps
+    use_pixpair13 = True
 
     def pixpair_accumulate_split(self, xs, alpha, blocks, plan):
         """:meth:`pixpair_accumulate_nhwc` on a SplitTensor ``xs [B, H, W, Cin]`` (three fp16 MFMAs per product block)."""
         _check(blocks, "blocks")
         _one_scale(xs, "pixpair_accumulate_split")
         B, H, W, Cin = xs.shape
-        nb, tiles, _ = plan
+        nb, tiles, slots = plan
         assert blocks.numel() == nb * Cin * Cin
         dev = blocks.device
         z = self._zero16(dev)
+        if Cin == 64 and self.use_pixpair13:
+            self._rc(self._timed("pixpair16", 8.0 * blocks.numel() + 4.0 * xs.planes[0].numel(), dev,
+                                 lambda: self.lib.lk_conv3x3_pixpair_accumulate13_f16x2(
+                                     _ptr(xs.planes[0]), _ptr(xs.planes[1]), _ptr(xs.sexp), B, H, W, Cin, float(alpha), _ptr(blocks),
+                                     ctypes.c_void_p(slots.data_ptr()), _ptr(z), self._stream(dev))),
+                     "lk_conv3x3_pixpair_accumulate13_f16x2")
+            return blocks
         self._rc(self._timed("pixpair16", 8.0 * blocks.numel() + 4.0 * xs.planes[0].numel(), dev,
                              lambda: self.lib.lk_conv3x3_pixpair_accumulate_f16x2(
                                  _ptr(xs.planes[0]), _ptr(xs.planes[1]), _ptr(xs.sexp), B, H, W, Cin, float(alpha), _ptr(blocks),

@@ -339,18 +339,22 @@ __global__ __launch_bounds__(256) void gram16_kernel(const _Float16* __restrict_
   const int f_row = (grp >> 1) * 8 + (r16 >> 2);        // + j * 4 + k16 * 16
   const int f_col = (grp & 1) * 16 + (r16 & 3) * 4;     // + tile * 32 (+ quadrant * 64)
 
+  // The fragment reads are inline assembly ON PURPOSE: hipcc knows that global_load_lds writes LDS and guards every LDS read it
+  // can see behind one with `s_waitcnt vmcnt(0)` — with the builtin the next stage's requests, issued right in front of this
+  // stage's products, were waited for on the spot (ISA checked) and a stage cost one round trip of the request path (~2500
+  // clocks) whatever its size.  The stage hand-over (vmcnt(0) + barrier at the top of the loop) is what orders them.
   auto load_frag = [&](const char* plane, int k16, int col0) -> f16x8 {
-    f16x8 out;
+    s16x4 v[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int row = k16 * 16 + f_row + j * 4;
       const int col = col0 + f_col;
       const int off = row * G::PITCH + (((col >> 5) ^ gram16_swz<NB>(row)) << 6) + (col & 31) * 2;
-      const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(plane + off));
-      const f16x4 f = __builtin_bit_cast(f16x4, v);
-      out[4 * j] = f[0], out[4 * j + 1] = f[1], out[4 * j + 2] = f[2], out[4 * j + 3] = f[3];
+      const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(plane + off);
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v[j]) : "v"(addr));
     }
-    return out;
+    const f16x4 f0 = __builtin_bit_cast(f16x4, v[0]), f1 = __builtin_bit_cast(f16x4, v[1]);
+    return f16x8{f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
   };
 
   // TNP: the block this workgroup adds into is requested NOW, so that the read of the read-modify-write runs under the K
@@ -402,6 +406,10 @@ __global__ __launch_bounds__(256) void gram16_kernel(const _Float16* __restrict_
         bh[b] = load_frag(pb, k16, wc * 64 + b * 32);
         bl[b] = load_frag(pb + G::PLANE, k16, wc * 64 + b * 32);
       }
+      if constexpr (TW == 2)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[0]), "+v"(al[0]), "+v"(bh[0]), "+v"(bl[0]), "+v"(ah[1]), "+v"(al[1]), "+v"(bh[1]), "+v"(bl[1]));
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[0]), "+v"(al[0]), "+v"(bh[0]), "+v"(bl[0]));
 #pragma unroll
       for (int a = 0; a < TW; ++a)
 #pragma unroll
@@ -680,8 +688,189 @@ extern "C" int lk_gram_tn_f16x2(const void* x_h, const void* x_l, const int* sex
   return check_launch("gram16_reduce4_kernel");
 }
 
+namespace lk {
+// ---- pixel-pair blocks of a 64-channel map, all 13 shifts of a pixel in ONE workgroup -------------------------------------
+// gram16_kernel<64, 64, 4, true> gives every (pixel, shift) block its own workgroup, which stages the pixel's panel and the
+// shifted pixel's panel: 32 KB per 48 MFMAs, 83 B per clock and CU at the matrix pipe's rate against the ~36 the LDS-DMA path
+// ingests from L2 (tools/probes/ldsdma_ingest_probe.hip) — the launch ran at that ingest rate, 23 % of the matrix peak.  Here a
+// workgroup owns a pixel q: per stage of 16 images it stages q's panel ONCE and the (up to) 12 other panels of its shifts —
+// 13 panels for 13 blocks instead of 26 —, and its eight waves hold the 13 blocks' accumulators: wave = (32 x 32 tile of the
+// 64 x 64 block) x (shifts 0 .. 6 | 7 .. 12).  Same stage image, swizzle and transposing fragment reads as gram16_kernel.
+struct Pix13Args {
+  const _Float16 *xh, *xl;
+  const _Float16* zero16;
+  const int* slots;   // [H W][13] block slot of (pixel, shift) or -1 (lk_conv3x3_pixpair_tables)
+  const int* sexp;
+  float* blocks;
+  float alpha;
+  int R, H, W;        // images, map
+};
+
+__device__ __forceinline__ f16x8 pix13_frag(unsigned plane, int lane, int col0) {  // (assembly: see gram16_kernel's load_frag)
+  const int grp = lane >> 4, r16 = lane & 15;
+  const int f_row = (grp >> 1) * 8 + (r16 >> 2), col = col0 + (grp & 1) * 16 + (r16 & 3) * 4;
+  s16x4 v[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = f_row + j * 4;
+    const unsigned off = plane + row * 128 + (((col >> 5) ^ gram16_swz<64>(row)) << 6) + (col & 31) * 2;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v[j]) : "v"(off));
+  }
+  const f16x4 f0 = __builtin_bit_cast(f16x4, v[0]), f1 = __builtin_bit_cast(f16x4, v[1]);
+  return f16x8{f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
+}
+
+#ifndef LK_PIX13_ABLATE  // development builds, timing only: 1 no block update, 2 no staging, 4 no fragment reads / MFMAs
+#define LK_PIX13_ABLATE 0
+#endif
+__global__ __launch_bounds__(512) void pixpair13_kernel(const Pix13Args p) {
+  constexpr int C = 64, BKR = 16, PLANE = BKR * C * 2, PANEL = 2 * PLANE, STAGE = 13 * PANEL;  // 2 KB, 4 KB, 52 KB
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int q;
+  {  // neighbouring pixels share panels: every XCD (block id % 8) takes a contiguous range of pixels
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int qq = nblk / 8, r = nblk % 8, x = bid % 8, j = bid / 8;
+    q = (x < r ? x * (qq + 1) : r * (qq + 1) + (x - r) * qq) + j;
+  }
+  // shift h: (dy, dx) = (0, 0 .. 2), (1, -2 .. 2), (2, -2 .. 2) — lk_gram.hip's kHalfDy / kHalfDx
+  auto panel_col = [&](int h) {  // first column of the panel of pixel q + shift h (scalar arithmetic: h is uniform)
+    const int dy = h < 3 ? 0 : (h < 8 ? 1 : 2), dx = h < 3 ? h : (h < 8 ? h - 5 : h - 10);
+    return (q + dy * p.W + dx) * C;
+  };
+  unsigned valid = 0;
+#pragma unroll
+  for (int h = 0; h < 13; ++h)
+    if (p.slots[q * 13 + h] >= 0) valid |= 1u << h;
+  valid = (unsigned)__builtin_amdgcn_readfirstlane((int)valid);
+  const int g = wave >> 2;  // shift group of this wave: shifts 7 g .. 7 g + 6
+  int myslot[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) myslot[i] = g * 7 + i < 13 ? __builtin_amdgcn_readfirstlane(p.slots[q * 13 + (g * 7 + i < 13 ? g * 7 + i : 0)]) : -1;
+  const int64_t ld = (int64_t)p.H * p.W * C;
+  const int nstage = (p.R + BKR - 1) / BKR;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+  // staging: round i (0 .. 6) of 512 lanes = planes 4 i .. 4 i + 3 (panels 2 i, 2 i + 1); a wave = half a plane (64 slots of 16 B)
+  const int s_half = wave & 1, s_pl = wave >> 1;            // plane 4 i + s_pl: panel 2 i + (s_pl >> 1), h / l = s_pl & 1
+  const int s_row = s_half * 8 + (lane >> 3);
+  const int s_col = ((lane & 7) ^ (gram16_swz<64>(s_row) << 2)) * 8;
+  // (every wave issues exactly SEVEN requests per stage — a panel outside the map stages zeros, the half round 6 that has no panel
+  //  repeats panel 12 (same bytes, same place) — so that the counted wait below is the same number for everybody)
+  auto stage_one = [&](int s, int buf, int i) {  // request i (0 .. 6) of this wave for stage s
+    const int64_t r = (int64_t)s * BKR + s_row;
+    const bool ok = r < p.R;
+    const int64_t e0 = r * ld + s_col;
+    int pnl = 2 * i + (s_pl >> 1), hl = s_pl & 1;
+    if (pnl > 12) pnl = 12;
+    const bool live = ok && ((valid >> pnl) & 1u);
+    const _Float16* src = live ? (hl ? p.xl : p.xh) + e0 + panel_col(pnl) : p.zero16;
+    const unsigned dst = lds0 + buf * STAGE + pnl * PANEL + hl * PLANE + s_half * 1024;
+    __builtin_amdgcn_global_load_lds((gbl_void16*)src, (lds_void16*)(uintptr_t)dst, 16, 0, 0);
+  };
+  auto stage = [&](int s, int buf) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) stage_one(s, buf, i);
+  };
+
+  const int t_a = (wave >> 1) & 1, t_b = wave & 1;  // tile (a, b) of the 64 x 64 block
+  f32x16 acc[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  // A ring of THREE stages, two in flight: with one in flight (request behind the barrier, wait in front of the next) a stage cost
+  // one round trip of the request path, ~2500 clocks, whatever its size — which is what bound the one-block-per-workgroup kernel.
+  if (nstage > 0) stage(0, 0);
+  if (nstage > 1) stage(1, 1);
+  int buf = 0;
+  for (int s = 0; s < nstage; ++s) {
+    // stage s has landed (this wave's part: all but the seven younger requests; then everybody's), and nobody reads the buffer
+    // that the request below overwrites any more (it was consumed one iteration ago)
+    if (s + 1 < nstage) asm volatile("s_waitcnt vmcnt(7)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    // The seven requests for stage s + 2 are issued ONE per shift, between the shifts' products: a wave whose request waits for
+    // room in the request path (the CU ingests ~36 B per clock: a kilobyte every ~28 clocks, eight waves queueing) issues nothing
+    // else meanwhile — in a block in front of the products that wait was the stage's whole ingest time, added to the MFMAs'.
+    const bool more = !(LK_PIX13_ABLATE & 2) && s + 2 < nstage;
+    const int nbuf = buf == 0 ? 2 : buf - 1;
+    const unsigned base = lds0 + buf * STAGE;
+    buf = buf == 2 ? 0 : buf + 1;
+    if (LK_PIX13_ABLATE & 4) {
+      if (more) stage(s + 2, nbuf);
+      continue;
+    }
+    f16x8 ah = pix13_frag(base, lane, t_a * 32), al = pix13_frag(base + PLANE, lane, t_a * 32);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int h = g * 7 + i;
+      if (more) stage_one(s + 2, nbuf, i);
+      if (myslot[i] >= 0) {  // (uniform: the shift exists and the shifted pixel is inside the map)
+        f16x8 bh = pix13_frag(base + h * PANEL, lane, t_b * 32), bl = pix13_frag(base + h * PANEL + PLANE, lane, t_b * 32);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah), "+v"(al), "+v"(bh), "+v"(bl));
+        f32x16 c = acc[i];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
+        acc[i] = c;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // blocks[slot][row][col] += alpha 2^(-2 sexp) acc: the block is this wave's alone (one workgroup per pixel, one wave per tile)
+  const float inv = exp2i16(-p.sexp[0]);
+  const float tscale = p.alpha * inv * inv;
+  const int lr = lane & 31, lh = lane >> 5;
+  // (the old values of FOUR blocks — then three — are requested together: one round trip of memory latency per batch, not per block)
+#pragma unroll
+  for (int i0 = 0; i0 < 7; i0 += 4) {
+    float old[4][16];
+#pragma unroll
+    for (int i = i0; i < (i0 + 4 < 7 ? i0 + 4 : 7); ++i) {
+      if (myslot[i] < 0 || ((LK_PIX13_ABLATE & 1) && p.alpha != 12345.f)) continue;
+      const float* blk = p.blocks + (int64_t)myslot[i] * (C * C);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) old[i - i0][r] = blk[(t_a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * C + t_b * 32 + lr];
+    }
+#pragma unroll
+    for (int i = i0; i < (i0 + 4 < 7 ? i0 + 4 : 7); ++i) {
+      if (myslot[i] < 0 || ((LK_PIX13_ABLATE & 1) && p.alpha != 12345.f)) continue;
+      float* blk = p.blocks + (int64_t)myslot[i] * (C * C);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) blk[(t_a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * C + t_b * 32 + lr] = old[i - i0][r] + tscale * acc[i][r];
+    }
+  }
+}
+}  // namespace lk
+
 // Pixel-pair blocks of a 3x3 convolution's A factor from a split tensor (see Gram16Tnp): x [B][H][W][Cin] as planes with
 // one scale, tables of lk_conv3x3_pixpair_tables (tile edge 64 for Cin % 128 != 0, else 128).
+/* The same blocks for a 64-channel map with one workgroup per PIXEL (pixpair13_kernel): slots_dev = the [H W][13] slot table of
+ * lk_conv3x3_pixpair_tables. */
+extern "C" int lk_conv3x3_pixpair_accumulate13_f16x2(const void* x_h, const void* x_l, const int* sexp, int64_t B, int64_t H,
+                                                     int64_t W, int64_t Cin, float alpha, float* blocks,
+                                                     const int32_t* slots_dev, const void* zero16, void* stream) {
+  LK_REQUIRE(x_h && x_l && sexp && blocks && slots_dev && zero16 && B >= 0 && H >= 1 && W >= 1,
+             "lk_conv3x3_pixpair_accumulate13_f16x2: bad arguments");
+  LK_REQUIRE(Cin == 64 && H * W * Cin < (1ll << 31) && B < (1ll << 31) && H * W * 13 * Cin * Cin < (1ll << 31),
+             "lk_conv3x3_pixpair_accumulate13_f16x2: needs Cin == 64 (and a map within 2^31 elements)");
+  if (B == 0) return LK_OK;
+  Pix13Args a;
+  a.xh = (const _Float16*)x_h, a.xl = (const _Float16*)x_l, a.zero16 = (const _Float16*)zero16, a.slots = slots_dev, a.sexp = sexp;
+  a.blocks = blocks, a.alpha = alpha, a.R = (int)B, a.H = (int)H, a.W = (int)W;
+  constexpr int LDS = 3 * 13 * 4096;  // 156 KB of the CU's 160: one workgroup per CU
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)pixpair13_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(pixpair13_kernel, dim3((unsigned)(H * W)), dim3(512), LDS, (hipStream_t)stream, a);
+  return check_launch("pixpair13_kernel");
+}
+
 extern "C" int lk_conv3x3_pixpair_accumulate_f16x2(const void* x_h, const void* x_l, const int* sexp, int64_t B, int64_t H,
                                                    int64_t W, int64_t Cin, float alpha, float* blocks,
                                                    const int32_t* tiles_dev, int64_t n_tiles, const void* zero16,

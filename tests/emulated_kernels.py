@@ -541,6 +541,7 @@ class EmulatedKernels:
         return blocks
 
     use_pixpair16 = True
+    use_pixpair13 = True
 
     def pixpair_accumulate_split(self, xs, alpha, blocks, plan):
         return self.pixpair_accumulate_nhwc(xs.float(), alpha, blocks, plan)

@@ -102,6 +102,7 @@ CASES = {
     "LK_FUSE_VJP=0": dict(sweep_attrs={"fuse_vjp": False}),
     "LK_NHWC_FORWARD=0": dict(sweep_attrs={"nhwc_forward": False}),
     "LK_PIXPAIR16=0": dict(kernel_attrs={"use_pixpair16": False}),
+    "64-channel pixel pairs: one workgroup per (pixel, shift)": dict(kernel_attrs={"use_pixpair13": False}),
     "LK_SHIFTCORR=0": dict(kernel_attrs={"use_shiftcorr": False}, acc_attrs={"use_pixgram": False}),
     "fp32-operand quadratic form": dict(kernel_attrs={"use_quad_planes": False}),
     "A factors of strided / stem convolutions on the exact-fp32 MFMA kernel": dict(kernel_attrs={"use_gram_conv16": False}),
