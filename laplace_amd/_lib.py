@@ -578,8 +578,10 @@ class HipKernels:
     use_conv_bn_act = True
 
     def conv_bn_act_nhwc(self, x, wplanes, wsexp, w_l1, Ho, Wo, in_mul, taps, scale, shift, scale_amax, shift_amax, act,
-                         addend=None, addend_bound=None, want_mask=True, want_split=True, amax_words=None, config=None):
-        """lk_conv_bn_act_nhwc_f16x2: ``act(conv(x, W) * scale[c] + shift[c] + addend)`` for the per-image SplitTensor
+                         addend=None, addend_bound=None, want_mask=True, want_split=True, amax_words=None, config=None,
+                         y_out=None):
+        """(``y_out``: where ``y`` is written — an fp32 NHWC tensor of its shape, e.g. a slot of the consumer's pixel-pair stack)
+        lk_conv_bn_act_nhwc_f16x2: ``act(conv(x, W) * scale[c] + shift[c] + addend)`` for the per-image SplitTensor
         ``x [N, Hi, Wi, Ci]`` (``x.amax``: the measured per-image maxima) -> ``(y, mask, split, bound)`` exactly as
         :meth:`conv_nhwc_f16x2` followed by :meth:`bn_act_forward_nhwc` returns them (``y`` fp32 NHWC ``[N, Ho, Wo, Co]``)"""
         N, Hi, Wi, Ci = x.planes.shape[1:]
@@ -589,7 +591,10 @@ class HipKernels:
             raise LaplaceHipError("conv_bn_act_nhwc: per-image maxima of the input, matching channels, Co % 8 == 0")
         if N > self.MAX_IMAGES_PER_LAUNCH:
             raise LaplaceHipError("conv_bn_act_nhwc: at most %d images per launch" % self.MAX_IMAGES_PER_LAUNCH)
-        y = torch.empty((N, Ho, Wo, Co), dtype=torch.float32, device=dev)
+        if y_out is not None and (tuple(y_out.shape) != (N, Ho, Wo, Co) or y_out.dtype != torch.float32 or not y_out.is_contiguous()
+                                  or y_out.device != dev):
+            raise LaplaceHipError("conv_bn_act_nhwc: y_out must be a contiguous fp32 [N, Ho, Wo, Co] tensor on the input's device")
+        y = y_out if y_out is not None else torch.empty((N, Ho, Wo, Co), dtype=torch.float32, device=dev)
         mask = torch.empty(y.shape, dtype=torch.uint8, device=dev) if (act == 1 and want_mask) else None
         planes = torch.empty((2,) + tuple(y.shape), dtype=torch.float16, device=dev) if want_split else None
         sexp = torch.empty(N, dtype=torch.int32, device=dev)

@@ -243,7 +243,7 @@ def conv_forward(prep: PreparedConv, x: SplitTensor, out=None, amax_out=None):
 
 
 def conv_forward_bn_act(prep: PreparedConv, x: SplitTensor, scale, shift, scale_amax, shift_amax, act: int, addend=None,
-                        addend_bound=None, want_mask: bool = True, amax_words=None):
+                        addend_bound=None, want_mask: bool = True, amax_words=None, y_out=None):
     """``act(conv(x) * scale[c] + shift[c] + addend)`` of the bias-free ``prep.m`` in ONE launch (lk_conv_bn_act_nhwc_f16x2):
     ``(y, mask, split, bound)`` as ``bn_act_forward_nhwc`` returns them for :func:`conv_forward`'s output — the same bits"""
     K = get_kernels()
@@ -256,7 +256,7 @@ def conv_forward_bn_act(prep: PreparedConv, x: SplitTensor, scale, shift, scale_
     assert bmax is None, "conv_forward_bn_act: bias-free convolutions only"
     taps = [(kh - ph, kw - pw, kh * KW + kw) for kh in range(KH) for kw in range(KW)]
     return K.conv_bn_act_nhwc(x, planes, sexp, l1, Ho, Wo, s, taps, scale, shift, scale_amax, shift_amax, act, addend=addend,
-                              addend_bound=addend_bound, want_mask=want_mask, amax_words=amax_words)
+                              addend_bound=addend_bound, want_mask=want_mask, amax_words=amax_words, y_out=y_out)
 
 
 def _filter_l1(W: torch.Tensor) -> torch.Tensor:

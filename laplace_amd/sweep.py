@@ -153,6 +153,7 @@ class SeedBatchedSweep:
                             addend, add_node = env[other], nxt
                             nxt = next(iter(add_node.users)) if len(add_node.users) == 1 else None
                     relu = nxt is not None and self._is_plain_relu(nxt) and nxt.args[0] is (add_node or node)
+                    self._group_out_node = nxt if relu else (add_node or node)  # (whose users read this launch's output)
                     out, mask = self._run_bn_act(node, inp, scale, shift, relu, addend, need_vjp)
                     if add_node is not None:
                         fused_relu[add_node] = (out, None)  # (the add node itself keeps nothing for its VJP)

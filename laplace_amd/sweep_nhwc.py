@@ -128,6 +128,9 @@ class SplitSweep(SeedBatchedSweep):
         self.split_reason = self._split_eligible()
         self.split_ok = self.split_reason is None
 
+    #: callable ``(tap name, NHWC shape, device) -> fp32 tensor or None``, set around a forward by the KFAC accumulator: where the
+    #: activation that a tapped convolution reads is to be written (see `_run_bn_act`)
+    act_sink = None
     #: ``False``: every backward-data writes fp32 and the element-wise VJP kernel runs on it
     fuse_vjp = True
     #: ``False``: strided convolutions run class by class into an fp32 tensor (one launch per
@@ -350,10 +353,20 @@ class SplitSweep(SeedBatchedSweep):
                     a_bound = a_aux["bound"] if a_aux is not None and "bound" in a_aux else K.absmax(a_h)
                 scale = scale.to(torch.float32).contiguous()
                 shift = shift.to(torch.float32).contiguous()
+                # `act_sink` (the KFAC accumulator): a tapped 3x3 convolution that reads this output may want it written straight
+                # into its pixel-pair stack — the copy it would otherwise make of every activation (13 per c4 minibatch)
+                y_out = None
+                sink, fin = self.act_sink, getattr(self, "_group_out_node", None)
+                if sink is not None and fin is not None:
+                    for u in fin.users:
+                        if u.op == "call_module" and u.target in self.tap_names and u.args and u.args[0] is fin:
+                            y_out = sink(u.target, (inp.shape[0], inp.shape[2], inp.shape[3], inp.shape[1]), inp.device)
+                            if y_out is not None:
+                                break
                 y, mask, split, bound = cv.conv_forward_bn_act(
                     inp.prep, inp.xs, scale, shift, self._amax_of((node.target, "s"), scale),
                     self._amax_of((node.target, "t"), shift), 1 if relu else 0, addend=a_h, addend_bound=a_bound,
-                    want_mask=want_mask, amax_words=self._fwd_word(inp.device, inp.shape[0]))
+                    want_mask=want_mask, amax_words=self._fwd_word(inp.device, inp.shape[0]), y_out=y_out)
                 out = y.permute(0, 3, 1, 2)
                 self._aux_put(out, {"split": split, "bound": split.amax if split is not None else bound})
                 if mask is not None:

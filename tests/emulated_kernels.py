@@ -306,14 +306,19 @@ class EmulatedKernels:
     use_conv_bn_act = True
 
     def conv_bn_act_nhwc(self, x, wplanes, wsexp, w_l1, Ho, Wo, in_mul, taps, scale, shift, scale_amax, shift_amax, act,
-                         addend=None, addend_bound=None, want_mask=True, want_split=True, amax_words=None, config=None):
+                         addend=None, addend_bound=None, want_mask=True, want_split=True, amax_words=None, config=None,
+                         y_out=None):
         """lk_conv_bn_act_nhwc_f16x2: by definition the convolution followed by lk_bn_act_fwd_nhwc_f16x2 with x_mul = w_l1"""
         assert x.amax is not None and x.amax.numel() in (1, x.shape[0]) and act in (0, 1)
         out = torch.zeros(x.shape[0], Ho, Wo, wplanes.shape[2])
         self.conv_nhwc_f16x2(x, wplanes, wsexp, Ho, Wo, in_mul, out, 1, 0, 0, taps)
-        return self.bn_act_forward_nhwc(out, x.amax, scale, shift, scale_amax, shift_amax, act, addend=addend,
-                                        addend_bound=addend_bound, want_mask=want_mask, want_split=want_split, x_mul=w_l1,
-                                        amax_words=amax_words)
+        res = self.bn_act_forward_nhwc(out, x.amax, scale, shift, scale_amax, shift_amax, act, addend=addend,
+                                       addend_bound=addend_bound, want_mask=want_mask, want_split=want_split, x_mul=w_l1,
+                                       amax_words=amax_words)
+        if y_out is not None:  # (where the caller wants y: a slot of a pixel-pair stack)
+            y_out.copy_(res[0])
+            res = (y_out,) + tuple(res[1:])
+        return res
 
     def unsplit_transpose(self, x, S, B):
         N, H, W, C = x.shape

@@ -91,6 +91,7 @@ CASES = {
     "LK_PIX_GROUP=1": dict(acc_attrs={"pix_group": 1}),
     "LK_PIX_GROUP=2": dict(acc_attrs={"pix_group": 2}),
     "LK_LAG_JOIN=0": dict(acc_attrs={"lag_join": False}),
+    "activations copied into the pixel-pair stacks": dict(acc_attrs={"direct_stack": False}),
     "lag_depth=3": dict(acc_attrs={"lag_depth": 3}),
     "LK_FUSE_STRIDED=0": dict(sweep_attrs={"fuse_strided": False}),
     "copies + a separate absmax pass": dict(kernel_attrs={"use_copy_absmax": False}),
