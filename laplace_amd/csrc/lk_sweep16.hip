@@ -691,11 +691,14 @@ extern "C" int lk_gram_tn_f16x2(const void* x_h, const void* x_l, const int* sex
 namespace lk {
 // ---- pixel-pair blocks of a 64-channel map, all 13 shifts of a pixel in ONE workgroup -------------------------------------
 // gram16_kernel<64, 64, 4, true> gives every (pixel, shift) block its own workgroup, which stages the pixel's panel and the
-// shifted pixel's panel: 32 KB per 48 MFMAs, 83 B per clock and CU at the matrix pipe's rate against the ~36 the LDS-DMA path
-// ingests from L2 (tools/probes/ldsdma_ingest_probe.hip) — the launch ran at that ingest rate, 23 % of the matrix peak.  Here a
-// workgroup owns a pixel q: per stage of 16 images it stages q's panel ONCE and the (up to) 12 other panels of its shifts —
-// 13 panels for 13 blocks instead of 26 —, and its eight waves hold the 13 blocks' accumulators: wave = (32 x 32 tile of the
-// 64 x 64 block) x (shifts 0 .. 6 | 7 .. 12).  Same stage image, swizzle and transposing fragment reads as gram16_kernel.
+// shifted pixel's panel: 26 panels per pixel, 6.8 GB through L2 per launch of 8 stacked minibatches.  Here a workgroup owns a
+// pixel q: per stage of 16 images it stages q's panel ONCE and the (up to) 12 other panels of its shifts — 13 panels for 13
+// blocks —, and its eight waves hold the 13 blocks' accumulators: wave = (32 x 32 tile of the 64 x 64 block) x (shifts 0 .. 6 |
+// 7 .. 12).  Same stage image, swizzle and transposing fragment reads as gram16_kernel; a ring of three stages (two in flight),
+// the requests of a stage issued one per shift between the shifts' products.  Measured (tools/pixpair_bench.py and its
+// -DLK_PIX13_ABLATE builds, B = 1024): 536 us per launch = 235 of products + 180 of staging + 107 of block updates, which add
+// rather than overlap (the CUs' joint ingest from L2, ~18 TB/s, and the matrix pipe share the power budget); 5 % less than one
+// workgroup per block, 0.62 against 0.66 ms per c4 step for the family.
 struct Pix13Args {
   const _Float16 *xh, *xl;
   const _Float16* zero16;
